@@ -1,0 +1,143 @@
+/*
+ * xflow_oracle.h — CPU restatement of the xswang/xflow LR/FM + FTRL/SGD hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under xflow_amd/ (the product) may include,
+ * link, import or execute this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg use it, as the checker / as the timed CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) whose
+ * behaviour it restates.  The implementation is C-style C++ compiled with g++ so
+ * that std::sort tie-order, std::log2 overload selection and libm are the very ones
+ * the reference itself would use in this image (see oracle/README.md, "pinning").
+ */
+#ifndef XFLOW_ORACLE_H_
+#define XFLOW_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- a2: key hash --------------------------------------------------------- */
+/* libstdc++ std::hash<std::string> == _Hash_bytes(ptr,len,0xc70f6907)
+ * (src/io/io.h:53, used at src/io/load_data_from_disk.cc:151). */
+uint64_t xo_hash_bytes(const void *ptr, size_t len);
+
+/* ps-lite default key-range owner rule: min(key/(UINT64_MAX/N), N-1). */
+uint32_t xo_shard_of(uint64_t key, uint32_t nshards);
+
+/* ---- a6: sigmoid ----------------------------------------------------------- */
+float xo_sigmoid(float x); /* src/base/base.h:54-63 */
+
+/* ---- a1: block reader / parser -------------------------------------------- */
+typedef struct xo_reader xo_reader;
+/* cap_bytes == the reference's `block_size << 20` (lr_worker.cc:184) */
+xo_reader *xo_reader_open(const char *path, size_t cap_bytes);
+void xo_reader_close(xo_reader *r);
+/* Parses the next block (load_data_from_disk.cc:103-210).  Returns number of rows
+ * (0 at end of file), -1 on malformed input.  Arrays stay valid until next call. */
+long xo_reader_next(xo_reader *r);
+size_t xo_reader_rows(const xo_reader *r);
+size_t xo_reader_nnz(const xo_reader *r);
+const uint64_t *xo_reader_rowptr(const xo_reader *r); /* rows+1 */
+const uint64_t *xo_reader_keys(const xo_reader *r);   /* nnz   */
+const int32_t *xo_reader_fgid(const xo_reader *r);    /* nnz   */
+const int32_t *xo_reader_labels(const xo_reader *r);  /* rows  */
+
+/* ---- a4/a8/a9/a10: parameter store ("server") ------------------------------ */
+enum { XO_OPT_FTRL = 0, XO_OPT_SGD = 1 };
+enum {
+  XO_INIT_ZERO = 0,    /* ftrl.h:27-36 (w table), sgd.h:22-27 */
+  XO_INIT_CONST = 1,   /* sgd.h:67-72 : every v coordinate = 0.001 */
+  XO_INIT_HASHNORM = 2 /* deterministic stand-in for ftrl.h:114-120 (time-seeded
+                          N(0,1)*1e-2 in the reference; documented deviation) */
+};
+typedef struct xo_store xo_store;
+xo_store *xo_store_create(int opt_kind, int dim, int init_kind, float init_const,
+                          uint64_t seed);
+void xo_store_destroy(xo_store *s);
+/* hyper-parameters: ftrl.h:17-20 / sgd.h:16 defaults are applied at create */
+void xo_store_set_ftrl(xo_store *s, float alpha, float beta, float l1, float l2);
+void xo_store_set_sgd(xo_store *s, float lr);
+size_t xo_store_size(const xo_store *s);
+/* pull branch: ftrl.h:49-52,75-77 / sgd.h — inserts missing keys (ftrl.h:56) */
+void xo_store_pull(xo_store *s, const uint64_t *keys, size_t n, float *out);
+/* push branch: ftrl.h:54-74 / sgd.h:52,96 */
+void xo_store_push(xo_store *s, const uint64_t *keys, size_t n, const float *grads);
+/* dump sorted by key; n/z are NULL-able (and zero for SGD). arrays sized size*dim */
+void xo_store_export(const xo_store *s, uint64_t *keys, float *w, float *n, float *z);
+/* overwrite/insert raw state (fixtures, resume) */
+void xo_store_import(xo_store *s, const uint64_t *keys, size_t n, const float *w,
+                     const float *nn, const float *z);
+/* the deterministic per-(key,j) initialiser used by XO_INIT_HASHNORM */
+float xo_hashnorm(uint64_t seed, uint64_t key, uint32_t j);
+
+/* one FTRL coordinate step, ftrl.h:59-74 (for unit vectors) */
+void xo_ftrl_step(float alpha, float beta, float l1, float l2, float g, float *w,
+                  float *n, float *z);
+
+/* ---- a3: minibatch key build ---------------------------------------------- */
+/* lr_worker.cc:146-166: all_keys sorted by fid (std::sort, base.h:71-73), unique keys.
+ * The compiled form is what the device path consumes (CSR + COO):
+ *   ukeys[U]   sorted unique keys                 (== unique_keys)
+ *   uidx[NNZ]  CSR-order index of each nnz into ukeys
+ *   segptr[U+1], coo_row[NNZ]  all_keys grouped by key: coo_row = sid in the
+ *              reference's post-sort order                                     */
+typedef struct xo_batch xo_batch;
+xo_batch *xo_batch_build(const uint64_t *rowptr, const uint64_t *keys,
+                         const int32_t *labels, size_t row_begin, size_t row_end);
+void xo_batch_free(xo_batch *b);
+size_t xo_batch_rows(const xo_batch *b);
+size_t xo_batch_nnz(const xo_batch *b);
+size_t xo_batch_nuniq(const xo_batch *b);
+const uint64_t *xo_batch_ukeys(const xo_batch *b);
+const uint32_t *xo_batch_rowptr(const xo_batch *b); /* rows+1, relative */
+const uint32_t *xo_batch_uidx(const xo_batch *b);
+const uint32_t *xo_batch_segptr(const xo_batch *b);
+const uint32_t *xo_batch_coo_row(const xo_batch *b);
+const int32_t *xo_batch_labels(const xo_batch *b);
+
+/* ---- a5/a7: LR math on a built batch --------------------------------------- */
+/* lr_worker.cc:121-143.  w: U floats (pulled).  loss,pctr: R floats. */
+void xo_lr_loss(const xo_batch *b, const float *w, float *loss, float *pctr);
+/* lr_worker.cc:100-119.  g: U floats */
+void xo_lr_grad(const xo_batch *b, const float *loss, float *g);
+/* lr_worker.cc:145-177 : pull, loss, grad, push */
+void xo_lr_update(xo_store *w, const xo_batch *b);
+
+/* ---- a11/a12/a13: FM math (reference's pooled-over-k form) ----------------- */
+/* fm_worker.cc:159-202.  v: U*k row-major.  v_sum out: R floats. */
+void xo_fm_loss(const xo_batch *b, int k, const float *w, const float *v, float *loss,
+                float *pctr, float *v_sum);
+/* fm_worker.cc:126-157.  gw: U, gv: U*k */
+void xo_fm_grad(const xo_batch *b, int k, const float *v, const float *v_sum,
+                const float *loss, float *gw, float *gv);
+/* fm_worker.cc:204-245 */
+void xo_fm_update(xo_store *w, xo_store *v, const xo_batch *b);
+
+/* ---- a15: metrics ---------------------------------------------------------- */
+/* base.h:84-110.  Returns the reference-format "logloss" (mean of
+ * y*log2 p + (1-y)*log2(1-p), negative) and AUC by descending-pctr rank sum.
+ * `acc_logloss_inout` is the never-reset member (base.h:113); pass 0 for a fresh Base. */
+void xo_auc_logloss(const int32_t *labels, const float *pctr, size_t n,
+                    float *acc_logloss_inout, float *auc, int *tp, int *fp);
+
+/* ---- a14: the training / predict loops ------------------------------------- */
+/* lr_worker.cc:179-217 (model 0) / fm_worker.cc:247-287 (model 1): init push of key 0,
+ * per epoch re-open + block loop, core_num equal row slices (remainder dropped,
+ * lr_worker.cc:190-194), slices applied one after another (a legal serialisation;
+ * core_num=1 is the deterministic reference schedule). Returns rows consumed. */
+long xo_train(int model, xo_store *w, xo_store *v, const char *train_path, int epochs,
+              size_t block_bytes, int core_num);
+/* lr_worker.cc:25-98 / fm_worker.cc:25-124: forward over the test file; appends to
+ * caller arrays (cap entries). Returns number of rows scored, -1 on error. */
+long xo_predict(int model, xo_store *w, xo_store *v, const char *test_path,
+                size_t block_bytes, int core_num, int32_t *labels_out, float *pctr_out,
+                size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFLOW_ORACLE_H_ */
