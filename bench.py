@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — examples/sec of the LR+FTRL (or FM) minibatch step on N MI355X.
+
+A "step" is one pass of the hot path over one compiled minibatch that is already resident in
+HBM: Pull (key->slot resolve + weight gather), forward (sigma(sum w)), gradient, Push
+(FTRL update) == one LRWorker::update of the reference (lr_worker.cc:167-176).
+
+Workload at N=1 (BASELINE.json configs[1]): synthetic libsvm-shaped data, 10^7 keys,
+200 nnz/row, 5x10^4 rows per minibatch (10^7 nnz), keys = std::hash of decimal strings.
+N>1 (configs[2] shape, weak scaling): every rank runs the same per-GPU minibatch shape,
+the key space grows with N (1.25x10^7 x N ... capped by --keys-per-gpu), keys are sharded by
+the ps-lite range rule and travel to their owner with an RCCL all-to-all.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md for the byte model behind `roofline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="lr", choices=["lr", "fm"])
+    ap.add_argument("--optimizer", default=None, choices=[None, "ftrl", "sgd"])
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--rows", type=int, default=50000)
+    ap.add_argument("--nnz-per-row", type=int, default=200)
+    ap.add_argument("--keys-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--batches", type=int, default=8, help="distinct minibatches cycled")
+    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--zipf", type=float, default=0.0)
+    ap.add_argument("--cpu-baseline-batches", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20260926)
+    return ap.parse_args()
+
+
+def make_key_table(nkeys):
+    """keys[i] = std::hash<std::string>(str(i)) — the reference's fid hashing (io.h:53)."""
+    from xflow_amd import capi
+    return capi.hash_decimal_range(0, nkeys)
+
+
+def make_batches(args, rank, nkeys_total, keytab):
+    rng = np.random.RandomState(args.seed + 1000 * rank)
+    R, nnz = args.rows, args.nnz_per_row
+    wstar_idx = np.random.RandomState(args.seed).rand(nkeys_total) < 0.01
+    wstar = np.where(wstar_idx, np.random.RandomState(args.seed + 1).randn(nkeys_total) * 0.1,
+                     0.0).astype(np.float32)
+    out = []
+    for _ in range(args.batches):
+        if args.zipf > 0:
+            fid = np.minimum(rng.zipf(args.zipf, size=R * nnz), nkeys_total) - 1
+        else:
+            fid = rng.randint(0, nkeys_total, size=R * nnz)
+        logit = wstar[fid].reshape(R, nnz).sum(axis=1)
+        labels = (rng.rand(R) < 1.0 / (1.0 + np.exp(-logit))).astype(np.int32)
+        rowptr = (np.arange(R + 1, dtype=np.uint64) * np.uint64(nnz))
+        out.append((rowptr, keytab[fid], labels))
+    return out
+
+
+def bytes_model(model, k, R, NNZ, U, opt):
+    """Algorithmic bytes per launch of each kernel of THIS implementation (indices counted
+    once at their stored width, no probe / sector overhead) and SURVEY §8(d)'s whole-step
+    figure."""
+    state = 24 if opt == "ftrl" else 8      # read+write of (w,n,z) or w per coordinate
+    d = 1 if model == "lr" else 1 + k
+    per = {
+        "resolve": U * (8 + 8 + 4) * (1 if model == "lr" else 2),  # key list + table key + slot
+        "gather": U * (4 + 4 * d + 4 * d),                          # slot + read w + write w_u
+        "forward": NNZ * (4 + 4 * d) + R * 12 + 4,                  # uidx + gathered rows
+        "gradient": NNZ * 8 + U * (4 + 4 * d) if model == "lr" else
+        NNZ * 12 + U * (4 + 4 * d + 4 * k),
+        "update": U * (4 + (4 + state) * d),                        # slot + g + state RMW
+    }
+    if model == "lr":
+        survey = 12 * NNZ + 8 * R + (32 if opt == "ftrl" else 16) * U
+    else:
+        survey = NNZ * (12 + 4 * k) + 8 * R + (32 if opt == "ftrl" else 16) * U * (1 + k)
+    return per, survey
+
+
+def cpu_baseline(args, batches):
+    """The oracle (CPU restatement of the reference) timed on this host, one thread, on a
+    bounded sample of the same compiled-minibatch step.  The key build (std::sort, a3) is
+    timed separately and NOT included in `value` (the GPU step does not include it either)."""
+    from oracle import pyoracle as O
+    nb = max(1, min(args.cpu_baseline_batches, len(batches)))
+    store = O.Store(O.OPT_FTRL if (args.optimizer or "ftrl") == "ftrl" else O.OPT_SGD, 1)
+    vstore = None
+    if args.model == "fm":
+        opt = O.OPT_FTRL if (args.optimizer or "sgd") == "ftrl" else O.OPT_SGD
+        store = O.Store(opt, 1)
+        vstore = O.Store(opt, args.k, O.INIT_HASHNORM if opt == O.OPT_FTRL else O.INIT_CONST,
+                         0.001, 7)
+    t_build = t_step = 0.0
+    rows = 0
+    for rowptr, keys, labels in batches[:nb]:
+        t0 = time.perf_counter()
+        ob = O.Batch(rowptr, keys, labels)
+        t1 = time.perf_counter()
+        if args.model == "lr":
+            O.lr_update(store, ob)
+        else:
+            O.fm_update(store, vstore, ob)
+        t2 = time.perf_counter()
+        t_build += t1 - t0
+        t_step += t2 - t1
+        rows += ob.R
+    return {"value": rows / t_step, "unit": "examples/sec", "cores": 1, "kind": "port",
+            "sample": "%d minibatch(es) of %d rows x %d nnz, oracle update() after the key "
+                      "build, -O2, 1 thread; with the reference's per-slice std::sort key "
+                      "build included: %.0f examples/sec" % (nb, args.rows, args.nnz_per_row,
+                                                            rows / (t_step + t_build))}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.optimizer is None:
+        args.optimizer = "ftrl" if args.model == "lr" else "sgd"
+    import torch
+    from xflow_amd import capi
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    capi.require_gpu()
+    dist = None
+    if world > 1 or args.gpus > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    nkeys_total = args.keys_per_gpu * world
+    keytab = make_key_table(nkeys_total)
+    batches = make_batches(args, rank, nkeys_total, keytab)
+
+    if world == 1:
+        from xflow_amd.single import SingleGpuTrainer as Trainer
+    else:
+        from xflow_amd.sharded import ShardedTrainer as Trainer
+    trainer = Trainer(model=args.model, optimizer=args.optimizer, k=args.k,
+                      capacity=int(args.keys_per_gpu / args.load_factor) + 1024,
+                      rank=rank, world=world)
+    compiled = [trainer.compile(*b) for b in batches]
+    R = compiled[0].R
+    NNZ = int(np.mean([c.NNZ for c in compiled]))
+    U = int(np.mean([c.U for c in compiled]))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(compiled[i % len(compiled)])
+    trainer.check()
+    barrier()
+    trainer.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(compiled[(args.warmup + i) % len(compiled)])
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, ksteps = trainer.profile_read()
+    trainer.profile(False)
+    trainer.check()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer)
+    avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
+    dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
+    achieved = per[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+    ms_per_step = dt / args.steps * 1e3
+    out = {
+        "metric": "examples/sec", "value": R * world * args.steps / dt, "unit": "examples/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s+%s, synthetic libsvm-shaped, %d keys/GPU x %d GPU, "
+                               "%d rows x %d nnz per GPU minibatch%s" % (
+                                   args.model.upper() + ("(k=%d)" % args.k if args.model == "fm"
+                                                         else ""),
+                                   args.optimizer.upper(), args.keys_per_gpu, world, args.rows,
+                                   args.nnz_per_row,
+                                   ", zipf %.2f" % args.zipf if args.zipf else ", uniform"),
+                   "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
+                   "unique_keys_per_gpu_batch": U, "table_load_factor": args.load_factor,
+                   "distinct_batches": len(compiled),
+                   "parallelism": "key-range sharded table x%d, all-to-all" % world
+                   if world > 1 else "single shard"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": per[dom],
+                     "avg_launch_ms": avg_ms[dom]},
+        "kernels_ms": avg_ms,
+        "step_bytes_survey_8d": survey_bytes,
+        "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, batches)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+/*
+ * xflow_amd.h — C ABI of libxflow_amd.so: the MI355X-native replacement for the
+ * ps-lite push/pull parameter server + worker math of xswang/xflow.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.  Every
+ * function returns 0 on success and a non-zero XF_E* code on failure; xf_last_error()
+ * returns a thread-local description.  Handles are opaque and NOT thread-safe (one
+ * driver thread per device/stream, like one ps-lite customer thread per server).
+ *
+ * What each group replaces in the reference (paths relative to /root/reference):
+ *   xf_hash_bytes / xf_reader_*   src/io/io.h:53, src/io/load_data_from_disk.cc:103-210
+ *   xf_table_*                    ps::KVWorker<float>::{Pull,Push,Wait} as used at
+ *                                 src/model/lr/lr_worker.cc:170,175 and
+ *                                 src/model/fm/fm_worker.cc:228-242, plus the server
+ *                                 handlers src/optimizer/ftrl.h:38-152, sgd.h:30-109 and
+ *                                 their wiring src/model/server.h:22-31
+ *   xf_batch_*                    key build in LRWorker::update, lr_worker.cc:146-166
+ *   xf_lr_* / xf_fm_*             calculate_loss / calculate_gradient / update,
+ *                                 lr_worker.cc:100-177, fm_worker.cc:126-245
+ *   xf_auc_logloss                Base::calculate_auc, src/base/base.h:84-110
+ *   XFCreate / XFStartTrain       src/c_api/c_api.h:26-29 (signatures kept verbatim)
+ */
+#ifndef XFLOW_AMD_H_
+#define XFLOW_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XF_OK 0
+#define XF_EINVAL 1   /* bad argument */
+#define XF_EHIP 2     /* HIP runtime error */
+#define XF_EFULL 3    /* table capacity exhausted */
+#define XF_EIO 4      /* file open / read error */
+#define XF_EPARSE 5   /* malformed libsvm-style input */
+#define XF_ENOGPU 6   /* no usable HIP device */
+
+const char *xf_last_error(void);
+int xf_version(void);
+int xf_device_count(int *count);
+
+/* ---------------------------------------------------------------- key hash / sharding */
+/* libstdc++ std::hash<std::string> (io.h:53), bit-exact */
+uint64_t xf_hash_bytes(const void *ptr, size_t len);
+/* out[i] = hash of the decimal string of (start + i): synthetic fids "0","1",... */
+int xf_hash_decimal_range(uint64_t start, size_t n, uint64_t *out);
+/* ps-lite default key-range owner: min(key / (UINT64_MAX / nshards), nshards-1) */
+uint32_t xf_shard_of(uint64_t key, uint32_t nshards);
+
+/* ---------------------------------------------------------------- text block reader   */
+/* load_minibatch_hash_data_fread (load_data_from_disk.cc:103-210): block = what fits in
+ * cap_bytes-1 bytes, cut at the last newline when the buffer fills; label = atof > 1e-7;
+ * key = hash of the middle field of fgid:fid:val; val is never read. */
+typedef struct xf_reader xf_reader;
+int xf_reader_open(xf_reader **out, const char *path, size_t cap_bytes);
+int xf_reader_close(xf_reader *r);
+/* rows_out = 0 at end of file.  Arrays are owned by the reader, valid until next call. */
+int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
+                   const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,
+                   const int32_t **labels);
+
+/* ---------------------------------------------------------------- compiled minibatch  */
+/* Host-side key build (lr_worker.cc:146-166): sorted unique keys (== unique_keys, the
+ * Pull/Push key list) + the two views of all_keys the kernels walk:
+ *   CSR:  rowptr[R+1], uidx[NNZ]   (index of each nnz's key in ukeys, row-major order)
+ *   COO grouped by key: segptr[U+1], coo_row[NNZ]  (row ids of each key's occurrences)
+ *   heavy[H]: indices u whose segment is longer than XF_HEAVY_SEG (wave-per-key path) */
+#define XF_HEAVY_SEG 64
+typedef struct xf_batch xf_batch; /* host arrays + (after upload) device mirror */
+int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
+                     const int32_t *labels, size_t row_begin, size_t row_end);
+int xf_batch_free(xf_batch *b);
+int xf_batch_dims(const xf_batch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U, uint32_t *H);
+/* host views (owned by the batch) */
+int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const uint32_t **rowptr,
+                  const uint32_t **uidx, const uint32_t **segptr,
+                  const uint32_t **coo_row, const int32_t **labels,
+                  const uint32_t **heavy);
+/* copy to the current device (async on stream); idempotent */
+int xf_batch_upload(xf_batch *b, void *stream);
+
+/* device view of a compiled batch: raw device pointers (e.g. torch tensors) */
+typedef struct {
+  uint32_t R, NNZ, U, H;
+  const uint32_t *rowptr;  /* R+1  */
+  const uint32_t *uidx;    /* NNZ  */
+  const uint64_t *ukeys;   /* U    */
+  const uint32_t *segptr;  /* U+1  */
+  const uint32_t *coo_row; /* NNZ  */
+  const int32_t *labels;   /* R    */
+  const uint32_t *heavy;   /* H (may be NULL when H == 0) */
+} xf_dev_batch;
+int xf_batch_dev_view(const xf_batch *b, xf_dev_batch *view);
+
+/* ---------------------------------------------------------------- sharded table       */
+enum { XF_OPT_FTRL = 0, XF_OPT_SGD = 1 };
+enum {
+  XF_INIT_ZERO = 0,    /* ftrl.h:27-36, sgd.h:22-27 */
+  XF_INIT_CONST = 1,   /* sgd.h:67-72 (0.001) */
+  XF_INIT_HASHNORM = 2 /* deterministic N(0,1)*1e-2 stand-in for ftrl.h:114-120 */
+};
+typedef struct {
+  int32_t opt_kind;     /* XF_OPT_* */
+  int32_t dim;          /* 1 for w, k for v */
+  int32_t init_kind;    /* XF_INIT_* */
+  float init_const;
+  uint64_t seed;        /* HASHNORM seed */
+  float alpha, beta, lambda1, lambda2; /* ftrl.h:17-20 : 0.05, 1, 5e-5, 10 */
+  float lr;                            /* sgd.h:16     : 0.001 */
+  uint64_t capacity;    /* slots on THIS shard (keys stored <= capacity) */
+  uint32_t shard, nshards; /* key range owned: ps-lite uniform range rule */
+} xf_table_config;
+void xf_table_config_default(xf_table_config *cfg); /* reference defaults, FTRL, dim 1 */
+
+typedef struct xf_table xf_table;
+int xf_table_create(xf_table **out, const xf_table_config *cfg); /* on current device */
+int xf_table_destroy(xf_table *t);
+int xf_table_size(xf_table *t, uint64_t *nkeys); /* synchronises */
+int xf_table_capacity(xf_table *t, uint64_t *slots);
+/* grow to new_capacity slots (rehash on device); earlier slot arrays become invalid */
+int xf_table_reserve(xf_table *t, uint64_t new_capacity);
+int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2, float lr);
+
+/* ps-lite-shaped host API: keys sorted & unique (the KVWorker contract), host pointers,
+ * blocking (== Push/Pull followed by Wait).  Pull inserts missing keys (ftrl.h:56). */
+int xf_table_pull(xf_table *t, const uint64_t *keys, size_t n, float *vals /* n*dim */);
+int xf_table_push(xf_table *t, const uint64_t *keys, size_t n, const float *grads);
+
+/* device-pointer API, asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ * resolve: key -> slot with insert-on-miss (+ first-touch init); keys of other shards
+ * are an error.  gather: vals[i*dim+j] = w[slot[i]*dim+j].  update: one optimizer step
+ * per (slot, j) — slots must be unique within one call. */
+int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_slots,
+                         void *stream);
+int xf_table_gather_dev(xf_table *t, const uint32_t *d_slots, size_t n, float *d_vals,
+                        void *stream);
+int xf_table_update_dev(xf_table *t, const uint32_t *d_slots, size_t n,
+                        const float *d_grads, void *stream);
+/* raises XF_EFULL / XF_EINVAL recorded by earlier async calls; synchronises the stream */
+int xf_table_check(xf_table *t, void *stream);
+
+/* state dump sorted by key (parity hook / checkpoint).  n_/z_ may be NULL. */
+int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_, float *z_,
+                    size_t cap_entries, size_t *n_out);
+int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, const float *w,
+                    const float *n_, const float *z_);
+
+/* ---------------------------------------------------------------- model kernels       */
+/* All pointers are device pointers; asynchronous on `stream`. */
+/* LR forward (lr_worker.cc:121-143): loss[r] = sigmoid(sum w_u[uidx]) - label */
+int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
+                      float *d_pctr /* may be NULL */, void *stream);
+/* LR gradient (lr_worker.cc:100-119): g[u] = (sum_{occurrences} loss[row]) / R */
+int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float *d_g, void *stream);
+/* FM forward, reference form (fm_worker.cc:159-202); v_u is U x k row-major */
+int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
+                      float *d_loss, float *d_pctr, float *d_vsum, void *stream);
+/* FM gradient (fm_worker.cc:126-157): gw U, gv U x k */
+int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu, const float *d_vsum,
+                   const float *d_loss, float *d_gw, float *d_gv, void *stream);
+
+/* ---------------------------------------------------------------- fused steps         */
+typedef struct xf_workspace xf_workspace; /* per-stream scratch: slots, w_u, g, loss... */
+int xf_workspace_create(xf_workspace **out);
+int xf_workspace_destroy(xf_workspace *ws);
+/* One LRWorker::update (lr_worker.cc:167-176) on a single-shard table, device-resident:
+ * pull(resolve+gather) -> loss -> gradient -> push(update).  Asynchronous. */
+int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream);
+/* One FMWorker::update (fm_worker.cc:226-242). */
+int xf_fm_step(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws, void *stream);
+/* forward only (calculate_pctr, lr_worker.cc:25-71 / fm_worker.cc:25-95): pulls (and so
+ * inserts) the batch's keys, writes R probabilities to host `pctr_out`.  Blocking. */
+int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *pctr_out);
+int xf_fm_predict(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws,
+                  float *pctr_out);
+/* copies of the last step's intermediates to host (parity hook): any pointer may be NULL */
+int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
+                       size_t R);
+/* optional per-kernel timing with HIP events recorded on the step's own stream:
+ * ms_sum[5] = resolve, gather, forward, gradient, update, summed over *steps steps */
+int xf_workspace_profile(xf_workspace *ws, int enable);
+int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long *steps);
+int xf_stream_sync(void *stream); /* == ps KVWorker::Wait */
+
+/* ---------------------------------------------------------------- metrics             */
+/* Base::calculate_auc (base.h:84-110): reference-format logloss (mean of y*log2 p +
+ * (1-y)*log2(1-p), negative), AUC by descending-pctr rank sum, plus the conventional
+ * natural-log logloss (positive).  acc_logloss_inout is the never-reset member. */
+int xf_auc_logloss(const int32_t *labels, const float *pctr, size_t n,
+                   float *acc_logloss_inout, float *auc, int *tp, int *fp,
+                   double *nat_logloss);
+
+/* ---------------------------------------------------------------- worker-level C API  */
+/* Signatures of src/c_api/c_api.h:26-29 kept verbatim.  The handle owns an LR or FM
+ * worker (XFSetParam "model") whose table lives on the current HIP device. */
+int XFCreate(void **h, const char *train_path, const char *test_path);
+int XFStartTrain(void **h);
+/* additive (the reference has no equivalents) */
+int XFDestroy(void **h);
+/* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
+ *        rank pred_path alpha beta lambda1 lambda2 lr seed */
+int XFSetParam(void *h, const char *name, const char *value);
+/* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
+ * examples_per_sec, keys */
+int XFGetMetric(void *h, const char *name, double *value);
+/* the worker's tables, for export/checkpoint (NULL v for LR) */
+int XFGetTables(void *h, xf_table **w, xf_table **v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFLOW_AMD_H_ */

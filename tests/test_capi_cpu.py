@@ -1,0 +1,164 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header
+declares, and its host logic (hash, block reader, key build, metrics) matches the golden
+vectors and the oracle.  No compute kernels run here (there is no GPU)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from xflow_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from xflow_amd import build
+    build.build(verbose=False)
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "xflow_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(xf_[a-z0-9_]+|XF[A-Z][A-Za-z]+)\s*\(", hdr))
+    assert len(names) >= 45
+    L = capi.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert names == set(capi.SIGNATURES), names ^ set(capi.SIGNATURES)
+
+
+def test_hash_kats(golden_dir):
+    kats = json.load(open(os.path.join(golden_dir, "ref_kats.json")))
+    for s, hx in kats["hash"].items():
+        assert capi.hash_str(s) == int(hx, 16), s
+    rng = np.random.RandomState(5)
+    for _ in range(500):
+        b = bytes(rng.randint(1, 255, size=rng.randint(0, 33)).astype(np.uint8))
+        assert capi.lib().xf_hash_bytes(b, len(b)) == O.lib().xo_hash_bytes(b, len(b))
+
+
+def test_shard_rule_matches_oracle():
+    rng = np.random.RandomState(6)
+    keys = [0, 2**64 - 1, 0x799107141a3182b9] + [int(x) for x in
+                                                   rng.randint(0, 2**63, size=200) * 2]
+    for n in (1, 2, 3, 8):
+        for k in keys:
+            assert capi.lib().xf_shard_of(k, n) == O.lib().xo_shard_of(k, n)
+    assert capi.lib().xf_shard_of(0x799107141a3182b9, 8) == 3
+
+
+@pytest.mark.parametrize("name", ["small_train-00000", "small_test-00000"])
+@pytest.mark.parametrize("cap", [2 << 20, 4096, 1000])
+def test_reader_golden(golden_dir, name, cap):
+    g = np.load(os.path.join(golden_dir, "ref_parse_%s_cap%d.npz" % (name, cap)))
+    blocks = list(capi.read_blocks(os.path.join(golden_dir, name), cap))
+    assert [len(b[3]) for b in blocks] == g["block_rows"].tolist()
+    assert np.array_equal(np.concatenate([b[1] for b in blocks]), g["keys"])
+    assert np.array_equal(np.concatenate([b[2] for b in blocks]), g["fgid"])
+    assert np.array_equal(np.concatenate([b[3] for b in blocks]), g["labels"])
+
+
+def test_reader_edges_vs_oracle(tmp_path):
+    line = "1\t0:12345:1 1:678:1\n"
+    cases = {"nonl": "1\t0:1:1 2:22:0.5\n0\t3:333:1",
+             "blank": "0.5\t0:1:1 2:22:0.5 \n0.00000001\t3:333:1\n",
+             "neg": "-1\t0:1:1\n1e-7\t1:2:1\n2e-7\t1:2:1\n", "empty": "", "exact": line * 10}
+    for nm, txt in cases.items():
+        p = tmp_path / nm
+        p.write_text(txt)
+        for cap in (41, 64, 1 << 16):
+            mine = list(capi.read_blocks(str(p), cap))
+            theirs = list(O.read_blocks(str(p), cap))
+            assert len(mine) == len(theirs)
+            for a, b in zip(mine, theirs):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), (nm, cap)
+    for txt in ["1 0:1:1\n", "1\t0:1\n", "1\t0:1:1  2:2:2\n"]:
+        p = tmp_path / "bad"
+        p.write_text(txt)
+        with pytest.raises(capi.XFError):
+            list(capi.read_blocks(str(p), 1 << 16))
+    with pytest.raises(capi.XFError):
+        list(capi.read_blocks(str(tmp_path / "missing"), 1 << 16))
+
+
+def _random_csr(rng, R, max_len, nkeys):
+    lens = rng.randint(0, max_len + 1, size=R)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    keys = rng.randint(0, nkeys, size=int(lens.sum())).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    labels = rng.randint(0, 2, size=R).astype(np.int32)
+    return rowptr, keys, labels
+
+
+@pytest.mark.parametrize("R,max_len,nkeys", [(1, 3, 5), (50, 8, 40), (3000, 40, 500),
+                                             (20000, 12, 100000)])
+def test_batch_compile_vs_oracle(R, max_len, nkeys):
+    rng = np.random.RandomState(R)
+    rowptr, keys, labels = _random_csr(rng, R, max_len, nkeys)
+    a, b0 = R // 5, R - R // 7
+    mine = capi.Batch(rowptr, keys, labels, a, b0)
+    ref = O.Batch(rowptr, keys, labels, a, b0)
+    h = mine.host()
+    assert (mine.R, mine.NNZ, mine.U) == (ref.R, ref.NNZ, ref.U)
+    assert np.array_equal(h["ukeys"], ref.ukeys)        # Pull/Push key list: bit-exact
+    assert np.array_equal(h["rowptr"], ref.rowptr)
+    assert np.array_equal(h["uidx"], ref.uidx)
+    assert np.array_equal(h["segptr"], ref.segptr)
+    assert np.array_equal(h["labels"], ref.labels)
+    # within a key the reference's order is std::sort's (unspecified): compare as multisets
+    for u in range(0, mine.U, max(1, mine.U // 300)):
+        s, e = ref.segptr[u], ref.segptr[u + 1]
+        assert np.array_equal(np.sort(h["coo_row"][s:e]), np.sort(ref.coo_row[s:e]))
+    seglen = np.diff(h["segptr"])
+    assert np.array_equal(h["heavy"], np.nonzero(seglen > capi.HEAVY_SEG)[0])
+
+
+def test_batch_compile_empty_and_ragged():
+    rowptr = np.array([0, 0, 2, 2, 5, 5], dtype=np.uint64)
+    keys = np.array([7, 7, 3, 9, 3], dtype=np.uint64)
+    labels = np.array([0, 1, 0, 1, 1], dtype=np.int32)
+    b = capi.Batch(rowptr, keys, labels)
+    h = b.host()
+    assert (b.R, b.NNZ, b.U) == (5, 5, 3)
+    assert h["ukeys"].tolist() == [3, 7, 9]
+    assert h["uidx"].tolist() == [1, 1, 0, 2, 0]
+    assert h["segptr"].tolist() == [0, 2, 4, 5]
+    assert h["coo_row"].tolist() == [3, 3, 1, 1, 3]
+    e = capi.Batch(np.array([0], dtype=np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int32))
+    assert (e.R, e.NNZ, e.U) == (0, 0, 0)
+
+
+def test_auc_logloss_golden(golden_dir):
+    a = json.load(open(os.path.join(golden_dir, "ref_kats.json")))["auc"]
+    lab = np.array(a["labels"], dtype=np.int32)
+    p = np.array([float.fromhex(h) for h in a["pctr_hex"]], dtype=np.float32)
+    ll, auc, tp, fp, nat = capi.auc_logloss(lab, p)
+    assert ll == float.fromhex(a["logloss_hex"])
+    assert O.format_auc_line(ll, auc, tp, fp) == a["line"]
+    assert np.isclose(nat, -np.mean(np.where(lab == 1, np.log(p.astype(np.float64)),
+                                             np.log1p(-p.astype(np.float64)))), rtol=1e-12)
+
+
+def test_product_fails_loudly_without_gpu():
+    n = capi.C.c_int(0)
+    capi.check(capi.lib().xf_device_count(capi.C.byref(n)))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.XFError, match="no HIP device"):
+        capi.Table(capacity=1024)
+    with pytest.raises(capi.XFError):
+        capi.XFlow("/nonexistent/train", "/nonexistent/test").train()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "xflow_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cc", ".h", ".hip")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "pyoracle" not in txt and "xflow_oracle" not in txt and \
+                    "liboracle" not in txt, os.path.join(dp, f)

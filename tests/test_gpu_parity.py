@@ -1,0 +1,356 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X.
+
+Bit-exact: keys, slots' key identity, shard ownership, the Pull/Push key lists, FTRL/SGD
+state for identical gradients.  Floating point: <= 1e-6 relative on loss / gradients /
+weights (north_star), the slack being summation order only (the reference's own order
+within a key is std::sort's, lr_worker.cc:162)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from xflow_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6      # north_star: "within 1e-6 relative on the float loss/weights"
+ATOL = 1e-9      # denormal-scale floor for values that are ~0
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    capi.require_gpu()
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    assert not bad.any(), "max rel err %.3g at %d of %d" % (
+        np.max(np.abs(a - b) / (np.abs(b) + 1e-30)), int(bad.sum()), a.size)
+
+
+def synth(rng, R, nnz_per_row, nkeys, zipf=None, ragged=False):
+    lens = rng.randint(0, 2 * nnz_per_row + 1, size=R) if ragged else np.full(R, nnz_per_row)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(lens.sum())
+    if zipf:
+        fid = np.minimum(rng.zipf(zipf, size=n), nkeys) - 1
+    else:
+        fid = rng.randint(0, nkeys, size=n)
+    table = np.array([O.hash_str(str(i)) for i in range(nkeys)], dtype=np.uint64)
+    keys = table[fid]
+    labels = rng.randint(0, 2, size=R).astype(np.int32)
+    return rowptr, keys, labels
+
+
+# ------------------------------------------------------------------------- table (a4, a8-a10)
+def test_pull_inserts_zero_and_push_ftrl_bit_exact():
+    rng = np.random.RandomState(0)
+    keys = np.unique(rng.randint(0, 2**63, size=5000).astype(np.uint64) * np.uint64(2) +
+                     np.uint64(1))
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 14)
+    s = O.Store(O.OPT_FTRL, 1)
+    assert np.array_equal(t.pull(keys), s.pull(keys))      # all zeros, keys inserted
+    assert len(t) == len(s) == len(keys)
+    for it in range(6):                                    # same gradients -> same bits
+        sub = np.sort(rng.choice(keys, size=3000, replace=False))
+        g = (rng.randn(len(sub)) * 10.0 ** rng.uniform(-7, 0, size=len(sub))).astype(np.float32)
+        if it == 3:
+            g[::5] = 0.0
+        t.push(sub, g)
+        s.push(sub, g)
+        assert np.array_equal(t.pull(sub), s.pull(sub))
+    kt, wt, nt, zt = t.export()
+    ks, ws, ns, zs = s.export()
+    assert np.array_equal(kt, ks)
+    assert np.array_equal(wt, ws) and np.array_equal(nt, ns) and np.array_equal(zt, zs)
+
+
+def test_ftrl_hyperparameters_and_l1_threshold():
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1024, alpha=0.1, beta=0.5, lambda1=1e-3,
+                   lambda2=1.0)
+    s = O.Store(O.OPT_FTRL, 1)
+    s.set_ftrl(0.1, 0.5, 1e-3, 1.0)
+    keys = np.arange(1, 201, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    keys.sort()
+    g = np.linspace(-2e-3, 2e-3, len(keys)).astype(np.float32)   # straddles |z| <= lambda1
+    for _ in range(3):
+        t.push(keys, g)
+        s.push(keys, g)
+    assert np.array_equal(t.pull(keys), s.pull(keys))
+    assert (t.pull(keys) == 0).sum() > 10
+
+
+def test_sgd_tables_bit_exact():
+    rng = np.random.RandomState(1)
+    keys = np.sort(np.unique(rng.randint(1, 2**62, size=800).astype(np.uint64)))
+    for dim, init, c in [(1, capi.INIT_ZERO, 0.0), (10, capi.INIT_CONST, 0.001)]:
+        t = capi.Table(capi.OPT_SGD, dim, init, c, capacity=4096)
+        s = O.Store(O.OPT_SGD, dim, init, c)
+        assert np.array_equal(t.pull(keys), s.pull(keys))
+        for _ in range(4):
+            g = rng.randn(len(keys) * dim).astype(np.float32)
+            t.push(keys, g)
+            s.push(keys, g)
+        assert np.array_equal(t.pull(keys), s.pull(keys))
+        assert np.array_equal(t.export()[1], s.export()[1])
+
+
+def test_ftrl_v_table_hashnorm_init_bit_exact():
+    keys = np.sort(np.array([O.hash_str(str(i)) for i in range(300)], dtype=np.uint64))
+    t = capi.Table(capi.OPT_FTRL, 16, capi.INIT_HASHNORM, seed=1234, capacity=2048)
+    s = O.Store(O.OPT_FTRL, 16, O.INIT_HASHNORM, 0.0, 1234)
+    a, b = t.pull(keys), s.pull(keys)
+    assert np.array_equal(a, b) and a.std() > 5e-3
+    g = np.random.RandomState(2).randn(len(keys), 16).astype(np.float32) * 0.01
+    t.push(keys, g)
+    s.push(keys, g)
+    assert np.array_equal(t.pull(keys), s.pull(keys))
+
+
+def test_reserved_and_special_keys():
+    keys = np.array([0, 1, 2**63, 2**64 - 2, 2**64 - 1], dtype=np.uint64)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=64)
+    s = O.Store(O.OPT_FTRL, 1)
+    g = np.array([0.5, -0.25, 0.125, 1.0, -1.0], dtype=np.float32)
+    t.push(keys, g)
+    s.push(keys, g)
+    assert len(t) == 5
+    assert np.array_equal(t.pull(keys), s.pull(keys))
+    assert np.array_equal(t.export()[0], s.export()[0])
+
+
+def test_table_full_is_reported_and_reserve_rehashes():
+    keys = np.sort(np.array([O.hash_str(str(i)) for i in range(400)], dtype=np.uint64))
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=256)
+    with pytest.raises(capi.XFError, match="table full"):
+        t.pull(keys)
+    t2 = capi.Table(capi.OPT_FTRL, 1, capacity=512)
+    s = O.Store(O.OPT_FTRL, 1)
+    g = np.random.RandomState(3).randn(400).astype(np.float32)
+    t2.push(keys, g)
+    s.push(keys, g)
+    t2.reserve(4096)
+    assert t2.capacity == 4096 and len(t2) == 400
+    t2.push(keys, g)
+    s.push(keys, g)
+    for a, b in zip(t2.export(), s.export()):
+        assert np.array_equal(a, b)
+
+
+def test_sharded_ownership_bit_exact():
+    """Shard g of N accepts exactly the keys ps-lite's range rule gives it."""
+    keys = np.sort(np.array([O.hash_str(str(i)) for i in range(4000)], dtype=np.uint64))
+    N = 8
+    owner = np.array([O.lib().xo_shard_of(int(k), N) for k in keys])
+    assert O.lib().xo_shard_of(0x799107141a3182b9, 8) == 3
+    total = 0
+    for g in range(N):
+        t = capi.Table(capi.OPT_FTRL, 1, capacity=2048, shard=g, nshards=N)
+        mine = keys[owner == g]
+        assert np.array_equal(t.pull(mine), np.zeros(len(mine), np.float32))
+        total += len(t)
+        other = keys[owner == (g + 1) % N][:3]
+        with pytest.raises(capi.XFError, match="outside shard"):
+            t.pull(other)
+    assert total == len(keys)
+
+
+def test_export_import_roundtrip():
+    rng = np.random.RandomState(4)
+    keys = np.sort(np.unique(rng.randint(1, 2**62, size=3000).astype(np.uint64)))
+    t = capi.Table(capi.OPT_FTRL, 4, capacity=8192)
+    for _ in range(3):
+        t.push(keys, rng.randn(len(keys), 4).astype(np.float32))
+    dump = t.export()
+    t2 = capi.Table(capi.OPT_FTRL, 4, capacity=5000)
+    t2.import_(*dump)
+    for a, b in zip(t2.export(), dump):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ LR step (a3-a8), FM (a11-a13)
+@pytest.mark.parametrize("R,nnz,nkeys,zipf,ragged", [
+    (200, 17, 900, None, False),       # sample-data shape: short rows (16-lane groups)
+    (3000, 200, 50000, None, False),   # config-2 shape, scaled down
+    (2000, 60, 20000, 1.2, True),      # power-law heads -> heavy-key path, ragged/empty rows
+])
+def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
+    rng = np.random.RandomState(R)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)
+    s = O.Store(O.OPT_FTRL, 1)
+    ws = capi.Workspace()
+    for step in range(4):
+        rowptr, keys, labels = synth(rng, R, nnz, nkeys, zipf, ragged)
+        b = capi.Batch(rowptr, keys, labels)
+        ob = O.Batch(rowptr, keys, labels)
+        if zipf:
+            assert b.H > 0
+        w_ref = s.pull(ob.ukeys)                   # what the worker's Pull returns
+        loss_ref, _ = ob.lr_loss(w_ref)
+        g_ref = ob.lr_grad(loss_ref)
+        O.lr_update(s, ob)
+        capi.lr_step(t, b, ws)
+        wu, loss, g = ws.fetch(b.U, b.R)
+        close(wu, w_ref)
+        close(loss, loss_ref)
+        close(g, g_ref)
+    for a, r in zip(t.export(), s.export()):
+        if a.dtype == np.uint64:
+            assert np.array_equal(a, r)            # same key set, bit-exact
+        else:
+            close(a, r)
+
+
+@pytest.mark.parametrize("opt,k", [(capi.OPT_SGD, 10), (capi.OPT_FTRL, 10), (capi.OPT_SGD, 16),
+                                   (capi.OPT_FTRL, 7)])
+def test_fm_step_state(opt, k):
+    rng = np.random.RandomState(k)
+    init = (capi.INIT_CONST, 0.001) if opt == capi.OPT_SGD else (capi.INIT_HASHNORM, 0.0)
+    tw = capi.Table(opt, 1, capacity=1 << 16)
+    tv = capi.Table(opt, k, init[0], init[1], seed=99, capacity=1 << 16)
+    sw = O.Store(opt, 1)
+    sv = O.Store(opt, k, init[0], init[1], 99)
+    ws = capi.Workspace()
+    for step in range(3):
+        rowptr, keys, labels = synth(rng, 500, 30, 4000, 1.3 if step == 2 else None, True)
+        b = capi.Batch(rowptr, keys, labels)
+        ob = O.Batch(rowptr, keys, labels)
+        O.fm_update(sw, sv, ob)
+        capi.fm_step(tw, tv, b, ws)
+    for tt, ss in ((tw, sw), (tv, sv)):
+        for a, r in zip(tt.export(), ss.export()):
+            if a.dtype == np.uint64:
+                assert np.array_equal(a, r)
+            else:
+                close(a, r, rtol=2e-6 if opt == capi.OPT_FTRL else RTOL)
+
+
+def test_predict_matches_oracle_and_inserts_keys():
+    rng = np.random.RandomState(9)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 15)
+    s = O.Store(O.OPT_FTRL, 1)
+    ws = capi.Workspace()
+    rowptr, keys, labels = synth(rng, 400, 20, 3000)
+    b, ob = capi.Batch(rowptr, keys, labels), O.Batch(rowptr, keys, labels)
+    capi.lr_step(t, b, ws)
+    O.lr_update(s, ob)
+    rowptr, keys, labels = synth(rng, 300, 20, 6000)
+    b, ob = capi.Batch(rowptr, keys, labels), O.Batch(rowptr, keys, labels)
+    p = capi.lr_predict(t, b, ws)
+    _, p_ref = ob.lr_loss(s.pull(ob.ukeys))
+    close(p, p_ref)
+    assert len(t) == len(s)                          # test-time pulls grow the table too
+
+
+# --------------------------------------------------------------------------- worker / C API (a14-a16)
+def test_worker_end_to_end_sample_data(sample_prefixes, tmp_path):
+    """XFCreate/XFStartTrain on data/small_*: the stdout metric line, the key counts and the
+    full (key,w,n,z) state against the oracle run with the reference schedule (core_num=1);
+    and against the values SURVEY records from the reference itself."""
+    tr, te = sample_prefixes
+    x = capi.XFlow(tr, te, epochs=10, pred_path=str(tmp_path / "pred.txt"), capacity=4096)
+    x.train()
+    s = O.Store(O.OPT_FTRL, 1)
+    O.train(0, s, None, tr + "-00000", 10, 2 << 20, 1)
+    lab, p = O.predict(0, s, None, te + "-00000")
+    ll, auc, tp, fp = O.auc_logloss(lab, p)
+    assert x.metric("keys") == 877 == len(s)
+    assert (x.metric("tp"), x.metric("fp")) == (46, 154)
+    line = O.format_auc_line(x.metric("logloss_ref"), x.metric("auc"), int(x.metric("tp")),
+                             int(x.metric("fp")))
+    assert line == "logloss: -0.886206\tauc = 0.547149\ttp = 46 fp = 154"
+    close([x.metric("logloss_ref"), x.metric("auc")], [ll, auc])
+    wh, _ = x.tables()
+    t = capi.Table.from_handle(wh, 1)
+    for a, r in zip(t.export(), s.export()):
+        if a.dtype == np.uint64:
+            assert np.array_equal(a, r)
+        else:
+            close(a, r)
+    pred = np.loadtxt(str(tmp_path / "pred.txt"))
+    assert pred.shape == (200, 3)
+    assert np.array_equal(pred[:, 2].astype(np.int32), lab)
+    close(pred[:, 0], p, rtol=1e-5)      # text file holds 6 significant digits
+    assert x.metric("rows_trained") == 2000
+
+
+def test_worker_fm_sgd_and_small_blocks(sample_prefixes, tmp_path):
+    tr, te = sample_prefixes
+    x = capi.XFlow(tr, te, model=1, optimizer="sgd", epochs=3, k=10, capacity=4096,
+                   pred_path=str(tmp_path / "p.txt"))
+    x.train()
+    sw = O.Store(O.OPT_SGD, 1)
+    sv = O.Store(O.OPT_SGD, 10, O.INIT_CONST, 0.001)
+    O.train(1, sw, sv, tr + "-00000", 3, 2 << 20, 1)
+    lab, p = O.predict(1, sw, sv, te + "-00000")
+    ll, auc, tp, fp = O.auc_logloss(lab, p)
+    close([x.metric("logloss_ref"), x.metric("auc")], [ll, auc], rtol=1e-5)
+    wh, vh = x.tables()
+    close(capi.Table.from_handle(vh, 10, capi.OPT_SGD).export()[1], sv.export()[1])
+    close(capi.Table.from_handle(wh, 1, capi.OPT_SGD).export()[1], sw.export()[1])
+
+
+def test_worker_core_num_slices_and_growth(sample_prefixes, tmp_path):
+    """core_num=3 drops the remainder rows (lr_worker.cc:190-194); tiny capacity forces the
+    on-device rehash while training."""
+    tr, te = sample_prefixes
+    x = capi.XFlow(tr, te, epochs=2, core_num=3, capacity=64, pred_path=str(tmp_path / "p.txt"))
+    x.train()
+    s = O.Store(O.OPT_FTRL, 1)
+    assert O.train(0, s, None, tr + "-00000", 2, 2 << 20, 3) == x.metric("rows_trained") == 396
+    lab, p = O.predict(0, s, None, te + "-00000", core_num=3)
+    ll, auc, tp, fp = O.auc_logloss(lab, p)
+    close([x.metric("logloss_ref"), x.metric("auc")], [ll, auc])
+    assert x.metric("keys") == len(s)
+
+
+# ------------------------------------------------------------ full-size properties (config 2)
+@pytest.fixture(scope="module")
+def big_batch():
+    """BASELINE config 2 shape: 5e4 rows x 200 nnz = 1e7 nnz over 1e7 keys."""
+    rng = np.random.RandomState(20260926)
+    R, nnz, K = 50000, 200, 10_000_000
+    fid = rng.randint(0, K, size=(R * nnz))
+    # injective stand-in for the string hash at this size (the oracle is not run here)
+    keys = (fid.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    rowptr = (np.arange(R + 1, dtype=np.uint64) * np.uint64(nnz))
+    labels = rng.randint(0, 2, size=R).astype(np.int32)
+    return capi.Batch(rowptr, keys, labels), fid
+
+
+def test_full_size_properties(big_batch):
+    b, fid = big_batch
+    assert b.NNZ == 10_000_000 and b.U == len(np.unique(fid))
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 24)
+    ws = capi.Workspace()
+    h = b.host()
+    # (1) linearity of the forward: import w = c for every key -> wx = c * nnz exactly
+    c = np.float32(2.0 ** -10)
+    t.import_(h["ukeys"], np.full(b.U, c, np.float32))
+    assert len(t) == b.U
+    p = capi.lr_predict(t, b, ws)
+    assert np.all(p == p[0])                       # wx = 200*c exactly in every row
+    close(p[:1], [O.sigmoid(np.float32(200 * c))])
+    # (2) one step: checksum of checksums  sum_u g[u] * R == sum_r loss[r] * nnz_r
+    capi.lr_step(t, b, ws)
+    wu, loss, g = ws.fetch(b.U, b.R)
+    assert np.all(wu == c)
+    lhs = g.astype(np.float64).sum() * b.R
+    rhs = loss.astype(np.float64).sum() * 200
+    assert abs(lhs - rhs) <= 1e-6 * abs(rhs)
+    # (3) the update touched every key of the batch once: n == g^2 (n started at 0)
+    k2, w2, n2, z2 = t.export()
+    assert np.array_equal(k2, h["ukeys"])
+    assert np.array_equal(n2, (g * g).astype(np.float32))
+    # (4) resolve is idempotent: a second step inserts nothing
+    capi.lr_step(t, b, ws)
+    assert len(t) == b.U
+    # (5) zero gradient leaves (w, z) where they are: FTRL fixed point
+    kz = h["ukeys"][:100000]
+    before = t.pull(kz)
+    t.push(kz, np.zeros(len(kz), np.float32))
+    assert np.array_equal(t.pull(kz), before)

@@ -1,0 +1,73 @@
+"""Build libxflow_amd.so (HIP kernels + host C++ + C ABI) and the xflow_lr CLI for gfx950.
+
+In-tree, explicit hipcc: the .so travels to the GPU box with the snapshot.
+  python -m xflow_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libxflow_amd.so")
+CLI = os.path.join(LIBDIR, "xflow_lr")
+
+LIB_SOURCES = ["xf_table.hip", "xf_model.hip", "xf_io.cc", "xf_batch.cc", "xf_metrics.cc",
+               "xf_worker.cc"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-unused-value",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = list(sources) + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "xflow_amd.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    if force or _stale(LIB, srcs):
+        objs = []
+        procs = []
+        for s in srcs:
+            o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+            objs.append(o)
+            cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + \
+                  ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("build failed: " + " ".join(cmd))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(CSRC, "xf_cli.cc")
+    if force or _stale(CLI, [cli_src, LIB]):
+        cmd = [_hipcc()] + FLAGS + [cli_src, "-o", CLI, "-L" + LIBDIR, "-lxflow_amd",
+                                    "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built", LIB)

@@ -1,0 +1,398 @@
+"""ctypes binding of libxflow_amd.so (include/xflow_amd.h).
+
+The library is the product; this module only marshals pointers.  It never falls back to
+a CPU implementation: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxflow_amd.so")
+
+XF_OK = 0
+OPT_FTRL, OPT_SGD = 0, 1
+INIT_ZERO, INIT_CONST, INIT_HASHNORM = 0, 1, 2
+HEAVY_SEG = 64
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class XFError(RuntimeError):
+    pass
+
+
+class TableConfig(C.Structure):
+    _fields_ = [("opt_kind", C.c_int32), ("dim", C.c_int32), ("init_kind", C.c_int32),
+                ("init_const", C.c_float), ("seed", C.c_uint64), ("alpha", C.c_float),
+                ("beta", C.c_float), ("lambda1", C.c_float), ("lambda2", C.c_float),
+                ("lr", C.c_float), ("capacity", C.c_uint64), ("shard", C.c_uint32),
+                ("nshards", C.c_uint32)]
+
+
+class DevBatch(C.Structure):
+    _fields_ = [("R", C.c_uint32), ("NNZ", C.c_uint32), ("U", C.c_uint32), ("H", C.c_uint32),
+                ("rowptr", vp), ("uidx", vp), ("ukeys", vp), ("segptr", vp), ("coo_row", vp),
+                ("labels", vp), ("heavy", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/xflow_amd.h declares
+SIGNATURES = {
+    "xf_last_error": (C.c_char_p, []),
+    "xf_version": (C.c_int, []),
+    "xf_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "xf_hash_bytes": (C.c_uint64, [C.c_char_p, C.c_size_t]),
+    "xf_shard_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+    "xf_hash_decimal_range": (C.c_int, [C.c_uint64, C.c_size_t, u64p]),
+    "xf_reader_open": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t]),
+    "xf_reader_close": (C.c_int, [vp]),
+    "xf_reader_next": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                 C.POINTER(u64p), C.POINTER(u64p), C.POINTER(i32p),
+                                 C.POINTER(i32p)]),
+    "xf_batch_compile": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t, C.c_size_t]),
+    "xf_batch_free": (C.c_int, [vp]),
+    "xf_batch_dims": (C.c_int, [vp, u32p, u32p, u32p, u32p]),
+    "xf_batch_host": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(u32p),
+                                C.POINTER(u32p), C.POINTER(u32p), C.POINTER(i32p),
+                                C.POINTER(u32p)]),
+    "xf_batch_upload": (C.c_int, [vp, vp]),
+    "xf_batch_dev_view": (C.c_int, [vp, C.POINTER(DevBatch)]),
+    "xf_table_config_default": (None, [C.POINTER(TableConfig)]),
+    "xf_table_create": (C.c_int, [C.POINTER(vp), C.POINTER(TableConfig)]),
+    "xf_table_destroy": (C.c_int, [vp]),
+    "xf_table_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "xf_table_capacity": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "xf_table_reserve": (C.c_int, [vp, C.c_uint64]),
+    "xf_table_set_hyper": (C.c_int, [vp] + [C.c_float] * 5),
+    "xf_table_pull": (C.c_int, [vp, u64p, C.c_size_t, f32p]),
+    "xf_table_push": (C.c_int, [vp, u64p, C.c_size_t, f32p]),
+    "xf_table_resolve_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "xf_table_gather_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "xf_table_update_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "xf_table_check": (C.c_int, [vp, vp]),
+    "xf_table_export": (C.c_int, [vp, u64p, f32p, f32p, f32p, C.c_size_t,
+                                  C.POINTER(C.c_size_t)]),
+    "xf_table_import": (C.c_int, [vp, u64p, C.c_size_t, f32p, f32p, f32p]),
+    "xf_lr_forward_dev": (C.c_int, [C.POINTER(DevBatch), vp, vp, vp, vp]),
+    "xf_lr_grad_dev": (C.c_int, [C.POINTER(DevBatch), vp, vp, vp]),
+    "xf_fm_forward_dev": (C.c_int, [C.POINTER(DevBatch), C.c_int, vp, vp, vp, vp, vp, vp]),
+    "xf_fm_grad_dev": (C.c_int, [C.POINTER(DevBatch), C.c_int, vp, vp, vp, vp, vp, vp]),
+    "xf_workspace_create": (C.c_int, [C.POINTER(vp)]),
+    "xf_workspace_destroy": (C.c_int, [vp]),
+    "xf_lr_step": (C.c_int, [vp, vp, vp, vp]),
+    "xf_fm_step": (C.c_int, [vp, vp, vp, vp, vp]),
+    "xf_lr_predict": (C.c_int, [vp, vp, vp, f32p]),
+    "xf_fm_predict": (C.c_int, [vp, vp, vp, vp, f32p]),
+    "xf_workspace_fetch": (C.c_int, [vp, f32p, f32p, f32p, C.c_size_t, C.c_size_t]),
+    "xf_workspace_profile": (C.c_int, [vp, C.c_int]),
+    "xf_workspace_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "xf_stream_sync": (C.c_int, [vp]),
+    "xf_auc_logloss": (C.c_int, [i32p, f32p, C.c_size_t, f32p, f32p, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "XFCreate": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_char_p]),
+    "XFStartTrain": (C.c_int, [C.POINTER(vp)]),
+    "XFDestroy": (C.c_int, [C.POINTER(vp)]),
+    "XFSetParam": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+    "XFGetMetric": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double)]),
+    "XFGetTables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XFError("libxflow_amd.so is not built: run `python -m xflow_amd.build` "
+                          "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != XF_OK:
+        raise XFError("xflow_amd error %d: %s" % (rc, lib().xf_last_error().decode()))
+
+
+def require_gpu():
+    n = C.c_int(0)
+    check(lib().xf_device_count(C.byref(n)))
+    if n.value < 1:
+        raise XFError("no HIP device visible: the xflow_amd hot path runs only on the GPU")
+    return n.value
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def hash_str(s):
+    b = s if isinstance(s, bytes) else str(s).encode()
+    return int(lib().xf_hash_bytes(b, len(b)))
+
+
+def hash_decimal_range(start, n):
+    out = np.empty(n, dtype=np.uint64)
+    check(lib().xf_hash_decimal_range(start, n, _p(out, u64p)))
+    return out
+
+
+def read_blocks(path, cap_bytes):
+    """Yield (rowptr, keys, fgid, labels) numpy copies per text block."""
+    L = lib()
+    h = vp()
+    check(L.xf_reader_open(C.byref(h), path.encode(), cap_bytes))
+    try:
+        while True:
+            rows, nnz = C.c_size_t(0), C.c_size_t(0)
+            rp, ks, fg, lb = u64p(), u64p(), i32p(), i32p()
+            check(L.xf_reader_next(h, C.byref(rows), C.byref(nnz), C.byref(rp), C.byref(ks),
+                                   C.byref(fg), C.byref(lb)))
+            if rows.value == 0:
+                return
+            r, n = rows.value, nnz.value
+            yield (np.ctypeslib.as_array(rp, (r + 1,)).copy(),
+                   np.ctypeslib.as_array(ks, (n,)).copy() if n else np.zeros(0, np.uint64),
+                   np.ctypeslib.as_array(fg, (n,)).copy() if n else np.zeros(0, np.int32),
+                   np.ctypeslib.as_array(lb, (r,)).copy())
+    finally:
+        L.xf_reader_close(h)
+
+
+class Batch:
+    """A compiled minibatch (host arrays; device mirror after upload())."""
+
+    def __init__(self, rowptr, keys, labels, row_begin=0, row_end=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if row_end is None:
+            row_end = len(rowptr) - 1
+        self.h = vp()
+        check(lib().xf_batch_compile(C.byref(self.h), _p(rowptr, u64p), _p(keys, u64p),
+                                     _p(labels, i32p), row_begin, row_end))
+        R, N, U, H = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), C.byref(U), C.byref(H)))
+        self.R, self.NNZ, self.U, self.H = R.value, N.value, U.value, H.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().xf_batch_free(self.h)
+            self.h = None
+
+    def host(self):
+        uk, rp, ui, sp, cr, hv = u64p(), u32p(), u32p(), u32p(), u32p(), u32p()
+        lb = i32p()
+        check(lib().xf_batch_host(self.h, C.byref(uk), C.byref(rp), C.byref(ui), C.byref(sp),
+                                  C.byref(cr), C.byref(lb), C.byref(hv)))
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, (n,)).copy() if n else np.zeros(0, dt)
+        return dict(ukeys=arr(uk, self.U, np.uint64), rowptr=arr(rp, self.R + 1, np.uint32),
+                    uidx=arr(ui, self.NNZ, np.uint32), segptr=arr(sp, self.U + 1, np.uint32),
+                    coo_row=arr(cr, self.NNZ, np.uint32), labels=arr(lb, self.R, np.int32),
+                    heavy=arr(hv, self.H, np.uint32))
+
+    def upload(self, stream=None):
+        check(lib().xf_batch_upload(self.h, stream))
+        return self
+
+    def dev_view(self):
+        v = DevBatch()
+        check(lib().xf_batch_dev_view(self.h, C.byref(v)))
+        return v
+
+
+class Table:
+    """One GPU's shard of the parameter table (ps-lite server replacement)."""
+
+    def __init__(self, opt=OPT_FTRL, dim=1, init=INIT_ZERO, init_const=0.0, seed=0,
+                 capacity=1 << 20, shard=0, nshards=1, **hyper):
+        require_gpu()
+        c = TableConfig()
+        lib().xf_table_config_default(C.byref(c))
+        c.opt_kind, c.dim, c.init_kind, c.init_const, c.seed = opt, dim, init, init_const, seed
+        c.capacity, c.shard, c.nshards = capacity, shard, nshards
+        for k, v in hyper.items():
+            setattr(c, k, v)
+        self.dim, self.opt = dim, opt
+        self.h = vp()
+        check(lib().xf_table_create(C.byref(self.h), C.byref(c)))
+
+    @classmethod
+    def from_handle(cls, h, dim, opt=OPT_FTRL):
+        """Non-owning view of a table owned by a worker (XFGetTables)."""
+        t = cls.__new__(cls)
+        t.h, t.dim, t.opt, t._borrowed = h, dim, opt, True
+        return t
+
+    def __del__(self):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
+            lib().xf_table_destroy(self.h)
+            self.h = None
+
+    def __len__(self):
+        n = C.c_uint64(0)
+        check(lib().xf_table_size(self.h, C.byref(n)))
+        return n.value
+
+    @property
+    def capacity(self):
+        n = C.c_uint64(0)
+        check(lib().xf_table_capacity(self.h, C.byref(n)))
+        return n.value
+
+    def reserve(self, capacity):
+        check(lib().xf_table_reserve(self.h, capacity))
+
+    def pull(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty(len(keys) * self.dim, dtype=np.float32)
+        check(lib().xf_table_pull(self.h, _p(keys, u64p), len(keys), _p(out, f32p)))
+        return out.reshape(len(keys), self.dim) if self.dim > 1 else out
+
+    def push(self, keys, grads):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        grads = np.ascontiguousarray(grads, dtype=np.float32).ravel()
+        assert grads.size == len(keys) * self.dim
+        check(lib().xf_table_push(self.h, _p(keys, u64p), len(keys), _p(grads, f32p)))
+
+    def export(self):
+        n = C.c_size_t(0)
+        check(lib().xf_table_export(self.h, None, None, None, None, 0, C.byref(n)))
+        m = n.value
+        keys = np.empty(m, dtype=np.uint64)
+        w = np.empty(m * self.dim, dtype=np.float32)
+        nn = np.empty(m * self.dim, dtype=np.float32)
+        z = np.empty(m * self.dim, dtype=np.float32)
+        if m:
+            check(lib().xf_table_export(self.h, _p(keys, u64p), _p(w, f32p), _p(nn, f32p),
+                                        _p(z, f32p), m, C.byref(n)))
+        sh = (m, self.dim) if self.dim > 1 else (m,)
+        return keys, w.reshape(sh), nn.reshape(sh), z.reshape(sh)
+
+    def import_(self, keys, w, n=None, z=None):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float32).ravel()
+                for a in (w, n, z)]
+        check(lib().xf_table_import(self.h, _p(keys, u64p), len(keys),
+                                    *[None if a is None else _p(a, f32p) for a in arrs]))
+
+    # device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr())
+    def resolve_dev(self, d_keys, n, d_slots, stream=None):
+        check(lib().xf_table_resolve_dev(self.h, d_keys, n, d_slots, stream))
+
+    def gather_dev(self, d_slots, n, d_vals, stream=None):
+        check(lib().xf_table_gather_dev(self.h, d_slots, n, d_vals, stream))
+
+    def update_dev(self, d_slots, n, d_grads, stream=None):
+        check(lib().xf_table_update_dev(self.h, d_slots, n, d_grads, stream))
+
+    def check(self, stream=None):
+        check(lib().xf_table_check(self.h, stream))
+
+
+class Workspace:
+    def __init__(self):
+        self.h = vp()
+        check(lib().xf_workspace_create(C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().xf_workspace_destroy(self.h)
+            self.h = None
+
+    def fetch(self, U, R):
+        wu = np.empty(U, np.float32)
+        loss = np.empty(R, np.float32)
+        g = np.empty(U, np.float32)
+        check(lib().xf_workspace_fetch(self.h, _p(wu, f32p), _p(loss, f32p), _p(g, f32p), U, R))
+        return wu, loss, g
+
+    def profile(self, enable):
+        check(lib().xf_workspace_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 5)()
+        steps = C.c_long(0)
+        check(lib().xf_workspace_profile_read(self.h, ms, C.byref(steps)))
+        names = ["resolve", "gather", "forward", "gradient", "update"]
+        return {k: ms[i] for i, k in enumerate(names)}, steps.value
+
+
+def lr_step(table, batch, ws, stream=None):
+    check(lib().xf_lr_step(table.h, batch.h, ws.h, stream))
+
+
+def fm_step(wt, vt, batch, ws, stream=None):
+    check(lib().xf_fm_step(wt.h, vt.h, batch.h, ws.h, stream))
+
+
+def lr_predict(table, batch, ws):
+    out = np.empty(batch.R, np.float32)
+    check(lib().xf_lr_predict(table.h, batch.h, ws.h, _p(out, f32p)))
+    return out
+
+
+def fm_predict(wt, vt, batch, ws):
+    out = np.empty(batch.R, np.float32)
+    check(lib().xf_fm_predict(wt.h, vt.h, batch.h, ws.h, _p(out, f32p)))
+    return out
+
+
+def stream_sync(stream=None):
+    check(lib().xf_stream_sync(stream))
+
+
+def auc_logloss(labels, pctr, acc=0.0):
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    pctr = np.ascontiguousarray(pctr, dtype=np.float32)
+    ll, auc = C.c_float(acc), C.c_float(0)
+    tp, fp = C.c_int(0), C.c_int(0)
+    nat = C.c_double(0)
+    check(lib().xf_auc_logloss(_p(labels, i32p), _p(pctr, f32p), len(labels), C.byref(ll),
+                               C.byref(auc), C.byref(tp), C.byref(fp), C.byref(nat)))
+    return ll.value, auc.value, tp.value, fp.value, nat.value
+
+
+class XFlow:
+    """XFCreate / XFSetParam / XFStartTrain / XFGetMetric / XFDestroy."""
+
+    def __init__(self, train_prefix, test_prefix, **params):
+        self.h = vp()
+        check(lib().XFCreate(C.byref(self.h), train_prefix.encode(), test_prefix.encode()))
+        for k, v in params.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        check(lib().XFSetParam(self.h, name.encode(), str(value).encode()))
+
+    def train(self):
+        require_gpu()
+        check(lib().XFStartTrain(C.byref(self.h)))
+
+    def metric(self, name):
+        v = C.c_double(0)
+        check(lib().XFGetMetric(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def tables(self):
+        w, v = vp(), vp()
+        check(lib().XFGetTables(self.h, C.byref(w), C.byref(v)))
+        return w, v
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().XFDestroy(C.byref(self.h))

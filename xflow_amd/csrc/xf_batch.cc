@@ -1,0 +1,192 @@
+// xf_batch.cc — host-side minibatch key build and its device mirror.
+//
+// Replaces the key build at the top of LRWorker::update / FMWorker::update
+// (src/model/lr/lr_worker.cc:146-166, src/model/fm/fm_worker.cc:205-225): flatten the
+// slice to all_keys[(fid,sid)], sort by fid, sorted-unique key list.  The reference keeps
+// `all_keys` as an array of 24-byte structs and walks it with merge-joins; here the same
+// information is stored as the two index views the kernels stream:
+//   CSR  rowptr/uidx   forward  (one wave per example gathers w_u[uidx])
+//   COO  segptr/coo_row gradient (one lane per key walks its occurrences)
+// The result depends only on the input rows, so a compiled batch can be cached across
+// epochs (the reference re-parses and re-sorts every epoch, lr_worker.cc:184).
+#include "xf_batch.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct KeyPos {
+  uint64_t key;
+  uint32_t pos;  // nnz position in row-major order
+};
+
+inline bool keypos_less(const KeyPos &a, const KeyPos &b) {
+  return a.key < b.key || (a.key == b.key && a.pos < b.pos);
+}
+
+// Sort (key,pos) by key, ties by position.  Keys are uniform 64-bit hashes, so one
+// counting pass on the top 16 bits leaves ~NNZ/65536 elements per bucket, which are
+// finished with std::sort in parallel.
+void sort_keypos(std::vector<KeyPos> &a) {
+  const size_t n = a.size();
+  if (n < (1u << 16)) {
+    std::sort(a.begin(), a.end(), keypos_less);
+    return;
+  }
+  constexpr int kBits = 16;
+  constexpr size_t kBuckets = (size_t)1 << kBits;
+  std::vector<size_t> start(kBuckets + 1, 0);
+  for (size_t i = 0; i < n; ++i) ++start[(a[i].key >> (64 - kBits)) + 1];
+  for (size_t b = 0; b < kBuckets; ++b) start[b + 1] += start[b];
+  std::vector<KeyPos> tmp(n);
+  {
+    std::vector<size_t> cur(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; ++i) tmp[cur[a[i].key >> (64 - kBits)]++] = a[i];
+  }
+  a.swap(tmp);
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 32) nt = 32;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) {
+    th.emplace_back([&, t]() {
+      for (size_t b = t; b < kBuckets; b += nt)
+        std::sort(a.begin() + start[b], a.begin() + start[b + 1], keypos_less);
+    });
+  }
+  for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
+                                const int32_t *labels, size_t row_begin, size_t row_end) {
+  XF_REQUIRE(out && rowptr && labels && row_end >= row_begin, "xf_batch_compile: bad argument");
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(NNZ == 0 || keys, "xf_batch_compile: null keys");
+  XF_REQUIRE(R < 0xFFFFFFFFull && NNZ < 0xFFFFFFFFull, "xf_batch_compile: batch too large");
+  xf_batch *b = new xf_batch;
+  b->R = (uint32_t)R;
+  b->NNZ = (uint32_t)NNZ;
+  b->rowptr.resize(R + 1);
+  b->labels.assign(labels + row_begin, labels + row_end);
+  std::vector<uint32_t> row_of(NNZ);
+  for (size_t r = 0; r < R; ++r) {
+    b->rowptr[r] = (uint32_t)(rowptr[row_begin + r] - base);
+    for (uint64_t j = rowptr[row_begin + r]; j < rowptr[row_begin + r + 1]; ++j)
+      row_of[j - base] = (uint32_t)r;
+  }
+  b->rowptr[R] = (uint32_t)NNZ;
+  std::vector<KeyPos> kp(NNZ);
+  for (size_t j = 0; j < NNZ; ++j) {
+    kp[j].key = keys[base + j];
+    kp[j].pos = (uint32_t)j;
+  }
+  sort_keypos(kp);
+  b->uidx.resize(NNZ);
+  b->coo_row.resize(NNZ);
+  b->segptr.clear();
+  b->ukeys.clear();
+  for (size_t j = 0; j < NNZ; ++j) {
+    if (j == 0 || kp[j].key != kp[j - 1].key) {
+      b->segptr.push_back((uint32_t)j);
+      b->ukeys.push_back(kp[j].key);
+    }
+    b->uidx[kp[j].pos] = (uint32_t)(b->ukeys.size() - 1);
+    b->coo_row[j] = row_of[kp[j].pos];
+  }
+  b->segptr.push_back((uint32_t)NNZ);
+  b->U = (uint32_t)b->ukeys.size();
+  for (uint32_t u = 0; u < b->U; ++u)
+    if (b->segptr[u + 1] - b->segptr[u] > XF_HEAVY_SEG) b->heavy.push_back(u);
+  b->H = (uint32_t)b->heavy.size();
+  *out = b;
+  return XF_OK;
+}
+
+extern "C" int xf_batch_free(xf_batch *b) {
+  if (!b) return XF_OK;
+  if (b->d_blob) hipFree(b->d_blob);
+  delete b;
+  return XF_OK;
+}
+
+extern "C" int xf_batch_dims(const xf_batch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
+                             uint32_t *H) {
+  XF_REQUIRE(b, "xf_batch_dims: null batch");
+  if (R) *R = b->R;
+  if (NNZ) *NNZ = b->NNZ;
+  if (U) *U = b->U;
+  if (H) *H = b->H;
+  return XF_OK;
+}
+
+extern "C" int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const uint32_t **rowptr,
+                             const uint32_t **uidx, const uint32_t **segptr,
+                             const uint32_t **coo_row, const int32_t **labels,
+                             const uint32_t **heavy) {
+  XF_REQUIRE(b, "xf_batch_host: null batch");
+  if (ukeys) *ukeys = b->ukeys.data();
+  if (rowptr) *rowptr = b->rowptr.data();
+  if (uidx) *uidx = b->uidx.data();
+  if (segptr) *segptr = b->segptr.data();
+  if (coo_row) *coo_row = b->coo_row.data();
+  if (labels) *labels = b->labels.data();
+  if (heavy) *heavy = b->heavy.data();
+  return XF_OK;
+}
+
+extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
+  XF_REQUIRE(b, "xf_batch_upload: null batch");
+  if (b->d_blob) return XF_OK;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_ukeys = 0;
+  const size_t o_rowptr = o_ukeys + al((size_t)b->U * 8);
+  const size_t o_uidx = o_rowptr + al(((size_t)b->R + 1) * 4);
+  const size_t o_segptr = o_uidx + al((size_t)b->NNZ * 4);
+  const size_t o_coo = o_segptr + al(((size_t)b->U + 1) * 4);
+  const size_t o_labels = o_coo + al((size_t)b->NNZ * 4);
+  const size_t o_heavy = o_labels + al((size_t)b->R * 4);
+  const size_t total = o_heavy + al((size_t)b->H * 4) + 256;
+  char *d = nullptr;
+  XF_HIP(hipMalloc((void **)&d, total));
+  hipStream_t s = (hipStream_t)stream;
+  auto put = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+    if (bytes == 0) return hipSuccess;
+    return hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  XF_HIP(put(o_ukeys, b->ukeys.data(), (size_t)b->U * 8));
+  XF_HIP(put(o_rowptr, b->rowptr.data(), ((size_t)b->R + 1) * 4));
+  XF_HIP(put(o_uidx, b->uidx.data(), (size_t)b->NNZ * 4));
+  XF_HIP(put(o_segptr, b->segptr.data(), ((size_t)b->U + 1) * 4));
+  XF_HIP(put(o_coo, b->coo_row.data(), (size_t)b->NNZ * 4));
+  XF_HIP(put(o_labels, b->labels.data(), (size_t)b->R * 4));
+  XF_HIP(put(o_heavy, b->heavy.data(), (size_t)b->H * 4));
+  XF_HIP(hipStreamSynchronize(s));  // host vectors are pageable: finish before returning
+  b->d_blob = d;
+  b->view.R = b->R;
+  b->view.NNZ = b->NNZ;
+  b->view.U = b->U;
+  b->view.H = b->H;
+  b->view.ukeys = (const uint64_t *)(d + o_ukeys);
+  b->view.rowptr = (const uint32_t *)(d + o_rowptr);
+  b->view.uidx = (const uint32_t *)(d + o_uidx);
+  b->view.segptr = (const uint32_t *)(d + o_segptr);
+  b->view.coo_row = (const uint32_t *)(d + o_coo);
+  b->view.labels = (const int32_t *)(d + o_labels);
+  b->view.heavy = b->H ? (const uint32_t *)(d + o_heavy) : nullptr;
+  return XF_OK;
+}
+
+extern "C" int xf_batch_dev_view(const xf_batch *b, xf_dev_batch *view) {
+  XF_REQUIRE(b && view, "xf_batch_dev_view: null argument");
+  XF_REQUIRE(b->d_blob, "xf_batch_dev_view: batch not uploaded");
+  *view = b->view;
+  return XF_OK;
+}

@@ -1,0 +1,18 @@
+// xf_batch.h — the compiled minibatch (host arrays + device mirror).
+#ifndef XF_BATCH_H_
+#define XF_BATCH_H_
+
+#include <vector>
+
+#include "xf_common.h"
+
+struct xf_batch {
+  uint32_t R = 0, NNZ = 0, U = 0, H = 0;
+  std::vector<uint64_t> ukeys;
+  std::vector<uint32_t> rowptr, uidx, segptr, coo_row, heavy;
+  std::vector<int32_t> labels;
+  void *d_blob = nullptr;  // one device allocation holding all arrays
+  xf_dev_batch view{};
+};
+
+#endif  // XF_BATCH_H_

@@ -1,0 +1,111 @@
+// xf_device.h — device-side structs and the scalar arithmetic of the path (gfx950).
+// Compiled with -ffp-contract=off: the reference is built without FMA contraction
+// (CMakeLists.txt:6-8), and hipcc's default correctly-rounded fp32 sqrt/divide is kept.
+#ifndef XF_DEVICE_H_
+#define XF_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xflow_amd.h"
+
+namespace xf {
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned kErrFull = 1u;
+constexpr unsigned kErrForeignKey = 2u;
+
+struct TableStat {
+  unsigned long long count;  // keys inserted (excluding the spare slot)
+  unsigned int err;          // kErr* bits, sticky
+  unsigned int spare_used;   // the reserved key value has been stored
+};
+
+struct TableDev {
+  uint64_t cap;   // slots; slot `cap` is the spare one
+  uint64_t lo;    // first key of this shard's range
+  uint64_t span;  // UINT64_MAX / nshards
+  uint64_t mult;  // floor(cap * 2^64 / span)
+  uint64_t seed;
+  uint64_t *keys;
+  float *w, *n, *z;
+  TableStat *stat;
+  int dim, init_kind;
+  float init_const;
+  float alpha, beta, lambda1, lambda2, lr;
+  bool last_shard, single;
+};
+
+// ps-lite uniform key-range ownership
+__device__ __forceinline__ bool owns(const TableDev &T, uint64_t key) {
+  if (T.single) return true;
+  if (key < T.lo) return false;
+  return T.last_shard || (key - T.lo) < T.span;
+}
+
+// order-preserving home slot: floor((key - lo) * cap / span), clamped
+__device__ __forceinline__ uint64_t home_of(const TableDev &T, uint64_t key) {
+  const uint64_t h = __umul64hi(key - T.lo, T.mult);
+  return h < T.cap ? h : T.cap - 1;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+// Deterministic first-touch value for FTRL v rows.  The reference draws N(0,1)*1e-2 from a
+// time-seeded engine (ftrl.h:114-120, base.h:33-44), which no implementation can
+// reproduce; this is an integer Irwin-Hall(12) normal, identical bits on any machine.
+__device__ __forceinline__ float hashnorm(uint64_t seed, uint64_t key, uint32_t j) {
+  const uint64_t base = mix64(seed ^ mix64(key)) + (uint64_t)j * 0xd1342543de82ef95ull;
+  uint64_t sum = 0;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const uint64_t r = mix64(base + (uint64_t)t);
+    sum += (r & 0xffff) + ((r >> 16) & 0xffff) + ((r >> 32) & 0xffff) + (r >> 48);
+  }
+  const double x = ((double)(int64_t)sum - 393210.0) / 65536.0;
+  return (float)(x * 1e-2);
+}
+
+// One FTRL-proximal coordinate step, ftrl.h:59-74 statement for statement: fp32, the OLD w
+// in the z update, left-to-right evaluation, no fused multiply-add.
+__device__ __forceinline__ void ftrl_step(float alpha, float beta, float lambda1,
+                                          float lambda2, float g, float &w, float &n,
+                                          float &z) {
+#pragma clang fp contract(off)
+  const float old_n = n;
+  const float nn = old_n + g * g;
+  z = z + (g - (sqrtf(nn) - sqrtf(old_n)) / alpha * w);
+  n = nn;
+  if (fabsf(z) <= lambda1) {
+    w = 0.0f;
+  } else {
+    float tmpr = 0.0f;
+    if (z > 0.0f) tmpr = z - lambda1;
+    if (z < 0.0f) tmpr = z + lambda1;
+    const float tmpl = -1.0f * ((beta + sqrtf(nn)) / alpha + lambda2);
+    w = tmpr / tmpl;
+  }
+}
+
+// sgd.h:52,96
+__device__ __forceinline__ float sgd_step(float lr, float g, float w) {
+#pragma clang fp contract(off)
+  return w - lr * g;
+}
+
+// Base::sigmoid, base.h:54-63: double pow with base 2.718281828 (not e), clamp to 1e-6
+// below -30 and to exactly 1 above +30.
+__device__ __forceinline__ float sigmoid_ref(float x) {
+  if (x < -30.0f) return 1e-6f;
+  if (x > 30.0f) return 1.0f;
+  const double ex = pow(2.718281828, (double)x);
+  return (float)(ex / (1.0 + ex));
+}
+
+}  // namespace xf
+#endif  // XF_DEVICE_H_

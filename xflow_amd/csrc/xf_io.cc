@@ -1,0 +1,223 @@
+// xf_io.cc — key hash, key-range owner rule, the block text reader, error plumbing.
+//
+// Replaces src/io/io.h + src/io/load_data_from_disk.{h,cc} of the reference for the one
+// loader the workers call, LoadData::load_minibatch_hash_data_fread
+// (load_data_from_disk.cc:103-210; callers lr_worker.cc:85,188, fm_worker.cc:110,258).
+// Host-side by design (north_star keeps the libsvm-format io path on the host); must be
+// bit-exact on keys, labels and on which rows fall in which block.
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "xf_common.h"
+
+namespace xf {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+}  // namespace xf
+
+extern "C" const char *xf_last_error(void) { return xf::g_err; }
+extern "C" int xf_version(void) { return 100; }
+
+extern "C" int xf_device_count(int *count) {
+  XF_REQUIRE(count, "xf_device_count: null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return XF_OK;
+}
+
+// ------------------------------------------------------------------------------- hash
+// std::hash<std::string> of libstdc++ (io.h:53): _Hash_bytes, a 64-bit Murmur-style mix
+// with multiplier 0xc6a4a7935bd1e995 and seed 0xc70f6907; 8-byte little-endian words, the
+// 1..7 tail bytes packed little-endian, two closing shift-mix rounds (v ^= v >> 47).
+extern "C" uint64_t xf_hash_bytes(const void *ptr, size_t len) {
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  const unsigned char *p = static_cast<const unsigned char *>(ptr);
+  uint64_t h = 0xc70f6907ull ^ (len * m);
+  size_t left = len;
+  while (left >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w *= m;
+    w ^= w >> 47;
+    w *= m;
+    h = (h ^ w) * m;
+    p += 8;
+    left -= 8;
+  }
+  if (left) {
+    uint64_t w = 0;
+    memcpy(&w, p, left);  // little-endian host: same packing as libstdc++'s load_bytes
+    h = (h ^ w) * m;
+  }
+  h ^= h >> 47;
+  h *= m;
+  h ^= h >> 47;
+  return h;
+}
+
+// keys of the decimal strings "start", "start+1", ... (synthetic-data generator helper:
+// the reference's fids are decimal strings, e.g. data/small_train "2:1163:0.3651")
+extern "C" int xf_hash_decimal_range(uint64_t start, size_t n, uint64_t *out) {
+  XF_REQUIRE(out || n == 0, "xf_hash_decimal_range: null output");
+  char buf[24];
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t v = start + i;
+    int len = 0;
+    char tmp[24];
+    do {
+      tmp[len++] = (char)('0' + v % 10);
+      v /= 10;
+    } while (v);
+    for (int j = 0; j < len; ++j) buf[j] = tmp[len - 1 - j];
+    out[i] = xf_hash_bytes(buf, (size_t)len);
+  }
+  return XF_OK;
+}
+
+extern "C" uint32_t xf_shard_of(uint64_t key, uint32_t nshards) {
+  if (nshards <= 1) return 0;
+  const uint64_t s = key / (UINT64_MAX / nshards);
+  return s >= nshards ? nshards - 1 : (uint32_t)s;
+}
+
+// ----------------------------------------------------------------------------- reader
+struct xf_reader {
+  FILE *fp = nullptr;
+  std::string path;
+  size_t cap = 0;
+  std::vector<char> buf;
+  size_t held = 0;  // bytes at the front of buf not yet parsed (carry + fresh read)
+  std::vector<uint64_t> rowptr, keys;
+  std::vector<int32_t> fgid, labels;
+};
+
+extern "C" int xf_reader_open(xf_reader **out, const char *path, size_t cap_bytes) {
+  XF_REQUIRE(out && path, "xf_reader_open: null argument");
+  XF_REQUIRE(cap_bytes >= 2, "xf_reader_open: block of %zu bytes", cap_bytes);
+  FILE *fp = fopen(path, "r");
+  if (!fp) return xf::set_error(XF_EIO, "open file %s error: %s", path, strerror(errno));
+  xf_reader *r = new xf_reader;
+  r->fp = fp;
+  r->path = path;
+  r->cap = cap_bytes;
+  r->buf.resize(cap_bytes);
+  *out = r;
+  return XF_OK;
+}
+
+extern "C" int xf_reader_close(xf_reader *r) {
+  if (!r) return XF_OK;
+  if (r->fp) fclose(r->fp);
+  delete r;
+  return XF_OK;
+}
+
+namespace {
+
+// atof on the byte range [b, e) (fields are short; copy to a NUL-terminated scratch)
+inline double field_atof(const char *b, const char *e, bool *ok) {
+  char tmp[48];
+  const size_t n = (size_t)(e - b);
+  if (n >= sizeof(tmp)) {
+    *ok = false;
+    return 0.0;
+  }
+  memcpy(tmp, b, n);
+  tmp[n] = '\0';
+  return atof(tmp);
+}
+
+}  // namespace
+
+extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
+                              const uint64_t **rowptr, const uint64_t **keys,
+                              const int32_t **fgid, const int32_t **labels) {
+  XF_REQUIRE(r && rows_out, "xf_reader_next: null argument");
+  r->rowptr.assign(1, 0);
+  r->keys.clear();
+  r->fgid.clear();
+  r->labels.clear();
+  // The reference fills a cap-byte buffer up to cap-1 bytes (:108-110).  A buffer that
+  // filled completely is cut after its last newline and the rest carried (:112-121,:104-107);
+  // a short read means end of file and everything is parsed.
+  char *base = r->buf.data();
+  r->held += fread(base + r->held, 1, r->cap - 1 - r->held, r->fp);
+  size_t take = r->held;   // bytes consumed by this block
+  size_t text = r->held;   // bytes of text to parse
+  if (r->held == r->cap - 1) {
+    size_t cut = r->held;
+    while (cut > 0 && base[cut - 1] != '\n' && base[cut - 1] != (char)EOF) --cut;
+    if (cut == 0)
+      return xf::set_error(XF_EPARSE, "%s: a line does not fit in a %zu-byte block",
+                           r->path.c_str(), r->cap);
+    take = cut;
+    text = cut - 1;  // the newline is replaced by the terminator (:116)
+  }
+  const char *p = base, *end = base + text;
+  while (p < end && *p != '\0') {
+    const char *eol = p;
+    const char *tab = nullptr;
+    while (eol < end && *eol != '\n') {
+      if (!tab && *eol == '\t') tab = eol;
+      ++eol;
+    }
+    if (!tab)
+      return xf::set_error(XF_EPARSE, "%s: row %zu has no '\\t' after the label",
+                           r->path.c_str(), r->labels.size());
+    bool ok = true;
+    const float y_tmp = (float)field_atof(p, tab, &ok);  // :129
+    if (!ok) return xf::set_error(XF_EPARSE, "%s: label field too long", r->path.c_str());
+    r->labels.push_back(y_tmp > 0.0000001 ? 1 : 0);       // :131-134
+    const char *t = tab + 1;
+    while (t < eol) {
+      const char *te = t;
+      const char *c1 = nullptr, *c2 = nullptr;
+      while (te < eol && *te != ' ') {
+        if (*te == ':') {
+          if (!c1) c1 = te;
+          else if (!c2)
+            c2 = te;
+        }
+        ++te;
+      }
+      if (te == t) {               // empty token
+        if (te + 1 >= eol) break;  // a single trailing blank is harmless in the reference
+        return xf::set_error(XF_EPARSE, "%s: empty token in row %zu", r->path.c_str(),
+                             r->labels.size() - 1);
+      }
+      if (!c1 || !c2)  // the reference would scan past the terminator here
+        return xf::set_error(XF_EPARSE, "%s: token without fgid:fid:val in row %zu",
+                             r->path.c_str(), r->labels.size() - 1);
+      const double fg = field_atof(t, c1, &ok);  // :149
+      if (!ok) return xf::set_error(XF_EPARSE, "%s: fgid field too long", r->path.c_str());
+      r->fgid.push_back((int32_t)fg);
+      r->keys.push_back(xf_hash_bytes(c1 + 1, (size_t)(c2 - (c1 + 1))));  // :151
+      t = te + 1;
+    }
+    r->rowptr.push_back(r->keys.size());
+    p = eol + 1;
+  }
+  if (take < r->held) memmove(base, base + take, r->held - take);
+  r->held -= take;
+  *rows_out = r->labels.size();
+  if (nnz_out) *nnz_out = r->keys.size();
+  if (rowptr) *rowptr = r->rowptr.data();
+  if (keys) *keys = r->keys.data();
+  if (fgid) *fgid = r->fgid.data();
+  if (labels) *labels = r->labels.data();
+  return XF_OK;
+}

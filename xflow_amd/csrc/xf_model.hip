@@ -1,0 +1,507 @@
+// xf_model.hip — LR / FM forward and gradient kernels (gfx950) and the fused per-minibatch
+// step built from them and the table kernels.
+//
+// Replaces (paths relative to /root/reference):
+//   LRWorker::calculate_loss      src/model/lr/lr_worker.cc:121-143
+//   LRWorker::calculate_gradient  src/model/lr/lr_worker.cc:100-119
+//   LRWorker::update              src/model/lr/lr_worker.cc:145-177
+//   LRWorker::calculate_pctr      src/model/lr/lr_worker.cc:25-71
+//   FMWorker::calculate_loss      src/model/fm/fm_worker.cc:159-202
+//   FMWorker::calculate_gradient  src/model/fm/fm_worker.cc:126-157
+//   FMWorker::update              src/model/fm/fm_worker.cc:204-245
+//   Base::sigmoid                 src/base/base.h:54-63
+//
+// This is a gather / segmented-reduce path: HBM- and L2-bound integer indexing plus a few
+// flops per byte.  No MFMA.  Forward = one 64-lane wavefront (or a 16-lane group for short
+// rows) per example: coalesced loads of the row's uidx[], gathers of w_u[uidx] from the
+// compact pulled-weight array (U floats, L2/Infinity-Cache resident), butterfly reduction
+// with __shfl_xor.  Gradient = one lane per unique key walking its occurrence list
+// (coalesced across neighbouring keys), gathers of loss[row] from an R-float array that
+// lives in L2; keys with long occurrence lists (power-law heads) take a wave-per-key path.
+// Sums are accumulated in fp64 so the result does not depend on lane assignment or
+// occurrence order (the reference's own order is unspecified: std::sort, lr_worker.cc:162),
+// then rounded to fp32 where the reference holds an fp32 value.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "xf_batch.h"
+#include "xf_common.h"
+#include "xf_device.h"
+
+namespace xf {
+const TableDev &table_dev(const xf_table *t);
+int table_dim(const xf_table *t);
+}  // namespace xf
+
+namespace {
+
+constexpr int kBlock = 256;
+inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+  return v;
+}
+
+// ------------------------------------------------------------------ LR forward (a5, a6)
+// loss[r] = sigmoid(sum_{j in row r} w_u[uidx[j]]) - label[r]
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_lr_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx,
+             const float *__restrict__ wu, const int32_t *__restrict__ labels, uint32_t R,
+             float *__restrict__ loss, float *__restrict__ pctr) {
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t ngroups = gridDim.x * (kBlock / G);
+  for (uint32_t r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < R; r += ngroups) {
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    double acc = 0.0;
+    uint32_t j = b + lane;
+    // 4 independent gathers in flight per lane
+    for (; j + 3 * G < e; j += 4 * G) {
+      const uint32_t i0 = uidx[j], i1 = uidx[j + G], i2 = uidx[j + 2 * G], i3 = uidx[j + 3 * G];
+      const float w0 = wu[i0], w1 = wu[i1], w2 = wu[i2], w3 = wu[i3];
+      acc += ((double)w0 + (double)w1) + ((double)w2 + (double)w3);
+    }
+    for (; j < e; j += G) acc += (double)wu[uidx[j]];
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+      const float p = xf::sigmoid_ref((float)acc);
+      if (pctr) pctr[r] = p;
+      loss[r] = p - (float)labels[r];  // lr_worker.cc:141
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LR gradient (a7)
+// g[u] = (sum_{j in seg u} loss[coo_row[j]]) / R   (divide in double: lr_worker.cc:117)
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
+          const float *__restrict__ loss, uint32_t U, uint32_t R, float *__restrict__ g) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += stride) {
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    if (e - b > XF_HEAVY_SEG) continue;  // wave-per-key path below
+    double acc = 0.0;
+    for (uint32_t j = b; j < e; ++j) acc += (double)loss[coo_row[j]];
+    g[u] = (float)((double)(float)acc / (1.0 * R));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
+                const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
+                const float *__restrict__ loss, uint32_t R, float *__restrict__ g) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  for (uint32_t h = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; h < H; h += nwaves) {
+    const uint32_t u = heavy[h];
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    double acc = 0.0;
+    for (uint32_t j = b + lane; j < e; j += 64) acc += (double)loss[coo_row[j]];
+    acc = group_sum<64>(acc);
+    if (lane == 0) g[u] = (float)((double)(float)acc / (1.0 * R));
+  }
+}
+
+// ------------------------------------------------------------------ FM forward (a11)
+// Reference form, fm_worker.cc:159-202: v_sum and v_pow_sum are SCALARS per row pooled over
+// all k factors; v_y = v_sum^2 - v_pow_sum (no 1/2); loss = sigmoid(wx + v_y) - label.
+// One wavefront per example; lane e walks the row's (nnz, factor) elements so every v_u
+// row is read as one contiguous k*4-byte segment.
+template <int K>
+__global__ void __launch_bounds__(kBlock)
+k_fm_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx,
+             const float *__restrict__ wu, const float *__restrict__ vu, int k_rt,
+             const int32_t *__restrict__ labels, uint32_t R, float *__restrict__ loss,
+             float *__restrict__ pctr, float *__restrict__ vsum_out) {
+#pragma clang fp contract(off)
+  const uint32_t k = K > 0 ? (uint32_t)K : (uint32_t)k_rt;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nwaves) {
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    const uint32_t nel = (e - b) * k;
+    double wx = 0.0, vs = 0.0, vp = 0.0;
+    for (uint32_t el = lane; el < nel; el += 64) {
+      const uint32_t jj = el / k, kk = el - jj * k;
+      const uint32_t ui = uidx[b + jj];
+      const float vv = vu[(size_t)ui * k + kk];
+      vs += (double)vv;
+      vp += (double)(vv * vv);  // fp32 product, as fm_worker.cc:187
+      if (kk == 0) wx += (double)wu[ui];
+    }
+    wx = group_sum<64>(wx);
+    vs = group_sum<64>(vs);
+    vp = group_sum<64>(vp);
+    if (lane == 0) {
+      const float vsf = (float)vs, vpf = (float)vp;
+      const float vy = vsf * vsf - vpf;                       // :194-195
+      const float p = xf::sigmoid_ref((float)wx + vy);        // :199
+      if (pctr) pctr[r] = p;
+      loss[r] = p - (float)labels[r];
+      vsum_out[r] = vsf;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ FM gradient (a12)
+// fm_worker.cc:126-157: for every factor kk (outer loop) and occurrence:
+//   gw[u]    += loss[sid]                        -> gw is k x the LR gradient (:140)
+//   gv[u,kk] += loss[sid] * (v_sum[sid] - v[u,kk])
+// then both / R.  One lane per (u, kk); neighbouring lanes share the occurrence list.
+__global__ void __launch_bounds__(kBlock)
+k_fm_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
+          const float *__restrict__ loss, const float *__restrict__ vsum,
+          const float *__restrict__ vu, uint32_t U, uint32_t R, int k,
+          float *__restrict__ gw, float *__restrict__ gv) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)U * k;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t el = (size_t)blockIdx.x * blockDim.x + threadIdx.x; el < total; el += stride) {
+    const uint32_t u = (uint32_t)(el / k);
+    const uint32_t kk = (uint32_t)(el - (size_t)u * k);
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    if (e - b > XF_HEAVY_SEG) continue;
+    const float v = vu[el];
+    double accw = 0.0, accv = 0.0;
+    for (uint32_t j = b; j < e; ++j) {
+      const uint32_t sid = coo_row[j];
+      const float l = loss[sid];
+      accw += (double)l;
+      accv += (double)(l * (vsum[sid] - v));
+    }
+    gv[el] = (float)((double)(float)accv / (1.0 * R));
+    if (kk == 0) gw[u] = (float)((double)(float)(accw * (double)k) / (1.0 * R));
+  }
+}
+
+// heavy keys: one block per key, wave w takes factors w, w+4, ...
+__global__ void __launch_bounds__(kBlock)
+k_fm_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
+                const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
+                const float *__restrict__ loss, const float *__restrict__ vsum,
+                const float *__restrict__ vu, uint32_t R, int k, float *__restrict__ gw,
+                float *__restrict__ gv) {
+#pragma clang fp contract(off)
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t h = blockIdx.x; h < H; h += gridDim.x) {
+    const uint32_t u = heavy[h];
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    for (uint32_t kk = wave; kk < (uint32_t)k; kk += kBlock / 64) {
+      const float v = vu[(size_t)u * k + kk];
+      double accw = 0.0, accv = 0.0;
+      for (uint32_t j = b + lane; j < e; j += 64) {
+        const uint32_t sid = coo_row[j];
+        const float l = loss[sid];
+        accw += (double)l;
+        accv += (double)(l * (vsum[sid] - v));
+      }
+      accw = group_sum<64>(accw);
+      accv = group_sum<64>(accv);
+      if (lane == 0) {
+        gv[(size_t)u * k + kk] = (float)((double)(float)accv / (1.0 * R));
+        if (kk == 0) gw[u] = (float)((double)(float)(accw * (double)k) / (1.0 * R));
+      }
+    }
+  }
+}
+
+inline int blocks_for_groups(uint32_t n_items, int items_per_block) {
+  size_t g = ((size_t)n_items + items_per_block - 1) / items_per_block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------ C entry points
+extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
+                                 float *d_pctr, void *stream) {
+  XF_REQUIRE(b && d_wu && d_loss, "xf_lr_forward_dev: null argument");
+  if (b->R == 0) return XF_OK;
+  const double avg = (double)b->NNZ / b->R;
+  if (avg <= 48.0) {  // short rows: four examples per wavefront
+    hipLaunchKernelGGL(k_lr_forward<16>, dim3(blocks_for_groups(b->R, kBlock / 16)),
+                       dim3(kBlock), 0, S(stream), b->rowptr, b->uidx, d_wu, b->labels, b->R,
+                       d_loss, d_pctr);
+  } else {
+    hipLaunchKernelGGL(k_lr_forward<64>, dim3(blocks_for_groups(b->R, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), b->rowptr, b->uidx, d_wu, b->labels, b->R,
+                       d_loss, d_pctr);
+  }
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float *d_g,
+                              void *stream) {
+  XF_REQUIRE(b && d_loss && d_g, "xf_lr_grad_dev: null argument");
+  if (b->U == 0) return XF_OK;
+  hipLaunchKernelGGL(k_lr_grad, dim3(blocks_for_groups(b->U, kBlock)), dim3(kBlock), 0,
+                     S(stream), b->segptr, b->coo_row, d_loss, b->U, b->R, d_g);
+  XF_HIP(hipGetLastError());
+  if (b->H) {
+    hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), b->heavy, b->H, b->segptr, b->coo_row,
+                       d_loss, b->R, d_g);
+    XF_HIP(hipGetLastError());
+  }
+  return XF_OK;
+}
+
+extern "C" int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu,
+                                 const float *d_vu, float *d_loss, float *d_pctr,
+                                 float *d_vsum, void *stream) {
+  XF_REQUIRE(b && d_wu && d_vu && d_loss && d_vsum && k >= 1, "xf_fm_forward_dev: bad argument");
+  if (b->R == 0) return XF_OK;
+  const dim3 g(blocks_for_groups(b->R, kBlock / 64)), blk(kBlock);
+#define XF_FM_FWD(KK)                                                                       \
+  hipLaunchKernelGGL(k_fm_forward<KK>, g, blk, 0, S(stream), b->rowptr, b->uidx, d_wu, d_vu, \
+                     k, b->labels, b->R, d_loss, d_pctr, d_vsum)
+  switch (k) {
+    case 8: XF_FM_FWD(8); break;
+    case 10: XF_FM_FWD(10); break;
+    case 16: XF_FM_FWD(16); break;
+    case 32: XF_FM_FWD(32); break;
+    case 64: XF_FM_FWD(64); break;
+    default: XF_FM_FWD(0); break;
+  }
+#undef XF_FM_FWD
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
+                              const float *d_vsum, const float *d_loss, float *d_gw,
+                              float *d_gv, void *stream) {
+  XF_REQUIRE(b && d_vu && d_vsum && d_loss && d_gw && d_gv && k >= 1,
+             "xf_fm_grad_dev: bad argument");
+  if (b->U == 0) return XF_OK;
+  const size_t total = (size_t)b->U * k;
+  size_t g = (total + kBlock - 1) / kBlock;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_fm_grad, dim3((int)g), dim3(kBlock), 0, S(stream), b->segptr, b->coo_row,
+                     d_loss, d_vsum, d_vu, b->U, b->R, k, d_gw, d_gv);
+  XF_HIP(hipGetLastError());
+  if (b->H) {
+    hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
+                       S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
+                       b->R, k, d_gw, d_gv);
+    XF_HIP(hipGetLastError());
+  }
+  return XF_OK;
+}
+
+// ---------------------------------------------------------------------------- workspace
+enum { kEvResolve = 0, kEvGather, kEvForward, kEvGrad, kEvUpdate, kEvCount };
+
+struct xf_workspace {
+  uint32_t *slots = nullptr, *slots2 = nullptr;
+  float *wu = nullptr, *g = nullptr, *vu = nullptr, *gv = nullptr;
+  float *loss = nullptr, *pctr = nullptr, *vsum = nullptr;
+  size_t capU = 0, capUK = 0, capR = 0;
+  uint32_t lastU = 0, lastR = 0;
+  // optional per-kernel HIP-event timing (same stream, inside the caller's timed region)
+  bool profiling = false;
+  hipEvent_t ev[kEvCount + 1] = {};
+  double ms_sum[kEvCount] = {};
+  long steps_timed = 0;
+  bool ev_pending = false;
+};
+
+static int ws_reserve(xf_workspace *ws, size_t U, size_t UK, size_t R) {
+  auto grow = [](void **p, size_t bytes) -> hipError_t {
+    if (*p) {
+      hipError_t e = hipFree(*p);
+      if (e != hipSuccess) return e;
+    }
+    return hipMalloc(p, bytes);
+  };
+  if (U > ws->capU) {
+    const size_t m = std::max<size_t>(U + U / 8, 1024);
+    XF_HIP(grow((void **)&ws->slots, m * 4));
+    XF_HIP(grow((void **)&ws->slots2, m * 4));
+    XF_HIP(grow((void **)&ws->wu, m * 4));
+    XF_HIP(grow((void **)&ws->g, m * 4));
+    ws->capU = m;
+  }
+  if (UK > ws->capUK) {
+    const size_t m = std::max<size_t>(UK + UK / 8, 1024);
+    XF_HIP(grow((void **)&ws->vu, m * 4));
+    XF_HIP(grow((void **)&ws->gv, m * 4));
+    ws->capUK = m;
+  }
+  if (R > ws->capR) {
+    const size_t m = std::max<size_t>(R + R / 8, 1024);
+    XF_HIP(grow((void **)&ws->loss, m * 4));
+    XF_HIP(grow((void **)&ws->pctr, m * 4));
+    XF_HIP(grow((void **)&ws->vsum, m * 4));
+    ws->capR = m;
+  }
+  return XF_OK;
+}
+
+extern "C" int xf_workspace_create(xf_workspace **out) {
+  XF_REQUIRE(out, "xf_workspace_create: null argument");
+  *out = new xf_workspace;
+  return XF_OK;
+}
+
+extern "C" int xf_workspace_destroy(xf_workspace *ws) {
+  if (!ws) return XF_OK;
+  void *ps[] = {ws->slots, ws->slots2, ws->wu, ws->g, ws->vu, ws->gv, ws->loss, ws->pctr, ws->vsum};
+  for (void *p : ps)
+    if (p) hipFree(p);
+  for (auto &e : ws->ev)
+    if (e) hipEventDestroy(e);
+  delete ws;
+  return XF_OK;
+}
+
+static int ws_collect(xf_workspace *ws) {  // fold the pending events into the sums
+  if (!ws->ev_pending) return XF_OK;
+  XF_HIP(hipEventSynchronize(ws->ev[kEvCount]));
+  for (int i = 0; i < kEvCount; ++i) {
+    float ms = 0.f;
+    XF_HIP(hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]));
+    ws->ms_sum[i] += ms;
+  }
+  ++ws->steps_timed;
+  ws->ev_pending = false;
+  return XF_OK;
+}
+
+extern "C" int xf_workspace_profile(xf_workspace *ws, int enable) {
+  XF_REQUIRE(ws, "xf_workspace_profile: null workspace");
+  if (enable && !ws->ev[0])
+    for (auto &e : ws->ev) XF_HIP(hipEventCreate(&e));
+  if (!enable) XF_TRY(ws_collect(ws));
+  ws->profiling = enable != 0;
+  if (enable) {
+    for (auto &m : ws->ms_sum) m = 0.0;
+    ws->steps_timed = 0;
+    ws->ev_pending = false;
+  }
+  return XF_OK;
+}
+
+// ms_sum[5] = resolve, gather, forward, gradient, update (summed over *steps steps)
+extern "C" int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long *steps) {
+  XF_REQUIRE(ws && ms_sum && steps, "xf_workspace_profile_read: null argument");
+  XF_TRY(ws_collect(ws));
+  for (int i = 0; i < kEvCount; ++i) ms_sum[i] = ws->ms_sum[i];
+  *steps = ws->steps_timed;
+  return XF_OK;
+}
+
+#define XF_MARK(i)                                                    \
+  do {                                                                \
+    if (ws->profiling) XF_HIP(hipEventRecord(ws->ev[i], S(stream)));  \
+  } while (0)
+
+// ---------------------------------------------------------------------------- fused steps
+extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream) {
+  XF_REQUIRE(w && b && ws, "xf_lr_step: null argument");
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_step: the w table must have dim 1");
+  XF_TRY(xf_batch_upload(b, stream));
+  XF_TRY(ws_reserve(ws, b->U, 0, b->R));
+  if (ws->profiling) XF_TRY(ws_collect(ws));
+  const xf_dev_batch &v = b->view;
+  ws->lastU = b->U;
+  ws->lastR = b->R;
+  XF_MARK(0);
+  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, stream));  // Pull: lr_worker.cc:170
+  XF_MARK(1);
+  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, stream));
+  XF_MARK(2);
+  XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, nullptr, stream));  // :172
+  XF_MARK(3);
+  XF_TRY(xf_lr_grad_dev(&v, ws->loss, ws->g, stream));               // :173
+  XF_MARK(4);
+  XF_TRY(xf_table_update_dev(w, ws->slots, v.U, ws->g, stream));     // Push: :175
+  XF_MARK(5);
+  if (ws->profiling) ws->ev_pending = true;
+  return XF_OK;
+}
+
+extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                          void *stream) {
+  XF_REQUIRE(w && vt && b && ws, "xf_fm_step: null argument");
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_fm_step: the w table must have dim 1");
+  const int k = xf::table_dim(vt);
+  XF_TRY(xf_batch_upload(b, stream));
+  XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
+  if (ws->profiling) XF_TRY(ws_collect(ws));
+  const xf_dev_batch &v = b->view;
+  ws->lastU = b->U;
+  ws->lastR = b->R;
+  // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself
+  XF_MARK(0);
+  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, stream));
+  XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, stream));
+  XF_MARK(1);
+  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, stream));
+  XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, stream));
+  XF_MARK(2);
+  XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));  // :237
+  XF_MARK(3);
+  XF_TRY(xf_fm_grad_dev(&v, k, ws->vu, ws->vsum, ws->loss, ws->g, ws->gv, stream));      // :238
+  XF_MARK(4);
+  XF_TRY(xf_table_update_dev(w, ws->slots, v.U, ws->g, stream));     // two Pushes: :241-242
+  XF_TRY(xf_table_update_dev(vt, ws->slots2, v.U, ws->gv, stream));
+  XF_MARK(5);
+  if (ws->profiling) ws->ev_pending = true;
+  return XF_OK;
+}
+
+// forward only: calculate_pctr (lr_worker.cc:25-71).  The pull inserts unseen keys, as the
+// reference's test-time Pull does (ftrl.h:56).
+extern "C" int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *pctr_out) {
+  XF_REQUIRE(w && b && ws && pctr_out, "xf_lr_predict: null argument");
+  XF_TRY(xf_batch_upload(b, nullptr));
+  XF_TRY(ws_reserve(ws, b->U, 0, b->R));
+  const xf_dev_batch &v = b->view;
+  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, nullptr));
+  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, nullptr));
+  XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, ws->pctr, nullptr));
+  if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
+  return xf_table_check(w, nullptr);
+}
+
+extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                             float *pctr_out) {
+  XF_REQUIRE(w && vt && b && ws && pctr_out, "xf_fm_predict: null argument");
+  const int k = xf::table_dim(vt);
+  XF_TRY(xf_batch_upload(b, nullptr));
+  XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
+  const xf_dev_batch &v = b->view;
+  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, nullptr));
+  XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, nullptr));
+  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, nullptr));
+  XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, nullptr));
+  XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, ws->pctr, ws->vsum, nullptr));
+  if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
+  XF_TRY(xf_table_check(w, nullptr));
+  return xf_table_check(vt, nullptr);
+}
+
+// parity hook: intermediates of the last step
+extern "C" int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
+                                  size_t R) {
+  XF_REQUIRE(ws, "xf_workspace_fetch: null workspace");
+  XF_REQUIRE(U <= ws->lastU && R <= ws->lastR, "xf_workspace_fetch: sizes exceed last step");
+  XF_HIP(hipDeviceSynchronize());
+  if (wu && U) XF_HIP(hipMemcpy(wu, ws->wu, U * 4, hipMemcpyDeviceToHost));
+  if (loss && R) XF_HIP(hipMemcpy(loss, ws->loss, R * 4, hipMemcpyDeviceToHost));
+  if (g && U) XF_HIP(hipMemcpy(g, ws->g, U * 4, hipMemcpyDeviceToHost));
+  return XF_OK;
+}
+
+extern "C" int xf_stream_sync(void *stream) {
+  XF_HIP(hipStreamSynchronize(S(stream)));
+  return XF_OK;
+}

@@ -1,0 +1,541 @@
+// xf_table.hip — the feature-key-range-sharded parameter table of one GPU and its
+// resolve / gather / update kernels (gfx950).
+//
+// Replaces: ps::KVWorker<float>::Pull/Push/Wait (src/model/lr/lr_worker.cc:170,175;
+// src/model/fm/fm_worker.cc:228-242), the server handlers FTRL::KVServerFTRLHandle_{w,v}
+// (src/optimizer/ftrl.h:38-152) and SGD::KVServerSGDHandle_{w,v} (src/optimizer/sgd.h:30-109)
+// and their std::unordered_map stores (ftrl.h:84, sgd.h:62).
+//
+// Layout in HBM (per shard, `cap` slots + 1 spare slot for the reserved key value):
+//   keys[cap+1] u64      exact keys, EMPTY = 0xFFFF'FFFF'FFFF'FFFF
+//   w[(cap+1)*dim] f32   weights (row-major [slot][dim])
+//   n,z[(cap+1)*dim] f32 FTRL accumulators (FTRL tables only)
+// The slot of a key is found by linear probing from an ORDER-PRESERVING home position
+//   home = floor((key - range_lo) * cap / range_span)
+// Keys are already uniform 64-bit hashes (io.h:53), so a linear map spreads them as well
+// as any hash — and it keeps the table (almost) sorted by key.  Pull/Push key lists are
+// sorted (the ps-lite contract), so lane i and lane i+1 of a wave probe neighbouring
+// slots: the random gather/scatter of a hash table becomes a monotone sweep over keys[],
+// w[], n[], z[] that the memory system coalesces.  Same idea as ps-lite's key-range
+// sharding across servers, continued inside the GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "xf_common.h"
+#include "xf_device.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(size_t n) {
+  size_t g = (n + kBlock - 1) / kBlock;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------- kernels
+
+// key -> slot with insert-on-miss: `store[key]` of ftrl.h:56 / sgd.h:46, first-touch init
+// of ftrl.h:112-121 / sgd.h:67-72.  One key per lane; with a sorted key list the probes
+// of a wave land in one neighbourhood of keys[].
+__global__ void __launch_bounds__(kBlock)
+k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
+          uint32_t *__restrict__ slots) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t key = keys[i];
+    bool inserted = false;
+    uint32_t slot;
+    if (key == xf::kEmptyKey) {  // reserved value lives in the spare slot
+      slot = (uint32_t)T.cap;
+      inserted = atomicExch(&T.stat->spare_used, 1u) == 0u;
+      if (inserted) T.keys[T.cap] = key;
+    } else {
+      if (!xf::owns(T, key)) {
+        atomicOr(&T.stat->err, xf::kErrForeignKey);
+        slots[i] = (uint32_t)T.cap;
+        continue;
+      }
+      uint64_t pos = xf::home_of(T, key);
+      uint64_t probes = 0;
+      slot = (uint32_t)T.cap;
+      while (probes < T.cap) {
+        uint64_t cur = T.keys[pos];
+        if (cur == xf::kEmptyKey) {
+          // claim; the atomic is served at the coherent point, so a stale EMPTY read
+          // (other XCD inserted meanwhile) is corrected by the returned value
+          cur = atomicCAS((unsigned long long *)&T.keys[pos], xf::kEmptyKey, key);
+          if (cur == xf::kEmptyKey) {
+            inserted = true;
+            slot = (uint32_t)pos;
+            break;
+          }
+        }
+        if (cur == key) {
+          slot = (uint32_t)pos;
+          break;
+        }
+        ++probes;
+        if (++pos == T.cap) pos = 0;
+      }
+      if (slot == (uint32_t)T.cap) atomicOr(&T.stat->err, xf::kErrFull);
+    }
+    if (inserted) {
+      atomicAdd(&T.stat->count, 1ull);
+      if (T.init_kind != XF_INIT_ZERO) {  // memory is pre-zeroed for XF_INIT_ZERO
+        float *row = T.w + (size_t)slot * T.dim;
+        for (int j = 0; j < T.dim; ++j)
+          row[j] = T.init_kind == XF_INIT_CONST ? T.init_const
+                                                : xf::hashnorm(T.seed, key, (uint32_t)j);
+      }
+    }
+    slots[i] = slot;
+  }
+}
+
+// Pull payload: vals[i][j] = w[slot[i]][j] (ftrl.h:75-77).  One element per lane; rows are
+// contiguous so a wave reads 64/dim rows as whole segments.
+__global__ void __launch_bounds__(kBlock)
+k_gather(const float *__restrict__ w, int dim, const uint32_t *__restrict__ slots, size_t n,
+         float *__restrict__ vals) {
+  const size_t total = n * (size_t)dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = dim == 1 ? e : e / (size_t)dim;
+    const size_t j = e - i * (size_t)dim;
+    vals[e] = w[(size_t)slots[i] * dim + j];
+  }
+}
+
+// Push: one optimizer step per (slot, j).  FTRL: ftrl.h:59-74 / :126-141.  SGD: sgd.h:52,96.
+template <int OPT>
+__global__ void __launch_bounds__(kBlock)
+k_update(xf::TableDev T, const uint32_t *__restrict__ slots, size_t n,
+         const float *__restrict__ grads) {
+  const size_t total = n * (size_t)T.dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = T.dim == 1 ? e : e / (size_t)T.dim;
+    const size_t j = e - i * (size_t)T.dim;
+    const size_t o = (size_t)slots[i] * T.dim + j;
+    const float g = grads[e];
+    if (OPT == XF_OPT_FTRL) {
+      float w = T.w[o], nn = T.n[o], z = T.z[o];
+      xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+      T.w[o] = w;
+      T.n[o] = nn;
+      T.z[o] = z;
+    } else {
+      T.w[o] = xf::sgd_step(T.lr, g, T.w[o]);
+    }
+  }
+}
+
+// import: scatter host rows into their slots
+__global__ void __launch_bounds__(kBlock)
+k_scatter_rows(float *__restrict__ dst, int dim, const uint32_t *__restrict__ slots,
+               size_t n, const float *__restrict__ src) {
+  const size_t total = n * (size_t)dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = e / (size_t)dim, j = e - i * (size_t)dim;
+    dst[(size_t)slots[i] * dim + j] = src[e];
+  }
+}
+
+// export: append every occupied slot (arbitrary order; host sorts by key)
+__global__ void __launch_bounds__(kBlock)
+k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
+                uint32_t *__restrict__ out_slots, unsigned long long *__restrict__ counter,
+                size_t out_cap) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride) {
+    const uint64_t key = T.keys[s];
+    const bool occ = s < T.cap ? key != xf::kEmptyKey : T.stat->spare_used != 0u;
+    if (occ) {
+      const unsigned long long p = atomicAdd(counter, 1ull);
+      if (p < out_cap) {
+        out_keys[p] = key;
+        out_slots[p] = (uint32_t)s;
+      }
+    }
+  }
+}
+
+__global__ void k_fill_u64(uint64_t *p, size_t n, uint64_t v) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// grow: re-insert every occupied slot of `O` into the (empty, larger) table `T`
+__global__ void __launch_bounds__(kBlock)
+k_rehash(xf::TableDev O, xf::TableDev T) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= O.cap; s += stride) {
+    const uint64_t key = O.keys[s];
+    uint64_t dst;
+    if (s == O.cap) {
+      if (O.stat->spare_used == 0u) continue;
+      dst = T.cap;
+      T.keys[T.cap] = key;
+    } else {
+      if (key == xf::kEmptyKey) continue;
+      uint64_t pos = xf::home_of(T, key);
+      while (atomicCAS((unsigned long long *)&T.keys[pos], xf::kEmptyKey, key) !=
+             xf::kEmptyKey)
+        if (++pos == T.cap) pos = 0;
+      dst = pos;
+    }
+    for (int j = 0; j < T.dim; ++j) {
+      T.w[dst * T.dim + j] = O.w[s * O.dim + j];
+      if (T.n) {
+        T.n[dst * T.dim + j] = O.n[s * O.dim + j];
+        T.z[dst * T.dim + j] = O.z[s * O.dim + j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ table
+struct xf_table {
+  xf_table_config cfg;
+  int dev = 0;
+  xf::TableDev T{};
+  // scratch for the host-pointer API
+  uint64_t *s_keys = nullptr;
+  uint32_t *s_slots = nullptr;
+  float *s_vals = nullptr;
+  size_t s_n = 0, s_vals_n = 0;
+};
+
+static void refresh_hyper(xf_table *t) {
+  t->T.alpha = t->cfg.alpha;
+  t->T.beta = t->cfg.beta;
+  t->T.lambda1 = t->cfg.lambda1;
+  t->T.lambda2 = t->cfg.lambda2;
+  t->T.lr = t->cfg.lr;
+}
+
+static int ensure_scratch(xf_table *t, size_t n) {
+  if (n > t->s_n) {
+    if (t->s_keys) XF_HIP(hipFree(t->s_keys));
+    if (t->s_slots) XF_HIP(hipFree(t->s_slots));
+    size_t m = std::max<size_t>(n, 1024);
+    XF_HIP(hipMalloc((void **)&t->s_keys, m * sizeof(uint64_t)));
+    XF_HIP(hipMalloc((void **)&t->s_slots, m * sizeof(uint32_t)));
+    t->s_n = m;
+  }
+  const size_t need = n * (size_t)t->cfg.dim;
+  if (need > t->s_vals_n) {
+    if (t->s_vals) XF_HIP(hipFree(t->s_vals));
+    size_t m = std::max<size_t>(need, 1024);
+    XF_HIP(hipMalloc((void **)&t->s_vals, m * sizeof(float)));
+    t->s_vals_n = m;
+  }
+  return XF_OK;
+}
+
+static int alloc_arrays(xf::TableDev &T, bool ftrl) {
+  const size_t slots = (size_t)T.cap + 1;
+  const size_t elems = slots * (size_t)T.dim;
+  T.n = T.z = nullptr;
+  XF_HIP(hipMalloc((void **)&T.keys, slots * sizeof(uint64_t)));
+  XF_HIP(hipMalloc((void **)&T.w, elems * sizeof(float)));
+  XF_HIP(hipMemset(T.w, 0, elems * sizeof(float)));
+  if (ftrl) {
+    XF_HIP(hipMalloc((void **)&T.n, elems * sizeof(float)));
+    XF_HIP(hipMalloc((void **)&T.z, elems * sizeof(float)));
+    XF_HIP(hipMemset(T.n, 0, elems * sizeof(float)));
+    XF_HIP(hipMemset(T.z, 0, elems * sizeof(float)));
+  }
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(slots)), dim3(kBlock), 0, 0, T.keys, slots,
+                     xf::kEmptyKey);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipDeviceSynchronize());
+  return XF_OK;
+}
+
+static void set_geometry(xf::TableDev &T, uint64_t cap, uint32_t shard, uint32_t nshards) {
+  const xf::ShardRange r = xf::shard_range(shard, nshards);
+  T.cap = cap;
+  T.lo = r.lo;
+  T.span = r.span;
+  T.last_shard = shard == nshards - 1;
+  T.single = nshards == 1;
+  // home = mulhi64(key - lo, mult), mult = floor(cap * 2^64 / span)
+  T.mult = (uint64_t)((((unsigned __int128)cap) << 64) / r.span);
+}
+
+extern "C" void xf_table_config_default(xf_table_config *c) {
+  c->opt_kind = XF_OPT_FTRL;
+  c->dim = 1;
+  c->init_kind = XF_INIT_ZERO;
+  c->init_const = 0.0f;
+  c->seed = 0;
+  c->alpha = 5e-2f;  // ftrl.h:17-20
+  c->beta = 1.0f;
+  c->lambda1 = 5e-5f;
+  c->lambda2 = 10.0f;
+  c->lr = 0.001f;  // sgd.h:16
+  c->capacity = 1u << 20;
+  c->shard = 0;
+  c->nshards = 1;
+}
+
+extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
+  XF_REQUIRE(out && cfg, "xf_table_create: null argument");
+  XF_REQUIRE(cfg->dim >= 1 && cfg->dim <= 4096, "xf_table_create: dim %d", cfg->dim);
+  XF_REQUIRE(cfg->opt_kind == XF_OPT_FTRL || cfg->opt_kind == XF_OPT_SGD,
+             "xf_table_create: opt_kind %d", cfg->opt_kind);
+  XF_REQUIRE(cfg->capacity >= 16 && cfg->capacity < 0xFFFFFFF0ull,
+             "xf_table_create: capacity %llu out of range",
+             (unsigned long long)cfg->capacity);
+  XF_REQUIRE(cfg->nshards >= 1 && cfg->shard < cfg->nshards, "xf_table_create: shard %u/%u",
+             cfg->shard, cfg->nshards);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return xf::set_error(XF_ENOGPU, "xf_table_create: no HIP device (the table lives in HBM)");
+  xf_table *t = new xf_table;
+  t->cfg = *cfg;
+  XF_HIP(hipGetDevice(&t->dev));
+  xf::TableDev &T = t->T;
+  T.dim = cfg->dim;
+  T.init_kind = cfg->init_kind;
+  T.init_const = cfg->init_const;
+  T.seed = cfg->seed;
+  set_geometry(T, cfg->capacity, cfg->shard, cfg->nshards);
+  refresh_hyper(t);
+  XF_TRY(alloc_arrays(T, cfg->opt_kind == XF_OPT_FTRL));
+  XF_HIP(hipMalloc((void **)&T.stat, sizeof(xf::TableStat)));
+  XF_HIP(hipMemset(T.stat, 0, sizeof(xf::TableStat)));
+  *out = t;
+  return XF_OK;
+}
+
+extern "C" int xf_table_destroy(xf_table *t) {
+  if (!t) return XF_OK;
+  hipFree(t->T.keys);
+  hipFree(t->T.w);
+  if (t->T.n) hipFree(t->T.n);
+  if (t->T.z) hipFree(t->T.z);
+  hipFree(t->T.stat);
+  if (t->s_keys) hipFree(t->s_keys);
+  if (t->s_slots) hipFree(t->s_slots);
+  if (t->s_vals) hipFree(t->s_vals);
+  delete t;
+  return XF_OK;
+}
+
+extern "C" int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2,
+                                  float lr) {
+  XF_REQUIRE(t, "xf_table_set_hyper: null table");
+  t->cfg.alpha = alpha;
+  t->cfg.beta = beta;
+  t->cfg.lambda1 = l1;
+  t->cfg.lambda2 = l2;
+  t->cfg.lr = lr;
+  refresh_hyper(t);
+  return XF_OK;
+}
+
+static int read_stat(xf_table *t, xf::TableStat *st) {
+  XF_HIP(hipMemcpy(st, t->T.stat, sizeof(*st), hipMemcpyDeviceToHost));
+  return XF_OK;
+}
+
+extern "C" int xf_table_size(xf_table *t, uint64_t *nkeys) {
+  XF_REQUIRE(t && nkeys, "xf_table_size: null argument");
+  XF_HIP(hipDeviceSynchronize());
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  *nkeys = st.count + (st.spare_used ? 1 : 0);
+  return XF_OK;
+}
+
+extern "C" int xf_table_capacity(xf_table *t, uint64_t *slots) {
+  XF_REQUIRE(t && slots, "xf_table_capacity: null argument");
+  *slots = t->T.cap;
+  return XF_OK;
+}
+
+extern "C" int xf_table_check(xf_table *t, void *stream) {
+  XF_REQUIRE(t, "xf_table_check: null table");
+  XF_HIP(hipStreamSynchronize(S(stream)));
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  if (st.err & xf::kErrFull)
+    return xf::set_error(XF_EFULL, "table full: %llu keys in %llu slots (shard %u/%u)",
+                         (unsigned long long)st.count, (unsigned long long)t->T.cap,
+                         t->cfg.shard, t->cfg.nshards);
+  if (st.err & xf::kErrForeignKey)
+    return xf::set_error(XF_EINVAL, "a key outside shard %u/%u's range was sent to it",
+                         t->cfg.shard, t->cfg.nshards);
+  return XF_OK;
+}
+
+extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t n,
+                                    uint32_t *d_slots, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys && d_slots)), "xf_table_resolve_dev: null argument");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T, d_keys,
+                     n, d_slots);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_table_gather_dev(xf_table *t, const uint32_t *d_slots, size_t n,
+                                   float *d_vals, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_slots && d_vals)), "xf_table_gather_dev: null argument");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, S(stream),
+                     t->T.w, t->T.dim, d_slots, n, d_vals);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_table_update_dev(xf_table *t, const uint32_t *d_slots, size_t n,
+                                   const float *d_grads, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_slots && d_grads)), "xf_table_update_dev: null argument");
+  if (n == 0) return XF_OK;
+  const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
+  if (t->cfg.opt_kind == XF_OPT_FTRL)
+    hipLaunchKernelGGL(k_update<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_slots, n, d_grads);
+  else
+    hipLaunchKernelGGL(k_update<XF_OPT_SGD>, g, b, 0, S(stream), t->T, d_slots, n, d_grads);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+
+// Re-house the table in `new_capacity` slots (keys and state preserved).  Slots change,
+// so slot arrays from earlier resolve calls are invalid afterwards.
+extern "C" int xf_table_reserve(xf_table *t, uint64_t new_capacity) {
+  XF_REQUIRE(t, "xf_table_reserve: null table");
+  if (new_capacity <= t->T.cap) return XF_OK;
+  XF_REQUIRE(new_capacity < 0xFFFFFFF0ull, "xf_table_reserve: capacity out of range");
+  XF_HIP(hipDeviceSynchronize());
+  xf::TableDev N = t->T;
+  set_geometry(N, new_capacity, t->cfg.shard, t->cfg.nshards);
+  XF_TRY(alloc_arrays(N, t->cfg.opt_kind == XF_OPT_FTRL));
+  hipLaunchKernelGGL(k_rehash, dim3(grid_for((size_t)t->T.cap + 1)), dim3(kBlock), 0, 0, t->T, N);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipDeviceSynchronize());
+  hipFree(t->T.keys);
+  hipFree(t->T.w);
+  if (t->T.n) hipFree(t->T.n);
+  if (t->T.z) hipFree(t->T.z);
+  t->T = N;
+  t->cfg.capacity = new_capacity;
+  return XF_OK;
+}
+
+// ---- ps-lite-shaped host API: Pull / Push followed by Wait ---------------------------
+extern "C" int xf_table_pull(xf_table *t, const uint64_t *keys, size_t n, float *vals) {
+  XF_REQUIRE(t && (n == 0 || (keys && vals)), "xf_table_pull: null argument");
+  if (n == 0) return XF_OK;
+  XF_TRY(ensure_scratch(t, n));
+  XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
+  XF_TRY(xf_table_gather_dev(t, t->s_slots, n, t->s_vals, nullptr));
+  XF_HIP(hipMemcpy(vals, t->s_vals, n * t->T.dim * sizeof(float), hipMemcpyDeviceToHost));
+  return xf_table_check(t, nullptr);
+}
+
+extern "C" int xf_table_push(xf_table *t, const uint64_t *keys, size_t n, const float *grads) {
+  XF_REQUIRE(t && (n == 0 || (keys && grads)), "xf_table_push: null argument");
+  if (n == 0) return XF_OK;
+  XF_TRY(ensure_scratch(t, n));
+  XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  XF_HIP(hipMemcpy(t->s_vals, grads, n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
+  XF_TRY(xf_table_update_dev(t, t->s_slots, n, t->s_vals, nullptr));
+  return xf_table_check(t, nullptr);
+}
+
+// ---- state dump / load ----------------------------------------------------------------
+extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_, float *z_,
+                               size_t cap_entries, size_t *n_out) {
+  XF_REQUIRE(t && n_out, "xf_table_export: null argument");
+  uint64_t nk = 0;
+  XF_TRY(xf_table_size(t, &nk));
+  *n_out = (size_t)nk;
+  if (!keys) return XF_OK;  // size query
+  XF_REQUIRE(cap_entries >= nk, "xf_table_export: %zu entries offered, %llu needed",
+             cap_entries, (unsigned long long)nk);
+  if (nk == 0) return XF_OK;
+  const int dim = t->T.dim;
+  uint64_t *d_keys = nullptr;
+  uint32_t *d_slots = nullptr;
+  unsigned long long *d_cnt = nullptr;
+  float *d_rows = nullptr;
+  XF_HIP(hipMalloc((void **)&d_keys, nk * sizeof(uint64_t)));
+  XF_HIP(hipMalloc((void **)&d_slots, nk * sizeof(uint32_t)));
+  XF_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
+  XF_HIP(hipMalloc((void **)&d_rows, nk * dim * sizeof(float)));
+  XF_HIP(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_list_occupied, dim3(grid_for((size_t)t->T.cap + 1)), dim3(kBlock), 0, 0,
+                     t->T, d_keys, d_slots, d_cnt, (size_t)nk);
+  XF_HIP(hipGetLastError());
+  std::vector<uint64_t> hk(nk);
+  XF_HIP(hipMemcpy(hk.data(), d_keys, nk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  std::vector<size_t> order(nk);
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
+  for (size_t i = 0; i < nk; ++i) keys[i] = hk[order[i]];
+  std::vector<float> rows(nk * dim);
+  float *srcs[3] = {t->T.w, t->T.n, t->T.z};
+  float *dsts[3] = {w, n_, z_};
+  for (int a = 0; a < 3; ++a) {
+    if (!dsts[a]) continue;
+    if (!srcs[a]) {  // SGD tables have no n/z: report zeros
+      std::fill(dsts[a], dsts[a] + nk * dim, 0.0f);
+      continue;
+    }
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(nk * dim)), dim3(kBlock), 0, 0, srcs[a], dim,
+                       d_slots, (size_t)nk, d_rows);
+    XF_HIP(hipGetLastError());
+    XF_HIP(hipMemcpy(rows.data(), d_rows, nk * dim * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nk; ++i)
+      std::copy(rows.begin() + order[i] * dim, rows.begin() + (order[i] + 1) * dim,
+                dsts[a] + i * dim);
+  }
+  hipFree(d_keys);
+  hipFree(d_slots);
+  hipFree(d_cnt);
+  hipFree(d_rows);
+  return XF_OK;
+}
+
+extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, const float *w,
+                               const float *n_, const float *z_) {
+  XF_REQUIRE(t && (n == 0 || keys), "xf_table_import: null argument");
+  if (n == 0) return XF_OK;
+  XF_TRY(ensure_scratch(t, n));
+  XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
+  const float *srcs[3] = {w, n_, z_};
+  float *dsts[3] = {t->T.w, t->T.n, t->T.z};
+  for (int a = 0; a < 3; ++a) {
+    if (!srcs[a] || !dsts[a]) continue;
+    XF_HIP(hipMemcpy(t->s_vals, srcs[a], n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, 0,
+                       dsts[a], t->T.dim, t->s_slots, n, t->s_vals);
+    XF_HIP(hipGetLastError());
+  }
+  return xf_table_check(t, nullptr);
+}
+
+// used by xf_model.hip
+namespace xf {
+const TableDev &table_dev(const xf_table *t) { return t->T; }
+int table_dim(const xf_table *t) { return t->T.dim; }
+}  // namespace xf

@@ -1,0 +1,326 @@
+// xf_worker.cc — LRWorker / FMWorker and the XFCreate / XFStartTrain C API.
+//
+// Mirrors the reference's worker surface (same public members and call order):
+//   xflow::LRWorker  src/model/lr/lr_worker.{h,cc}  (ctor(train,test), epochs, train(),
+//                    batch_training(), update(), predict(), calculate_pctr())
+//   xflow::FMWorker  src/model/fm/fm_worker.{h,cc}
+//   xflow::Server    src/model/server.h:22-31        (which optimizer serves w and v)
+//   XFCreate/XFStartTrain  src/c_api/c_api.{h,cc}
+// but every Pull / Push / loss / gradient runs on the GPU through the extern "C" shim
+// (xf_table_*, xf_lr_step, xf_fm_step).  What stays on the host is what north_star keeps
+// there: the libsvm-format block reader and the per-block key build.
+#include "xf_worker.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <fstream>
+#include <iostream>
+
+namespace xflow_amd {
+
+static double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+Worker::Worker(int model, const char *train_file, const char *test_file)
+    : model_(model), train_file_path(train_file ? train_file : ""),
+      test_file_path(test_file ? test_file : "") {}
+
+Worker::~Worker() {
+  for (xf_batch *b : cache_) xf_batch_free(b);
+  if (ws_) xf_workspace_destroy(ws_);
+  if (table_w_) xf_table_destroy(table_w_);
+  if (table_v_) xf_table_destroy(table_v_);
+}
+
+// xflow::Server (server.h:22-31): app 0 serves w, app 1 serves v; FTRL by default, the
+// SGD handlers are the commented-out alternative (server.h:25,29).
+int Worker::create_tables() {
+  if (table_w_) return XF_OK;
+  xf_table_config c;
+  xf_table_config_default(&c);
+  c.opt_kind = optimizer;
+  c.alpha = alpha;
+  c.beta = beta;
+  c.lambda1 = lambda1;
+  c.lambda2 = lambda2;
+  c.lr = learning_rate;
+  c.capacity = capacity;
+  c.dim = 1;
+  c.init_kind = XF_INIT_ZERO;
+  XF_TRY(xf_table_create(&table_w_, &c));
+  if (model_ == 1) {
+    c.dim = v_dim_;
+    if (optimizer == XF_OPT_FTRL) {  // ftrl.h:114-120
+      c.init_kind = XF_INIT_HASHNORM;
+      c.seed = seed;
+    } else {  // sgd.h:67-72
+      c.init_kind = XF_INIT_CONST;
+      c.init_const = 0.001f;
+    }
+    XF_TRY(xf_table_create(&table_v_, &c));
+  }
+  XF_TRY(xf_workspace_create(&ws_));
+  return XF_OK;
+}
+
+int Worker::grow_if_needed() {
+  xf_table *ts[2] = {table_w_, table_v_};
+  for (xf_table *t : ts) {
+    if (!t) continue;
+    uint64_t n = 0, cap = 0;
+    XF_TRY(xf_table_size(t, &n));
+    XF_TRY(xf_table_capacity(t, &cap));
+    if (n * 10 > cap * 6) XF_TRY(xf_table_reserve(t, cap * 2));  // keep load <= 0.6
+  }
+  return XF_OK;
+}
+
+// LRWorker::update / FMWorker::update (lr_worker.cc:145-177, fm_worker.cc:204-245)
+int Worker::update(xf_batch *b) {
+  if (model_ == 0) XF_TRY(xf_lr_step(table_w_, b, ws_, nullptr));
+  else
+    XF_TRY(xf_fm_step(table_w_, table_v_, b, ws_, nullptr));
+  return XF_OK;
+}
+
+// batch_training (lr_worker.cc:179-205, fm_worker.cc:247-275)
+int Worker::batch_training() {
+  {  // init push of key 0 with a zero gradient (lr_worker.cc:180-182, fm_worker.cc:248-252)
+    const uint64_t key0 = 0;
+    const float zero = 0.0f;
+    XF_TRY(xf_table_push(table_w_, &key0, 1, &zero));
+    if (model_ == 1) {
+      std::vector<float> zv(v_dim_, 0.0f);
+      XF_TRY(xf_table_push(table_v_, &key0, 1, zv.data()));
+    }
+  }
+  const double t0 = now_s();
+  rows_trained_ = 0;
+  bool cached = false;
+  for (int epoch = 0; epoch < epochs; ++epoch) {
+    if (cached) {
+      // The compiled batches depend only on the file, so later epochs replay them from
+      // HBM instead of re-reading and re-sorting the text (the reference re-opens and
+      // re-parses per epoch, lr_worker.cc:184).
+      for (xf_batch *b : cache_) {
+        XF_TRY(update(b));
+        uint32_t R = 0;
+        xf_batch_dims(b, &R, nullptr, nullptr, nullptr);
+        rows_trained_ += R;
+      }
+      XF_TRY(xf_table_check(table_w_, nullptr));
+      XF_TRY(grow_if_needed());
+    } else {
+      xf_reader *rd = nullptr;
+      XF_TRY(xf_reader_open(&rd, train_data_path, (size_t)block_size << 20));
+      while (true) {
+        size_t rows = 0, nnz = 0;
+        const uint64_t *rowptr, *keys;
+        const int32_t *fgid, *labels;
+        int rc = xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels);
+        if (rc != XF_OK) {
+          xf_reader_close(rd);
+          return rc;
+        }
+        if (rows == 0) break;
+        const size_t thread_size = rows / core_num;  // remainder dropped, lr_worker.cc:190
+        for (int i = 0; i < core_num; ++i) {
+          const size_t start = i * thread_size, end = (i + 1) * thread_size;
+          if (end == start) continue;
+          xf_batch *b = nullptr;
+          XF_TRY(xf_batch_compile(&b, rowptr, keys, labels, start, end));
+          rc = update(b);
+          if (rc == XF_OK) rc = xf_table_check(table_w_, nullptr);
+          if (rc == XF_OK && table_v_) rc = xf_table_check(table_v_, nullptr);
+          if (rc != XF_OK) {
+            xf_batch_free(b);
+            xf_reader_close(rd);
+            return rc;
+          }
+          rows_trained_ += (long)(end - start);
+          if (cache_batches) cache_.push_back(b);
+          else
+            xf_batch_free(b);
+          XF_TRY(grow_if_needed());
+        }
+      }
+      xf_reader_close(rd);
+      cached = cache_batches != 0;
+    }
+    if ((epoch + 1) % 30 == 0) std::cout << "epoch : " << epoch << std::endl;  // :202
+  }
+  XF_TRY(xf_stream_sync(nullptr));
+  train_seconds_ = now_s() - t0;
+  return XF_OK;
+}
+
+// predict + calculate_pctr (lr_worker.cc:25-98, fm_worker.cc:25-124)
+int Worker::predict(int rank, int block) {
+  char name[1200];
+  if (pred_path.empty()) snprintf(name, sizeof(name), "pred_%d_%d.txt", rank, block);
+  else
+    snprintf(name, sizeof(name), "%s", pred_path.c_str());
+  std::ofstream md(name);
+  if (!md.is_open()) std::cout << "open pred file failure!" << std::endl;
+  snprintf(test_data_path, sizeof(test_data_path), "%s-%05d", test_file_path.c_str(), rank);
+  // 4 MiB blocks for LR (lr_worker.cc:80), 2 MiB for FM (fm_worker.cc:106)
+  const size_t cap = model_ == 0 ? ((size_t)4 << 20) : ((size_t)2 << 20);
+  xf_reader *rd = nullptr;
+  XF_TRY(xf_reader_open(&rd, test_data_path, cap));
+  std::vector<int32_t> all_labels;
+  std::vector<float> all_pctr, pctr;
+  while (true) {
+    size_t rows = 0, nnz = 0;
+    const uint64_t *rowptr, *keys;
+    const int32_t *fgid, *labels;
+    int rc = xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels);
+    if (rc != XF_OK) {
+      xf_reader_close(rd);
+      return rc;
+    }
+    if (rows == 0) break;
+    const size_t thread_size = rows / core_num;
+    for (int i = 0; i < core_num; ++i) {
+      const size_t start = i * thread_size, end = (i + 1) * thread_size;
+      if (end == start) continue;
+      xf_batch *b = nullptr;
+      XF_TRY(xf_batch_compile(&b, rowptr, keys, labels, start, end));
+      pctr.resize(end - start);
+      rc = model_ == 0 ? xf_lr_predict(table_w_, b, ws_, pctr.data())
+                       : xf_fm_predict(table_w_, table_v_, b, ws_, pctr.data());
+      xf_batch_free(b);
+      if (rc != XF_OK) {
+        xf_reader_close(rd);
+        return rc;
+      }
+      for (size_t r = 0; r < end - start; ++r) {
+        const int label = labels[start + r];
+        all_labels.push_back(label);
+        all_pctr.push_back(pctr[r]);
+        md << pctr[r] << "\t" << 1 - label << "\t" << label << std::endl;  // :67
+      }
+      XF_TRY(grow_if_needed());
+    }
+  }
+  xf_reader_close(rd);
+  md.close();
+  // Base::calculate_auc (base.h:84-110) and its stdout line
+  XF_TRY(xf_auc_logloss(all_labels.data(), all_pctr.data(), all_labels.size(), &logloss_acc_,
+                        &auc_, &tp_, &fp_, &logloss_nat_));
+  std::cout << "logloss: " << logloss_acc_ << "\t";
+  if (isnan(auc_)) std::cout << "tp_n = " << tp_ << std::endl;
+  else
+    std::cout << "auc = " << auc_ << "\ttp = " << tp_ << " fp = " << fp_ << std::endl;
+  return XF_OK;
+}
+
+// train (lr_worker.cc:207-217, fm_worker.cc:277-287)
+int Worker::train() {
+  XF_TRY(create_tables());
+  std::cout << "my rank is = " << rank << std::endl;
+  snprintf(train_data_path, sizeof(train_data_path), "%s-%05d", train_file_path.c_str(), rank);
+  XF_TRY(batch_training());
+  if (rank == 0) {
+    std::cout << (model_ == 0 ? "LR AUC: " : "FM AUC: ") << std::endl;
+    XF_TRY(predict(rank, 0));
+  }
+  std::cout << "train end......" << std::endl;
+  return XF_OK;
+}
+
+int Worker::set_param(const char *name, const char *value) {
+  XF_REQUIRE(name && value, "XFSetParam: null argument");
+  const std::string n = name;
+  if (n == "model") {
+    XF_REQUIRE(!table_w_, "XFSetParam: model cannot change after training started");
+    model_ = atoi(value);
+    XF_REQUIRE(model_ == 0 || model_ == 1, "XFSetParam: model must be 0 (LR) or 1 (FM)");
+  } else if (n == "epochs") epochs = atoi(value);
+  else if (n == "block_size_mb") block_size = atoi(value);
+  else if (n == "core_num") core_num = atoi(value) > 0 ? atoi(value) : 1;
+  else if (n == "k") v_dim_ = atoi(value);
+  else if (n == "optimizer") {
+    if (!strcmp(value, "ftrl")) optimizer = XF_OPT_FTRL;
+    else if (!strcmp(value, "sgd")) optimizer = XF_OPT_SGD;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: optimizer must be ftrl or sgd");
+  } else if (n == "capacity") capacity = strtoull(value, nullptr, 10);
+  else if (n == "rank") rank = atoi(value);
+  else if (n == "pred_path") pred_path = value;
+  else if (n == "alpha") alpha = (float)atof(value);
+  else if (n == "beta") beta = (float)atof(value);
+  else if (n == "lambda1") lambda1 = (float)atof(value);
+  else if (n == "lambda2") lambda2 = (float)atof(value);
+  else if (n == "lr") learning_rate = (float)atof(value);
+  else if (n == "seed") seed = strtoull(value, nullptr, 10);
+  else if (n == "cache_batches") cache_batches = atoi(value);
+  else
+    return xf::set_error(XF_EINVAL, "XFSetParam: unknown parameter '%s'", name);
+  return XF_OK;
+}
+
+int Worker::get_metric(const char *name, double *value) {
+  XF_REQUIRE(name && value, "XFGetMetric: null argument");
+  const std::string n = name;
+  if (n == "logloss_ref") *value = logloss_acc_;
+  else if (n == "logloss_nat") *value = logloss_nat_;
+  else if (n == "auc") *value = auc_;
+  else if (n == "tp") *value = tp_;
+  else if (n == "fp") *value = fp_;
+  else if (n == "rows_trained") *value = (double)rows_trained_;
+  else if (n == "train_seconds") *value = train_seconds_;
+  else if (n == "examples_per_sec") *value = train_seconds_ > 0 ? rows_trained_ / train_seconds_ : 0;
+  else if (n == "keys") {
+    uint64_t k = 0;
+    if (table_w_) XF_TRY(xf_table_size(table_w_, &k));
+    *value = (double)k;
+  } else
+    return xf::set_error(XF_EINVAL, "XFGetMetric: unknown metric '%s'", name);
+  return XF_OK;
+}
+
+}  // namespace xflow_amd
+
+// ------------------------------------------------------------------------------- C API
+// c_api.h:26-41: the handle is an XFlow object owning the worker.
+extern "C" int XFCreate(void **h, const char *train_path, const char *test_path) {
+  XF_REQUIRE(h && train_path && test_path, "XFCreate: null argument");
+  *h = new xflow_amd::Worker(0, train_path, test_path);
+  return XF_OK;
+}
+
+extern "C" int XFStartTrain(void **h) {
+  XF_REQUIRE(h && *h, "XFStartTrain: null handle");
+  return reinterpret_cast<xflow_amd::Worker *>(*h)->train();
+}
+
+extern "C" int XFDestroy(void **h) {
+  if (h && *h) {
+    delete reinterpret_cast<xflow_amd::Worker *>(*h);
+    *h = nullptr;
+  }
+  return XF_OK;
+}
+
+extern "C" int XFSetParam(void *h, const char *name, const char *value) {
+  XF_REQUIRE(h, "XFSetParam: null handle");
+  return reinterpret_cast<xflow_amd::Worker *>(h)->set_param(name, value);
+}
+
+extern "C" int XFGetMetric(void *h, const char *name, double *value) {
+  XF_REQUIRE(h, "XFGetMetric: null handle");
+  return reinterpret_cast<xflow_amd::Worker *>(h)->get_metric(name, value);
+}
+
+extern "C" int XFGetTables(void *h, xf_table **w, xf_table **v) {
+  XF_REQUIRE(h, "XFGetTables: null handle");
+  xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
+  if (w) *w = wk->table_w();
+  if (v) *v = wk->table_v();
+  return XF_OK;
+}
