@@ -86,6 +86,7 @@ def lib():
     L.xo_fm_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.xo_auc_logloss.argtypes = [_i32p, _f32p, C.c_size_t, _f32p, _f32p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.xo_set_sum_mode.argtypes = [C.c_int]
     L.xo_train.restype = C.c_long
     L.xo_train.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int,
                            C.c_size_t, C.c_int]
@@ -97,6 +98,21 @@ def lib():
 
 
 # ----------------------------------------------------------------------------- helpers
+class sum_mode:
+    """with sum_mode(1): ...  -> the exact-sum variant of the oracle (see xflow_oracle.cc)"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib().xo_get_sum_mode()
+        lib().xo_set_sum_mode(self.mode)
+
+    def __exit__(self, *a):
+        lib().xo_set_sum_mode(self.prev)
+
+
+
 def hash_str(s):
     b = s if isinstance(s, bytes) else str(s).encode()
     return int(lib().xo_hash_bytes(b, len(b)))

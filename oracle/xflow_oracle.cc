@@ -443,12 +443,31 @@ extern "C" const uint32_t *xo_batch_segptr(const xo_batch *b) { return b->segptr
 extern "C" const uint32_t *xo_batch_coo_row(const xo_batch *b) { return b->coo_row.data(); }
 extern "C" const int32_t *xo_batch_labels(const xo_batch *b) { return b->labels.data(); }
 
+/* Summation mode.  0 (default) = the reference's own arithmetic: every per-row / per-key
+ * sum is an fp32 running sum in the reference's visiting order.  1 = "exact-sum" variant
+ * of the SAME algorithm: the sums (and only the sums) are accumulated in fp64 and rounded
+ * to fp32 where the reference stores an fp32 value.  The reference's order within a key is
+ * std::sort's (unspecified, lr_worker.cc:162), so mode 0 is one of several legal roundings;
+ * mode 1 is order-independent and is what the GPU kernels compute (tests compare the GPU
+ * with mode 1 bit-for-bit, and mode 1 with mode 0 within the fp32 accumulation noise). */
+static int g_sum_mode = 0;
+extern "C" void xo_set_sum_mode(int mode) { g_sum_mode = mode; }
+extern "C" int xo_get_sum_mode(void) { return g_sum_mode; }
+
 /* ==================================================================== a5/a7 */
 /* The reference walks all_keys (sorted) against unique_keys with a merge-join
  * (lr_worker.cc:127-138); iterating segment by segment visits the same (j, i) pairs in
  * the same order, so every fp32 accumulation below happens in the reference's order. */
 static void xo_wx(const xo_batch *b, const float *w, std::vector<float> &wx) {
   wx.assign(b->rows, 0.0f);
+  if (g_sum_mode == 1) {
+    std::vector<double> acc(b->rows, 0.0);
+    for (size_t u = 0; u < b->nu; ++u)
+      for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j)
+        acc[b->coo_row[j]] += (double)w[u];
+    for (size_t i = 0; i < b->rows; ++i) wx[i] = (float)acc[i];
+    return;
+  }
   for (size_t u = 0; u < b->nu; ++u)
     for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) wx[b->coo_row[j]] += w[u];
 }
@@ -465,6 +484,13 @@ extern "C" void xo_lr_loss(const xo_batch *b, const float *w, float *loss, float
 
 extern "C" void xo_lr_grad(const xo_batch *b, const float *loss, float *g) {
   for (size_t u = 0; u < b->nu; ++u) { /* lr_worker.cc:104-115 */
+    if (g_sum_mode == 1) {
+      double acc = 0.0;
+      for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j)
+        acc += (double)loss[b->coo_row[j]];
+      g[u] = (float)acc;
+      continue;
+    }
     float acc = 0.0f;
     for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) acc += loss[b->coo_row[j]];
     g[u] = acc;
@@ -487,6 +513,21 @@ extern "C" void xo_fm_loss(const xo_batch *b, int k, const float *w, const float
   xo_wx(b, w, wx); /* fm_worker.cc:166-176 */
   std::vector<float> v_pow_sum(b->rows, 0.0f);
   for (size_t i = 0; i < b->rows; ++i) v_sum[i] = 0.0f;
+  if (g_sum_mode == 1) {
+    std::vector<double> vs(b->rows, 0.0), vp(b->rows, 0.0);
+    for (int kk = 0; kk < k; ++kk)
+      for (size_t u = 0; u < b->nu; ++u)
+        for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) {
+          const uint32_t sid = b->coo_row[j];
+          float v_weight = v[u * k + kk];
+          vs[sid] += (double)v_weight;
+          vp[sid] += (double)(v_weight * v_weight);
+        }
+    for (size_t i = 0; i < b->rows; ++i) {
+      v_sum[i] = (float)vs[i];
+      v_pow_sum[i] = (float)vp[i];
+    }
+  } else
   for (int kk = 0; kk < k; ++kk) { /* k-outer, pooled over k: fm_worker.cc:177-192 */
     for (size_t u = 0; u < b->nu; ++u) {
       for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) {
@@ -509,6 +550,22 @@ extern "C" void xo_fm_grad(const xo_batch *b, int k, const float *v, const float
                            const float *loss, float *gw, float *gv) {
   for (size_t u = 0; u < b->nu; ++u) gw[u] = 0.0f;
   for (size_t u = 0; u < b->nu * (size_t)k; ++u) gv[u] = 0.0f;
+  if (g_sum_mode == 1) {
+    for (size_t u = 0; u < b->nu; ++u) {
+      double accw = 0.0;
+      for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j)
+        accw += (double)loss[b->coo_row[j]];
+      gw[u] = (float)(accw * (double)k); /* :140 adds loss once per factor */
+      for (int kk = 0; kk < k; ++kk) {
+        double accv = 0.0;
+        for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) {
+          const uint32_t sid = b->coo_row[j];
+          accv += (double)(loss[sid] * (v_sum[sid] - v[u * k + kk]));
+        }
+        gv[u * k + kk] = (float)accv;
+      }
+    }
+  } else
   for (int kk = 0; kk < k; ++kk) { /* fm_worker.cc:134-148: gw accumulates k times */
     for (size_t u = 0; u < b->nu; ++u) {
       for (uint32_t j = b->segptr[u]; j < b->segptr[u + 1]; ++j) {

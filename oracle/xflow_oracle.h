@@ -99,6 +99,12 @@ const uint32_t *xo_batch_segptr(const xo_batch *b);
 const uint32_t *xo_batch_coo_row(const xo_batch *b);
 const int32_t *xo_batch_labels(const xo_batch *b);
 
+/* Summation mode: 0 = reference arithmetic (fp32 running sums in the reference's order,
+ * default); 1 = exact-sum variant (per-row / per-key sums accumulated in fp64, rounded to
+ * fp32 where the reference stores fp32) — what the GPU kernels compute.  See the .cc. */
+void xo_set_sum_mode(int mode);
+int xo_get_sum_mode(void);
+
 /* ---- a5/a7: LR math on a built batch --------------------------------------- */
 /* lr_worker.cc:121-143.  w: U floats (pulled).  loss,pctr: R floats. */
 void xo_lr_loss(const xo_batch *b, const float *w, float *loss, float *pctr);

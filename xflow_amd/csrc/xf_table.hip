@@ -88,7 +88,7 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       if (slot == (uint32_t)T.cap) atomicOr(&T.stat->err, xf::kErrFull);
     }
     if (inserted) {
-      atomicAdd(&T.stat->count, 1ull);
+      if (slot != (uint32_t)T.cap) atomicAdd(&T.stat->count, 1ull);  // spare counted apart
       if (T.init_kind != XF_INIT_ZERO) {  // memory is pre-zeroed for XF_INIT_ZERO
         float *row = T.w + (size_t)slot * T.dim;
         for (int j = 0; j < T.dim; ++j)

@@ -68,20 +68,34 @@ int Worker::create_tables() {
   return XF_OK;
 }
 
-int Worker::grow_if_needed() {
+// Make room for up to `incoming` new keys before a pull can insert them: keep the load
+// factor <= 0.6.  `seen_upper_` is a host-side upper bound on the key count so that the
+// exact (synchronising) size query only runs when the bound gets close.
+int Worker::grow_if_needed(size_t incoming) {
   xf_table *ts[2] = {table_w_, table_v_};
-  for (xf_table *t : ts) {
-    if (!t) continue;
-    uint64_t n = 0, cap = 0;
-    XF_TRY(xf_table_size(t, &n));
-    XF_TRY(xf_table_capacity(t, &cap));
-    if (n * 10 > cap * 6) XF_TRY(xf_table_reserve(t, cap * 2));  // keep load <= 0.6
+  uint64_t cap = 0;
+  XF_TRY(xf_table_capacity(table_w_, &cap));
+  if ((seen_upper_ + incoming) * 10 <= cap * 6) {
+    seen_upper_ += incoming;
+    return XF_OK;
   }
+  uint64_t n = 0;
+  XF_TRY(xf_table_size(table_w_, &n));
+  if ((n + incoming) * 10 > cap * 6) {
+    uint64_t want = cap * 2;
+    while ((n + incoming) * 10 > want * 6) want *= 2;
+    for (xf_table *t : ts)
+      if (t) XF_TRY(xf_table_reserve(t, want));
+  }
+  seen_upper_ = n + incoming;
   return XF_OK;
 }
 
 // LRWorker::update / FMWorker::update (lr_worker.cc:145-177, fm_worker.cc:204-245)
 int Worker::update(xf_batch *b) {
+  uint32_t U = 0;
+  xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
+  XF_TRY(grow_if_needed(U));
   if (model_ == 0) XF_TRY(xf_lr_step(table_w_, b, ws_, nullptr));
   else
     XF_TRY(xf_fm_step(table_w_, table_v_, b, ws_, nullptr));
@@ -114,7 +128,6 @@ int Worker::batch_training() {
         rows_trained_ += R;
       }
       XF_TRY(xf_table_check(table_w_, nullptr));
-      XF_TRY(grow_if_needed());
     } else {
       xf_reader *rd = nullptr;
       XF_TRY(xf_reader_open(&rd, train_data_path, (size_t)block_size << 20));
@@ -146,7 +159,6 @@ int Worker::batch_training() {
           if (cache_batches) cache_.push_back(b);
           else
             xf_batch_free(b);
-          XF_TRY(grow_if_needed());
         }
       }
       xf_reader_close(rd);
@@ -191,6 +203,9 @@ int Worker::predict(int rank, int block) {
       xf_batch *b = nullptr;
       XF_TRY(xf_batch_compile(&b, rowptr, keys, labels, start, end));
       pctr.resize(end - start);
+      uint32_t U = 0;
+      xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
+      XF_TRY(grow_if_needed(U));
       rc = model_ == 0 ? xf_lr_predict(table_w_, b, ws_, pctr.data())
                        : xf_fm_predict(table_w_, table_v_, b, ws_, pctr.data());
       xf_batch_free(b);
@@ -204,7 +219,6 @@ int Worker::predict(int rank, int block) {
         all_pctr.push_back(pctr[r]);
         md << pctr[r] << "\t" << 1 - label << "\t" << label << std::endl;  // :67
       }
-      XF_TRY(grow_if_needed());
     }
   }
   xf_reader_close(rd);

@@ -44,7 +44,8 @@ class Worker {
 
  private:
   int create_tables();
-  int grow_if_needed();
+  int grow_if_needed(size_t incoming);
+  uint64_t seen_upper_ = 0;
 
   int model_;
   std::string train_file_path, test_file_path;

@@ -1,0 +1,249 @@
+"""Multi-GPU driver: one process per GPU, the parameter table sharded by key range, keys /
+weights / gradients moved to and from their owning shard with all-to-all collectives
+(torch.distributed: backend "nccl" is RCCL over xGMI on ROCm).
+
+Replaces ps-lite's worker<->server routing (src/model/lr/lr_worker.cc:170,175;
+src/model/fm/fm_worker.cc:228-242): `Pull(keys)` = keys to owners, weights back;
+`Push(keys, grads)` = gradients to owners, owner-side FTRL/SGD.  Like ps-lite's default
+slicer, a SORTED key list splits into one contiguous range per owner
+(owner = min(key / (UINT64_MAX / N), N-1)), so the exchange is a plain all-to-all-v with
+no permutation.  xGMI is a full mesh: each peer pair has its own link, an all-to-all is one
+message per link.
+
+Update semantics with N workers: every worker's gradient is its own FTRL step
+(scaled by its own 1/R, lr_worker.cc:116-118); the owner applies the N pushes of a step in
+RANK ORDER after all N pulls — one legal, deterministic serialisation of what ps-lite does
+asynchronously.
+
+This module contains no arithmetic: the stages are the HIP kernels behind the C ABI
+(`HipStages`).  The stage object is injectable so that the collective plumbing can be
+exercised on CPU (`gloo`) in tests with a checker-backed stage object; the default, and the
+only one this package ships, is the GPU one, and it raises without a GPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def owner_boundaries(world):
+    """First key of every shard under the ps-lite uniform range rule."""
+    span = (2**64 - 1) // world
+    return [span * i for i in range(world)]
+
+
+def split_counts(ukeys_sorted_u64, world):
+    """How many of the sorted unique keys each owner gets (contiguous ranges)."""
+    bounds = np.array(owner_boundaries(world)[1:], dtype=np.uint64)
+    cuts = np.searchsorted(ukeys_sorted_u64, bounds, side="left")
+    edges = np.concatenate([[0], cuts, [len(ukeys_sorted_u64)]])
+    return np.diff(edges).astype(np.int64)
+
+
+class HipStages:
+    """The product stages: torch CUDA tensors hold the buffers, the HIP kernels do the work
+    on torch's current stream (so they order correctly with the RCCL collectives)."""
+
+    def __init__(self, model, optimizer, k, capacity, rank, world, seed=7, **hyper):
+        capi.require_gpu()
+        if not torch.cuda.is_available():
+            raise capi.XFError("HipStages needs a GPU (no CPU fallback)")
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        opt = capi.OPT_FTRL if optimizer == "ftrl" else capi.OPT_SGD
+        self.model, self.k = model, (k if model == "fm" else 0)
+        self.w = capi.Table(opt, 1, capi.INIT_ZERO, capacity=capacity, shard=rank,
+                            nshards=world, **hyper)
+        self.v = None
+        if model == "fm":
+            init = capi.INIT_HASHNORM if opt == capi.OPT_FTRL else capi.INIT_CONST
+            self.v = capi.Table(opt, k, init, 0.001, seed=seed, capacity=capacity, shard=rank,
+                                nshards=world, **hyper)
+
+    # -- buffers -------------------------------------------------------------------------
+    def empty(self, n, dtype):
+        return torch.empty(int(n), dtype=dtype, device=self.dev)
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    # -- batch ---------------------------------------------------------------------------
+    def compile_batch(self, rowptr, keys, labels):
+        hb = capi.Batch(rowptr, keys, labels)
+        h = hb.host()
+        b = _DeviceBatch()
+        b.R, b.NNZ, b.U, b.H = hb.R, hb.NNZ, hb.U, hb.H
+        b.ukeys_host = h["ukeys"]
+        b.t = {n: self.from_numpy(h[n].view(np.int64) if n == "ukeys" else
+                                  h[n].view(np.int32))
+               for n in ("ukeys", "rowptr", "uidx", "segptr", "coo_row", "labels", "heavy")}
+        v = capi.DevBatch()
+        v.R, v.NNZ, v.U, v.H = b.R, b.NNZ, b.U, b.H
+        for n in ("rowptr", "uidx", "ukeys", "segptr", "coo_row", "labels"):
+            setattr(v, n, b.t[n].data_ptr())
+        v.heavy = b.t["heavy"].data_ptr() if b.H else None
+        b.view = v
+        b.ukeys = b.t["ukeys"]
+        return b
+
+    # -- table stages (owner side) -------------------------------------------------------
+    def resolve(self, table, keys_i64):
+        slots = self.empty(keys_i64.numel(), torch.int32)
+        table.resolve_dev(keys_i64.data_ptr(), keys_i64.numel(), slots.data_ptr(),
+                          self._stream())
+        return slots
+
+    def gather(self, table, slots):
+        vals = self.empty(slots.numel() * table.dim, torch.float32)
+        table.gather_dev(slots.data_ptr(), slots.numel(), vals.data_ptr(), self._stream())
+        return vals
+
+    def update(self, table, slots, grads):
+        table.update_dev(slots.data_ptr(), slots.numel(), grads.data_ptr(), self._stream())
+
+    # -- model stages (worker side) ------------------------------------------------------
+    def lr_forward(self, b, wu):
+        loss = self.empty(b.R, torch.float32)
+        capi.check(capi.lib().xf_lr_forward_dev(capi.C.byref(b.view), wu.data_ptr(),
+                                                loss.data_ptr(), None, self._stream()))
+        return loss
+
+    def lr_grad(self, b, loss):
+        g = self.empty(b.U, torch.float32)
+        capi.check(capi.lib().xf_lr_grad_dev(capi.C.byref(b.view), loss.data_ptr(),
+                                             g.data_ptr(), self._stream()))
+        return g
+
+    def fm_forward(self, b, wu, vu):
+        loss = self.empty(b.R, torch.float32)
+        vsum = self.empty(b.R, torch.float32)
+        capi.check(capi.lib().xf_fm_forward_dev(capi.C.byref(b.view), self.k, wu.data_ptr(),
+                                                vu.data_ptr(), loss.data_ptr(), None,
+                                                vsum.data_ptr(), self._stream()))
+        return loss, vsum
+
+    def fm_grad(self, b, vu, vsum, loss):
+        gw = self.empty(b.U, torch.float32)
+        gv = self.empty(b.U * self.k, torch.float32)
+        capi.check(capi.lib().xf_fm_grad_dev(capi.C.byref(b.view), self.k, vu.data_ptr(),
+                                             vsum.data_ptr(), loss.data_ptr(), gw.data_ptr(),
+                                             gv.data_ptr(), self._stream()))
+        return gw, gv
+
+    def check(self):
+        self.w.check(self._stream())
+        if self.v is not None:
+            self.v.check(self._stream())
+
+    def tables(self):
+        return self.w, self.v
+
+
+class _DeviceBatch:
+    pass
+
+
+class ShardedTrainer:
+    """LRWorker/FMWorker::update across `world` ranks with a key-range-sharded table."""
+
+    def __init__(self, model="lr", optimizer="ftrl", k=10, capacity=1 << 22, rank=None,
+                 world=None, stages=None, group=None, **hyper):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.model = model
+        self.stages = stages if stages is not None else HipStages(
+            model, optimizer, k, capacity, self.rank, self.world, **hyper)
+        self.k = k if model == "fm" else 0
+        self._prof = None
+
+    # ---- compile: key build + the (static) exchange plan of this minibatch ---------------
+    def compile(self, rowptr, keys, labels):
+        b = self.stages.compile_batch(rowptr, keys, labels)
+        send = split_counts(b.ukeys_host, self.world)
+        recv = torch.empty(self.world, dtype=torch.int64)
+        cnt = torch.from_numpy(send.copy())
+        if self.world > 1:
+            dev = b.ukeys.device
+            cnt_d, recv_d = cnt.to(dev), recv.to(dev)
+            dist.all_to_all_single(recv_d, cnt_d, group=self.group)
+            recv = recv_d.cpu()
+        else:
+            recv = cnt.clone()
+        b.send_counts = send.tolist()
+        b.recv_counts = recv.tolist()
+        b.n_recv = int(sum(b.recv_counts))
+        return b
+
+    def _a2a(self, src, in_counts, out_counts, width=1):
+        out = self.stages.empty(sum(out_counts) * width, src.dtype)
+        if self.world == 1:
+            out.copy_(src)
+            return out
+        dist.all_to_all_single(out, src, [c * width for c in out_counts],
+                               [c * width for c in in_counts], group=self.group)
+        return out
+
+    # ---- one minibatch step ----------------------------------------------------------------
+    def step(self, b):
+        st = self.stages
+        tw, tv = st.tables()
+        # Pull, part 1: sorted unique keys to their owners (ps-lite slicer ranges)
+        rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
+        # owner: key -> slot (insert on first touch, ftrl.h:56), gather weights
+        slots_w = st.resolve(tw, rkeys)
+        w_recv = st.gather(tw, slots_w)
+        if self.model == "fm":
+            slots_v = st.resolve(tv, rkeys)
+            v_recv = st.gather(tv, slots_v)
+        # Pull, part 2: weights back, in the order the keys were sent
+        wu = self._a2a(w_recv, b.recv_counts, b.send_counts)
+        if self.model == "lr":
+            loss = st.lr_forward(b, wu)
+            g = st.lr_grad(b, loss)
+        else:
+            vu = self._a2a(v_recv, b.recv_counts, b.send_counts, self.k)
+            loss, vsum = st.fm_forward(b, wu, vu)
+            g, gv = st.fm_grad(b, vu, vsum, loss)
+        # Push: gradients to the owners (keys are already there), owner-side optimizer step,
+        # one worker after the other in rank order
+        g_recv = self._a2a(g, b.send_counts, b.recv_counts)
+        if self.model == "fm":
+            gv_recv = self._a2a(gv, b.send_counts, b.recv_counts, self.k)
+        off = 0
+        for src in range(self.world):
+            c = b.recv_counts[src]
+            if c:
+                st.update(tw, slots_w[off:off + c], g_recv[off:off + c])
+                if self.model == "fm":
+                    st.update(tv, slots_v[off:off + c],
+                              gv_recv[off * self.k:(off + c) * self.k])
+            off += c
+        self._last = dict(wu=wu, loss=loss, g=g)
+
+    def predict(self, b):
+        """forward only (calculate_pctr): pulls insert unseen keys, as in the reference."""
+        st = self.stages
+        tw, tv = st.tables()
+        rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
+        wu = self._a2a(st.gather(tw, st.resolve(tw, rkeys)), b.recv_counts, b.send_counts)
+        if self.model == "lr":
+            return st.lr_forward(b, wu)
+        vu = self._a2a(st.gather(tv, st.resolve(tv, rkeys)), b.recv_counts, b.send_counts,
+                       self.k)
+        return st.fm_forward(b, wu, vu)[0]
+
+    def check(self):
+        self.stages.check()
+
+    # bench hooks: per-kernel events are a single-GPU facility (xf_workspace_profile); the
+    # sharded path reports whole-step time only
+    def profile(self, enable):
+        pass
+
+    def profile_read(self):
+        return {}, 0
