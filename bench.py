@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--zipf", type=float, default=0.0)
     ap.add_argument("--cpu-baseline-batches", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
 
@@ -141,14 +143,17 @@ def main():
     torch.cuda.set_device(local_rank)
     capi.require_gpu()
     dist = None
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     nkeys_total = args.keys_per_gpu * world
     keytab = make_key_table(nkeys_total)
     batches = make_batches(args, rank, nkeys_total, keytab)
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         from xflow_amd.single import SingleGpuTrainer as Trainer
     else:
         from xflow_amd.sharded import ShardedTrainer as Trainer

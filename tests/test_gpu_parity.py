@@ -413,3 +413,41 @@ def test_full_size_properties(big_batch):
     before = t.pull(kz)
     t.push(kz, np.zeros(len(kz), np.float32))
     assert np.array_equal(t.pull(kz), before)
+
+
+# ------------------------------------------------------------------ N-GPU code path at N=1
+def test_sharded_trainer_world1_matches_fused_step():
+    """The multi-GPU driver (all-to-all of keys / weights / gradients through RCCL, owner-side
+    resolve/gather/update, rank-ordered pushes) at world_size 1 must give exactly what the
+    fused single-GPU step gives."""
+    import torch
+    import torch.distributed as dist
+    from xflow_amd.sharded import ShardedTrainer
+    from xflow_amd.single import SingleGpuTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for model, opt in (("lr", "ftrl"), ("fm", "sgd"), ("fm", "ftrl")):
+            rng = np.random.RandomState(11)
+            a = ShardedTrainer(model=model, optimizer=opt, k=8, capacity=1 << 16, rank=0, world=1)
+            b = SingleGpuTrainer(model=model, optimizer=opt, k=8, capacity=1 << 16)
+            for step in range(3):
+                data = synth(rng, 700, 25, 6000, 1.3 if step == 1 else None, True)
+                a.step(a.compile(*data))
+                b.step(b.compile(*data))
+            a.check()
+            b.check()
+            ta, tb = a.stages.tables(), (b.w, b.v)
+            for x, y in zip(ta, tb):
+                if x is not None:
+                    for p, q in zip(x.export(), y.export()):
+                        same(p, q)
+            data = synth(rng, 300, 25, 9000)
+            pa = a.predict(a.compile(*data)).cpu().numpy()
+            pb = b.predict(b.compile(*data))
+            ob = O.Batch(*data)
+            assert pa.shape == pb.shape == (ob.R,)
+    finally:
+        dist.destroy_process_group()

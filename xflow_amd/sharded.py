@@ -159,7 +159,12 @@ class ShardedTrainer:
         self.stages = stages if stages is not None else HipStages(
             model, optimizer, k, capacity, self.rank, self.world, **hyper)
         self.k = k if model == "fm" else 0
+        # with a process group the exchange always goes through the collective, also at
+        # world 1 (RCCL handles it; keeps the one-GPU run on the N-GPU code path)
+        self._collective = dist.is_available() and dist.is_initialized()
+        assert self._collective or self.world == 1, "world > 1 needs a process group"
         self._prof = None
+        self._ev = []
 
     # ---- compile: key build + the (static) exchange plan of this minibatch ---------------
     def compile(self, rowptr, keys, labels):
@@ -167,7 +172,7 @@ class ShardedTrainer:
         send = split_counts(b.ukeys_host, self.world)
         recv = torch.empty(self.world, dtype=torch.int64)
         cnt = torch.from_numpy(send.copy())
-        if self.world > 1:
+        if self._collective:
             dev = b.ukeys.device
             cnt_d, recv_d = cnt.to(dev), recv.to(dev)
             dist.all_to_all_single(recv_d, cnt_d, group=self.group)
@@ -181,7 +186,7 @@ class ShardedTrainer:
 
     def _a2a(self, src, in_counts, out_counts, width=1):
         out = self.stages.empty(sum(out_counts) * width, src.dtype)
-        if self.world == 1:
+        if not self._collective:
             out.copy_(src)
             return out
         dist.all_to_all_single(out, src, [c * width for c in out_counts],
@@ -189,31 +194,48 @@ class ShardedTrainer:
         return out
 
     # ---- one minibatch step ----------------------------------------------------------------
+    def _mark(self, name):
+        if self._prof is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev.append((name, e))
+
     def step(self, b):
         st = self.stages
         tw, tv = st.tables()
+        self._mark("begin")
         # Pull, part 1: sorted unique keys to their owners (ps-lite slicer ranges)
         rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
+        self._mark("a2a_keys")
         # owner: key -> slot (insert on first touch, ftrl.h:56), gather weights
         slots_w = st.resolve(tw, rkeys)
-        w_recv = st.gather(tw, slots_w)
         if self.model == "fm":
             slots_v = st.resolve(tv, rkeys)
+        self._mark("resolve")
+        w_recv = st.gather(tw, slots_w)
+        if self.model == "fm":
             v_recv = st.gather(tv, slots_v)
+        self._mark("gather")
         # Pull, part 2: weights back, in the order the keys were sent
         wu = self._a2a(w_recv, b.recv_counts, b.send_counts)
+        if self.model == "fm":
+            vu = self._a2a(v_recv, b.recv_counts, b.send_counts, self.k)
+        self._mark("a2a_weights")
         if self.model == "lr":
             loss = st.lr_forward(b, wu)
+            self._mark("forward")
             g = st.lr_grad(b, loss)
         else:
-            vu = self._a2a(v_recv, b.recv_counts, b.send_counts, self.k)
             loss, vsum = st.fm_forward(b, wu, vu)
+            self._mark("forward")
             g, gv = st.fm_grad(b, vu, vsum, loss)
+        self._mark("gradient")
         # Push: gradients to the owners (keys are already there), owner-side optimizer step,
         # one worker after the other in rank order
         g_recv = self._a2a(g, b.send_counts, b.recv_counts)
         if self.model == "fm":
             gv_recv = self._a2a(gv, b.send_counts, b.recv_counts, self.k)
+        self._mark("a2a_grads")
         off = 0
         for src in range(self.world):
             c = b.recv_counts[src]
@@ -223,6 +245,7 @@ class ShardedTrainer:
                     st.update(tv, slots_v[off:off + c],
                               gv_recv[off * self.k:(off + c) * self.k])
             off += c
+        self._mark("update")
         self._last = dict(wu=wu, loss=loss, g=g)
 
     def predict(self, b):
@@ -240,10 +263,21 @@ class ShardedTrainer:
     def check(self):
         self.stages.check()
 
-    # bench hooks: per-kernel events are a single-GPU facility (xf_workspace_profile); the
-    # sharded path reports whole-step time only
+    # bench hooks: per-stage timing with events recorded on the stream the kernels and the
+    # collectives are enqueued on
     def profile(self, enable):
-        pass
+        self._prof = {} if enable else None
+        self._ev = []
 
     def profile_read(self):
-        return {}, 0
+        if not self._ev:
+            return {}, 0
+        torch.cuda.synchronize()
+        sums, steps = {}, 0
+        for (n0, e0), (n1, e1) in zip(self._ev[:-1], self._ev[1:]):
+            if n1 == "begin":
+                continue
+            sums[n1] = sums.get(n1, 0.0) + e0.elapsed_time(e1)
+            steps += n1 == "update"
+        self._ev = []
+        return sums, steps
