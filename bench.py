@@ -43,6 +43,10 @@ def parse_args():
     ap.add_argument("--zipf", type=float, default=0.0)
     ap.add_argument("--cpu-baseline-batches", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--panel-slice-kb", type=float, default=0.0,
+                    help="tuning: bytes of w_u per forward panel (0 = library default)")
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--seed", type=int, default=20260926)
@@ -74,12 +78,20 @@ def make_batches(args, rank, nkeys_total, keytab):
     return out
 
 
-def bytes_model(model, k, R, NNZ, U, opt):
+def bytes_model(model, k, R, NNZ, U, opt, fused=False):
     """Algorithmic bytes per launch of each kernel of THIS implementation (indices counted
     once at their stored width, no probe / sector overhead) and SURVEY §8(d)'s whole-step
     figure."""
     state = 24 if opt == "ftrl" else 8      # read+write of (w,n,z) or w per coordinate
     d = 1 if model == "lr" else 1 + k
+    if model == "lr" and fused:
+        per = {
+            "resolve": U * (8 + 8 + 4 + 4 + 4),      # pull: key list, table key, slot, w, w_u
+            "forward": NNZ * (4 + 4) + R * 12 + 4,    # uidx + gathered w_u
+            "gradient": NNZ * 8 + U * (4 + 4 + 4 + state),  # grad+push: rows, loss gathers,
+        }                                             # segptr, slot, g, state RMW
+        survey = 12 * NNZ + 8 * R + (32 if opt == "ftrl" else 16) * U
+        return per, survey
     per = {
         "resolve": U * (8 + 8 + 4) * (1 if model == "lr" else 2),  # key list + table key + slot
         "gather": U * (4 + 4 * d + 4 * d),                          # slot + read w + write w_u
@@ -149,6 +161,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    if args.panel_slice_kb > 0:
+        capi.tune("panel_slice_bytes", args.panel_slice_kb * 1024)
+    elif args.panel_slice_kb < 0:
+        capi.tune("min_panel_nnz", 1e18)   # disable panels
     nkeys_total = args.keys_per_gpu * world
     keytab = make_key_table(nkeys_total)
     batches = make_batches(args, rank, nkeys_total, keytab)
@@ -191,8 +207,9 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer)
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
+    fused = args.model == "lr" and world == 1 and not args.force_sharded
+    per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused)
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
     achieved = per[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
@@ -213,7 +230,9 @@ def main():
                    "distinct_batches": len(compiled),
                    "parallelism": "key-range sharded table x%d, all-to-all" % world
                    if world > 1 else "single shard"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": {"resolve": "k_resolve<gather>" if fused else
+                                                "k_resolve", "gradient": "k_lr_grad_update"
+                                                if fused else "k_lr_grad"}.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": per[dom],
                      "avg_launch_ms": avg_ms[dom]},
@@ -221,6 +240,9 @@ def main():
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
+    if args.pmc_calibrate:
+        for kind in range(6):
+            capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, batches)
     print(json.dumps(out))

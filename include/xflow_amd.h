@@ -79,6 +79,12 @@ int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const uint32_t **ro
                   const uint32_t **uidx, const uint32_t **segptr,
                   const uint32_t **coo_row, const int32_t **labels,
                   const uint32_t **heavy);
+/* panel view (host arrays); *P == 0 when the batch is too small to need panels */
+int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
+                    const uint32_t **pidx);
+/* tuning knobs (process-wide): "panel_slice_bytes" (default 1.5 MiB: w_u bytes per panel),
+ * "min_panel_nnz" (default 4e6: smaller batches keep the plain CSR forward) */
+int xf_tune(const char *name, double value);
 /* copy to the current device (async on stream); idempotent */
 int xf_batch_upload(xf_batch *b, void *stream);
 
@@ -92,6 +98,14 @@ typedef struct {
   const uint32_t *coo_row; /* NNZ  */
   const int32_t *labels;   /* R    */
   const uint32_t *heavy;   /* H (may be NULL when H == 0) */
+  /* LR forward, panel-major view of the CSR (P == 0: absent, the plain CSR is used).
+   * Panel p holds the nonzeros whose uidx lies in [U*p/P, U*(p+1)/P): row r's part is
+   * pidx[pptr[p*(R+1)+r] .. pptr[p*(R+1)+r+1]).  Blocks working on panel p gather from
+   * one L2-sized slice of w_u; p % 8 selects the XCD. */
+  uint32_t P, pad_;
+  const uint32_t *pptr;    /* P*(R+1) */
+  const uint32_t *pidx;    /* NNZ     */
+  double *fwd_scratch;     /* P*R partial sums (device scratch owned by the batch) */
 } xf_dev_batch;
 int xf_batch_dev_view(const xf_batch *b, xf_dev_batch *view);
 
@@ -137,6 +151,9 @@ int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t
                          void *stream);
 int xf_table_gather_dev(xf_table *t, const uint32_t *d_slots, size_t n, float *d_vals,
                         void *stream);
+/* resolve + gather in one pass (dim-1 tables, keys unique within the call) */
+int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_slots,
+                      float *d_vals, void *stream);
 int xf_table_update_dev(xf_table *t, const uint32_t *d_slots, size_t n,
                         const float *d_grads, void *stream);
 /* raises XF_EFULL / XF_EINVAL recorded by earlier async calls; synchronises the stream */
@@ -155,6 +172,10 @@ int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
                       float *d_pctr /* may be NULL */, void *stream);
 /* LR gradient (lr_worker.cc:100-119): g[u] = (sum_{occurrences} loss[row]) / R */
 int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float *d_g, void *stream);
+/* LR gradient fused with the Push for a table on the same GPU (single shard): g is still
+ * written (parity hook); slots as returned by resolve/pull for b->ukeys */
+int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const uint32_t *d_slots,
+                          const float *d_loss, float *d_g, void *stream);
 /* FM forward, reference form (fm_worker.cc:159-202); v_u is U x k row-major */
 int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
                       float *d_loss, float *d_pctr, float *d_vsum, void *stream);
@@ -180,10 +201,15 @@ int xf_fm_predict(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws,
 int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
                        size_t R);
 /* optional per-kernel timing with HIP events recorded on the step's own stream:
- * ms_sum[5] = resolve, gather, forward, gradient, update, summed over *steps steps */
+ * ms_sum[5] = resolve, gather, forward, gradient, update, summed over *steps steps.
+ * xf_lr_step fuses gather into resolve and update into gradient: slots 1 and 4 read 0. */
 int xf_workspace_profile(xf_workspace *ws, int enable);
 int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long *steps);
-int xf_stream_sync(void *stream); /* == ps KVWorker::Wait */
+int xf_stream_sync(void *stream);
+/* measurement support: stream `bytes` of scratch with a known access width, `repeat` times
+ * (kind 0/1/2 = read 4/8/16 B per lane, 3/4/5 = write 4/8/16 B per lane): calibrates the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py) */
+int xf_calib_stream(int kind, size_t bytes, int repeat); /* == ps KVWorker::Wait */
 
 /* ---------------------------------------------------------------- metrics             */
 /* Base::calculate_auc (base.h:84-110): reference-format logloss (mean of y*log2 p +

@@ -162,3 +162,33 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in txt and "xflow_oracle" not in txt and \
                     "liboracle" not in txt, os.path.join(dp, f)
+
+
+def test_forward_panels_partition_the_csr():
+    """The panel-major view holds exactly the CSR's nonzeros, each in the panel its uidx
+    falls in, CSR order kept inside a (panel,row) cell."""
+    rng = np.random.RandomState(12)
+    rowptr, keys, labels = _random_csr(rng, 400, 30, 3000)
+    capi.tune("min_panel_nnz", 0)
+    capi.tune("panel_slice_bytes", 1024)      # force several panels on a tiny batch
+    try:
+        b = capi.Batch(rowptr, keys, labels)
+    finally:
+        capi.tune("min_panel_nnz", 4e6)
+        capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+    h = b.host()
+    P, pptr, pidx = b.panels()
+    assert P >= 8 and P % 8 == 0 and len(pidx) == b.NNZ
+    pptr = pptr.reshape(P, b.R + 1)
+    assert pptr[0, 0] == 0 and pptr[-1, -1] == b.NNZ
+    for r in range(0, b.R, 7):
+        row = h["uidx"][h["rowptr"][r]:h["rowptr"][r + 1]]
+        got = []
+        for p in range(P):
+            cell = pidx[pptr[p, r]:pptr[p, r + 1]]
+            assert np.all((cell.astype(np.uint64) * P) // b.U == p)
+            assert np.array_equal(cell, row[(row.astype(np.uint64) * P) // b.U == p])
+            got.append(cell)
+        assert sorted(np.concatenate(got).tolist()) == sorted(row.tolist())
+    small = capi.Batch(rowptr, keys, labels)
+    assert small.panels()[0] == 0               # default: small batches keep the plain CSR

@@ -243,6 +243,36 @@ def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
             near_state(a, r, RTOL_HEAVY if zipf else RTOL)
 
 
+def test_lr_forward_panel_kernel_bit_exact():
+    """The XCD/L2-aware panel-major forward (used for large minibatches) forced onto a small
+    one: same bits as the exact-sum oracle, for 8- and 16-lane cells."""
+    rng = np.random.RandomState(77)
+    for nnz, slice_bytes in ((40, 2048), (200, 4096)):
+        rowptr, keys, labels = synth(rng, 1500, nnz, 30000, None, True)
+        capi.tune("min_panel_nnz", 0)
+        capi.tune("panel_slice_bytes", slice_bytes)
+        try:
+            b = capi.Batch(rowptr, keys, labels)
+        finally:
+            capi.tune("min_panel_nnz", 4e6)
+            capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+        assert b.panels()[0] >= 8
+        ob = O.Batch(rowptr, keys, labels)
+        t, s = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 17), O.Store(O.OPT_FTRL, 1)
+        ws = capi.Workspace()
+        for _ in range(3):
+            capi.lr_step(t, b, ws)
+            with O.sum_mode(1):
+                w_ex = s.pull(ob.ukeys)
+                loss_ex, p_ex = ob.lr_loss(w_ex)
+                O.lr_update(s, ob)
+            same(ws.fetch(b.U, b.R)[1], loss_ex)
+        for a, e in zip(t.export(), s.export()):
+            same(a, e)
+        with O.sum_mode(1):
+            same(capi.lr_predict(t, b, ws), ob.lr_loss(s.pull(ob.ukeys))[1])
+
+
 @pytest.mark.parametrize("opt,k", [(capi.OPT_SGD, 10), (capi.OPT_FTRL, 10), (capi.OPT_SGD, 16),
                                    (capi.OPT_FTRL, 7)])
 def test_fm_step_state(opt, k):

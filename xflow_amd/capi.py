@@ -38,7 +38,8 @@ class TableConfig(C.Structure):
 class DevBatch(C.Structure):
     _fields_ = [("R", C.c_uint32), ("NNZ", C.c_uint32), ("U", C.c_uint32), ("H", C.c_uint32),
                 ("rowptr", vp), ("uidx", vp), ("ukeys", vp), ("segptr", vp), ("coo_row", vp),
-                ("labels", vp), ("heavy", vp)]
+                ("labels", vp), ("heavy", vp), ("P", C.c_uint32), ("pad_", C.c_uint32),
+                ("pptr", vp), ("pidx", vp), ("fwd_scratch", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/xflow_amd.h declares
@@ -60,6 +61,8 @@ SIGNATURES = {
     "xf_batch_host": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(u32p),
                                 C.POINTER(u32p), C.POINTER(u32p), C.POINTER(i32p),
                                 C.POINTER(u32p)]),
+    "xf_batch_panels": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
+    "xf_tune": (C.c_int, [C.c_char_p, C.c_double]),
     "xf_batch_upload": (C.c_int, [vp, vp]),
     "xf_batch_dev_view": (C.c_int, [vp, C.POINTER(DevBatch)]),
     "xf_table_config_default": (None, [C.POINTER(TableConfig)]),
@@ -74,6 +77,8 @@ SIGNATURES = {
     "xf_table_resolve_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "xf_table_gather_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "xf_table_update_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "xf_table_pull_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
+    "xf_lr_grad_update_dev": (C.c_int, [vp, C.POINTER(DevBatch), vp, vp, vp, vp]),
     "xf_table_check": (C.c_int, [vp, vp]),
     "xf_table_export": (C.c_int, [vp, u64p, f32p, f32p, f32p, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
@@ -92,6 +97,7 @@ SIGNATURES = {
     "xf_workspace_profile": (C.c_int, [vp, C.c_int]),
     "xf_workspace_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "xf_stream_sync": (C.c_int, [vp]),
+    "xf_calib_stream": (C.c_int, [C.c_int, C.c_size_t, C.c_int]),
     "xf_auc_logloss": (C.c_int, [i32p, f32p, C.c_size_t, f32p, f32p, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "XFCreate": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_char_p]),
@@ -141,6 +147,10 @@ def _p(a, t):
 def hash_str(s):
     b = s if isinstance(s, bytes) else str(s).encode()
     return int(lib().xf_hash_bytes(b, len(b)))
+
+
+def tune(name, value):
+    check(lib().xf_tune(name.encode(), float(value)))
 
 
 def hash_decimal_range(start, n):
@@ -204,6 +214,14 @@ class Batch:
                     uidx=arr(ui, self.NNZ, np.uint32), segptr=arr(sp, self.U + 1, np.uint32),
                     coo_row=arr(cr, self.NNZ, np.uint32), labels=arr(lb, self.R, np.int32),
                     heavy=arr(hv, self.H, np.uint32))
+
+    def panels(self):
+        P, pp, pi = C.c_uint32(0), u32p(), u32p()
+        check(lib().xf_batch_panels(self.h, C.byref(P), C.byref(pp), C.byref(pi)))
+        if P.value == 0:
+            return 0, np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        return (P.value, np.ctypeslib.as_array(pp, (P.value * (self.R + 1),)).copy(),
+                np.ctypeslib.as_array(pi, (self.NNZ,)).copy())
 
     def upload(self, stream=None):
         check(lib().xf_batch_upload(self.h, stream))

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -61,7 +62,69 @@ void sort_keypos(std::vector<KeyPos> &a) {
   for (auto &x : th) x.join();
 }
 
+double g_panel_slice_bytes = 1.5 * 1024 * 1024;
+double g_min_panel_nnz = 4e6;
+
+// Panel-major copy of the CSR for the LR forward: the uidx space [0,U) is cut into P equal
+// ranges (P a multiple of 8 = XCDs) so that one range of w_u (U/P floats) fits an XCD's
+// 4 MiB L2 beside the index stream; within a (panel,row) cell the CSR order is kept.
+void build_panels(xf_batch *b) {
+  b->P = 0;
+  b->pptr.clear();
+  b->pidx.clear();
+  if ((double)b->NNZ < g_min_panel_nnz || b->U == 0) return;
+  const double slices = std::ceil((double)b->U * 4.0 / g_panel_slice_bytes);
+  uint32_t P = (uint32_t)(8 * std::ceil(slices / 8.0));
+  if (P < 8) P = 8;
+  if (P > 256) P = 256;
+  const uint64_t U = b->U, R = b->R;
+  auto panel_of = [&](uint32_t ui) { return (uint32_t)(((uint64_t)ui * P) / U); };
+  b->pptr.assign((size_t)P * (R + 1), 0);
+  // counts per (panel,row) -> exclusive prefix in panel-major order
+  for (uint64_t r = 0; r < R; ++r)
+    for (uint32_t j = b->rowptr[r]; j < b->rowptr[r + 1]; ++j)
+      ++b->pptr[(size_t)panel_of(b->uidx[j]) * (R + 1) + r + 1];
+  uint32_t run = 0;
+  for (uint32_t p = 0; p < P; ++p) {
+    uint32_t *pp = &b->pptr[(size_t)p * (R + 1)];
+    pp[0] = run;
+    for (uint64_t r = 0; r < R; ++r) {
+      const uint32_t c = pp[r + 1];
+      pp[r + 1] = pp[r] + c;
+    }
+    run = pp[R];
+  }
+  b->pidx.resize(b->NNZ);
+  std::vector<uint32_t> cur((size_t)P * R);
+  for (uint32_t p = 0; p < P; ++p)
+    for (uint64_t r = 0; r < R; ++r) cur[(size_t)p * R + r] = b->pptr[(size_t)p * (R + 1) + r];
+  for (uint64_t r = 0; r < R; ++r)
+    for (uint32_t j = b->rowptr[r]; j < b->rowptr[r + 1]; ++j) {
+      const uint32_t ui = b->uidx[j];
+      b->pidx[cur[(size_t)panel_of(ui) * R + r]++] = ui;
+    }
+  b->P = P;
+}
+
 }  // namespace
+
+extern "C" int xf_tune(const char *name, double value) {
+  XF_REQUIRE(name, "xf_tune: null name");
+  if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
+  else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
+  else
+    return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);
+  return XF_OK;
+}
+
+extern "C" int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
+                               const uint32_t **pidx) {
+  XF_REQUIRE(b && P, "xf_batch_panels: null argument");
+  *P = b->P;
+  if (pptr) *pptr = b->pptr.data();
+  if (pidx) *pidx = b->pidx.data();
+  return XF_OK;
+}
 
 extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                                 const int32_t *labels, size_t row_begin, size_t row_end) {
@@ -106,6 +169,7 @@ extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const ui
   for (uint32_t u = 0; u < b->U; ++u)
     if (b->segptr[u + 1] - b->segptr[u] > XF_HEAVY_SEG) b->heavy.push_back(u);
   b->H = (uint32_t)b->heavy.size();
+  build_panels(b);
   *out = b;
   return XF_OK;
 }
@@ -153,7 +217,10 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   const size_t o_coo = o_segptr + al(((size_t)b->U + 1) * 4);
   const size_t o_labels = o_coo + al((size_t)b->NNZ * 4);
   const size_t o_heavy = o_labels + al((size_t)b->R * 4);
-  const size_t total = o_heavy + al((size_t)b->H * 4) + 256;
+  const size_t o_pptr = o_heavy + al((size_t)b->H * 4);
+  const size_t o_pidx = o_pptr + al((size_t)b->P * ((size_t)b->R + 1) * 4);
+  const size_t o_scr = o_pidx + al(b->P ? (size_t)b->NNZ * 4 : 0);
+  const size_t total = o_scr + al((size_t)b->P * b->R * 8) + 256;
   char *d = nullptr;
   XF_HIP(hipMalloc((void **)&d, total));
   hipStream_t s = (hipStream_t)stream;
@@ -168,6 +235,10 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   XF_HIP(put(o_coo, b->coo_row.data(), (size_t)b->NNZ * 4));
   XF_HIP(put(o_labels, b->labels.data(), (size_t)b->R * 4));
   XF_HIP(put(o_heavy, b->heavy.data(), (size_t)b->H * 4));
+  if (b->P) {
+    XF_HIP(put(o_pptr, b->pptr.data(), b->pptr.size() * 4));
+    XF_HIP(put(o_pidx, b->pidx.data(), b->pidx.size() * 4));
+  }
   XF_HIP(hipStreamSynchronize(s));  // host vectors are pageable: finish before returning
   b->d_blob = d;
   b->view.R = b->R;
@@ -181,6 +252,11 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   b->view.coo_row = (const uint32_t *)(d + o_coo);
   b->view.labels = (const int32_t *)(d + o_labels);
   b->view.heavy = b->H ? (const uint32_t *)(d + o_heavy) : nullptr;
+  b->view.P = b->P;
+  b->view.pad_ = 0;
+  b->view.pptr = b->P ? (const uint32_t *)(d + o_pptr) : nullptr;
+  b->view.pidx = b->P ? (const uint32_t *)(d + o_pidx) : nullptr;
+  b->view.fwd_scratch = b->P ? (double *)(d + o_scr) : nullptr;
   return XF_OK;
 }
 

@@ -10,6 +10,8 @@ struct xf_batch {
   uint32_t R = 0, NNZ = 0, U = 0, H = 0;
   std::vector<uint64_t> ukeys;
   std::vector<uint32_t> rowptr, uidx, segptr, coo_row, heavy;
+  uint32_t P = 0;  // forward panels (0 = none)
+  std::vector<uint32_t> pptr, pidx;
   std::vector<int32_t> labels;
   void *d_blob = nullptr;  // one device allocation holding all arrays
   xf_dev_batch view{};

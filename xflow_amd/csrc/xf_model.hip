@@ -75,6 +75,51 @@ k_lr_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
   }
 }
 
+// LR forward, panel-major variant for large minibatches.  The compact weight array w_u
+// (U floats, 25 MB at the config-2 shape) does not fit an XCD's 4 MiB L2, so the plain
+// kernel's gathers are served by the Infinity Cache at fabric rate.  Here the uidx space is
+// cut into P key-range panels (P a multiple of 8): blocks with blockIdx % 8 == x — which the
+// dispatcher places on XCD x — work only on panels p with p % 8 == x, panel after panel, so
+// each XCD's L2 holds the 1/P slice of w_u it is gathering from.  A (row, panel) cell is
+// summed by a G-lane group; the P partial sums of a row are added in panel order by
+// k_lr_finalize (deterministic).  The index stream is read with non-temporal loads so it
+// does not evict the slice.  Placement is a performance assumption only.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_lr_forward_panel(const uint32_t *__restrict__ pptr, const uint32_t *__restrict__ pidx,
+                   const float *__restrict__ wu, uint32_t R, uint32_t P,
+                   double *__restrict__ partial) {
+  constexpr uint32_t kGroups = kBlock / G;       // (row,panel) cells per block pass
+  const uint32_t lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
+  const uint32_t chunks = (R + kGroups - 1) / kGroups;  // row chunks per panel
+  const uint32_t units = (P >> 3) * chunks;              // work units of this XCD
+  for (uint32_t w = q; w < units; w += nq) {
+    const uint32_t p = xcd + 8u * (w / chunks);
+    const uint32_t r = (w % chunks) * kGroups + grp;
+    if (r >= R) continue;
+    const uint32_t *pp = pptr + (size_t)p * (R + 1) + r;
+    const uint32_t b = pp[0], e = pp[1];
+    double acc = 0.0;
+    for (uint32_t j = b + lane; j < e; j += G)
+      acc += (double)wu[__builtin_nontemporal_load(pidx + j)];
+    acc = group_sum<G>(acc);
+    if (lane == 0) partial[(size_t)p * R + r] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_lr_finalize(const double *__restrict__ partial, const int32_t *__restrict__ labels,
+              uint32_t R, uint32_t P, float *__restrict__ loss, float *__restrict__ pctr) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double acc = 0.0;
+  for (uint32_t p = 0; p < P; ++p) acc += partial[(size_t)p * R + r];
+  const float pr = xf::sigmoid_ref((float)acc);
+  if (pctr) pctr[r] = pr;
+  loss[r] = pr - (float)labels[r];
+}
+
 // ------------------------------------------------------------------ LR gradient (a7)
 // g[u] = (sum_{j in seg u} loss[coo_row[j]]) / R   (divide in double: lr_worker.cc:117)
 __global__ void __launch_bounds__(kBlock)
@@ -103,6 +148,62 @@ k_lr_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
     for (uint32_t j = b + lane; j < e; j += 64) acc += (double)loss[coo_row[j]];
     acc = group_sum<64>(acc);
     if (lane == 0) g[u] = (float)((double)(float)acc / (1.0 * R));
+  }
+}
+
+// LR gradient fused with the Push for a table that lives on the same GPU (single shard):
+// the lane that reduced key u's occurrences applies the optimizer step to slot[u] right
+// away (ftrl.h:59-74 / sgd.h:52).  The state words are requested before the occurrence
+// walk so their latency overlaps it; g never round-trips through HBM (it is still stored,
+// once, for the parity hook).  Slots are monotone in u, so the state accesses of a wave
+// are one neighbourhood of w[], n[], z[].
+template <int OPT>
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_update(xf::TableDev T, const uint32_t *__restrict__ segptr,
+                 const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
+                 const uint32_t *__restrict__ slots, uint32_t U, uint32_t R,
+                 float *__restrict__ g_out) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += stride) {
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    if (e - b > XF_HEAVY_SEG) continue;  // k_lr_grad_heavy + k_update_listed
+    const uint32_t slot = slots[u];
+    float w = T.w[slot], nn = 0.f, z = 0.f;
+    if (OPT == XF_OPT_FTRL) {
+      nn = T.n[slot];
+      z = T.z[slot];
+    }
+    double acc = 0.0;
+    for (uint32_t j = b; j < e; ++j) acc += (double)loss[coo_row[j]];
+    const float g = (float)((double)(float)acc / (1.0 * R));
+    g_out[u] = g;
+    if (OPT == XF_OPT_FTRL) {
+      xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+      T.w[slot] = w;
+      T.n[slot] = nn;
+      T.z[slot] = z;
+    } else {
+      T.w[slot] = xf::sgd_step(T.lr, g, w);
+    }
+  }
+}
+
+// the optimizer step for a listed subset of keys (the heavy ones)
+template <int OPT>
+__global__ void __launch_bounds__(kBlock)
+k_update_listed(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t H,
+                const uint32_t *__restrict__ slots, const float *__restrict__ g) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const uint32_t u = list[h], slot = slots[u];
+  if (OPT == XF_OPT_FTRL) {
+    float w = T.w[slot], nn = T.n[slot], z = T.z[slot];
+    xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g[u], w, nn, z);
+    T.w[slot] = w;
+    T.n[slot] = nn;
+    T.z[slot] = z;
+  } else {
+    T.w[slot] = xf::sgd_step(T.lr, g[u], T.w[slot]);
   }
 }
 
@@ -224,6 +325,21 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   XF_REQUIRE(b && d_wu && d_loss, "xf_lr_forward_dev: null argument");
   if (b->R == 0) return XF_OK;
   const double avg = (double)b->NNZ / b->R;
+  if (b->P >= 8 && b->pptr && b->pidx && b->fwd_scratch) {
+    const int grid = 8 * 256;  // 256 blocks per XCD
+    const double cell = avg / b->P;  // nonzeros per (row,panel) cell
+    if (cell <= 10.0)
+      hipLaunchKernelGGL(k_lr_forward_panel<8>, dim3(grid), dim3(kBlock), 0, S(stream), b->pptr,
+                         b->pidx, d_wu, b->R, b->P, b->fwd_scratch);
+    else
+      hipLaunchKernelGGL(k_lr_forward_panel<16>, dim3(grid), dim3(kBlock), 0, S(stream), b->pptr,
+                         b->pidx, d_wu, b->R, b->P, b->fwd_scratch);
+    XF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
+    XF_HIP(hipGetLastError());
+    return XF_OK;
+  }
   if (avg <= 48.0) {  // short rows: four examples per wavefront
     hipLaunchKernelGGL(k_lr_forward<16>, dim3(blocks_for_groups(b->R, kBlock / 16)),
                        dim3(kBlock), 0, S(stream), b->rowptr, b->uidx, d_wu, b->labels, b->R,
@@ -248,6 +364,38 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
     hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
                        dim3(kBlock), 0, S(stream), b->heavy, b->H, b->segptr, b->coo_row,
                        d_loss, b->R, d_g);
+    XF_HIP(hipGetLastError());
+  }
+  return XF_OK;
+}
+
+extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const uint32_t *d_slots,
+                                     const float *d_loss, float *d_g, void *stream) {
+  XF_REQUIRE(t && b && d_slots && d_loss && d_g, "xf_lr_grad_update_dev: null argument");
+  XF_REQUIRE(xf::table_dim(t) == 1, "xf_lr_grad_update_dev: dim must be 1");
+  if (b->U == 0) return XF_OK;
+  const xf::TableDev &T = xf::table_dev(t);
+  const bool ftrl = T.n != nullptr;
+  const dim3 g(blocks_for_groups(b->U, kBlock)), blk(kBlock);
+  if (ftrl)
+    hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_FTRL>, g, blk, 0, S(stream), T, b->segptr,
+                       b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
+  else
+    hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_SGD>, g, blk, 0, S(stream), T, b->segptr,
+                       b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
+  XF_HIP(hipGetLastError());
+  if (b->H) {
+    hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), b->heavy, b->H, b->segptr, b->coo_row,
+                       d_loss, b->R, d_g);
+    XF_HIP(hipGetLastError());
+    const dim3 gh((b->H + kBlock - 1) / kBlock);
+    if (ftrl)
+      hipLaunchKernelGGL(k_update_listed<XF_OPT_FTRL>, gh, blk, 0, S(stream), T, b->heavy, b->H,
+                         d_slots, d_g);
+    else
+      hipLaunchKernelGGL(k_update_listed<XF_OPT_SGD>, gh, blk, 0, S(stream), T, b->heavy, b->H,
+                         d_slots, d_g);
     XF_HIP(hipGetLastError());
   }
   return XF_OK;
@@ -311,6 +459,9 @@ struct xf_workspace {
   double ms_sum[kEvCount] = {};
   long steps_timed = 0;
   bool ev_pending = false;
+  int nseg = 0;                 // segments recorded by the pending step
+  int seg_slot[kEvCount] = {};  // segment k is accounted to ms_sum[seg_slot[k]]
+  int nmark = 0;
 };
 
 static int ws_reserve(xf_workspace *ws, size_t U, size_t UK, size_t R) {
@@ -364,11 +515,11 @@ extern "C" int xf_workspace_destroy(xf_workspace *ws) {
 
 static int ws_collect(xf_workspace *ws) {  // fold the pending events into the sums
   if (!ws->ev_pending) return XF_OK;
-  XF_HIP(hipEventSynchronize(ws->ev[kEvCount]));
-  for (int i = 0; i < kEvCount; ++i) {
+  XF_HIP(hipEventSynchronize(ws->ev[ws->nseg]));
+  for (int i = 0; i < ws->nseg; ++i) {
     float ms = 0.f;
     XF_HIP(hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]));
-    ws->ms_sum[i] += ms;
+    ws->ms_sum[ws->seg_slot[i]] += ms;
   }
   ++ws->steps_timed;
   ws->ev_pending = false;
@@ -398,9 +549,23 @@ extern "C" int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long 
   return XF_OK;
 }
 
-#define XF_MARK(i)                                                    \
-  do {                                                                \
-    if (ws->profiling) XF_HIP(hipEventRecord(ws->ev[i], S(stream)));  \
+// XF_BEGIN opens the step's first segment; XF_END(slot) closes the running segment,
+// accounting it to ms_sum[slot], and opens the next one.  One event per boundary.
+#define XF_BEGIN()                                                      \
+  do {                                                                  \
+    if (ws->profiling) {                                                \
+      ws->nmark = 0;                                                    \
+      XF_HIP(hipEventRecord(ws->ev[0], S(stream)));                     \
+    }                                                                   \
+  } while (0)
+#define XF_END(slot)                                                    \
+  do {                                                                  \
+    if (ws->profiling) {                                                \
+      ws->seg_slot[ws->nmark] = (slot);                                 \
+      ++ws->nmark;                                                      \
+      XF_HIP(hipEventRecord(ws->ev[ws->nmark], S(stream)));             \
+      ws->nseg = ws->nmark;                                             \
+    }                                                                   \
   } while (0)
 
 // ---------------------------------------------------------------------------- fused steps
@@ -413,17 +578,13 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   const xf_dev_batch &v = b->view;
   ws->lastU = b->U;
   ws->lastR = b->R;
-  XF_MARK(0);
-  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, stream));  // Pull: lr_worker.cc:170
-  XF_MARK(1);
-  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, stream));
-  XF_MARK(2);
+  XF_BEGIN();  // Pull (lr_worker.cc:170): key -> slot and the weight payload in one pass
+  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, stream));
+  XF_END(kEvResolve);
   XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, nullptr, stream));  // :172
-  XF_MARK(3);
-  XF_TRY(xf_lr_grad_dev(&v, ws->loss, ws->g, stream));               // :173
-  XF_MARK(4);
-  XF_TRY(xf_table_update_dev(w, ws->slots, v.U, ws->g, stream));     // Push: :175
-  XF_MARK(5);
+  XF_END(kEvForward);  // gradient (:173) + Push (:175) in one pass: the table is on this GPU
+  XF_TRY(xf_lr_grad_update_dev(w, &v, ws->slots, ws->loss, ws->g, stream));
+  XF_END(kEvGrad);
   if (ws->profiling) ws->ev_pending = true;
   return XF_OK;
 }
@@ -440,20 +601,19 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   ws->lastU = b->U;
   ws->lastR = b->R;
   // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself
-  XF_MARK(0);
-  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, stream));
+  XF_BEGIN();
+  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, stream));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, stream));
-  XF_MARK(1);
-  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, stream));
+  XF_END(kEvResolve);
   XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, stream));
-  XF_MARK(2);
+  XF_END(kEvGather);
   XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));  // :237
-  XF_MARK(3);
+  XF_END(kEvForward);
   XF_TRY(xf_fm_grad_dev(&v, k, ws->vu, ws->vsum, ws->loss, ws->g, ws->gv, stream));      // :238
-  XF_MARK(4);
+  XF_END(kEvGrad);
   XF_TRY(xf_table_update_dev(w, ws->slots, v.U, ws->g, stream));     // two Pushes: :241-242
   XF_TRY(xf_table_update_dev(vt, ws->slots2, v.U, ws->gv, stream));
-  XF_MARK(5);
+  XF_END(kEvUpdate);
   if (ws->profiling) ws->ev_pending = true;
   return XF_OK;
 }
@@ -465,8 +625,7 @@ extern "C" int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *
   XF_TRY(xf_batch_upload(b, nullptr));
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
   const xf_dev_batch &v = b->view;
-  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, nullptr));
-  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, nullptr));
+  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
   XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, ws->pctr, nullptr));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
   return xf_table_check(w, nullptr);
@@ -479,9 +638,8 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
   XF_TRY(xf_batch_upload(b, nullptr));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
   const xf_dev_batch &v = b->view;
-  XF_TRY(xf_table_resolve_dev(w, v.ukeys, v.U, ws->slots, nullptr));
+  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, nullptr));
-  XF_TRY(xf_table_gather_dev(w, ws->slots, v.U, ws->wu, nullptr));
   XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, nullptr));
   XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, ws->pctr, ws->vsum, nullptr));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));

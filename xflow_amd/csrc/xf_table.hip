@@ -44,48 +44,65 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 // key -> slot with insert-on-miss: `store[key]` of ftrl.h:56 / sgd.h:46, first-touch init
 // of ftrl.h:112-121 / sgd.h:67-72.  One key per lane; with a sorted key list the probes
-// of a wave land in one neighbourhood of keys[].
+// of a wave land in one neighbourhood of keys[].  Each probe round reads a window of
+// kWin consecutive slots with independent loads (one memory round trip instead of up to
+// kWin dependent ones): a wavefront waits for its slowest lane, and the longest of 64
+// linear-probe chains is several slots even at load 0.5.
+// GATHER (dim == 1, keys unique within the launch): also emit the Pull payload w[slot]
+// (ftrl.h:75-77), saving the separate gather pass over the slots.
+constexpr int kWin = 4;
+
+template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
-          uint32_t *__restrict__ slots) {
+          uint32_t *__restrict__ slots, float *__restrict__ wu) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint64_t key = keys[i];
     bool inserted = false;
-    uint32_t slot;
+    uint32_t slot = (uint32_t)T.cap;
     if (key == xf::kEmptyKey) {  // reserved value lives in the spare slot
-      slot = (uint32_t)T.cap;
       inserted = atomicExch(&T.stat->spare_used, 1u) == 0u;
       if (inserted) T.keys[T.cap] = key;
+    } else if (!xf::owns(T, key)) {
+      atomicOr(&T.stat->err, xf::kErrForeignKey);
+      slots[i] = slot;
+      if (GATHER) wu[i] = 0.0f;
+      continue;
     } else {
-      if (!xf::owns(T, key)) {
-        atomicOr(&T.stat->err, xf::kErrForeignKey);
-        slots[i] = (uint32_t)T.cap;
-        continue;
-      }
       uint64_t pos = xf::home_of(T, key);
-      uint64_t probes = 0;
-      slot = (uint32_t)T.cap;
-      while (probes < T.cap) {
-        uint64_t cur = T.keys[pos];
-        if (cur == xf::kEmptyKey) {
-          // claim; the atomic is served at the coherent point, so a stale EMPTY read
-          // (other XCD inserted meanwhile) is corrected by the returned value
-          cur = atomicCAS((unsigned long long *)&T.keys[pos], xf::kEmptyKey, key);
-          if (cur == xf::kEmptyKey) {
-            inserted = true;
-            slot = (uint32_t)pos;
-            break;
+      bool done = false;
+      for (uint64_t probes = 0; probes < T.cap && !done; probes += kWin) {
+        uint64_t idx[kWin], cur[kWin];
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+          idx[t] = pos + t;
+          if (idx[t] >= T.cap) idx[t] -= T.cap;
+        }
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) cur[t] = T.keys[idx[t]];
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+          if (done) break;
+          uint64_t c = cur[t];
+          if (c == xf::kEmptyKey) {
+            // claim; the atomic is served at the coherent point, so a stale EMPTY read
+            // (another XCD inserted meanwhile) is corrected by the returned value
+            c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key);
+            if (c == xf::kEmptyKey) {
+              inserted = true;
+              c = key;
+            }
+          }
+          if (c == key) {
+            slot = (uint32_t)idx[t];
+            done = true;
           }
         }
-        if (cur == key) {
-          slot = (uint32_t)pos;
-          break;
-        }
-        ++probes;
-        if (++pos == T.cap) pos = 0;
+        pos = idx[kWin - 1] + 1;
+        if (pos >= T.cap) pos -= T.cap;
       }
-      if (slot == (uint32_t)T.cap) atomicOr(&T.stat->err, xf::kErrFull);
+      if (!done) atomicOr(&T.stat->err, xf::kErrFull);
     }
     if (inserted) {
       if (slot != (uint32_t)T.cap) atomicAdd(&T.stat->count, 1ull);  // spare counted apart
@@ -97,6 +114,7 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       }
     }
     slots[i] = slot;
+    if (GATHER) wu[i] = T.w[slot];
   }
 }
 
@@ -386,8 +404,21 @@ extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t 
                                     uint32_t *d_slots, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_keys && d_slots)), "xf_table_resolve_dev: null argument");
   if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_resolve, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T, d_keys,
-                     n, d_slots);
+  hipLaunchKernelGGL(k_resolve<false>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
+                     d_keys, n, d_slots, (float *)nullptr);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+// Pull in one pass: resolve + the weight payload, for dim-1 tables and key lists that are
+// unique within the call (the worker's sorted unique key list).
+extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
+                                 uint32_t *d_slots, float *d_vals, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys && d_slots && d_vals)), "xf_table_pull_dev: null argument");
+  XF_REQUIRE(t->T.dim == 1, "xf_table_pull_dev: dim must be 1 (use resolve + gather)");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_resolve<true>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
+                     d_keys, n, d_slots, d_vals);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }

@@ -86,6 +86,14 @@ class HipStages:
         for n in ("rowptr", "uidx", "ukeys", "segptr", "coo_row", "labels"):
             setattr(v, n, b.t[n].data_ptr())
         v.heavy = b.t["heavy"].data_ptr() if b.H else None
+        P, pptr, pidx = hb.panels()
+        v.P = P
+        if P:
+            b.t["pptr"] = self.from_numpy(pptr.view(np.int32))
+            b.t["pidx"] = self.from_numpy(pidx.view(np.int32))
+            b.t["fwd_scratch"] = self.empty(P * b.R, torch.float64)
+            v.pptr, v.pidx = b.t["pptr"].data_ptr(), b.t["pidx"].data_ptr()
+            v.fwd_scratch = b.t["fwd_scratch"].data_ptr()
         b.view = v
         b.ukeys = b.t["ukeys"]
         return b
