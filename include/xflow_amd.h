@@ -69,6 +69,8 @@ int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
  *   COO grouped by key: segptr[U+1], coo_row[NNZ]  (row ids of each key's occurrences)
  *   heavy[H]: indices u whose segment is longer than XF_HEAVY_SEG (wave-per-key path) */
 #define XF_HEAVY_SEG 64
+#define XF_TILE_NNZ 2048
+#define XF_TILE_KEYS 2048
 typedef struct xf_batch xf_batch; /* host arrays + (after upload) device mirror */
 int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                      const int32_t *labels, size_t row_begin, size_t row_end);
@@ -82,6 +84,10 @@ int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const uint32_t **ro
 /* panel view (host arrays); *P == 0 when the batch is too small to need panels */
 int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
                     const uint32_t **pidx);
+int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
+                       const uint32_t **order);
+/* gradient tiles (host array, ntiles+1 key indices) */
+int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr);
 /* tuning knobs (process-wide): "panel_slice_bytes" (default 1.5 MiB: w_u bytes per panel),
  * "min_panel_nnz" (default 4e6: smaller batches keep the plain CSR forward) */
 int xf_tune(const char *name, double value);
@@ -102,10 +108,21 @@ typedef struct {
    * Panel p holds the nonzeros whose uidx lies in [U*p/P, U*(p+1)/P): row r's part is
    * pidx[pptr[p*(R+1)+r] .. pptr[p*(R+1)+r+1]).  Blocks working on panel p gather from
    * one L2-sized slice of w_u; p % 8 selects the XCD. */
-  uint32_t P, pad_;
+  uint32_t P, fwd_ntiles;
   const uint32_t *pptr;    /* P*(R+1) */
   const uint32_t *pidx;    /* NNZ     */
   double *fwd_scratch;     /* P*R partial sums (device scratch owned by the batch) */
+  /* forward tiles over the (panel,row) cells s = p*(R+1)+r: tile t = cells
+   * [fwd_tile_ptr[t], fwd_tile_ptr[t+1]) of ONE panel, <= XF_TILE_NNZ nonzeros;
+   * fwd_order[b] = tile of workgroup b (panel p's tiles go to workgroups b with b%8 == p%8) */
+  const uint32_t *fwd_tile_ptr; /* fwd_ntiles+1 */
+  const uint32_t *fwd_order;    /* fwd_ntiles   */
+  /* gradient tiles: tile t covers keys [tile_ptr[t], tile_ptr[t+1]) whose occurrences
+   * (<= XF_TILE_NNZ of them, <= XF_TILE_KEYS keys) are staged through LDS by one
+   * workgroup; a heavy key (> XF_HEAVY_SEG occurrences) is a tile of its own, skipped by
+   * the tile kernel and handled by the wave-per-key path. */
+  uint32_t ntiles, pad2_;
+  const uint32_t *tile_ptr; /* ntiles+1 */
 } xf_dev_batch;
 int xf_batch_dev_view(const xf_batch *b, xf_dev_batch *view);
 

@@ -192,3 +192,50 @@ def test_forward_panels_partition_the_csr():
         assert sorted(np.concatenate(got).tolist()) == sorted(row.tolist())
     small = capi.Batch(rowptr, keys, labels)
     assert small.panels()[0] == 0               # default: small batches keep the plain CSR
+
+
+def test_gradient_tiles_cover_the_keys():
+    rng = np.random.RandomState(21)
+    R = 6000
+    lens = rng.randint(0, 30, size=R)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    fid = np.minimum(rng.zipf(1.3, size=int(lens.sum())), 5000)   # heavy heads
+    keys = fid.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    b = capi.Batch(rowptr, keys, rng.randint(0, 2, size=R).astype(np.int32))
+    h, tp = b.host(), b.tiles()
+    assert tp[0] == 0 and tp[-1] == b.U and np.all(np.diff(tp) > 0)
+    seg = np.diff(h["segptr"])
+    assert b.H > 0
+    for a, e in zip(tp[:-1], tp[1:]):
+        nnz = int(h["segptr"][e] - h["segptr"][a])
+        if e - a == 1 and seg[a] > capi.HEAVY_SEG:
+            continue                       # heavy key: a tile of its own
+        assert nnz <= 2048 and e - a <= 2048 and np.all(seg[a:e] <= capi.HEAVY_SEG)
+
+
+def test_forward_tiles_cover_every_cell_once():
+    rng = np.random.RandomState(13)
+    rowptr, keys, labels = _random_csr(rng, 500, 40, 4000)
+    capi.tune("min_panel_nnz", 0)
+    capi.tune("panel_slice_bytes", 2048)
+    try:
+        b = capi.Batch(rowptr, keys, labels)
+    finally:
+        capi.tune("min_panel_nnz", 4e6)
+        capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+    P, pptr, pidx = b.panels()
+    tp, order = b.fwd_tiles()
+    nt = len(order)
+    assert sorted(order.tolist()) == list(range(nt))          # a permutation of the tiles
+    assert tp[0] == 0 and tp[-1] == (P - 1) * (b.R + 1) + b.R and np.all(np.diff(tp) > 0)
+    seen = np.zeros(P * (b.R + 1), dtype=np.int32)
+    for a, e in zip(tp[:-1], tp[1:]):
+        assert a // (b.R + 1) == (e - 1) // (b.R + 1)          # one panel per tile
+        assert pptr[e] - pptr[a] <= 2048 or e - a == 1
+        seen[a:e] += 1
+    cells = seen.reshape(P, b.R + 1)
+    assert np.all(cells[:, :b.R] == 1)
+    # XCD affinity: workgroup w gets a tile of a panel p with p % 8 == w % 8 (when available)
+    panel_of_tile = tp[:-1] // (b.R + 1)
+    match = sum(int(panel_of_tile[order[w]] % 8 == w % 8) for w in range(nt))
+    assert match >= 0.9 * nt

@@ -158,7 +158,7 @@ def test_table_full_is_reported_and_reserve_rehashes():
     t = capi.Table(capi.OPT_FTRL, 1, capacity=256)
     with pytest.raises(capi.XFError, match="table full"):
         t.pull(keys)
-    t2 = capi.Table(capi.OPT_FTRL, 1, capacity=512)
+    t2 = capi.Table(capi.OPT_FTRL, 1, capacity=1024)
     s = O.Store(O.OPT_FTRL, 1)
     g = np.random.RandomState(3).randn(400).astype(np.float32)
     t2.push(keys, g)
@@ -187,6 +187,25 @@ def test_sharded_ownership_bit_exact():
         with pytest.raises(capi.XFError, match="outside shard"):
             t.pull(other)
     assert total == len(keys)
+
+
+def test_rows_are_dense_and_survive_reserve():
+    """State rows are handed out densely on first touch and keep their numbers when the
+    key index is rehashed (so a row array from an earlier resolve stays valid)."""
+    import ctypes as C
+    import torch
+    keys = np.sort(np.array([O.hash_str(str(i)) for i in range(3000)], dtype=np.uint64))
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=8192)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    r1 = torch.empty(len(keys), dtype=torch.int32, device="cuda")
+    t.resolve_dev(dk.data_ptr(), len(keys), r1.data_ptr())
+    t.check()
+    assert sorted(r1.cpu().tolist()) == list(range(3000))
+    t.reserve(1 << 16)
+    r2 = torch.empty_like(r1)
+    t.resolve_dev(dk.data_ptr(), len(keys), r2.data_ptr())
+    t.check()
+    assert torch.equal(r1, r2) and len(t) == 3000
 
 
 def test_export_import_roundtrip():

@@ -38,8 +38,10 @@ class TableConfig(C.Structure):
 class DevBatch(C.Structure):
     _fields_ = [("R", C.c_uint32), ("NNZ", C.c_uint32), ("U", C.c_uint32), ("H", C.c_uint32),
                 ("rowptr", vp), ("uidx", vp), ("ukeys", vp), ("segptr", vp), ("coo_row", vp),
-                ("labels", vp), ("heavy", vp), ("P", C.c_uint32), ("pad_", C.c_uint32),
-                ("pptr", vp), ("pidx", vp), ("fwd_scratch", vp)]
+                ("labels", vp), ("heavy", vp), ("P", C.c_uint32), ("fwd_ntiles", C.c_uint32),
+                ("pptr", vp), ("pidx", vp), ("fwd_scratch", vp), ("fwd_tile_ptr", vp),
+                ("fwd_order", vp), ("ntiles", C.c_uint32),
+                ("pad2_", C.c_uint32), ("tile_ptr", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/xflow_amd.h declares
@@ -63,6 +65,8 @@ SIGNATURES = {
                                 C.POINTER(u32p)]),
     "xf_batch_panels": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
     "xf_tune": (C.c_int, [C.c_char_p, C.c_double]),
+    "xf_batch_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p)]),
+    "xf_batch_fwd_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
     "xf_batch_upload": (C.c_int, [vp, vp]),
     "xf_batch_dev_view": (C.c_int, [vp, C.POINTER(DevBatch)]),
     "xf_table_config_default": (None, [C.POINTER(TableConfig)]),
@@ -222,6 +226,19 @@ class Batch:
             return 0, np.zeros(0, np.uint32), np.zeros(0, np.uint32)
         return (P.value, np.ctypeslib.as_array(pp, (P.value * (self.R + 1),)).copy(),
                 np.ctypeslib.as_array(pi, (self.NNZ,)).copy())
+
+    def fwd_tiles(self):
+        n, tp, od = C.c_uint32(0), u32p(), u32p()
+        check(lib().xf_batch_fwd_tiles(self.h, C.byref(n), C.byref(tp), C.byref(od)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        return (np.ctypeslib.as_array(tp, (n.value + 1,)).copy(),
+                np.ctypeslib.as_array(od, (n.value,)).copy())
+
+    def tiles(self):
+        n, tp = C.c_uint32(0), u32p()
+        check(lib().xf_batch_tiles(self.h, C.byref(n), C.byref(tp)))
+        return np.ctypeslib.as_array(tp, (n.value + 1,)).copy()
 
     def upload(self, stream=None):
         check(lib().xf_batch_upload(self.h, stream))

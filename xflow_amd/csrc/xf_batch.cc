@@ -104,6 +104,75 @@ void build_panels(xf_batch *b) {
       b->pidx[cur[(size_t)panel_of(ui) * R + r]++] = ui;
     }
   b->P = P;
+  // forward tiles: consecutive cells of one panel, <= XF_TILE_NNZ nonzeros / XF_TILE_KEYS cells
+  b->ftile_ptr.clear();
+  std::vector<uint32_t> panel_first(P + 1, 0);
+  for (uint32_t p = 0; p < P; ++p) {
+    panel_first[p] = (uint32_t)b->ftile_ptr.size();
+    const uint32_t s0 = (uint32_t)((size_t)p * (R + 1));
+    uint32_t start = 0, nnz = 0;
+    b->ftile_ptr.push_back(s0);
+    for (uint32_t r = 0; r < R; ++r) {
+      const uint32_t len = b->pptr[s0 + r + 1] - b->pptr[s0 + r];
+      if (r > start && (nnz + len > XF_TILE_NNZ || r - start == XF_TILE_KEYS)) {
+        b->ftile_ptr.push_back(s0 + r);
+        start = r;
+        nnz = 0;
+      }
+      nnz += len;
+    }
+  }
+  panel_first[P] = (uint32_t)b->ftile_ptr.size();
+  b->ftile_ptr.push_back((uint32_t)((size_t)(P - 1) * (R + 1) + R));  // end of the last panel
+  // panel p's tiles end at the start of panel p+1's first tile == p*(R+1)+R + 1 cell (empty)
+  const uint32_t nft = (uint32_t)b->ftile_ptr.size() - 1;
+  // workgroup -> tile: XCD x (= workgroup % 8) walks the tiles of panels p % 8 == x in order
+  b->forder.assign(nft, 0);
+  std::vector<std::vector<uint32_t>> lists(8);
+  for (uint32_t p = 0; p < P; ++p)
+    for (uint32_t t = panel_first[p]; t < panel_first[p + 1]; ++t) lists[p & 7].push_back(t);
+  b->forder.assign(nft, 0xFFFFFFFFu);
+  std::vector<uint32_t> spill;
+  for (uint32_t x = 0; x < 8; ++x) {
+    uint32_t w = x;
+    for (uint32_t t : lists[x]) {
+      if (w < nft) {
+        b->forder[w] = t;
+        w += 8;
+      } else {
+        spill.push_back(t);
+      }
+    }
+  }
+  for (uint32_t w = 0; w < nft && !spill.empty(); ++w)
+    if (b->forder[w] == 0xFFFFFFFFu) {
+      b->forder[w] = spill.back();
+      spill.pop_back();
+    }
+}
+
+// Gradient tiles: consecutive key ranges whose occurrence lists fit one workgroup's LDS.
+void build_tiles(xf_batch *b) {
+  b->tile_ptr.clear();
+  b->tile_ptr.push_back(0);
+  uint32_t start = 0, nnz = 0;
+  for (uint32_t u = 0; u < b->U; ++u) {
+    const uint32_t len = b->segptr[u + 1] - b->segptr[u];
+    if (len > XF_HEAVY_SEG) {  // a tile of its own
+      if (u > start) b->tile_ptr.push_back(u);
+      b->tile_ptr.push_back(u + 1);
+      start = u + 1;
+      nnz = 0;
+      continue;
+    }
+    if (nnz + len > XF_TILE_NNZ || u - start == XF_TILE_KEYS) {
+      b->tile_ptr.push_back(u);
+      start = u;
+      nnz = 0;
+    }
+    nnz += len;
+  }
+  if (b->U > start) b->tile_ptr.push_back(b->U);
 }
 
 }  // namespace
@@ -114,6 +183,22 @@ extern "C" int xf_tune(const char *name, double value) {
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
   else
     return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);
+  return XF_OK;
+}
+
+extern "C" int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr) {
+  XF_REQUIRE(b && ntiles, "xf_batch_tiles: null argument");
+  *ntiles = (uint32_t)(b->tile_ptr.size() - 1);
+  if (tile_ptr) *tile_ptr = b->tile_ptr.data();
+  return XF_OK;
+}
+
+extern "C" int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
+                                  const uint32_t **order) {
+  XF_REQUIRE(b && ntiles, "xf_batch_fwd_tiles: null argument");
+  *ntiles = b->P ? (uint32_t)b->ftile_ptr.size() - 1 : 0;
+  if (tile_ptr) *tile_ptr = b->ftile_ptr.data();
+  if (order) *order = b->forder.data();
   return XF_OK;
 }
 
@@ -170,6 +255,7 @@ extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const ui
     if (b->segptr[u + 1] - b->segptr[u] > XF_HEAVY_SEG) b->heavy.push_back(u);
   b->H = (uint32_t)b->heavy.size();
   build_panels(b);
+  build_tiles(b);
   *out = b;
   return XF_OK;
 }
@@ -220,7 +306,10 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   const size_t o_pptr = o_heavy + al((size_t)b->H * 4);
   const size_t o_pidx = o_pptr + al((size_t)b->P * ((size_t)b->R + 1) * 4);
   const size_t o_scr = o_pidx + al(b->P ? (size_t)b->NNZ * 4 : 0);
-  const size_t total = o_scr + al((size_t)b->P * b->R * 8) + 256;
+  const size_t o_tile = o_scr + al((size_t)b->P * b->R * 8);
+  const size_t o_ftile = o_tile + al(b->tile_ptr.size() * 4);
+  const size_t o_forder = o_ftile + al(b->ftile_ptr.size() * 4);
+  const size_t total = o_forder + al(b->forder.size() * 4) + 256;
   char *d = nullptr;
   XF_HIP(hipMalloc((void **)&d, total));
   hipStream_t s = (hipStream_t)stream;
@@ -239,6 +328,11 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
     XF_HIP(put(o_pptr, b->pptr.data(), b->pptr.size() * 4));
     XF_HIP(put(o_pidx, b->pidx.data(), b->pidx.size() * 4));
   }
+  XF_HIP(put(o_tile, b->tile_ptr.data(), b->tile_ptr.size() * 4));
+  if (b->P) {
+    XF_HIP(put(o_ftile, b->ftile_ptr.data(), b->ftile_ptr.size() * 4));
+    XF_HIP(put(o_forder, b->forder.data(), b->forder.size() * 4));
+  }
   XF_HIP(hipStreamSynchronize(s));  // host vectors are pageable: finish before returning
   b->d_blob = d;
   b->view.R = b->R;
@@ -253,10 +347,15 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   b->view.labels = (const int32_t *)(d + o_labels);
   b->view.heavy = b->H ? (const uint32_t *)(d + o_heavy) : nullptr;
   b->view.P = b->P;
-  b->view.pad_ = 0;
+  b->view.fwd_ntiles = b->P ? (uint32_t)b->ftile_ptr.size() - 1 : 0;
+  b->view.fwd_tile_ptr = b->P ? (const uint32_t *)(d + o_ftile) : nullptr;
+  b->view.fwd_order = b->P ? (const uint32_t *)(d + o_forder) : nullptr;
   b->view.pptr = b->P ? (const uint32_t *)(d + o_pptr) : nullptr;
   b->view.pidx = b->P ? (const uint32_t *)(d + o_pidx) : nullptr;
   b->view.fwd_scratch = b->P ? (double *)(d + o_scr) : nullptr;
+  b->view.ntiles = (uint32_t)(b->tile_ptr.size() - 1);
+  b->view.pad2_ = 0;
+  b->view.tile_ptr = (const uint32_t *)(d + o_tile);
   return XF_OK;
 }
 

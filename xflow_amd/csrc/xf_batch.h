@@ -12,6 +12,8 @@ struct xf_batch {
   std::vector<uint32_t> rowptr, uidx, segptr, coo_row, heavy;
   uint32_t P = 0;  // forward panels (0 = none)
   std::vector<uint32_t> pptr, pidx;
+  std::vector<uint32_t> tile_ptr;  // gradient tiles (key ranges)
+  std::vector<uint32_t> ftile_ptr, forder;  // forward tiles over (panel,row) cells
   std::vector<int32_t> labels;
   void *d_blob = nullptr;  // one device allocation holding all arrays
   xf_dev_batch view{};

@@ -12,23 +12,27 @@
 namespace xf {
 
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr unsigned kErrFull = 1u;
 constexpr unsigned kErrForeignKey = 2u;
+constexpr unsigned kErrDupKey = 4u;
 
 struct TableStat {
-  unsigned long long count;  // keys inserted (excluding the spare slot)
+  unsigned long long count;  // state rows handed out == keys stored
   unsigned int err;          // kErr* bits, sticky
   unsigned int spare_used;   // the reserved key value has been stored
 };
 
 struct TableDev {
-  uint64_t cap;   // slots; slot `cap` is the spare one
-  uint64_t lo;    // first key of this shard's range
-  uint64_t span;  // UINT64_MAX / nshards
-  uint64_t mult;  // floor(cap * 2^64 / span)
+  uint64_t cap;       // positions of the key index; position `cap` is the spare one
+  uint64_t max_rows;  // state rows allocated; row `max_rows` is a write-off row for errors
+  uint64_t lo;        // first key of this shard's range
+  uint64_t span;      // UINT64_MAX / nshards
+  uint64_t mult;      // floor(cap * 2^64 / span)
   uint64_t seed;
-  uint64_t *keys;
-  float *w, *n, *z;
+  uint64_t *keys;     // [cap+1]   key index (open addressing, order-preserving home)
+  uint32_t *rows;     // [cap+1]   state row of the key stored at that position
+  float *w, *n, *z;   // [(max_rows+1)*dim] dense state, row-major
   TableStat *stat;
   int dim, init_kind;
   float init_const;

@@ -82,8 +82,7 @@ k_lr_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
 // dispatcher places on XCD x — work only on panels p with p % 8 == x, panel after panel, so
 // each XCD's L2 holds the 1/P slice of w_u it is gathering from.  A (row, panel) cell is
 // summed by a G-lane group; the P partial sums of a row are added in panel order by
-// k_lr_finalize (deterministic).  The index stream is read with non-temporal loads so it
-// does not evict the slice.  Placement is a performance assumption only.
+// k_lr_finalize (deterministic).  Placement is a performance assumption only.
 template <int G>
 __global__ void __launch_bounds__(kBlock)
 k_lr_forward_panel(const uint32_t *__restrict__ pptr, const uint32_t *__restrict__ pidx,
@@ -102,9 +101,57 @@ k_lr_forward_panel(const uint32_t *__restrict__ pptr, const uint32_t *__restrict
     const uint32_t b = pp[0], e = pp[1];
     double acc = 0.0;
     for (uint32_t j = b + lane; j < e; j += G)
-      acc += (double)wu[__builtin_nontemporal_load(pidx + j)];
+      acc += (double)wu[pidx[j]];
     acc = group_sum<G>(acc);
     if (lane == 0) partial[(size_t)p * R + r] = acc;
+  }
+}
+
+// Tiled form of the panel forward: a workgroup takes a run of (panel,row) cells holding
+// <= XF_TILE_NNZ nonzeros, gathers w_u[pidx[j]] for all of them at once into LDS (one
+// coalesced index read, every lane with independent gathers in flight), then one lane per
+// cell adds the cell's short run in fp64.  fwd_order sends panel p's tiles to workgroups
+// b with b % 8 == p % 8 (observed: XCD b % 8), so an XCD's L2 holds its panels' w_u slices.
+__global__ void __launch_bounds__(kBlock)
+k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ order,
+                   uint32_t ntiles, const uint32_t *__restrict__ pptr,
+                   const uint32_t *__restrict__ pidx, const float *__restrict__ wu, uint32_t R,
+                   double *__restrict__ partial) {
+  __shared__ float vals[XF_TILE_NNZ];
+  __shared__ uint32_t sp[XF_TILE_KEYS + 2];
+  __shared__ double red[kBlock / 64];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
+    const uint32_t tile = order[b];
+    const uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1], ns = sb - sa;
+    const uint32_t p = sa / (R + 1), r0 = sa - p * (R + 1);
+    const uint32_t j0 = pptr[sa], j1 = pptr[sb];
+    if (j1 - j0 > XF_TILE_NNZ) {  // one oversized cell (a row with > XF_TILE_NNZ nonzeros)
+      double acc = 0.0;
+      for (uint32_t j = j0 + tid; j < j1; j += kBlock) acc += (double)wu[pidx[j]];
+      acc = group_sum<64>(acc);
+      if ((tid & 63) == 0) red[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        double s = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) s += red[k];
+        partial[(size_t)p * R + r0] = s;
+      }
+      __syncthreads();
+      continue;
+    }
+    for (uint32_t k = tid; k <= ns; k += kBlock) sp[k] = pptr[sa + k] - j0;
+    for (uint32_t j = j0 + tid; j < j1; j += kBlock) vals[j - j0] = wu[pidx[j]];
+    __syncthreads();
+    for (uint32_t k = tid; k < ns; k += kBlock) {
+      const uint32_t r = r0 + k;
+      if (r < R) {  // r == R is the empty cell between two panels
+        double acc = 0.0;
+        for (uint32_t j = sp[k]; j < sp[k + 1]; ++j) acc += (double)vals[j];
+        partial[(size_t)p * R + r] = acc;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -185,6 +232,78 @@ k_lr_grad_update(xf::TableDev T, const uint32_t *__restrict__ segptr,
     } else {
       T.w[slot] = xf::sgd_step(T.lr, g, w);
     }
+  }
+}
+
+// LDS-tiled gradient (optionally fused with the Push).  The per-key kernels above walk a
+// key's occurrences with a chain of dependent global loads (coo_row[j] -> loss[row]), and a
+// wavefront waits for its longest chain.  Here a workgroup takes a tile of consecutive keys
+// whose occurrence lists total <= XF_TILE_NNZ entries: phase 1 stages loss[coo_row[j]] for
+// the whole tile into LDS with one coalesced read of coo_row[] and one round of gathers, all
+// lanes busy; phase 2 sums each key's (short) run out of LDS in fp64 and, when UPDATE, applies
+// the optimizer step to the key's state row, whose words were requested before the sums.
+constexpr int kKeysPerThread = XF_TILE_KEYS / kBlock;
+
+template <int OPT, bool UPDATE>
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t ntiles,
+                const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
+                const float *__restrict__ loss, const uint32_t *__restrict__ slots, uint32_t R,
+                float *__restrict__ g_out) {
+  __shared__ float vals[XF_TILE_NNZ];
+  __shared__ uint32_t sp[XF_TILE_KEYS + 1];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t ua = tile_ptr[tile], ub = tile_ptr[tile + 1];
+    const uint32_t nk = ub - ua;
+    const uint32_t j0 = segptr[ua], j1 = segptr[ub];
+    if (nk == 1 && j1 - j0 > XF_HEAVY_SEG) continue;  // a heavy key: wave-per-key path
+    for (uint32_t k = tid; k <= nk; k += kBlock) sp[k] = segptr[ua + k] - j0;
+    for (uint32_t j = j0 + tid; j < j1; j += kBlock)
+      vals[j - j0] = loss[coo_row[j]];
+    // state rows of this thread's keys: request them before the barrier
+    uint32_t slot[kKeysPerThread];
+    float w[kKeysPerThread], nn[kKeysPerThread], z[kKeysPerThread];
+    if (UPDATE) {
+#pragma unroll
+      for (int q = 0; q < kKeysPerThread; ++q) {
+        const uint32_t k = tid + q * kBlock;
+        slot[q] = k < nk ? slots[ua + k] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < kKeysPerThread; ++q) {
+        const uint32_t k = tid + q * kBlock;
+        if (k < nk) {
+          w[q] = T.w[slot[q]];
+          if (OPT == XF_OPT_FTRL) {
+            nn[q] = T.n[slot[q]];
+            z[q] = T.z[slot[q]];
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kKeysPerThread; ++q) {
+      const uint32_t k = tid + q * kBlock;
+      if (k < nk) {
+        double acc = 0.0;
+        for (uint32_t j = sp[k]; j < sp[k + 1]; ++j) acc += (double)vals[j];
+        const float g = (float)((double)(float)acc / (1.0 * R));
+        g_out[ua + k] = g;
+        if (UPDATE) {
+          if (OPT == XF_OPT_FTRL) {
+            xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w[q], nn[q], z[q]);
+            T.w[slot[q]] = w[q];
+            T.n[slot[q]] = nn[q];
+            T.z[slot[q]] = z[q];
+          } else {
+            T.w[slot[q]] = xf::sgd_step(T.lr, g, w[q]);
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -310,6 +429,11 @@ k_fm_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
   }
 }
 
+// one tile per workgroup while the grid stays reasonable (measured: a workgroup that walks
+// several tiles serialises their load->barrier->sum chains; 1e7 occurrences take 50 us with
+// one tile per workgroup, 58 us with five)
+inline int tile_grid(uint32_t ntiles) { return (int)std::min<uint32_t>(ntiles, 1u << 16); }
+
 inline int blocks_for_groups(uint32_t n_items, int items_per_block) {
   size_t g = ((size_t)n_items + items_per_block - 1) / items_per_block;
   if (g > 8192) g = 8192;
@@ -325,6 +449,16 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   XF_REQUIRE(b && d_wu && d_loss, "xf_lr_forward_dev: null argument");
   if (b->R == 0) return XF_OK;
   const double avg = (double)b->NNZ / b->R;
+  if (b->P >= 8 && b->fwd_ntiles && b->fwd_tile_ptr && b->fwd_order && b->fwd_scratch) {
+    hipLaunchKernelGGL(k_lr_forward_tiled, dim3(tile_grid(b->fwd_ntiles)), dim3(kBlock), 0,
+                       S(stream), b->fwd_tile_ptr, b->fwd_order, b->fwd_ntiles, b->pptr, b->pidx,
+                       d_wu, b->R, b->fwd_scratch);
+    XF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
+    XF_HIP(hipGetLastError());
+    return XF_OK;
+  }
   if (b->P >= 8 && b->pptr && b->pidx && b->fwd_scratch) {
     const int grid = 8 * 256;  // 256 blocks per XCD
     const double cell = avg / b->P;  // nonzeros per (row,panel) cell
@@ -357,8 +491,14 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
                               void *stream) {
   XF_REQUIRE(b && d_loss && d_g, "xf_lr_grad_dev: null argument");
   if (b->U == 0) return XF_OK;
-  hipLaunchKernelGGL(k_lr_grad, dim3(blocks_for_groups(b->U, kBlock)), dim3(kBlock), 0,
-                     S(stream), b->segptr, b->coo_row, d_loss, b->U, b->R, d_g);
+  if (b->ntiles && b->tile_ptr) {
+    hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_SGD, false>), dim3(tile_grid(b->ntiles)),
+                       dim3(kBlock), 0, S(stream), xf::TableDev{}, b->tile_ptr, b->ntiles,
+                       b->segptr, b->coo_row, d_loss, (const uint32_t *)nullptr, b->R, d_g);
+  } else {
+    hipLaunchKernelGGL(k_lr_grad, dim3(blocks_for_groups(b->U, kBlock)), dim3(kBlock), 0,
+                       S(stream), b->segptr, b->coo_row, d_loss, b->U, b->R, d_g);
+  }
   XF_HIP(hipGetLastError());
   if (b->H) {
     hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
@@ -377,12 +517,23 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
   const xf::TableDev &T = xf::table_dev(t);
   const bool ftrl = T.n != nullptr;
   const dim3 g(blocks_for_groups(b->U, kBlock)), blk(kBlock);
-  if (ftrl)
+  if (b->ntiles && b->tile_ptr) {
+    const dim3 gt(tile_grid(b->ntiles));
+    if (ftrl)
+      hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_FTRL, true>), gt, blk, 0, S(stream), T,
+                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, b->R,
+                         d_g);
+    else
+      hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_SGD, true>), gt, blk, 0, S(stream), T,
+                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, b->R,
+                         d_g);
+  } else if (ftrl) {
     hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_FTRL>, g, blk, 0, S(stream), T, b->segptr,
                        b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
-  else
+  } else {
     hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_SGD>, g, blk, 0, S(stream), T, b->segptr,
                        b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
+  }
   XF_HIP(hipGetLastError());
   if (b->H) {
     hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),

@@ -6,18 +6,23 @@
 // (src/optimizer/ftrl.h:38-152) and SGD::KVServerSGDHandle_{w,v} (src/optimizer/sgd.h:30-109)
 // and their std::unordered_map stores (ftrl.h:84, sgd.h:62).
 //
-// Layout in HBM (per shard, `cap` slots + 1 spare slot for the reserved key value):
-//   keys[cap+1] u64      exact keys, EMPTY = 0xFFFF'FFFF'FFFF'FFFF
-//   w[(cap+1)*dim] f32   weights (row-major [slot][dim])
-//   n,z[(cap+1)*dim] f32 FTRL accumulators (FTRL tables only)
-// The slot of a key is found by linear probing from an ORDER-PRESERVING home position
+// Layout in HBM (per shard):
+//   key index   keys[cap+1] u64, rows[cap+1] u32     open addressing, EMPTY = 2^64-1
+//               (position `cap` is a spare for the reserved key value)
+//   state       w[(max_rows+1)*dim], and for FTRL n[], z[] likewise; DENSE: a key gets the
+//               next free row on first touch and keeps it.  No slack in the state arrays
+//               (they are what Push streams through), the slack of open addressing is paid
+//               only on 12 bytes per key.
+// A key's position is found by linear probing from an ORDER-PRESERVING home
 //   home = floor((key - range_lo) * cap / range_span)
-// Keys are already uniform 64-bit hashes (io.h:53), so a linear map spreads them as well
-// as any hash — and it keeps the table (almost) sorted by key.  Pull/Push key lists are
-// sorted (the ps-lite contract), so lane i and lane i+1 of a wave probe neighbouring
-// slots: the random gather/scatter of a hash table becomes a monotone sweep over keys[],
-// w[], n[], z[] that the memory system coalesces.  Same idea as ps-lite's key-range
-// sharding across servers, continued inside the GPU.
+// Keys are already uniform 64-bit hashes (io.h:53), so a linear map spreads them as well as
+// any hash — and the index stays (almost) sorted by key.  Pull/Push key lists are sorted (the
+// ps-lite contract), so lane i and lane i+1 of a wave probe neighbouring positions: the
+// pointer-chasing unordered_map walk becomes a monotone sweep over keys[] / rows[].
+// Rows are handed out per wavefront in key order (one atomicAdd per wave): the keys a sorted
+// list inserts together occupy runs of consecutive rows, so later sorted lists touch the
+// state in contiguous runs as well.  Same idea as ps-lite's key-range sharding across
+// servers, continued inside the GPU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,6 +35,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr double kMaxLoad = 0.75;  // state rows allocated per index position
 
 inline int grid_for(size_t n) {
   size_t g = (n + kBlock - 1) / kBlock;
@@ -42,107 +48,138 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 // ---------------------------------------------------------------------------- kernels
 
-// key -> slot with insert-on-miss: `store[key]` of ftrl.h:56 / sgd.h:46, first-touch init
-// of ftrl.h:112-121 / sgd.h:67-72.  One key per lane; with a sorted key list the probes
-// of a wave land in one neighbourhood of keys[].  Each probe round reads a window of
-// kWin consecutive slots with independent loads (one memory round trip instead of up to
-// kWin dependent ones): a wavefront waits for its slowest lane, and the longest of 64
-// linear-probe chains is several slots even at load 0.5.
-// GATHER (dim == 1, keys unique within the launch): also emit the Pull payload w[slot]
-// (ftrl.h:75-77), saving the separate gather pass over the slots.
+// key -> state row with insert-on-miss: `store[key]` of ftrl.h:56 / sgd.h:46, first-touch
+// init of ftrl.h:112-121 / sgd.h:67-72.  One key per lane.  Each probe round reads a window
+// of kWin consecutive index positions with independent loads (one memory round trip instead
+// of up to kWin dependent ones: a wavefront waits for its slowest lane, and the longest of
+// 64 linear-probe chains is several positions even at load 0.5).
+// Keys must be unique within one launch (a second lane could otherwise read rows[] of a key
+// before its inserter has published the row).
+// GATHER (dim == 1): also emit the Pull payload w[row] (ftrl.h:75-77).
 constexpr int kWin = 4;
 
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
-          uint32_t *__restrict__ slots, float *__restrict__ wu) {
+          uint32_t *__restrict__ rows_out, float *__restrict__ wu) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint64_t key = keys[i];
-    bool inserted = false;
-    uint32_t slot = (uint32_t)T.cap;
-    if (key == xf::kEmptyKey) {  // reserved value lives in the spare slot
-      inserted = atomicExch(&T.stat->spare_used, 1u) == 0u;
-      if (inserted) T.keys[T.cap] = key;
-    } else if (!xf::owns(T, key)) {
-      atomicOr(&T.stat->err, xf::kErrForeignKey);
-      slots[i] = slot;
-      if (GATHER) wu[i] = 0.0f;
-      continue;
-    } else {
-      uint64_t pos = xf::home_of(T, key);
-      bool done = false;
-      for (uint64_t probes = 0; probes < T.cap && !done; probes += kWin) {
-        uint64_t idx[kWin], cur[kWin];
+  const unsigned lane = threadIdx.x & 63u;
+  // wave-uniform trip count: every lane of a wave reaches the ballot below
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    const size_t i = i0 + lane;
+    const bool active = i < n;
+    const uint64_t key = active ? keys[i] : 0;
+    bool inserted = false, bad = false;
+    uint64_t pos = T.cap;
+    if (active) {
+      if (key == xf::kEmptyKey) {  // reserved value lives at the spare position
+        inserted = atomicExch(&T.stat->spare_used, 1u) == 0u;
+        if (inserted) T.keys[T.cap] = key;
+      } else if (!xf::owns(T, key)) {
+        atomicOr(&T.stat->err, xf::kErrForeignKey);
+        bad = true;
+      } else {
+        uint64_t p = xf::home_of(T, key);
+        bool done = false;
+        for (uint64_t probes = 0; probes < T.cap && !done; probes += kWin) {
+          uint64_t idx[kWin], cur[kWin];
 #pragma unroll
-        for (int t = 0; t < kWin; ++t) {
-          idx[t] = pos + t;
-          if (idx[t] >= T.cap) idx[t] -= T.cap;
-        }
+          for (int t = 0; t < kWin; ++t) {
+            idx[t] = p + t;
+            if (idx[t] >= T.cap) idx[t] -= T.cap;
+          }
 #pragma unroll
-        for (int t = 0; t < kWin; ++t) cur[t] = T.keys[idx[t]];
+          for (int t = 0; t < kWin; ++t) cur[t] = T.keys[idx[t]];
 #pragma unroll
-        for (int t = 0; t < kWin; ++t) {
-          if (done) break;
-          uint64_t c = cur[t];
-          if (c == xf::kEmptyKey) {
-            // claim; the atomic is served at the coherent point, so a stale EMPTY read
-            // (another XCD inserted meanwhile) is corrected by the returned value
-            c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key);
+          for (int t = 0; t < kWin; ++t) {
+            if (done) break;
+            uint64_t c = cur[t];
             if (c == xf::kEmptyKey) {
-              inserted = true;
-              c = key;
+              // claim; the atomic is served at the coherent point, so a stale EMPTY read
+              // (another XCD inserted meanwhile) is corrected by the returned value
+              c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key);
+              if (c == xf::kEmptyKey) {
+                inserted = true;
+                c = key;
+              }
+            }
+            if (c == key) {
+              pos = idx[t];
+              done = true;
             }
           }
-          if (c == key) {
-            slot = (uint32_t)idx[t];
-            done = true;
-          }
+          p = idx[kWin - 1] + 1;
+          if (p >= T.cap) p -= T.cap;
         }
-        pos = idx[kWin - 1] + 1;
-        if (pos >= T.cap) pos -= T.cap;
-      }
-      if (!done) atomicOr(&T.stat->err, xf::kErrFull);
-    }
-    if (inserted) {
-      if (slot != (uint32_t)T.cap) atomicAdd(&T.stat->count, 1ull);  // spare counted apart
-      if (T.init_kind != XF_INIT_ZERO) {  // memory is pre-zeroed for XF_INIT_ZERO
-        float *row = T.w + (size_t)slot * T.dim;
-        for (int j = 0; j < T.dim; ++j)
-          row[j] = T.init_kind == XF_INIT_CONST ? T.init_const
-                                                : xf::hashnorm(T.seed, key, (uint32_t)j);
+        if (!done) {
+          atomicOr(&T.stat->err, xf::kErrFull);
+          bad = true;
+        }
       }
     }
-    slots[i] = slot;
-    if (GATHER) wu[i] = T.w[slot];
+    // hand out state rows: consecutive rows for the wave's new keys, in key order
+    uint32_t row = (uint32_t)T.max_rows;  // write-off row
+    const unsigned long long m = __ballot(inserted);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned long long base = 0;
+      if ((int)lane == leader) base = atomicAdd(&T.stat->count, (unsigned long long)__popcll(m));
+      base = __shfl(base, leader);
+      if (inserted) {
+        const unsigned long long r = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (r < T.max_rows) {
+          row = (uint32_t)r;
+          T.rows[pos] = row;
+          if (T.init_kind != XF_INIT_ZERO) {  // memory is pre-zeroed for XF_INIT_ZERO
+            float *dst = T.w + (size_t)row * T.dim;
+            for (int j = 0; j < T.dim; ++j)
+              dst[j] = T.init_kind == XF_INIT_CONST ? T.init_const
+                                                    : xf::hashnorm(T.seed, key, (uint32_t)j);
+          }
+        } else {
+          atomicOr(&T.stat->err, xf::kErrFull);
+        }
+      }
+    }
+    if (active) {
+      if (!inserted && !bad) {
+        row = T.rows[pos];
+        if (row == xf::kNoRow) {  // inserted by another lane of this launch: contract breach
+          atomicOr(&T.stat->err, xf::kErrDupKey);
+          row = (uint32_t)T.max_rows;
+        }
+      }
+      rows_out[i] = row;
+      if (GATHER) wu[i] = T.w[row];
+    }
   }
 }
 
-// Pull payload: vals[i][j] = w[slot[i]][j] (ftrl.h:75-77).  One element per lane; rows are
+// Pull payload: vals[i][j] = w[row[i]][j] (ftrl.h:75-77).  One element per lane; rows are
 // contiguous so a wave reads 64/dim rows as whole segments.
 __global__ void __launch_bounds__(kBlock)
-k_gather(const float *__restrict__ w, int dim, const uint32_t *__restrict__ slots, size_t n,
+k_gather(const float *__restrict__ w, int dim, const uint32_t *__restrict__ rows, size_t n,
          float *__restrict__ vals) {
   const size_t total = n * (size_t)dim;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const size_t i = dim == 1 ? e : e / (size_t)dim;
     const size_t j = e - i * (size_t)dim;
-    vals[e] = w[(size_t)slots[i] * dim + j];
+    vals[e] = w[(size_t)rows[i] * dim + j];
   }
 }
 
-// Push: one optimizer step per (slot, j).  FTRL: ftrl.h:59-74 / :126-141.  SGD: sgd.h:52,96.
+// Push: one optimizer step per (row, j).  FTRL: ftrl.h:59-74 / :126-141.  SGD: sgd.h:52,96.
 template <int OPT>
 __global__ void __launch_bounds__(kBlock)
-k_update(xf::TableDev T, const uint32_t *__restrict__ slots, size_t n,
+k_update(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
          const float *__restrict__ grads) {
   const size_t total = n * (size_t)T.dim;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const size_t i = T.dim == 1 ? e : e / (size_t)T.dim;
     const size_t j = e - i * (size_t)T.dim;
-    const size_t o = (size_t)slots[i] * T.dim + j;
+    const size_t o = (size_t)rows[i] * T.dim + j;
     const float g = grads[e];
     if (OPT == XF_OPT_FTRL) {
       float w = T.w[o], nn = T.n[o], z = T.z[o];
@@ -156,22 +193,22 @@ k_update(xf::TableDev T, const uint32_t *__restrict__ slots, size_t n,
   }
 }
 
-// import: scatter host rows into their slots
+// import: scatter host rows into their state rows
 __global__ void __launch_bounds__(kBlock)
-k_scatter_rows(float *__restrict__ dst, int dim, const uint32_t *__restrict__ slots,
+k_scatter_rows(float *__restrict__ dst, int dim, const uint32_t *__restrict__ rows,
                size_t n, const float *__restrict__ src) {
   const size_t total = n * (size_t)dim;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const size_t i = e / (size_t)dim, j = e - i * (size_t)dim;
-    dst[(size_t)slots[i] * dim + j] = src[e];
+    dst[(size_t)rows[i] * dim + j] = src[e];
   }
 }
 
-// export: append every occupied slot (arbitrary order; host sorts by key)
+// export: append every stored key with its row (arbitrary order; host sorts by key)
 __global__ void __launch_bounds__(kBlock)
 k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
-                uint32_t *__restrict__ out_slots, unsigned long long *__restrict__ counter,
+                uint32_t *__restrict__ out_rows, unsigned long long *__restrict__ counter,
                 size_t out_cap) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride) {
@@ -181,7 +218,7 @@ k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
       const unsigned long long p = atomicAdd(counter, 1ull);
       if (p < out_cap) {
         out_keys[p] = key;
-        out_slots[p] = (uint32_t)s;
+        out_rows[p] = T.rows[s];
       }
     }
   }
@@ -192,7 +229,8 @@ __global__ void k_fill_u64(uint64_t *p, size_t n, uint64_t v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-// grow: re-insert every occupied slot of `O` into the (empty, larger) table `T`
+// grow the key index: re-insert every stored key of `O` into the (empty, larger) index `T`;
+// state rows stay where they are
 __global__ void __launch_bounds__(kBlock)
 k_rehash(xf::TableDev O, xf::TableDev T) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -211,13 +249,7 @@ k_rehash(xf::TableDev O, xf::TableDev T) {
         if (++pos == T.cap) pos = 0;
       dst = pos;
     }
-    for (int j = 0; j < T.dim; ++j) {
-      T.w[dst * T.dim + j] = O.w[s * O.dim + j];
-      if (T.n) {
-        T.n[dst * T.dim + j] = O.n[s * O.dim + j];
-        T.z[dst * T.dim + j] = O.z[s * O.dim + j];
-      }
-    }
+    T.rows[dst] = O.rows[s];
   }
 }
 
@@ -230,7 +262,7 @@ struct xf_table {
   xf::TableDev T{};
   // scratch for the host-pointer API
   uint64_t *s_keys = nullptr;
-  uint32_t *s_slots = nullptr;
+  uint32_t *s_rows = nullptr;
   float *s_vals = nullptr;
   size_t s_n = 0, s_vals_n = 0;
 };
@@ -246,10 +278,10 @@ static void refresh_hyper(xf_table *t) {
 static int ensure_scratch(xf_table *t, size_t n) {
   if (n > t->s_n) {
     if (t->s_keys) XF_HIP(hipFree(t->s_keys));
-    if (t->s_slots) XF_HIP(hipFree(t->s_slots));
+    if (t->s_rows) XF_HIP(hipFree(t->s_rows));
     size_t m = std::max<size_t>(n, 1024);
     XF_HIP(hipMalloc((void **)&t->s_keys, m * sizeof(uint64_t)));
-    XF_HIP(hipMalloc((void **)&t->s_slots, m * sizeof(uint32_t)));
+    XF_HIP(hipMalloc((void **)&t->s_rows, m * sizeof(uint32_t)));
     t->s_n = m;
   }
   const size_t need = n * (size_t)t->cfg.dim;
@@ -262,23 +294,35 @@ static int ensure_scratch(xf_table *t, size_t n) {
   return XF_OK;
 }
 
-static int alloc_arrays(xf::TableDev &T, bool ftrl) {
+static int alloc_index(xf::TableDev &T) {
   const size_t slots = (size_t)T.cap + 1;
-  const size_t elems = slots * (size_t)T.dim;
-  T.n = T.z = nullptr;
   XF_HIP(hipMalloc((void **)&T.keys, slots * sizeof(uint64_t)));
-  XF_HIP(hipMalloc((void **)&T.w, elems * sizeof(float)));
-  XF_HIP(hipMemset(T.w, 0, elems * sizeof(float)));
-  if (ftrl) {
-    XF_HIP(hipMalloc((void **)&T.n, elems * sizeof(float)));
-    XF_HIP(hipMalloc((void **)&T.z, elems * sizeof(float)));
-    XF_HIP(hipMemset(T.n, 0, elems * sizeof(float)));
-    XF_HIP(hipMemset(T.z, 0, elems * sizeof(float)));
-  }
+  XF_HIP(hipMalloc((void **)&T.rows, slots * sizeof(uint32_t)));
+  XF_HIP(hipMemset(T.rows, 0xFF, slots * sizeof(uint32_t)));  // kNoRow
   hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(slots)), dim3(kBlock), 0, 0, T.keys, slots,
                      xf::kEmptyKey);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
+  return XF_OK;
+}
+
+// (re)allocate the dense state for `max_rows` rows, keeping the first `keep` rows
+static int alloc_state(xf::TableDev &T, uint64_t max_rows, bool ftrl, uint64_t keep) {
+  const size_t elems = ((size_t)max_rows + 1) * (size_t)T.dim;
+  float **arrs[3] = {&T.w, &T.n, &T.z};
+  for (int a = 0; a < (ftrl ? 3 : 1); ++a) {
+    float *fresh = nullptr;
+    XF_HIP(hipMalloc((void **)&fresh, elems * sizeof(float)));
+    XF_HIP(hipMemset(fresh, 0, elems * sizeof(float)));
+    if (*arrs[a]) {
+      if (keep)
+        XF_HIP(hipMemcpy(fresh, *arrs[a], (size_t)keep * T.dim * sizeof(float),
+                         hipMemcpyDeviceToDevice));
+      XF_HIP(hipFree(*arrs[a]));
+    }
+    *arrs[a] = fresh;
+  }
+  T.max_rows = max_rows;
   return XF_OK;
 }
 
@@ -292,6 +336,8 @@ static void set_geometry(xf::TableDev &T, uint64_t cap, uint32_t shard, uint32_t
   // home = mulhi64(key - lo, mult), mult = floor(cap * 2^64 / span)
   T.mult = (uint64_t)((((unsigned __int128)cap) << 64) / r.span);
 }
+
+static uint64_t rows_for(uint64_t cap) { return (uint64_t)((double)cap * kMaxLoad) + 1; }
 
 extern "C" void xf_table_config_default(xf_table_config *c) {
   c->opt_kind = XF_OPT_FTRL;
@@ -332,7 +378,8 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
   T.seed = cfg->seed;
   set_geometry(T, cfg->capacity, cfg->shard, cfg->nshards);
   refresh_hyper(t);
-  XF_TRY(alloc_arrays(T, cfg->opt_kind == XF_OPT_FTRL));
+  XF_TRY(alloc_index(T));
+  XF_TRY(alloc_state(T, rows_for(cfg->capacity), cfg->opt_kind == XF_OPT_FTRL, 0));
   XF_HIP(hipMalloc((void **)&T.stat, sizeof(xf::TableStat)));
   XF_HIP(hipMemset(T.stat, 0, sizeof(xf::TableStat)));
   *out = t;
@@ -341,14 +388,10 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
-  hipFree(t->T.keys);
-  hipFree(t->T.w);
-  if (t->T.n) hipFree(t->T.n);
-  if (t->T.z) hipFree(t->T.z);
-  hipFree(t->T.stat);
-  if (t->s_keys) hipFree(t->s_keys);
-  if (t->s_slots) hipFree(t->s_slots);
-  if (t->s_vals) hipFree(t->s_vals);
+  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.n, t->T.z, t->T.stat,
+                t->s_keys, t->s_rows, t->s_vals};
+  for (void *p : ps)
+    if (p) hipFree(p);
   delete t;
   return XF_OK;
 }
@@ -375,7 +418,7 @@ extern "C" int xf_table_size(xf_table *t, uint64_t *nkeys) {
   XF_HIP(hipDeviceSynchronize());
   xf::TableStat st;
   XF_TRY(read_stat(t, &st));
-  *nkeys = st.count + (st.spare_used ? 1 : 0);
+  *nkeys = std::min<uint64_t>(st.count, t->T.max_rows);
   return XF_OK;
 }
 
@@ -391,81 +434,86 @@ extern "C" int xf_table_check(xf_table *t, void *stream) {
   xf::TableStat st;
   XF_TRY(read_stat(t, &st));
   if (st.err & xf::kErrFull)
-    return xf::set_error(XF_EFULL, "table full: %llu keys in %llu slots (shard %u/%u)",
-                         (unsigned long long)st.count, (unsigned long long)t->T.cap,
-                         t->cfg.shard, t->cfg.nshards);
+    return xf::set_error(XF_EFULL,
+                         "table full: %llu keys for %llu state rows / %llu index positions "
+                         "(shard %u/%u); raise capacity or call xf_table_reserve",
+                         (unsigned long long)st.count, (unsigned long long)t->T.max_rows,
+                         (unsigned long long)t->T.cap, t->cfg.shard, t->cfg.nshards);
   if (st.err & xf::kErrForeignKey)
     return xf::set_error(XF_EINVAL, "a key outside shard %u/%u's range was sent to it",
                          t->cfg.shard, t->cfg.nshards);
+  if (st.err & xf::kErrDupKey)
+    return xf::set_error(XF_EINVAL, "duplicate keys inside one resolve/pull call");
   return XF_OK;
 }
 
-extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t n,
-                                    uint32_t *d_slots, void *stream) {
-  XF_REQUIRE(t && (n == 0 || (d_keys && d_slots)), "xf_table_resolve_dev: null argument");
-  if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_resolve<false>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
-                     d_keys, n, d_slots, (float *)nullptr);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
-}
-
-// Pull in one pass: resolve + the weight payload, for dim-1 tables and key lists that are
-// unique within the call (the worker's sorted unique key list).
-extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
-                                 uint32_t *d_slots, float *d_vals, void *stream) {
-  XF_REQUIRE(t && (n == 0 || (d_keys && d_slots && d_vals)), "xf_table_pull_dev: null argument");
-  XF_REQUIRE(t->T.dim == 1, "xf_table_pull_dev: dim must be 1 (use resolve + gather)");
-  if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_resolve<true>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
-                     d_keys, n, d_slots, d_vals);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
-}
-
-extern "C" int xf_table_gather_dev(xf_table *t, const uint32_t *d_slots, size_t n,
-                                   float *d_vals, void *stream) {
-  XF_REQUIRE(t && (n == 0 || (d_slots && d_vals)), "xf_table_gather_dev: null argument");
-  if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_gather, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, S(stream),
-                     t->T.w, t->T.dim, d_slots, n, d_vals);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
-}
-
-extern "C" int xf_table_update_dev(xf_table *t, const uint32_t *d_slots, size_t n,
-                                   const float *d_grads, void *stream) {
-  XF_REQUIRE(t && (n == 0 || (d_slots && d_grads)), "xf_table_update_dev: null argument");
-  if (n == 0) return XF_OK;
-  const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
-  if (t->cfg.opt_kind == XF_OPT_FTRL)
-    hipLaunchKernelGGL(k_update<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_slots, n, d_grads);
-  else
-    hipLaunchKernelGGL(k_update<XF_OPT_SGD>, g, b, 0, S(stream), t->T, d_slots, n, d_grads);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
-}
-
-
-// Re-house the table in `new_capacity` slots (keys and state preserved).  Slots change,
-// so slot arrays from earlier resolve calls are invalid afterwards.
+// Re-house the key index in `new_capacity` positions and extend the state (rows keep their
+// numbers, so row arrays from earlier resolve calls stay valid).
 extern "C" int xf_table_reserve(xf_table *t, uint64_t new_capacity) {
   XF_REQUIRE(t, "xf_table_reserve: null table");
   if (new_capacity <= t->T.cap) return XF_OK;
   XF_REQUIRE(new_capacity < 0xFFFFFFF0ull, "xf_table_reserve: capacity out of range");
   XF_HIP(hipDeviceSynchronize());
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  if (st.err & xf::kErrFull)
+    return xf::set_error(XF_EFULL, "xf_table_reserve: the table already overflowed");
   xf::TableDev N = t->T;
   set_geometry(N, new_capacity, t->cfg.shard, t->cfg.nshards);
-  XF_TRY(alloc_arrays(N, t->cfg.opt_kind == XF_OPT_FTRL));
+  XF_TRY(alloc_index(N));
   hipLaunchKernelGGL(k_rehash, dim3(grid_for((size_t)t->T.cap + 1)), dim3(kBlock), 0, 0, t->T, N);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  hipFree(t->T.keys);
-  hipFree(t->T.w);
-  if (t->T.n) hipFree(t->T.n);
-  if (t->T.z) hipFree(t->T.z);
+  XF_HIP(hipFree(t->T.keys));
+  XF_HIP(hipFree(t->T.rows));
+  XF_TRY(alloc_state(N, rows_for(new_capacity), t->cfg.opt_kind == XF_OPT_FTRL, st.count));
   t->T = N;
   t->cfg.capacity = new_capacity;
+  return XF_OK;
+}
+
+extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t n,
+                                    uint32_t *d_rows, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys && d_rows)), "xf_table_resolve_dev: null argument");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_resolve<false>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
+                     d_keys, n, d_rows, (float *)nullptr);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+// Pull in one pass: resolve + the weight payload, for dim-1 tables.
+extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
+                                 uint32_t *d_rows, float *d_vals, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys && d_rows && d_vals)), "xf_table_pull_dev: null argument");
+  XF_REQUIRE(t->T.dim == 1, "xf_table_pull_dev: dim must be 1 (use resolve + gather)");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_resolve<true>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
+                     d_keys, n, d_rows, d_vals);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_table_gather_dev(xf_table *t, const uint32_t *d_rows, size_t n,
+                                   float *d_vals, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_rows && d_vals)), "xf_table_gather_dev: null argument");
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, S(stream),
+                     t->T.w, t->T.dim, d_rows, n, d_vals);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+extern "C" int xf_table_update_dev(xf_table *t, const uint32_t *d_rows, size_t n,
+                                   const float *d_grads, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_rows && d_grads)), "xf_table_update_dev: null argument");
+  if (n == 0) return XF_OK;
+  const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
+  if (t->cfg.opt_kind == XF_OPT_FTRL)
+    hipLaunchKernelGGL(k_update<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_rows, n, d_grads);
+  else
+    hipLaunchKernelGGL(k_update<XF_OPT_SGD>, g, b, 0, S(stream), t->T, d_rows, n, d_grads);
+  XF_HIP(hipGetLastError());
   return XF_OK;
 }
 
@@ -475,8 +523,8 @@ extern "C" int xf_table_pull(xf_table *t, const uint64_t *keys, size_t n, float 
   if (n == 0) return XF_OK;
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
-  XF_TRY(xf_table_gather_dev(t, t->s_slots, n, t->s_vals, nullptr));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
+  XF_TRY(xf_table_gather_dev(t, t->s_rows, n, t->s_vals, nullptr));
   XF_HIP(hipMemcpy(vals, t->s_vals, n * t->T.dim * sizeof(float), hipMemcpyDeviceToHost));
   return xf_table_check(t, nullptr);
 }
@@ -487,8 +535,8 @@ extern "C" int xf_table_push(xf_table *t, const uint64_t *keys, size_t n, const 
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
   XF_HIP(hipMemcpy(t->s_vals, grads, n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
-  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
-  XF_TRY(xf_table_update_dev(t, t->s_slots, n, t->s_vals, nullptr));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
+  XF_TRY(xf_table_update_dev(t, t->s_rows, n, t->s_vals, nullptr));
   return xf_table_check(t, nullptr);
 }
 
@@ -505,16 +553,16 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
   if (nk == 0) return XF_OK;
   const int dim = t->T.dim;
   uint64_t *d_keys = nullptr;
-  uint32_t *d_slots = nullptr;
+  uint32_t *d_rows = nullptr;
   unsigned long long *d_cnt = nullptr;
-  float *d_rows = nullptr;
+  float *d_vals = nullptr;
   XF_HIP(hipMalloc((void **)&d_keys, nk * sizeof(uint64_t)));
-  XF_HIP(hipMalloc((void **)&d_slots, nk * sizeof(uint32_t)));
+  XF_HIP(hipMalloc((void **)&d_rows, nk * sizeof(uint32_t)));
   XF_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
-  XF_HIP(hipMalloc((void **)&d_rows, nk * dim * sizeof(float)));
+  XF_HIP(hipMalloc((void **)&d_vals, nk * dim * sizeof(float)));
   XF_HIP(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
   hipLaunchKernelGGL(k_list_occupied, dim3(grid_for((size_t)t->T.cap + 1)), dim3(kBlock), 0, 0,
-                     t->T, d_keys, d_slots, d_cnt, (size_t)nk);
+                     t->T, d_keys, d_rows, d_cnt, (size_t)nk);
   XF_HIP(hipGetLastError());
   std::vector<uint64_t> hk(nk);
   XF_HIP(hipMemcpy(hk.data(), d_keys, nk * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -522,7 +570,7 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
   std::iota(order.begin(), order.end(), (size_t)0);
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
   for (size_t i = 0; i < nk; ++i) keys[i] = hk[order[i]];
-  std::vector<float> rows(nk * dim);
+  std::vector<float> vals(nk * dim);
   float *srcs[3] = {t->T.w, t->T.n, t->T.z};
   float *dsts[3] = {w, n_, z_};
   for (int a = 0; a < 3; ++a) {
@@ -532,17 +580,17 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
       continue;
     }
     hipLaunchKernelGGL(k_gather, dim3(grid_for(nk * dim)), dim3(kBlock), 0, 0, srcs[a], dim,
-                       d_slots, (size_t)nk, d_rows);
+                       d_rows, (size_t)nk, d_vals);
     XF_HIP(hipGetLastError());
-    XF_HIP(hipMemcpy(rows.data(), d_rows, nk * dim * sizeof(float), hipMemcpyDeviceToHost));
+    XF_HIP(hipMemcpy(vals.data(), d_vals, nk * dim * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nk; ++i)
-      std::copy(rows.begin() + order[i] * dim, rows.begin() + (order[i] + 1) * dim,
+      std::copy(vals.begin() + order[i] * dim, vals.begin() + (order[i] + 1) * dim,
                 dsts[a] + i * dim);
   }
-  hipFree(d_keys);
-  hipFree(d_slots);
-  hipFree(d_cnt);
-  hipFree(d_rows);
+  XF_HIP(hipFree(d_keys));
+  XF_HIP(hipFree(d_rows));
+  XF_HIP(hipFree(d_cnt));
+  XF_HIP(hipFree(d_vals));
   return XF_OK;
 }
 
@@ -552,14 +600,14 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
   if (n == 0) return XF_OK;
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_slots, nullptr));
+  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
   const float *srcs[3] = {w, n_, z_};
   float *dsts[3] = {t->T.w, t->T.n, t->T.z};
   for (int a = 0; a < 3; ++a) {
     if (!srcs[a] || !dsts[a]) continue;
     XF_HIP(hipMemcpy(t->s_vals, srcs[a], n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, 0,
-                       dsts[a], t->T.dim, t->s_slots, n, t->s_vals);
+                       dsts[a], t->T.dim, t->s_rows, n, t->s_vals);
     XF_HIP(hipGetLastError());
   }
   return xf_table_check(t, nullptr);

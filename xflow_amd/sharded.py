@@ -94,6 +94,15 @@ class HipStages:
             b.t["fwd_scratch"] = self.empty(P * b.R, torch.float64)
             v.pptr, v.pidx = b.t["pptr"].data_ptr(), b.t["pidx"].data_ptr()
             v.fwd_scratch = b.t["fwd_scratch"].data_ptr()
+            ftp, fod = hb.fwd_tiles()
+            b.t["fwd_tile_ptr"] = self.from_numpy(ftp.view(np.int32))
+            b.t["fwd_order"] = self.from_numpy(fod.view(np.int32))
+            v.fwd_ntiles = len(fod)
+            v.fwd_tile_ptr = b.t["fwd_tile_ptr"].data_ptr()
+            v.fwd_order = b.t["fwd_order"].data_ptr()
+        tp = hb.tiles()
+        b.t["tile_ptr"] = self.from_numpy(tp.view(np.int32))
+        v.ntiles, v.tile_ptr = len(tp) - 1, b.t["tile_ptr"].data_ptr()
         b.view = v
         b.ukeys = b.t["ukeys"]
         return b
@@ -202,6 +211,19 @@ class ShardedTrainer:
         return out
 
     # ---- one minibatch step ----------------------------------------------------------------
+    def _resolve(self, table, rkeys, counts):
+        """key -> state row on the owner.  One resolve call per source rank: a key list is
+        unique only within its source (the table's resolve contract), the same key may
+        arrive from several workers."""
+        parts, off = [], 0
+        for c in counts:
+            if c:
+                parts.append(self.stages.resolve(table, rkeys[off:off + c]))
+            off += c
+        if not parts:
+            return self.stages.empty(0, torch.int32)
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+
     def _mark(self, name):
         if self._prof is not None:
             e = torch.cuda.Event(enable_timing=True)
@@ -216,9 +238,9 @@ class ShardedTrainer:
         rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
         self._mark("a2a_keys")
         # owner: key -> slot (insert on first touch, ftrl.h:56), gather weights
-        slots_w = st.resolve(tw, rkeys)
+        slots_w = self._resolve(tw, rkeys, b.recv_counts)
         if self.model == "fm":
-            slots_v = st.resolve(tv, rkeys)
+            slots_v = self._resolve(tv, rkeys, b.recv_counts)
         self._mark("resolve")
         w_recv = st.gather(tw, slots_w)
         if self.model == "fm":
@@ -261,11 +283,12 @@ class ShardedTrainer:
         st = self.stages
         tw, tv = st.tables()
         rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
-        wu = self._a2a(st.gather(tw, st.resolve(tw, rkeys)), b.recv_counts, b.send_counts)
+        wu = self._a2a(st.gather(tw, self._resolve(tw, rkeys, b.recv_counts)), b.recv_counts,
+                       b.send_counts)
         if self.model == "lr":
             return st.lr_forward(b, wu)
-        vu = self._a2a(st.gather(tv, st.resolve(tv, rkeys)), b.recv_counts, b.send_counts,
-                       self.k)
+        vu = self._a2a(st.gather(tv, self._resolve(tv, rkeys, b.recv_counts)), b.recv_counts,
+                       b.send_counts, self.k)
         return st.fm_forward(b, wu, vu)[0]
 
     def check(self):
