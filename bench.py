@@ -107,6 +107,22 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False):
     return per, survey
 
 
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE need separate profiled runs, so bench.py
+    cannot measure them itself).  Only used when the profile was taken on this workload."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+    except (OSError, ValueError):
+        return None
+    if d.get("workload") != workload:
+        return None
+    for k, e in d.get("kernels", {}).items():
+        if k.split("<")[0] == kernel:
+            return e["traffic"]
+    return None
+
+
 def cpu_baseline(args, batches):
     """The oracle (CPU restatement of the reference) timed on this host, one thread, on a
     bounded sample of the same compiled-minibatch step.  The key build (std::sort, a3) is
@@ -213,27 +229,31 @@ def main():
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
     achieved = per[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
+    workload = "%s+%s, synthetic libsvm-shaped, %d keys/GPU x %d GPU, %d rows x %d nnz per " \
+               "GPU minibatch%s" % (args.model.upper() + ("(k=%d)" % args.k if args.model == "fm"
+                                                          else ""), args.optimizer.upper(),
+                                    args.keys_per_gpu, world, args.rows, args.nnz_per_row,
+                                    ", zipf %.2f" % args.zipf if args.zipf else ", uniform")
+    lr = args.model == "lr"
+    dom_kernel = {"resolve": "k_resolve", "gather": "k_gather", "update": "k_update",
+                  "forward": "k_lr_forward_tiled" if lr else "k_fm_forward",
+                  "gradient": "k_lr_grad_tiled" if lr else "k_fm_grad"}.get(dom, dom)
+    dom_note = {"resolve": " (Pull: resolve+gather)", "gradient": " (gradient+Push)"}.get(
+        dom, "") if fused else ""
     out = {
         "metric": "examples/sec", "value": R * world * args.steps / dt, "unit": "examples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s+%s, synthetic libsvm-shaped, %d keys/GPU x %d GPU, "
-                               "%d rows x %d nnz per GPU minibatch%s" % (
-                                   args.model.upper() + ("(k=%d)" % args.k if args.model == "fm"
-                                                         else ""),
-                                   args.optimizer.upper(), args.keys_per_gpu, world, args.rows,
-                                   args.nnz_per_row,
-                                   ", zipf %.2f" % args.zipf if args.zipf else ", uniform"),
+        "config": {"workload": workload,
                    "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
                    "unique_keys_per_gpu_batch": U, "table_load_factor": args.load_factor,
                    "distinct_batches": len(compiled),
                    "parallelism": "key-range sharded table x%d, all-to-all" % world
                    if world > 1 else "single shard"},
-        "roofline": {"bound": "hbm", "kernel": {"resolve": "k_resolve<gather>" if fused else
-                                                "k_resolve", "gradient": "k_lr_grad_update"
-                                                if fused else "k_lr_grad"}.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(dom_kernel, workload),
                      "algorithmic_bytes_per_launch": per[dom],
                      "avg_launch_ms": avg_ms[dom]},
         "kernels_ms": avg_ms,

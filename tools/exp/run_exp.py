@@ -46,3 +46,10 @@ for grid in (256, 512):
 nwt = len(wt) - 1
 for grid in (2048, 4096):
     t("wavetile grid %d (nwt %d)" % (grid, nwt), lambda: X.x_wavetile(vp(wtp.data_ptr()), nwt, vp(segptr.data_ptr()), vp(coo.data_ptr()), vp(loss.data_ptr()), vp(g.data_ptr()), grid, vp(s)))
+
+for grid in (256, 512):
+    t("wavetile_lds grid %d" % grid, lambda: X.x_wavetile_lds(vp(wtp.data_ptr()), nwt, vp(segptr.data_ptr()), vp(coo.data_ptr()), vp(loss.data_ptr()), R, vp(g.data_ptr()), grid, vp(s)))
+gref = torch.empty_like(g)
+X.x_tiled256(vp(tilep.data_ptr()), nt, vp(segptr.data_ptr()), vp(coo.data_ptr()), vp(loss.data_ptr()), vp(gref.data_ptr()), nt, vp(s))
+torch.cuda.synchronize()
+print("wavetile_lds == tiled256:", bool(torch.equal(g, gref)))

@@ -24,7 +24,8 @@ CALIB_BYTES = 1 << 30
 # access width (bytes per lane) that dominates each kernel's reads / writes
 WIDTH = {
     "k_resolve": (8, 4), "k_gather": (4, 4), "k_update": (4, 4), "k_lr_forward": (4, 4),
-    "k_lr_forward_panel": (4, 8), "k_lr_finalize": (8, 4), "k_lr_grad": (4, 4),
+    "k_lr_forward_panel": (4, 8), "k_lr_forward_tiled": (4, 8), "k_lr_finalize": (8, 4),
+    "k_lr_grad": (4, 4), "k_lr_grad_tiled": (4, 4),
     "k_lr_grad_update": (4, 4), "k_lr_grad_heavy": (4, 4), "k_fm_forward": (4, 4),
     "k_fm_grad": (4, 4),
 }
@@ -61,7 +62,16 @@ def main():
             calib["read%d" % w] = CALIB_BYTES / (median([x[0] for x in fetch[kr[0]]]) * 1024)
         if kw:
             calib["write%d" % w] = CALIB_BYTES / (median([x[0] for x in write[kw[0]]]) * 1024)
-    out = {"unit": "bytes per launch (median over steady-state launches)",
+    workload = None
+    for d in sys.argv[1:3]:   # the bench's own JSON line, written next to the pass directory
+        try:
+            workload = json.loads(open(d.rstrip("/") + ".json").read().strip().splitlines()[-1])[
+                "config"]["workload"]
+            break
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
+    out = {"workload": workload,
+           "unit": "bytes per launch (median over steady-state launches)",
            "calibration_true_bytes_per_counted_byte": calib, "kernels": {}}
     for k in sorted(set(fetch) & set(write)):
         if k.startswith("k_calib") or not k.startswith("k_"):
