@@ -85,7 +85,7 @@ int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const uint32_t **ro
 int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
                     const uint32_t **pidx);
 int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
-                       const uint32_t **order);
+                       const uint32_t **panel_first, uint32_t *grid);
 /* gradient tiles (host array, ntiles+1 key indices) */
 int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr);
 /* tuning knobs (process-wide): "panel_slice_bytes" (default 1.5 MiB: w_u bytes per panel),
@@ -114,9 +114,12 @@ typedef struct {
   double *fwd_scratch;     /* P*R partial sums (device scratch owned by the batch) */
   /* forward tiles over the (panel,row) cells s = p*(R+1)+r: tile t = cells
    * [fwd_tile_ptr[t], fwd_tile_ptr[t+1]) of ONE panel, <= XF_TILE_NNZ nonzeros;
-   * fwd_order[b] = tile of workgroup b (panel p's tiles go to workgroups b with b%8 == p%8) */
-  const uint32_t *fwd_tile_ptr; /* fwd_ntiles+1 */
-  const uint32_t *fwd_order;    /* fwd_ntiles   */
+   * fwd_panel_first[p] = first tile of panel p.  Workgroup b takes the (b/8)-th tile of the
+   * panels p with p % 8 == b % 8 (observed placement: XCD b % 8); fwd_grid = 8 x the longest
+   * such list. */
+  const uint32_t *fwd_tile_ptr;    /* fwd_ntiles+1 */
+  const uint32_t *fwd_panel_first; /* P+1 */
+  uint32_t fwd_grid, pad3_;
   /* gradient tiles: tile t covers keys [tile_ptr[t], tile_ptr[t+1]) whose occurrences
    * (<= XF_TILE_NNZ of them, <= XF_TILE_KEYS keys) are staged through LDS by one
    * workgroup; a heavy key (> XF_HEAVY_SEG occurrences) is a tile of its own, skipped by

@@ -224,18 +224,64 @@ def test_forward_tiles_cover_every_cell_once():
         capi.tune("min_panel_nnz", 4e6)
         capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
     P, pptr, pidx = b.panels()
-    tp, order = b.fwd_tiles()
-    nt = len(order)
-    assert sorted(order.tolist()) == list(range(nt))          # a permutation of the tiles
+    tp, pf, grid = b.fwd_tiles()
+    nt = len(tp) - 1
     assert tp[0] == 0 and tp[-1] == (P - 1) * (b.R + 1) + b.R and np.all(np.diff(tp) > 0)
+    assert pf[0] == 0 and pf[-1] == nt and len(pf) == P + 1
     seen = np.zeros(P * (b.R + 1), dtype=np.int32)
-    for a, e in zip(tp[:-1], tp[1:]):
-        assert a // (b.R + 1) == (e - 1) // (b.R + 1)          # one panel per tile
+    for t, (a, e) in enumerate(zip(tp[:-1], tp[1:])):
+        p = a // (b.R + 1)
+        assert p == (e - 1) // (b.R + 1) and pf[p] <= t < pf[p + 1]   # one panel per tile
         assert pptr[e] - pptr[a] <= 2048 or e - a == 1
+        assert e - a <= 2049
         seen[a:e] += 1
     cells = seen.reshape(P, b.R + 1)
     assert np.all(cells[:, :b.R] == 1)
-    # XCD affinity: workgroup w gets a tile of a panel p with p % 8 == w % 8 (when available)
-    panel_of_tile = tp[:-1] // (b.R + 1)
-    match = sum(int(panel_of_tile[order[w]] % 8 == w % 8) for w in range(nt))
-    assert match >= 0.9 * nt
+    # the workgroup -> tile map of k_lr_forward_tiled reaches every tile exactly once
+    hit = np.zeros(nt, dtype=np.int32)
+    assert grid % 8 == 0
+    for w in range(grid):
+        q = w // 8
+        for p in range(w % 8, P, 8):
+            cnt = pf[p + 1] - pf[p]
+            if q < cnt:
+                hit[pf[p] + q] += 1
+                break
+            q -= cnt
+    assert np.all(hit == 1)
+
+
+def test_tiling_rules_bounds_with_heavy_and_ragged_rows():
+    """xf_tiling.h: gradient tiles < 2048 occurrences / keys, heavy keys alone; forward tiles
+    < 2048 nonzeros / <= 2048 cells even with many empty cells and one huge row."""
+    rng = np.random.RandomState(14)
+    R = 9000
+    lens = np.where(rng.rand(R) < 0.7, 0, rng.randint(1, 12, size=R))
+    lens[1234] = 40000                                 # one oversized row: cells > 2048
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    fid = np.minimum(rng.zipf(1.25, size=int(lens.sum())), 3000)
+    keys = fid.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    capi.tune("min_panel_nnz", 0)
+    capi.tune("panel_slice_bytes", 4096)
+    try:
+        b = capi.Batch(rowptr, keys, rng.randint(0, 2, size=R).astype(np.int32))
+    finally:
+        capi.tune("min_panel_nnz", 4e6)
+        capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+    h, tp = b.host(), b.tiles()
+    seg = np.diff(h["segptr"])
+    for a, e in zip(tp[:-1], tp[1:]):
+        if e - a == 1 and seg[a] > capi.HEAVY_SEG:
+            continue
+        assert h["segptr"][e] - h["segptr"][a] < 2048 and e - a <= 2048
+        assert np.all(seg[a:e] <= capi.HEAVY_SEG)
+    P, pptr, _ = b.panels()
+    ftp = b.fwd_tiles()[0]
+    big = 0
+    for a, e in zip(ftp[:-1], ftp[1:]):
+        n = int(pptr[e] - pptr[a])
+        if n >= 2048:
+            assert e - a <= 2 and n > 256          # a single oversized cell (+ the panel gap)
+            big += 1
+        assert e - a <= 2049
+    assert big >= 1

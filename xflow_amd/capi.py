@@ -40,7 +40,8 @@ class DevBatch(C.Structure):
                 ("rowptr", vp), ("uidx", vp), ("ukeys", vp), ("segptr", vp), ("coo_row", vp),
                 ("labels", vp), ("heavy", vp), ("P", C.c_uint32), ("fwd_ntiles", C.c_uint32),
                 ("pptr", vp), ("pidx", vp), ("fwd_scratch", vp), ("fwd_tile_ptr", vp),
-                ("fwd_order", vp), ("ntiles", C.c_uint32),
+                ("fwd_panel_first", vp), ("fwd_grid", C.c_uint32), ("pad3_", C.c_uint32),
+                ("ntiles", C.c_uint32),
                 ("pad2_", C.c_uint32), ("tile_ptr", vp)]
 
 
@@ -66,7 +67,7 @@ SIGNATURES = {
     "xf_batch_panels": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
     "xf_tune": (C.c_int, [C.c_char_p, C.c_double]),
     "xf_batch_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p)]),
-    "xf_batch_fwd_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
+    "xf_batch_fwd_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p), u32p]),
     "xf_batch_upload": (C.c_int, [vp, vp]),
     "xf_batch_dev_view": (C.c_int, [vp, C.POINTER(DevBatch)]),
     "xf_table_config_default": (None, [C.POINTER(TableConfig)]),
@@ -228,12 +229,15 @@ class Batch:
                 np.ctypeslib.as_array(pi, (self.NNZ,)).copy())
 
     def fwd_tiles(self):
-        n, tp, od = C.c_uint32(0), u32p(), u32p()
-        check(lib().xf_batch_fwd_tiles(self.h, C.byref(n), C.byref(tp), C.byref(od)))
+        """(tile_ptr[ntiles+1], panel_first[P+1], grid) of the forward tiles"""
+        n, tp, pf, g = C.c_uint32(0), u32p(), u32p(), C.c_uint32(0)
+        check(lib().xf_batch_fwd_tiles(self.h, C.byref(n), C.byref(tp), C.byref(pf),
+                                       C.byref(g)))
         if n.value == 0:
-            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), 0
+        P = self.panels()[0]
         return (np.ctypeslib.as_array(tp, (n.value + 1,)).copy(),
-                np.ctypeslib.as_array(od, (n.value,)).copy())
+                np.ctypeslib.as_array(pf, (P + 1,)).copy(), g.value)
 
     def tiles(self):
         n, tp = C.c_uint32(0), u32p()

@@ -10,6 +10,7 @@
 // The result depends only on the input rows, so a compiled batch can be cached across
 // epochs (the reference re-parses and re-sorts every epoch, lr_worker.cc:184).
 #include "xf_batch.h"
+#include "xf_tiling.h"
 
 #include <string.h>
 
@@ -72,18 +73,18 @@ void build_panels(xf_batch *b) {
   b->P = 0;
   b->pptr.clear();
   b->pidx.clear();
-  if ((double)b->NNZ < g_min_panel_nnz || b->U == 0) return;
-  const double slices = std::ceil((double)b->U * 4.0 / g_panel_slice_bytes);
-  uint32_t P = (uint32_t)(8 * std::ceil(slices / 8.0));
-  if (P < 8) P = 8;
-  if (P > 256) P = 256;
-  const uint64_t U = b->U, R = b->R;
-  auto panel_of = [&](uint32_t ui) { return (uint32_t)(((uint64_t)ui * P) / U); };
+  b->ftile_ptr.clear();
+  b->fpanel_first.clear();
+  b->fwd_grid = 0;
+  const uint32_t P = xf::panel_count(b->U, b->NNZ, g_panel_slice_bytes, g_min_panel_nnz);
+  if (P == 0) return;
+  const uint64_t R = b->R;
+  const uint32_t U = b->U;
   b->pptr.assign((size_t)P * (R + 1), 0);
   // counts per (panel,row) -> exclusive prefix in panel-major order
   for (uint64_t r = 0; r < R; ++r)
     for (uint32_t j = b->rowptr[r]; j < b->rowptr[r + 1]; ++j)
-      ++b->pptr[(size_t)panel_of(b->uidx[j]) * (R + 1) + r + 1];
+      ++b->pptr[(size_t)xf::panel_of(b->uidx[j], P, U) * (R + 1) + r + 1];
   uint32_t run = 0;
   for (uint32_t p = 0; p < P; ++p) {
     uint32_t *pp = &b->pptr[(size_t)p * (R + 1)];
@@ -101,78 +102,37 @@ void build_panels(xf_batch *b) {
   for (uint64_t r = 0; r < R; ++r)
     for (uint32_t j = b->rowptr[r]; j < b->rowptr[r + 1]; ++j) {
       const uint32_t ui = b->uidx[j];
-      b->pidx[cur[(size_t)panel_of(ui) * R + r]++] = ui;
+      b->pidx[cur[(size_t)xf::panel_of(ui, P, U) * R + r]++] = ui;
     }
   b->P = P;
-  // forward tiles: consecutive cells of one panel, <= XF_TILE_NNZ nonzeros / XF_TILE_KEYS cells
-  b->ftile_ptr.clear();
-  std::vector<uint32_t> panel_first(P + 1, 0);
+  // forward tiles (xf_tiling.h): tile t = cells [ftile_ptr[t], ftile_ptr[t+1]) of one panel;
+  // the last tile of a panel also covers the empty cell p*(R+1)+R between two panels
+  b->fpanel_first.assign(P + 1, 0);
   for (uint32_t p = 0; p < P; ++p) {
-    panel_first[p] = (uint32_t)b->ftile_ptr.size();
+    b->fpanel_first[p] = (uint32_t)b->ftile_ptr.size();
     const uint32_t s0 = (uint32_t)((size_t)p * (R + 1));
-    uint32_t start = 0, nnz = 0;
-    b->ftile_ptr.push_back(s0);
-    for (uint32_t r = 0; r < R; ++r) {
-      const uint32_t len = b->pptr[s0 + r + 1] - b->pptr[s0 + r];
-      if (r > start && (nnz + len > XF_TILE_NNZ || r - start == XF_TILE_KEYS)) {
-        b->ftile_ptr.push_back(s0 + r);
-        start = r;
-        nnz = 0;
-      }
-      nnz += len;
-    }
+    const uint32_t *pp = &b->pptr[s0];
+    for (uint32_t r = 0; r < R; ++r)
+      if (xf::fwd_tile_starts_at(pp, r)) b->ftile_ptr.push_back(s0 + r);
   }
-  panel_first[P] = (uint32_t)b->ftile_ptr.size();
+  b->fpanel_first[P] = (uint32_t)b->ftile_ptr.size();
   b->ftile_ptr.push_back((uint32_t)((size_t)(P - 1) * (R + 1) + R));  // end of the last panel
-  // panel p's tiles end at the start of panel p+1's first tile == p*(R+1)+R + 1 cell (empty)
-  const uint32_t nft = (uint32_t)b->ftile_ptr.size() - 1;
-  // workgroup -> tile: XCD x (= workgroup % 8) walks the tiles of panels p % 8 == x in order
-  b->forder.assign(nft, 0);
-  std::vector<std::vector<uint32_t>> lists(8);
-  for (uint32_t p = 0; p < P; ++p)
-    for (uint32_t t = panel_first[p]; t < panel_first[p + 1]; ++t) lists[p & 7].push_back(t);
-  b->forder.assign(nft, 0xFFFFFFFFu);
-  std::vector<uint32_t> spill;
+  // workgroup b serves XCD b % 8: it takes the (b / 8)-th tile of the panels p % 8 == b % 8
+  uint32_t longest = 0;
   for (uint32_t x = 0; x < 8; ++x) {
-    uint32_t w = x;
-    for (uint32_t t : lists[x]) {
-      if (w < nft) {
-        b->forder[w] = t;
-        w += 8;
-      } else {
-        spill.push_back(t);
-      }
-    }
+    uint32_t len = 0;
+    for (uint32_t p = x; p < P; p += 8) len += b->fpanel_first[p + 1] - b->fpanel_first[p];
+    longest = std::max(longest, len);
   }
-  for (uint32_t w = 0; w < nft && !spill.empty(); ++w)
-    if (b->forder[w] == 0xFFFFFFFFu) {
-      b->forder[w] = spill.back();
-      spill.pop_back();
-    }
+  b->fwd_grid = 8 * longest;
 }
 
-// Gradient tiles: consecutive key ranges whose occurrence lists fit one workgroup's LDS.
+// Gradient tiles (xf_tiling.h): consecutive key ranges whose occurrences fit one workgroup's LDS
 void build_tiles(xf_batch *b) {
   b->tile_ptr.clear();
-  b->tile_ptr.push_back(0);
-  uint32_t start = 0, nnz = 0;
-  for (uint32_t u = 0; u < b->U; ++u) {
-    const uint32_t len = b->segptr[u + 1] - b->segptr[u];
-    if (len > XF_HEAVY_SEG) {  // a tile of its own
-      if (u > start) b->tile_ptr.push_back(u);
-      b->tile_ptr.push_back(u + 1);
-      start = u + 1;
-      nnz = 0;
-      continue;
-    }
-    if (nnz + len > XF_TILE_NNZ || u - start == XF_TILE_KEYS) {
-      b->tile_ptr.push_back(u);
-      start = u;
-      nnz = 0;
-    }
-    nnz += len;
-  }
-  if (b->U > start) b->tile_ptr.push_back(b->U);
+  for (uint32_t u = 0; u < b->U; ++u)
+    if (xf::grad_tile_starts_at(b->segptr.data(), u)) b->tile_ptr.push_back(u);
+  b->tile_ptr.push_back(b->U);
 }
 
 }  // namespace
@@ -194,11 +154,12 @@ extern "C" int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_
 }
 
 extern "C" int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
-                                  const uint32_t **order) {
+                                  const uint32_t **panel_first, uint32_t *grid) {
   XF_REQUIRE(b && ntiles, "xf_batch_fwd_tiles: null argument");
   *ntiles = b->P ? (uint32_t)b->ftile_ptr.size() - 1 : 0;
   if (tile_ptr) *tile_ptr = b->ftile_ptr.data();
-  if (order) *order = b->forder.data();
+  if (panel_first) *panel_first = b->fpanel_first.data();
+  if (grid) *grid = b->fwd_grid;
   return XF_OK;
 }
 
@@ -309,7 +270,7 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   const size_t o_tile = o_scr + al((size_t)b->P * b->R * 8);
   const size_t o_ftile = o_tile + al(b->tile_ptr.size() * 4);
   const size_t o_forder = o_ftile + al(b->ftile_ptr.size() * 4);
-  const size_t total = o_forder + al(b->forder.size() * 4) + 256;
+  const size_t total = o_forder + al(b->fpanel_first.size() * 4) + 256;
   char *d = nullptr;
   XF_HIP(hipMalloc((void **)&d, total));
   hipStream_t s = (hipStream_t)stream;
@@ -331,7 +292,7 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   XF_HIP(put(o_tile, b->tile_ptr.data(), b->tile_ptr.size() * 4));
   if (b->P) {
     XF_HIP(put(o_ftile, b->ftile_ptr.data(), b->ftile_ptr.size() * 4));
-    XF_HIP(put(o_forder, b->forder.data(), b->forder.size() * 4));
+    XF_HIP(put(o_forder, b->fpanel_first.data(), b->fpanel_first.size() * 4));
   }
   XF_HIP(hipStreamSynchronize(s));  // host vectors are pageable: finish before returning
   b->d_blob = d;
@@ -349,7 +310,8 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   b->view.P = b->P;
   b->view.fwd_ntiles = b->P ? (uint32_t)b->ftile_ptr.size() - 1 : 0;
   b->view.fwd_tile_ptr = b->P ? (const uint32_t *)(d + o_ftile) : nullptr;
-  b->view.fwd_order = b->P ? (const uint32_t *)(d + o_forder) : nullptr;
+  b->view.fwd_panel_first = b->P ? (const uint32_t *)(d + o_forder) : nullptr;
+  b->view.fwd_grid = b->fwd_grid;
   b->view.pptr = b->P ? (const uint32_t *)(d + o_pptr) : nullptr;
   b->view.pidx = b->P ? (const uint32_t *)(d + o_pidx) : nullptr;
   b->view.fwd_scratch = b->P ? (double *)(d + o_scr) : nullptr;

@@ -13,7 +13,8 @@ struct xf_batch {
   uint32_t P = 0;  // forward panels (0 = none)
   std::vector<uint32_t> pptr, pidx;
   std::vector<uint32_t> tile_ptr;  // gradient tiles (key ranges)
-  std::vector<uint32_t> ftile_ptr, forder;  // forward tiles over (panel,row) cells
+  std::vector<uint32_t> ftile_ptr, fpanel_first;  // forward tiles over (panel,row) cells
+  uint32_t fwd_grid = 0;
   std::vector<int32_t> labels;
   void *d_blob = nullptr;  // one device allocation holding all arrays
   xf_dev_batch view{};

@@ -110,19 +110,29 @@ k_lr_forward_panel(const uint32_t *__restrict__ pptr, const uint32_t *__restrict
 // Tiled form of the panel forward: a workgroup takes a run of (panel,row) cells holding
 // <= XF_TILE_NNZ nonzeros, gathers w_u[pidx[j]] for all of them at once into LDS (one
 // coalesced index read, every lane with independent gathers in flight), then one lane per
-// cell adds the cell's short run in fp64.  fwd_order sends panel p's tiles to workgroups
-// b with b % 8 == p % 8 (observed: XCD b % 8), so an XCD's L2 holds its panels' w_u slices.
+// cell adds the cell's short run in fp64.  Workgroup b takes the (b/8)-th tile of the panels p
+// with p % 8 == b % 8 (observed placement: XCD b % 8), so an XCD's L2 holds its panels'
+// w_u slices.
 __global__ void __launch_bounds__(kBlock)
-k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ order,
-                   uint32_t ntiles, const uint32_t *__restrict__ pptr,
-                   const uint32_t *__restrict__ pidx, const float *__restrict__ wu, uint32_t R,
-                   double *__restrict__ partial) {
+k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
+                   const uint32_t *__restrict__ panel_first, uint32_t P,
+                   const uint32_t *__restrict__ pptr, const uint32_t *__restrict__ pidx,
+                   const float *__restrict__ wu, uint32_t R, double *__restrict__ partial) {
   __shared__ float vals[XF_TILE_NNZ];
   __shared__ uint32_t sp[XF_TILE_KEYS + 2];
   __shared__ double red[kBlock / 64];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
-    const uint32_t tile = order[b];
+  {
+    uint32_t q = blockIdx.x >> 3, tile = 0xFFFFFFFFu;
+    for (uint32_t p = blockIdx.x & 7u; p < P; p += 8) {  // uniform, <= P/8 iterations
+      const uint32_t first = panel_first[p], cnt = panel_first[p + 1] - first;
+      if (q < cnt) {
+        tile = first + q;
+        break;
+      }
+      q -= cnt;
+    }
+    if (tile == 0xFFFFFFFFu) return;
     const uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1], ns = sb - sa;
     const uint32_t p = sa / (R + 1), r0 = sa - p * (R + 1);
     const uint32_t j0 = pptr[sa], j1 = pptr[sb];
@@ -137,8 +147,7 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr, const uint32_t *__rest
         for (int k = 0; k < kBlock / 64; ++k) s += red[k];
         partial[(size_t)p * R + r0] = s;
       }
-      __syncthreads();
-      continue;
+      return;
     }
     for (uint32_t k = tid; k <= ns; k += kBlock) sp[k] = pptr[sa + k] - j0;
     for (uint32_t j = j0 + tid; j < j1; j += kBlock) vals[j - j0] = wu[pidx[j]];
@@ -151,7 +160,6 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr, const uint32_t *__rest
         partial[(size_t)p * R + r] = acc;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -449,10 +457,10 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   XF_REQUIRE(b && d_wu && d_loss, "xf_lr_forward_dev: null argument");
   if (b->R == 0) return XF_OK;
   const double avg = (double)b->NNZ / b->R;
-  if (b->P >= 8 && b->fwd_ntiles && b->fwd_tile_ptr && b->fwd_order && b->fwd_scratch) {
-    hipLaunchKernelGGL(k_lr_forward_tiled, dim3(tile_grid(b->fwd_ntiles)), dim3(kBlock), 0,
-                       S(stream), b->fwd_tile_ptr, b->fwd_order, b->fwd_ntiles, b->pptr, b->pidx,
-                       d_wu, b->R, b->fwd_scratch);
+  if (b->P >= 8 && b->fwd_grid && b->fwd_tile_ptr && b->fwd_panel_first && b->fwd_scratch) {
+    hipLaunchKernelGGL(k_lr_forward_tiled, dim3(b->fwd_grid), dim3(kBlock), 0, S(stream),
+                       b->fwd_tile_ptr, b->fwd_panel_first, b->P, b->pptr, b->pidx, d_wu, b->R,
+                       b->fwd_scratch);
     XF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);

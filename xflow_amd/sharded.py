@@ -94,12 +94,12 @@ class HipStages:
             b.t["fwd_scratch"] = self.empty(P * b.R, torch.float64)
             v.pptr, v.pidx = b.t["pptr"].data_ptr(), b.t["pidx"].data_ptr()
             v.fwd_scratch = b.t["fwd_scratch"].data_ptr()
-            ftp, fod = hb.fwd_tiles()
+            ftp, fpf, fgrid = hb.fwd_tiles()
             b.t["fwd_tile_ptr"] = self.from_numpy(ftp.view(np.int32))
-            b.t["fwd_order"] = self.from_numpy(fod.view(np.int32))
-            v.fwd_ntiles = len(fod)
+            b.t["fwd_panel_first"] = self.from_numpy(fpf.view(np.int32))
+            v.fwd_ntiles, v.fwd_grid = len(ftp) - 1, fgrid
             v.fwd_tile_ptr = b.t["fwd_tile_ptr"].data_ptr()
-            v.fwd_order = b.t["fwd_order"].data_ptr()
+            v.fwd_panel_first = b.t["fwd_panel_first"].data_ptr()
         tp = hb.tiles()
         b.t["tile_ptr"] = self.from_numpy(tp.view(np.int32))
         v.ntiles, v.tile_ptr = len(tp) - 1, b.t["tile_ptr"].data_ptr()
