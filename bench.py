@@ -47,6 +47,8 @@ def parse_args():
                     help="tuning: bytes of w_u per forward panel (0 = library default)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
+    ap.add_argument("--key-build-steps", type=int, default=10,
+                    help="extra timed steps that include the GPU key build (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--seed", type=int, default=20260926)
@@ -121,6 +123,42 @@ def pmc_traffic(kernel, workload):
         if k.split("<")[0] == kernel:
             return e["traffic"]
     return None
+
+
+def with_key_build(args, trainer, batches):
+    """Supplementary figure (not `value`): the whole LRWorker::update including its key build
+    (lr_worker.cc:146-166) per step — raw CSR keys resident in HBM, xf_batch_compile_dev
+    (GPU sort + unique + views) and then the step, nothing cached between steps."""
+    import ctypes as C
+    import torch
+    from xflow_amd import capi
+    L = capi.lib()
+    raw = []
+    for rowptr, keys, labels in batches[:4]:
+        raw.append((torch.from_numpy(keys.view(np.int64)).cuda(),
+                    torch.from_numpy(rowptr.astype(np.uint32).view(np.int32)).cuda(),
+                    torch.from_numpy(labels).cuda(), len(labels), len(keys)))
+
+    def one(i):
+        k, rp, lb, R, NNZ = raw[i % len(raw)]
+        h = capi.vp()
+        capi.check(L.xf_batch_compile_dev(C.byref(h), k.data_ptr(), rp.data_ptr(),
+                                          lb.data_ptr(), R, NNZ, None))
+        capi.check(L.xf_lr_step(trainer.w.h, h, trainer.ws.h, None))
+        capi.stream_sync()
+        L.xf_batch_free(h)
+    for i in range(2):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.key_build_steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": args.rows * args.key_build_steps / dt, "unit": "examples/sec",
+            "ms_per_step": dt / args.key_build_steps * 1e3, "steps": args.key_build_steps,
+            "what": "key build on the GPU (rocPRIM radix sort + unique/views/tiles kernels) + "
+                    "the step, per minibatch, raw keys resident in HBM"}
 
 
 def cpu_baseline(args, batches):
@@ -260,6 +298,8 @@ def main():
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
+    if world == 1 and not args.force_sharded and args.model == "lr" and args.key_build_steps > 0:
+        out["with_key_build"] = with_key_build(args, trainer, batches)
     if args.pmc_calibrate:
         for kind in range(6):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))

@@ -74,6 +74,16 @@ int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
 typedef struct xf_batch xf_batch; /* host arrays + (after upload) device mirror */
 int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                      const int32_t *labels, size_t row_begin, size_t row_end);
+/* The same key build on the GPU (rocPRIM radix sort + flag/scan/scatter kernels): the
+ * compiled batch is born on the device, identical array for array to xf_batch_compile's.
+ * _dev takes raw device arrays (d_rowptr row-relative, d_rowptr[0] == 0); _gpu takes the
+ * reader's host arrays and a row slice like xf_batch_compile and uploads the raw slice. */
+int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys, const uint32_t *d_rowptr,
+                         const int32_t *d_labels, uint32_t R, uint32_t NNZ, void *stream);
+int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
+                         const int32_t *labels, size_t row_begin, size_t row_end, void *stream);
+/* copy a device-built batch's arrays into its host views (xf_batch_host etc. do it on demand) */
+int xf_batch_download(xf_batch *b);
 int xf_batch_free(xf_batch *b);
 int xf_batch_dims(const xf_batch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U, uint32_t *H);
 /* host views (owned by the batch) */
@@ -247,7 +257,7 @@ int XFStartTrain(void **h);
 /* additive (the reference has no equivalents) */
 int XFDestroy(void **h);
 /* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
- *        rank pred_path alpha beta lambda1 lambda2 lr seed */
+ *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host) */
 int XFSetParam(void *h, const char *name, const char *value);
 /* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
  * examples_per_sec, keys */

@@ -500,3 +500,91 @@ def test_sharded_trainer_world1_matches_fused_step():
             assert pa.shape == pb.shape == (ob.R,)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------ device key build (a3 on the GPU)
+def _same_batch(a, b):
+    """every array of two compiled batches, bit for bit"""
+    assert (a.R, a.NNZ, a.U, a.H) == (b.R, b.NNZ, b.U, b.H)
+    ha, hb = a.host(), b.host()
+    for k in ha:
+        same(ha[k], hb[k])
+    same(a.tiles(), b.tiles())
+    pa, pb = a.panels(), b.panels()
+    assert pa[0] == pb[0]
+    if pa[0]:
+        same(pa[1], pb[1])
+        same(pa[2], pb[2])
+        fa, fb = a.fwd_tiles(), b.fwd_tiles()
+        same(fa[0], fb[0])
+        same(fa[1], fb[1])
+        assert fa[2] == fb[2]
+
+
+@pytest.mark.parametrize("case", ["uniform", "zipf_ragged", "empty_rows", "one_row", "empty"])
+def test_device_key_build_equals_host(case):
+    """xf_batch_compile_gpu (rocPRIM sort + flag/scan/scatter kernels) must produce exactly
+    what the host builder produces: unique keys, CSR/COO views, heavy list, tiles, panels."""
+    rng = np.random.RandomState(len(case))
+    if case == "uniform":
+        rowptr, keys, labels = synth(rng, 3000, 40, 30000)
+    elif case == "zipf_ragged":
+        rowptr, keys, labels = synth(rng, 4000, 30, 20000, 1.2, True)
+    elif case == "empty_rows":
+        lens = np.where(rng.rand(2500) < 0.6, 0, rng.randint(1, 9, size=2500))
+        lens[77] = 5000                                   # one oversized row
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        keys = (rng.randint(0, 900, size=int(lens.sum())).astype(np.uint64) + np.uint64(1)) * \
+            np.uint64(0x9E3779B97F4A7C15)
+        labels = rng.randint(0, 2, size=2500).astype(np.int32)
+    elif case == "one_row":
+        rowptr = np.array([0, 5], dtype=np.uint64)
+        keys = np.array([9, 3, 9, 2**64 - 1, 0], dtype=np.uint64)
+        labels = np.array([1], dtype=np.int32)
+    else:
+        rowptr, keys, labels = np.array([0], np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int32)
+    for force_panels in (False, True):
+        if force_panels:
+            capi.tune("min_panel_nnz", 0)
+            capi.tune("panel_slice_bytes", 4096)
+        try:
+            host = capi.Batch(rowptr, keys, labels)
+            dev = capi.Batch(rowptr, keys, labels, on_gpu=True)
+        finally:
+            capi.tune("min_panel_nnz", 4e6)
+            capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+        _same_batch(dev, host)
+    # a slice of the block, like the worker's core_num slices
+    if len(rowptr) > 10:
+        a, e = (len(rowptr) - 1) // 5, (len(rowptr) - 1) // 2
+        _same_batch(capi.Batch(rowptr, keys, labels, a, e, on_gpu=True),
+                    capi.Batch(rowptr, keys, labels, a, e))
+
+
+def test_step_on_device_built_batches_and_oversized_cell():
+    """Training on GPU-built batches gives the exact-sum oracle's bits; includes a row whose
+    panel cell exceeds one tile (block-strided path of k_lr_forward_tiled)."""
+    rng = np.random.RandomState(5)
+    lens = rng.randint(0, 40, size=3000)
+    lens[100] = 9000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    keytab = np.array([O.hash_str(str(i)) for i in range(20000)], dtype=np.uint64)
+    keys = keytab[rng.randint(0, 20000, size=int(lens.sum()))]
+    labels = rng.randint(0, 2, size=3000).astype(np.int32)
+    capi.tune("min_panel_nnz", 0)
+    capi.tune("panel_slice_bytes", 32768)
+    try:
+        b = capi.Batch(rowptr, keys, labels, on_gpu=True)
+    finally:
+        capi.tune("min_panel_nnz", 4e6)
+        capi.tune("panel_slice_bytes", 1.5 * 1024 * 1024)
+    assert b.panels()[0] >= 8
+    ob = O.Batch(rowptr, keys, labels)
+    t, s = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 16), O.Store(O.OPT_FTRL, 1)
+    ws = capi.Workspace()
+    for _ in range(3):
+        capi.lr_step(t, b, ws)
+        with O.sum_mode(1):
+            O.lr_update(s, ob)
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)

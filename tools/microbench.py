@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--keybuild", action="store_true")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     st = HipStages("lr", "ftrl", 0, int(a.keys / a.load_factor) + 1024, 0, 1)
@@ -83,5 +84,39 @@ def main():
     st.check()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--keybuild" not in sys.argv:
     main()
+
+
+def keybuild():
+    """device key build (a3) at the config-2 shape: raw CSR already in HBM"""
+    import ctypes as C
+    import time
+    torch.cuda.set_device(0)
+    R, nnz, K = 50000, 200, 10_000_000
+    keytab = capi.hash_decimal_range(0, K)
+    rng = np.random.RandomState(2)
+    keys = torch.from_numpy(keytab[rng.randint(0, K, size=R * nnz)].view(np.int64)).cuda()
+    rowptr = torch.arange(R + 1, dtype=torch.int32, device="cuda") * nnz
+    labels = torch.zeros(R, dtype=torch.int32, device="cuda")
+    L = capi.lib()
+    ts = []
+    for it in range(6):
+        h = capi.vp()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.check(L.xf_batch_compile_dev(C.byref(h), keys.data_ptr(), rowptr.data_ptr(),
+                                          labels.data_ptr(), R, R * nnz, None))
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        L.xf_batch_free(h)
+    print("device key build (sort+unique+views+tiles+panels): %.2f ms  (min %.2f)" % (
+        float(np.median(ts[1:])) * 1e3, min(ts[1:]) * 1e3))
+    t0 = time.perf_counter()
+    hb = capi.Batch(np.arange(R + 1, dtype=np.uint64) * np.uint64(nnz),
+                    keytab[rng.randint(0, K, size=R * nnz)], np.zeros(R, np.int32))
+    print("host key build (%d threads): %.0f ms" % (os.cpu_count(), (time.perf_counter() - t0) * 1e3))
+
+
+if __name__ == "__main__" and "--keybuild" in sys.argv:
+    keybuild()

@@ -60,6 +60,10 @@ SIGNATURES = {
                                  C.POINTER(i32p)]),
     "xf_batch_compile": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t, C.c_size_t]),
     "xf_batch_free": (C.c_int, [vp]),
+    "xf_batch_compile_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
+    "xf_batch_compile_gpu": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t,
+                                       C.c_size_t, vp]),
+    "xf_batch_download": (C.c_int, [vp]),
     "xf_batch_dims": (C.c_int, [vp, u32p, u32p, u32p, u32p]),
     "xf_batch_host": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(u32p),
                                 C.POINTER(u32p), C.POINTER(u32p), C.POINTER(i32p),
@@ -189,15 +193,21 @@ def read_blocks(path, cap_bytes):
 class Batch:
     """A compiled minibatch (host arrays; device mirror after upload())."""
 
-    def __init__(self, rowptr, keys, labels, row_begin=0, row_end=None):
+    def __init__(self, rowptr, keys, labels, row_begin=0, row_end=None, on_gpu=False):
+        """on_gpu=False: host key build (xf_batch_compile); True: the GPU one
+        (xf_batch_compile_gpu), the batch is then already device-resident."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         labels = np.ascontiguousarray(labels, dtype=np.int32)
         if row_end is None:
             row_end = len(rowptr) - 1
         self.h = vp()
-        check(lib().xf_batch_compile(C.byref(self.h), _p(rowptr, u64p), _p(keys, u64p),
-                                     _p(labels, i32p), row_begin, row_end))
+        if on_gpu:
+            check(lib().xf_batch_compile_gpu(C.byref(self.h), _p(rowptr, u64p), _p(keys, u64p),
+                                             _p(labels, i32p), row_begin, row_end, None))
+        else:
+            check(lib().xf_batch_compile(C.byref(self.h), _p(rowptr, u64p), _p(keys, u64p),
+                                         _p(labels, i32p), row_begin, row_end))
         R, N, U, H = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), C.byref(U), C.byref(H)))
         self.R, self.NNZ, self.U, self.H = R.value, N.value, U.value, H.value

@@ -137,6 +137,18 @@ void build_tiles(xf_batch *b) {
 
 }  // namespace
 
+namespace xf {
+double panel_slice_bytes() { return g_panel_slice_bytes; }
+double min_panel_nnz() { return g_min_panel_nnz; }
+}  // namespace xf
+
+extern "C" int xf_batch_download(xf_batch *b);
+
+static int need_host(const xf_batch *b) {
+  if (b && b->on_device_only) return xf_batch_download(const_cast<xf_batch *>(b));
+  return XF_OK;
+}
+
 extern "C" int xf_tune(const char *name, double value) {
   XF_REQUIRE(name, "xf_tune: null name");
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
@@ -148,6 +160,7 @@ extern "C" int xf_tune(const char *name, double value) {
 
 extern "C" int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr) {
   XF_REQUIRE(b && ntiles, "xf_batch_tiles: null argument");
+  XF_TRY(need_host(b));
   *ntiles = (uint32_t)(b->tile_ptr.size() - 1);
   if (tile_ptr) *tile_ptr = b->tile_ptr.data();
   return XF_OK;
@@ -156,6 +169,7 @@ extern "C" int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_
 extern "C" int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
                                   const uint32_t **panel_first, uint32_t *grid) {
   XF_REQUIRE(b && ntiles, "xf_batch_fwd_tiles: null argument");
+  XF_TRY(need_host(b));
   *ntiles = b->P ? (uint32_t)b->ftile_ptr.size() - 1 : 0;
   if (tile_ptr) *tile_ptr = b->ftile_ptr.data();
   if (panel_first) *panel_first = b->fpanel_first.data();
@@ -166,6 +180,7 @@ extern "C" int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uin
 extern "C" int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
                                const uint32_t **pidx) {
   XF_REQUIRE(b && P, "xf_batch_panels: null argument");
+  XF_TRY(need_host(b));
   *P = b->P;
   if (pptr) *pptr = b->pptr.data();
   if (pidx) *pidx = b->pidx.data();
@@ -243,6 +258,7 @@ extern "C" int xf_batch_host(const xf_batch *b, const uint64_t **ukeys, const ui
                              const uint32_t **coo_row, const int32_t **labels,
                              const uint32_t **heavy) {
   XF_REQUIRE(b, "xf_batch_host: null batch");
+  XF_TRY(need_host(b));
   if (ukeys) *ukeys = b->ukeys.data();
   if (rowptr) *rowptr = b->rowptr.data();
   if (uidx) *uidx = b->uidx.data();

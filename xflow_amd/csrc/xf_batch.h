@@ -16,6 +16,7 @@ struct xf_batch {
   std::vector<uint32_t> ftile_ptr, fpanel_first;  // forward tiles over (panel,row) cells
   uint32_t fwd_grid = 0;
   std::vector<int32_t> labels;
+  bool on_device_only = false;  // built by xf_batch_compile_dev and not downloaded yet
   void *d_blob = nullptr;  // one device allocation holding all arrays
   xf_dev_batch view{};
 };

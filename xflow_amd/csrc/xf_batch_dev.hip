@@ -1,0 +1,510 @@
+// xf_batch_dev.hip — the minibatch key build ON THE GPU (gfx950).
+//
+// Replaces the same reference code as xf_batch.cc (the key build at the top of
+// LRWorker::update / FMWorker::update, src/model/lr/lr_worker.cc:146-166,
+// src/model/fm/fm_worker.cc:205-225: flatten the slice to all_keys[(fid,sid)], std::sort by
+// fid, sorted-unique key list) and produces the identical compiled batch — every array equals
+// the host builder's (tests/test_gpu_parity.py::test_device_key_build_equals_host).
+//
+// Pipeline, all on one stream:
+//   1. (key, position) pairs sorted by key           rocPRIM device radix sort (library sort,
+//                                                    as hipBLASLt would be for a plain GEMM)
+//   2. segment heads -> unique index (scan), ukeys / segptr / uidx / coo_row
+//   3. heavy-key list and gradient tiles             flag + scan + scatter (xf_tiling.h rules)
+//   4. panel-major forward view: cell counts (atomics), scan, stable in-row placement with
+//      wave ballots; forward tiles by the same flag + scan + scatter
+// The sort is stable on (key, position): radix sort is stable and positions are the values,
+// so inside a key the occurrences stay in row-major order, like the host builder's.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "xf_batch.h"
+#include "xf_common.h"
+#include "xf_tiling.h"
+
+namespace xf {
+double panel_slice_bytes();  // xf_batch.cc tuning knobs
+double min_panel_nnz();
+}  // namespace xf
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(size_t n) {
+  size_t g = (n + kBlock - 1) / kBlock;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define XF_GRID_STRIDE(i, n)                                                     \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); \
+       i += (size_t)gridDim.x * blockDim.x)
+
+__global__ void k_iota(uint32_t *p, size_t n) { XF_GRID_STRIDE(i, n) p[i] = (uint32_t)i; }
+
+__global__ void k_heads(const uint64_t *__restrict__ sk, size_t n, uint32_t *__restrict__ head) {
+  XF_GRID_STRIDE(j, n) head[j] = (j == 0 || sk[j] != sk[j - 1]) ? 1u : 0u;
+}
+
+// uid1 = inclusive scan of head (1-based unique index)
+__global__ void k_unique(const uint64_t *__restrict__ sk, const uint32_t *__restrict__ head,
+                         const uint32_t *__restrict__ uid1, size_t n, uint32_t U,
+                         uint64_t *__restrict__ ukeys, uint32_t *__restrict__ segptr) {
+  XF_GRID_STRIDE(j, n) {
+    if (head[j]) {
+      ukeys[uid1[j] - 1] = sk[j];
+      segptr[uid1[j] - 1] = (uint32_t)j;
+    }
+    if (j == 0) segptr[U] = (uint32_t)n;
+  }
+}
+
+// row_of[pos] = row of the pos-th nonzero: one wave per row, coalesced writes
+__global__ void k_row_of(const uint32_t *__restrict__ rowptr, uint32_t R,
+                         uint32_t *__restrict__ row_of) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nw)
+    for (uint32_t j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) row_of[j] = r;
+}
+
+__global__ void k_uidx_coo(const uint32_t *__restrict__ spos, const uint32_t *__restrict__ uid1,
+                           const uint32_t *__restrict__ row_of, size_t n,
+                           uint32_t *__restrict__ uidx, uint32_t *__restrict__ coo_row) {
+  XF_GRID_STRIDE(j, n) {
+    const uint32_t pos = spos[j];
+    uidx[pos] = uid1[j] - 1;
+    coo_row[j] = row_of[pos];
+  }
+}
+
+__global__ void k_key_flags(const uint32_t *__restrict__ segptr, uint32_t U,
+                            uint32_t *__restrict__ heavy_flag, uint32_t *__restrict__ tile_flag) {
+  XF_GRID_STRIDE(u, U) {
+    heavy_flag[u] = segptr[u + 1] - segptr[u] > XF_HEAVY_SEG ? 1u : 0u;
+    tile_flag[u] = xf::grad_tile_starts_at(segptr, (uint32_t)u) ? 1u : 0u;
+  }
+}
+
+// out[scan[i]] = i for flagged i (scan = exclusive scan of flag); out[total] = sentinel
+__global__ void k_compact_index(const uint32_t *__restrict__ flag,
+                                const uint32_t *__restrict__ scan, size_t n,
+                                uint32_t *__restrict__ out) {
+  XF_GRID_STRIDE(i, n) if (flag[i]) out[scan[i]] = (uint32_t)i;
+}
+
+// cnt[p*(R+1) + r + 1] = nonzeros of row r in panel p.  One wave per row; the per-panel
+// counters live in LDS and are bumped once per distinct panel of a 64-nonzero chunk (ballot),
+// so there are no global atomics.
+__global__ void __launch_bounds__(kBlock)
+k_cell_counts(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx, uint32_t R,
+              uint32_t P, uint32_t U, uint32_t *__restrict__ cnt /* P*(R+1) */) {
+  __shared__ uint32_t off_all[kBlock / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t *off = off_all[wv];
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + wv; r < R; r += nw) {
+    for (uint32_t p = lane; p < P; p += 64) off[p] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    for (uint32_t j0 = b; j0 < e; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool act = j < e;
+      const uint32_t p = act ? xf::panel_of(uidx[j], P, U) : 0xFFFFFFFFu;
+      unsigned long long todo = __ballot(act);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t p0 = __shfl(p, leader);
+        const unsigned long long m = __ballot(p == p0);
+        if ((int)lane == leader) off[p0] += __popcll(m);
+        todo &= ~m;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t p = lane; p < P; p += 64) cnt[(size_t)p * (R + 1) + r + 1] = off[p];
+    if (lane == 0 && r == 0)
+      for (uint32_t p = 0; p < P; ++p) cnt[(size_t)p * (R + 1)] = 0;  // the panels' first cells
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// pptr = exclusive scan of cnt laid out [p][r+1] -> here cnt already holds counts shifted by
+// one cell, so an INCLUSIVE scan over the flat array gives pptr directly.
+
+// stable placement: within a (panel,row) cell the CSR order is kept
+__global__ void __launch_bounds__(kBlock)
+k_fill_pidx(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx,
+            const uint32_t *__restrict__ pptr, uint32_t R, uint32_t P, uint32_t U,
+            uint32_t *__restrict__ pidx) {
+  __shared__ uint32_t off_all[kBlock / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t *off = off_all[wv];
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + wv; r < R; r += nw) {
+    for (uint32_t p = lane; p < P; p += 64) off[p] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    for (uint32_t j0 = b; j0 < e; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool act = j < e;
+      const uint32_t ui = act ? uidx[j] : 0;
+      const uint32_t p = act ? xf::panel_of(ui, P, U) : 0xFFFFFFFFu;
+      unsigned long long todo = __ballot(act);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t p0 = __shfl(p, leader);
+        const unsigned long long m = __ballot(p == p0);
+        if (p == p0) {
+          const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+          pidx[pptr[(size_t)p0 * (R + 1) + r] + off[p0] + rank] = ui;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((int)lane == leader) off[p0] += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~m;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void k_cell_flags(const uint32_t *__restrict__ pptr, uint32_t R, uint32_t P,
+                             uint32_t *__restrict__ flag /* P*(R+1) */) {
+  const size_t n = (size_t)P * (R + 1);
+  XF_GRID_STRIDE(s, n) {
+    const uint32_t p = (uint32_t)(s / (R + 1)), r = (uint32_t)(s - (size_t)p * (R + 1));
+    flag[s] = (r < R && xf::fwd_tile_starts_at(pptr + (size_t)p * (R + 1), r)) ? 1u : 0u;
+  }
+}
+
+__global__ void k_panel_first(const uint32_t *__restrict__ scan, uint32_t R, uint32_t P,
+                              uint32_t total, uint32_t *__restrict__ panel_first) {
+  XF_GRID_STRIDE(p, (size_t)P + 1)
+  panel_first[p] = p < P ? scan[(size_t)p * (R + 1)] : total;
+}
+
+// Scratch for one build: a bump allocator over one persistent device arena (a build
+// synchronises its stream before it returns, so the arena can be reused by the next one).
+// Scratch objects nest like a stack (xf_batch_compile_gpu -> xf_batch_compile_dev).
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, used = 0, high = 0;  // high = bytes the deepest nesting wanted
+};
+Arena &arena() {
+  static thread_local Arena a;
+  return a;
+}
+
+struct Scratch {
+  size_t mark;
+  std::vector<void *> overflow;  // when the arena was too small: plain allocations
+  size_t spilled = 0;
+  Scratch() : mark(arena().used) {}
+  ~Scratch() {
+    for (void *p : overflow) (void)hipFree(p);
+    Arena &a = arena();
+    a.high = std::max(a.high, a.used + spilled);
+    a.used = mark;
+    if (mark == 0 && a.high > a.cap) {  // outermost scope: grow for the next build
+      if (a.base) (void)hipFree(a.base);
+      a.base = nullptr;
+      a.cap = 0;
+      const size_t want = a.high + a.high / 4;
+      if (hipMalloc((void **)&a.base, want) == hipSuccess) a.cap = want;
+    }
+  }
+  template <typename T>
+  int get(T **p, size_t n) {
+    const size_t bytes = ((std::max<size_t>(n, 1) * sizeof(T)) + 255) & ~(size_t)255;
+    Arena &a = arena();
+    if (a.used + bytes <= a.cap) {
+      *p = (T *)(a.base + a.used);
+      a.used += bytes;
+      return XF_OK;
+    }
+    spilled += bytes;
+    XF_HIP(hipMalloc((void **)p, bytes));
+    overflow.push_back(*p);
+    return XF_OK;
+  }
+};
+
+int exclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+  size_t tb = 0;
+  XF_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::exclusive_scan(tmp, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+  return XF_OK;
+}
+
+int inclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+  size_t tb = 0;
+  XF_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, n, rocprim::plus<uint32_t>(), s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::plus<uint32_t>(), s));
+  return XF_OK;
+}
+
+}  // namespace
+
+// Device key build.  d_keys[NNZ], d_rowptr[R+1] (row-relative, d_rowptr[0] == 0),
+// d_labels[R] are device pointers; the compiled batch stays on the device
+// (xf_batch_download brings the arrays to the host for inspection).
+extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
+                                    const uint32_t *d_rowptr, const int32_t *d_labels,
+                                    uint32_t R, uint32_t NNZ, void *stream) {
+  XF_REQUIRE(out && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
+             "xf_batch_compile_dev: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  xf_batch *b = new xf_batch;
+  b->R = R;
+  b->NNZ = NNZ;
+  b->on_device_only = true;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+
+  // ---- 1. sort (key, position)
+  uint64_t *sk = nullptr;
+  uint32_t *pos = nullptr, *spos = nullptr, *head = nullptr, *uid1 = nullptr;
+  XF_TRY(sc.get(&sk, NNZ));
+  XF_TRY(sc.get(&pos, NNZ));
+  XF_TRY(sc.get(&spos, NNZ));
+  XF_TRY(sc.get(&head, NNZ));
+  XF_TRY(sc.get(&uid1, NNZ));
+  uint32_t U = 0;
+  if (NNZ) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, pos, (size_t)NNZ);
+    size_t tb = 0;
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, sk, pos, spos, (size_t)NNZ, 0, 64, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, d_keys, sk, pos, spos, (size_t)NNZ, 0, 64, s));
+    // ---- 2. unique index
+    hipLaunchKernelGGL(k_heads, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, sk, (size_t)NNZ, head);
+    XF_TRY(inclusive_scan_u32(sc, head, uid1, NNZ, s));
+    XF_HIP(hipMemcpyAsync(&U, uid1 + (NNZ - 1), 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+  }
+  b->U = U;
+  uint64_t *ukeys = nullptr;
+  uint32_t *segptr = nullptr, *uidx = nullptr, *coo = nullptr;
+  XF_TRY(sc.get(&ukeys, U));
+  XF_TRY(sc.get(&segptr, (size_t)U + 1));
+  XF_TRY(sc.get(&uidx, NNZ));
+  XF_TRY(sc.get(&coo, NNZ));
+  if (NNZ) {
+    hipLaunchKernelGGL(k_unique, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, sk, head, uid1,
+                       (size_t)NNZ, U, ukeys, segptr);
+    hipLaunchKernelGGL(k_row_of, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr, R,
+                       pos /* reused: iota is no longer needed after the sort */);
+    hipLaunchKernelGGL(k_uidx_coo, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, spos, uid1, pos,
+                       (size_t)NNZ, uidx, coo);
+  } else {
+    XF_HIP(hipMemsetAsync(segptr, 0, 4, s));
+  }
+  // ---- 3. heavy keys and gradient tiles
+  uint32_t *hflag = nullptr, *tflag = nullptr, *hscan = nullptr, *tscan = nullptr;
+  uint32_t *heavy = nullptr, *tile_ptr = nullptr;
+  XF_TRY(sc.get(&hflag, (size_t)U + 1));
+  XF_TRY(sc.get(&tflag, (size_t)U + 1));
+  XF_TRY(sc.get(&hscan, (size_t)U + 1));
+  XF_TRY(sc.get(&tscan, (size_t)U + 1));
+  XF_TRY(sc.get(&heavy, (size_t)U + 1));
+  XF_TRY(sc.get(&tile_ptr, (size_t)U + 2));
+  uint32_t H = 0, ntiles = 0;
+  if (U) {
+    XF_HIP(hipMemsetAsync(hflag + U, 0, 4, s));
+    XF_HIP(hipMemsetAsync(tflag + U, 0, 4, s));
+    hipLaunchKernelGGL(k_key_flags, dim3(grid_for(U)), dim3(kBlock), 0, s, segptr, U, hflag,
+                       tflag);
+    XF_TRY(exclusive_scan_u32(sc, hflag, hscan, (size_t)U + 1, s));  // hscan[U] = H
+    XF_TRY(exclusive_scan_u32(sc, tflag, tscan, (size_t)U + 1, s));  // tscan[U] = ntiles
+    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, hflag, hscan,
+                       (size_t)U, heavy);
+    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, tflag, tscan,
+                       (size_t)U, tile_ptr);
+    XF_HIP(hipMemcpyAsync(&H, hscan + U, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipMemcpyAsync(&ntiles, tscan + U, 4, hipMemcpyDeviceToHost, s));
+  }
+  // ---- 4. panel-major forward view
+  const uint32_t P = xf::panel_count(U, NNZ, xf::panel_slice_bytes(), xf::min_panel_nnz());
+  const size_t ncell = (size_t)P * ((size_t)R + 1);
+  uint32_t *pptr = nullptr, *pidx = nullptr, *cflag = nullptr, *cscan = nullptr;
+  uint32_t *ftile = nullptr, *fpf = nullptr;
+  uint32_t nft = 0;
+  std::vector<uint32_t> h_fpf;
+  if (P) {
+    XF_TRY(sc.get(&pptr, ncell));
+    XF_TRY(sc.get(&pidx, NNZ));
+    XF_TRY(sc.get(&cflag, ncell + 1));
+    XF_TRY(sc.get(&cscan, ncell + 1));
+    XF_TRY(sc.get(&ftile, ncell + 2));
+    XF_TRY(sc.get(&fpf, (size_t)P + 1));
+    hipLaunchKernelGGL(k_cell_counts, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s,
+                       d_rowptr, uidx, R, P, U, pptr);
+    XF_TRY(inclusive_scan_u32(sc, pptr, pptr, ncell, s));  // shifted counts -> offsets
+    hipLaunchKernelGGL(k_fill_pidx, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr,
+                       uidx, pptr, R, P, U, pidx);
+    XF_HIP(hipMemsetAsync(cflag + ncell, 0, 4, s));
+    hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(ncell)), dim3(kBlock), 0, s, pptr, R, P, cflag);
+    XF_TRY(exclusive_scan_u32(sc, cflag, cscan, ncell + 1, s));  // cscan[ncell] = nft
+    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(ncell)), dim3(kBlock), 0, s, cflag, cscan,
+                       ncell, ftile);
+    XF_HIP(hipMemcpyAsync(&nft, cscan + ncell, 4, hipMemcpyDeviceToHost, s));
+  }
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  b->H = H;
+  if (U) {  // close the tile lists
+    XF_HIP(hipMemcpyAsync(tile_ptr + ntiles, &U, 4, hipMemcpyHostToDevice, s));
+  } else {
+    const uint32_t zero = 0;
+    XF_HIP(hipMemcpyAsync(tile_ptr, &zero, 4, hipMemcpyHostToDevice, s));
+  }
+  if (P) {
+    const uint32_t endcell = (uint32_t)((size_t)(P - 1) * ((size_t)R + 1) + R);
+    XF_HIP(hipMemcpyAsync(ftile + nft, &endcell, 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_panel_first, dim3(1), dim3(kBlock), 0, s, cscan, R, P, nft, fpf);
+    h_fpf.resize((size_t)P + 1);
+    XF_HIP(hipMemcpyAsync(h_fpf.data(), fpf, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+    uint32_t longest = 0;
+    for (uint32_t x = 0; x < 8; ++x) {
+      uint32_t len = 0;
+      for (uint32_t p = x; p < P; p += 8) len += h_fpf[p + 1] - h_fpf[p];
+      longest = std::max(longest, len);
+    }
+    b->fwd_grid = 8 * longest;
+  }
+  b->P = P;
+
+  // ---- assemble the batch's own device allocation (same layout as xf_batch_upload)
+  const size_t n_tile = (size_t)ntiles + 1, n_ftile = P ? (size_t)nft + 1 : 0;
+  const size_t o_ukeys = 0;
+  const size_t o_rowptr = o_ukeys + al((size_t)U * 8);
+  const size_t o_uidx = o_rowptr + al(((size_t)R + 1) * 4);
+  const size_t o_segptr = o_uidx + al((size_t)NNZ * 4);
+  const size_t o_coo = o_segptr + al(((size_t)U + 1) * 4);
+  const size_t o_labels = o_coo + al((size_t)NNZ * 4);
+  const size_t o_heavy = o_labels + al((size_t)R * 4);
+  const size_t o_pptr = o_heavy + al((size_t)H * 4);
+  const size_t o_pidx = o_pptr + al(ncell * 4);
+  const size_t o_scr = o_pidx + al(P ? (size_t)NNZ * 4 : 0);
+  const size_t o_tile = o_scr + al((size_t)P * R * 8);
+  const size_t o_ftile = o_tile + al(n_tile * 4);
+  const size_t o_fpf = o_ftile + al(n_ftile * 4);
+  const size_t total = o_fpf + al(P ? ((size_t)P + 1) * 4 : 0) + 256;
+  char *d = nullptr;
+  XF_HIP(hipMalloc((void **)&d, total));
+  auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    return hipMemcpyAsync(d + off, src, bytes, hipMemcpyDeviceToDevice, s);
+  };
+  XF_HIP(cp(o_ukeys, ukeys, (size_t)U * 8));
+  XF_HIP(cp(o_rowptr, d_rowptr, ((size_t)R + 1) * 4));
+  XF_HIP(cp(o_uidx, uidx, (size_t)NNZ * 4));
+  XF_HIP(cp(o_segptr, segptr, ((size_t)U + 1) * 4));
+  XF_HIP(cp(o_coo, coo, (size_t)NNZ * 4));
+  XF_HIP(cp(o_labels, d_labels, (size_t)R * 4));
+  XF_HIP(cp(o_heavy, heavy, (size_t)H * 4));
+  XF_HIP(cp(o_tile, tile_ptr, n_tile * 4));
+  if (P) {
+    XF_HIP(cp(o_pptr, pptr, ncell * 4));
+    XF_HIP(cp(o_pidx, pidx, (size_t)NNZ * 4));
+    XF_HIP(cp(o_ftile, ftile, n_ftile * 4));
+    XF_HIP(cp(o_fpf, fpf, ((size_t)P + 1) * 4));
+  }
+  XF_HIP(hipStreamSynchronize(s));
+  b->d_blob = d;
+  xf_dev_batch &v = b->view;
+  v.R = R;
+  v.NNZ = NNZ;
+  v.U = U;
+  v.H = H;
+  v.ukeys = (const uint64_t *)(d + o_ukeys);
+  v.rowptr = (const uint32_t *)(d + o_rowptr);
+  v.uidx = (const uint32_t *)(d + o_uidx);
+  v.segptr = (const uint32_t *)(d + o_segptr);
+  v.coo_row = (const uint32_t *)(d + o_coo);
+  v.labels = (const int32_t *)(d + o_labels);
+  v.heavy = H ? (const uint32_t *)(d + o_heavy) : nullptr;
+  v.P = P;
+  v.fwd_ntiles = P ? nft : 0;
+  v.pptr = P ? (const uint32_t *)(d + o_pptr) : nullptr;
+  v.pidx = P ? (const uint32_t *)(d + o_pidx) : nullptr;
+  v.fwd_scratch = P ? (double *)(d + o_scr) : nullptr;
+  v.fwd_tile_ptr = P ? (const uint32_t *)(d + o_ftile) : nullptr;
+  v.fwd_panel_first = P ? (const uint32_t *)(d + o_fpf) : nullptr;
+  v.fwd_grid = b->fwd_grid;
+  v.pad3_ = 0;
+  v.ntiles = ntiles;
+  v.pad2_ = 0;
+  v.tile_ptr = (const uint32_t *)(d + o_tile);
+  *out = b;
+  return XF_OK;
+}
+
+// Bring a device-built batch's arrays to the host vectors (inspection / tests).
+extern "C" int xf_batch_download(xf_batch *b) {
+  XF_REQUIRE(b && b->d_blob, "xf_batch_download: batch is not on the device");
+  const xf_dev_batch &v = b->view;
+  auto get = [&](auto &vec, const void *src, size_t n) -> hipError_t {
+    vec.resize(n);
+    if (!n) return hipSuccess;
+    return hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost);
+  };
+  XF_HIP(get(b->ukeys, v.ukeys, v.U));
+  XF_HIP(get(b->rowptr, v.rowptr, (size_t)v.R + 1));
+  XF_HIP(get(b->uidx, v.uidx, v.NNZ));
+  XF_HIP(get(b->segptr, v.segptr, (size_t)v.U + 1));
+  XF_HIP(get(b->coo_row, v.coo_row, v.NNZ));
+  XF_HIP(get(b->labels, v.labels, v.R));
+  XF_HIP(get(b->heavy, v.heavy, v.H));
+  XF_HIP(get(b->tile_ptr, v.tile_ptr, (size_t)v.ntiles + 1));
+  if (v.P) {
+    XF_HIP(get(b->pptr, v.pptr, (size_t)v.P * ((size_t)v.R + 1)));
+    XF_HIP(get(b->pidx, v.pidx, v.NNZ));
+    XF_HIP(get(b->ftile_ptr, v.fwd_tile_ptr, (size_t)v.fwd_ntiles + 1));
+    XF_HIP(get(b->fpanel_first, v.fwd_panel_first, (size_t)v.P + 1));
+  }
+  b->on_device_only = false;
+  return XF_OK;
+}
+
+// Host-array front end of the device key build: same arguments as xf_batch_compile (the
+// reader's block arrays and a row slice); uploads the raw slice and builds on the GPU.
+extern "C" int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
+                                    const int32_t *labels, size_t row_begin, size_t row_end,
+                                    void *stream) {
+  XF_REQUIRE(out && rowptr && labels && row_end >= row_begin, "xf_batch_compile_gpu: bad argument");
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(NNZ == 0 || keys, "xf_batch_compile_gpu: null keys");
+  XF_REQUIRE(R < 0xFFFFFFFFull && NNZ < 0xFFFFFFFFull, "xf_batch_compile_gpu: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<uint32_t> rp(R + 1);
+  for (size_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+  Scratch sc;
+  uint64_t *d_keys = nullptr;
+  uint32_t *d_rp = nullptr;
+  int32_t *d_lab = nullptr;
+  XF_TRY(sc.get(&d_keys, NNZ));
+  XF_TRY(sc.get(&d_rp, R + 1));
+  XF_TRY(sc.get(&d_lab, R));
+  if (NNZ) XF_HIP(hipMemcpyAsync(d_keys, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_rp, rp.data(), (R + 1) * 4, hipMemcpyHostToDevice, s));
+  if (R) XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return xf_batch_compile_dev(out, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ, stream);
+}

@@ -91,6 +91,13 @@ int Worker::grow_if_needed(size_t incoming) {
   return XF_OK;
 }
 
+// the key build of update() (lr_worker.cc:146-166): on the GPU unless key_build=host
+int Worker::compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys,
+                    const int32_t *labels, size_t start, size_t end) {
+  if (key_build_gpu) return xf_batch_compile_gpu(b, rowptr, keys, labels, start, end, nullptr);
+  return xf_batch_compile(b, rowptr, keys, labels, start, end);
+}
+
 // LRWorker::update / FMWorker::update (lr_worker.cc:145-177, fm_worker.cc:204-245)
 int Worker::update(xf_batch *b) {
   uint32_t U = 0;
@@ -146,7 +153,7 @@ int Worker::batch_training() {
           const size_t start = i * thread_size, end = (i + 1) * thread_size;
           if (end == start) continue;
           xf_batch *b = nullptr;
-          XF_TRY(xf_batch_compile(&b, rowptr, keys, labels, start, end));
+          XF_TRY(compile(&b, rowptr, keys, labels, start, end));
           rc = update(b);
           if (rc == XF_OK) rc = xf_table_check(table_w_, nullptr);
           if (rc == XF_OK && table_v_) rc = xf_table_check(table_v_, nullptr);
@@ -201,7 +208,7 @@ int Worker::predict(int rank, int block) {
       const size_t start = i * thread_size, end = (i + 1) * thread_size;
       if (end == start) continue;
       xf_batch *b = nullptr;
-      XF_TRY(xf_batch_compile(&b, rowptr, keys, labels, start, end));
+      XF_TRY(compile(&b, rowptr, keys, labels, start, end));
       pctr.resize(end - start);
       uint32_t U = 0;
       xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
@@ -273,6 +280,12 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "lr") learning_rate = (float)atof(value);
   else if (n == "seed") seed = strtoull(value, nullptr, 10);
   else if (n == "cache_batches") cache_batches = atoi(value);
+  else if (n == "key_build") {
+    if (!strcmp(value, "gpu")) key_build_gpu = true;
+    else if (!strcmp(value, "host")) key_build_gpu = false;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: key_build must be gpu or host");
+  }
   else
     return xf::set_error(XF_EINVAL, "XFSetParam: unknown parameter '%s'", name);
   return XF_OK;

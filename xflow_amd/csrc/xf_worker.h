@@ -40,10 +40,13 @@ class Worker {
   float learning_rate = 0.001f;                                       // sgd.h:16
   uint64_t seed = 0;
   int cache_batches = 1;
+  bool key_build_gpu = true;  // key build of update() on the GPU (xf_batch_compile_gpu)
   std::string pred_path;
 
  private:
   int create_tables();
+  int compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys, const int32_t *labels,
+              size_t start, size_t end);
   int grow_if_needed(size_t incoming);
   uint64_t seen_upper_ = 0;
 
