@@ -189,6 +189,28 @@ def test_sharded_ownership_bit_exact():
     assert total == len(keys)
 
 
+def test_duplicate_keys_across_sources_in_one_resolve():
+    """The sharded owner resolves the key lists of all workers in one launch: the same new key
+    from several sources must get ONE row, whichever lane wins the insert."""
+    import torch
+    rng = np.random.RandomState(8)
+    base = np.array([O.hash_str(str(i)) for i in range(200000)], dtype=np.uint64)
+    lists = [np.sort(rng.choice(base, size=120000, replace=False)) for _ in range(4)]
+    allk = np.concatenate(lists)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 19)
+    dk = torch.from_numpy(allk.view(np.int64)).cuda()
+    rows = torch.empty(len(allk), dtype=torch.int32, device="cuda")
+    t.resolve_dev(dk.data_ptr(), len(allk), rows.data_ptr())
+    t.check()
+    r = rows.cpu().numpy()
+    uniq, inv = np.unique(allk, return_inverse=True)
+    assert len(t) == len(uniq)
+    first = np.full(len(uniq), -1, dtype=np.int64)
+    first[inv] = r                      # any occurrence: they must all agree
+    assert np.array_equal(first[inv], r)
+    assert sorted(first.tolist()) == list(range(len(uniq)))   # dense rows, one per key
+
+
 def test_rows_are_dense_and_survive_reserve():
     """State rows are handed out densely on first touch and keep their numbers when the
     key index is rehashed (so a row array from an earlier resolve stays valid)."""

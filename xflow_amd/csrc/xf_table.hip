@@ -53,9 +53,10 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 // of kWin consecutive index positions with independent loads (one memory round trip instead
 // of up to kWin dependent ones: a wavefront waits for its slowest lane, and the longest of
 // 64 linear-probe chains is several positions even at load 0.5).
-// Keys must be unique within one launch (a second lane could otherwise read rows[] of a key
-// before its inserter has published the row).
-// GATHER (dim == 1): also emit the Pull payload w[row] (ftrl.h:75-77).
+// The same key may appear several times in one launch (key lists of several workers): the
+// lane that wins the insert publishes the row, the others wait for it.
+// GATHER (dim == 1, zero-initialised tables or unique keys): also emit the Pull payload
+// w[row] (ftrl.h:75-77).
 constexpr int kWin = 4;
 
 template <bool GATHER>
@@ -129,7 +130,6 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
         const unsigned long long r = base + __popcll(m & ((1ull << lane) - 1ull));
         if (r < T.max_rows) {
           row = (uint32_t)r;
-          T.rows[pos] = row;
           if (T.init_kind != XF_INIT_ZERO) {  // memory is pre-zeroed for XF_INIT_ZERO
             float *dst = T.w + (size_t)row * T.dim;
             for (int j = 0; j < T.dim; ++j)
@@ -139,12 +139,22 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
         } else {
           atomicOr(&T.stat->err, xf::kErrFull);
         }
+        // publish the row (agent scope: lanes of other CUs that meet this key in the same
+        // launch wait for it below); an overflowed key publishes the write-off row
+        __hip_atomic_store(&T.rows[pos], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (active) {
       if (!inserted && !bad) {
         row = T.rows[pos];
-        if (row == xf::kNoRow) {  // inserted by another lane of this launch: contract breach
+        // The key may have been inserted by another lane of THIS launch (the same key sent by
+        // several workers): its row is published right after the insert; the inserter never
+        // waits for anybody, so this bounded wait cannot deadlock.
+        for (int spin = 0; row == xf::kNoRow && spin < (1 << 22); ++spin) {
+          __builtin_amdgcn_s_sleep(1);
+          row = __hip_atomic_load(&T.rows[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (row == xf::kNoRow) {
           atomicOr(&T.stat->err, xf::kErrDupKey);
           row = (uint32_t)T.max_rows;
         }
@@ -443,7 +453,7 @@ extern "C" int xf_table_check(xf_table *t, void *stream) {
     return xf::set_error(XF_EINVAL, "a key outside shard %u/%u's range was sent to it",
                          t->cfg.shard, t->cfg.nshards);
   if (st.err & xf::kErrDupKey)
-    return xf::set_error(XF_EINVAL, "duplicate keys inside one resolve/pull call");
+    return xf::set_error(XF_EINVAL, "a key's row was never published (internal error)");
   return XF_OK;
 }
 

@@ -114,6 +114,15 @@ class HipStages:
                           self._stream())
         return slots
 
+    def pull(self, table, keys_i64):
+        """resolve + weight payload in one pass (dim-1, zero-initialised tables)"""
+        n = keys_i64.numel()
+        rows = self.empty(n, torch.int32)
+        vals = self.empty(n, torch.float32)
+        capi.check(capi.lib().xf_table_pull_dev(table.h, keys_i64.data_ptr(), n, rows.data_ptr(),
+                                                vals.data_ptr(), self._stream()))
+        return rows, vals
+
     def gather(self, table, slots):
         vals = self.empty(slots.numel() * table.dim, torch.float32)
         table.gather_dev(slots.data_ptr(), slots.numel(), vals.data_ptr(), self._stream())
@@ -199,6 +208,10 @@ class ShardedTrainer:
         b.send_counts = send.tolist()
         b.recv_counts = recv.tolist()
         b.n_recv = int(sum(b.recv_counts))
+        # The owner-side key lists are part of the compiled minibatch too: like the batch
+        # itself they depend only on the input rows, so the key all-to-all runs once here and
+        # a step exchanges only what changes — weights one way, gradients the other.
+        b.rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
         return b
 
     def _a2a(self, src, in_counts, out_counts, width=1):
@@ -212,17 +225,11 @@ class ShardedTrainer:
 
     # ---- one minibatch step ----------------------------------------------------------------
     def _resolve(self, table, rkeys, counts):
-        """key -> state row on the owner.  One resolve call per source rank: a key list is
-        unique only within its source (the table's resolve contract), the same key may
-        arrive from several workers."""
-        parts, off = [], 0
-        for c in counts:
-            if c:
-                parts.append(self.stages.resolve(table, rkeys[off:off + c]))
-            off += c
-        if not parts:
+        """key -> state row on the owner, all source ranks' lists in one call (the same key
+        may arrive from several workers; the table's resolve handles that)."""
+        if rkeys.numel() == 0:
             return self.stages.empty(0, torch.int32)
-        return parts[0] if len(parts) == 1 else torch.cat(parts)
+        return self.stages.resolve(table, rkeys)
 
     def _mark(self, name):
         if self._prof is not None:
@@ -234,15 +241,17 @@ class ShardedTrainer:
         st = self.stages
         tw, tv = st.tables()
         self._mark("begin")
-        # Pull, part 1: sorted unique keys to their owners (ps-lite slicer ranges)
-        rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
-        self._mark("a2a_keys")
-        # owner: key -> slot (insert on first touch, ftrl.h:56), gather weights
-        slots_w = self._resolve(tw, rkeys, b.recv_counts)
+        # Pull, part 1 (keys to their owners, ps-lite slicer ranges) happened at compile time
+        rkeys = b.rkeys
+        # owner: key -> state row (insert on first touch, ftrl.h:56) and the weight payload
+        if hasattr(st, "pull") and rkeys.numel():
+            slots_w, w_recv = st.pull(tw, rkeys)
+        else:
+            slots_w = self._resolve(tw, rkeys, b.recv_counts)
+            w_recv = st.gather(tw, slots_w)
         if self.model == "fm":
             slots_v = self._resolve(tv, rkeys, b.recv_counts)
         self._mark("resolve")
-        w_recv = st.gather(tw, slots_w)
         if self.model == "fm":
             v_recv = st.gather(tv, slots_v)
         self._mark("gather")
@@ -282,7 +291,7 @@ class ShardedTrainer:
         """forward only (calculate_pctr): pulls insert unseen keys, as in the reference."""
         st = self.stages
         tw, tv = st.tables()
-        rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
+        rkeys = b.rkeys
         wu = self._a2a(st.gather(tw, self._resolve(tw, rkeys, b.recv_counts)), b.recv_counts,
                        b.send_counts)
         if self.model == "lr":
