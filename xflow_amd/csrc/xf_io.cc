@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "xf_common.h"
@@ -128,8 +129,15 @@ extern "C" int xf_reader_close(xf_reader *r) {
 
 namespace {
 
-// atof on the byte range [b, e) (fields are short; copy to a NUL-terminated scratch)
+// atof on the byte range [b, e).  Plain decimal integers (what fgid and most labels are) are
+// converted directly — the same value atof gives — everything else goes through atof.
 inline double field_atof(const char *b, const char *e, bool *ok) {
+  if (e - b >= 1 && e - b <= 9) {
+    uint32_t v = 0;
+    const char *c = b;
+    for (; c < e && *c >= '0' && *c <= '9'; ++c) v = v * 10 + (uint32_t)(*c - '0');
+    if (c == e) return (double)v;
+  }
   char tmp[48];
   const size_t n = (size_t)(e - b);
   if (n >= sizeof(tmp)) {
@@ -139,6 +147,75 @@ inline double field_atof(const char *b, const char *e, bool *ok) {
   memcpy(tmp, b, n);
   tmp[n] = '\0';
   return atof(tmp);
+}
+
+struct Piece {
+  std::vector<uint64_t> keys, rowend;
+  std::vector<int32_t> fgid, labels;
+  const char *err = nullptr;
+  bool hit_nul = false;
+};
+
+// One contiguous run of whole lines (load_data_from_disk.cc:126-208).
+void parse_piece(const char *p, const char *end, Piece *out) {
+  while (p < end) {
+    if (*p == '\0') {
+      out->hit_nul = true;
+      return;
+    }
+    const char *eol = p;
+    const char *tab = nullptr;
+    while (eol < end && *eol != '\n') {
+      if (!tab && *eol == '\t') tab = eol;
+      ++eol;
+    }
+    if (!tab) {
+      out->err = "no '\\t' after the label";
+      return;
+    }
+    bool ok = true;
+    const float y_tmp = (float)field_atof(p, tab, &ok);  // :129
+    if (!ok) {
+      out->err = "label field too long";
+      return;
+    }
+    out->labels.push_back(y_tmp > 0.0000001 ? 1 : 0);  // :131-134
+    const char *t = tab + 1;
+    while (t < eol) {
+      const char *te = t;
+      const char *c1 = nullptr, *c2 = nullptr;
+      while (te < eol && *te != ' ') {
+        if (*te == ':') {
+          if (!c1) c1 = te;
+          else if (!c2)
+            c2 = te;
+        }
+        ++te;
+      }
+      if (te == t) {               // empty token
+        if (te + 1 >= eol) break;  // a single trailing blank is harmless in the reference
+        out->labels.pop_back();
+        out->err = "empty token";
+        return;
+      }
+      if (!c1 || !c2) {  // the reference would scan past the terminator here
+        out->labels.pop_back();
+        out->err = "token without fgid:fid:val";
+        return;
+      }
+      const double fg = field_atof(t, c1, &ok);  // :149
+      if (!ok) {
+        out->labels.pop_back();
+        out->err = "fgid field too long";
+        return;
+      }
+      out->fgid.push_back((int32_t)fg);
+      out->keys.push_back(xf_hash_bytes(c1 + 1, (size_t)(c2 - (c1 + 1))));  // :151
+      t = te + 1;
+    }
+    out->rowend.push_back(out->keys.size());
+    p = eol + 1;
+  }
 }
 
 }  // namespace
@@ -167,49 +244,44 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
     take = cut;
     text = cut - 1;  // the newline is replaced by the terminator (:116)
   }
-  const char *p = base, *end = base + text;
-  while (p < end && *p != '\0') {
-    const char *eol = p;
-    const char *tab = nullptr;
-    while (eol < end && *eol != '\n') {
-      if (!tab && *eol == '\t') tab = eol;
-      ++eol;
+  // Parse the text.  Lines are independent, so a large block is cut at newlines into one
+  // piece per thread; the pieces are concatenated in order (bit-identical to a serial pass).
+  const char *p0 = base, *end = base + text;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 64) nt = 64;
+  const size_t min_piece = 256 << 10;
+  if ((size_t)(end - p0) / min_piece + 1 < nt) nt = (unsigned)((size_t)(end - p0) / min_piece + 1);
+  std::vector<const char *> cut(nt + 1, end);
+  cut[0] = p0;
+  for (unsigned t = 1; t < nt; ++t) {
+    const char *c = p0 + (size_t)(end - p0) * t / nt;
+    if (c < cut[t - 1]) c = cut[t - 1];
+    while (c < end && *c != '\n') ++c;  // a piece ends after a newline
+    cut[t] = c < end ? c + 1 : end;
+  }
+  std::vector<Piece> pieces(nt);
+  if (nt == 1) {
+    parse_piece(cut[0], cut[1], &pieces[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+      th.emplace_back(parse_piece, cut[t], cut[t + 1], &pieces[t]);
+    for (auto &x : th) x.join();
+  }
+  for (unsigned t = 0; t < nt; ++t) {
+    Piece &pc = pieces[t];
+    if (pc.err) {
+      size_t row = r->labels.size() + pc.labels.size();
+      return xf::set_error(XF_EPARSE, "%s: %s in row %zu of the block", r->path.c_str(), pc.err,
+                           row);
     }
-    if (!tab)
-      return xf::set_error(XF_EPARSE, "%s: row %zu has no '\\t' after the label",
-                           r->path.c_str(), r->labels.size());
-    bool ok = true;
-    const float y_tmp = (float)field_atof(p, tab, &ok);  // :129
-    if (!ok) return xf::set_error(XF_EPARSE, "%s: label field too long", r->path.c_str());
-    r->labels.push_back(y_tmp > 0.0000001 ? 1 : 0);       // :131-134
-    const char *t = tab + 1;
-    while (t < eol) {
-      const char *te = t;
-      const char *c1 = nullptr, *c2 = nullptr;
-      while (te < eol && *te != ' ') {
-        if (*te == ':') {
-          if (!c1) c1 = te;
-          else if (!c2)
-            c2 = te;
-        }
-        ++te;
-      }
-      if (te == t) {               // empty token
-        if (te + 1 >= eol) break;  // a single trailing blank is harmless in the reference
-        return xf::set_error(XF_EPARSE, "%s: empty token in row %zu", r->path.c_str(),
-                             r->labels.size() - 1);
-      }
-      if (!c1 || !c2)  // the reference would scan past the terminator here
-        return xf::set_error(XF_EPARSE, "%s: token without fgid:fid:val in row %zu",
-                             r->path.c_str(), r->labels.size() - 1);
-      const double fg = field_atof(t, c1, &ok);  // :149
-      if (!ok) return xf::set_error(XF_EPARSE, "%s: fgid field too long", r->path.c_str());
-      r->fgid.push_back((int32_t)fg);
-      r->keys.push_back(xf_hash_bytes(c1 + 1, (size_t)(c2 - (c1 + 1))));  // :151
-      t = te + 1;
-    }
-    r->rowptr.push_back(r->keys.size());
-    p = eol + 1;
+    const uint64_t base_nnz = r->keys.size();
+    r->keys.insert(r->keys.end(), pc.keys.begin(), pc.keys.end());
+    r->fgid.insert(r->fgid.end(), pc.fgid.begin(), pc.fgid.end());
+    r->labels.insert(r->labels.end(), pc.labels.begin(), pc.labels.end());
+    for (uint64_t e : pc.rowend) r->rowptr.push_back(base_nnz + e);
+    if (pc.hit_nul) break;  // the reference stops at a NUL byte (:126)
   }
   if (take < r->held) memmove(base, base + take, r->held - take);
   r->held -= take;
