@@ -244,6 +244,11 @@ def main():
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
     barrier()
+    if dist is not None:
+        # RCCL writes its version banner through C stdio; push it out now so that the JSON
+        # line below is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     trainer.profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -305,9 +310,11 @@ def main():
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, batches)
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

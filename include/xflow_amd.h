@@ -213,6 +213,12 @@ int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu, const flo
 int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu, const float *d_vsum,
                    const float *d_loss, float *d_gw, float *d_gv, void *stream);
 
+/* FM gradient fused with the two Pushes (fm_worker.cc:241-242), both tables on this GPU */
+int xf_fm_grad_update_dev(xf_table *w, xf_table *v, const xf_dev_batch *b,
+                          const uint32_t *d_rows_w, const uint32_t *d_rows_v, const float *d_wu,
+                          const float *d_vu, const float *d_vsum, const float *d_loss,
+                          float *d_gw, float *d_gv, void *stream);
+
 /* ---------------------------------------------------------------- fused steps         */
 typedef struct xf_workspace xf_workspace; /* per-stream scratch: slots, w_u, g, loss... */
 int xf_workspace_create(xf_workspace **out);

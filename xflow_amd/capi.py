@@ -96,6 +96,7 @@ SIGNATURES = {
     "xf_lr_grad_dev": (C.c_int, [C.POINTER(DevBatch), vp, vp, vp]),
     "xf_fm_forward_dev": (C.c_int, [C.POINTER(DevBatch), C.c_int, vp, vp, vp, vp, vp, vp]),
     "xf_fm_grad_dev": (C.c_int, [C.POINTER(DevBatch), C.c_int, vp, vp, vp, vp, vp, vp]),
+    "xf_fm_grad_update_dev": (C.c_int, [vp, vp, C.POINTER(DevBatch)] + [vp] * 9),
     "xf_workspace_create": (C.c_int, [C.POINTER(vp)]),
     "xf_workspace_destroy": (C.c_int, [vp]),
     "xf_lr_step": (C.c_int, [vp, vp, vp, vp]),
@@ -211,6 +212,7 @@ class Batch:
         R, N, U, H = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), C.byref(U), C.byref(H)))
         self.R, self.NNZ, self.U, self.H = R.value, N.value, U.value, H.value
+        self.on_gpu = on_gpu
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -259,6 +261,8 @@ class Batch:
         return self
 
     def dev_view(self):
+        if not self.on_gpu:
+            self.upload()
         v = DevBatch()
         check(lib().xf_batch_dev_view(self.h, C.byref(v)))
         return v

@@ -353,6 +353,29 @@ k_fm_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
     const uint32_t b = rowptr[r], e = rowptr[r + 1];
     const uint32_t nel = (e - b) * k;
     double wx = 0.0, vs = 0.0, vp = 0.0;
+    if (K > 0 && 64 % K == 0) {
+      // K divides the wavefront: lane = (nnz slot, factor); 4 nnz slots in flight per lane
+      constexpr uint32_t kG = K > 0 ? 64 / (K > 0 ? K : 1) : 1;  // nnz per wave pass
+      const uint32_t kk = lane % (K > 0 ? K : 1), sub = lane / (K > 0 ? K : 1);
+      const uint32_t n = e - b;
+      for (uint32_t j0 = sub; j0 < n; j0 += kG * 4) {
+        uint32_t ui[4];
+        float vv[4], ww[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ui[i] = j0 + i * kG < n ? uidx[b + j0 + i * kG] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vv[i] = ui[i] != 0xFFFFFFFFu ? vu[(size_t)ui[i] * K + kk] : 0.0f;
+          ww[i] = (ui[i] != 0xFFFFFFFFu && kk == 0) ? wu[ui[i]] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vs += (double)vv[i];
+          vp += (double)(vv[i] * vv[i]);  // fp32 product, as fm_worker.cc:187
+          wx += (double)ww[i];
+        }
+      }
+    } else
     for (uint32_t el = lane; el < nel; el += 64) {
       const uint32_t jj = el / k, kk = el - jj * k;
       const uint32_t ui = uidx[b + jj];
@@ -403,6 +426,126 @@ k_fm_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_
     }
     gv[el] = (float)((double)(float)accv / (1.0 * R));
     if (kk == 0) gw[u] = (float)((double)(float)(accw * (double)k) / (1.0 * R));
+  }
+}
+
+// LDS-tiled FM gradient, optionally fused with the two Pushes (fm_worker.cc:241-242) when
+// both tables live on this GPU.  The per-(key,factor) kernel above gathers loss[sid] and
+// v_sum[sid] once per factor — k times too often.  Here a workgroup takes a gradient tile
+// (the same key tiles as the LR kernel), stages (loss, v_sum) of every occurrence in LDS once,
+// and its lanes walk the tile's (key, factor) pairs: v_u is read coalesced, the occurrence
+// runs come out of LDS.  UPDATE: the lane then applies the optimizer step to its coordinate
+// of the key's v row (the pulled value IS the current weight: nothing touched the row since
+// the Pull) and, for factor 0, to the key's w row.
+template <int OPT, bool UPDATE>
+__global__ void __launch_bounds__(kBlock)
+k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ tile_ptr,
+                uint32_t ntiles, const uint32_t *__restrict__ segptr,
+                const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
+                const float *__restrict__ vsum, const float *__restrict__ wu,
+                const float *__restrict__ vu, const uint32_t *__restrict__ rows_w,
+                const uint32_t *__restrict__ rows_v, uint32_t R, int k,
+                float *__restrict__ gw, float *__restrict__ gv) {
+#pragma clang fp contract(off)
+  __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
+  __shared__ uint32_t sp[XF_TILE_KEYS + 1];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t ua = tile_ptr[tile], ub = tile_ptr[tile + 1], nk = ub - ua;
+    const uint32_t j0 = segptr[ua], j1 = segptr[ub];
+    if (nk == 1 && j1 - j0 > XF_HEAVY_SEG) continue;  // heavy key: k_fm_grad_heavy
+    for (uint32_t q = tid; q <= nk; q += kBlock) sp[q] = segptr[ua + q] - j0;
+    for (uint32_t j = j0 + tid; j < j1; j += kBlock) {
+      const uint32_t sid = coo_row[j];
+      lv[j - j0] = loss[sid];
+      sv[j - j0] = vsum[sid];
+    }
+    __syncthreads();
+    const uint32_t nel = nk * (uint32_t)k;
+    constexpr int kUn = 4;  // independent (key,factor) items in flight per lane
+    for (uint32_t el0 = tid; el0 < nel; el0 += kBlock * kUn) {
+      uint32_t kq[kUn], kk[kUn];
+      float v[kUn];
+      size_t to[kUn];
+      bool on[kUn];
+#pragma unroll
+      for (int i = 0; i < kUn; ++i) {
+        const uint32_t el = el0 + i * kBlock;
+        on[i] = el < nel;
+        kq[i] = on[i] ? el / (uint32_t)k : 0;
+        kk[i] = on[i] ? el - kq[i] * (uint32_t)k : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < kUn; ++i) {
+        v[i] = on[i] ? vu[(size_t)(ua + kq[i]) * k + kk[i]] : 0.0f;
+        to[i] = (UPDATE && on[i]) ? (size_t)rows_v[ua + kq[i]] * k + kk[i] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < kUn; ++i) {
+        if (!on[i]) continue;
+        const size_t o = (size_t)(ua + kq[i]) * k + kk[i];
+        double accw = 0.0, accv = 0.0;
+        for (uint32_t j = sp[kq[i]]; j < sp[kq[i] + 1]; ++j) {
+          const float l = lv[j];
+          accw += (double)l;
+          accv += (double)(l * (sv[j] - v[i]));
+        }
+        const float g = (float)((double)(float)accv / (1.0 * R));
+        gv[o] = g;
+        if (UPDATE) {
+          if (OPT == XF_OPT_FTRL) {
+            float w = v[i], nn = TV.n[to[i]], z = TV.z[to[i]];
+            xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g, w, nn, z);
+            TV.w[to[i]] = w;
+            TV.n[to[i]] = nn;
+            TV.z[to[i]] = z;
+          } else {
+            TV.w[to[i]] = xf::sgd_step(TV.lr, g, v[i]);
+          }
+        }
+        if (kk[i] == 0) {
+          const float g1 = (float)((double)(float)(accw * (double)k) / (1.0 * R));
+          gw[ua + kq[i]] = g1;
+          if (UPDATE) {
+            const uint32_t rw = rows_w[ua + kq[i]];
+            if (OPT == XF_OPT_FTRL) {
+              float w = wu[ua + kq[i]], nn = TW.n[rw], z = TW.z[rw];
+              xf::ftrl_step(TW.alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
+              TW.w[rw] = w;
+              TW.n[rw] = nn;
+              TW.z[rw] = z;
+            } else {
+              TW.w[rw] = xf::sgd_step(TW.lr, g1, wu[ua + kq[i]]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// optimizer step for the listed keys of a dim-k table (the heavy ones)
+template <int OPT>
+__global__ void __launch_bounds__(kBlock)
+k_update_listed_rows(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t H,
+                     const uint32_t *__restrict__ rows, const float *__restrict__ g) {
+  const size_t total = (size_t)H * T.dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t h = e / T.dim, j = e - h * T.dim;
+    const uint32_t u = list[h];
+    const size_t o = (size_t)rows[u] * T.dim + j;
+    const float gg = g[(size_t)u * T.dim + j];
+    if (OPT == XF_OPT_FTRL) {
+      float w = T.w[o], nn = T.n[o], z = T.z[o];
+      xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, gg, w, nn, z);
+      T.w[o] = w;
+      T.n[o] = nn;
+      T.z[o] = z;
+    } else {
+      T.w[o] = xf::sgd_step(T.lr, gg, T.w[o]);
+    }
   }
 }
 
@@ -588,16 +731,70 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
   XF_REQUIRE(b && d_vu && d_vsum && d_loss && d_gw && d_gv && k >= 1,
              "xf_fm_grad_dev: bad argument");
   if (b->U == 0) return XF_OK;
-  const size_t total = (size_t)b->U * k;
-  size_t g = (total + kBlock - 1) / kBlock;
-  if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(k_fm_grad, dim3((int)g), dim3(kBlock), 0, S(stream), b->segptr, b->coo_row,
-                     d_loss, d_vsum, d_vu, b->U, b->R, k, d_gw, d_gv);
+  if (b->ntiles && b->tile_ptr) {
+    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_SGD, false>), dim3(tile_grid(b->ntiles)),
+                       dim3(kBlock), 0, S(stream), xf::TableDev{}, xf::TableDev{}, b->tile_ptr,
+                       b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, (const float *)nullptr,
+                       d_vu, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b->R, k, d_gw,
+                       d_gv);
+  } else {
+    const size_t total = (size_t)b->U * k;
+    size_t g = (total + kBlock - 1) / kBlock;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_fm_grad, dim3((int)g), dim3(kBlock), 0, S(stream), b->segptr,
+                       b->coo_row, d_loss, d_vsum, d_vu, b->U, b->R, k, d_gw, d_gv);
+  }
   XF_HIP(hipGetLastError());
   if (b->H) {
     hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
                        S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
                        b->R, k, d_gw, d_gv);
+    XF_HIP(hipGetLastError());
+  }
+  return XF_OK;
+}
+
+// FM gradient fused with the two Pushes, for tables on this GPU (single shard).  rows_w /
+// rows_v as returned by the Pulls of b->ukeys; gw, gv are still written (parity hook).
+extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
+                                     const uint32_t *d_rows_w, const uint32_t *d_rows_v,
+                                     const float *d_wu, const float *d_vu, const float *d_vsum,
+                                     const float *d_loss, float *d_gw, float *d_gv, void *stream) {
+  XF_REQUIRE(tw && tv && b && d_rows_w && d_rows_v && d_wu && d_vu && d_vsum && d_loss && d_gw &&
+                 d_gv, "xf_fm_grad_update_dev: null argument");
+  if (b->U == 0) return XF_OK;
+  const xf::TableDev &TW = xf::table_dev(tw), &TV = xf::table_dev(tv);
+  const int k = TV.dim;
+  const bool ftrl = TV.n != nullptr;
+  XF_REQUIRE((TW.n != nullptr) == ftrl, "xf_fm_grad_update_dev: w and v use different optimizers");
+  XF_REQUIRE(b->ntiles && b->tile_ptr, "xf_fm_grad_update_dev: batch has no gradient tiles");
+  const dim3 gt(tile_grid(b->ntiles)), blk(kBlock);
+  if (ftrl)
+    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_FTRL, true>), gt, blk, 0, S(stream), TW, TV,
+                       b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu,
+                       d_rows_w, d_rows_v, b->R, k, d_gw, d_gv);
+  else
+    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_SGD, true>), gt, blk, 0, S(stream), TW, TV,
+                       b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu,
+                       d_rows_w, d_rows_v, b->R, k, d_gw, d_gv);
+  XF_HIP(hipGetLastError());
+  if (b->H) {
+    hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
+                       S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
+                       b->R, k, d_gw, d_gv);
+    XF_HIP(hipGetLastError());
+    const dim3 gh((b->H + kBlock - 1) / kBlock), gk(blocks_for_groups(b->H * k, kBlock));
+    if (ftrl) {
+      hipLaunchKernelGGL(k_update_listed<XF_OPT_FTRL>, gh, blk, 0, S(stream), TW, b->heavy, b->H,
+                         d_rows_w, d_gw);
+      hipLaunchKernelGGL(k_update_listed_rows<XF_OPT_FTRL>, gk, blk, 0, S(stream), TV, b->heavy,
+                         b->H, d_rows_v, d_gv);
+    } else {
+      hipLaunchKernelGGL(k_update_listed<XF_OPT_SGD>, gh, blk, 0, S(stream), TW, b->heavy, b->H,
+                         d_rows_w, d_gw);
+      hipLaunchKernelGGL(k_update_listed_rows<XF_OPT_SGD>, gk, blk, 0, S(stream), TV, b->heavy,
+                         b->H, d_rows_v, d_gv);
+    }
     XF_HIP(hipGetLastError());
   }
   return XF_OK;
@@ -768,11 +965,10 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   XF_END(kEvGather);
   XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));  // :237
   XF_END(kEvForward);
-  XF_TRY(xf_fm_grad_dev(&v, k, ws->vu, ws->vsum, ws->loss, ws->g, ws->gv, stream));      // :238
+  // gradient (:238) and the two Pushes (:241-242) in one pass: both tables are on this GPU
+  XF_TRY(xf_fm_grad_update_dev(w, vt, &v, ws->slots, ws->slots2, ws->wu, ws->vu, ws->vsum,
+                               ws->loss, ws->g, ws->gv, stream));
   XF_END(kEvGrad);
-  XF_TRY(xf_table_update_dev(w, ws->slots, v.U, ws->g, stream));     // two Pushes: :241-242
-  XF_TRY(xf_table_update_dev(vt, ws->slots2, v.U, ws->gv, stream));
-  XF_END(kEvUpdate);
   if (ws->profiling) ws->ev_pending = true;
   return XF_OK;
 }

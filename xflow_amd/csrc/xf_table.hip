@@ -179,6 +179,24 @@ k_gather(const float *__restrict__ w, int dim, const uint32_t *__restrict__ rows
   }
 }
 
+// 16-byte variant for dim % 4 == 0 (FM factor rows): four coordinates per lane
+__global__ void __launch_bounds__(kBlock)
+k_gather4(const float4 *__restrict__ w, int dim4, const uint32_t *__restrict__ rows, size_t n,
+          float4 *__restrict__ vals) {
+  const size_t total = n * (size_t)dim4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride * 2) {
+    const size_t e1 = e + stride;
+    const size_t i0 = e / (size_t)dim4, j0 = e - i0 * (size_t)dim4;
+    const bool two = e1 < total;
+    const size_t i1 = two ? e1 / (size_t)dim4 : 0, j1 = two ? e1 - i1 * (size_t)dim4 : 0;
+    const float4 a = w[(size_t)rows[i0] * dim4 + j0];
+    const float4 b = two ? w[(size_t)rows[i1] * dim4 + j1] : float4{};
+    vals[e] = a;
+    if (two) vals[e1] = b;
+  }
+}
+
 // Push: one optimizer step per (row, j).  FTRL: ftrl.h:59-74 / :126-141.  SGD: sgd.h:52,96.
 template <int OPT>
 __global__ void __launch_bounds__(kBlock)
@@ -508,8 +526,14 @@ extern "C" int xf_table_gather_dev(xf_table *t, const uint32_t *d_rows, size_t n
                                    float *d_vals, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_rows && d_vals)), "xf_table_gather_dev: null argument");
   if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_gather, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, S(stream),
-                     t->T.w, t->T.dim, d_rows, n, d_vals);
+  if (t->T.dim % 4 == 0 && ((uintptr_t)d_vals & 15) == 0) {
+    const int dim4 = t->T.dim / 4;
+    hipLaunchKernelGGL(k_gather4, dim3(grid_for(n * dim4)), dim3(kBlock), 0, S(stream),
+                       (const float4 *)t->T.w, dim4, d_rows, n, (float4 *)d_vals);
+  } else {
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, S(stream),
+                       t->T.w, t->T.dim, d_rows, n, d_vals);
+  }
   XF_HIP(hipGetLastError());
   return XF_OK;
 }

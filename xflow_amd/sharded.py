@@ -73,38 +73,15 @@ class HipStages:
 
     # -- batch ---------------------------------------------------------------------------
     def compile_batch(self, rowptr, keys, labels):
-        hb = capi.Batch(rowptr, keys, labels)
-        h = hb.host()
+        """Key build on the GPU; the kernels use the batch's own device arrays, only the
+        sorted unique key list is also kept as a tensor (it is what the all-to-all sends)."""
+        hb = capi.Batch(rowptr, keys, labels, on_gpu=True)
         b = _DeviceBatch()
+        b.hb = hb                       # owns the device arrays behind `view`
         b.R, b.NNZ, b.U, b.H = hb.R, hb.NNZ, hb.U, hb.H
-        b.ukeys_host = h["ukeys"]
-        b.t = {n: self.from_numpy(h[n].view(np.int64) if n == "ukeys" else
-                                  h[n].view(np.int32))
-               for n in ("ukeys", "rowptr", "uidx", "segptr", "coo_row", "labels", "heavy")}
-        v = capi.DevBatch()
-        v.R, v.NNZ, v.U, v.H = b.R, b.NNZ, b.U, b.H
-        for n in ("rowptr", "uidx", "ukeys", "segptr", "coo_row", "labels"):
-            setattr(v, n, b.t[n].data_ptr())
-        v.heavy = b.t["heavy"].data_ptr() if b.H else None
-        P, pptr, pidx = hb.panels()
-        v.P = P
-        if P:
-            b.t["pptr"] = self.from_numpy(pptr.view(np.int32))
-            b.t["pidx"] = self.from_numpy(pidx.view(np.int32))
-            b.t["fwd_scratch"] = self.empty(P * b.R, torch.float64)
-            v.pptr, v.pidx = b.t["pptr"].data_ptr(), b.t["pidx"].data_ptr()
-            v.fwd_scratch = b.t["fwd_scratch"].data_ptr()
-            ftp, fpf, fgrid = hb.fwd_tiles()
-            b.t["fwd_tile_ptr"] = self.from_numpy(ftp.view(np.int32))
-            b.t["fwd_panel_first"] = self.from_numpy(fpf.view(np.int32))
-            v.fwd_ntiles, v.fwd_grid = len(ftp) - 1, fgrid
-            v.fwd_tile_ptr = b.t["fwd_tile_ptr"].data_ptr()
-            v.fwd_panel_first = b.t["fwd_panel_first"].data_ptr()
-        tp = hb.tiles()
-        b.t["tile_ptr"] = self.from_numpy(tp.view(np.int32))
-        v.ntiles, v.tile_ptr = len(tp) - 1, b.t["tile_ptr"].data_ptr()
-        b.view = v
-        b.ukeys = b.t["ukeys"]
+        b.view = hb.dev_view()
+        b.ukeys_host = hb.host()["ukeys"]
+        b.ukeys = self.from_numpy(b.ukeys_host.view(np.int64))
         return b
 
     # -- table stages (owner side) -------------------------------------------------------
