@@ -49,6 +49,8 @@ def parse_args():
                     help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
     ap.add_argument("--key-build-steps", type=int, default=10,
                     help="extra timed steps that include the GPU key build (0 = skip)")
+    ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1"],
+                    help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--seed", type=int, default=20260926)
@@ -227,9 +229,12 @@ def main():
         from xflow_amd.single import SingleGpuTrainer as Trainer
     else:
         from xflow_amd.sharded import ShardedTrainer as Trainer
+    sharded = world > 1 or args.force_sharded
+    schedule = (args.schedule or "stale1") if sharded else "sequential"
+    kw = {"schedule": schedule} if sharded else {}
     trainer = Trainer(model=args.model, optimizer=args.optimizer, k=args.k,
                       capacity=int(args.keys_per_gpu / args.load_factor) + 1024,
-                      rank=rank, world=world)
+                      rank=rank, world=world, **kw)
     compiled = [trainer.compile(*b) for b in batches]
     R = compiled[0].R
     NNZ = int(np.mean([c.NNZ for c in compiled]))
@@ -258,6 +263,20 @@ def main():
     kern_ms, ksteps = trainer.profile_read()
     trainer.profile(False)
     trainer.check()
+    kernel_timing = "HIP events on the step's stream inside the timed region"
+    if not kern_ms and sharded:
+        # the overlapped schedule runs two streams: per-kernel events are taken in a short
+        # sequential pass after the timed region instead
+        trainer.schedule = "sequential"
+        trainer.profile(True)
+        for i in range(8):
+            trainer.step(compiled[i % len(compiled)])
+        barrier()
+        kern_ms, ksteps = trainer.profile_read()
+        trainer.profile(False)
+        trainer.check()
+        kernel_timing = "HIP events in a sequential pass of 8 steps after the timed region " \
+                        "(the timed region overlaps two streams)"
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -292,14 +311,15 @@ def main():
                    "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
                    "unique_keys_per_gpu_batch": U, "table_load_factor": args.load_factor,
                    "distinct_batches": len(compiled),
-                   "parallelism": "key-range sharded table x%d, all-to-all" % world
-                   if world > 1 else "single shard"},
+                   "parallelism": ("key-range sharded table x%d, all-to-all of weights and "
+                                   "gradients per step, schedule %s" % (world, schedule))
+                   if sharded else "single shard"},
         "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
                      "algorithmic_bytes_per_launch": per[dom],
                      "avg_launch_ms": avg_ms[dom]},
-        "kernels_ms": avg_ms,
+        "kernels_ms": avg_ms, "kernel_timing": kernel_timing,
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
@@ -308,7 +328,7 @@ def main():
     if args.pmc_calibrate:
         for kind in range(6):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, batches)
     if dist is not None:
         dist.destroy_process_group()

@@ -82,6 +82,26 @@ class CpuOracleStages:
         gw, gv = b.ob.fm_grad(self.k, vu.numpy(), vsum.numpy(), loss.numpy())
         return torch.from_numpy(gw), torch.from_numpy(gv.ravel().copy())
 
+    # the stale1 schedule's stream plumbing: nothing to do on one CPU thread
+    class _Null:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def on(self, name):
+        return self._Null()
+
+    def record(self, stream, event):
+        pass
+
+    def wait(self, stream, event):
+        pass
+
+    def sync(self):
+        pass
+
     def check(self):
         pass
 

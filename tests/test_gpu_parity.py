@@ -610,3 +610,39 @@ def test_step_on_device_built_batches_and_oversized_cell():
             O.lr_update(s, ob)
     for a, e in zip(t.export(), s.export()):
         same(a, e)
+
+
+def test_sharded_stale1_schedule_overlapped_streams():
+    """The overlapped schedule (Push of step t on a second stream, applied after the Pull of
+    step t+1) through RCCL at world 1: bit-identical to the exact-sum oracle run on the same
+    one-step-stale schedule, repeatedly (a stream race would show as a mismatch)."""
+    import torch
+    import torch.distributed as dist
+    from xflow_amd.sharded import ShardedTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for rep in range(3):
+            rng = np.random.RandomState(40 + rep)
+            tr = ShardedTrainer(model="lr", optimizer="ftrl", capacity=1 << 18, rank=0, world=1,
+                                schedule="stale1")
+            s = O.Store(O.OPT_FTRL, 1)
+            outstanding = None
+            for step in range(6):
+                data = synth(rng, 4000, 30, 60000)
+                tr.step(tr.compile(*data))
+                ob = O.Batch(*data)
+                with O.sum_mode(1):
+                    pw = s.pull(ob.ukeys)
+                    if outstanding is not None:
+                        s.push(*outstanding)
+                    outstanding = (ob.ukeys, ob.lr_grad(ob.lr_loss(pw)[0]))
+            tr.check()          # flushes the outstanding Push
+            with O.sum_mode(1):
+                s.push(*outstanding)
+            for a, e in zip(tr.stages.w.export(), s.export()):
+                same(a, e)
+    finally:
+        dist.destroy_process_group()

@@ -26,7 +26,7 @@ def _data(rank, step, R=120, nnz=9, nkeys=700):
     return rowptr, keys, labels
 
 
-def _worker(rank, world, port, model, optimizer, steps, outdir):
+def _worker(rank, world, port, model, optimizer, steps, outdir, schedule="sequential"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,11 +35,12 @@ def _worker(rank, world, port, model, optimizer, steps, outdir):
     from xflow_amd.sharded import ShardedTrainer
     st = CpuOracleStages(model, optimizer, 4, rank, world)
     tr = ShardedTrainer(model=model, optimizer=optimizer, k=4, rank=rank, world=world,
-                        stages=st)
+                        stages=st, schedule=schedule)
     for s in range(steps):
         b = tr.compile(*_data(rank, s))
         assert sum(b.send_counts) == b.U
         tr.step(b)
+    tr.flush()
     pb = tr.compile(*_data(rank, 99))
     loss = tr.predict(pb).numpy()
     out = {"loss": loss}
@@ -52,16 +53,23 @@ def _worker(rank, world, port, model, optimizer, steps, outdir):
     dist.destroy_process_group()
 
 
-def _simulate(world, model, optimizer, steps):
+def _simulate(world, model, optimizer, steps, schedule="sequential"):
     from oracle import pyoracle as O
     opt = O.OPT_FTRL if optimizer == "ftrl" else O.OPT_SGD
     w = O.Store(opt, 1)
     v = None
     if model == "fm":
         v = O.Store(opt, 4, O.INIT_HASHNORM if opt == O.OPT_FTRL else O.INIT_CONST, 0.001, 7)
+    outstanding = None      # stale1: the Push of the previous step, applied after this Pull
     for s in range(steps):
         obs = [O.Batch(*_data(r, s)) for r in range(world)]
         pulled = [(w.pull(ob.ukeys), v.pull(ob.ukeys) if v is not None else None) for ob in obs]
+        if outstanding is not None:
+            for ob, (gw, gv) in outstanding:
+                w.push(ob.ukeys, gw)
+                if v is not None:
+                    v.push(ob.ukeys, gv)
+            outstanding = None
         grads = []
         for ob, (pw, pv) in zip(obs, pulled):
             if model == "lr":
@@ -69,7 +77,15 @@ def _simulate(world, model, optimizer, steps):
             else:
                 loss, _, vsum = ob.fm_loss(4, pw, pv)
                 grads.append(ob.fm_grad(4, pv, vsum, loss))
+        if schedule == "stale1":
+            outstanding = list(zip(obs, grads))
+            continue
         for ob, (gw, gv) in zip(obs, grads):       # rank order
+            w.push(ob.ukeys, gw)
+            if v is not None:
+                v.push(ob.ukeys, gv)
+    if outstanding is not None:
+        for ob, (gw, gv) in outstanding:
             w.push(ob.ukeys, gw)
             if v is not None:
                 v.push(ob.ukeys, gv)
@@ -84,14 +100,15 @@ def _simulate(world, model, optimizer, steps):
     return w, v, losses
 
 
-@pytest.mark.parametrize("world,model,optimizer", [(2, "lr", "ftrl"), (2, "fm", "sgd"),
-                                                   (3, "fm", "ftrl")])
-def test_sharded_matches_rank_ordered_schedule(tmp_path, world, model, optimizer):
+@pytest.mark.parametrize("world,model,optimizer,schedule", [
+    (2, "lr", "ftrl", "sequential"), (2, "fm", "sgd", "sequential"),
+    (3, "fm", "ftrl", "sequential"), (2, "lr", "ftrl", "stale1"), (3, "fm", "sgd", "stale1")])
+def test_sharded_matches_rank_ordered_schedule(tmp_path, world, model, optimizer, schedule):
     from oracle import pyoracle as O
-    port = 29600 + (os.getpid() % 300) + world
-    mp.spawn(_worker, args=(world, port, model, optimizer, 3, str(tmp_path)), nprocs=world,
-             join=True)
-    w, v, losses = _simulate(world, model, optimizer, 3)
+    port = 29600 + (os.getpid() % 300) + world + (7 if schedule == "stale1" else 0)
+    mp.spawn(_worker, args=(world, port, model, optimizer, 4, str(tmp_path), schedule),
+             nprocs=world, join=True)
+    w, v, losses = _simulate(world, model, optimizer, 4, schedule)
     for nm, store in (("w", w), ("v", v)):
         if store is None:
             continue

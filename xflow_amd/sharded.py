@@ -137,7 +137,46 @@ class HipStages:
                                              gv.data_ptr(), self._stream()))
         return gw, gv
 
+    def update_multi(self, table, slots, grads, counts):
+        """one optimizer pass per source rank, in rank order"""
+        off = 0
+        for cnt in counts:
+            if cnt:
+                self.update(table, slots[off:off + cnt],
+                            grads[off * table.dim:(off + cnt) * table.dim])
+            off += cnt
+
+    # -- streams / events for the stale1 schedule ------------------------------------------
+    def _s(self, name):
+        if name == "main":
+            return torch.cuda.current_stream() if not hasattr(self, "_main") else self._main
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def on(self, name):
+        if not hasattr(self, "_main"):
+            self._main = torch.cuda.current_stream()
+        return torch.cuda.stream(self._s(name))
+
+    def record(self, stream, event):
+        if not hasattr(self, "_main"):
+            self._main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(self._s(stream))
+        self._events = getattr(self, "_events", {})
+        self._events[event] = ev
+
+    def wait(self, stream, event):
+        ev = getattr(self, "_events", {}).get(event)
+        if ev is not None:
+            self._s(stream).wait_event(ev)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
     def check(self):
+        torch.cuda.synchronize()
         self.w.check(self._stream())
         if self.v is not None:
             self.v.check(self._stream())
@@ -154,7 +193,11 @@ class ShardedTrainer:
     """LRWorker/FMWorker::update across `world` ranks with a key-range-sharded table."""
 
     def __init__(self, model="lr", optimizer="ftrl", k=10, capacity=1 << 22, rank=None,
-                 world=None, stages=None, group=None, **hyper):
+                 world=None, stages=None, group=None, schedule="sequential", **hyper):
+        assert schedule in ("sequential", "stale1")
+        self.schedule = schedule
+        self._pending = None
+        self._retired = None
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -209,60 +252,130 @@ class ShardedTrainer:
         return self.stages.resolve(table, rkeys)
 
     def _mark(self, name):
-        if self._prof is not None:
+        if self._prof is not None and self.schedule == "sequential":
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self._ev.append((name, e))
 
-    def step(self, b):
+    # ---- one minibatch step -------------------------------------------------------------
+    # front half: Pull (owner resolve + gather, weights back) -> forward -> gradient
+    # back half : Push (gradients to the owners, owner-side optimizer step per source rank)
+    def _front_pull(self, b):
         st = self.stages
         tw, tv = st.tables()
-        self._mark("begin")
-        # Pull, part 1 (keys to their owners, ps-lite slicer ranges) happened at compile time
-        rkeys = b.rkeys
+        rkeys = b.rkeys     # keys went to their owners at compile time (ps-lite slicer ranges)
+        c = {}
         # owner: key -> state row (insert on first touch, ftrl.h:56) and the weight payload
         if hasattr(st, "pull") and rkeys.numel():
-            slots_w, w_recv = st.pull(tw, rkeys)
+            c["slots_w"], c["w_recv"] = st.pull(tw, rkeys)
         else:
-            slots_w = self._resolve(tw, rkeys, b.recv_counts)
-            w_recv = st.gather(tw, slots_w)
+            c["slots_w"] = self._resolve(tw, rkeys, b.recv_counts)
+            c["w_recv"] = st.gather(tw, c["slots_w"])
         if self.model == "fm":
-            slots_v = self._resolve(tv, rkeys, b.recv_counts)
+            c["slots_v"] = self._resolve(tv, rkeys, b.recv_counts)
         self._mark("resolve")
         if self.model == "fm":
-            v_recv = st.gather(tv, slots_v)
+            c["v_recv"] = st.gather(tv, c["slots_v"])
         self._mark("gather")
+        return c
+
+    def _front_compute(self, b, c):
+        st = self.stages
         # Pull, part 2: weights back, in the order the keys were sent
-        wu = self._a2a(w_recv, b.recv_counts, b.send_counts)
+        wu = self._a2a(c["w_recv"], b.recv_counts, b.send_counts)
         if self.model == "fm":
-            vu = self._a2a(v_recv, b.recv_counts, b.send_counts, self.k)
+            vu = self._a2a(c["v_recv"], b.recv_counts, b.send_counts, self.k)
         self._mark("a2a_weights")
         if self.model == "lr":
             loss = st.lr_forward(b, wu)
             self._mark("forward")
-            g = st.lr_grad(b, loss)
+            c["g"] = st.lr_grad(b, loss)
         else:
             loss, vsum = st.fm_forward(b, wu, vu)
             self._mark("forward")
-            g, gv = st.fm_grad(b, vu, vsum, loss)
+            c["g"], c["gv"] = st.fm_grad(b, vu, vsum, loss)
         self._mark("gradient")
-        # Push: gradients to the owners (keys are already there), owner-side optimizer step,
-        # one worker after the other in rank order
-        g_recv = self._a2a(g, b.send_counts, b.recv_counts)
+        c["wu"], c["loss"] = wu, loss
+
+    def _back(self, b, c):
+        """Push: gradients to the owners (keys are already there), owner-side optimizer
+        step, one worker after the other in rank order."""
+        st = self.stages
+        tw, tv = st.tables()
+        g_recv = self._a2a(c["g"], b.send_counts, b.recv_counts)
         if self.model == "fm":
-            gv_recv = self._a2a(gv, b.send_counts, b.recv_counts, self.k)
+            gv_recv = self._a2a(c["gv"], b.send_counts, b.recv_counts, self.k)
         self._mark("a2a_grads")
-        off = 0
-        for src in range(self.world):
-            c = b.recv_counts[src]
-            if c:
-                st.update(tw, slots_w[off:off + c], g_recv[off:off + c])
-                if self.model == "fm":
-                    st.update(tv, slots_v[off:off + c],
-                              gv_recv[off * self.k:(off + c) * self.k])
-            off += c
+        c["g_recv"] = g_recv
+        return g_recv, (gv_recv if self.model == "fm" else None)
+
+    def _apply(self, b, c, g_recv, gv_recv):
+        st = self.stages
+        tw, tv = st.tables()
+        if hasattr(st, "update_multi"):
+            st.update_multi(tw, c["slots_w"], g_recv, b.recv_counts)
+            if self.model == "fm":
+                st.update_multi(tv, c["slots_v"], gv_recv, b.recv_counts)
+        else:
+            off = 0
+            for cnt in b.recv_counts:
+                if cnt:
+                    st.update(tw, c["slots_w"][off:off + cnt], g_recv[off:off + cnt])
+                    if self.model == "fm":
+                        st.update(tv, c["slots_v"][off:off + cnt],
+                                  gv_recv[off * self.k:(off + cnt) * self.k])
+                off += cnt
         self._mark("update")
-        self._last = dict(wu=wu, loss=loss, g=g)
+
+    def step(self, b):
+        """schedule "sequential" (default): Pull, compute, Push of a step finish before the
+        next step's Pull — the order the single-GPU path and the parity tests use.
+        schedule "stale1": the Push of step t is applied after the Pull of step t+1 has read
+        the table (weights are one step stale — inside ps-lite's asynchronous semantics, and
+        still deterministic), on a second stream: its all-to-all overlaps the next Pull and
+        its optimizer pass overlaps the next weights exchange, forward and gradient."""
+        st = self.stages
+        self._mark("begin")
+        if self.schedule == "sequential":
+            c = self._front_pull(b)
+            self._front_compute(b, c)
+            g_recv, gv_recv = self._back(b, c)
+            self._apply(b, c, g_recv, gv_recv)
+            self._last = c
+            return
+        # ---- stale1 ----
+        prev = self._pending                      # (batch, ctx) whose Push is outstanding
+        st.wait("main", "applied")                # the Push of step t-2 is in the table
+        c = self._front_pull(b)                   # reads the table before Push(t-1) lands
+        st.record("main", "pulled")
+        if prev is not None:
+            pb, pc = prev
+            with st.on("side"):
+                st.wait("side", "graded")         # gradient of step t-1 is complete
+                g_recv, gv_recv = self._back(pb, pc)
+                st.wait("side", "pulled")         # do not write while Pull(t) reads
+                self._apply(pb, pc, g_recv, gv_recv)
+                st.record("side", "applied")
+        self._front_compute(b, c)
+        st.record("main", "graded")
+        self._retired = prev                      # keep step t-1's buffers alive one more step
+        self._pending = (b, c)
+        self._last = c
+
+    def flush(self):
+        """apply the outstanding Push of the stale1 schedule (end of training / before export)"""
+        st = self.stages
+        if self.schedule != "sequential" and self._pending is not None:
+            pb, pc = self._pending
+            with st.on("side"):
+                st.wait("side", "graded")
+                g_recv, gv_recv = self._back(pb, pc)
+                st.wait("side", "pulled")
+                self._apply(pb, pc, g_recv, gv_recv)
+                st.record("side", "applied")
+            st.wait("main", "applied")
+            self._pending = None
+        st.sync()
 
     def predict(self, b):
         """forward only (calculate_pctr): pulls insert unseen keys, as in the reference."""
@@ -278,6 +391,7 @@ class ShardedTrainer:
         return st.fm_forward(b, wu, vu)[0]
 
     def check(self):
+        self.flush()
         self.stages.check()
 
     # bench hooks: per-stage timing with events recorded on the stream the kernels and the
