@@ -646,3 +646,29 @@ def test_sharded_stale1_schedule_overlapped_streams():
                 same(a, e)
     finally:
         dist.destroy_process_group()
+
+
+def test_empty_and_degenerate_batches():
+    """R = 0, rows without features (sigmoid(0) = 0.5), a batch whose rows are all empty."""
+    ws = capi.Workspace()
+    for on_gpu in (False, True):
+        t, s = capi.Table(capi.OPT_FTRL, 1, capacity=1024), O.Store(O.OPT_FTRL, 1)
+        e = capi.Batch(np.array([0], np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int32),
+                       on_gpu=on_gpu)
+        capi.lr_step(t, e, ws)
+        assert len(t) == 0
+        rowptr = np.array([0, 0, 0, 0], dtype=np.uint64)
+        b = capi.Batch(rowptr, np.zeros(0, np.uint64), np.array([1, 0, 1], np.int32), on_gpu=on_gpu)
+        capi.lr_step(t, b, ws)
+        assert len(t) == 0
+        p = capi.lr_predict(t, b, ws)
+        assert np.all(p == np.float32(O.sigmoid(0.0)))
+        rowptr = np.array([0, 0, 2, 2, 3], dtype=np.uint64)
+        keys = np.array([7, 7, 9], dtype=np.uint64)
+        labels = np.array([1, 0, 1, 0], np.int32)
+        b = capi.Batch(rowptr, keys, labels, on_gpu=on_gpu)
+        capi.lr_step(t, b, ws)
+        with O.sum_mode(1):
+            O.lr_update(s, O.Batch(rowptr, keys, labels))
+        for a, r in zip(t.export(), s.export()):
+            same(a, r)

@@ -828,7 +828,7 @@ static int ws_reserve(xf_workspace *ws, size_t U, size_t UK, size_t R) {
     }
     return hipMalloc(p, bytes);
   };
-  if (U > ws->capU) {
+  if (!ws->slots || U > ws->capU) {
     const size_t m = std::max<size_t>(U + U / 8, 1024);
     XF_HIP(grow((void **)&ws->slots, m * 4));
     XF_HIP(grow((void **)&ws->slots2, m * 4));
@@ -836,13 +836,13 @@ static int ws_reserve(xf_workspace *ws, size_t U, size_t UK, size_t R) {
     XF_HIP(grow((void **)&ws->g, m * 4));
     ws->capU = m;
   }
-  if (UK > ws->capUK) {
+  if (!ws->vu || UK > ws->capUK) {
     const size_t m = std::max<size_t>(UK + UK / 8, 1024);
     XF_HIP(grow((void **)&ws->vu, m * 4));
     XF_HIP(grow((void **)&ws->gv, m * 4));
     ws->capUK = m;
   }
-  if (R > ws->capR) {
+  if (!ws->loss || R > ws->capR) {
     const size_t m = std::max<size_t>(R + R / 8, 1024);
     XF_HIP(grow((void **)&ws->loss, m * 4));
     XF_HIP(grow((void **)&ws->pctr, m * 4));
