@@ -71,6 +71,7 @@ int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
 #define XF_HEAVY_SEG 64
 #define XF_TILE_NNZ 2048
 #define XF_TILE_KEYS 2048
+#define XF_HEAVY_KMAX 64
 typedef struct xf_batch xf_batch; /* host arrays + (after upload) device mirror */
 int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                      const int32_t *labels, size_t row_begin, size_t row_end);
@@ -96,6 +97,8 @@ int xf_batch_panels(const xf_batch *b, uint32_t *P, const uint32_t **pptr,
                     const uint32_t **pidx);
 int xf_batch_fwd_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr,
                        const uint32_t **panel_first, uint32_t *grid);
+/* chunk offsets of the heavy keys (host array, H+1 entries) */
+int xf_batch_heavy_chunks(const xf_batch *b, uint32_t *H, const uint32_t **chunk_ptr);
 /* gradient tiles (host array, ntiles+1 key indices) */
 int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr);
 /* tuning knobs (process-wide): "panel_slice_bytes" (default 1.5 MiB: w_u bytes per panel),
@@ -134,8 +137,14 @@ typedef struct {
    * (<= XF_TILE_NNZ of them, <= XF_TILE_KEYS keys) are staged through LDS by one
    * workgroup; a heavy key (> XF_HEAVY_SEG occurrences) is a tile of its own, skipped by
    * the tile kernel and handled by the wave-per-key path. */
-  uint32_t ntiles, pad2_;
+  uint32_t ntiles, n_heavy_chunks;
   const uint32_t *tile_ptr; /* ntiles+1 */
+  /* heavy keys are reduced in chunks of XF_TILE_NNZ occurrences spread over the whole chip
+   * (a power-law head key can own millions of occurrences): heavy key h owns chunks
+   * [heavy_chunk_ptr[h], heavy_chunk_ptr[h+1]); heavy_scratch holds
+   * n_heavy_chunks * (1 + XF_HEAVY_KMAX) partial sums. */
+  const uint32_t *heavy_chunk_ptr; /* H+1 (NULL when H == 0) */
+  double *heavy_scratch;
 } xf_dev_batch;
 int xf_batch_dev_view(const xf_batch *b, xf_dev_batch *view);
 

@@ -532,6 +532,7 @@ def _same_batch(a, b):
     for k in ha:
         same(ha[k], hb[k])
     same(a.tiles(), b.tiles())
+    same(a.heavy_chunks(), b.heavy_chunks())
     pa, pb = a.panels(), b.panels()
     assert pa[0] == pb[0]
     if pa[0]:
@@ -672,3 +673,45 @@ def test_empty_and_degenerate_batches():
             O.lr_update(s, O.Batch(rowptr, keys, labels))
         for a, r in zip(t.export(), s.export()):
             same(a, r)
+
+
+@pytest.mark.parametrize("model", ["lr", "fm"])
+def test_giant_heavy_keys_chunked_reduction(model):
+    """Power-law heads: keys that own tens of thousands of occurrences are reduced in
+    2048-occurrence chunks by many workgroups; same bits as the exact-sum oracle."""
+    rng = np.random.RandomState(31)
+    R = 6000
+    lens = rng.randint(3, 12, size=R)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(lens.sum())
+    fid = rng.randint(0, 5000, size=n)
+    fid[rng.rand(n) < 0.35] = 7          # ~15k occurrences
+    fid[rng.rand(n) < 0.10] = 11         # ~4k
+    fid[rng.rand(n) < 0.03] = 13         # ~1k  (heavy, single chunk)
+    keytab = np.array([O.hash_str(str(i)) for i in range(5000)], dtype=np.uint64)
+    keys, labels = keytab[fid], rng.randint(0, 2, size=R).astype(np.int32)
+    for on_gpu in (False, True):
+        b = capi.Batch(rowptr, keys, labels, on_gpu=on_gpu)
+        hc = b.heavy_chunks()
+        assert b.H >= 3 and hc[-1] >= 8 and np.diff(hc).max() >= 6
+        ob = O.Batch(rowptr, keys, labels)
+        ws = capi.Workspace()
+        if model == "lr":
+            t, s = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 14), O.Store(O.OPT_FTRL, 1)
+            for _ in range(3):
+                capi.lr_step(t, b, ws)
+                with O.sum_mode(1):
+                    O.lr_update(s, ob)
+            pairs = [(t, s)]
+        else:
+            tw, tv = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 14), \
+                capi.Table(capi.OPT_FTRL, 16, capi.INIT_HASHNORM, seed=3, capacity=1 << 14)
+            sw, sv = O.Store(O.OPT_FTRL, 1), O.Store(O.OPT_FTRL, 16, O.INIT_HASHNORM, 0.0, 3)
+            for _ in range(3):
+                capi.fm_step(tw, tv, b, ws)
+                with O.sum_mode(1):
+                    O.fm_update(sw, sv, ob)
+            pairs = [(tw, sw), (tv, sv)]
+        for tt, ss in pairs:
+            for a, e in zip(tt.export(), ss.export()):
+                same(a, e)

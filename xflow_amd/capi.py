@@ -42,7 +42,8 @@ class DevBatch(C.Structure):
                 ("pptr", vp), ("pidx", vp), ("fwd_scratch", vp), ("fwd_tile_ptr", vp),
                 ("fwd_panel_first", vp), ("fwd_grid", C.c_uint32), ("pad3_", C.c_uint32),
                 ("ntiles", C.c_uint32),
-                ("pad2_", C.c_uint32), ("tile_ptr", vp)]
+                ("n_heavy_chunks", C.c_uint32), ("tile_ptr", vp), ("heavy_chunk_ptr", vp),
+                ("heavy_scratch", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/xflow_amd.h declares
@@ -71,6 +72,7 @@ SIGNATURES = {
     "xf_batch_panels": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p)]),
     "xf_tune": (C.c_int, [C.c_char_p, C.c_double]),
     "xf_batch_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p)]),
+    "xf_batch_heavy_chunks": (C.c_int, [vp, u32p, C.POINTER(u32p)]),
     "xf_batch_fwd_tiles": (C.c_int, [vp, u32p, C.POINTER(u32p), C.POINTER(u32p), u32p]),
     "xf_batch_upload": (C.c_int, [vp, vp]),
     "xf_batch_dev_view": (C.c_int, [vp, C.POINTER(DevBatch)]),
@@ -250,6 +252,11 @@ class Batch:
         P = self.panels()[0]
         return (np.ctypeslib.as_array(tp, (n.value + 1,)).copy(),
                 np.ctypeslib.as_array(pf, (P + 1,)).copy(), g.value)
+
+    def heavy_chunks(self):
+        n, cp = C.c_uint32(0), u32p()
+        check(lib().xf_batch_heavy_chunks(self.h, C.byref(n), C.byref(cp)))
+        return np.ctypeslib.as_array(cp, (n.value + 1,)).copy()
 
     def tiles(self):
         n, tp = C.c_uint32(0), u32p()

@@ -158,6 +158,14 @@ extern "C" int xf_tune(const char *name, double value) {
   return XF_OK;
 }
 
+extern "C" int xf_batch_heavy_chunks(const xf_batch *b, uint32_t *H, const uint32_t **chunk_ptr) {
+  XF_REQUIRE(b && H, "xf_batch_heavy_chunks: null argument");
+  XF_TRY(need_host(b));
+  *H = b->H;
+  if (chunk_ptr) *chunk_ptr = b->hchunk_ptr.data();
+  return XF_OK;
+}
+
 extern "C" int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_ptr) {
   XF_REQUIRE(b && ntiles, "xf_batch_tiles: null argument");
   XF_TRY(need_host(b));
@@ -230,6 +238,10 @@ extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const ui
   for (uint32_t u = 0; u < b->U; ++u)
     if (b->segptr[u + 1] - b->segptr[u] > XF_HEAVY_SEG) b->heavy.push_back(u);
   b->H = (uint32_t)b->heavy.size();
+  b->hchunk_ptr.assign(1, 0);
+  for (uint32_t u : b->heavy)
+    b->hchunk_ptr.push_back(b->hchunk_ptr.back() +
+                            (b->segptr[u + 1] - b->segptr[u] + XF_TILE_NNZ - 1) / XF_TILE_NNZ);
   build_panels(b);
   build_tiles(b);
   *out = b;
@@ -286,7 +298,10 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   const size_t o_tile = o_scr + al((size_t)b->P * b->R * 8);
   const size_t o_ftile = o_tile + al(b->tile_ptr.size() * 4);
   const size_t o_forder = o_ftile + al(b->ftile_ptr.size() * 4);
-  const size_t total = o_forder + al(b->fpanel_first.size() * 4) + 256;
+  const size_t o_hch = o_forder + al(b->fpanel_first.size() * 4);
+  const size_t n_hch = b->H ? b->hchunk_ptr.back() : 0;
+  const size_t o_hscr = o_hch + al(b->H ? ((size_t)b->H + 1) * 4 : 0);
+  const size_t total = o_hscr + al(n_hch * (1 + XF_HEAVY_KMAX) * 8) + 256;
   char *d = nullptr;
   XF_HIP(hipMalloc((void **)&d, total));
   hipStream_t s = (hipStream_t)stream;
@@ -306,6 +321,7 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
     XF_HIP(put(o_pidx, b->pidx.data(), b->pidx.size() * 4));
   }
   XF_HIP(put(o_tile, b->tile_ptr.data(), b->tile_ptr.size() * 4));
+  if (b->H) XF_HIP(put(o_hch, b->hchunk_ptr.data(), b->hchunk_ptr.size() * 4));
   if (b->P) {
     XF_HIP(put(o_ftile, b->ftile_ptr.data(), b->ftile_ptr.size() * 4));
     XF_HIP(put(o_forder, b->fpanel_first.data(), b->fpanel_first.size() * 4));
@@ -332,7 +348,9 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   b->view.pidx = b->P ? (const uint32_t *)(d + o_pidx) : nullptr;
   b->view.fwd_scratch = b->P ? (double *)(d + o_scr) : nullptr;
   b->view.ntiles = (uint32_t)(b->tile_ptr.size() - 1);
-  b->view.pad2_ = 0;
+  b->view.n_heavy_chunks = (uint32_t)n_hch;
+  b->view.heavy_chunk_ptr = b->H ? (const uint32_t *)(d + o_hch) : nullptr;
+  b->view.heavy_scratch = b->H ? (double *)(d + o_hscr) : nullptr;
   b->view.tile_ptr = (const uint32_t *)(d + o_tile);
   return XF_OK;
 }

@@ -10,6 +10,7 @@ struct xf_batch {
   uint32_t R = 0, NNZ = 0, U = 0, H = 0;
   std::vector<uint64_t> ukeys;
   std::vector<uint32_t> rowptr, uidx, segptr, coo_row, heavy;
+  std::vector<uint32_t> hchunk_ptr;  // chunks of XF_TILE_NNZ occurrences per heavy key
   uint32_t P = 0;  // forward panels (0 = none)
   std::vector<uint32_t> pptr, pidx;
   std::vector<uint32_t> tile_ptr;  // gradient tiles (key ranges)

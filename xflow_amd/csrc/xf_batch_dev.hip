@@ -176,6 +176,16 @@ k_fill_pidx(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ ui
   }
 }
 
+// chunks of XF_TILE_NNZ occurrences per heavy key
+__global__ void k_heavy_chunk_counts(const uint32_t *__restrict__ heavy, uint32_t H,
+                                     const uint32_t *__restrict__ segptr,
+                                     uint32_t *__restrict__ cnt /* H+1, cnt[H] = 0 */) {
+  XF_GRID_STRIDE(h, (size_t)H + 1) {
+    const uint32_t u = h < H ? heavy[h] : 0;
+    cnt[h] = h < H ? (segptr[u + 1] - segptr[u] + XF_TILE_NNZ - 1) / XF_TILE_NNZ : 0u;
+  }
+}
+
 __global__ void k_cell_flags(const uint32_t *__restrict__ pptr, uint32_t R, uint32_t P,
                              uint32_t *__restrict__ flag /* P*(R+1) */) {
   const size_t n = (size_t)P * (R + 1);
@@ -365,6 +375,18 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
   b->H = H;
+  uint32_t *hch = nullptr;
+  uint32_t n_hch = 0;
+  if (H) {
+    uint32_t *hcnt = nullptr;
+    XF_TRY(sc.get(&hcnt, (size_t)H + 1));
+    XF_TRY(sc.get(&hch, (size_t)H + 1));
+    hipLaunchKernelGGL(k_heavy_chunk_counts, dim3(grid_for((size_t)H + 1)), dim3(kBlock), 0, s,
+                       heavy, H, segptr, hcnt);
+    XF_TRY(exclusive_scan_u32(sc, hcnt, hch, (size_t)H + 1, s));  // hch[H] = total chunks
+    XF_HIP(hipMemcpyAsync(&n_hch, hch + H, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+  }
   if (U) {  // close the tile lists
     XF_HIP(hipMemcpyAsync(tile_ptr + ntiles, &U, 4, hipMemcpyHostToDevice, s));
   } else {
@@ -403,7 +425,9 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   const size_t o_tile = o_scr + al((size_t)P * R * 8);
   const size_t o_ftile = o_tile + al(n_tile * 4);
   const size_t o_fpf = o_ftile + al(n_ftile * 4);
-  const size_t total = o_fpf + al(P ? ((size_t)P + 1) * 4 : 0) + 256;
+  const size_t o_hch = o_fpf + al(P ? ((size_t)P + 1) * 4 : 0);
+  const size_t o_hscr = o_hch + al(H ? ((size_t)H + 1) * 4 : 0);
+  const size_t total = o_hscr + al((size_t)n_hch * (1 + XF_HEAVY_KMAX) * 8) + 256;
   char *d = nullptr;
   XF_HIP(hipMalloc((void **)&d, total));
   auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
@@ -418,6 +442,7 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   XF_HIP(cp(o_labels, d_labels, (size_t)R * 4));
   XF_HIP(cp(o_heavy, heavy, (size_t)H * 4));
   XF_HIP(cp(o_tile, tile_ptr, n_tile * 4));
+  if (H) XF_HIP(cp(o_hch, hch, ((size_t)H + 1) * 4));
   if (P) {
     XF_HIP(cp(o_pptr, pptr, ncell * 4));
     XF_HIP(cp(o_pidx, pidx, (size_t)NNZ * 4));
@@ -448,7 +473,9 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   v.fwd_grid = b->fwd_grid;
   v.pad3_ = 0;
   v.ntiles = ntiles;
-  v.pad2_ = 0;
+  v.n_heavy_chunks = n_hch;
+  v.heavy_chunk_ptr = H ? (const uint32_t *)(d + o_hch) : nullptr;
+  v.heavy_scratch = H ? (double *)(d + o_hscr) : nullptr;
   v.tile_ptr = (const uint32_t *)(d + o_tile);
   *out = b;
   return XF_OK;
@@ -470,6 +497,9 @@ extern "C" int xf_batch_download(xf_batch *b) {
   XF_HIP(get(b->coo_row, v.coo_row, v.NNZ));
   XF_HIP(get(b->labels, v.labels, v.R));
   XF_HIP(get(b->heavy, v.heavy, v.H));
+  if (v.H) XF_HIP(get(b->hchunk_ptr, v.heavy_chunk_ptr, (size_t)v.H + 1));
+  else
+    b->hchunk_ptr.assign(1, 0);
   XF_HIP(get(b->tile_ptr, v.tile_ptr, (size_t)v.ntiles + 1));
   if (v.P) {
     XF_HIP(get(b->pptr, v.pptr, (size_t)v.P * ((size_t)v.R + 1)));

@@ -315,6 +315,125 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
   }
 }
 
+// ---- heavy keys in chunks ------------------------------------------------------------------
+// A power-law head key can own millions of a minibatch's occurrences; one wavefront walking
+// them takes milliseconds.  Every heavy key is cut into chunks of XF_TILE_NNZ occurrences
+// (heavy_chunk_ptr, built with the batch), one workgroup reduces one chunk, and a second
+// small kernel adds a key's chunk sums in chunk order (deterministic) and applies the step.
+__device__ __forceinline__ uint32_t heavy_of_chunk(const uint32_t *__restrict__ hch, uint32_t H,
+                                                   uint32_t c) {
+  uint32_t lo = 0, hi = H;  // largest h with hch[h] <= c
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (hch[mid] <= c) lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  v = group_sum<64>(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int k = 0; k < kBlock / 64; ++k) s += red[k];
+  __syncthreads();
+  return s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_lr_heavy_partial(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
+                   uint32_t H, const uint32_t *__restrict__ segptr,
+                   const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
+                   double *__restrict__ partial) {
+  __shared__ double red[kBlock / 64];
+  const uint32_t c = blockIdx.x;
+  const uint32_t h = heavy_of_chunk(hch, H, c);
+  const uint32_t u = heavy[h];
+  const uint32_t b = segptr[u] + (c - hch[h]) * XF_TILE_NNZ;
+  const uint32_t e = min(segptr[u + 1], b + XF_TILE_NNZ);
+  double acc = 0.0;
+  for (uint32_t j = b + threadIdx.x; j < e; j += kBlock) acc += (double)loss[coo_row[j]];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[c] = acc;
+}
+
+template <int OPT, bool UPDATE>
+__global__ void __launch_bounds__(kBlock)
+k_lr_heavy_finish(xf::TableDev T, const uint32_t *__restrict__ heavy,
+                  const uint32_t *__restrict__ hch, uint32_t H,
+                  const double *__restrict__ partial, const uint32_t *__restrict__ slots,
+                  uint32_t R, float *__restrict__ g_out) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  double acc = 0.0;
+  for (uint32_t c = hch[h]; c < hch[h + 1]; ++c) acc += partial[c];
+  const uint32_t u = heavy[h];
+  const float g = (float)((double)(float)acc / (1.0 * R));
+  g_out[u] = g;
+  if (UPDATE) {
+    const uint32_t slot = slots[u];
+    if (OPT == XF_OPT_FTRL) {
+      float w = T.w[slot], nn = T.n[slot], z = T.z[slot];
+      xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+      T.w[slot] = w;
+      T.n[slot] = nn;
+      T.z[slot] = z;
+    } else {
+      T.w[slot] = xf::sgd_step(T.lr, g, T.w[slot]);
+    }
+  }
+}
+
+// FM: per chunk and factor kk the sum of loss*(v_sum - v[u,kk]) (fp32 products, fm_worker.cc:141),
+// plus the plain loss sum in slot k.  partial is [chunk][k+1].
+__global__ void __launch_bounds__(kBlock)
+k_fm_heavy_partial(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
+                   uint32_t H, const uint32_t *__restrict__ segptr,
+                   const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
+                   const float *__restrict__ vsum, const float *__restrict__ vu, int k,
+                   double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
+  const uint32_t c = blockIdx.x;
+  const uint32_t h = heavy_of_chunk(hch, H, c);
+  const uint32_t u = heavy[h];
+  const uint32_t b = segptr[u] + (c - hch[h]) * XF_TILE_NNZ;
+  const uint32_t e = min(segptr[u + 1], b + XF_TILE_NNZ);
+  const uint32_t n = e - b;
+  for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
+    const uint32_t sid = coo_row[b + j];
+    lv[j] = loss[sid];
+    sv[j] = vsum[sid];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t kk = wave; kk <= (uint32_t)k; kk += kBlock / 64) {  // kk == k: the loss sum
+    const float v = kk < (uint32_t)k ? vu[(size_t)u * k + kk] : 0.0f;
+    double acc = 0.0;
+    for (uint32_t j = lane; j < n; j += 64)
+      acc += kk < (uint32_t)k ? (double)(lv[j] * (sv[j] - v)) : (double)lv[j];
+    acc = group_sum<64>(acc);
+    if (lane == 0) partial[(size_t)c * (k + 1) + kk] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fm_heavy_finish(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
+                  uint32_t H, const double *__restrict__ partial, uint32_t R, int k,
+                  float *__restrict__ gw, float *__restrict__ gv) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= H * (uint32_t)(k + 1)) return;
+  const uint32_t h = t / (uint32_t)(k + 1), kk = t - h * (uint32_t)(k + 1);
+  double acc = 0.0;
+  for (uint32_t c = hch[h]; c < hch[h + 1]; ++c) acc += partial[(size_t)c * (k + 1) + kk];
+  const uint32_t u = heavy[h];
+  if (kk < (uint32_t)k) gv[(size_t)u * k + kk] = (float)((double)(float)acc / (1.0 * R));
+  else
+    gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
+}
+
 // the optimizer step for a listed subset of keys (the heavy ones)
 template <int OPT>
 __global__ void __launch_bounds__(kBlock)
@@ -651,7 +770,15 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
                        S(stream), b->segptr, b->coo_row, d_loss, b->U, b->R, d_g);
   }
   XF_HIP(hipGetLastError());
-  if (b->H) {
+  if (b->H && b->heavy_chunk_ptr && b->heavy_scratch) {
+    hipLaunchKernelGGL(k_lr_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
+                       b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss,
+                       b->heavy_scratch);
+    hipLaunchKernelGGL((k_lr_heavy_finish<XF_OPT_SGD, false>), dim3((b->H + kBlock - 1) / kBlock),
+                       dim3(kBlock), 0, S(stream), xf::TableDev{}, b->heavy, b->heavy_chunk_ptr,
+                       b->H, b->heavy_scratch, (const uint32_t *)nullptr, b->R, d_g);
+    XF_HIP(hipGetLastError());
+  } else if (b->H) {
     hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
                        dim3(kBlock), 0, S(stream), b->heavy, b->H, b->segptr, b->coo_row,
                        d_loss, b->R, d_g);
@@ -686,7 +813,18 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
                        b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
   }
   XF_HIP(hipGetLastError());
-  if (b->H) {
+  if (b->H && b->heavy_chunk_ptr && b->heavy_scratch) {
+    const dim3 gh((b->H + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_lr_heavy_partial, dim3(b->n_heavy_chunks), blk, 0, S(stream), b->heavy,
+                       b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, b->heavy_scratch);
+    if (ftrl)
+      hipLaunchKernelGGL((k_lr_heavy_finish<XF_OPT_FTRL, true>), gh, blk, 0, S(stream), T,
+                         b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, d_slots, b->R, d_g);
+    else
+      hipLaunchKernelGGL((k_lr_heavy_finish<XF_OPT_SGD, true>), gh, blk, 0, S(stream), T,
+                         b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, d_slots, b->R, d_g);
+    XF_HIP(hipGetLastError());
+  } else if (b->H) {
     hipLaunchKernelGGL(k_lr_grad_heavy, dim3(blocks_for_groups(b->H, kBlock / 64)),
                        dim3(kBlock), 0, S(stream), b->heavy, b->H, b->segptr, b->coo_row,
                        d_loss, b->R, d_g);
@@ -746,9 +884,19 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
   }
   XF_HIP(hipGetLastError());
   if (b->H) {
-    hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
-                       S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
-                       b->R, k, d_gw, d_gv);
+    if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {
+      hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
+                         b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
+                         d_vu, k, b->heavy_scratch);
+      hipLaunchKernelGGL(k_fm_heavy_finish,
+                         dim3(((size_t)b->H * (k + 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                         S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
+                         d_gw, d_gv);
+    } else {
+      hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
+                         S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
+                         b->R, k, d_gw, d_gv);
+    }
     XF_HIP(hipGetLastError());
   }
   return XF_OK;
@@ -779,9 +927,19 @@ extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_ba
                        d_rows_w, d_rows_v, b->R, k, d_gw, d_gv);
   XF_HIP(hipGetLastError());
   if (b->H) {
-    hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
-                       S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
-                       b->R, k, d_gw, d_gv);
+    if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {
+      hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
+                         b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
+                         d_vu, k, b->heavy_scratch);
+      hipLaunchKernelGGL(k_fm_heavy_finish,
+                         dim3(((size_t)b->H * (k + 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                         S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
+                         d_gw, d_gv);
+    } else {
+      hipLaunchKernelGGL(k_fm_grad_heavy, dim3(std::min<uint32_t>(b->H, 4096)), dim3(kBlock), 0,
+                         S(stream), b->heavy, b->H, b->segptr, b->coo_row, d_loss, d_vsum, d_vu,
+                         b->R, k, d_gw, d_gv);
+    }
     XF_HIP(hipGetLastError());
     const dim3 gh((b->H + kBlock - 1) / kBlock), gk(blocks_for_groups(b->H * k, kBlock));
     if (ftrl) {
