@@ -75,39 +75,13 @@ k_lr_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
   }
 }
 
-// LR forward, panel-major variant for large minibatches.  The compact weight array w_u
-// (U floats, 25 MB at the config-2 shape) does not fit an XCD's 4 MiB L2, so the plain
-// kernel's gathers are served by the Infinity Cache at fabric rate.  Here the uidx space is
-// cut into P key-range panels (P a multiple of 8): blocks with blockIdx % 8 == x — which the
-// dispatcher places on XCD x — work only on panels p with p % 8 == x, panel after panel, so
-// each XCD's L2 holds the 1/P slice of w_u it is gathering from.  A (row, panel) cell is
-// summed by a G-lane group; the P partial sums of a row are added in panel order by
-// k_lr_finalize (deterministic).  Placement is a performance assumption only.
-template <int G>
-__global__ void __launch_bounds__(kBlock)
-k_lr_forward_panel(const uint32_t *__restrict__ pptr, const uint32_t *__restrict__ pidx,
-                   const float *__restrict__ wu, uint32_t R, uint32_t P,
-                   double *__restrict__ partial) {
-  constexpr uint32_t kGroups = kBlock / G;       // (row,panel) cells per block pass
-  const uint32_t lane = threadIdx.x % G, grp = threadIdx.x / G;
-  const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
-  const uint32_t chunks = (R + kGroups - 1) / kGroups;  // row chunks per panel
-  const uint32_t units = (P >> 3) * chunks;              // work units of this XCD
-  for (uint32_t w = q; w < units; w += nq) {
-    const uint32_t p = xcd + 8u * (w / chunks);
-    const uint32_t r = (w % chunks) * kGroups + grp;
-    if (r >= R) continue;
-    const uint32_t *pp = pptr + (size_t)p * (R + 1) + r;
-    const uint32_t b = pp[0], e = pp[1];
-    double acc = 0.0;
-    for (uint32_t j = b + lane; j < e; j += G)
-      acc += (double)wu[pidx[j]];
-    acc = group_sum<G>(acc);
-    if (lane == 0) partial[(size_t)p * R + r] = acc;
-  }
-}
-
-// Tiled form of the panel forward: a workgroup takes a run of (panel,row) cells holding
+// LR forward for large minibatches.  The compact weight array w_u (U floats, 25 MB at the
+// config-2 shape) does not fit an XCD's 4 MiB L2, so the plain kernel's gathers are served by
+// the Infinity Cache at fabric rate (1e7 gathers: 155 us).  The batch therefore carries a
+// panel-major copy of the CSR: the uidx space is cut into P key-range panels (P a multiple of
+// 8) so that one panel's slice of w_u fits an L2, and the partial sums of a row over the
+// panels are added in panel order by k_lr_finalize (deterministic).
+// A workgroup takes a run of (panel,row) cells holding
 // <= XF_TILE_NNZ nonzeros, gathers w_u[pidx[j]] for all of them at once into LDS (one
 // coalesced index read, every lane with independent gathers in flight), then one lane per
 // cell adds the cell's short run in fp64.  Workgroup b takes the (b/8)-th tile of the panels p
@@ -206,46 +180,10 @@ k_lr_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
   }
 }
 
-// LR gradient fused with the Push for a table that lives on the same GPU (single shard):
-// the lane that reduced key u's occurrences applies the optimizer step to slot[u] right
-// away (ftrl.h:59-74 / sgd.h:52).  The state words are requested before the occurrence
-// walk so their latency overlaps it; g never round-trips through HBM (it is still stored,
-// once, for the parity hook).  Slots are monotone in u, so the state accesses of a wave
-// are one neighbourhood of w[], n[], z[].
-template <int OPT>
-__global__ void __launch_bounds__(kBlock)
-k_lr_grad_update(xf::TableDev T, const uint32_t *__restrict__ segptr,
-                 const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
-                 const uint32_t *__restrict__ slots, uint32_t U, uint32_t R,
-                 float *__restrict__ g_out) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += stride) {
-    const uint32_t b = segptr[u], e = segptr[u + 1];
-    if (e - b > XF_HEAVY_SEG) continue;  // k_lr_grad_heavy + k_update_listed
-    const uint32_t slot = slots[u];
-    float w = T.w[slot], nn = 0.f, z = 0.f;
-    if (OPT == XF_OPT_FTRL) {
-      nn = T.n[slot];
-      z = T.z[slot];
-    }
-    double acc = 0.0;
-    for (uint32_t j = b; j < e; ++j) acc += (double)loss[coo_row[j]];
-    const float g = (float)((double)(float)acc / (1.0 * R));
-    g_out[u] = g;
-    if (OPT == XF_OPT_FTRL) {
-      xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
-      T.w[slot] = w;
-      T.n[slot] = nn;
-      T.z[slot] = z;
-    } else {
-      T.w[slot] = xf::sgd_step(T.lr, g, w);
-    }
-  }
-}
-
-// LDS-tiled gradient (optionally fused with the Push).  The per-key kernels above walk a
-// key's occurrences with a chain of dependent global loads (coo_row[j] -> loss[row]), and a
-// wavefront waits for its longest chain.  Here a workgroup takes a tile of consecutive keys
+// LDS-tiled gradient, optionally fused with the Push for a table that lives on the same GPU
+// (single shard): g then never round-trips through HBM (it is still stored, once, for the
+// parity hook).  The per-key kernel above walks a key's occurrences with a chain of dependent
+// global loads (coo_row[j] -> loss[row]), and a wavefront waits for its longest chain.  Here a workgroup takes a tile of consecutive keys
 // whose occurrence lists total <= XF_TILE_NNZ entries: phase 1 stages loss[coo_row[j]] for
 // the whole tile into LDS with one coalesced read of coo_row[] and one round of gathers, all
 // lanes busy; phase 2 sums each key's (short) run out of LDS in fp64 and, when UPDATE, applies
@@ -729,21 +667,6 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
     XF_HIP(hipGetLastError());
     return XF_OK;
   }
-  if (b->P >= 8 && b->pptr && b->pidx && b->fwd_scratch) {
-    const int grid = 8 * 256;  // 256 blocks per XCD
-    const double cell = avg / b->P;  // nonzeros per (row,panel) cell
-    if (cell <= 10.0)
-      hipLaunchKernelGGL(k_lr_forward_panel<8>, dim3(grid), dim3(kBlock), 0, S(stream), b->pptr,
-                         b->pidx, d_wu, b->R, b->P, b->fwd_scratch);
-    else
-      hipLaunchKernelGGL(k_lr_forward_panel<16>, dim3(grid), dim3(kBlock), 0, S(stream), b->pptr,
-                         b->pidx, d_wu, b->R, b->P, b->fwd_scratch);
-    XF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                       S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
-    XF_HIP(hipGetLastError());
-    return XF_OK;
-  }
   if (avg <= 48.0) {  // short rows: four examples per wavefront
     hipLaunchKernelGGL(k_lr_forward<16>, dim3(blocks_for_groups(b->R, kBlock / 16)),
                        dim3(kBlock), 0, S(stream), b->rowptr, b->uidx, d_wu, b->labels, b->R,
@@ -792,10 +715,14 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
   XF_REQUIRE(t && b && d_slots && d_loss && d_g, "xf_lr_grad_update_dev: null argument");
   XF_REQUIRE(xf::table_dim(t) == 1, "xf_lr_grad_update_dev: dim must be 1");
   if (b->U == 0) return XF_OK;
+  if (!(b->ntiles && b->tile_ptr)) {  // a view without gradient tiles: unfused
+    XF_TRY(xf_lr_grad_dev(b, d_loss, d_g, stream));
+    return xf_table_update_dev(t, d_slots, b->U, d_g, stream);
+  }
   const xf::TableDev &T = xf::table_dev(t);
   const bool ftrl = T.n != nullptr;
-  const dim3 g(blocks_for_groups(b->U, kBlock)), blk(kBlock);
-  if (b->ntiles && b->tile_ptr) {
+  const dim3 blk(kBlock);
+  {
     const dim3 gt(tile_grid(b->ntiles));
     if (ftrl)
       hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_FTRL, true>), gt, blk, 0, S(stream), T,
@@ -805,12 +732,6 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
       hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_SGD, true>), gt, blk, 0, S(stream), T,
                          b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, b->R,
                          d_g);
-  } else if (ftrl) {
-    hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_FTRL>, g, blk, 0, S(stream), T, b->segptr,
-                       b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
-  } else {
-    hipLaunchKernelGGL(k_lr_grad_update<XF_OPT_SGD>, g, blk, 0, S(stream), T, b->segptr,
-                       b->coo_row, d_loss, d_slots, b->U, b->R, d_g);
   }
   XF_HIP(hipGetLastError());
   if (b->H && b->heavy_chunk_ptr && b->heavy_scratch) {
