@@ -212,9 +212,10 @@ int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
 /* LR gradient (lr_worker.cc:100-119): g[u] = (sum_{occurrences} loss[row]) / R */
 int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float *d_g, void *stream);
 /* LR gradient fused with the Push for a table on the same GPU (single shard): g is still
- * written (parity hook); slots as returned by resolve/pull for b->ukeys */
+ * written (parity hook); slots as returned by resolve/pull for b->ukeys; d_wu = the weights
+ * that Pull returned, if nothing has touched those rows since (saves re-reading w), or NULL */
 int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const uint32_t *d_slots,
-                          const float *d_loss, float *d_g, void *stream);
+                          const float *d_wu, const float *d_loss, float *d_g, void *stream);
 /* FM forward, reference form (fm_worker.cc:159-202); v_u is U x k row-major */
 int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
                       float *d_loss, float *d_pctr, float *d_vsum, void *stream);

@@ -79,7 +79,7 @@ def main():
         capi.check(L.xf_table_pull_dev(tw.h, b.ukeys.data_ptr(), b.U, rows.data_ptr(),
                                        wu.data_ptr(), s))
         capi.check(L.xf_lr_grad_update_dev(tw.h, capi.C.byref(b.view), rows.data_ptr(),
-                                           loss.data_ptr(), g.data_ptr(), s))
+                                           wu.data_ptr(), loss.data_ptr(), g.data_ptr(), s))
     timed("pull + grad_update", gu, 28 * U + 8 * NNZ + 36 * U)
     st.check()
 

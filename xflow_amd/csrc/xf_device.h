@@ -32,13 +32,24 @@ struct TableDev {
   uint64_t seed;
   uint64_t *keys;     // [cap+1]   key index (open addressing, order-preserving home)
   uint32_t *rows;     // [cap+1]   state row of the key stored at that position
-  float *w, *n, *z;   // [(max_rows+1)*dim] dense state, row-major
+  float *w;           // [(max_rows+1)*dim] dense weights, row-major
+  float2 *nz;         // [(max_rows+1)*dim] FTRL accumulators {n, z} side by side (FTRL only):
+                      // the Push reads and writes them together, one 8-byte access each
   TableStat *stat;
   int dim, init_kind;
   float init_const;
   float alpha, beta, lambda1, lambda2, lr;
   bool last_shard, single;
 };
+
+__device__ __forceinline__ void load_nz(const TableDev &T, size_t o, float &n, float &z) {
+  const float2 s = T.nz[o];
+  n = s.x;
+  z = s.y;
+}
+__device__ __forceinline__ void store_nz(const TableDev &T, size_t o, float n, float z) {
+  T.nz[o] = make_float2(n, z);
+}
 
 // ps-lite uniform key-range ownership
 __device__ __forceinline__ bool owns(const TableDev &T, uint64_t key) {

@@ -194,8 +194,9 @@ template <int OPT, bool UPDATE>
 __global__ void __launch_bounds__(kBlock)
 k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t ntiles,
                 const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
-                const float *__restrict__ loss, const uint32_t *__restrict__ slots, uint32_t R,
-                float *__restrict__ g_out) {
+                const float *__restrict__ loss, const uint32_t *__restrict__ slots,
+                const float *__restrict__ wu /* pulled weights == current w, or null */,
+                uint32_t R, float *__restrict__ g_out) {
   __shared__ float vals[XF_TILE_NNZ];
   __shared__ uint32_t sp[XF_TILE_KEYS + 1];
   const uint32_t tid = threadIdx.x;
@@ -220,10 +221,9 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
       for (int q = 0; q < kKeysPerThread; ++q) {
         const uint32_t k = tid + q * kBlock;
         if (k < nk) {
-          w[q] = T.w[slot[q]];
+          w[q] = wu ? wu[ua + k] : T.w[slot[q]];  // the Pull's copy is still current
           if (OPT == XF_OPT_FTRL) {
-            nn[q] = T.n[slot[q]];
-            z[q] = T.z[slot[q]];
+            xf::load_nz(T, slot[q], nn[q], z[q]);
           }
         }
       }
@@ -241,8 +241,7 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
           if (OPT == XF_OPT_FTRL) {
             xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w[q], nn[q], z[q]);
             T.w[slot[q]] = w[q];
-            T.n[slot[q]] = nn[q];
-            T.z[slot[q]] = z[q];
+            xf::store_nz(T, slot[q], nn[q], z[q]);
           } else {
             T.w[slot[q]] = xf::sgd_step(T.lr, g, w[q]);
           }
@@ -313,11 +312,11 @@ k_lr_heavy_finish(xf::TableDev T, const uint32_t *__restrict__ heavy,
   if (UPDATE) {
     const uint32_t slot = slots[u];
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[slot], nn = T.n[slot], z = T.z[slot];
+      float w = T.w[slot], nn, z;
+      xf::load_nz(T, slot, nn, z);
       xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
       T.w[slot] = w;
-      T.n[slot] = nn;
-      T.z[slot] = z;
+      xf::store_nz(T, slot, nn, z);
     } else {
       T.w[slot] = xf::sgd_step(T.lr, g, T.w[slot]);
     }
@@ -381,11 +380,11 @@ k_update_listed(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t H,
   if (h >= H) return;
   const uint32_t u = list[h], slot = slots[u];
   if (OPT == XF_OPT_FTRL) {
-    float w = T.w[slot], nn = T.n[slot], z = T.z[slot];
+    float w = T.w[slot], nn, z;
+      xf::load_nz(T, slot, nn, z);
     xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g[u], w, nn, z);
     T.w[slot] = w;
-    T.n[slot] = nn;
-    T.z[slot] = z;
+    xf::store_nz(T, slot, nn, z);
   } else {
     T.w[slot] = xf::sgd_step(T.lr, g[u], T.w[slot]);
   }
@@ -410,7 +409,7 @@ k_fm_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
     const uint32_t b = rowptr[r], e = rowptr[r + 1];
     const uint32_t nel = (e - b) * k;
     double wx = 0.0, vs = 0.0, vp = 0.0;
-    if (K > 0 && 64 % K == 0) {
+    if (K > 0 && 64 % (K > 0 ? K : 1) == 0) {
       // K divides the wavefront: lane = (nnz slot, factor); 4 nnz slots in flight per lane
       constexpr uint32_t kG = K > 0 ? 64 / (K > 0 ? K : 1) : 1;  // nnz per wave pass
       const uint32_t kk = lane % (K > 0 ? K : 1), sub = lane / (K > 0 ? K : 1);
@@ -551,11 +550,11 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         gv[o] = g;
         if (UPDATE) {
           if (OPT == XF_OPT_FTRL) {
-            float w = v[i], nn = TV.n[to[i]], z = TV.z[to[i]];
+            float w = v[i], nn, z;
+            xf::load_nz(TV, to[i], nn, z);
             xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g, w, nn, z);
             TV.w[to[i]] = w;
-            TV.n[to[i]] = nn;
-            TV.z[to[i]] = z;
+            xf::store_nz(TV, to[i], nn, z);
           } else {
             TV.w[to[i]] = xf::sgd_step(TV.lr, g, v[i]);
           }
@@ -566,11 +565,11 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
           if (UPDATE) {
             const uint32_t rw = rows_w[ua + kq[i]];
             if (OPT == XF_OPT_FTRL) {
-              float w = wu[ua + kq[i]], nn = TW.n[rw], z = TW.z[rw];
+              float w = wu[ua + kq[i]], nn, z;
+      xf::load_nz(TW, rw, nn, z);
               xf::ftrl_step(TW.alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
               TW.w[rw] = w;
-              TW.n[rw] = nn;
-              TW.z[rw] = z;
+              xf::store_nz(TW, rw, nn, z);
             } else {
               TW.w[rw] = xf::sgd_step(TW.lr, g1, wu[ua + kq[i]]);
             }
@@ -595,11 +594,11 @@ k_update_listed_rows(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t
     const size_t o = (size_t)rows[u] * T.dim + j;
     const float gg = g[(size_t)u * T.dim + j];
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[o], nn = T.n[o], z = T.z[o];
+      float w = T.w[o], nn, z;
+      xf::load_nz(T, o, nn, z);
       xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, gg, w, nn, z);
       T.w[o] = w;
-      T.n[o] = nn;
-      T.z[o] = z;
+      xf::store_nz(T, o, nn, z);
     } else {
       T.w[o] = xf::sgd_step(T.lr, gg, T.w[o]);
     }
@@ -687,7 +686,8 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
   if (b->ntiles && b->tile_ptr) {
     hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_SGD, false>), dim3(tile_grid(b->ntiles)),
                        dim3(kBlock), 0, S(stream), xf::TableDev{}, b->tile_ptr, b->ntiles,
-                       b->segptr, b->coo_row, d_loss, (const uint32_t *)nullptr, b->R, d_g);
+                       b->segptr, b->coo_row, d_loss, (const uint32_t *)nullptr,
+                       (const float *)nullptr, b->R, d_g);
   } else {
     hipLaunchKernelGGL(k_lr_grad, dim3(blocks_for_groups(b->U, kBlock)), dim3(kBlock), 0,
                        S(stream), b->segptr, b->coo_row, d_loss, b->U, b->R, d_g);
@@ -711,7 +711,8 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
 }
 
 extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const uint32_t *d_slots,
-                                     const float *d_loss, float *d_g, void *stream) {
+                                     const float *d_wu, const float *d_loss, float *d_g,
+                                     void *stream) {
   XF_REQUIRE(t && b && d_slots && d_loss && d_g, "xf_lr_grad_update_dev: null argument");
   XF_REQUIRE(xf::table_dim(t) == 1, "xf_lr_grad_update_dev: dim must be 1");
   if (b->U == 0) return XF_OK;
@@ -720,18 +721,18 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
     return xf_table_update_dev(t, d_slots, b->U, d_g, stream);
   }
   const xf::TableDev &T = xf::table_dev(t);
-  const bool ftrl = T.n != nullptr;
+  const bool ftrl = T.nz != nullptr;
   const dim3 blk(kBlock);
   {
     const dim3 gt(tile_grid(b->ntiles));
     if (ftrl)
       hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_FTRL, true>), gt, blk, 0, S(stream), T,
-                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, b->R,
-                         d_g);
+                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, d_wu,
+                         b->R, d_g);
     else
       hipLaunchKernelGGL((k_lr_grad_tiled<XF_OPT_SGD, true>), gt, blk, 0, S(stream), T,
-                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, b->R,
-                         d_g);
+                         b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_slots, d_wu,
+                         b->R, d_g);
   }
   XF_HIP(hipGetLastError());
   if (b->H && b->heavy_chunk_ptr && b->heavy_scratch) {
@@ -834,8 +835,8 @@ extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_ba
   if (b->U == 0) return XF_OK;
   const xf::TableDev &TW = xf::table_dev(tw), &TV = xf::table_dev(tv);
   const int k = TV.dim;
-  const bool ftrl = TV.n != nullptr;
-  XF_REQUIRE((TW.n != nullptr) == ftrl, "xf_fm_grad_update_dev: w and v use different optimizers");
+  const bool ftrl = TV.nz != nullptr;
+  XF_REQUIRE((TW.nz != nullptr) == ftrl, "xf_fm_grad_update_dev: w and v use different optimizers");
   XF_REQUIRE(b->ntiles && b->tile_ptr, "xf_fm_grad_update_dev: batch has no gradient tiles");
   const dim3 gt(tile_grid(b->ntiles)), blk(kBlock);
   if (ftrl)
@@ -1018,7 +1019,7 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   XF_END(kEvResolve);
   XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, nullptr, stream));  // :172
   XF_END(kEvForward);  // gradient (:173) + Push (:175) in one pass: the table is on this GPU
-  XF_TRY(xf_lr_grad_update_dev(w, &v, ws->slots, ws->loss, ws->g, stream));
+  XF_TRY(xf_lr_grad_update_dev(w, &v, ws->slots, ws->wu, ws->loss, ws->g, stream));
   XF_END(kEvGrad);
   if (ws->profiling) ws->ev_pending = true;
   return XF_OK;

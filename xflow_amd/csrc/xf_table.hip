@@ -210,14 +210,39 @@ k_update(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
     const size_t o = (size_t)rows[i] * T.dim + j;
     const float g = grads[e];
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[o], nn = T.n[o], z = T.z[o];
+      float w = T.w[o], nn, z;
+      xf::load_nz(T, o, nn, z);
       xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
       T.w[o] = w;
-      T.n[o] = nn;
-      T.z[o] = z;
+      xf::store_nz(T, o, nn, z);
     } else {
       T.w[o] = xf::sgd_step(T.lr, g, T.w[o]);
     }
+  }
+}
+
+// export / import of one FTRL accumulator (comp 0 = n, 1 = z)
+__global__ void __launch_bounds__(kBlock)
+k_gather_nz(const float2 *__restrict__ nz, int comp, int dim, const uint32_t *__restrict__ rows,
+            size_t n, float *__restrict__ vals) {
+  const size_t total = n * (size_t)dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = e / (size_t)dim, j = e - i * (size_t)dim;
+    const float2 s = nz[(size_t)rows[i] * dim + j];
+    vals[e] = comp ? s.y : s.x;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_scatter_nz(float2 *__restrict__ nz, int comp, int dim, const uint32_t *__restrict__ rows,
+             size_t n, const float *__restrict__ src) {
+  const size_t total = n * (size_t)dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = e / (size_t)dim, j = e - i * (size_t)dim;
+    float *cell = reinterpret_cast<float *>(&nz[(size_t)rows[i] * dim + j]);
+    cell[comp] = src[e];
   }
 }
 
@@ -337,18 +362,29 @@ static int alloc_index(xf::TableDev &T) {
 // (re)allocate the dense state for `max_rows` rows, keeping the first `keep` rows
 static int alloc_state(xf::TableDev &T, uint64_t max_rows, bool ftrl, uint64_t keep) {
   const size_t elems = ((size_t)max_rows + 1) * (size_t)T.dim;
-  float **arrs[3] = {&T.w, &T.n, &T.z};
-  for (int a = 0; a < (ftrl ? 3 : 1); ++a) {
+  {
     float *fresh = nullptr;
     XF_HIP(hipMalloc((void **)&fresh, elems * sizeof(float)));
     XF_HIP(hipMemset(fresh, 0, elems * sizeof(float)));
-    if (*arrs[a]) {
+    if (T.w) {
       if (keep)
-        XF_HIP(hipMemcpy(fresh, *arrs[a], (size_t)keep * T.dim * sizeof(float),
+        XF_HIP(hipMemcpy(fresh, T.w, (size_t)keep * T.dim * sizeof(float),
                          hipMemcpyDeviceToDevice));
-      XF_HIP(hipFree(*arrs[a]));
+      XF_HIP(hipFree(T.w));
     }
-    *arrs[a] = fresh;
+    T.w = fresh;
+  }
+  if (ftrl) {
+    float2 *fresh = nullptr;
+    XF_HIP(hipMalloc((void **)&fresh, elems * sizeof(float2)));
+    XF_HIP(hipMemset(fresh, 0, elems * sizeof(float2)));
+    if (T.nz) {
+      if (keep)
+        XF_HIP(hipMemcpy(fresh, T.nz, (size_t)keep * T.dim * sizeof(float2),
+                         hipMemcpyDeviceToDevice));
+      XF_HIP(hipFree(T.nz));
+    }
+    T.nz = fresh;
   }
   T.max_rows = max_rows;
   return XF_OK;
@@ -416,7 +452,7 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
-  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.n, t->T.z, t->T.stat,
+  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat,
                 t->s_keys, t->s_rows, t->s_vals};
   for (void *p : ps)
     if (p) hipFree(p);
@@ -605,16 +641,19 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
   for (size_t i = 0; i < nk; ++i) keys[i] = hk[order[i]];
   std::vector<float> vals(nk * dim);
-  float *srcs[3] = {t->T.w, t->T.n, t->T.z};
   float *dsts[3] = {w, n_, z_};
   for (int a = 0; a < 3; ++a) {
     if (!dsts[a]) continue;
-    if (!srcs[a]) {  // SGD tables have no n/z: report zeros
+    if (a > 0 && !t->T.nz) {  // SGD tables have no n/z: report zeros
       std::fill(dsts[a], dsts[a] + nk * dim, 0.0f);
       continue;
     }
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(nk * dim)), dim3(kBlock), 0, 0, srcs[a], dim,
-                       d_rows, (size_t)nk, d_vals);
+    if (a == 0)
+      hipLaunchKernelGGL(k_gather, dim3(grid_for(nk * dim)), dim3(kBlock), 0, 0, t->T.w, dim,
+                         d_rows, (size_t)nk, d_vals);
+    else
+      hipLaunchKernelGGL(k_gather_nz, dim3(grid_for(nk * dim)), dim3(kBlock), 0, 0, t->T.nz, a - 1,
+                         dim, d_rows, (size_t)nk, d_vals);
     XF_HIP(hipGetLastError());
     XF_HIP(hipMemcpy(vals.data(), d_vals, nk * dim * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nk; ++i)
@@ -636,12 +675,15 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
   XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
   const float *srcs[3] = {w, n_, z_};
-  float *dsts[3] = {t->T.w, t->T.n, t->T.z};
   for (int a = 0; a < 3; ++a) {
-    if (!srcs[a] || !dsts[a]) continue;
+    if (!srcs[a] || (a > 0 && !t->T.nz)) continue;
     XF_HIP(hipMemcpy(t->s_vals, srcs[a], n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, 0,
-                       dsts[a], t->T.dim, t->s_rows, n, t->s_vals);
+    if (a == 0)
+      hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, 0, t->T.w,
+                         t->T.dim, t->s_rows, n, t->s_vals);
+    else
+      hipLaunchKernelGGL(k_scatter_nz, dim3(grid_for(n * t->T.dim)), dim3(kBlock), 0, 0, t->T.nz,
+                         a - 1, t->T.dim, t->s_rows, n, t->s_vals);
     XF_HIP(hipGetLastError());
   }
   return xf_table_check(t, nullptr);
