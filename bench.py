@@ -51,6 +51,7 @@ def parse_args():
                     help="extra timed steps that include the GPU key build (0 = skip)")
     ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1"],
                     help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped)")
+    ap.add_argument("--no-defrag", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--seed", type=int, default=20260926)
@@ -248,6 +249,10 @@ def main():
     for i in range(args.warmup):
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
+    if hasattr(trainer, "defrag") and not args.no_defrag:
+        # table maintenance between steps, as the worker does at epoch boundaries: once the
+        # warm-up has inserted the keys, renumber the state rows in key order
+        trainer.defrag()
     barrier()
     if dist is not None:
         # RCCL writes its version banner through C stdio; push it out now so that the JSON

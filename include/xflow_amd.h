@@ -175,6 +175,9 @@ int xf_table_size(xf_table *t, uint64_t *nkeys); /* synchronises */
 int xf_table_capacity(xf_table *t, uint64_t *slots);
 /* grow to new_capacity slots (rehash on device); earlier slot arrays become invalid */
 int xf_table_reserve(xf_table *t, uint64_t new_capacity);
+/* renumber the state rows in key order (locality of the Pull gather and the Push pass once
+ * the key set has settled); row numbers change — call it between steps */
+int xf_table_defrag(xf_table *t);
 int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2, float lr);
 
 /* ps-lite-shaped host API: keys sorted & unique (the KVWorker contract), host pointers,

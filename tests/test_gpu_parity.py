@@ -230,6 +230,36 @@ def test_rows_are_dense_and_survive_reserve():
     assert torch.equal(r1, r2) and len(t) == 3000
 
 
+def test_defrag_keeps_the_table_and_orders_rows_by_key():
+    import torch
+    rng = np.random.RandomState(6)
+    keys = np.array([O.hash_str(str(i)) for i in range(20000)], dtype=np.uint64)
+    for dim, opt in ((1, capi.OPT_FTRL), (8, capi.OPT_FTRL), (4, capi.OPT_SGD)):
+        t = capi.Table(opt, dim, capacity=1 << 16)
+        for _ in range(4):                     # several arrival orders
+            sub = np.sort(rng.choice(keys, size=9000, replace=False))
+            t.push(sub, rng.randn(len(sub), dim).astype(np.float32))
+        before = t.export()
+        t.defrag()
+        for a, b in zip(t.export(), before):
+            same(a, b)
+        sk = np.sort(before[0])
+        dk = torch.from_numpy(sk.view(np.int64)).cuda()
+        rows = torch.empty(len(sk), dtype=torch.int32, device="cuda")
+        t.resolve_dev(dk.data_ptr(), len(sk), rows.data_ptr())
+        t.check()
+        r = rows.cpu().numpy().astype(np.int64)
+        assert sorted(r.tolist()) == list(range(len(sk)))
+        assert np.mean(np.abs(np.diff(r)) <= 8) > 0.99   # key order = row order, almost
+        g = rng.randn(len(sk), dim).astype(np.float32)  # and it keeps training correctly
+        s = O.Store(opt, dim)
+        s.import_(*before)
+        t.push(sk, g)
+        s.push(sk, g)
+        for a, b in zip(t.export(), s.export()):
+            same(a, b)
+
+
 def test_export_import_roundtrip():
     rng = np.random.RandomState(4)
     keys = np.sort(np.unique(rng.randint(1, 2**62, size=3000).astype(np.uint64)))

@@ -82,6 +82,7 @@ SIGNATURES = {
     "xf_table_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_capacity": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_reserve": (C.c_int, [vp, C.c_uint64]),
+    "xf_table_defrag": (C.c_int, [vp]),
     "xf_table_set_hyper": (C.c_int, [vp] + [C.c_float] * 5),
     "xf_table_pull": (C.c_int, [vp, u64p, C.c_size_t, f32p]),
     "xf_table_push": (C.c_int, [vp, u64p, C.c_size_t, f32p]),
@@ -316,6 +317,9 @@ class Table:
 
     def reserve(self, capacity):
         check(lib().xf_table_reserve(self.h, capacity))
+
+    def defrag(self):
+        check(lib().xf_table_defrag(self.h))
 
     def pull(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -24,6 +24,11 @@
 // state in contiguous runs as well.  Same idea as ps-lite's key-range sharding across
 // servers, continued inside the GPU.
 #include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <numeric>
@@ -306,6 +311,42 @@ k_rehash(xf::TableDev O, xf::TableDev T) {
   }
 }
 
+// defrag: state rows renumbered in index-position (= key) order
+__global__ void __launch_bounds__(kBlock)
+k_occupied_flags(xf::TableDev T, uint32_t *__restrict__ flag) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride)
+    flag[s] = (s < T.cap ? T.keys[s] != xf::kEmptyKey : T.stat->spare_used != 0u) &&
+                      T.rows[s] != xf::kNoRow
+                  ? 1u
+                  : 0u;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_defrag_move(xf::TableDev T, const uint32_t *__restrict__ flag,
+              const uint32_t *__restrict__ newrow, float *__restrict__ w2,
+              float2 *__restrict__ nz2) {
+  // one work item per (position, coordinate); dim is small or a multiple of the wave for FM
+  const size_t total = ((size_t)T.cap + 1) * T.dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t s = T.dim == 1 ? e : e / (size_t)T.dim;
+    if (!flag[s]) continue;
+    const size_t j = e - s * (size_t)T.dim;
+    const size_t src = (size_t)T.rows[s] * T.dim + j, dst = (size_t)newrow[s] * T.dim + j;
+    w2[dst] = T.w[src];
+    if (nz2) nz2[dst] = T.nz[src];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_defrag_rows(xf::TableDev T, const uint32_t *__restrict__ flag,
+              const uint32_t *__restrict__ newrow) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride)
+    if (flag[s]) T.rows[s] = newrow[s];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ table
@@ -533,6 +574,57 @@ extern "C" int xf_table_reserve(xf_table *t, uint64_t new_capacity) {
   XF_TRY(alloc_state(N, rows_for(new_capacity), t->cfg.opt_kind == XF_OPT_FTRL, st.count));
   t->T = N;
   t->cfg.capacity = new_capacity;
+  return XF_OK;
+}
+
+// Renumber the state rows in key order.  Rows are handed out in arrival order (per-wave runs),
+// so after the key set has settled a sorted key list still hops between runs; with rows in
+// index-position order — the index is all but sorted by key — the lanes of a wave touch
+// neighbouring rows and both the Pull's weight gather and the Push's state pass coalesce.
+// Row numbers change: call it between steps, never between a resolve and its update.
+extern "C" int xf_table_defrag(xf_table *t) {
+  XF_REQUIRE(t, "xf_table_defrag: null table");
+  XF_HIP(hipDeviceSynchronize());
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  if (st.err) return xf_table_check(t, nullptr);
+  if (st.count == 0) return XF_OK;
+  xf::TableDev &T = t->T;
+  const size_t npos = (size_t)T.cap + 1;
+  const size_t elems = ((size_t)T.max_rows + 1) * (size_t)T.dim;
+  uint32_t *flag = nullptr, *newrow = nullptr;
+  float *w2 = nullptr;
+  float2 *nz2 = nullptr;
+  void *tmp = nullptr;
+  XF_HIP(hipMalloc((void **)&flag, npos * 4));
+  XF_HIP(hipMalloc((void **)&newrow, npos * 4));
+  XF_HIP(hipMalloc((void **)&w2, elems * sizeof(float)));
+  XF_HIP(hipMemset(w2, 0, elems * sizeof(float)));
+  if (T.nz) {
+    XF_HIP(hipMalloc((void **)&nz2, elems * sizeof(float2)));
+    XF_HIP(hipMemset(nz2, 0, elems * sizeof(float2)));
+  }
+  hipLaunchKernelGGL(k_occupied_flags, dim3(grid_for(npos)), dim3(kBlock), 0, 0, T, flag);
+  size_t tb = 0;
+  XF_HIP(rocprim::exclusive_scan(nullptr, tb, flag, newrow, 0u, npos, rocprim::plus<uint32_t>(),
+                                 (hipStream_t)0));
+  XF_HIP(hipMalloc(&tmp, tb ? tb : 1));
+  XF_HIP(rocprim::exclusive_scan(tmp, tb, flag, newrow, 0u, npos, rocprim::plus<uint32_t>(),
+                                 (hipStream_t)0));
+  hipLaunchKernelGGL(k_defrag_move, dim3(grid_for(npos * T.dim)), dim3(kBlock), 0, 0, T, flag,
+                     newrow, w2, nz2);
+  hipLaunchKernelGGL(k_defrag_rows, dim3(grid_for(npos)), dim3(kBlock), 0, 0, T, flag, newrow);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipDeviceSynchronize());
+  XF_HIP(hipFree(T.w));
+  T.w = w2;
+  if (T.nz) {
+    XF_HIP(hipFree(T.nz));
+    T.nz = nz2;
+  }
+  XF_HIP(hipFree(flag));
+  XF_HIP(hipFree(newrow));
+  XF_HIP(hipFree(tmp));
   return XF_OK;
 }
 

@@ -91,6 +91,17 @@ int Worker::grow_if_needed(size_t incoming) {
   return XF_OK;
 }
 
+int Worker::defrag_if_grown() {
+  uint64_t n = 0;
+  XF_TRY(xf_table_size(table_w_, &n));
+  if (n > keys_at_defrag_ + keys_at_defrag_ / 20) {  // > 5 % new keys since the last one
+    XF_TRY(xf_table_defrag(table_w_));
+    if (table_v_) XF_TRY(xf_table_defrag(table_v_));
+    keys_at_defrag_ = n;
+  }
+  return XF_OK;
+}
+
 // the key build of update() (lr_worker.cc:146-166): on the GPU unless key_build=host
 int Worker::compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys,
                     const int32_t *labels, size_t start, size_t end) {
@@ -171,6 +182,9 @@ int Worker::batch_training() {
       xf_reader_close(rd);
       cached = cache_batches != 0;
     }
+    // table maintenance at the epoch boundary: when this epoch inserted a noticeable share of
+    // the keys, renumber the state rows in key order for the epochs that replay them
+    if (epoch + 1 < epochs) XF_TRY(defrag_if_grown());
     if ((epoch + 1) % 30 == 0) std::cout << "epoch : " << epoch << std::endl;  // :202
   }
   XF_TRY(xf_stream_sync(nullptr));

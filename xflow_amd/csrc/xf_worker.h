@@ -48,6 +48,8 @@ class Worker {
   int compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys, const int32_t *labels,
               size_t start, size_t end);
   int grow_if_needed(size_t incoming);
+  int defrag_if_grown();
+  uint64_t keys_at_defrag_ = 0;
   uint64_t seen_upper_ = 0;
 
   int model_;

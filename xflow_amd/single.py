@@ -31,6 +31,12 @@ class SingleGpuTrainer:
             return capi.lr_predict(self.w, batch, self.ws)
         return capi.fm_predict(self.w, self.v, batch, self.ws)
 
+    def defrag(self):
+        """renumber state rows in key order (call when the key set has settled)"""
+        self.w.defrag()
+        if self.v is not None:
+            self.v.defrag()
+
     def check(self):
         self.w.check()
         if self.v is not None:
