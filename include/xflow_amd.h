@@ -281,6 +281,11 @@ int XFSetParam(void *h, const char *name, const char *value);
 /* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
  * examples_per_sec, keys */
 int XFGetMetric(void *h, const char *name, double *value);
+/* model file (the reference never saves its model): key-sorted (key, w, n, z) dumps of the
+ * worker's tables; XFPredict scores the test file with the current tables, no training */
+int XFSaveModel(void *h, const char *path);
+int XFLoadModel(void *h, const char *path);
+int XFPredict(void *h);
 /* the worker's tables, for export/checkpoint (NULL v for LR) */
 int XFGetTables(void *h, xf_table **w, xf_table **v);
 

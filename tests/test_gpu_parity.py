@@ -745,3 +745,23 @@ def test_giant_heavy_keys_chunked_reduction(model):
         for tt, ss in pairs:
             for a, e in zip(tt.export(), ss.export()):
                 same(a, e)
+
+
+def test_model_file_roundtrip(sample_prefixes, tmp_path):
+    """XFSaveModel / XFLoadModel / XFPredict: a worker that loads the file scores the test set
+    exactly like the worker that trained it (the reference has no model file)."""
+    tr, te = sample_prefixes
+    for model, extra in ((0, {}), (1, {"optimizer": "sgd", "k": 10})):
+        a = capi.XFlow(tr, te, model=model, epochs=3, capacity=4096,
+                       pred_path=str(tmp_path / "pa.txt"), **extra)
+        a.train()
+        a.save(str(tmp_path / "m.bin"))
+        b = capi.XFlow(tr, te, model=model, capacity=64, pred_path=str(tmp_path / "pb.txt"), **extra)
+        b.load(str(tmp_path / "m.bin"))
+        b.predict()
+        for m in ("logloss_ref", "auc", "tp", "fp", "keys"):
+            assert a.metric(m) == b.metric(m), m
+        assert open(str(tmp_path / "pa.txt")).read() == open(str(tmp_path / "pb.txt")).read()
+    with pytest.raises(capi.XFError, match="not an xflow_amd model"):
+        (tmp_path / "junk").write_bytes(b"0123456789abcdef")
+        b.load(str(tmp_path / "junk"))

@@ -119,6 +119,9 @@ SIGNATURES = {
     "XFSetParam": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
     "XFGetMetric": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double)]),
     "XFGetTables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "XFSaveModel": (C.c_int, [vp, C.c_char_p]),
+    "XFLoadModel": (C.c_int, [vp, C.c_char_p]),
+    "XFPredict": (C.c_int, [vp]),
 }
 
 _lib = None
@@ -446,6 +449,16 @@ class XFlow:
     def train(self):
         require_gpu()
         check(lib().XFStartTrain(C.byref(self.h)))
+
+    def save(self, path):
+        check(lib().XFSaveModel(self.h, path.encode()))
+
+    def load(self, path):
+        require_gpu()
+        check(lib().XFLoadModel(self.h, path.encode()))
+
+    def predict(self):
+        check(lib().XFPredict(self.h))
 
     def metric(self, name):
         v = C.c_double(0)

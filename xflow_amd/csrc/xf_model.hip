@@ -493,18 +493,19 @@ k_fm_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_
 // runs come out of LDS.  UPDATE: the lane then applies the optimizer step to its coordinate
 // of the key's v row (the pulled value IS the current weight: nothing touched the row since
 // the Pull) and, for factor 0, to the key's w row.
-template <int OPT, bool UPDATE>
+template <int OPT, bool UPDATE, int K /* compile-time factor count, 0 = use k_rt */>
 __global__ void __launch_bounds__(kBlock)
 k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ tile_ptr,
                 uint32_t ntiles, const uint32_t *__restrict__ segptr,
                 const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
                 const float *__restrict__ vsum, const float *__restrict__ wu,
                 const float *__restrict__ vu, const uint32_t *__restrict__ rows_w,
-                const uint32_t *__restrict__ rows_v, uint32_t R, int k,
+                const uint32_t *__restrict__ rows_v, uint32_t R, int k_rt,
                 float *__restrict__ gw, float *__restrict__ gv) {
 #pragma clang fp contract(off)
   __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
   __shared__ uint32_t sp[XF_TILE_KEYS + 1];
+  const int k = K > 0 ? K : k_rt;  // a constant for the common factor counts: no divisions
   const uint32_t tid = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t ua = tile_ptr[tile], ub = tile_ptr[tile + 1], nk = ub - ua;
@@ -792,11 +793,21 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
              "xf_fm_grad_dev: bad argument");
   if (b->U == 0) return XF_OK;
   if (b->ntiles && b->tile_ptr) {
-    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_SGD, false>), dim3(tile_grid(b->ntiles)),
-                       dim3(kBlock), 0, S(stream), xf::TableDev{}, xf::TableDev{}, b->tile_ptr,
-                       b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, (const float *)nullptr,
-                       d_vu, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b->R, k, d_gw,
-                       d_gv);
+#define XF_FM_GRAD(KK)                                                                       \
+  hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_SGD, false, KK>), dim3(tile_grid(b->ntiles)),    \
+                     dim3(kBlock), 0, S(stream), xf::TableDev{}, xf::TableDev{}, b->tile_ptr, \
+                     b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, (const float *)nullptr, \
+                     d_vu, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b->R, k, d_gw, \
+                     d_gv)
+    switch (k) {
+      case 8: XF_FM_GRAD(8); break;
+      case 10: XF_FM_GRAD(10); break;
+      case 16: XF_FM_GRAD(16); break;
+      case 32: XF_FM_GRAD(32); break;
+      case 64: XF_FM_GRAD(64); break;
+      default: XF_FM_GRAD(0); break;
+    }
+#undef XF_FM_GRAD
   } else {
     const size_t total = (size_t)b->U * k;
     size_t g = (total + kBlock - 1) / kBlock;
@@ -839,14 +850,26 @@ extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_ba
   XF_REQUIRE((TW.nz != nullptr) == ftrl, "xf_fm_grad_update_dev: w and v use different optimizers");
   XF_REQUIRE(b->ntiles && b->tile_ptr, "xf_fm_grad_update_dev: batch has no gradient tiles");
   const dim3 gt(tile_grid(b->ntiles)), blk(kBlock);
-  if (ftrl)
-    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_FTRL, true>), gt, blk, 0, S(stream), TW, TV,
-                       b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu,
-                       d_rows_w, d_rows_v, b->R, k, d_gw, d_gv);
-  else
-    hipLaunchKernelGGL((k_fm_grad_tiled<XF_OPT_SGD, true>), gt, blk, 0, S(stream), TW, TV,
-                       b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu,
-                       d_rows_w, d_rows_v, b->R, k, d_gw, d_gv);
+#define XF_FM_GU(OPTV, KK)                                                                     \
+  hipLaunchKernelGGL((k_fm_grad_tiled<OPTV, true, KK>), gt, blk, 0, S(stream), TW, TV,          \
+                     b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu, \
+                     d_rows_w, d_rows_v, b->R, k, d_gw, d_gv)
+#define XF_FM_GU_K(OPTV)                       \
+  switch (k) {                                 \
+    case 8: XF_FM_GU(OPTV, 8); break;          \
+    case 10: XF_FM_GU(OPTV, 10); break;        \
+    case 16: XF_FM_GU(OPTV, 16); break;        \
+    case 32: XF_FM_GU(OPTV, 32); break;        \
+    case 64: XF_FM_GU(OPTV, 64); break;        \
+    default: XF_FM_GU(OPTV, 0); break;         \
+  }
+  if (ftrl) {
+    XF_FM_GU_K(XF_OPT_FTRL)
+  } else {
+    XF_FM_GU_K(XF_OPT_SGD)
+  }
+#undef XF_FM_GU_K
+#undef XF_FM_GU
   XF_HIP(hipGetLastError());
   if (b->H) {
     if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {

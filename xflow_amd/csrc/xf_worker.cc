@@ -358,6 +358,88 @@ extern "C" int XFGetMetric(void *h, const char *name, double *value) {
   return reinterpret_cast<xflow_amd::Worker *>(h)->get_metric(name, value);
 }
 
+// ---- model file: the tables' (key, w, n, z) dumps, sorted by key -------------------------
+// (the reference never saves its model; this is the export/import hook with a
+// file format around it)
+namespace {
+const char kMagic[8] = {'X', 'F', 'A', 'M', 'D', '0', '0', '1'};
+
+int save_table(FILE *f, xf_table *t, int dim) {
+  size_t n = 0;
+  XF_TRY(xf_table_export(t, nullptr, nullptr, nullptr, nullptr, 0, &n));
+  std::vector<uint64_t> keys(n);
+  std::vector<float> w(n * dim), nn(n * dim), z(n * dim);
+  if (n) XF_TRY(xf_table_export(t, keys.data(), w.data(), nn.data(), z.data(), n, &n));
+  const uint64_t hdr[2] = {(uint64_t)n, (uint64_t)dim};
+  if (fwrite(hdr, 8, 2, f) != 2 || fwrite(keys.data(), 8, n, f) != n ||
+      fwrite(w.data(), 4, n * dim, f) != n * dim || fwrite(nn.data(), 4, n * dim, f) != n * dim ||
+      fwrite(z.data(), 4, n * dim, f) != n * dim)
+    return xf::set_error(XF_EIO, "XFSaveModel: short write");
+  return XF_OK;
+}
+
+int load_table(FILE *f, xf_table *t, int dim) {
+  uint64_t hdr[2];
+  if (fread(hdr, 8, 2, f) != 2) return xf::set_error(XF_EIO, "XFLoadModel: truncated file");
+  if ((int)hdr[1] != dim)
+    return xf::set_error(XF_EINVAL, "XFLoadModel: file has dim %llu, table has %d",
+                         (unsigned long long)hdr[1], dim);
+  const size_t n = (size_t)hdr[0];
+  std::vector<uint64_t> keys(n);
+  std::vector<float> w(n * dim), nn(n * dim), z(n * dim);
+  if (fread(keys.data(), 8, n, f) != n || fread(w.data(), 4, n * dim, f) != n * dim ||
+      fread(nn.data(), 4, n * dim, f) != n * dim || fread(z.data(), 4, n * dim, f) != n * dim)
+    return xf::set_error(XF_EIO, "XFLoadModel: truncated file");
+  uint64_t cap = 0;
+  XF_TRY(xf_table_capacity(t, &cap));
+  if ((uint64_t)n * 10 > cap * 6) XF_TRY(xf_table_reserve(t, (uint64_t)n * 2 + 1024));
+  return xf_table_import(t, keys.data(), n, w.data(), nn.data(), z.data());
+}
+}  // namespace
+
+extern "C" int XFSaveModel(void *h, const char *path) {
+  XF_REQUIRE(h && path, "XFSaveModel: null argument");
+  xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
+  XF_REQUIRE(wk->table_w(), "XFSaveModel: nothing trained or loaded yet");
+  FILE *f = fopen(path, "wb");
+  if (!f) return xf::set_error(XF_EIO, "XFSaveModel: cannot open %s", path);
+  const uint64_t nt = wk->table_v() ? 2 : 1;
+  int rc = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&nt, 8, 1, f) == 1 ? XF_OK
+                                                                       : xf::set_error(XF_EIO, "XFSaveModel: short write");
+  if (rc == XF_OK) rc = save_table(f, wk->table_w(), 1);
+  if (rc == XF_OK && wk->table_v()) rc = save_table(f, wk->table_v(), wk->v_dim_);
+  fclose(f);
+  return rc;
+}
+
+extern "C" int XFLoadModel(void *h, const char *path) {
+  XF_REQUIRE(h && path, "XFLoadModel: null argument");
+  xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
+  XF_TRY(wk->ensure_tables());
+  FILE *f = fopen(path, "rb");
+  if (!f) return xf::set_error(XF_EIO, "XFLoadModel: cannot open %s", path);
+  char magic[8];
+  uint64_t nt = 0;
+  int rc = XF_OK;
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(&nt, 8, 1, f) != 1)
+    rc = xf::set_error(XF_EINVAL, "XFLoadModel: %s is not an xflow_amd model file", path);
+  if (rc == XF_OK && nt != (wk->table_v() ? 2u : 1u))
+    rc = xf::set_error(XF_EINVAL, "XFLoadModel: file holds %llu table(s), worker has %d",
+                       (unsigned long long)nt, wk->table_v() ? 2 : 1);
+  if (rc == XF_OK) rc = load_table(f, wk->table_w(), 1);
+  if (rc == XF_OK && wk->table_v()) rc = load_table(f, wk->table_v(), wk->v_dim_);
+  fclose(f);
+  return rc;
+}
+
+// score the test file with the current tables (no training): predict + AUC/logloss
+extern "C" int XFPredict(void *h) {
+  XF_REQUIRE(h, "XFPredict: null handle");
+  xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
+  XF_TRY(wk->ensure_tables());
+  return wk->predict(wk->rank, 0);
+}
+
 extern "C" int XFGetTables(void *h, xf_table **w, xf_table **v) {
   XF_REQUIRE(h, "XFGetTables: null handle");
   xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);

@@ -23,6 +23,7 @@ class Worker {
 
   int set_param(const char *name, const char *value);
   int get_metric(const char *name, double *value);
+  int ensure_tables() { return create_tables(); }
   xf_table *table_w() { return table_w_; }
   xf_table *table_v() { return table_v_; }
 
