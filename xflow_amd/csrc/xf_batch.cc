@@ -153,6 +153,7 @@ extern "C" int xf_tune(const char *name, double value) {
   XF_REQUIRE(name, "xf_tune: null name");
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
+  else if (!strcmp(name, "parse_threads")) xf::set_parse_threads((int)value);
   else
     return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);
   return XF_OK;

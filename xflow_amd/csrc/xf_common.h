@@ -12,6 +12,8 @@
 namespace xf {
 
 int set_error(int code, const char *fmt, ...);
+int parse_threads();
+void set_parse_threads(int n);
 
 #define XF_HIP(expr)                                                                  \
   do {                                                                                \

@@ -17,6 +17,10 @@
 
 namespace xf {
 
+static int g_parse_threads = 64;
+int parse_threads() { return g_parse_threads; }
+void set_parse_threads(int n) { g_parse_threads = n < 1 ? 1 : n; }
+
 static thread_local char g_err[512] = "";
 
 int set_error(int code, const char *fmt, ...) {
@@ -158,6 +162,13 @@ struct Piece {
 
 // One contiguous run of whole lines (load_data_from_disk.cc:126-208).
 void parse_piece(const char *p, const char *end, Piece *out) {
+  // one reservation per piece instead of reallocating under 64 threads' malloc contention:
+  // a token is at least "0:0:0 " (6 bytes), a row at least "0\t0:0:0\n" (8 bytes)
+  const size_t bytes = (size_t)(end - p);
+  out->keys.reserve(bytes / 6 + 16);
+  out->fgid.reserve(bytes / 6 + 16);
+  out->labels.reserve(bytes / 8 + 16);
+  out->rowend.reserve(bytes / 8 + 16);
   while (p < end) {
     if (*p == '\0') {
       out->hit_nul = true;
@@ -249,7 +260,7 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
   const char *p0 = base, *end = base + text;
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
-  if (nt > 64) nt = 64;
+  if (nt > (unsigned)xf::parse_threads()) nt = (unsigned)xf::parse_threads();
   const size_t min_piece = 256 << 10;
   if ((size_t)(end - p0) / min_piece + 1 < nt) nt = (unsigned)((size_t)(end - p0) / min_piece + 1);
   std::vector<const char *> cut(nt + 1, end);
@@ -269,19 +280,46 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
       th.emplace_back(parse_piece, cut[t], cut[t + 1], &pieces[t]);
     for (auto &x : th) x.join();
   }
+  // offsets of every piece in the block's arrays, then a parallel copy
+  std::vector<size_t> key_off(nt + 1, 0), row_off(nt + 1, 0);
+  unsigned used = nt;
   for (unsigned t = 0; t < nt; ++t) {
     Piece &pc = pieces[t];
     if (pc.err) {
-      size_t row = r->labels.size() + pc.labels.size();
+      size_t row = row_off[t] + pc.labels.size();
       return xf::set_error(XF_EPARSE, "%s: %s in row %zu of the block", r->path.c_str(), pc.err,
                            row);
     }
-    const uint64_t base_nnz = r->keys.size();
-    r->keys.insert(r->keys.end(), pc.keys.begin(), pc.keys.end());
-    r->fgid.insert(r->fgid.end(), pc.fgid.begin(), pc.fgid.end());
-    r->labels.insert(r->labels.end(), pc.labels.begin(), pc.labels.end());
-    for (uint64_t e : pc.rowend) r->rowptr.push_back(base_nnz + e);
-    if (pc.hit_nul) break;  // the reference stops at a NUL byte (:126)
+    key_off[t + 1] = key_off[t] + pc.keys.size();
+    row_off[t + 1] = row_off[t] + pc.labels.size();
+    if (pc.hit_nul) {  // the reference stops at a NUL byte (:126)
+      used = t + 1;
+      break;
+    }
+  }
+  const size_t nkeys = key_off[used], nrows = row_off[used];
+  r->keys.resize(nkeys);
+  r->fgid.resize(nkeys);
+  r->labels.resize(nrows);
+  r->rowptr.resize(nrows + 1);
+  r->rowptr[0] = 0;
+  auto place = [&](unsigned t) {
+    Piece &pc = pieces[t];
+    if (!pc.keys.empty()) {
+      memcpy(&r->keys[key_off[t]], pc.keys.data(), pc.keys.size() * sizeof(uint64_t));
+      memcpy(&r->fgid[key_off[t]], pc.fgid.data(), pc.fgid.size() * sizeof(int32_t));
+    }
+    if (!pc.labels.empty())
+      memcpy(&r->labels[row_off[t]], pc.labels.data(), pc.labels.size() * sizeof(int32_t));
+    for (size_t i = 0; i < pc.rowend.size(); ++i)
+      r->rowptr[row_off[t] + i + 1] = key_off[t] + pc.rowend[i];
+  };
+  if (used == 1) {
+    place(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < used; ++t) th.emplace_back(place, t);
+    for (auto &x : th) x.join();
   }
   if (take < r->held) memmove(base, base + take, r->held - take);
   r->held -= take;
