@@ -277,7 +277,8 @@ int XFStartTrain(void **h);
 /* additive (the reference has no equivalents) */
 int XFDestroy(void **h);
 /* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
- *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host) */
+ *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host)
+ *        model_in model_out (model file to load before / save after training) */
 int XFSetParam(void *h, const char *name, const char *value);
 /* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
  * examples_per_sec, keys */

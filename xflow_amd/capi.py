@@ -221,9 +221,12 @@ class Batch:
         self.on_gpu = on_gpu
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().xf_batch_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().xf_batch_free(self.h)
+                self.h = None
+        except Exception:      # interpreter shutdown: the module globals may be gone
+            pass
 
     def host(self):
         uk, rp, ui, sp, cr, hv = u64p(), u32p(), u32p(), u32p(), u32p(), u32p()
@@ -303,9 +306,12 @@ class Table:
         return t
 
     def __del__(self):
-        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
-            lib().xf_table_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
+                lib().xf_table_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def __len__(self):
         n = C.c_uint64(0)
@@ -377,9 +383,12 @@ class Workspace:
         check(lib().xf_workspace_create(C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().xf_workspace_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().xf_workspace_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def fetch(self, U, R):
         wu = np.empty(U, np.float32)
@@ -471,5 +480,8 @@ class XFlow:
         return w, v
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().XFDestroy(C.byref(self.h))
+        try:
+            if getattr(self, "h", None):
+                lib().XFDestroy(C.byref(self.h))
+        except Exception:
+            pass

@@ -259,7 +259,15 @@ int Worker::train() {
   XF_TRY(create_tables());
   std::cout << "my rank is = " << rank << std::endl;
   snprintf(train_data_path, sizeof(train_data_path), "%s-%05d", train_file_path.c_str(), rank);
+  if (!model_in.empty()) {  // resume from a model file (XFLoadModel)
+    void *self = this;
+    XF_TRY(XFLoadModel(self, model_in.c_str()));
+  }
   XF_TRY(batch_training());
+  if (!model_out.empty()) {
+    void *self = this;
+    XF_TRY(XFSaveModel(self, model_out.c_str()));
+  }
   if (rank == 0) {
     std::cout << (model_ == 0 ? "LR AUC: " : "FM AUC: ") << std::endl;
     XF_TRY(predict(rank, 0));
@@ -294,6 +302,8 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "lr") learning_rate = (float)atof(value);
   else if (n == "seed") seed = strtoull(value, nullptr, 10);
   else if (n == "cache_batches") cache_batches = atoi(value);
+  else if (n == "model_in") model_in = value;
+  else if (n == "model_out") model_out = value;
   else if (n == "key_build") {
     if (!strcmp(value, "gpu")) key_build_gpu = true;
     else if (!strcmp(value, "host")) key_build_gpu = false;

@@ -43,6 +43,7 @@ class Worker {
   int cache_batches = 1;
   bool key_build_gpu = true;  // key build of update() on the GPU (xf_batch_compile_gpu)
   std::string pred_path;
+  std::string model_in, model_out;  // load before / save after training (model file)
 
  private:
   int create_tables();
