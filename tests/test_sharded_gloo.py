@@ -140,3 +140,48 @@ def test_split_counts_are_the_ps_lite_ranges():
     edge = np.array([0, (2**64 - 1) // 3 - 1, (2**64 - 1) // 3, 2**64 - 2, 2**64 - 1],
                     dtype=np.uint64)
     assert split_counts(edge, 3).tolist() == [2, 1, 2]
+
+
+# ---- BASELINE configs[0]: LR + FTRL on data/small_train-0000{0,1}, world_size 2, no GPU -------
+def _sample_worker(rank, world, port, train_prefix, epochs, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    from tests._cpu_stages import CpuOracleStages
+    from xflow_amd.sharded import ShardedTrainer
+    st = CpuOracleStages("lr", "ftrl", 0, rank, world)
+    tr = ShardedTrainer(model="lr", optimizer="ftrl", rank=rank, world=world, stages=st)
+    for _ in range(epochs):                       # worker r reads <prefix>-%05d (lr_worker.cc:210)
+        for rowptr, keys, _, labels in O.read_blocks("%s-%05d" % (train_prefix, rank), 2 << 20):
+            tr.step(tr.compile(rowptr, keys, labels))
+    k, w, n, z = st.w.store.export()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), k=k, w=w, n=n, z=z)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config0_sample_data_two_workers(tmp_path, sample_prefixes):
+    """Two workers, two key-range shards, the reference's sample shards (which are identical
+    files): equals one store receiving both workers' pushes in rank order."""
+    from oracle import pyoracle as O
+    tr_prefix, _ = sample_prefixes
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_sample_worker, args=(2, port, tr_prefix, 3, str(tmp_path)), nprocs=2, join=True)
+    s = O.Store(O.OPT_FTRL, 1)
+    for _ in range(3):
+        blocks = [list(O.read_blocks("%s-%05d" % (tr_prefix, r), 2 << 20)) for r in range(2)]
+        for b0, b1 in zip(*blocks):
+            obs = [O.Batch(b[0], b[1], b[3]) for b in (b0, b1)]
+            pulled = [s.pull(ob.ukeys) for ob in obs]
+            grads = [ob.lr_grad(ob.lr_loss(pw)[0]) for ob, pw in zip(obs, pulled)]
+            for ob, g in zip(obs, grads):
+                s.push(ob.ukeys, g)
+    ks, ws, ns, zs = s.export()
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    k = np.concatenate([p["k"] for p in parts])
+    order = np.argsort(k)
+    assert np.array_equal(k[order], ks) and len(ks) == 524        # 524 distinct train fids
+    for f, ref in (("w", ws), ("n", ns), ("z", zs)):
+        assert np.array_equal(np.concatenate([p[f] for p in parts])[order], ref)
