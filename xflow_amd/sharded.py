@@ -193,9 +193,15 @@ class ShardedTrainer:
     """LRWorker/FMWorker::update across `world` ranks with a key-range-sharded table."""
 
     def __init__(self, model="lr", optimizer="ftrl", k=10, capacity=1 << 22, rank=None,
-                 world=None, stages=None, group=None, schedule="sequential", **hyper):
+                 world=None, stages=None, group=None, schedule="sequential", exchange=None,
+                 **hyper):
+        """`exchange(out, src, out_splits, in_splits, group)`: the all-to-all-v primitive;
+        default torch.distributed.all_to_all_single on the device buffers (RCCL on GPUs).
+        Injectable so that tests can run several ranks of the real HIP stages on ONE GPU
+        (RCCL refuses two ranks per device) by staging the exchange through gloo."""
         assert schedule in ("sequential", "stale1")
         self.schedule = schedule
+        self._xchg = exchange
         self._pending = None
         self._retired = None
         self.group = group
@@ -221,7 +227,7 @@ class ShardedTrainer:
         if self._collective:
             dev = b.ukeys.device
             cnt_d, recv_d = cnt.to(dev), recv.to(dev)
-            dist.all_to_all_single(recv_d, cnt_d, group=self.group)
+            self._exchange(recv_d, cnt_d, None, None)
             recv = recv_d.cpu()
         else:
             recv = cnt.clone()
@@ -239,9 +245,14 @@ class ShardedTrainer:
         if not self._collective:
             out.copy_(src)
             return out
-        dist.all_to_all_single(out, src, [c * width for c in out_counts],
-                               [c * width for c in in_counts], group=self.group)
+        self._exchange(out, src, [c * width for c in out_counts], [c * width for c in in_counts])
         return out
+
+    def _exchange(self, out, src, out_splits, in_splits):
+        if self._xchg is not None:
+            self._xchg(out, src, out_splits, in_splits, self.group)
+        else:
+            dist.all_to_all_single(out, src, out_splits, in_splits, group=self.group)
 
     # ---- one minibatch step ----------------------------------------------------------------
     def _resolve(self, table, rkeys, counts):
