@@ -106,6 +106,9 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False):
         "update": U * (4 + (4 + state) * d),                        # slot + g + state RMW
     }
     if model == "lr":
+        # the sharded LR path pulls with the fused resolve+gather kernel (xf_table_pull_dev)
+        per["resolve"] = U * (8 + 8 + 4 + 4 + 4)
+        per["gather"] = 0
         survey = 12 * NNZ + 8 * R + (32 if opt == "ftrl" else 16) * U
     else:
         survey = NNZ * (12 + 4 * k) + 8 * R + (32 if opt == "ftrl" else 16) * U * (1 + k)

@@ -789,6 +789,8 @@ def _two_rank_gpu_worker(rank, world, port, model, optimizer, schedule, steps, o
                         world=world, schedule=schedule, exchange=host_staged)
     for s in range(steps):
         tr.step(tr.compile(*_data(rank, s)))
+        if schedule == "sequential" and s == 1:
+            tr.defrag()              # row renumbering between steps must not change a bit
     tr.check()
     out = {"loss": tr.predict(tr.compile(*_data(rank, 99))).cpu().numpy()}
     tr.check()

@@ -100,6 +100,8 @@ def keybuild():
     rowptr = torch.arange(R + 1, dtype=torch.int32, device="cuda") * nnz
     labels = torch.zeros(R, dtype=torch.int32, device="cuda")
     L = capi.lib()
+    if "--no-pool" in sys.argv:
+        capi.tune("batch_pool_blobs", 0)
     ts = []
     for it in range(6):
         h = capi.vp()

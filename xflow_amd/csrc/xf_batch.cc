@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -149,11 +150,80 @@ static int need_host(const xf_batch *b) {
   return XF_OK;
 }
 
+namespace xf {
+namespace {
+struct Blob {
+  void *p;
+  size_t bytes;
+  int dev;
+};
+std::mutex g_pool_mu;
+std::vector<Blob> g_pool;
+int g_pool_limit = 4;
+}  // namespace
+
+int blob_alloc(void **p, size_t bytes, size_t *got) {
+  int dev = 0;
+  XF_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); ++i) {
+      const Blob &c = g_pool[i];
+      if (c.dev != dev || c.bytes < bytes || c.bytes > bytes + bytes / 4 + (1u << 20)) continue;
+      if (best == g_pool.size() || c.bytes < g_pool[best].bytes) best = i;
+    }
+    if (best != g_pool.size()) {
+      *p = g_pool[best].p;
+      *got = g_pool[best].bytes;
+      g_pool.erase(g_pool.begin() + best);
+      return XF_OK;
+    }
+  }
+  XF_HIP(hipMalloc(p, bytes));
+  *got = bytes;
+  return XF_OK;
+}
+
+void blob_free(void *p, size_t bytes) {
+  if (!p) return;
+  int dev = 0;
+  void *evict = nullptr;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_limit > 0) {
+      if ((int)g_pool.size() >= g_pool_limit) {  // drop the oldest
+        evict = g_pool.front().p;
+        g_pool.erase(g_pool.begin());
+      }
+      g_pool.push_back({p, bytes, dev});
+      p = nullptr;
+    }
+  }
+  if (evict) (void)hipFree(evict);
+  if (p) (void)hipFree(p);
+}
+
+void blob_pool_limit(int blobs) {
+  std::vector<Blob> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_limit = blobs < 0 ? 0 : blobs;
+    while ((int)g_pool.size() > g_pool_limit) {
+      drop.push_back(g_pool.back());
+      g_pool.pop_back();
+    }
+  }
+  for (const Blob &b : drop) (void)hipFree(b.p);
+}
+}  // namespace xf
+
 extern "C" int xf_tune(const char *name, double value) {
   XF_REQUIRE(name, "xf_tune: null name");
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
   else if (!strcmp(name, "parse_threads")) xf::set_parse_threads((int)value);
+  else if (!strcmp(name, "batch_pool_blobs")) xf::blob_pool_limit((int)value);
   else
     return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);
   return XF_OK;
@@ -251,7 +321,11 @@ extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const ui
 
 extern "C" int xf_batch_free(xf_batch *b) {
   if (!b) return XF_OK;
-  if (b->d_blob) hipFree(b->d_blob);
+  if (b->d_blob) {
+    // kernels still running on the batch must finish first (hipFree used to imply that)
+    (void)hipDeviceSynchronize();
+    xf::blob_free(b->d_blob, b->d_blob_bytes);
+  }
   delete b;
   return XF_OK;
 }
@@ -304,7 +378,7 @@ extern "C" int xf_batch_upload(xf_batch *b, void *stream) {
   const size_t o_hscr = o_hch + al(b->H ? ((size_t)b->H + 1) * 4 : 0);
   const size_t total = o_hscr + al(n_hch * (1 + XF_HEAVY_KMAX) * 8) + 256;
   char *d = nullptr;
-  XF_HIP(hipMalloc((void **)&d, total));
+  XF_TRY(xf::blob_alloc((void **)&d, total, &b->d_blob_bytes));
   hipStream_t s = (hipStream_t)stream;
   auto put = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
     if (bytes == 0) return hipSuccess;

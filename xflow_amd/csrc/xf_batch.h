@@ -19,7 +19,17 @@ struct xf_batch {
   std::vector<int32_t> labels;
   bool on_device_only = false;  // built by xf_batch_compile_dev and not downloaded yet
   void *d_blob = nullptr;  // one device allocation holding all arrays
+  size_t d_blob_bytes = 0;
   xf_dev_batch view{};
 };
+
+namespace xf {
+// Device blobs of compiled minibatches are recycled through a small pool: a worker that
+// streams blocks (compile -> step -> free per block) would otherwise pay a hipMalloc and a
+// hipFree of ~200 MB per minibatch, which costs more than the key build itself.
+int blob_alloc(void **p, size_t bytes, size_t *got);
+void blob_free(void *p, size_t bytes);
+void blob_pool_limit(int blobs);  // 0 = no pooling (every free goes back to the driver)
+}  // namespace xf
 
 #endif  // XF_BATCH_H_

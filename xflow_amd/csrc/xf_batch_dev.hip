@@ -429,7 +429,7 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   const size_t o_hscr = o_hch + al(H ? ((size_t)H + 1) * 4 : 0);
   const size_t total = o_hscr + al((size_t)n_hch * (1 + XF_HEAVY_KMAX) * 8) + 256;
   char *d = nullptr;
-  XF_HIP(hipMalloc((void **)&d, total));
+  XF_TRY(xf::blob_alloc((void **)&d, total, &b->d_blob_bytes));
   auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
     if (!bytes) return hipSuccess;
     return hipMemcpyAsync(d + off, src, bytes, hipMemcpyDeviceToDevice, s);

@@ -388,6 +388,15 @@ class ShardedTrainer:
             self._pending = None
         st.sync()
 
+    def defrag(self):
+        """renumber this shard's state rows in key order (table maintenance between steps,
+        once the key set has settled; local to the rank, no exchange).  Applies an outstanding
+        stale1 Push first, because row numbers held by a step in flight would go stale."""
+        self.flush()
+        for t in self.stages.tables():
+            if t is not None and hasattr(t, "defrag"):
+                t.defrag()
+
     def predict(self, b):
         """forward only (calculate_pctr): pulls insert unseen keys, as in the reference."""
         st = self.stages
