@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-defrag", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
+    ap.add_argument("--exp-knob", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
 
@@ -221,6 +222,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    if args.exp_knob:
+        capi.tune("exp_knob", args.exp_knob)
     if args.panel_slice_kb > 0:
         capi.tune("panel_slice_bytes", args.panel_slice_kb * 1024)
     elif args.panel_slice_kb < 0:

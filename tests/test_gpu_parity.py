@@ -249,13 +249,41 @@ def test_defrag_keeps_the_table_and_orders_rows_by_key():
         t.resolve_dev(dk.data_ptr(), len(sk), rows.data_ptr())
         t.check()
         r = rows.cpu().numpy().astype(np.int64)
-        assert sorted(r.tolist()) == list(range(len(sk)))
-        assert np.mean(np.abs(np.diff(r)) <= 8) > 0.99   # key order = row order, almost
+        assert np.array_equal(r, np.arange(len(sk)))     # settled tier: row == rank of the key
         g = rng.randn(len(sk), dim).astype(np.float32)  # and it keeps training correctly
         s = O.Store(opt, dim)
         s.import_(*before)
         t.push(sk, g)
         s.push(sk, g)
+        for a, b in zip(t.export(), s.export()):
+            same(a, b)
+        # keys that arrive after a defrag live in the open-addressing index next to the settled
+        # tier (with the reserved key value and key 0 among them); the next defrag merges them
+        late = np.array([O.hash_str("late%d" % i) for i in range(5000)] + [0, 2**64 - 1],
+                        dtype=np.uint64)
+        for rnd in range(2):
+            mix = np.sort(np.unique(np.concatenate([rng.choice(keys, 4000, replace=False),
+                                                    rng.choice(late, 3000, replace=False),
+                                                    late[-2:]])))
+            g = rng.randn(len(mix), dim).astype(np.float32)
+            same(t.pull(mix), s.pull(mix))
+            t.push(mix, g)
+            s.push(mix, g)
+            for a, b in zip(t.export(), s.export()):
+                same(a, b)
+            assert len(t) == len(s)
+            t.defrag()
+            t.defrag()                                   # second call: nothing new, a no-op
+            for a, b in zip(t.export(), s.export()):
+                same(a, b)
+            allk = s.export()[0]
+            ordinary = allk[allk != np.uint64(2**64 - 1)]
+            dk = torch.from_numpy(ordinary.view(np.int64)).cuda()
+            rows = torch.empty(len(ordinary), dtype=torch.int32, device="cuda")
+            t.resolve_dev(dk.data_ptr(), len(ordinary), rows.data_ptr())
+            t.check()
+            assert np.array_equal(rows.cpu().numpy(), np.arange(len(ordinary)))
+        t.reserve(1 << 18)                               # index rehash leaves the tier alone
         for a, b in zip(t.export(), s.export()):
             same(a, b)
 

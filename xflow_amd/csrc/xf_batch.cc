@@ -218,11 +218,18 @@ void blob_pool_limit(int blobs) {
 }
 }  // namespace xf
 
+namespace xf {
+static int g_exp_knob = 0;
+int exp_knob() { return g_exp_knob; }
+void set_exp_knob(int v) { g_exp_knob = v; }
+}  // namespace xf
+
 extern "C" int xf_tune(const char *name, double value) {
   XF_REQUIRE(name, "xf_tune: null name");
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
   else if (!strcmp(name, "parse_threads")) xf::set_parse_threads((int)value);
+  else if (!strcmp(name, "exp_knob")) xf::set_exp_knob((int)value);
   else if (!strcmp(name, "batch_pool_blobs")) xf::blob_pool_limit((int)value);
   else
     return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);

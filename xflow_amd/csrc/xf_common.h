@@ -14,6 +14,8 @@ namespace xf {
 int set_error(int code, const char *fmt, ...);
 int parse_threads();
 void set_parse_threads(int n);
+int exp_knob();
+void set_exp_knob(int v);
 
 #define XF_HIP(expr)                                                                  \
   do {                                                                                \

@@ -16,6 +16,7 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr unsigned kErrFull = 1u;
 constexpr unsigned kErrForeignKey = 2u;
 constexpr unsigned kErrDupKey = 4u;
+constexpr int kBaseWin = 4;  // settled-tier keys compared per probe round
 
 struct TableStat {
   unsigned long long count;  // state rows handed out == keys stored
@@ -35,6 +36,16 @@ struct TableDev {
   float *w;           // [(max_rows+1)*dim] dense weights, row-major
   float2 *nz;         // [(max_rows+1)*dim] FTRL accumulators {n, z} side by side (FTRL only):
                       // the Push reads and writes them together, one 8-byte access each
+  // settled tier (built by xf_table_defrag): the keys known at the last defrag, sorted and
+  // dense; the key at rank r owns state row r.  Found through a bucket directory over the
+  // same order-preserving map as `home`, so a sorted key list sweeps bkeys[] once, at 8 bytes
+  // per stored key instead of the 24 of the half-empty open-addressing index.  Keys that
+  // arrive later live in keys[]/rows[] until the next defrag.
+  uint64_t nbase;         // keys in the settled tier == rows 0..nbase-1
+  uint64_t ndir;          // directory buckets
+  uint64_t dmult;         // bucket = mulhi64(key - lo, dmult), clamped to ndir-1
+  const uint64_t *bkeys;  // [nbase + kBaseWin] ascending, padded
+  const uint32_t *bdir;   // [ndir+1] bdir[b] = keys in buckets < b
   TableStat *stat;
   int dim, init_kind;
   float init_const;
@@ -62,6 +73,11 @@ __device__ __forceinline__ bool owns(const TableDev &T, uint64_t key) {
 __device__ __forceinline__ uint64_t home_of(const TableDev &T, uint64_t key) {
   const uint64_t h = __umul64hi(key - T.lo, T.mult);
   return h < T.cap ? h : T.cap - 1;
+}
+
+__device__ __forceinline__ uint64_t bucket_of(const TableDev &T, uint64_t key) {
+  const uint64_t h = __umul64hi(key - T.lo, T.dmult);
+  return h < T.ndir ? h : T.ndir - 1;
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser

@@ -188,10 +188,14 @@ k_lr_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
 // the whole tile into LDS with one coalesced read of coo_row[] and one round of gathers, all
 // lanes busy; phase 2 sums each key's (short) run out of LDS in fp64 and, when UPDATE, applies
 // the optimizer step to the key's state row, whose words were requested before the sums.
+// kKeysPerThread keys' state rides in registers across the barrier.  The kernel waits on
+// memory, so what matters is how many tiles a CU keeps in flight: __launch_bounds__(256, 5)
+// holds the allocation at 96 VGPRs = 5 workgroups per CU (124 -> 111 us on the config-2
+// shape); 6+ need spills and 512/1024-thread tiles were slower (131 / 152 us).
 constexpr int kKeysPerThread = XF_TILE_KEYS / kBlock;
 
 template <int OPT, bool UPDATE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 5)
 k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t ntiles,
                 const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_row,
                 const float *__restrict__ loss, const uint32_t *__restrict__ slots,

@@ -28,7 +28,7 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <numeric>
@@ -67,15 +67,19 @@ constexpr int kWin = 4;
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
-          uint32_t *__restrict__ rows_out, float *__restrict__ wu) {
+          uint32_t *__restrict__ rows_out, float *__restrict__ wu,
+          const uint32_t *__restrict__ list, const unsigned long long *__restrict__ list_n) {
+  // with a work list (the keys k_pull_settled did not find): entries list[0 .. *list_n)
+  if (list) n = (size_t)*list_n;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const unsigned lane = threadIdx.x & 63u;
   // wave-uniform trip count: every lane of a wave reaches the ballot below
   for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
-    const size_t i = i0 + lane;
-    const bool active = i < n;
+    const bool active = i0 + lane < n;
+    const size_t i = !active ? 0 : list ? (size_t)list[i0 + lane] : i0 + lane;
     const uint64_t key = active ? keys[i] : 0;
-    bool inserted = false, bad = false;
+    bool inserted = false, bad = false, in_base = false;
+    uint32_t base_row = 0;
     uint64_t pos = T.cap;
     if (active) {
       if (key == xf::kEmptyKey) {  // reserved value lives at the spare position
@@ -85,8 +89,25 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
         atomicOr(&T.stat->err, xf::kErrForeignKey);
         bad = true;
       } else {
-        uint64_t p = xf::home_of(T, key);
         bool done = false;
+        if (T.nbase) {  // settled tier: one directory word pair, then a short dense run
+          const uint64_t bk = xf::bucket_of(T, key);
+          uint32_t s = T.bdir[bk];
+          const uint32_t e = T.bdir[bk + 1];
+          for (; s < e && !done; s += xf::kBaseWin) {
+            uint64_t c[xf::kBaseWin];
+#pragma unroll
+            for (int t = 0; t < xf::kBaseWin; ++t) c[t] = T.bkeys[s + t];
+#pragma unroll
+            for (int t = 0; t < xf::kBaseWin; ++t)
+              if (s + t < e && c[t] == key) {
+                base_row = s + t;
+                done = true;
+              }
+          }
+          in_base = done;
+        }
+        uint64_t p = xf::home_of(T, key);
         for (uint64_t probes = 0; probes < T.cap && !done; probes += kWin) {
           uint64_t idx[kWin], cur[kWin];
 #pragma unroll
@@ -150,7 +171,9 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       }
     }
     if (active) {
-      if (!inserted && !bad) {
+      if (in_base) {
+        row = base_row;  // rank in the settled tier == state row
+      } else if (!inserted && !bad) {
         row = T.rows[pos];
         // The key may have been inserted by another lane of THIS launch (the same key sent by
         // several workers): its row is published right after the insert; the inserter never
@@ -166,6 +189,72 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       }
       rows_out[i] = row;
       if (GATHER) wu[i] = T.w[row];
+    }
+  }
+}
+
+// The steady-state Pull: every key of the list is looked up in the settled tier, kIlp keys per
+// lane so that kIlp independent chains (key -> directory pair -> dense key run -> weight) are
+// in flight per lane.  Read-only on the table.  Keys the
+// tier does not hold (new since the last defrag, the reserved key value, foreign keys) go to
+// a work list that k_resolve finishes with the general insert-on-miss path.
+template <bool GATHER, int ILP, int WIN>
+__global__ void __launch_bounds__(kBlock)
+k_pull_settled(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
+               uint32_t *__restrict__ rows_out, float *__restrict__ wu,
+               uint32_t *__restrict__ miss, unsigned long long *__restrict__ miss_n) {
+  const size_t chunk = (size_t)kBlock * ILP;
+  for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+    uint64_t key[ILP];
+    uint32_t s[ILP], e[ILP], row[ILP];
+    bool act[ILP], hit[ILP];
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      const size_t i = base + (size_t)q * kBlock + threadIdx.x;
+      act[q] = i < n;
+      key[q] = act[q] ? keys[i] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      hit[q] = false;
+      const bool look = act[q] && key[q] != xf::kEmptyKey && xf::owns(T, key[q]);
+      const uint64_t bk = look ? xf::bucket_of(T, key[q]) : 0;
+      s[q] = look ? T.bdir[bk] : 0u;
+      e[q] = look ? T.bdir[bk + 1] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      uint64_t c[WIN];
+#pragma unroll
+      for (int t = 0; t < WIN; ++t) c[t] = T.bkeys[s[q] + t];  // padded: always readable
+#pragma unroll
+      for (int t = 0; t < WIN; ++t)
+        if (s[q] + t < e[q] && c[t] == key[q]) {
+          row[q] = s[q] + t;
+          hit[q] = true;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {  // buckets longer than one window (rare)
+      for (uint32_t p = s[q] + WIN; p < e[q] && !hit[q]; ++p)
+        if (T.bkeys[p] == key[q]) {
+          row[q] = p;
+          hit[q] = true;
+        }
+    }
+    float wv[ILP];
+#pragma unroll
+    for (int q = 0; q < ILP; ++q)
+      if (GATHER && hit[q]) wv[q] = T.w[row[q]];
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      const size_t i = base + (size_t)q * kBlock + threadIdx.x;
+      if (hit[q]) {
+        rows_out[i] = row[q];
+        if (GATHER) wu[i] = wv[q];
+      } else if (act[q]) {
+        miss[atomicAdd(miss_n, 1ull)] = (uint32_t)i;
+      }
     }
   }
 }
@@ -263,7 +352,8 @@ k_scatter_rows(float *__restrict__ dst, int dim, const uint32_t *__restrict__ ro
   }
 }
 
-// export: append every stored key with its row (arbitrary order; host sorts by key)
+// export: append every key of the index (and the spare) with its row, after the settled
+// tier's entries (arbitrary order; the host sorts by key)
 __global__ void __launch_bounds__(kBlock)
 k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
                 uint32_t *__restrict__ out_rows, unsigned long long *__restrict__ counter,
@@ -273,7 +363,7 @@ k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
     const uint64_t key = T.keys[s];
     const bool occ = s < T.cap ? key != xf::kEmptyKey : T.stat->spare_used != 0u;
     if (occ) {
-      const unsigned long long p = atomicAdd(counter, 1ull);
+      const unsigned long long p = T.nbase + atomicAdd(counter, 1ull);
       if (p < out_cap) {
         out_keys[p] = key;
         out_rows[p] = T.rows[s];
@@ -311,40 +401,67 @@ k_rehash(xf::TableDev O, xf::TableDev T) {
   }
 }
 
-// defrag: state rows renumbered in index-position (= key) order
+// ---- defrag: every stored key into the settled tier ----------------------------------------
+// (key, current row) of the keys held by the open-addressing index, appended in any order
+// (the sort that follows fixes the order); the spare position is handled by the host code
 __global__ void __launch_bounds__(kBlock)
-k_occupied_flags(xf::TableDev T, uint32_t *__restrict__ flag) {
+k_list_index(xf::TableDev T, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_rows,
+             unsigned long long *__restrict__ counter, size_t out_cap) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride)
-    flag[s] = (s < T.cap ? T.keys[s] != xf::kEmptyKey : T.stat->spare_used != 0u) &&
-                      T.rows[s] != xf::kNoRow
-                  ? 1u
-                  : 0u;
-}
-
-__global__ void __launch_bounds__(kBlock)
-k_defrag_move(xf::TableDev T, const uint32_t *__restrict__ flag,
-              const uint32_t *__restrict__ newrow, float *__restrict__ w2,
-              float2 *__restrict__ nz2) {
-  // one work item per (position, coordinate); dim is small or a multiple of the wave for FM
-  const size_t total = ((size_t)T.cap + 1) * T.dim;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const size_t s = T.dim == 1 ? e : e / (size_t)T.dim;
-    if (!flag[s]) continue;
-    const size_t j = e - s * (size_t)T.dim;
-    const size_t src = (size_t)T.rows[s] * T.dim + j, dst = (size_t)newrow[s] * T.dim + j;
-    w2[dst] = T.w[src];
-    if (nz2) nz2[dst] = T.nz[src];
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < T.cap; s += stride) {
+    const uint64_t key = T.keys[s];
+    const uint32_t row = T.rows[s];
+    if (key == xf::kEmptyKey || row == xf::kNoRow) continue;
+    const unsigned long long p = atomicAdd(counter, 1ull);
+    if (p < out_cap) {
+      out_keys[p] = key;
+      out_rows[p] = row;
+    }
   }
 }
 
+// the settled tier's own (key, row == rank) pairs
 __global__ void __launch_bounds__(kBlock)
-k_defrag_rows(xf::TableDev T, const uint32_t *__restrict__ flag,
-              const uint32_t *__restrict__ newrow) {
+k_list_base(xf::TableDev T, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_rows) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride)
-    if (flag[s]) T.rows[s] = newrow[s];
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < T.nbase; r += stride) {
+    out_keys[r] = T.bkeys[r];
+    out_rows[r] = (uint32_t)r;
+  }
+}
+
+// new row r <- old row oldrow[r]
+__global__ void __launch_bounds__(kBlock)
+k_move_rows(const float *__restrict__ w, const float2 *__restrict__ nz, int dim,
+            const uint32_t *__restrict__ oldrow, size_t n, size_t dst_first,
+            float *__restrict__ w2, float2 *__restrict__ nz2) {
+  const size_t total = n * (size_t)dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t r = dim == 1 ? e : e / (size_t)dim;
+    const size_t j = e - r * (size_t)dim;
+    const size_t src = (size_t)oldrow[r] * dim + j, dst = (dst_first + r) * dim + j;
+    w2[dst] = w[src];
+    if (nz2) nz2[dst] = nz[src];
+  }
+}
+
+// bucket directory over the sorted keys: dir[b] = number of keys whose bucket is < b.
+// Work item r closes the buckets between key r-1's and key r's (r == n closes the tail).
+__global__ void __launch_bounds__(kBlock)
+k_build_dir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
+            uint32_t *__restrict__ dir) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
+    const uint64_t first = r == 0 ? 0 : xf::bucket_of(T, skeys[r - 1]) + 1;
+    const uint64_t last = r == n ? T.ndir : xf::bucket_of(T, skeys[r]);
+    for (uint64_t b = first; b <= last; ++b) dir[b] = (uint32_t)r;
+  }
+}
+
+__global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
 }  // namespace
@@ -359,6 +476,10 @@ struct xf_table {
   uint32_t *s_rows = nullptr;
   float *s_vals = nullptr;
   size_t s_n = 0, s_vals_n = 0;
+  // work list of the two-stage resolve (keys the settled tier did not hold)
+  uint32_t *miss = nullptr;
+  unsigned long long *miss_n = nullptr;
+  size_t miss_cap = 0;
 };
 
 static void refresh_hyper(xf_table *t) {
@@ -493,8 +614,8 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
-  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat,
-                t->s_keys, t->s_rows, t->s_vals};
+  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
+                (void *)t->T.bdir, t->s_keys, t->s_rows, t->s_vals, t->miss, t->miss_n};
   for (void *p : ps)
     if (p) hipFree(p);
   delete t;
@@ -577,10 +698,12 @@ extern "C" int xf_table_reserve(xf_table *t, uint64_t new_capacity) {
   return XF_OK;
 }
 
-// Renumber the state rows in key order.  Rows are handed out in arrival order (per-wave runs),
-// so after the key set has settled a sorted key list still hops between runs; with rows in
-// index-position order — the index is all but sorted by key — the lanes of a wave touch
-// neighbouring rows and both the Pull's weight gather and the Push's state pass coalesce.
+// Settle the table: every stored key moves into the settled tier — sorted, dense, the key of
+// rank r owning state row r — and the open-addressing index is emptied for the keys still
+// to come.  Rows are handed out in arrival order, so before this a sorted key list hops
+// between runs of rows and pays 24 bytes of half-empty index per stored key to find them;
+// afterwards the lookup sweeps 8 bytes per stored key plus a small directory, and the Pull's
+// weight gather and the Push's state pass walk the state arrays front to back.
 // Row numbers change: call it between steps, never between a resolve and its update.
 extern "C" int xf_table_defrag(xf_table *t) {
   XF_REQUIRE(t, "xf_table_defrag: null table");
@@ -590,41 +713,129 @@ extern "C" int xf_table_defrag(xf_table *t) {
   if (st.err) return xf_table_check(t, nullptr);
   if (st.count == 0) return XF_OK;
   xf::TableDev &T = t->T;
-  const size_t npos = (size_t)T.cap + 1;
+  const size_t spare = st.spare_used ? 1 : 0;
+  const size_t n = (size_t)st.count - spare;  // ordinary keys: settled tier + index
+  const size_t n_idx = n - (size_t)T.nbase;
+  if (n_idx == 0) return XF_OK;                // nothing arrived since the last defrag
   const size_t elems = ((size_t)T.max_rows + 1) * (size_t)T.dim;
-  uint32_t *flag = nullptr, *newrow = nullptr;
+  uint64_t *k_all = nullptr, *k_sorted = nullptr;
+  uint32_t *r_all = nullptr, *r_sorted = nullptr, *dir = nullptr;
+  unsigned long long *d_cnt = nullptr;
   float *w2 = nullptr;
   float2 *nz2 = nullptr;
   void *tmp = nullptr;
-  XF_HIP(hipMalloc((void **)&flag, npos * 4));
-  XF_HIP(hipMalloc((void **)&newrow, npos * 4));
+  XF_HIP(hipMalloc((void **)&k_all, n * 8));
+  XF_HIP(hipMalloc((void **)&r_all, n * 4));
+  XF_HIP(hipMalloc((void **)&k_sorted, (n + xf::kBaseWin) * 8));
+  XF_HIP(hipMalloc((void **)&r_sorted, n * 4));
+  XF_HIP(hipMalloc((void **)&d_cnt, 8));
+  XF_HIP(hipMemset(d_cnt, 0, 8));
+  if (T.nbase)
+    hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all, r_all);
+  hipLaunchKernelGGL(k_list_index, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T,
+                     k_all + T.nbase, r_all + T.nbase, d_cnt, n_idx);
+  XF_HIP(hipGetLastError());
+  unsigned long long listed = 0;
+  XF_HIP(hipMemcpy(&listed, d_cnt, 8, hipMemcpyDeviceToHost));
+  if (listed != n_idx)
+    return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
+                         listed, n_idx);
+  size_t tb = 0;
+  XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
+                                   (hipStream_t)0));
+  XF_HIP(hipMalloc(&tmp, tb ? tb : 1));
+  XF_HIP(rocprim::radix_sort_pairs(tmp, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
+                                   (hipStream_t)0));
+  hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted + n,
+                     (size_t)xf::kBaseWin, xf::kEmptyKey);
+  // state in rank order; the spare key's row, if any, follows the settled tier
   XF_HIP(hipMalloc((void **)&w2, elems * sizeof(float)));
   XF_HIP(hipMemset(w2, 0, elems * sizeof(float)));
   if (T.nz) {
     XF_HIP(hipMalloc((void **)&nz2, elems * sizeof(float2)));
     XF_HIP(hipMemset(nz2, 0, elems * sizeof(float2)));
   }
-  hipLaunchKernelGGL(k_occupied_flags, dim3(grid_for(npos)), dim3(kBlock), 0, 0, T, flag);
-  size_t tb = 0;
-  XF_HIP(rocprim::exclusive_scan(nullptr, tb, flag, newrow, 0u, npos, rocprim::plus<uint32_t>(),
-                                 (hipStream_t)0));
-  XF_HIP(hipMalloc(&tmp, tb ? tb : 1));
-  XF_HIP(rocprim::exclusive_scan(tmp, tb, flag, newrow, 0u, npos, rocprim::plus<uint32_t>(),
-                                 (hipStream_t)0));
-  hipLaunchKernelGGL(k_defrag_move, dim3(grid_for(npos * T.dim)), dim3(kBlock), 0, 0, T, flag,
-                     newrow, w2, nz2);
-  hipLaunchKernelGGL(k_defrag_rows, dim3(grid_for(npos)), dim3(kBlock), 0, 0, T, flag, newrow);
+  hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * T.dim)), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
+                     r_sorted, n, (size_t)0, w2, nz2);
+  if (spare)
+    hipLaunchKernelGGL(k_move_rows, dim3(1), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
+                       T.rows + T.cap, (size_t)1, n, w2, nz2);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipDeviceSynchronize());
+  // empty the index (the spare position keeps its key) and point the spare at its new row
+  hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T.keys, (size_t)T.cap,
+                     xf::kEmptyKey);
+  hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T.rows, (size_t)T.cap,
+                     xf::kNoRow);
+  if (spare)
+    hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(kBlock), 0, 0, T.rows + T.cap, (size_t)1,
+                       (uint32_t)n);
+  // the directory: one key per bucket on average
+  xf::TableDev N = T;
+  N.nbase = n;
+  N.ndir = n + 1;
+  N.dmult = (uint64_t)((((unsigned __int128)N.ndir) << 64) / T.span);
+  XF_HIP(hipMalloc((void **)&dir, (N.ndir + 1) * 4));
+  hipLaunchKernelGGL(k_build_dir, dim3(grid_for(n + 1)), dim3(kBlock), 0, 0, N, k_sorted, n, dir);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
   XF_HIP(hipFree(T.w));
-  T.w = w2;
-  if (T.nz) {
-    XF_HIP(hipFree(T.nz));
-    T.nz = nz2;
-  }
-  XF_HIP(hipFree(flag));
-  XF_HIP(hipFree(newrow));
+  if (T.nz) XF_HIP(hipFree(T.nz));
+  if (T.bkeys) XF_HIP(hipFree((void *)T.bkeys));
+  if (T.bdir) XF_HIP(hipFree((void *)T.bdir));
+  N.w = w2;
+  N.nz = nz2;
+  N.bkeys = k_sorted;
+  N.bdir = dir;
+  T = N;
+  XF_HIP(hipFree(k_all));
+  XF_HIP(hipFree(r_all));
+  XF_HIP(hipFree(r_sorted));
+  XF_HIP(hipFree(d_cnt));
   XF_HIP(hipFree(tmp));
+  return XF_OK;
+}
+
+// key -> row for a device key list (+ the weight payload when GATHER).  With a settled tier:
+// the read-only tier lookup for all keys, then the insert-on-miss kernel over what is left.
+// The work list belongs to the table: one resolve per table at a time.
+// Measured on the config-2 shape (6.3e6 sorted keys against 1e7 settled ones): one key per
+// lane 63 us, two 67, four 75; one key per directory bucket on average 63 us, two 67, four
+// 80 (the 4-byte directory word is cheaper than a longer run of 8-byte keys); the old
+// single-tier index took 95.  At 63 us the kernel moves ~260 MB: HBM-bound.
+constexpr int kIlp = 1;
+
+template <bool GATHER>
+static int launch_resolve(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
+                          float *d_vals, hipStream_t s) {
+  XF_REQUIRE(n < 0xFFFFFFFFull, "resolve: %zu keys in one call", n);
+  if (t->T.nbase == 0) {
+    hipLaunchKernelGGL(k_resolve<GATHER>, dim3(grid_for(n)), dim3(kBlock), 0, s, t->T, d_keys, n,
+                       d_rows, d_vals, (const uint32_t *)nullptr,
+                       (const unsigned long long *)nullptr);
+    XF_HIP(hipGetLastError());
+    return XF_OK;
+  }
+  if (n > t->miss_cap) {
+    XF_HIP(hipStreamSynchronize(s));
+    if (t->miss) XF_HIP(hipFree(t->miss));
+    t->miss = nullptr;
+    t->miss_cap = 0;
+    const size_t want = n + n / 4 + 1024;
+    XF_HIP(hipMalloc((void **)&t->miss, want * 4));
+    t->miss_cap = want;
+  }
+  if (!t->miss_n) XF_HIP(hipMalloc((void **)&t->miss_n, 8));
+  XF_HIP(hipMemsetAsync(t->miss_n, 0, 8, s));
+  const size_t chunk = (size_t)kBlock * kIlp;
+  const size_t blocks = std::min<size_t>((n + chunk - 1) / chunk, 1u << 16);
+  hipLaunchKernelGGL((k_pull_settled<GATHER, kIlp, xf::kBaseWin>), dim3((unsigned)blocks),
+                     dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, d_vals, t->miss, t->miss_n);
+  // few keys miss in the steady state: a small grid, whose waves find the count in memory
+  hipLaunchKernelGGL(k_resolve<GATHER>, dim3(std::min(grid_for(n), 2048)), dim3(kBlock), 0, s,
+                     t->T, d_keys, n, d_rows, d_vals, (const uint32_t *)t->miss,
+                     (const unsigned long long *)t->miss_n);
+  XF_HIP(hipGetLastError());
   return XF_OK;
 }
 
@@ -632,10 +843,7 @@ extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t 
                                     uint32_t *d_rows, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_keys && d_rows)), "xf_table_resolve_dev: null argument");
   if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_resolve<false>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
-                     d_keys, n, d_rows, (float *)nullptr);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
+  return launch_resolve<false>(t, d_keys, n, d_rows, nullptr, S(stream));
 }
 
 // Pull in one pass: resolve + the weight payload, for dim-1 tables.
@@ -644,10 +852,7 @@ extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
   XF_REQUIRE(t && (n == 0 || (d_keys && d_rows && d_vals)), "xf_table_pull_dev: null argument");
   XF_REQUIRE(t->T.dim == 1, "xf_table_pull_dev: dim must be 1 (use resolve + gather)");
   if (n == 0) return XF_OK;
-  hipLaunchKernelGGL(k_resolve<true>, dim3(grid_for(n)), dim3(kBlock), 0, S(stream), t->T,
-                     d_keys, n, d_rows, d_vals);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
+  return launch_resolve<true>(t, d_keys, n, d_rows, d_vals, S(stream));
 }
 
 extern "C" int xf_table_gather_dev(xf_table *t, const uint32_t *d_rows, size_t n,
@@ -723,6 +928,9 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
   XF_HIP(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
   XF_HIP(hipMalloc((void **)&d_vals, nk * dim * sizeof(float)));
   XF_HIP(hipMemset(d_cnt, 0, sizeof(unsigned long long)));
+  if (t->T.nbase)
+    hipLaunchKernelGGL(k_list_base, dim3(grid_for(t->T.nbase)), dim3(kBlock), 0, 0, t->T, d_keys,
+                       d_rows);
   hipLaunchKernelGGL(k_list_occupied, dim3(grid_for((size_t)t->T.cap + 1)), dim3(kBlock), 0, 0,
                      t->T, d_keys, d_rows, d_cnt, (size_t)nk);
   XF_HIP(hipGetLastError());
