@@ -168,6 +168,27 @@ def with_key_build(args, trainer, batches):
                     "the step, per minibatch, raw keys resident in HBM"}
 
 
+def stream_copy_gbs():
+    """Empirical HBM peak of this box: a 1 GiB device-to-device copy (read + write bytes over
+    the time of the copy kernel), best of 5 — SURVEY 8(d) asks for the fraction of both the
+    spec and the measured peak."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    a.zero_()
+    best = 0.0
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def cpu_baseline(args, batches):
     """The oracle (CPU restatement of the reference) timed on this host, one thread, on a
     bounded sample of the same compiled-minibatch step.  The key build (std::sort, a3) is
@@ -334,6 +355,10 @@ def main():
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
+    if world == 1:
+        copy = stream_copy_gbs()
+        out["roofline"]["peak_measured_copy"] = copy
+        out["roofline"]["frac_of_measured_copy"] = achieved / copy if copy > 0 else None
     if world == 1 and not args.force_sharded and args.model == "lr" and args.key_build_steps > 0:
         out["with_key_build"] = with_key_build(args, trainer, batches)
     if args.pmc_calibrate:

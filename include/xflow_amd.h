@@ -56,6 +56,12 @@ uint32_t xf_shard_of(uint64_t key, uint32_t nshards);
  * key = hash of the middle field of fgid:fid:val; val is never read. */
 typedef struct xf_reader xf_reader;
 int xf_reader_open(xf_reader **out, const char *path, size_t cap_bytes);
+/* The same reader over a binarized block cache: when `cache_path` holds the
+ * blocks of this exact file (size, mtime) at this block size, they are served from it and the
+ * text is not touched (*from_cache = 1); otherwise the text is parsed as above and every block
+ * is also written to the cache, which becomes valid once a pass has reached end of file. */
+int xf_reader_open_cached(xf_reader **out, const char *path, size_t cap_bytes,
+                          const char *cache_path, int *from_cache);
 int xf_reader_close(xf_reader *r);
 /* rows_out = 0 at end of file.  Arrays are owned by the reader, valid until next call. */
 int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
@@ -280,7 +286,8 @@ int XFStartTrain(void **h);
 int XFDestroy(void **h);
 /* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
  *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host)
- *        model_in model_out (model file to load before / save after training) */
+ *        model_in model_out (model file to load before / save after training)
+ *        block_cache(0|1) block_cache_dir (binarized block cache of the text files) */
 int XFSetParam(void *h, const char *name, const char *value);
 /* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
  * examples_per_sec, keys */

@@ -285,3 +285,54 @@ def test_tiling_rules_bounds_with_heavy_and_ragged_rows():
             big += 1
         assert e - a <= 2049
     assert big >= 1
+
+
+def test_block_cache_replays_the_parse_bit_for_bit(tmp_path, sample_prefixes):
+    """the binarized block cache.  A first pass parses the text and writes the
+    cache, later passes are served from it and must return exactly the same blocks; the cache
+    is tied to the block size and to the source file (size, mtime), and a pass that stops
+    before end of file leaves none."""
+    import shutil
+    src = str(tmp_path / "train-00000")
+    shutil.copy(sample_prefixes[0] + "-00000", src)
+    cache = str(tmp_path / "train.xfcsr")
+    cap = 6000                                     # several blocks
+    plain = list(capi.read_blocks(src, cap))
+    assert len(plain) > 3
+
+    def same_blocks(got):
+        assert len(got) == len(plain)
+        for a, b in zip(got, plain):
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and np.array_equal(x, y)
+
+    info = {}
+    it = capi.read_blocks(src, cap, cache, info)    # abandoned after one block: no cache file
+    next(it)
+    it.close()
+    assert not info["from_cache"] and not os.path.exists(cache)
+    assert [f for f in os.listdir(str(tmp_path)) if ".tmp." in f] == []
+    same_blocks(list(capi.read_blocks(src, cap, cache, info)))
+    assert not info["from_cache"] and os.path.exists(cache)
+    same_blocks(list(capi.read_blocks(src, cap, cache, info)))
+    assert info["from_cache"]
+    # another block size does not match the cache: parsed again, cache rebuilt for that size
+    other = list(capi.read_blocks(src, 3 * cap, cache, info))
+    assert not info["from_cache"] and len(other) < len(plain)
+    list(capi.read_blocks(src, cap, cache, info))
+    assert not info["from_cache"]                  # (it was overwritten for 3*cap)
+    list(capi.read_blocks(src, cap, cache, info))
+    assert info["from_cache"]
+    # the source changes: stale cache is ignored
+    with open(src, "a") as f:
+        f.write("1\t0:424242:1\n")
+    changed = list(capi.read_blocks(src, cap, cache, info))
+    assert not info["from_cache"]
+    assert sum(len(b[3]) for b in changed) == sum(len(b[3]) for b in plain) + 1
+    # a truncated cache file is reported, not silently shortened
+    list(capi.read_blocks(src, cap, cache, info))
+    assert info["from_cache"]
+    with open(cache, "r+b") as f:
+        f.truncate(os.path.getsize(cache) - 64)
+    with pytest.raises(capi.XFError):
+        list(capi.read_blocks(src, cap, cache, info))

@@ -496,6 +496,31 @@ def test_worker_core_num_slices_and_growth(sample_prefixes, tmp_path):
     assert x.metric("keys") == len(s)
 
 
+def test_worker_block_cache_gives_the_same_run(sample_prefixes, tmp_path):
+    """block_cache=1: the first run parses the text and leaves <file>.xfcsr<cap> files, the
+    second is served from them (train and test files) and must reproduce the run exactly."""
+    tr, te = sample_prefixes
+    cdir = tmp_path / "cache"
+    cdir.mkdir()
+    runs = []
+    for i in range(2):
+        x = capi.XFlow(tr, te, epochs=3, capacity=4096, block_cache=1, block_cache_dir=str(cdir),
+                       pred_path=str(tmp_path / ("p%d.txt" % i)))
+        x.train()
+        wh, _ = x.tables()
+        runs.append((capi.Table.from_handle(wh, 1, capi.OPT_FTRL).export(),
+                     x.metric("logloss_ref"), x.metric("auc"), x.metric("rows_trained")))
+        files = sorted(os.listdir(str(cdir)))
+        assert len(files) == 2 and all(".xfcsr" in f for f in files)
+    for a, b in zip(runs[0][0], runs[1][0]):
+        same(a, b)
+    assert runs[0][1:] == runs[1][1:]
+    assert open(str(tmp_path / "p0.txt")).read() == open(str(tmp_path / "p1.txt")).read()
+    plain = capi.XFlow(tr, te, epochs=3, capacity=4096, pred_path=str(tmp_path / "p2.txt"))
+    plain.train()
+    assert (plain.metric("logloss_ref"), plain.metric("auc")) == runs[0][1:3]
+
+
 # ------------------------------------------------------------ full-size properties (config 2)
 @pytest.fixture(scope="module")
 def big_batch():

@@ -55,6 +55,8 @@ SIGNATURES = {
     "xf_shard_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "xf_hash_decimal_range": (C.c_int, [C.c_uint64, C.c_size_t, u64p]),
     "xf_reader_open": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t]),
+    "xf_reader_open_cached": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_char_p,
+                                        C.POINTER(C.c_int)]),
     "xf_reader_close": (C.c_int, [vp]),
     "xf_reader_next": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                  C.POINTER(u64p), C.POINTER(u64p), C.POINTER(i32p),
@@ -175,11 +177,19 @@ def hash_decimal_range(start, n):
     return out
 
 
-def read_blocks(path, cap_bytes):
-    """Yield (rowptr, keys, fgid, labels) numpy copies per text block."""
+def read_blocks(path, cap_bytes, cache_path=None, info=None):
+    """Yield (rowptr, keys, fgid, labels) numpy copies per text block.  With `cache_path` the
+    blocks come from / go to the binarized block cache; info["from_cache"] says which."""
     L = lib()
     h = vp()
-    check(L.xf_reader_open(C.byref(h), path.encode(), cap_bytes))
+    if cache_path is None:
+        check(L.xf_reader_open(C.byref(h), path.encode(), cap_bytes))
+    else:
+        hit = C.c_int(0)
+        check(L.xf_reader_open_cached(C.byref(h), path.encode(), cap_bytes, cache_path.encode(),
+                                      C.byref(hit)))
+        if info is not None:
+            info["from_cache"] = bool(hit.value)
     try:
         while True:
             rows, nnz = C.c_size_t(0), C.c_size_t(0)

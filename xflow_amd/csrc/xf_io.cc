@@ -6,6 +6,9 @@
 // Host-side by design (north_star keeps the libsvm-format io path on the host); must be
 // bit-exact on keys, labels and on which rows fall in which block.
 #include <errno.h>
+#include <stdio.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -108,7 +111,40 @@ struct xf_reader {
   size_t held = 0;  // bytes at the front of buf not yet parsed (carry + fresh read)
   std::vector<uint64_t> rowptr, keys;
   std::vector<int32_t> fgid, labels;
+  // block cache (xf_reader_open_cached): either replaying `cfp`, or teeing into `tfp`
+  FILE *cfp = nullptr, *tfp = nullptr;
+  std::string cache_path, tmp_path;
+  uint64_t cache_blocks = 0, served = 0, teed = 0;
+  uint64_t src_size = 0, src_mtime_ns = 0;
 };
+
+namespace {
+// The binarized block cache: what xf_reader_next returned for every block of one pass over
+// a text file at one block size, so that later passes skip the text (the
+// reference re-parses every epoch, lr_worker.cc:184).  Blocks are byte-determined, so a
+// cache is only valid for the block size and the exact source file it was made from.
+//   header  : magic[8] "XFCSR001", cap_bytes, src_size, src_mtime_ns, nblocks   (u64 each)
+//   block   : rows, nnz (u64), rowptr[rows+1] u64, keys[nnz] u64, fgid[nnz] i32, labels[rows] i32
+// Written to <cache>.tmp.<pid> and renamed when the pass reached end of file.
+const char kCacheMagic[8] = {'X', 'F', 'C', 'S', 'R', '0', '0', '1'};
+struct CacheHeader {
+  char magic[8];
+  uint64_t cap, src_size, src_mtime_ns, nblocks;
+};
+
+bool source_stamp(const char *path, uint64_t *size, uint64_t *mtime_ns) {
+  struct stat st;
+  if (stat(path, &st) != 0) return false;
+  *size = (uint64_t)st.st_size;
+  *mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+  return true;
+}
+
+template <typename T>
+bool put(FILE *f, const T *p, size_t n) { return n == 0 || fwrite(p, sizeof(T), n, f) == n; }
+template <typename T>
+bool get(FILE *f, T *p, size_t n) { return n == 0 || fread(p, sizeof(T), n, f) == n; }
+}  // namespace
 
 extern "C" int xf_reader_open(xf_reader **out, const char *path, size_t cap_bytes) {
   XF_REQUIRE(out && path, "xf_reader_open: null argument");
@@ -124,11 +160,118 @@ extern "C" int xf_reader_open(xf_reader **out, const char *path, size_t cap_byte
   return XF_OK;
 }
 
+extern "C" int xf_reader_open_cached(xf_reader **out, const char *path, size_t cap_bytes,
+                                     const char *cache_path, int *from_cache) {
+  XF_REQUIRE(out && path && cache_path, "xf_reader_open_cached: null argument");
+  if (from_cache) *from_cache = 0;
+  uint64_t size = 0, mtime = 0;
+  if (!source_stamp(path, &size, &mtime))
+    return xf::set_error(XF_EIO, "open file %s error: %s", path, strerror(errno));
+  if (FILE *c = fopen(cache_path, "rb")) {
+    CacheHeader h;
+    if (fread(&h, sizeof(h), 1, c) == 1 && !memcmp(h.magic, kCacheMagic, 8) &&
+        h.cap == (uint64_t)cap_bytes && h.src_size == size && h.src_mtime_ns == mtime) {
+      xf_reader *r = new xf_reader;
+      r->path = path;
+      r->cap = cap_bytes;
+      r->cfp = c;
+      r->cache_path = cache_path;
+      r->cache_blocks = h.nblocks;
+      if (from_cache) *from_cache = 1;
+      *out = r;
+      return XF_OK;
+    }
+    fclose(c);  // stale or foreign: rebuilt below
+  }
+  XF_TRY(xf_reader_open(out, path, cap_bytes));
+  xf_reader *r = *out;
+  r->cache_path = cache_path;
+  r->tmp_path = r->cache_path + ".tmp." + std::to_string((long)getpid());
+  r->src_size = size;
+  r->src_mtime_ns = mtime;
+  r->tfp = fopen(r->tmp_path.c_str(), "wb");
+  if (r->tfp) {  // a cache that cannot be written is not an error: the text is still parsed
+    CacheHeader h{};
+    if (fwrite(&h, sizeof(h), 1, r->tfp) != 1) {
+      fclose(r->tfp);
+      r->tfp = nullptr;
+      unlink(r->tmp_path.c_str());
+    }
+  }
+  return XF_OK;
+}
+
+static void abandon_cache(xf_reader *r) {
+  if (r->tfp) {
+    fclose(r->tfp);
+    r->tfp = nullptr;
+    unlink(r->tmp_path.c_str());
+  }
+}
+
 extern "C" int xf_reader_close(xf_reader *r) {
   if (!r) return XF_OK;
+  abandon_cache(r);  // a pass that did not reach end of file leaves no cache
   if (r->fp) fclose(r->fp);
+  if (r->cfp) fclose(r->cfp);
   delete r;
   return XF_OK;
+}
+
+// one block out of the cache file
+static int next_from_cache(xf_reader *r, size_t *rows_out, size_t *nnz_out) {
+  *rows_out = 0;
+  if (nnz_out) *nnz_out = 0;
+  r->rowptr.assign(1, 0);
+  r->keys.clear();
+  r->fgid.clear();
+  r->labels.clear();
+  if (r->served == r->cache_blocks) return XF_OK;
+  uint64_t dims[2];
+  bool ok = get(r->cfp, dims, 2);
+  if (ok) {
+    r->rowptr.resize(dims[0] + 1);
+    r->keys.resize(dims[1]);
+    r->fgid.resize(dims[1]);
+    r->labels.resize(dims[0]);
+    ok = get(r->cfp, r->rowptr.data(), r->rowptr.size()) && get(r->cfp, r->keys.data(), dims[1]) &&
+         get(r->cfp, r->fgid.data(), dims[1]) && get(r->cfp, r->labels.data(), dims[0]);
+  }
+  if (!ok)
+    return xf::set_error(XF_EIO, "%s: truncated block cache (block %llu of %llu)",
+                         r->cache_path.c_str(), (unsigned long long)r->served,
+                         (unsigned long long)r->cache_blocks);
+  ++r->served;
+  *rows_out = dims[0];
+  if (nnz_out) *nnz_out = dims[1];
+  return XF_OK;
+}
+
+// tee the block just parsed; at end of file seal the cache
+static void tee_block(xf_reader *r, size_t rows) {
+  if (!r->tfp) return;
+  bool ok = true;
+  if (rows) {
+    const uint64_t dims[2] = {(uint64_t)rows, (uint64_t)r->keys.size()};
+    ok = put(r->tfp, dims, 2) && put(r->tfp, r->rowptr.data(), r->rowptr.size()) &&
+         put(r->tfp, r->keys.data(), r->keys.size()) && put(r->tfp, r->fgid.data(), r->fgid.size()) &&
+         put(r->tfp, r->labels.data(), r->labels.size());
+    ++r->teed;
+  } else {
+    CacheHeader h;
+    memcpy(h.magic, kCacheMagic, 8);
+    h.cap = r->cap;
+    h.src_size = r->src_size;
+    h.src_mtime_ns = r->src_mtime_ns;
+    h.nblocks = r->teed;
+    ok = fseek(r->tfp, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, r->tfp) == 1;
+    ok = (fclose(r->tfp) == 0) && ok;
+    r->tfp = nullptr;
+    if (ok) ok = rename(r->tmp_path.c_str(), r->cache_path.c_str()) == 0;
+    if (!ok) unlink(r->tmp_path.c_str());
+    return;
+  }
+  if (!ok) abandon_cache(r);
 }
 
 namespace {
@@ -235,6 +378,14 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
                               const uint64_t **rowptr, const uint64_t **keys,
                               const int32_t **fgid, const int32_t **labels) {
   XF_REQUIRE(r && rows_out, "xf_reader_next: null argument");
+  if (r->cfp) {
+    XF_TRY(next_from_cache(r, rows_out, nnz_out));
+    if (rowptr) *rowptr = r->rowptr.data();
+    if (keys) *keys = r->keys.data();
+    if (fgid) *fgid = r->fgid.data();
+    if (labels) *labels = r->labels.data();
+    return XF_OK;
+  }
   r->rowptr.assign(1, 0);
   r->keys.clear();
   r->fgid.clear();
@@ -323,6 +474,7 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
   }
   if (take < r->held) memmove(base, base + take, r->held - take);
   r->held -= take;
+  tee_block(r, r->labels.size());
   *rows_out = r->labels.size();
   if (nnz_out) *nnz_out = r->keys.size();
   if (rowptr) *rowptr = r->rowptr.data();

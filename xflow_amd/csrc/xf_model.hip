@@ -209,10 +209,17 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
     const uint32_t nk = ub - ua;
     const uint32_t j0 = segptr[ua], j1 = segptr[ub];
     if (nk == 1 && j1 - j0 > XF_HEAVY_SEG) continue;  // a heavy key: wave-per-key path
-    for (uint32_t k = tid; k <= nk; k += kBlock) sp[k] = segptr[ua + k] - j0;
-    for (uint32_t j = j0 + tid; j < j1; j += kBlock)
-      vals[j - j0] = loss[coo_row[j]];
-    // state rows of this thread's keys: request them before the barrier
+    // Three rounds of loads, each issued as one batch so that a tile costs three memory round
+    // trips, not one per dependent pointer: (1) the tile's bounds above; (2) everything
+    // addressed by them — occurrence rows, key offsets, state-row numbers, pulled weights;
+    // (3) everything addressed by round 2 — the loss gathers and the {n,z} words.
+    constexpr int kOccPerThread = XF_TILE_NNZ / kBlock;
+    uint32_t orow[kOccPerThread];
+#pragma unroll
+    for (int q = 0; q < kOccPerThread; ++q) {
+      const uint32_t j = j0 + tid + q * kBlock;
+      orow[q] = j < j1 ? coo_row[j] : 0u;
+    }
     uint32_t slot[kKeysPerThread];
     float w[kKeysPerThread], nn[kKeysPerThread], z[kKeysPerThread];
     if (UPDATE) {
@@ -220,12 +227,21 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
       for (int q = 0; q < kKeysPerThread; ++q) {
         const uint32_t k = tid + q * kBlock;
         slot[q] = k < nk ? slots[ua + k] : 0u;
+        if (wu) w[q] = k < nk ? wu[ua + k] : 0.0f;  // the Pull's copy is still current
       }
+    }
+    for (uint32_t k = tid; k <= nk; k += kBlock) sp[k] = segptr[ua + k] - j0;
+#pragma unroll
+    for (int q = 0; q < kOccPerThread; ++q) {
+      const uint32_t j = j0 + tid + q * kBlock;
+      if (j < j1) vals[j - j0] = loss[orow[q]];
+    }
+    if (UPDATE) {
 #pragma unroll
       for (int q = 0; q < kKeysPerThread; ++q) {
         const uint32_t k = tid + q * kBlock;
         if (k < nk) {
-          w[q] = wu ? wu[ua + k] : T.w[slot[q]];  // the Pull's copy is still current
+          if (!wu) w[q] = T.w[slot[q]];
           if (OPT == XF_OPT_FTRL) {
             xf::load_nz(T, slot[q], nn[q], z[q]);
           }

@@ -120,6 +120,17 @@ int Worker::update(xf_batch *b) {
   return XF_OK;
 }
 
+int Worker::open_reader(xf_reader **rd, const char *path, size_t cap) {
+  if (!block_cache) return xf_reader_open(rd, path, cap);
+  std::string base = path;
+  if (!block_cache_dir.empty()) {
+    const size_t slash = base.find_last_of('/');
+    base = block_cache_dir + "/" + (slash == std::string::npos ? base : base.substr(slash + 1));
+  }
+  const std::string cpath = base + ".xfcsr" + std::to_string(cap);
+  return xf_reader_open_cached(rd, path, cap, cpath.c_str(), nullptr);
+}
+
 // batch_training (lr_worker.cc:179-205, fm_worker.cc:247-275)
 int Worker::batch_training() {
   {  // init push of key 0 with a zero gradient (lr_worker.cc:180-182, fm_worker.cc:248-252)
@@ -148,7 +159,7 @@ int Worker::batch_training() {
       XF_TRY(xf_table_check(table_w_, nullptr));
     } else {
       xf_reader *rd = nullptr;
-      XF_TRY(xf_reader_open(&rd, train_data_path, (size_t)block_size << 20));
+      XF_TRY(open_reader(&rd, train_data_path, (size_t)block_size << 20));
       while (true) {
         size_t rows = 0, nnz = 0;
         const uint64_t *rowptr, *keys;
@@ -204,7 +215,7 @@ int Worker::predict(int rank, int block) {
   // 4 MiB blocks for LR (lr_worker.cc:80), 2 MiB for FM (fm_worker.cc:106)
   const size_t cap = model_ == 0 ? ((size_t)4 << 20) : ((size_t)2 << 20);
   xf_reader *rd = nullptr;
-  XF_TRY(xf_reader_open(&rd, test_data_path, cap));
+  XF_TRY(open_reader(&rd, test_data_path, cap));
   std::vector<int32_t> all_labels;
   std::vector<float> all_pctr, pctr;
   while (true) {
@@ -302,6 +313,8 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "lr") learning_rate = (float)atof(value);
   else if (n == "seed") seed = strtoull(value, nullptr, 10);
   else if (n == "cache_batches") cache_batches = atoi(value);
+  else if (n == "block_cache") block_cache = atoi(value);
+  else if (n == "block_cache_dir") block_cache_dir = value;
   else if (n == "model_in") model_in = value;
   else if (n == "model_out") model_out = value;
   else if (n == "key_build") {

@@ -44,6 +44,11 @@ class Worker {
   bool key_build_gpu = true;  // key build of update() on the GPU (xf_batch_compile_gpu)
   std::string pred_path;
   std::string model_in, model_out;  // load before / save after training (model file)
+  // binarized block cache of the text files (xf_reader_open_cached): 0 = off; the cache
+  // files go next to the data (<file>.xfcsr<cap>) or into block_cache_dir
+  int block_cache = 0;
+  std::string block_cache_dir;
+  int open_reader(xf_reader **rd, const char *path, size_t cap);
 
  private:
   int create_tables();
