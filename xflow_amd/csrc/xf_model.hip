@@ -98,7 +98,8 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
   const uint32_t tid = threadIdx.x;
   {
     uint32_t q = blockIdx.x >> 3, tile = 0xFFFFFFFFu;
-    for (uint32_t p = blockIdx.x & 7u; p < P; p += 8) {  // uniform, <= P/8 iterations
+    const uint32_t Pn = P & 0x3FFFFFFFu;
+    for (uint32_t p = blockIdx.x & 7u; p < Pn; p += 8) {  // uniform, <= P/8 iterations
       const uint32_t first = panel_first[p], cnt = panel_first[p + 1] - first;
       if (q < cnt) {
         tile = first + q;
@@ -107,7 +108,12 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
       q -= cnt;
     }
     if (tile == 0xFFFFFFFFu) return;
-    const uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1], ns = sb - sa;
+    uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1];
+    if (P & 0x40000000u) {  // EXPERIMENT: two extra dependent round trips
+      sa = tile_ptr[tile + (sa >> 31)];
+      sb = tile_ptr[tile + 1 + (sa >> 31)];
+    }
+    const uint32_t ns = sb - sa;
     const uint32_t p = sa / (R + 1), r0 = sa - p * (R + 1);
     const uint32_t j0 = pptr[sa], j1 = pptr[sb];
     if (j1 - j0 > XF_TILE_NNZ) {  // one oversized cell (a row with > XF_TILE_NNZ nonzeros)
@@ -679,8 +685,9 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   const double avg = (double)b->NNZ / b->R;
   if (b->P >= 8 && b->fwd_grid && b->fwd_tile_ptr && b->fwd_panel_first && b->fwd_scratch) {
     hipLaunchKernelGGL(k_lr_forward_tiled, dim3(b->fwd_grid), dim3(kBlock), 0, S(stream),
-                       b->fwd_tile_ptr, b->fwd_panel_first, b->P, b->pptr, b->pidx, d_wu, b->R,
-                       b->fwd_scratch);
+                       b->fwd_tile_ptr, b->fwd_panel_first,
+                       b->P | (xf::exp_knob() == 77 ? 0x40000000u : 0u), b->pptr, b->pidx, d_wu,
+                       b->R, b->fwd_scratch);
     XF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
