@@ -98,8 +98,7 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
   const uint32_t tid = threadIdx.x;
   {
     uint32_t q = blockIdx.x >> 3, tile = 0xFFFFFFFFu;
-    const uint32_t Pn = P & 0x3FFFFFFFu;
-    for (uint32_t p = blockIdx.x & 7u; p < Pn; p += 8) {  // uniform, <= P/8 iterations
+    for (uint32_t p = blockIdx.x & 7u; p < P; p += 8) {  // uniform, <= P/8 iterations
       const uint32_t first = panel_first[p], cnt = panel_first[p + 1] - first;
       if (q < cnt) {
         tile = first + q;
@@ -108,12 +107,7 @@ k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
       q -= cnt;
     }
     if (tile == 0xFFFFFFFFu) return;
-    uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1];
-    if (P & 0x40000000u) {  // EXPERIMENT: two extra dependent round trips
-      sa = tile_ptr[tile + (sa >> 31)];
-      sb = tile_ptr[tile + 1 + (sa >> 31)];
-    }
-    const uint32_t ns = sb - sa;
+    const uint32_t sa = tile_ptr[tile], sb = tile_ptr[tile + 1], ns = sb - sa;
     const uint32_t p = sa / (R + 1), r0 = sa - p * (R + 1);
     const uint32_t j0 = pptr[sa], j1 = pptr[sb];
     if (j1 - j0 > XF_TILE_NNZ) {  // one oversized cell (a row with > XF_TILE_NNZ nonzeros)
@@ -328,10 +322,15 @@ k_lr_heavy_finish(xf::TableDev T, const uint32_t *__restrict__ heavy,
                   const uint32_t *__restrict__ hch, uint32_t H,
                   const double *__restrict__ partial, const uint32_t *__restrict__ slots,
                   uint32_t R, float *__restrict__ g_out) {
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= H) return;
+  // one wavefront per heavy key: the head of a power-law batch owns hundreds of chunks, and
+  // one lane adding them one dependent load after the other took 70 us on its own.  Lanes
+  // take the chunks round-robin, then a fixed butterfly: the same association every run.
+  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (h >= H) return;  // wave-uniform
   double acc = 0.0;
-  for (uint32_t c = hch[h]; c < hch[h + 1]; ++c) acc += partial[c];
+  for (uint32_t c = hch[h] + lane; c < hch[h + 1]; c += 64) acc += partial[c];
+  acc = group_sum<64>(acc);
+  if (lane != 0) return;
   const uint32_t u = heavy[h];
   const float g = (float)((double)(float)acc / (1.0 * R));
   g_out[u] = g;
@@ -386,15 +385,20 @@ __global__ void __launch_bounds__(kBlock)
 k_fm_heavy_finish(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
                   uint32_t H, const double *__restrict__ partial, uint32_t R, int k,
                   float *__restrict__ gw, float *__restrict__ gv) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= H * (uint32_t)(k + 1)) return;
-  const uint32_t h = t / (uint32_t)(k + 1), kk = t - h * (uint32_t)(k + 1);
-  double acc = 0.0;
-  for (uint32_t c = hch[h]; c < hch[h + 1]; ++c) acc += partial[(size_t)c * (k + 1) + kk];
-  const uint32_t u = heavy[h];
-  if (kk < (uint32_t)k) gv[(size_t)u * k + kk] = (float)((double)(float)acc / (1.0 * R));
-  else
-    gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
+  // one wavefront per heavy key (see k_lr_heavy_finish), one butterfly per factor
+  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (h >= H) return;  // wave-uniform
+  const uint32_t c0 = hch[h], c1 = hch[h + 1], u = heavy[h];
+  for (uint32_t kk = 0; kk <= (uint32_t)k; ++kk) {
+    double acc = 0.0;
+    for (uint32_t c = c0 + lane; c < c1; c += 64) acc += partial[(size_t)c * (k + 1) + kk];
+    acc = group_sum<64>(acc);
+    if (lane == 0) {
+      if (kk < (uint32_t)k) gv[(size_t)u * k + kk] = (float)((double)(float)acc / (1.0 * R));
+      else
+        gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
+    }
+  }
 }
 
 // the optimizer step for a listed subset of keys (the heavy ones)
@@ -668,6 +672,9 @@ k_fm_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
 // one tile per workgroup, 58 us with five)
 inline int tile_grid(uint32_t ntiles) { return (int)std::min<uint32_t>(ntiles, 1u << 16); }
 
+// blocks for one wavefront per item
+inline unsigned waves_grid(uint32_t n) { return (unsigned)(((size_t)n * 64 + kBlock - 1) / kBlock); }
+
 inline int blocks_for_groups(uint32_t n_items, int items_per_block) {
   size_t g = ((size_t)n_items + items_per_block - 1) / items_per_block;
   if (g > 8192) g = 8192;
@@ -685,9 +692,8 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   const double avg = (double)b->NNZ / b->R;
   if (b->P >= 8 && b->fwd_grid && b->fwd_tile_ptr && b->fwd_panel_first && b->fwd_scratch) {
     hipLaunchKernelGGL(k_lr_forward_tiled, dim3(b->fwd_grid), dim3(kBlock), 0, S(stream),
-                       b->fwd_tile_ptr, b->fwd_panel_first,
-                       b->P | (xf::exp_knob() == 77 ? 0x40000000u : 0u), b->pptr, b->pidx, d_wu,
-                       b->R, b->fwd_scratch);
+                       b->fwd_tile_ptr, b->fwd_panel_first, b->P, b->pptr, b->pidx, d_wu, b->R,
+                       b->fwd_scratch);
     XF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
@@ -725,7 +731,7 @@ extern "C" int xf_lr_grad_dev(const xf_dev_batch *b, const float *d_loss, float 
     hipLaunchKernelGGL(k_lr_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                        b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss,
                        b->heavy_scratch);
-    hipLaunchKernelGGL((k_lr_heavy_finish<XF_OPT_SGD, false>), dim3((b->H + kBlock - 1) / kBlock),
+    hipLaunchKernelGGL((k_lr_heavy_finish<XF_OPT_SGD, false>), dim3(waves_grid(b->H)),
                        dim3(kBlock), 0, S(stream), xf::TableDev{}, b->heavy, b->heavy_chunk_ptr,
                        b->H, b->heavy_scratch, (const uint32_t *)nullptr, b->R, d_g);
     XF_HIP(hipGetLastError());
@@ -764,7 +770,7 @@ extern "C" int xf_lr_grad_update_dev(xf_table *t, const xf_dev_batch *b, const u
   }
   XF_HIP(hipGetLastError());
   if (b->H && b->heavy_chunk_ptr && b->heavy_scratch) {
-    const dim3 gh((b->H + kBlock - 1) / kBlock);
+    const dim3 gh(waves_grid(b->H));  // a wavefront per heavy key
     hipLaunchKernelGGL(k_lr_heavy_partial, dim3(b->n_heavy_chunks), blk, 0, S(stream), b->heavy,
                        b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, b->heavy_scratch);
     if (ftrl)
@@ -848,8 +854,7 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
                          d_vu, k, b->heavy_scratch);
-      hipLaunchKernelGGL(k_fm_heavy_finish,
-                         dim3(((size_t)b->H * (k + 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
+      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(waves_grid(b->H)), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
     } else {
@@ -903,8 +908,7 @@ extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_ba
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
                          d_vu, k, b->heavy_scratch);
-      hipLaunchKernelGGL(k_fm_heavy_finish,
-                         dim3(((size_t)b->H * (k + 1) + kBlock - 1) / kBlock), dim3(kBlock), 0,
+      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(waves_grid(b->H)), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
     } else {

@@ -53,6 +53,21 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 // ---------------------------------------------------------------------------- kernels
 
+// append slot for this lane if `want`: one atomicAdd per wavefront (10^7 lanes bumping one
+// counter one by one took milliseconds).  Every lane of the wave must call it.
+__device__ __forceinline__ unsigned long long wave_append(unsigned long long *counter,
+                                                          bool want) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return 0;
+  const unsigned lane = threadIdx.x & 63u;
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned long long base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+  base = __shfl(base, leader);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+
 // key -> state row with insert-on-miss: `store[key]` of ftrl.h:56 / sgd.h:46, first-touch
 // init of ftrl.h:112-121 / sgd.h:67-72.  One key per lane.  Each probe round reads a window
 // of kWin consecutive index positions with independent loads (one memory round trip instead
@@ -252,9 +267,11 @@ k_pull_settled(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       if (hit[q]) {
         rows_out[i] = row[q];
         if (GATHER) wu[i] = wv[q];
-      } else if (act[q]) {
-        miss[atomicAdd(miss_n, 1ull)] = (uint32_t)i;
       }
+      // (all lanes reach this: the loop bounds are workgroup-uniform)
+      const bool lost = act[q] && !hit[q];
+      const unsigned long long p = wave_append(miss_n, lost);
+      if (lost) miss[p] = (uint32_t)i;
     }
   }
 }
@@ -359,15 +376,15 @@ k_list_occupied(xf::TableDev T, uint64_t *__restrict__ out_keys,
                 uint32_t *__restrict__ out_rows, unsigned long long *__restrict__ counter,
                 size_t out_cap) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s <= T.cap; s += stride) {
-    const uint64_t key = T.keys[s];
-    const bool occ = s < T.cap ? key != xf::kEmptyKey : T.stat->spare_used != 0u;
-    if (occ) {
-      const unsigned long long p = T.nbase + atomicAdd(counter, 1ull);
-      if (p < out_cap) {
-        out_keys[p] = key;
-        out_rows[p] = T.rows[s];
-      }
+  for (size_t s0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); s0 <= T.cap;
+       s0 += stride) {  // wave-uniform trip count
+    const size_t s = s0 + (threadIdx.x & 63u);
+    const uint64_t key = s <= T.cap ? T.keys[s] : xf::kEmptyKey;
+    const bool occ = s < T.cap ? key != xf::kEmptyKey : s == T.cap && T.stat->spare_used != 0u;
+    const unsigned long long p = T.nbase + wave_append(counter, occ);
+    if (occ && p < out_cap) {
+      out_keys[p] = key;
+      out_rows[p] = T.rows[s];
     }
   }
 }
@@ -408,12 +425,14 @@ __global__ void __launch_bounds__(kBlock)
 k_list_index(xf::TableDev T, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_rows,
              unsigned long long *__restrict__ counter, size_t out_cap) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < T.cap; s += stride) {
-    const uint64_t key = T.keys[s];
-    const uint32_t row = T.rows[s];
-    if (key == xf::kEmptyKey || row == xf::kNoRow) continue;
-    const unsigned long long p = atomicAdd(counter, 1ull);
-    if (p < out_cap) {
+  for (size_t s0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); s0 < T.cap;
+       s0 += stride) {  // wave-uniform trip count
+    const size_t s = s0 + (threadIdx.x & 63u);
+    const uint64_t key = s < T.cap ? T.keys[s] : xf::kEmptyKey;
+    const uint32_t row = s < T.cap ? T.rows[s] : xf::kNoRow;
+    const bool occ = key != xf::kEmptyKey && row != xf::kNoRow;
+    const unsigned long long p = wave_append(counter, occ);
+    if (occ && p < out_cap) {
       out_keys[p] = key;
       out_rows[p] = row;
     }
