@@ -91,14 +91,18 @@ __global__ void __launch_bounds__(kBlock)
 k_lr_forward_tiled(const uint32_t *__restrict__ tile_ptr,
                    const uint32_t *__restrict__ panel_first, uint32_t P,
                    const uint32_t *__restrict__ pptr, const uint32_t *__restrict__ pidx,
-                   const float *__restrict__ wu, uint32_t R, double *__restrict__ partial) {
+                   const float *__restrict__ wu, uint32_t R, double *__restrict__ partial,
+                   uint32_t flat_tiles) {
   __shared__ float vals[XF_TILE_NNZ];
   __shared__ uint32_t sp[XF_TILE_KEYS + 2];
   __shared__ double red[kBlock / 64];
   const uint32_t tid = threadIdx.x;
   {
-    uint32_t q = blockIdx.x >> 3, tile = 0xFFFFFFFFu;
-    for (uint32_t p = blockIdx.x & 7u; p < P; p += 8) {  // uniform, <= P/8 iterations
+    // flat_tiles != 0: w_u as a whole fits an XCD's L2, tiles are taken in order by any XCD
+    // (a power-law batch puts a fifth of its nonzeros into one panel: pinning panels to XCDs
+    // would leave the other seven waiting for that one)
+    uint32_t q = blockIdx.x >> 3, tile = flat_tiles ? blockIdx.x : 0xFFFFFFFFu;
+    for (uint32_t p = blockIdx.x & 7u; !flat_tiles && p < P; p += 8) {  // <= P/8 iterations
       const uint32_t first = panel_first[p], cnt = panel_first[p + 1] - first;
       if (q < cnt) {
         tile = first + q;
@@ -672,6 +676,10 @@ k_fm_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
 // one tile per workgroup, 58 us with five)
 inline int tile_grid(uint32_t ntiles) { return (int)std::min<uint32_t>(ntiles, 1u << 16); }
 
+// the forward takes its tiles in plain order when the pulled weights fit one XCD's L2 (4 MiB)
+// next to the index stream
+constexpr size_t kFlatForwardBytes = (size_t)4 << 20;
+
 // blocks for one wavefront per item
 inline unsigned waves_grid(uint32_t n) { return (unsigned)(((size_t)n * 64 + kBlock - 1) / kBlock); }
 
@@ -691,9 +699,13 @@ extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float
   if (b->R == 0) return XF_OK;
   const double avg = (double)b->NNZ / b->R;
   if (b->P >= 8 && b->fwd_grid && b->fwd_tile_ptr && b->fwd_panel_first && b->fwd_scratch) {
-    hipLaunchKernelGGL(k_lr_forward_tiled, dim3(b->fwd_grid), dim3(kBlock), 0, S(stream),
-                       b->fwd_tile_ptr, b->fwd_panel_first, b->P, b->pptr, b->pidx, d_wu, b->R,
-                       b->fwd_scratch);
+    // ... or when pinning would leave XCDs idle: fwd_grid is 8 x the longest per-XCD tile list
+    // (Zipf 1.05: 125 us pinned, 54 us flat; uniform batches are balanced and stay pinned)
+    const bool flat = (size_t)b->U * 4 <= kFlatForwardBytes ||
+                      (double)b->fwd_grid > 1.25 * (double)b->fwd_ntiles;
+    hipLaunchKernelGGL(k_lr_forward_tiled, dim3(flat ? b->fwd_ntiles : b->fwd_grid), dim3(kBlock),
+                       0, S(stream), b->fwd_tile_ptr, b->fwd_panel_first, b->P, b->pptr, b->pidx,
+                       d_wu, b->R, b->fwd_scratch, flat ? b->fwd_ntiles : 0u);
     XF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_lr_finalize, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        S(stream), b->fwd_scratch, b->labels, b->R, b->P, d_loss, d_pctr);
