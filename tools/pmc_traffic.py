@@ -23,7 +23,7 @@ import sys
 CALIB_BYTES = 1 << 30
 # access width (bytes per lane) that dominates each kernel's reads / writes
 WIDTH = {
-    "k_resolve": (8, 4), "k_gather": (4, 4), "k_update": (4, 4), "k_lr_forward": (4, 4),
+    "k_resolve": (8, 4), "k_pull_settled": (8, 4), "k_gather": (4, 4), "k_update": (4, 4), "k_lr_forward": (4, 4),
     "k_lr_forward_panel": (4, 8), "k_lr_forward_tiled": (4, 8), "k_lr_finalize": (8, 4),
     "k_lr_grad": (4, 4), "k_lr_grad_tiled": (4, 4),
     "k_lr_grad_update": (4, 4), "k_lr_grad_heavy": (4, 4), "k_fm_forward": (4, 4),

@@ -86,10 +86,13 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
           const uint32_t *__restrict__ list, const unsigned long long *__restrict__ list_n) {
   // with a work list (the keys k_pull_settled did not find): entries list[0 .. *list_n)
   if (list) n = (size_t)*list_n;
+  __shared__ unsigned int wcount[kBlock / 64];
+  __shared__ unsigned long long wbase;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const unsigned lane = threadIdx.x & 63u;
-  // wave-uniform trip count: every lane of a wave reaches the ballot below
-  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // workgroup-uniform trip count: every thread reaches the barriers of the row hand-out
+  for (size_t b0 = (size_t)blockIdx.x * blockDim.x; b0 < n; b0 += stride) {
+    const size_t i0 = b0 + (threadIdx.x & ~63u);
     const bool active = i0 + lane < n;
     const size_t i = !active ? 0 : list ? (size_t)list[i0 + lane] : i0 + lane;
     const uint64_t key = active ? keys[i] : 0;
@@ -159,14 +162,22 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
         }
       }
     }
-    // hand out state rows: consecutive rows for the wave's new keys, in key order
+    // hand out state rows: consecutive rows for the workgroup's new keys, in key order.  One
+    // atomicAdd per workgroup: same-address atomics serialise (~10 ns each), and one per
+    // wavefront made a batch of 6e6 first-touch keys a 1.25 ms launch.
     uint32_t row = (uint32_t)T.max_rows;  // write-off row
     const unsigned long long m = __ballot(inserted);
+    if (lane == 0) wcount[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned total = 0;
+      for (int w = 0; w < kBlock / 64; ++w) total += wcount[w];
+      wbase = total ? atomicAdd(&T.stat->count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
     if (m) {
-      const int leader = __ffsll((long long)m) - 1;
-      unsigned long long base = 0;
-      if ((int)lane == leader) base = atomicAdd(&T.stat->count, (unsigned long long)__popcll(m));
-      base = __shfl(base, leader);
+      unsigned long long base = wbase;
+      for (unsigned w = 0; w < wave; ++w) base += wcount[w];
       if (inserted) {
         const unsigned long long r = base + __popcll(m & ((1ull << lane) - 1ull));
         if (r < T.max_rows) {
@@ -205,6 +216,7 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
       rows_out[i] = row;
       if (GATHER) wu[i] = T.w[row];
     }
+    __syncthreads();  // wcount / wbase are reused by the next pass
   }
 }
 
@@ -424,18 +436,35 @@ k_rehash(xf::TableDev O, xf::TableDev T) {
 __global__ void __launch_bounds__(kBlock)
 k_list_index(xf::TableDev T, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_rows,
              unsigned long long *__restrict__ counter, size_t out_cap) {
+  // one atomicAdd per workgroup and pass: same-address atomics serialise at ~10 ns each, and
+  // one per wavefront still made this a 3.7 ms kernel for 2e7 index positions
+  __shared__ unsigned int wcount[kBlock / 64];
+  __shared__ unsigned long long wbase;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t s0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); s0 < T.cap;
-       s0 += stride) {  // wave-uniform trip count
-    const size_t s = s0 + (threadIdx.x & 63u);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (size_t s0 = (size_t)blockIdx.x * blockDim.x; s0 < T.cap; s0 += stride) {  // block-uniform
+    const size_t s = s0 + threadIdx.x;
     const uint64_t key = s < T.cap ? T.keys[s] : xf::kEmptyKey;
     const uint32_t row = s < T.cap ? T.rows[s] : xf::kNoRow;
     const bool occ = key != xf::kEmptyKey && row != xf::kNoRow;
-    const unsigned long long p = wave_append(counter, occ);
-    if (occ && p < out_cap) {
-      out_keys[p] = key;
-      out_rows[p] = row;
+    const unsigned long long m = __ballot(occ);
+    if (lane == 0) wcount[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned total = 0;
+      for (int w = 0; w < kBlock / 64; ++w) total += wcount[w];
+      wbase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
     }
+    __syncthreads();
+    if (occ) {
+      unsigned long long p = wbase + __popcll(m & ((1ull << lane) - 1ull));
+      for (unsigned w = 0; w < wave; ++w) p += wcount[w];
+      if (p < out_cap) {
+        out_keys[p] = key;
+        out_rows[p] = row;
+      }
+    }
+    __syncthreads();
   }
 }
 
