@@ -336,3 +336,17 @@ def test_block_cache_replays_the_parse_bit_for_bit(tmp_path, sample_prefixes):
         f.truncate(os.path.getsize(cache) - 64)
     with pytest.raises(capi.XFError):
         list(capi.read_blocks(src, cap, cache, info))
+
+
+def test_binding_demo_builds_against_the_c_abi_only():
+    """examples/kv_demo.cc + examples/ps_gpu.h compile with g++ and nothing but
+    include/xflow_amd.h; without a GPU the program reports the library's error and exits 1."""
+    import subprocess
+    import torch
+    from xflow_amd import build
+    exe = os.path.join(build.LIBDIR, "kv_demo")
+    assert os.path.exists(exe), "python -m xflow_amd.build builds it"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the demo's result is checked in the gpu suite")
+    out = subprocess.run([exe, "8", "1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "no HIP device" in out.stderr

@@ -887,3 +887,26 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, model, optimizer, schedule
             same(np.concatenate([p[nm + f] for p in parts])[order].reshape(ref.shape), ref)
     for r in range(world):
         same(parts[r]["loss"], losses[r])
+
+
+# ------------------------------------------------ the reference-side binding of INTEGRATION.md
+def test_ps_lite_shaped_binding_demo():
+    """examples/ps_gpu.h is the `ps::KVWorker<float>` a maintainer of the reference would put
+    in place of ps/ps.h; examples/kv_demo.cc (built with plain g++ against the C ABI) drives it
+    like LRWorker::update does.  Its printed weights must equal the oracle's store, bit for bit."""
+    import subprocess
+    from xflow_amd import build
+    exe = os.path.join(build.LIBDIR, "kv_demo")
+    n, steps = 5000, 3
+    out = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = [ln.split() for ln in out.stdout.strip().splitlines()]
+    keys = np.sort(np.array([O.hash_str(str(i)) for i in range(n)], dtype=np.uint64))
+    s = O.Store(O.OPT_FTRL, 1)
+    for st in range(steps):
+        s.pull(keys)
+        g = np.array([0.01 * (((i + st) % 7) - 3) for i in range(n)], dtype=np.float32)
+        s.push(keys, g)
+    w = s.pull(keys)
+    assert [int(k) for k, _ in got] == keys.tolist()
+    same(np.array([float.fromhex(v) for _, v in got], dtype=np.float32), w)

@@ -65,6 +65,18 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # the INTEGRATION.md binding (examples/ps_gpu.h) and its driver: a plain host program,
+    # built with g++ against the C ABI only — what a maintainer of the reference would do
+    demo_src = os.path.join(ROOT, "examples", "kv_demo.cc")
+    demo = os.path.join(LIBDIR, "kv_demo")
+    if os.path.exists(demo_src) and (force or _stale(
+            demo, [demo_src, os.path.join(ROOT, "examples", "ps_gpu.h"), LIB])):
+        cmd = ["g++", "-O2", "-std=c++11", "-Wall", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "examples"), demo_src, "-o", demo, "-L" + LIBDIR,
+               "-lxflow_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 
