@@ -51,6 +51,25 @@ inline int grid_for(size_t n) {
 
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
+// a device allocation that is released on every return path unless handed over with take()
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+  T *take() {
+    T *q = p;
+    p = nullptr;
+    return q;
+  }
+  operator T *() const { return p; }
+};
+
 // ---------------------------------------------------------------------------- kernels
 
 // append slot for this lane if `want`: one atomicAdd per wavefront (10^7 lanes bumping one
@@ -766,22 +785,23 @@ extern "C" int xf_table_defrag(xf_table *t) {
   const size_t n_idx = n - (size_t)T.nbase;
   if (n_idx == 0) return XF_OK;                // nothing arrived since the last defrag
   const size_t elems = ((size_t)T.max_rows + 1) * (size_t)T.dim;
-  uint64_t *k_all = nullptr, *k_sorted = nullptr;
-  uint32_t *r_all = nullptr, *r_sorted = nullptr, *dir = nullptr;
-  unsigned long long *d_cnt = nullptr;
-  float *w2 = nullptr;
-  float2 *nz2 = nullptr;
-  void *tmp = nullptr;
-  XF_HIP(hipMalloc((void **)&k_all, n * 8));
-  XF_HIP(hipMalloc((void **)&r_all, n * 4));
-  XF_HIP(hipMalloc((void **)&k_sorted, (n + xf::kBaseWin) * 8));
-  XF_HIP(hipMalloc((void **)&r_sorted, n * 4));
-  XF_HIP(hipMalloc((void **)&d_cnt, 8));
+  DevBuf<uint64_t> k_all, k_sorted;
+  DevBuf<uint32_t> r_all, r_sorted, dir;
+  DevBuf<unsigned long long> d_cnt;
+  DevBuf<float> w2;
+  DevBuf<float2> nz2;
+  DevBuf<char> tmp;
+  XF_HIP(k_all.alloc(n));
+  XF_HIP(r_all.alloc(n));
+  XF_HIP(k_sorted.alloc(n + xf::kBaseWin));
+  XF_HIP(r_sorted.alloc(n));
+  XF_HIP(d_cnt.alloc(1));
   XF_HIP(hipMemset(d_cnt, 0, 8));
   if (T.nbase)
-    hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all, r_all);
+    hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all.p,
+                       r_all.p);
   hipLaunchKernelGGL(k_list_index, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T,
-                     k_all + T.nbase, r_all + T.nbase, d_cnt, n_idx);
+                     k_all.p + T.nbase, r_all.p + T.nbase, d_cnt.p, n_idx);
   XF_HIP(hipGetLastError());
   unsigned long long listed = 0;
   XF_HIP(hipMemcpy(&listed, d_cnt, 8, hipMemcpyDeviceToHost));
@@ -789,28 +809,37 @@ extern "C" int xf_table_defrag(xf_table *t) {
     return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
                          listed, n_idx);
   size_t tb = 0;
-  XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
+  XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n, 0, 64,
                                    (hipStream_t)0));
-  XF_HIP(hipMalloc(&tmp, tb ? tb : 1));
-  XF_HIP(rocprim::radix_sort_pairs(tmp, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
-                                   (hipStream_t)0));
-  hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted + n,
+  XF_HIP(tmp.alloc(tb));
+  XF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n,
+                                   0, 64, (hipStream_t)0));
+  hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted.p + n,
                      (size_t)xf::kBaseWin, xf::kEmptyKey);
   // state in rank order; the spare key's row, if any, follows the settled tier
-  XF_HIP(hipMalloc((void **)&w2, elems * sizeof(float)));
+  XF_HIP(w2.alloc(elems));
   XF_HIP(hipMemset(w2, 0, elems * sizeof(float)));
   if (T.nz) {
-    XF_HIP(hipMalloc((void **)&nz2, elems * sizeof(float2)));
+    XF_HIP(nz2.alloc(elems));
     XF_HIP(hipMemset(nz2, 0, elems * sizeof(float2)));
   }
   hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * T.dim)), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
-                     r_sorted, n, (size_t)0, w2, nz2);
+                     r_sorted.p, n, (size_t)0, w2.p, nz2.p);
   if (spare)
     hipLaunchKernelGGL(k_move_rows, dim3(1), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
-                       T.rows + T.cap, (size_t)1, n, w2, nz2);
+                       T.rows + T.cap, (size_t)1, n, w2.p, nz2.p);
+  // the directory: one key per bucket on average
+  xf::TableDev N = T;
+  N.nbase = n;
+  N.ndir = n + 1;
+  N.dmult = (uint64_t)((((unsigned __int128)N.ndir) << 64) / T.span);
+  XF_HIP(dir.alloc(N.ndir + 1));
+  hipLaunchKernelGGL(k_build_dir, dim3(grid_for(n + 1)), dim3(kBlock), 0, 0, N, k_sorted.p, n,
+                     dir.p);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  // empty the index (the spare position keeps its key) and point the spare at its new row
+  // everything is built: from here on nothing fails half-way.  Empty the index (the spare
+  // position keeps its key), point the spare at its new row, swap the arrays in.
   hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T.keys, (size_t)T.cap,
                      xf::kEmptyKey);
   hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T.rows, (size_t)T.cap,
@@ -818,29 +847,17 @@ extern "C" int xf_table_defrag(xf_table *t) {
   if (spare)
     hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(kBlock), 0, 0, T.rows + T.cap, (size_t)1,
                        (uint32_t)n);
-  // the directory: one key per bucket on average
-  xf::TableDev N = T;
-  N.nbase = n;
-  N.ndir = n + 1;
-  N.dmult = (uint64_t)((((unsigned __int128)N.ndir) << 64) / T.span);
-  XF_HIP(hipMalloc((void **)&dir, (N.ndir + 1) * 4));
-  hipLaunchKernelGGL(k_build_dir, dim3(grid_for(n + 1)), dim3(kBlock), 0, 0, N, k_sorted, n, dir);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  XF_HIP(hipFree(T.w));
-  if (T.nz) XF_HIP(hipFree(T.nz));
-  if (T.bkeys) XF_HIP(hipFree((void *)T.bkeys));
-  if (T.bdir) XF_HIP(hipFree((void *)T.bdir));
-  N.w = w2;
-  N.nz = nz2;
-  N.bkeys = k_sorted;
-  N.bdir = dir;
+  (void)hipFree(T.w);
+  if (T.nz) (void)hipFree(T.nz);
+  if (T.bkeys) (void)hipFree((void *)T.bkeys);
+  if (T.bdir) (void)hipFree((void *)T.bdir);
+  N.w = w2.take();
+  N.nz = T.nz ? nz2.take() : nullptr;
+  N.bkeys = k_sorted.take();
+  N.bdir = dir.take();
   T = N;
-  XF_HIP(hipFree(k_all));
-  XF_HIP(hipFree(r_all));
-  XF_HIP(hipFree(r_sorted));
-  XF_HIP(hipFree(d_cnt));
-  XF_HIP(hipFree(tmp));
   return XF_OK;
 }
 
