@@ -162,12 +162,22 @@ extern "C" long xo_reader_next(xo_reader *r) {
       y = 0;
     r->labels.push_back((int32_t)y);
     const char *t = tab + 1;
+    const size_t row_first = r->keys.size();
+    /* An EMPTY token (two blanks in a row, or a blank right before the block terminator)
+     * makes the reference push its `keyval` again without having parsed anything into it
+     * (:178-196 with pp == qq, :160-177 for the terminator case): the row gets a duplicate of
+     * its previous token.  A blank right before '\n' is not a token at all (:138 ends the
+     * row).  With no previous token in the row the stale value comes from an earlier row or
+     * is uninitialised: rejected. */
     while (t < le) {
       const char *te = (const char *)memchr(t, ' ', (size_t)(le - t));
       if (!te) te = le;
-      if (te == t) { /* empty token: only a trailing blank before '\n' is tolerated */
-        if (te + 1 >= le) break;
-        return -1;
+      if (te == t) {
+        if (r->keys.size() == row_first) return -1;
+        r->keys.push_back(r->keys.back());
+        r->fgid.push_back(r->fgid.back());
+        t = te + 1;
+        continue;
       }
       int32_t fg;
       uint64_t fid;
@@ -175,6 +185,13 @@ extern "C" long xo_reader_next(xo_reader *r) {
       r->keys.push_back(fid);
       r->fgid.push_back(fg);
       t = te + 1;
+    }
+    if (le == end && le > tab + 1 && le[-1] == ' ') { /* blank, then the terminator */
+      if (r->keys.size() == row_first) return -1;
+      r->keys.push_back(r->keys.back());
+      r->fgid.push_back(r->fgid.back());
+    } else if (le == end && le == tab + 1) {
+      return -1; /* a row without tokens at the terminator: the reference pushes a stale token */
     }
     r->rowptr.push_back(r->keys.size());
     p = le + 1;

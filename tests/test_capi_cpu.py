@@ -66,7 +66,11 @@ def test_reader_edges_vs_oracle(tmp_path):
     line = "1\t0:12345:1 1:678:1\n"
     cases = {"nonl": "1\t0:1:1 2:22:0.5\n0\t3:333:1",
              "blank": "0.5\t0:1:1 2:22:0.5 \n0.00000001\t3:333:1\n",
-             "neg": "-1\t0:1:1\n1e-7\t1:2:1\n2e-7\t1:2:1\n", "empty": "", "exact": line * 10}
+             "neg": "-1\t0:1:1\n1e-7\t1:2:1\n2e-7\t1:2:1\n", "empty": "", "exact": line * 10,
+             # empty tokens duplicate the previous token, as in the reference (oracle test)
+             "dblank": "1\t0:1:1  2:2:2 \n0\t3:3:3   4:4:4\n",
+             "blank_eof": "1\t0:1:1 2:22:0.5 \n0\t3:333:1 ",
+             "blank_cut": ("1\t0:12345:1 1:67:1 \n") * 6 + "0\t5:5:5\n"}
     for nm, txt in cases.items():
         p = tmp_path / nm
         p.write_text(txt)
@@ -77,7 +81,7 @@ def test_reader_edges_vs_oracle(tmp_path):
             for a, b in zip(mine, theirs):
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y), (nm, cap)
-    for txt in ["1 0:1:1\n", "1\t0:1\n", "1\t0:1:1  2:2:2\n"]:
+    for txt in ["1 0:1:1\n", "1\t0:1\n", "1\t 0:1:1\n", "1\t0:1:1\n0\t"]:
         p = tmp_path / "bad"
         p.write_text(txt)
         with pytest.raises(capi.XFError):
@@ -350,3 +354,49 @@ def test_binding_demo_builds_against_the_c_abi_only():
         pytest.skip("GPU present: the demo's result is checked in the gpu suite")
     out = subprocess.run([exe, "8", "1"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "no HIP device" in out.stderr
+
+
+def _random_libsvm_text(rng, rows):
+    """label\\tfg:fid:val tokens the way real files look: integer and float labels around the
+    1e-7 threshold, decimal and alphanumeric fids of 1..14 bytes, int/float vals, an occasional
+    trailing blank, the last line with or without newline."""
+    labels = ["0", "1", "0.0", "1.0", "0.5", "1e-7", "1.1e-7", "-1", "3", "0.00000009", "2e-7"]
+    alnum = "0123456789abcdefXYZ_"
+    out = []
+    for _ in range(rows):
+        toks = []
+        for _ in range(rng.randint(1, 12)):
+            n = rng.randint(1, 15)
+            fid = "".join(alnum[i] for i in rng.randint(0, 10 if rng.rand() < 0.7 else len(alnum), n))
+            val = ["1", "0", "0.3651", "12", "1e-3"][rng.randint(0, 5)]
+            toks.append("%d:%s:%s" % (rng.randint(0, 40), fid, val))
+        out.append(labels[rng.randint(0, len(labels))] + "\t" + " ".join(toks) +
+                   (" " if rng.rand() < 0.15 else ""))
+    text = "\n".join(out) + ("\n" if rng.rand() < 0.7 else "")
+    # not generated: a blank before the file's final newline.  The reference is left pointing
+    # at that newline and scans past its terminator for the next tab (:127-128) — undefined.
+    return text[:-2] + "\n" if text.endswith(" \n") else text
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_reader_fuzz_three_way(tmp_path, seed):
+    """Random well-formed files x random block sizes: the product's parser, the oracle's
+    restatement and — when oracle/_ref is built (this container) — the real reference parser
+    must return identical blocks (row partition, keys, fgid, labels)."""
+    rng = np.random.RandomState(100 + seed)
+    txt = _random_libsvm_text(rng, rng.randint(1, 400))
+    p = tmp_path / "f"
+    p.write_text(txt)
+    longest = max(len(l) for l in txt.split("\n")) + 2
+    for cap in sorted({longest + 1, longest + int(rng.randint(1, 200)), 4096, 1 << 20}):
+        mine = list(capi.read_blocks(str(p), cap))
+        theirs = list(O.read_blocks(str(p), cap))
+        sets = [("oracle", theirs)]
+        if O.ref_available():
+            sets.append(("reference", list(O.ref_read_blocks(str(p), cap))))
+        for name, other in sets:
+            assert len(mine) == len(other), (name, cap)
+            for a, b in zip(mine, other):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), (name, cap)
+        assert sum(len(b[3]) for b in mine) == txt.count("\n") + (0 if txt.endswith("\n") else 1)

@@ -74,6 +74,11 @@ def test_parser_edge_cases_vs_live_ref(tmp_path):
     }
     line = "1\t0:12345:1 1:678:1\n"            # 20 bytes
     cases["exact"] = line * 10                  # cap-1 == 40 lands on a newline
+    # empty tokens: the reference pushes its previous token again (two blanks in a row, or a
+    # blank right before the block terminator); a single blank before a newline adds nothing
+    cases["dblank"] = "1\t0:1:1  2:2:2 \n0\t3:3:3   4:4:4\n"
+    cases["blank_eof"] = "1\t0:1:1 2:22:0.5 \n0\t3:333:1 "
+    cases["blank_cut"] = ("1\t0:12345:1 1:67:1 \n") * 6 + "0\t5:5:5\n"   # 20-byte lines ending in a blank
     for nm, txt in cases.items():
         p = tmp_path / nm
         p.write_text(txt)
@@ -87,7 +92,9 @@ def test_parser_edge_cases_vs_live_ref(tmp_path):
 
 
 def test_parser_rejects_malformed(tmp_path):
-    for txt in ["1 0:1:1\n", "1\t0:1\n", "1\t0:1:1  2:2:2\n"]:
+    # no tab, a token without two ':', an empty FIRST token (stale value in the reference), a
+    # row without tokens closed by the block terminator (same)
+    for txt in ["1 0:1:1\n", "1\t0:1\n", "1\t 0:1:1\n", "1\t0:1:1\n0\t"]:
         p = tmp_path / "bad"
         p.write_text(txt)
         with pytest.raises(ValueError):

@@ -304,7 +304,7 @@ struct Piece {
 };
 
 // One contiguous run of whole lines (load_data_from_disk.cc:126-208).
-void parse_piece(const char *p, const char *end, Piece *out) {
+void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
   // one reservation per piece instead of reallocating under 64 threads' malloc contention:
   // a token is at least "0:0:0 " (6 bytes), a row at least "0\t0:0:0\n" (8 bytes)
   const size_t bytes = (size_t)(end - p);
@@ -335,6 +335,12 @@ void parse_piece(const char *p, const char *end, Piece *out) {
     }
     out->labels.push_back(y_tmp > 0.0000001 ? 1 : 0);  // :131-134
     const char *t = tab + 1;
+    const size_t row_first = out->keys.size();
+    // An EMPTY token (two blanks in a row, or a blank right before the block terminator) makes
+    // the reference push its `keyval` again without parsing anything into it (:178-196 with an
+    // empty field, :160-177 at the terminator): the row gets a duplicate of its previous
+    // token.  A single blank before '\n' is not a token (:138 ends the row).  Without a
+    // previous token in the row the value is stale or uninitialised there: rejected here.
     while (t < eol) {
       const char *te = t;
       const char *c1 = nullptr, *c2 = nullptr;
@@ -346,11 +352,16 @@ void parse_piece(const char *p, const char *end, Piece *out) {
         }
         ++te;
       }
-      if (te == t) {               // empty token
-        if (te + 1 >= eol) break;  // a single trailing blank is harmless in the reference
-        out->labels.pop_back();
-        out->err = "empty token";
-        return;
+      if (te == t) {  // empty token
+        if (out->keys.size() == row_first) {
+          out->labels.pop_back();
+          out->err = "empty first token";
+          return;
+        }
+        out->keys.push_back(out->keys.back());
+        out->fgid.push_back(out->fgid.back());
+        t = te + 1;
+        continue;
       }
       if (!c1 || !c2) {  // the reference would scan past the terminator here
         out->labels.pop_back();
@@ -366,6 +377,16 @@ void parse_piece(const char *p, const char *end, Piece *out) {
       out->fgid.push_back((int32_t)fg);
       out->keys.push_back(xf_hash_bytes(c1 + 1, (size_t)(c2 - (c1 + 1))));  // :151
       t = te + 1;
+    }
+    if (eol == end && last_piece) {  // this line is closed by the block terminator, not by '\n'
+      if (eol > tab + 1 && eol[-1] == ' ' && out->keys.size() > row_first) {
+        out->keys.push_back(out->keys.back());
+        out->fgid.push_back(out->fgid.back());
+      } else if (eol == tab + 1 || (eol[-1] == ' ' && out->keys.size() == row_first)) {
+        out->labels.pop_back();
+        out->err = "row without tokens at the end of the block";
+        return;
+      }
     }
     out->rowend.push_back(out->keys.size());
     p = eol + 1;
@@ -424,11 +445,11 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
   }
   std::vector<Piece> pieces(nt);
   if (nt == 1) {
-    parse_piece(cut[0], cut[1], &pieces[0]);
+    parse_piece(cut[0], cut[1], true, &pieces[0]);
   } else {
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t)
-      th.emplace_back(parse_piece, cut[t], cut[t + 1], &pieces[t]);
+      th.emplace_back(parse_piece, cut[t], cut[t + 1], cut[t + 1] == end, &pieces[t]);
     for (auto &x : th) x.join();
   }
   // offsets of every piece in the block's arrays, then a parallel copy
