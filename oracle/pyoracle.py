@@ -311,7 +311,10 @@ def predict(model, wstore, vstore, path, block_bytes=None, core_num=1, cap=1 << 
 def format_auc_line(logloss, auc, tp, fp):
     """The reference's stdout line (base.h:101-108), std::cout default precision 6."""
     def g6(x):
-        return "%g" % float(np.float32(x))
+        x = np.float32(x)
+        if np.isnan(x):  # iostream prints the sign of a NaN (0 * log2(0) is negative here)
+            return "-nan" if np.signbit(x) else "nan"
+        return "%g" % float(x)
     if np.isnan(auc):
         return "logloss: %s\ttp_n = %d" % (g6(logloss), tp)
     return "logloss: %s\tauc = %s\ttp = %d fp = %d" % (g6(logloss), g6(auc), tp, fp)

@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+from ctypes import c_float as C_float
 import pytest
 
 from oracle import pyoracle as O
@@ -400,3 +401,41 @@ def test_reader_fuzz_three_way(tmp_path, seed):
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y), (name, cap)
         assert sum(len(b[3]) for b in mine) == txt.count("\n") + (0 if txt.endswith("\n") else 1)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_auc_logloss_fuzz_three_way(seed):
+    """Random score vectors with many exact ties (rows that only hit unseen keys all score
+    0.5), the sigmoid clamps (1e-6 and exactly 1.0 -> log2(0)), one-class label sets and sizes
+    beyond 2^24 / n where the fp32 `area` accumulator starts rounding: xf_auc_logloss = the
+    oracle = Base::calculate_auc of the real reference (when oracle/_ref is built), including
+    the printed line."""
+    rng = np.random.RandomState(500 + seed)
+    n = int(rng.choice([1, 2, 7, 200, 5000, 60000]))
+    pool = np.concatenate([rng.rand(max(2, n // 20)).astype(np.float32),
+                           np.array([0.5, 0.5, 1e-6, 1.0, 0.999999], dtype=np.float32)])
+    p = pool[rng.randint(0, len(pool), size=n)]
+    lab = rng.randint(0, 2, size=n).astype(np.int32)
+    if seed % 5 == 0:
+        lab[:] = seed % 2                      # one class only: the reference prints tp_n alone
+    if seed % 3 == 0:
+        lab[p == 1.0] = 1                      # keep -inf out of this case
+    ll, auc, tp, fp, _ = capi.auc_logloss(lab, p)
+    oll, oauc, otp, ofp = O.auc_logloss(lab, p)
+    assert (tp, fp) == (otp, ofp)
+    assert np.array_equal(np.float32([ll, auc]), np.float32([oll, oauc]), equal_nan=True)
+    if O.ref_available():
+        rll, line = O.ref_auc(lab, p)
+        assert np.array_equal(np.float32([ll]), np.float32([rll]), equal_nan=True)
+        if tp and fp:
+            assert line == O.format_auc_line(oll, oauc, otp, ofp)
+
+
+def test_sigmoid_fuzz_vs_live_ref():
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.RandomState(9)
+    xs = np.concatenate([rng.uniform(-40, 40, 4000), rng.normal(0, 1e-3, 500),
+                         [-30.0, 30.0, -30.000002, 30.000002, 0.0, -0.0, 88.0, -104.0]])
+    for x in xs.astype(np.float32):
+        assert O.sigmoid(x) == O.ref().ref_sigmoid(C_float(x)), x
