@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root
 from oracle import pyoracle as O  # noqa: E402
 
 REF_DATA = "/root/reference/data"
@@ -59,6 +59,31 @@ def main():
                 keys=np.concatenate([b[1] for b in blocks]),
                 fgid=np.concatenate([b[2] for b in blocks]),
                 labels=np.concatenate([b[3] for b in blocks]))
+    # (5) a synthetic input of our own that holds the parser's less obvious behaviours — empty
+    #     tokens (consecutive blanks, a blank before the block terminator) duplicating the
+    #     previous token, labels around the 1e-7 threshold, alphanumeric fids, float fgids —
+    #     with the real parser's output at several block sizes.  Same generator as the fuzz in
+    #     tests/test_capi_cpu.py, fixed seed.
+    from tests.test_capi_cpu import _random_libsvm_text
+    rng = np.random.RandomState(424242)
+    text = _random_libsvm_text(rng, 120)
+    lines = text.split("\n")
+    lines[3] = lines[3].rstrip(" ") + "  " + lines[4].split("\t")[1].split(" ")[0]  # two blanks
+    lines[10] = "0.5\t3.7:abc:1 4:0:0"                                               # fgid 3.7
+    text = "\n".join(lines)
+    with open(os.path.join(HERE, "quirks-00000"), "w") as f:
+        f.write(text)
+    longest = max(len(l) for l in lines) + 2
+    for cap in (longest + 1, 777, 1 << 20):
+        blocks = list(O.ref_read_blocks(os.path.join(HERE, "quirks-00000"), cap))
+        np.savez_compressed(
+            os.path.join(HERE, "ref_parse_quirks_cap%d.npz" % cap),
+            block_rows=np.array([len(b[3]) for b in blocks], dtype=np.int64),
+            rowptr=np.concatenate([[0]] + [np.diff(b[0]) for b in blocks]).cumsum()
+            .astype(np.uint64),
+            keys=np.concatenate([b[1] for b in blocks]),
+            fgid=np.concatenate([b[2] for b in blocks]),
+            labels=np.concatenate([b[3] for b in blocks]))
     print("golden vectors written to", HERE)
 
 

@@ -439,3 +439,18 @@ def test_sigmoid_fuzz_vs_live_ref():
                          [-30.0, 30.0, -30.000002, 30.000002, 0.0, -0.0, 88.0, -104.0]])
     for x in xs.astype(np.float32):
         assert O.sigmoid(x) == O.ref().ref_sigmoid(C_float(x)), x
+
+
+@pytest.mark.parametrize("cap", [202, 777, 1 << 20])
+def test_reader_quirks_golden(golden_dir, cap):
+    """tests/golden/quirks-00000 (our own synthetic input) against the real parser's output:
+    empty tokens duplicating the previous token — how many depends on where the blocks are cut
+    —, labels around 1e-7, alphanumeric fids, a fractional fgid."""
+    g = np.load(os.path.join(golden_dir, "ref_parse_quirks_cap%d.npz" % cap))
+    blocks = list(capi.read_blocks(os.path.join(golden_dir, "quirks-00000"), cap))
+    assert [len(b[3]) for b in blocks] == g["block_rows"].tolist()
+    assert np.array_equal(np.concatenate([b[1] for b in blocks]), g["keys"])
+    assert np.array_equal(np.concatenate([b[2] for b in blocks]), g["fgid"])
+    assert np.array_equal(np.concatenate([b[3] for b in blocks]), g["labels"])
+    rp = np.concatenate([[0]] + [np.diff(b[0]) for b in blocks]).cumsum()
+    assert np.array_equal(rp.astype(np.uint64), g["rowptr"])

@@ -208,3 +208,18 @@ def test_hashnorm_statistics():
     x = np.array([O.hashnorm(42, k, j) for k in range(4000) for j in range(4)])
     assert abs(x.mean()) < 5e-4 and abs(x.std() - 1e-2) < 3e-4
     assert O.hashnorm(42, 7, 1) == O.hashnorm(42, 7, 1) != O.hashnorm(43, 7, 1)
+
+
+@pytest.mark.parametrize("cap", [202, 777, 1 << 20])
+def test_parser_quirks_golden(golden_dir, cap):
+    """tests/golden/quirks-00000 (our own synthetic input) against the real parser's output:
+    empty tokens duplicating the previous token — how many depends on where the blocks are cut
+    —, labels around 1e-7, alphanumeric fids, a fractional fgid."""
+    g = np.load(os.path.join(golden_dir, "ref_parse_quirks_cap%d.npz" % cap))
+    blocks = list(O.read_blocks(os.path.join(golden_dir, "quirks-00000"), cap))
+    assert [len(b[3]) for b in blocks] == g["block_rows"].tolist()
+    assert np.array_equal(np.concatenate([b[1] for b in blocks]), g["keys"])
+    assert np.array_equal(np.concatenate([b[2] for b in blocks]), g["fgid"])
+    assert np.array_equal(np.concatenate([b[3] for b in blocks]), g["labels"])
+    rp = np.concatenate([[0]] + [np.diff(b[0]) for b in blocks]).cumsum()
+    assert np.array_equal(rp.astype(np.uint64), g["rowptr"])
