@@ -358,6 +358,16 @@ def main():
                      "algorithmic_bytes_per_launch": per[dom],
                      "avg_launch_ms": avg_ms[dom]},
         "kernels_ms": avg_ms, "kernel_timing": kernel_timing,
+        # the same three figures for every kernel of the step (algorithmic GB/s, fraction of
+        # the 8 TB/s spec, PMC traffic per launch where the committed profile has the kernel)
+        "kernels_roofline": {
+            k: {"achieved": per[k] / (avg_ms[k] * 1e-3) / 1e9,
+                "frac": per[k] / (avg_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": per[k],
+                "traffic": pmc_traffic({"resolve": "k_pull_settled", "forward": "k_lr_forward_tiled",
+                                        "gradient": "k_lr_grad_tiled"}.get(k, k), workload)
+                if fused else None}
+            for k in avg_ms if k in per and avg_ms[k] > 0 and per[k] > 0},
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
