@@ -81,18 +81,28 @@ extern "C" uint64_t xf_hash_bytes(const void *ptr, size_t len) {
 // the reference's fids are decimal strings, e.g. data/small_train "2:1163:0.3651")
 extern "C" int xf_hash_decimal_range(uint64_t start, size_t n, uint64_t *out) {
   XF_REQUIRE(out || n == 0, "xf_hash_decimal_range: null output");
-  char buf[24];
-  for (size_t i = 0; i < n; ++i) {
-    uint64_t v = start + i;
-    int len = 0;
-    char tmp[24];
-    do {
-      tmp[len++] = (char)('0' + v % 10);
-      v /= 10;
-    } while (v);
-    for (int j = 0; j < len; ++j) buf[j] = tmp[len - 1 - j];
-    out[i] = xf_hash_bytes(buf, (size_t)len);
+  auto run = [=](size_t lo, size_t hi) {
+    char buf[24], tmp[24];
+    for (size_t i = lo; i < hi; ++i) {
+      uint64_t v = start + i;
+      int len = 0;
+      do {
+        tmp[len++] = (char)('0' + v % 10);
+        v /= 10;
+      } while (v);
+      for (int j = 0; j < len; ++j) buf[j] = tmp[len - 1 - j];
+      out[i] = xf_hash_bytes(buf, (size_t)len);
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;  // several ranks of one node generate their key tables at once
+  if (nt < 2 || n < (1u << 16)) {
+    run(0, n);
+    return XF_OK;
   }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) th.emplace_back(run, n * t / nt, n * (t + 1) / nt);
+  for (auto &x : th) x.join();
   return XF_OK;
 }
 
