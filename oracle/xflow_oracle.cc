@@ -12,11 +12,14 @@
  *
  * PINNING (details in oracle/README.md):
  *   a1/a2/a6/a15 (parser, key hash, sigmoid, AUC/logloss) are checked against the real
- *   reference sources compiled into oracle/_ref (tests/test_oracle_vs_ref.py) and the
- *   committed golden vectors made from them.  a3-a14 (worker math, FTRL/SGD handlers)
+ *   reference sources compiled into oracle/_ref (tests/test_oracle.py, and the three-way
+ *   fuzzes of tests/test_capi_cpu.py) and the committed golden vectors made from them
+ *   (tests/golden/).  a3-a10, a13, a14 (LR worker math, FTRL/SGD handlers, train loop)
  *   cannot be compiled here without a stand-in for the absent ps-lite headers, so they
  *   are pinned only by the end-to-end values SURVEY.md §4/§8c records from the survey's
  *   run of the reference (logloss -0.886206, auc 0.547149, tp 46, fp 154, 525/877 keys).
+ *   a11/a12 (FM loss / gradient) have no reference-side number at all: PARITY UNPINNED
+ *   beyond the line-by-line citation.
  */
 #include "xflow_oracle.h"
 
