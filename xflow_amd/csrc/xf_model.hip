@@ -488,6 +488,104 @@ k_fm_forward(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ u
   }
 }
 
+// ------------------------------------------------ FM forward over per-key scalars (a11)
+// The reference pools its second-order sums over ALL k factors (fm_worker.cc:178-192):
+//   v_sum[row] = sum_k sum_nnz v[u,k],   v_pow_sum[row] = sum_k sum_nnz v[u,k]^2
+// so both are sums over the row's keys of per-key scalars a[u] = sum_k v[u,k] and
+// b[u] = sum_k v[u,k]^2 (fp32 products, as :187).  The v-row gather of the Pull reads every
+// row anyway: it forms (a, b) on the way — exactly, in fp64 — and stores them with the pulled
+// w as one 32-byte record per key.  The per-nonzero pass then gathers 32 bytes per nonzero
+// from a U x 32 B table instead of a k x 4-byte row from U x k x 4 B plus w_u from a third
+// array: at k = 16, 1e7 nonzeros, 383 -> see DESIGN.md 8 (the gather count, not the bytes, is
+// what costs: tools/exp/gather_widths.py).
+struct __attribute__((aligned(32))) FmKey {
+  double a, b;
+  float w;
+  float pad[3];
+};
+
+template <int DIM4>  // floats per factor row / 4; a power of two <= 16
+__global__ void __launch_bounds__(kBlock)
+k_fm_gather_scalars(const float4 *__restrict__ tv, const uint32_t *__restrict__ rows,
+                    const float *__restrict__ wu, size_t n, float4 *__restrict__ vu,
+                    FmKey *__restrict__ ks) {
+#pragma clang fp contract(off)
+  const size_t total = n * DIM4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const unsigned lane = threadIdx.x & 63u;
+  // wave-uniform trip count (the shuffles below need every lane); a key's DIM4 lanes are
+  // consecutive and never straddle a wavefront
+  for (size_t e0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < total;
+       e0 += stride) {
+    const size_t e = e0 + lane;
+    const bool on = e < total;
+    const size_t i = on ? e / DIM4 : 0, j = on ? e % DIM4 : 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+      v = tv[(size_t)rows[i] * DIM4 + j];
+      vu[e] = v;
+    }
+    double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    double b = (double)(v.x * v.x) + (double)(v.y * v.y) + (double)(v.z * v.z) +
+               (double)(v.w * v.w);
+#pragma unroll
+    for (int off = DIM4 / 2; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, DIM4);
+      b += __shfl_xor(b, off, DIM4);
+    }
+    if (on && j == 0) {
+      FmKey q;
+      q.a = a;
+      q.b = b;
+      q.w = wu[i];
+      q.pad[0] = q.pad[1] = q.pad[2] = 0.f;
+      ks[i] = q;
+    }
+  }
+}
+
+// one wavefront per example, one 32-byte record per nonzero, four in flight per lane
+__global__ void __launch_bounds__(kBlock)
+k_fm_forward_scalars(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx,
+                     const FmKey *__restrict__ ks, const int32_t *__restrict__ labels,
+                     uint32_t R, float *__restrict__ loss, float *__restrict__ pctr,
+                     float *__restrict__ vsum_out) {
+#pragma clang fp contract(off)
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nwaves) {
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    double wx = 0.0, vs = 0.0, vp = 0.0;
+    for (uint32_t j0 = b + lane; j0 < e; j0 += 64 * 4) {
+      uint32_t ui[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ui[i] = j0 + 64 * i < e ? uidx[j0 + 64 * i] : 0xFFFFFFFFu;
+      FmKey q[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ui[i] != 0xFFFFFFFFu) q[i] = ks[ui[i]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ui[i] != 0xFFFFFFFFu) {
+          wx += (double)q[i].w;
+          vs += q[i].a;
+          vp += q[i].b;
+        }
+    }
+    wx = group_sum<64>(wx);
+    vs = group_sum<64>(vs);
+    vp = group_sum<64>(vp);
+    if (lane == 0) {
+      const float vsf = (float)vs, vpf = (float)vp;
+      const float vy = vsf * vsf - vpf;                       // :194-195
+      const float p = xf::sigmoid_ref((float)wx + vy);        // :199
+      if (pctr) pctr[r] = p;
+      loss[r] = p - (float)labels[r];
+      vsum_out[r] = vsf;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ FM gradient (a12)
 // fm_worker.cc:126-157: for every factor kk (outer loop) and occurrence:
 //   gw[u]    += loss[sid]                        -> gw is k x the LR gradient (:140)
@@ -964,6 +1062,7 @@ struct xf_workspace {
   uint32_t *slots = nullptr, *slots2 = nullptr;
   float *wu = nullptr, *g = nullptr, *vu = nullptr, *gv = nullptr;
   float *loss = nullptr, *pctr = nullptr, *vsum = nullptr;
+  void *ks = nullptr;  // FM: per-key (a, b, w) records, 32 B each
   size_t capU = 0, capUK = 0, capR = 0;
   uint32_t lastU = 0, lastR = 0;
   // optional per-kernel HIP-event timing (same stream, inside the caller's timed region)
@@ -997,6 +1096,7 @@ static int ws_reserve(xf_workspace *ws, size_t U, size_t UK, size_t R) {
     const size_t m = std::max<size_t>(UK + UK / 8, 1024);
     XF_HIP(grow((void **)&ws->vu, m * 4));
     XF_HIP(grow((void **)&ws->gv, m * 4));
+    XF_HIP(grow(&ws->ks, std::max<size_t>(U + U / 8, 1024) * sizeof(FmKey)));
     ws->capUK = m;
   }
   if (!ws->loss || R > ws->capR) {
@@ -1017,7 +1117,7 @@ extern "C" int xf_workspace_create(xf_workspace **out) {
 
 extern "C" int xf_workspace_destroy(xf_workspace *ws) {
   if (!ws) return XF_OK;
-  void *ps[] = {ws->slots, ws->slots2, ws->wu, ws->g, ws->vu, ws->gv, ws->loss, ws->pctr, ws->vsum};
+  void *ps[] = {ws->slots, ws->slots2, ws->wu, ws->g, ws->vu, ws->gv, ws->loss, ws->pctr, ws->vsum, ws->ks};
   for (void *p : ps)
     if (p) hipFree(p);
   for (auto &e : ws->ev)
@@ -1118,9 +1218,34 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, stream));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, stream));
   XF_END(kEvResolve);
-  XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, stream));
-  XF_END(kEvGather);
-  XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));  // :237
+  const int dim4 = k / 4;
+  const bool scalars = k % 4 == 0 && dim4 <= 16 && (dim4 & (dim4 - 1)) == 0 && v.U && v.R;
+  if (scalars) {  // v-row gather that also forms the per-key scalars of the forward
+    const float4 *tv = (const float4 *)xf::table_dev(vt).w;
+    const size_t tot = (size_t)v.U * dim4;
+    const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
+#define XF_FM_GS(D)                                                                        \
+  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, S(stream), tv, ws->slots2, ws->wu, \
+                     (size_t)v.U, (float4 *)ws->vu, (FmKey *)ws->ks)
+    switch (dim4) {
+      case 1: XF_FM_GS(1); break;
+      case 2: XF_FM_GS(2); break;
+      case 4: XF_FM_GS(4); break;
+      case 8: XF_FM_GS(8); break;
+      default: XF_FM_GS(16); break;
+    }
+#undef XF_FM_GS
+    XF_HIP(hipGetLastError());
+    XF_END(kEvGather);
+    hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), v.rowptr, v.uidx, (const FmKey *)ws->ks,
+                       v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
+    XF_HIP(hipGetLastError());
+  } else {
+    XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, stream));
+    XF_END(kEvGather);
+    XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));
+  }
   XF_END(kEvForward);
   // gradient (:238) and the two Pushes (:241-242) in one pass: both tables are on this GPU
   XF_TRY(fm_grad_update(w, vt, &v, ws->slots, ws->slots2, ws->wu, ws->vu, ws->vsum, ws->loss,
