@@ -454,3 +454,20 @@ def test_reader_quirks_golden(golden_dir, cap):
     assert np.array_equal(np.concatenate([b[3] for b in blocks]), g["labels"])
     rp = np.concatenate([[0]] + [np.diff(b[0]) for b in blocks]).cumsum()
     assert np.array_equal(rp.astype(np.uint64), g["rowptr"])
+
+
+def test_fp32_division_by_row_count_equals_the_reference_double_division():
+    """The FM gradient kernel computes `(float)acc / (float)R` where the reference does
+    `float /= 1.0 * line_num` (double division, rounded back to float; fm_worker.cc:150-156).
+    For fp32 x and integer R < 2^24 the two are the same number (xf_model.hip: div_by_rows);
+    checked here on 2e7 random (x, R) with IEEE arithmetic on the host."""
+    rng = np.random.RandomState(3)
+    for it in range(4):
+        n = 5_000_000
+        m = rng.randint(1, 1 << 24, size=n).astype(np.float32)
+        x = np.ldexp(m, rng.randint(-70, 20, size=n)).astype(np.float32)
+        x *= np.where(rng.rand(n) < 0.5, -1, 1).astype(np.float32)
+        R = rng.randint(1, 1 << 24, size=n) if it % 2 else \
+            rng.choice(np.array([3, 7, 200, 49999, 50000, 65537, (1 << 24) - 1]), size=n)
+        want = (x.astype(np.float64) / R.astype(np.float64)).astype(np.float32)
+        assert np.array_equal(want, x / R.astype(np.float32))

@@ -39,6 +39,20 @@ namespace {
 constexpr int kBlock = 256;
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
+// x / R exactly as the reference computes it — `float /= 1.0 * line_num`, i.e. the fp32 value
+// divided in double and rounded back to fp32 (lr_worker.cc:117, fm_worker.cc:150-156) — at the
+// price of an fp32 division: for x an fp32 number and R an integer below 2^24 the exact
+// quotient is either a float midpoint or at least 2^-49 (relative) away from one, far more
+// than the 2^-53 the intermediate double rounding can move it, so rounding the double
+// quotient to float gives the correctly rounded fp32 quotient, which is what x / (float)R
+// is (hipcc keeps fp32 division correctly rounded).  One fp64 division per (key, factor) was a
+// fifth of the FM gradient kernel.
+__device__ __forceinline__ float div_by_rows(float x, uint32_t R) {
+#pragma clang fp contract(off)
+  if (R < (1u << 24)) return x / (float)R;
+  return (float)((double)x / (1.0 * R));
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
@@ -651,7 +665,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
     }
     __syncthreads();
     const uint32_t nel = nk * (uint32_t)k;
-    constexpr int kUn = 4;  // independent (key,factor) items in flight per lane
+    constexpr int kUn = 2;  // independent (key,factor) items in flight per lane
     for (uint32_t el0 = tid; el0 < nel; el0 += kBlock * kUn) {
       uint32_t kq[kUn], kk[kUn];
       float v[kUn];
@@ -679,7 +693,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
           accw += (double)l;
           accv += (double)(l * (sv[j] - v[i]));
         }
-        const float g = (float)((double)(float)accv / (1.0 * R));
+        const float g = div_by_rows((float)accv, R);
         if (gv) gv[o] = g;
         if (UPDATE) {
           if (OPT == XF_OPT_FTRL) {
@@ -693,7 +707,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
           }
         }
         if (kk[i] == 0) {
-          const float g1 = (float)((double)(float)(accw * (double)k) / (1.0 * R));
+          const float g1 = div_by_rows((float)(accw * (double)k), R);
           gw[ua + kq[i]] = g1;
           if (UPDATE) {
             const uint32_t rw = rows_w[ua + kq[i]];
