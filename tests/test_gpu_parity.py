@@ -372,8 +372,11 @@ def test_lr_forward_panel_kernel_bit_exact():
             same(capi.lr_predict(t, b, ws), ob.lr_loss(s.pull(ob.ukeys))[1])
 
 
+# k in {4, 8, 16, 32, 64}: the forward over per-key scalars (4/8/16-lane shuffle reduce of a
+# factor row); other k: the row-gather forward
 @pytest.mark.parametrize("opt,k", [(capi.OPT_SGD, 10), (capi.OPT_FTRL, 10), (capi.OPT_SGD, 16),
-                                   (capi.OPT_FTRL, 7)])
+                                   (capi.OPT_FTRL, 7), (capi.OPT_SGD, 4), (capi.OPT_FTRL, 32),
+                                   (capi.OPT_FTRL, 64)])
 def test_fm_step_state(opt, k):
     rng = np.random.RandomState(k)
     init = (capi.INIT_CONST, 0.001) if opt == capi.OPT_SGD else (capi.INIT_HASHNORM, 0.0)
@@ -395,7 +398,10 @@ def test_fm_step_state(opt, k):
         for a, e, r in zip(tt.export(), se.export(), sr.export()):
             same(a, e)
             if a.dtype != np.uint64:
-                near_state(a, r, RTOL_HEAVY)
+                # reference arithmetic pools v_sum over k x nnz terms in one fp32 accumulator
+                # (fm_worker.cc:178-192): its own rounding noise grows with k; at k = 64 a
+                # power-law step moves single FTRL z coordinates by 4e-4 relative
+                near_state(a, r, RTOL_HEAVY * (20 if k >= 32 else 1))
 
 
 def test_predict_matches_oracle_and_inserts_keys():
