@@ -68,6 +68,15 @@ int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
                    const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,
                    const int32_t **labels);
 
+/* The same, into a block object the caller owns: the arrays stay valid until the block is
+ * reused or destroyed, also while the reader already parses the next block on another thread. */
+typedef struct xf_block xf_block;
+int xf_block_create(xf_block **out);
+int xf_block_destroy(xf_block *b);
+int xf_reader_next_into(xf_reader *r, xf_block *blk, size_t *rows_out, size_t *nnz_out,
+                        const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,
+                        const int32_t **labels);
+
 /* ---------------------------------------------------------------- compiled minibatch  */
 /* Host-side key build (lr_worker.cc:146-166): sorted unique keys (== unique_keys, the
  * Pull/Push key list) + the two views of all_keys the kernels walk:

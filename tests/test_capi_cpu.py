@@ -471,3 +471,41 @@ def test_fp32_division_by_row_count_equals_the_reference_double_division():
             rng.choice(np.array([3, 7, 200, 49999, 50000, 65537, (1 << 24) - 1]), size=n)
         want = (x.astype(np.float64) / R.astype(np.float64)).astype(np.float32)
         assert np.array_equal(want, x / R.astype(np.float32))
+
+
+def test_reader_next_into_keeps_blocks_alive(sample_prefixes):
+    """xf_reader_next_into moves a block's arrays into a caller-owned xf_block: two blocks stay
+    readable while the reader moves on (what the worker's prefetch thread relies on)."""
+    import ctypes as C
+    L = capi.lib()
+    path = sample_prefixes[0] + "-00000"
+    want = list(capi.read_blocks(path, 6000))
+    rd = capi.vp()
+    capi.check(L.xf_reader_open(C.byref(rd), path.encode(), 6000))
+    blks = [capi.vp(), capi.vp()]
+    for b in blks:
+        capi.check(L.xf_block_create(C.byref(b)))
+    held = [None, None]
+    seen = 0
+    try:
+        for i in range(len(want) + 1):
+            rows, nnz = C.c_size_t(0), C.c_size_t(0)
+            rp, ks, fg, lb = capi.u64p(), capi.u64p(), capi.i32p(), capi.i32p()
+            capi.check(L.xf_reader_next_into(rd, blks[i % 2], C.byref(rows), C.byref(nnz),
+                                             C.byref(rp), C.byref(ks), C.byref(fg), C.byref(lb)))
+            if rows.value == 0:
+                break
+            held[i % 2] = (i, rows.value, nnz.value, rp, ks, lb)
+            for h in held:                       # the previous block is still intact
+                if h is None:
+                    continue
+                j, r, n, hrp, hks, hlb = h
+                assert np.array_equal(np.ctypeslib.as_array(hrp, (r + 1,)), want[j][0])
+                assert np.array_equal(np.ctypeslib.as_array(hks, (n,)), want[j][1])
+                assert np.array_equal(np.ctypeslib.as_array(hlb, (r,)), want[j][3])
+            seen += 1
+        assert seen == len(want) > 3
+    finally:
+        for b in blks:
+            L.xf_block_destroy(b)
+        L.xf_reader_close(rd)

@@ -7,11 +7,14 @@
 // bit-exact on keys, labels and on which rows fall in which block.
 #include <errno.h>
 #include <stdio.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,6 +118,10 @@ extern "C" uint32_t xf_shard_of(uint64_t key, uint32_t nshards) {
 // ----------------------------------------------------------------------------- reader
 struct xf_reader {
   FILE *fp = nullptr;
+  // A regular file is mapped and parsed in place (no copy of the text through a stdio
+  // buffer, which cost as much as the 64-thread parse); anything else is read with fread.
+  const char *map = nullptr;
+  size_t map_size = 0, pos = 0;
   std::string path;
   size_t cap = 0;
   std::vector<char> buf;
@@ -162,10 +169,21 @@ extern "C" int xf_reader_open(xf_reader **out, const char *path, size_t cap_byte
   FILE *fp = fopen(path, "r");
   if (!fp) return xf::set_error(XF_EIO, "open file %s error: %s", path, strerror(errno));
   xf_reader *r = new xf_reader;
-  r->fp = fp;
   r->path = path;
   r->cap = cap_bytes;
-  r->buf.resize(cap_bytes);
+  struct stat st;
+  if (fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+      r->map = (const char *)m;
+      r->map_size = (size_t)st.st_size;
+      fclose(fp);
+      fp = nullptr;
+    }
+  }
+  r->fp = fp;
+  if (fp) r->buf.resize(cap_bytes);
   *out = r;
   return XF_OK;
 }
@@ -222,6 +240,7 @@ static void abandon_cache(xf_reader *r) {
 extern "C" int xf_reader_close(xf_reader *r) {
   if (!r) return XF_OK;
   abandon_cache(r);  // a pass that did not reach end of file leaves no cache
+  if (r->map) munmap((void *)r->map, r->map_size);
   if (r->fp) fclose(r->fp);
   if (r->cfp) fclose(r->cfp);
   delete r;
@@ -405,6 +424,40 @@ void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
 
 }  // namespace
 
+// a parsed block owned by the caller: xf_reader_next_into moves the reader's arrays into it, so
+// the block stays valid while the reader parses the next one (the worker's prefetch thread)
+struct xf_block {
+  std::vector<uint64_t> rowptr, keys;
+  std::vector<int32_t> fgid, labels;
+};
+
+extern "C" int xf_block_create(xf_block **out) {
+  XF_REQUIRE(out, "xf_block_create: null argument");
+  *out = new xf_block;
+  return XF_OK;
+}
+
+extern "C" int xf_block_destroy(xf_block *b) {
+  delete b;
+  return XF_OK;
+}
+
+extern "C" int xf_reader_next_into(xf_reader *r, xf_block *blk, size_t *rows_out, size_t *nnz_out,
+                                   const uint64_t **rowptr, const uint64_t **keys,
+                                   const int32_t **fgid, const int32_t **labels) {
+  XF_REQUIRE(r && blk && rows_out, "xf_reader_next_into: null argument");
+  XF_TRY(xf_reader_next(r, rows_out, nnz_out, nullptr, nullptr, nullptr, nullptr));
+  blk->rowptr.swap(r->rowptr);
+  blk->keys.swap(r->keys);
+  blk->fgid.swap(r->fgid);
+  blk->labels.swap(r->labels);
+  if (rowptr) *rowptr = blk->rowptr.data();
+  if (keys) *keys = blk->keys.data();
+  if (fgid) *fgid = blk->fgid.data();
+  if (labels) *labels = blk->labels.data();
+  return XF_OK;
+}
+
 extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
                               const uint64_t **rowptr, const uint64_t **keys,
                               const int32_t **fgid, const int32_t **labels) {
@@ -424,8 +477,15 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
   // The reference fills a cap-byte buffer up to cap-1 bytes (:108-110).  A buffer that
   // filled completely is cut after its last newline and the rest carried (:112-121,:104-107);
   // a short read means end of file and everything is parsed.
-  char *base = r->buf.data();
-  r->held += fread(base + r->held, 1, r->cap - 1 - r->held, r->fp);
+  const char *base;
+  if (r->map) {  // the next cap-1 bytes of the mapping == carried tail + fresh read
+    base = r->map + r->pos;
+    r->held = std::min(r->map_size - r->pos, r->cap - 1);
+  } else {
+    char *buf = r->buf.data();
+    r->held += fread(buf + r->held, 1, r->cap - 1 - r->held, r->fp);
+    base = buf;
+  }
   size_t take = r->held;   // bytes consumed by this block
   size_t text = r->held;   // bytes of text to parse
   if (r->held == r->cap - 1) {
@@ -503,8 +563,13 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
     for (unsigned t = 0; t < used; ++t) th.emplace_back(place, t);
     for (auto &x : th) x.join();
   }
-  if (take < r->held) memmove(base, base + take, r->held - take);
-  r->held -= take;
+  if (r->map) {
+    r->pos += take;
+    r->held = 0;
+  } else {
+    if (take < r->held) memmove(r->buf.data(), r->buf.data() + take, r->held - take);
+    r->held -= take;
+  }
   tee_block(r, r->labels.size());
   *rows_out = r->labels.size();
   if (nnz_out) *nnz_out = r->keys.size();

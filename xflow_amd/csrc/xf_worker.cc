@@ -16,6 +16,9 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <fstream>
 #include <iostream>
 
@@ -160,35 +163,96 @@ int Worker::batch_training() {
     } else {
       xf_reader *rd = nullptr;
       XF_TRY(open_reader(&rd, train_data_path, (size_t)block_size << 20));
-      while (true) {
+      // The text of block i+1 is parsed on a second host thread while the GPU builds the keys
+      // of block i and trains on it: two caller-owned blocks go round between the two threads.
+      struct Parsed {
+        xf_block *blk = nullptr;
         size_t rows = 0, nnz = 0;
-        const uint64_t *rowptr, *keys;
-        const int32_t *fgid, *labels;
-        int rc = xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels);
+        const uint64_t *rowptr = nullptr, *keys = nullptr;
+        const int32_t *labels = nullptr;
+        int rc = XF_OK;
+        std::string err;
+      };
+      Parsed slot[2];
+      for (auto &p : slot) {
+        int rc = xf_block_create(&p.blk);
         if (rc != XF_OK) {
           xf_reader_close(rd);
           return rc;
         }
-        if (rows == 0) break;
-        const size_t thread_size = rows / core_num;  // remainder dropped, lr_worker.cc:190
-        for (int i = 0; i < core_num; ++i) {
+      }
+      std::mutex mu;
+      std::condition_variable cv;
+      int filled[2] = {0, 0};  // 0 = free for the parser, 1 = parsed, waiting for the trainer
+      bool stop = false;
+      std::thread parser([&] {
+        for (int k = 0;; k ^= 1) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || !filled[k]; });
+            if (stop) return;
+          }
+          Parsed &p = slot[k];
+          const int32_t *fgid = nullptr;
+          p.rc = xf_reader_next_into(rd, p.blk, &p.rows, &p.nnz, &p.rowptr, &p.keys, &fgid,
+                                     &p.labels);
+          if (p.rc != XF_OK) p.err = xf_last_error();  // the message is thread-local
+          const bool last = p.rc != XF_OK || p.rows == 0;
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            filled[k] = 1;
+          }
+          cv.notify_all();
+          if (last) return;
+        }
+      });
+      int rc = XF_OK;
+      for (int k = 0; rc == XF_OK; k ^= 1) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return filled[k] != 0; });
+        }
+        Parsed &p = slot[k];
+        if (p.rc != XF_OK) {
+          rc = xf::set_error(p.rc, "%s", p.err.c_str());
+          break;
+        }
+        if (p.rows == 0) break;
+        const size_t thread_size = p.rows / core_num;  // remainder dropped, lr_worker.cc:190
+        for (int i = 0; i < core_num && rc == XF_OK; ++i) {
           const size_t start = i * thread_size, end = (i + 1) * thread_size;
           if (end == start) continue;
           xf_batch *b = nullptr;
-          XF_TRY(compile(&b, rowptr, keys, labels, start, end));
+          rc = compile(&b, p.rowptr, p.keys, p.labels, start, end);
+          if (rc != XF_OK) break;
           rc = update(b);
           if (rc == XF_OK) rc = xf_table_check(table_w_, nullptr);
           if (rc == XF_OK && table_v_) rc = xf_table_check(table_v_, nullptr);
           if (rc != XF_OK) {
             xf_batch_free(b);
-            xf_reader_close(rd);
-            return rc;
+            break;
           }
           rows_trained_ += (long)(end - start);
           if (cache_batches) cache_.push_back(b);
           else
             xf_batch_free(b);
         }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          filled[k] = 0;
+        }
+        cv.notify_all();
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv.notify_all();
+      parser.join();
+      for (auto &p : slot) xf_block_destroy(p.blk);
+      if (rc != XF_OK) {
+        xf_reader_close(rd);
+        return rc;
       }
       xf_reader_close(rd);
       cached = cache_batches != 0;
@@ -313,6 +377,7 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "lr") learning_rate = (float)atof(value);
   else if (n == "seed") seed = strtoull(value, nullptr, 10);
   else if (n == "cache_batches") cache_batches = atoi(value);
+  else if (n == "parse_threads") return xf_tune("parse_threads", atof(value));
   else if (n == "block_cache") block_cache = atoi(value);
   else if (n == "block_cache_dir") block_cache_dir = value;
   else if (n == "model_in") model_in = value;
