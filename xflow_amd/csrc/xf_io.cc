@@ -116,6 +116,14 @@ extern "C" uint32_t xf_shard_of(uint64_t key, uint32_t nshards) {
 }
 
 // ----------------------------------------------------------------------------- reader
+// what one parser thread produces for its run of lines
+struct Piece {
+  std::vector<uint64_t> keys, rowend;
+  std::vector<int32_t> fgid, labels;
+  const char *err = nullptr;
+  bool hit_nul = false;
+};
+
 struct xf_reader {
   FILE *fp = nullptr;
   // A regular file is mapped and parsed in place (no copy of the text through a stdio
@@ -128,6 +136,9 @@ struct xf_reader {
   size_t held = 0;  // bytes at the front of buf not yet parsed (carry + fresh read)
   std::vector<uint64_t> rowptr, keys;
   std::vector<int32_t> fgid, labels;
+  // per-thread pieces, kept between blocks: fresh 100 MB vectors per block meant page faults
+  // and munmap under 64 threads every time
+  std::vector<Piece> pieces;
   // block cache (xf_reader_open_cached): either replaying `cfp`, or teeing into `tfp`
   FILE *cfp = nullptr, *tfp = nullptr;
   std::string cache_path, tmp_path;
@@ -325,12 +336,6 @@ inline double field_atof(const char *b, const char *e, bool *ok) {
   return atof(tmp);
 }
 
-struct Piece {
-  std::vector<uint64_t> keys, rowend;
-  std::vector<int32_t> fgid, labels;
-  const char *err = nullptr;
-  bool hit_nul = false;
-};
 
 // One contiguous run of whole lines (load_data_from_disk.cc:126-208).
 void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
@@ -513,7 +518,17 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
     while (c < end && *c != '\n') ++c;  // a piece ends after a newline
     cut[t] = c < end ? c + 1 : end;
   }
-  std::vector<Piece> pieces(nt);
+  if (r->pieces.size() < nt) r->pieces.resize(nt);
+  std::vector<Piece> &pieces = r->pieces;
+  for (unsigned t = 0; t < nt; ++t) {
+    Piece &pc = pieces[t];
+    pc.keys.clear();
+    pc.rowend.clear();
+    pc.fgid.clear();
+    pc.labels.clear();
+    pc.err = nullptr;
+    pc.hit_nul = false;
+  }
   if (nt == 1) {
     parse_piece(cut[0], cut[1], true, &pieces[0]);
   } else {
