@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _product_library_is_built():
+    """libxflow_amd.so, the CLI and the binding demo are build artefacts (git-ignored):
+    (re)build them when a source is newer — a no-op on an up-to-date tree, and on the GPU box
+    where the built files travel with the snapshot."""
+    from xflow_amd import build
+    build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
