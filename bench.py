@@ -84,7 +84,7 @@ def make_batches(args, rank, nkeys_total, keytab):
     return out
 
 
-def bytes_model(model, k, R, NNZ, U, opt, fused=False):
+def bytes_model(model, k, R, NNZ, U, opt, fused=False, fused_fm=False):
     """Algorithmic bytes per launch of each kernel of THIS implementation (indices counted
     once at their stored width, no probe / sector overhead) and SURVEY §8(d)'s whole-step
     figure."""
@@ -106,6 +106,11 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False):
         NNZ * 12 + U * (4 + 4 * d + 4 * k),
         "update": U * (4 + (4 + state) * d),                        # slot + g + state RMW
     }
+    if model == "fm" and fused_fm and k % 4 == 0 and k // 4 in (1, 2, 4, 8, 16):
+        # fused single-GPU FM step: the v-row gather also writes a 32-byte (sum_k v, sum_k v^2,
+        # w) record per key, the forward gathers one record per nonzero
+        per["gather"] = U * (4 + 8 * k + 4 + 32)
+        per["forward"] = NNZ * (4 + 32) + R * 12 + 4
     if model == "lr":
         # the sharded LR path pulls with the fused resolve+gather kernel (xf_table_pull_dev)
         per["resolve"] = U * (8 + 8 + 4 + 4 + 4)
@@ -325,7 +330,9 @@ def main():
         return
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
     fused = args.model == "lr" and world == 1 and not args.force_sharded
-    per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused)
+    per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused,
+                                    fused_fm=(args.model == "fm" and world == 1 and
+                                              not args.force_sharded))
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
     achieved = per[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
