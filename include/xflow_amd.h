@@ -214,6 +214,18 @@ int xf_table_gather_dev(xf_table *t, const uint32_t *d_slots, size_t n, float *d
 /* resolve + gather in one pass (dim-1 tables, keys unique within the call) */
 int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_slots,
                       float *d_vals, void *stream);
+/* The owner side of a step with N source ranks, in ONE pass over the shard instead of one per
+ * source: d_keys_sorted = the concatenated per-source key lists in (stable) ascending key
+ * order, d_order[i] = position of sorted entry i in the per-source layout.  Rows / weights
+ * are written, gradients read, in the per-source layout.  A key that several sources sent gets
+ * their optimizer steps one after the other in source order, as N separate
+ * xf_table_update_dev passes in rank order would apply them. */
+int xf_table_pull_ordered_dev(xf_table *t, const uint64_t *d_keys_sorted,
+                              const uint32_t *d_order, size_t n, uint32_t *d_slots,
+                              float *d_vals /* may be null: resolve only */, void *stream);
+int xf_table_update_merged_dev(xf_table *t, const uint64_t *d_keys_sorted,
+                               const uint32_t *d_order, size_t n, const uint32_t *d_slots,
+                               const float *d_grads, void *stream);
 int xf_table_update_dev(xf_table *t, const uint32_t *d_slots, size_t n,
                         const float *d_grads, void *stream);
 /* raises XF_EFULL / XF_EINVAL recorded by earlier async calls; synchronises the stream */

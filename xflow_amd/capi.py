@@ -97,6 +97,8 @@ SIGNATURES = {
     "xf_table_gather_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "xf_table_update_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "xf_table_pull_dev": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
+    "xf_table_pull_ordered_dev": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, vp]),
+    "xf_table_update_merged_dev": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, vp]),
     "xf_lr_grad_update_dev": (C.c_int, [vp, C.POINTER(DevBatch), vp, vp, vp, vp, vp]),
     "xf_table_check": (C.c_int, [vp, vp]),
     "xf_table_export": (C.c_int, [vp, u64p, f32p, f32p, f32p, C.c_size_t,

@@ -102,7 +102,8 @@ template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
 k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
           uint32_t *__restrict__ rows_out, float *__restrict__ wu,
-          const uint32_t *__restrict__ list, const unsigned long long *__restrict__ list_n) {
+          const uint32_t *__restrict__ list, const unsigned long long *__restrict__ list_n,
+          const uint32_t *__restrict__ out_idx /* null, or where entry i's results go */) {
   // with a work list (the keys k_pull_settled did not find): entries list[0 .. *list_n)
   if (list) n = (size_t)*list_n;
   __shared__ unsigned int wcount[kBlock / 64];
@@ -232,8 +233,9 @@ k_resolve(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
           row = (uint32_t)T.max_rows;
         }
       }
-      rows_out[i] = row;
-      if (GATHER) wu[i] = T.w[row];
+      const size_t o = out_idx ? (size_t)out_idx[i] : i;
+      rows_out[o] = row;
+      if (GATHER) wu[o] = T.w[row];
     }
     __syncthreads();  // wcount / wbase are reused by the next pass
   }
@@ -248,7 +250,8 @@ template <bool GATHER, int ILP, int WIN>
 __global__ void __launch_bounds__(kBlock)
 k_pull_settled(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
                uint32_t *__restrict__ rows_out, float *__restrict__ wu,
-               uint32_t *__restrict__ miss, unsigned long long *__restrict__ miss_n) {
+               uint32_t *__restrict__ miss, unsigned long long *__restrict__ miss_n,
+               const uint32_t *__restrict__ out_idx) {
   const size_t chunk = (size_t)kBlock * ILP;
   for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
     uint64_t key[ILP];
@@ -296,8 +299,9 @@ k_pull_settled(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
     for (int q = 0; q < ILP; ++q) {
       const size_t i = base + (size_t)q * kBlock + threadIdx.x;
       if (hit[q]) {
-        rows_out[i] = row[q];
-        if (GATHER) wu[i] = wv[q];
+        const size_t o = out_idx ? (size_t)out_idx[i] : i;
+        rows_out[o] = row[q];
+        if (GATHER) wu[o] = wv[q];
       }
       // (all lanes reach this: the loop bounds are workgroup-uniform)
       const bool lost = act[q] && !hit[q];
@@ -359,6 +363,44 @@ k_update(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
       xf::store_nz(T, o, nn, z);
     } else {
       T.w[o] = xf::sgd_step(T.lr, g, T.w[o]);
+    }
+  }
+}
+
+// Push of several workers' gradients in ONE pass over the owner's state.  The entries of all
+// source ranks are visited in key order (keys_sorted = the concatenated per-source key lists,
+// stably sorted; order[i] = position of sorted entry i in the per-source layout that rows[] and
+// grads[] use), so a key's entries are adjacent, in source-rank order.  The first of them
+// applies all of that key's optimizer steps one after the other — exactly the rank-ordered
+// sequence of per-source passes — with the state row read and written once.  A pass per source
+// instead sweeps (nearly) every cache line of the state once per source: each source's list
+// touches a tenth of the keys, but sixteen 8-byte accumulators share a line.
+template <int OPT>
+__global__ void __launch_bounds__(kBlock)
+k_update_merged(xf::TableDev T, const uint64_t *__restrict__ keys_sorted,
+                const uint32_t *__restrict__ order, size_t n,
+                const uint32_t *__restrict__ rows, const float *__restrict__ grads) {
+  const size_t total = n * (size_t)T.dim;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const size_t i = T.dim == 1 ? e : e / (size_t)T.dim;
+    const size_t j = e - i * (size_t)T.dim;
+    const uint64_t key = keys_sorted[i];
+    if (i > 0 && keys_sorted[i - 1] == key) continue;  // not the first entry of its key
+    const size_t o = (size_t)rows[order[i]] * T.dim + j;
+    if (OPT == XF_OPT_FTRL) {
+      float w = T.w[o], nn, z;
+      xf::load_nz(T, o, nn, z);
+      for (size_t s = i; s < n && keys_sorted[s] == key; ++s)
+        xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2,
+                      grads[(size_t)order[s] * T.dim + j], w, nn, z);
+      T.w[o] = w;
+      xf::store_nz(T, o, nn, z);
+    } else {
+      float w = T.w[o];
+      for (size_t s = i; s < n && keys_sorted[s] == key; ++s)
+        w = xf::sgd_step(T.lr, grads[(size_t)order[s] * T.dim + j], w);
+      T.w[o] = w;
     }
   }
 }
@@ -872,12 +914,12 @@ constexpr int kIlp = 1;
 
 template <bool GATHER>
 static int launch_resolve(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
-                          float *d_vals, hipStream_t s) {
+                          float *d_vals, hipStream_t s, const uint32_t *d_out_idx = nullptr) {
   XF_REQUIRE(n < 0xFFFFFFFFull, "resolve: %zu keys in one call", n);
   if (t->T.nbase == 0) {
     hipLaunchKernelGGL(k_resolve<GATHER>, dim3(grid_for(n)), dim3(kBlock), 0, s, t->T, d_keys, n,
                        d_rows, d_vals, (const uint32_t *)nullptr,
-                       (const unsigned long long *)nullptr);
+                       (const unsigned long long *)nullptr, d_out_idx);
     XF_HIP(hipGetLastError());
     return XF_OK;
   }
@@ -895,11 +937,12 @@ static int launch_resolve(xf_table *t, const uint64_t *d_keys, size_t n, uint32_
   const size_t chunk = (size_t)kBlock * kIlp;
   const size_t blocks = std::min<size_t>((n + chunk - 1) / chunk, 1u << 16);
   hipLaunchKernelGGL((k_pull_settled<GATHER, kIlp, xf::kBaseWin>), dim3((unsigned)blocks),
-                     dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, d_vals, t->miss, t->miss_n);
+                     dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, d_vals, t->miss, t->miss_n,
+                     d_out_idx);
   // few keys miss in the steady state: a small grid, whose waves find the count in memory
   hipLaunchKernelGGL(k_resolve<GATHER>, dim3(std::min(grid_for(n), 2048)), dim3(kBlock), 0, s,
                      t->T, d_keys, n, d_rows, d_vals, (const uint32_t *)t->miss,
-                     (const unsigned long long *)t->miss_n);
+                     (const unsigned long long *)t->miss_n, d_out_idx);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }
@@ -945,6 +988,39 @@ extern "C" int xf_table_update_dev(xf_table *t, const uint32_t *d_rows, size_t n
     hipLaunchKernelGGL(k_update<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_rows, n, d_grads);
   else
     hipLaunchKernelGGL(k_update<XF_OPT_SGD>, g, b, 0, S(stream), t->T, d_rows, n, d_grads);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+
+// Owner-side Pull over the key lists of ALL source ranks at once, visited in key order (see
+// k_update_merged): the settled tier and the weights are swept once instead of once per
+// source.  d_rows / d_vals are written in the per-source layout (entry d_order[i]).
+extern "C" int xf_table_pull_ordered_dev(xf_table *t, const uint64_t *d_keys_sorted,
+                                         const uint32_t *d_order, size_t n, uint32_t *d_rows,
+                                         float *d_vals, void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys_sorted && d_order && d_rows)),
+             "xf_table_pull_ordered_dev: null argument");
+  XF_REQUIRE(!d_vals || t->T.dim == 1, "xf_table_pull_ordered_dev: values only for dim 1");
+  if (n == 0) return XF_OK;
+  if (d_vals) return launch_resolve<true>(t, d_keys_sorted, n, d_rows, d_vals, S(stream), d_order);
+  return launch_resolve<false>(t, d_keys_sorted, n, d_rows, nullptr, S(stream), d_order);
+}
+
+extern "C" int xf_table_update_merged_dev(xf_table *t, const uint64_t *d_keys_sorted,
+                                          const uint32_t *d_order, size_t n,
+                                          const uint32_t *d_rows, const float *d_grads,
+                                          void *stream) {
+  XF_REQUIRE(t && (n == 0 || (d_keys_sorted && d_order && d_rows && d_grads)),
+             "xf_table_update_merged_dev: null argument");
+  if (n == 0) return XF_OK;
+  const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
+  if (t->cfg.opt_kind == XF_OPT_FTRL)
+    hipLaunchKernelGGL(k_update_merged<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_keys_sorted,
+                       d_order, n, d_rows, d_grads);
+  else
+    hipLaunchKernelGGL(k_update_merged<XF_OPT_SGD>, g, b, 0, S(stream), t->T, d_keys_sorted,
+                       d_order, n, d_rows, d_grads);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }

@@ -100,6 +100,22 @@ class HipStages:
                                                 vals.data_ptr(), self._stream()))
         return rows, vals
 
+    # the same, all source ranks' key lists in one pass over the shard (entries visited in key
+    # order, results in the per-source layout); see xf_table_pull_ordered_dev
+    def pull_ordered(self, table, keys_sorted, order, want_values):
+        n = keys_sorted.numel()
+        rows = self.empty(n, torch.int32)
+        vals = self.empty(n, torch.float32) if want_values else None
+        capi.check(capi.lib().xf_table_pull_ordered_dev(
+            table.h, keys_sorted.data_ptr(), order.data_ptr(), n, rows.data_ptr(),
+            vals.data_ptr() if want_values else None, self._stream()))
+        return rows, vals
+
+    def update_merged(self, table, keys_sorted, order, slots, grads):
+        capi.check(capi.lib().xf_table_update_merged_dev(
+            table.h, keys_sorted.data_ptr(), order.data_ptr(), keys_sorted.numel(),
+            slots.data_ptr(), grads.data_ptr(), self._stream()))
+
     def gather(self, table, slots):
         vals = self.empty(slots.numel() * table.dim, torch.float32)
         table.gather_dev(slots.data_ptr(), slots.numel(), vals.data_ptr(), self._stream())
@@ -238,6 +254,16 @@ class ShardedTrainer:
         # itself they depend only on the input rows, so the key all-to-all runs once here and
         # a step exchanges only what changes — weights one way, gradients the other.
         b.rkeys = self._a2a(b.ukeys, b.send_counts, b.recv_counts)
+        # ... and so is the order in which the owner walks them: all sources' lists merged by
+        # key (stable, so a key's entries stay in source-rank order).  Walking the lists one
+        # source after the other would sweep the shard's index and state once per source.
+        b.rkeys_sorted = b.rorder = None
+        # (with one source there is nothing to merge: the plain passes are 25 us cheaper)
+        if hasattr(self.stages, "pull_ordered") and b.n_recv and self.world > 1:
+            flip = torch.iinfo(torch.int64).min           # u64 order through an i64 sort
+            srt, order = torch.sort(b.rkeys ^ flip, stable=True)
+            b.rkeys_sorted = srt ^ flip
+            b.rorder = order.to(torch.int32)
         return b
 
     def _a2a(self, src, in_counts, out_counts, width=1):
@@ -277,13 +303,19 @@ class ShardedTrainer:
         rkeys = b.rkeys     # keys went to their owners at compile time (ps-lite slicer ranges)
         c = {}
         # owner: key -> state row (insert on first touch, ftrl.h:56) and the weight payload
-        if hasattr(st, "pull") and rkeys.numel():
+        merged = getattr(b, "rorder", None) is not None
+        if merged:
+            c["slots_w"], c["w_recv"] = st.pull_ordered(tw, b.rkeys_sorted, b.rorder, True)
+        elif hasattr(st, "pull") and rkeys.numel():
             c["slots_w"], c["w_recv"] = st.pull(tw, rkeys)
         else:
             c["slots_w"] = self._resolve(tw, rkeys, b.recv_counts)
             c["w_recv"] = st.gather(tw, c["slots_w"])
         if self.model == "fm":
-            c["slots_v"] = self._resolve(tv, rkeys, b.recv_counts)
+            if merged:
+                c["slots_v"], _ = st.pull_ordered(tv, b.rkeys_sorted, b.rorder, False)
+            else:
+                c["slots_v"] = self._resolve(tv, rkeys, b.recv_counts)
         self._mark("resolve")
         if self.model == "fm":
             c["v_recv"] = st.gather(tv, c["slots_v"])
@@ -323,7 +355,11 @@ class ShardedTrainer:
     def _apply(self, b, c, g_recv, gv_recv):
         st = self.stages
         tw, tv = st.tables()
-        if hasattr(st, "update_multi"):
+        if getattr(b, "rorder", None) is not None:   # one pass, a key's sources in rank order
+            st.update_merged(tw, b.rkeys_sorted, b.rorder, c["slots_w"], g_recv)
+            if self.model == "fm":
+                st.update_merged(tv, b.rkeys_sorted, b.rorder, c["slots_v"], gv_recv)
+        elif hasattr(st, "update_multi"):
             st.update_multi(tw, c["slots_w"], g_recv, b.recv_counts)
             if self.model == "fm":
                 st.update_multi(tv, c["slots_v"], gv_recv, b.recv_counts)
@@ -402,12 +438,15 @@ class ShardedTrainer:
         st = self.stages
         tw, tv = st.tables()
         rkeys = b.rkeys
-        wu = self._a2a(st.gather(tw, self._resolve(tw, rkeys, b.recv_counts)), b.recv_counts,
-                       b.send_counts)
+
+        def rows_of(table):
+            if getattr(b, "rorder", None) is not None:
+                return st.pull_ordered(table, b.rkeys_sorted, b.rorder, False)[0]
+            return self._resolve(table, rkeys, b.recv_counts)
+        wu = self._a2a(st.gather(tw, rows_of(tw)), b.recv_counts, b.send_counts)
         if self.model == "lr":
             return st.lr_forward(b, wu)
-        vu = self._a2a(st.gather(tv, self._resolve(tv, rkeys, b.recv_counts)), b.recv_counts,
-                       b.send_counts, self.k)
+        vu = self._a2a(st.gather(tv, rows_of(tv)), b.recv_counts, b.send_counts, self.k)
         return st.fm_forward(b, wu, vu)[0]
 
     def check(self):
