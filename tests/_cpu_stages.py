@@ -107,3 +107,32 @@ class CpuOracleStages:
 
     def tables(self):
         return self.w, self.v
+
+
+class CpuOracleStagesMerged(CpuOracleStages):
+    """The same double with the owner-side stages of the merged walk (all sources' key lists
+    in key order, xf_table_pull_ordered_dev / xf_table_update_merged_dev): when a stage object
+    offers them and world > 1, ShardedTrainer sorts the received keys at compile time and
+    calls these instead of one pass per source."""
+
+    def pull_ordered(self, table, keys_sorted, order, want_values):
+        ks = keys_sorted.numpy().view(np.uint64)
+        od = order.numpy().astype(np.int64)
+        assert np.all(ks[:-1] <= ks[1:]), "entries must arrive in (unsigned) key order"
+        rows = np.empty(len(ks), dtype=np.int32)
+        rows[od] = table.resolve(ks)
+        vals = None
+        if want_values:
+            v = np.empty(len(ks), dtype=np.float32)
+            v[od] = np.asarray(table.store.pull(ks), dtype=np.float32).ravel()
+            vals = torch.from_numpy(v)
+        return torch.from_numpy(rows), vals
+
+    def update_merged(self, table, keys_sorted, order, slots, grads):
+        ks = keys_sorted.numpy().view(np.uint64)
+        od = order.numpy().astype(np.int64)
+        g = grads.numpy().reshape(len(ks), table.dim)
+        sl = slots.numpy()
+        for i in range(len(ks)):          # key order; a key's sources in rank order (stable)
+            assert table.keys[sl[od[i]]] == int(ks[i])
+            table.store.push(ks[i:i + 1], g[od[i]])

@@ -26,14 +26,15 @@ def _data(rank, step, R=120, nnz=9, nkeys=700):
     return rowptr, keys, labels
 
 
-def _worker(rank, world, port, model, optimizer, steps, outdir, schedule="sequential"):
+def _worker(rank, world, port, model, optimizer, steps, outdir, schedule="sequential",
+            merged=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tests._cpu_stages import CpuOracleStages
+    from tests._cpu_stages import CpuOracleStages, CpuOracleStagesMerged
     from xflow_amd.sharded import ShardedTrainer
-    st = CpuOracleStages(model, optimizer, 4, rank, world)
+    st = (CpuOracleStagesMerged if merged else CpuOracleStages)(model, optimizer, 4, rank, world)
     tr = ShardedTrainer(model=model, optimizer=optimizer, k=4, rank=rank, world=world,
                         stages=st, schedule=schedule)
     for s in range(steps):
@@ -100,13 +101,18 @@ def _simulate(world, model, optimizer, steps, schedule="sequential"):
     return w, v, losses
 
 
-@pytest.mark.parametrize("world,model,optimizer,schedule", [
-    (2, "lr", "ftrl", "sequential"), (2, "fm", "sgd", "sequential"),
-    (3, "fm", "ftrl", "sequential"), (2, "lr", "ftrl", "stale1"), (3, "fm", "sgd", "stale1")])
-def test_sharded_matches_rank_ordered_schedule(tmp_path, world, model, optimizer, schedule):
+# merged = the owner walks all sources' key lists merged by key (one pass over its shard per
+# step) instead of one pass per source; both must give the rank-ordered result
+@pytest.mark.parametrize("world,model,optimizer,schedule,merged", [
+    (2, "lr", "ftrl", "sequential", False), (2, "fm", "sgd", "sequential", False),
+    (3, "fm", "ftrl", "sequential", True), (2, "lr", "ftrl", "stale1", True),
+    (3, "fm", "sgd", "stale1", False), (3, "lr", "ftrl", "sequential", True)])
+def test_sharded_matches_rank_ordered_schedule(tmp_path, world, model, optimizer, schedule,
+                                               merged):
     from oracle import pyoracle as O
-    port = 29600 + (os.getpid() % 300) + world + (7 if schedule == "stale1" else 0)
-    mp.spawn(_worker, args=(world, port, model, optimizer, 4, str(tmp_path), schedule),
+    port = 29600 + (os.getpid() % 300) + world + (7 if schedule == "stale1" else 0) + \
+        (13 if merged else 0)
+    mp.spawn(_worker, args=(world, port, model, optimizer, 4, str(tmp_path), schedule, merged),
              nprocs=world, join=True)
     w, v, losses = _simulate(world, model, optimizer, 4, schedule)
     for nm, store in (("w", w), ("v", v)):
