@@ -509,3 +509,22 @@ def test_reader_next_into_keeps_blocks_alive(sample_prefixes):
         for b in blks:
             L.xf_block_destroy(b)
         L.xf_reader_close(rd)
+
+
+def test_bench_byte_model_matches_survey_8d():
+    """bench.py's whole-step figure is SURVEY 8(d)'s formula, and the per-kernel algorithmic
+    bytes of the fused LR step add up to no more than a few index arrays above it."""
+    import bench
+    R, NNZ, U = 50_000, 10_000_000, 6_320_289
+    per, survey = bench.bytes_model("lr", 0, R, NNZ, U, "ftrl", fused=True)
+    assert survey == 12 * NNZ + 8 * R + 32 * U
+    assert set(per) == {"resolve", "forward", "gradient"}
+    assert per["gradient"] == NNZ * 8 + U * (4 + 4 + 4 + 24)
+    assert survey < sum(per.values()) < 2 * survey
+    _, survey = bench.bytes_model("lr", 0, R, NNZ, U, "sgd", fused=True)
+    assert survey == 12 * NNZ + 8 * R + 16 * U
+    for opt, state in (("sgd", 16), ("ftrl", 32)):
+        _, survey = bench.bytes_model("fm", 16, R, NNZ, U, opt)
+        assert survey == NNZ * (12 + 4 * 16) + 8 * R + state * U * 17
+    per, _ = bench.bytes_model("fm", 16, R, NNZ, U, "sgd", fused_fm=True)
+    assert per["forward"] == NNZ * 36 + R * 12 + 4        # one 32-byte record per nonzero
