@@ -346,10 +346,11 @@ def main():
                                   "(every rank scores its own; the exchange is collective); "
                                   "reference_format = mean(y*log2 p + (1-y)*log2(1-p)), "
                                   "base.h:97-100.  With the reference's hyper-parameters "
-                                  "(lambda1 = 5e-5, gradients scaled by 1/R) every |z| is still "
-                                  "inside the L1 dead zone after a few hundred minibatches of "
-                                  "this generator, so ln 2 is the expected value here; the "
-                                  "learning behaviour is what the parity tests pin"}
+                                  "(lambda1 = 5e-5, lambda2 = 10, gradients scaled by 1/R) the few "
+                                  "weights that have left the L1 dead zone after some hundred "
+                                  "minibatches of this generator are still ~1e-6, so ln 2 is "
+                                  "the expected value here; learning behaviour is what the "
+                                  "parity tests pin"}
     except Exception as e:  # the throughput line must not depend on this extra
         logloss = {"error": str(e)}
     if rank != 0:
