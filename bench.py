@@ -37,7 +37,9 @@ def parse_args():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--rows", type=int, default=50000)
     ap.add_argument("--nnz-per-row", type=int, default=200)
-    ap.add_argument("--keys-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--keys-per-gpu", type=int, default=0,
+                    help="key space per GPU; default 10^7 at N=1 (BASELINE configs[1]) and "
+                         "1.25x10^7 at N>1 (configs[2]: 10^8 keys over 8 GPUs)")
     ap.add_argument("--batches", type=int, default=8, help="distinct minibatches cycled")
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--zipf", type=float, default=0.0)
@@ -92,11 +94,12 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False, fused_fm=False):
     state = 24 if opt == "ftrl" else 8      # read+write of (w,n,z) or w per coordinate
     d = 1 if model == "lr" else 1 + k
     if model == "lr" and fused:
+        # SURVEY 8(d), LR: forward NNZ x (8 key + 4 w) + R x (4 label + 4 loss); gradient U x 4;
+        # update U x (4 g + state read + state write)
         per = {
-            "resolve": U * (8 + 8 + 4 + 4 + 4),      # pull: key list, table key, slot, w, w_u
-            "forward": NNZ * (4 + 4) + R * 12 + 4,    # uidx + gathered w_u
-            "gradient": NNZ * 8 + U * (4 + 4 + 4 + state),  # grad+push: rows, loss gathers,
-        }                                             # segptr, slot, g, state RMW
+            "forward": NNZ * 12 + R * 8,
+            "gradient": U * (4 + 4 + state),
+        }
         survey = 12 * NNZ + 8 * R + (32 if opt == "ftrl" else 16) * U
         return per, survey
     per = {
@@ -122,6 +125,17 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False, fused_fm=False):
     return per, survey
 
 
+def impl_bytes_cells(R, NNZ, U, opt, info, table_rows):
+    """Bytes the cells kernels of THIS implementation must move per launch (indices and values
+    once at their stored width, no sector or cache-line overhead): forward = one 4-byte entry
+    and one 4-byte weight per nonzero + the window workgroups' fp64 partial row sums written and
+    read back + labels/loss; gradient+Push = entry + loss per nonzero + the state rows of the
+    touched keys read and written (w 4 B, {n,z} 8 B)."""
+    partial = info["G"] * info["nwin"] * info["W"] * 8
+    state = 24 if opt == "ftrl" else 8
+    return {"forward": NNZ * 8 + 2 * partial + R * 8, "gradient": NNZ * 8 + U * state}
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE need separate profiled runs, so bench.py
@@ -140,8 +154,8 @@ def pmc_traffic(kernel, workload):
 
 def with_key_build(args, trainer, batches):
     """Supplementary figure (not `value`): the whole LRWorker::update including its key build
-    (lr_worker.cc:146-166) per step — raw CSR keys resident in HBM, xf_batch_compile_dev
-    (GPU sort + unique + views) and then the step, nothing cached between steps."""
+    (lr_worker.cc:146-166) per step — raw CSR keys resident in HBM, xf_batch_compile_local_dev
+    (keys -> state rows, cells by a stable radix pass) and then the step, nothing cached."""
     import ctypes as C
     import torch
     from xflow_amd import capi
@@ -155,8 +169,8 @@ def with_key_build(args, trainer, batches):
     def one(i):
         k, rp, lb, R, NNZ = raw[i % len(raw)]
         h = capi.vp()
-        capi.check(L.xf_batch_compile_dev(C.byref(h), k.data_ptr(), rp.data_ptr(),
-                                          lb.data_ptr(), R, NNZ, None))
+        capi.check(L.xf_batch_compile_local_dev(C.byref(h), trainer.w.h, k.data_ptr(),
+                                                rp.data_ptr(), lb.data_ptr(), R, NNZ, 0, None))
         capi.check(L.xf_lr_step(trainer.w.h, h, trainer.ws.h, None))
         capi.stream_sync()
         L.xf_batch_free(h)
@@ -170,8 +184,9 @@ def with_key_build(args, trainer, batches):
     dt = time.perf_counter() - t0
     return {"value": args.rows * args.key_build_steps / dt, "unit": "examples/sec",
             "ms_per_step": dt / args.key_build_steps * 1e3, "steps": args.key_build_steps,
-            "what": "key build on the GPU (rocPRIM radix sort + unique/views/tiles kernels) + "
-                    "the step, per minibatch, raw keys resident in HBM"}
+            "what": "key build on the GPU (raw keys -> state rows through the table's settled "
+                    "tier, then a stable radix pass into cells) + the step, per minibatch, raw "
+                    "keys resident in HBM, nothing cached"}
 
 
 def stream_copy_gbs():
@@ -229,11 +244,44 @@ def cpu_baseline(args, batches):
                                                             rows / (t_step + t_build))}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would set), and wait for them.  Rank 0
+    prints the JSON line; the other ranks' stdout is dropped."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used"
+              % (args.gpus, world), file=sys.stderr)
+    if not args.keys_per_gpu:
+        args.keys_per_gpu = 10_000_000 if world == 1 else 12_500_000
     if args.optimizer is None:
         args.optimizer = "ftrl" if args.model == "lr" else "sgd"
     import torch
@@ -273,6 +321,8 @@ def main():
     R = compiled[0].R
     NNZ = int(np.mean([c.NNZ for c in compiled]))
     U = int(np.mean([c.U for c in compiled]))
+    if U == 0:   # local batches carry no key list: count the unique keys of two of them
+        U = int(np.mean([len(np.unique(b[1])) for b in batches[:2]]))
 
     def barrier():
         if dist is not None:
@@ -289,6 +339,12 @@ def main():
             trainer.predict(c)
         trainer.check()
         trainer.defrag()
+        if not sharded:
+            # the defrag renumbered the state rows: a forward-only pass rebuilds every
+            # minibatch's cells against the new numbering, outside the timed region
+            for c in compiled:
+                trainer.predict(c)
+            trainer.check()
     for i in range(args.warmup):
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
@@ -371,11 +427,16 @@ def main():
                                     args.keys_per_gpu, world, args.rows, args.nnz_per_row,
                                     ", zipf %.2f" % args.zipf if args.zipf else ", uniform")
     lr = args.model == "lr"
-    dom_kernel = {"resolve": "k_resolve", "gather": "k_gather", "update": "k_update",
-                  "forward": "k_lr_forward_tiled" if lr else "k_fm_forward",
-                  "gradient": "k_lr_grad_tiled" if lr else "k_fm_grad"}.get(dom, dom)
-    dom_note = {"resolve": " (Pull: resolve+gather)", "gradient": " (gradient+Push)"}.get(
+    names = {"resolve": "k_resolve", "gather": "k_gather", "update": "k_update",
+             "forward": "k_lr_forward_tiled" if lr else "k_fm_forward",
+             "gradient": "k_lr_grad_tiled" if lr else "k_fm_grad"}
+    if fused:
+        names.update(forward="k_lr_fwd_cells", gradient="k_lr_grad_cells")
+    dom_kernel = names.get(dom, dom)
+    dom_note = {"forward": " (+ k_lr_finalize_cells)", "gradient": " (gradient+Push)"}.get(
         dom, "") if fused else ""
+    impl = impl_bytes_cells(R, NNZ, U, args.optimizer, compiled[0].cells_info(),
+                            args.keys_per_gpu) if fused else {}
     out = {
         "metric": "examples/sec", "value": R * world * args.steps / dt, "unit": "examples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -392,6 +453,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
                      "algorithmic_bytes_per_launch": per[dom],
+                     "algorithmic_bytes_source": "SURVEY.md 8(d)" if fused else
+                     "this implementation's per-kernel byte model (bench.py: bytes_model)",
                      "avg_launch_ms": avg_ms[dom]},
         "logloss": logloss,
         "kernels_ms": avg_ms, "kernel_timing": kernel_timing,
@@ -401,9 +464,8 @@ def main():
             k: {"achieved": per[k] / (avg_ms[k] * 1e-3) / 1e9,
                 "frac": per[k] / (avg_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": per[k],
-                "traffic": pmc_traffic({"resolve": "k_pull_settled", "forward": "k_lr_forward_tiled",
-                                        "gradient": "k_lr_grad_tiled"}.get(k, k), workload)
-                if fused else None}
+                "implementation_bytes_per_launch": impl.get(k),
+                "traffic": pmc_traffic(names.get(k, k), workload) if fused else None}
             for k in avg_ms if k in per and avg_ms[k] > 0 and per[k] > 0},
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -77,6 +77,8 @@ int xf_reader_next_into(xf_reader *r, xf_block *blk, size_t *rows_out, size_t *n
                         const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,
                         const int32_t **labels);
 
+typedef struct xf_table xf_table;
+
 /* ---------------------------------------------------------------- compiled minibatch  */
 /* Host-side key build (lr_worker.cc:146-166): sorted unique keys (== unique_keys, the
  * Pull/Push key list) + the two views of all_keys the kernels walk:
@@ -98,6 +100,22 @@ int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys, const uint32_t 
                          const int32_t *d_labels, uint32_t R, uint32_t NNZ, void *stream);
 int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                          const int32_t *labels, size_t row_begin, size_t row_end, void *stream);
+/* The key build for a table on THIS GPU, without the sort (LR): every raw key is resolved
+ * straight to its state row in `t` (insert on first touch, ftrl.h:56; the table grows when
+ * needed) and the nonzeros are grouped into cells (row window x 4096-row chunk of the state)
+ * by a stable radix pass — no unique-key list, the state row is the key's identity.  The
+ * result feeds xf_lr_step / xf_lr_predict on `t` only.  retain_keys != 0 keeps the raw arrays
+ * on the device so that the batch survives a renumbering of the rows (xf_table_defrag). */
+int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
+                               const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                               uint32_t NNZ, int retain_keys, void *stream);
+int xf_batch_compile_local(xf_batch **out, xf_table *t, const uint64_t *rowptr,
+                           const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                           size_t row_end, int retain_keys, void *stream);
+/* shape of a batch's cells once a step / predict has built them: out[0..8) = rows per window,
+ * windows, chunks, forward workgroups per window, gradient work items, 0 (reserved), chunks
+ * cut into several work items, size of the index space */
+int xf_batch_cells_info(const xf_batch *b, uint32_t *out);
 /* copy a device-built batch's arrays into its host views (xf_batch_host etc. do it on demand) */
 int xf_batch_download(xf_batch *b);
 int xf_batch_free(xf_batch *b);
@@ -186,7 +204,6 @@ typedef struct {
 } xf_table_config;
 void xf_table_config_default(xf_table_config *cfg); /* reference defaults, FTRL, dim 1 */
 
-typedef struct xf_table xf_table;
 int xf_table_create(xf_table **out, const xf_table_config *cfg); /* on current device */
 int xf_table_destroy(xf_table *t);
 int xf_table_size(xf_table *t, uint64_t *nkeys); /* synchronises */
@@ -276,6 +293,11 @@ int xf_fm_step(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws, void *st
 int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *pctr_out);
 int xf_fm_predict(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws,
                   float *pctr_out);
+/* parity hook of the LR step: when enabled, the step also stores the pulled weights and the
+ * gradients per unique key of the minibatch for xf_workspace_fetch (the production step never
+ * forms them: the forward reads the table in place, the gradient is consumed where it is
+ * summed).  Needs a minibatch with a key list (xf_batch_compile*). */
+int xf_workspace_capture(xf_workspace *ws, int enable);
 /* copies of the last step's intermediates to host (parity hook): any pointer may be NULL */
 int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
                        size_t R);

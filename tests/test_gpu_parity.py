@@ -312,7 +312,7 @@ def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)
     s_ref = O.Store(O.OPT_FTRL, 1)      # reference arithmetic (fp32 running sums)
     s_exact = O.Store(O.OPT_FTRL, 1)    # exact-sum mode
-    ws = capi.Workspace()
+    ws = capi.Workspace(capture=True)
     for step in range(4):
         rowptr, keys, labels = synth(rng, R, nnz, nkeys, zipf, ragged)
         b = capi.Batch(rowptr, keys, labels)
@@ -358,7 +358,7 @@ def test_lr_forward_panel_kernel_bit_exact():
         assert b.panels()[0] >= 8
         ob = O.Batch(rowptr, keys, labels)
         t, s = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 17), O.Store(O.OPT_FTRL, 1)
-        ws = capi.Workspace()
+        ws = capi.Workspace(capture=True)
         for _ in range(3):
             capi.lr_step(t, b, ws)
             with O.sum_mode(1):
@@ -545,7 +545,7 @@ def test_full_size_properties(big_batch):
     b, fid = big_batch
     assert b.NNZ == 10_000_000 and b.U == len(np.unique(fid))
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 24)
-    ws = capi.Workspace()
+    ws = capi.Workspace(capture=True)
     h = b.host()
     # (1) linearity of the forward: import w = c for every key -> wx = c * nnz exactly
     c = np.float32(2.0 ** -10)

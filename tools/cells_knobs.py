@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Experiment driver (GPU box): the LR step of the config-2 shape under the exp_knob variants
+of the cells kernels (parts switched off to see what each part costs).  Not a benchmark."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from xflow_amd import capi  # noqa: E402
+from xflow_amd.single import SingleGpuTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--knobs", default="0")
+    ap.add_argument("--zipf", type=float, default=0.0)
+    ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
+    a = ap.parse_args()
+    args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=a.batches,
+                              zipf=a.zipf)
+    nkeys = 10_000_000
+    keytab = capi.hash_decimal_range(0, nkeys)
+    batches = bench.make_batches(args, 0, nkeys, keytab)
+    tr = SingleGpuTrainer(model="lr", optimizer="ftrl", capacity=2 * nkeys + 1024)
+    comp = [tr.compile(*b) for b in batches]
+    tr.check()
+    tr.defrag()
+    for c in comp:
+        tr.predict(c)
+    print(json.dumps(comp[0].cells_info()))
+    for knob in [int(x) for x in a.knobs.split(",")]:
+        capi.tune("exp_knob", knob)
+        for i in range(4):
+            tr.step(comp[i % len(comp)])
+        tr.check()
+        tr.profile(True)
+        for i in range(a.steps):
+            tr.step(comp[i % len(comp)])
+        ms, n = tr.profile_read()
+        tr.profile(False)
+        print("knob %3d  forward %.1f us  gradient %.1f us" % (
+            knob, ms["forward"] / n * 1e3, ms["gradient"] / n * 1e3), flush=True)
+    capi.tune("exp_knob", 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxflow_amd.so")
+LIB_PATH = os.environ.get("XF_LIB") or os.path.join(_HERE, "lib", "libxflow_amd.so")
 
 XF_OK = 0
 OPT_FTRL, OPT_SGD = 0, 1
@@ -72,6 +72,12 @@ SIGNATURES = {
     "xf_batch_compile_gpu": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t,
                                        C.c_size_t, vp]),
     "xf_batch_download": (C.c_int, [vp]),
+    "xf_batch_compile_local_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, C.c_uint32,
+                                             C.c_uint32, C.c_int, vp]),
+    "xf_batch_compile_local": (C.c_int, [C.POINTER(vp), vp, u64p, u64p, i32p, C.c_size_t,
+                                         C.c_size_t, C.c_int, vp]),
+    "xf_batch_cells_info": (C.c_int, [vp, u32p]),
+    "xf_workspace_capture": (C.c_int, [vp, C.c_int]),
     "xf_batch_dims": (C.c_int, [vp, u32p, u32p, u32p, u32p]),
     "xf_batch_host": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(u32p),
                                 C.POINTER(u32p), C.POINTER(u32p), C.POINTER(i32p),
@@ -136,6 +142,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The torch wheel bundles its own libamdhip64.so.7; this
+    library links the one under /opt/rocm.  Both have the same SONAME, so whichever is mapped
+    first serves everybody — and torch finds no GPU when it is handed /opt/rocm's.  When torch
+    is installed (it is only plumbing here: device buffers and process groups of the multi-GPU
+    driver and of some tests) map ITS runtime first, whether or not torch gets imported later."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the shared library; raise (never fall back) when it is missing."""
     global _lib
@@ -143,6 +173,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise XFError("libxflow_amd.so is not built: run `python -m xflow_amd.build` "
                           "(there is no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)
@@ -299,6 +330,40 @@ class Batch:
         return v
 
 
+class LocalBatch:
+    """A minibatch compiled straight against one table on this GPU (xf_batch_compile_local):
+    raw keys -> state rows -> cells; no key list.  Feeds lr_step / lr_predict on that table."""
+
+    def __init__(self, table, rowptr, keys, labels, row_begin=0, row_end=None, retain_keys=True):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if row_end is None:
+            row_end = len(rowptr) - 1
+        self.h = vp()
+        check(lib().xf_batch_compile_local(C.byref(self.h), table.h, _p(rowptr, u64p),
+                                           _p(keys, u64p), _p(labels, i32p), row_begin, row_end,
+                                           1 if retain_keys else 0, None))
+        R, N = C.c_uint32(), C.c_uint32()
+        check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), None, None))
+        self.R, self.NNZ, self.U, self.H = R.value, N.value, 0, 0
+
+    def cells_info(self):
+        return cells_info(self)
+
+    def upload(self, stream=None):
+        return self
+
+    __del__ = Batch.__del__
+
+
+def cells_info(batch):
+    out = (C.c_uint32 * 8)()
+    check(lib().xf_batch_cells_info(batch.h, out))
+    names = ["W", "nwin", "nchunk", "G", "nitems", "reserved", "nsplit_chunks", "M"]
+    return dict(zip(names, list(out)))
+
+
 class Table:
     """One GPU's shard of the parameter table (ps-lite server replacement)."""
 
@@ -395,9 +460,13 @@ class Table:
 
 
 class Workspace:
-    def __init__(self):
+    def __init__(self, capture=False):
+        """capture=True: LR steps also keep the pulled weights and gradients per unique key for
+        fetch() (the parity hook; the production step never forms them)."""
         self.h = vp()
         check(lib().xf_workspace_create(C.byref(self.h)))
+        if capture:
+            check(lib().xf_workspace_capture(self.h, 1))
 
     def __del__(self):
         try:
@@ -413,6 +482,11 @@ class Workspace:
         g = np.empty(U, np.float32)
         check(lib().xf_workspace_fetch(self.h, _p(wu, f32p), _p(loss, f32p), _p(g, f32p), U, R))
         return wu, loss, g
+
+    def fetch_loss(self, R):
+        loss = np.empty(R, np.float32)
+        check(lib().xf_workspace_fetch(self.h, None, _p(loss, f32p), None, 0, R))
+        return loss
 
     def profile(self, enable):
         check(lib().xf_workspace_profile(self.h, 1 if enable else 0))

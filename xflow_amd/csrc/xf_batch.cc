@@ -326,13 +326,20 @@ extern "C" int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const ui
   return XF_OK;
 }
 
+namespace xf {
+void cells_free(xf_cells *c);
+}
+
 extern "C" int xf_batch_free(xf_batch *b) {
   if (!b) return XF_OK;
-  if (b->d_blob) {
+  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u) {
     // kernels still running on the batch must finish first (hipFree used to imply that)
     (void)hipDeviceSynchronize();
-    xf::blob_free(b->d_blob, b->d_blob_bytes);
   }
+  if (b->d_blob) xf::blob_free(b->d_blob, b->d_blob_bytes);
+  if (b->cells) xf::cells_free(b->cells);
+  if (b->d_raw) (void)hipFree(b->d_raw);
+  if (b->d_rows_u) (void)hipFree(b->d_rows_u);
   delete b;
   return XF_OK;
 }

@@ -6,6 +6,8 @@
 
 #include "xf_common.h"
 
+struct xf_cells;
+
 struct xf_batch {
   uint32_t R = 0, NNZ = 0, U = 0, H = 0;
   std::vector<uint64_t> ukeys;
@@ -21,6 +23,19 @@ struct xf_batch {
   void *d_blob = nullptr;  // one device allocation holding all arrays
   size_t d_blob_bytes = 0;
   xf_dev_batch view{};
+  // the cell-sorted form the LR kernels stream (xf_cells.h), compiled against ONE table's row
+  // numbering (rebuilt when another table or another epoch of it comes along)
+  xf_cells *cells = nullptr;
+  uint32_t *d_rows_u = nullptr;  // state row of each unique key [U] (batches with a key list)
+  // "local" batches (xf_batch_compile_local_*): no key list at all — the raw keys were resolved
+  // straight to state rows.  The raw arrays are kept (device) when the cells must be
+  // rebuildable after the table renumbers its rows.
+  bool local = false;
+  void *d_raw = nullptr;  // keys u64[NNZ] | rowptr u32[R+1] | labels i32[R]
+  size_t d_raw_bytes = 0;
+  const uint64_t *raw_keys = nullptr;
+  const uint32_t *raw_rowptr = nullptr;
+  const int32_t *raw_labels = nullptr;
 };
 
 namespace xf {

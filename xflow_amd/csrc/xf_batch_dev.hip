@@ -28,6 +28,7 @@
 
 #include "xf_batch.h"
 #include "xf_common.h"
+#include "xf_scratch.h"
 #include "xf_tiling.h"
 
 namespace xf {
@@ -201,51 +202,7 @@ __global__ void k_panel_first(const uint32_t *__restrict__ scan, uint32_t R, uin
   panel_first[p] = p < P ? scan[(size_t)p * (R + 1)] : total;
 }
 
-// Scratch for one build: a bump allocator over one persistent device arena (a build
-// synchronises its stream before it returns, so the arena can be reused by the next one).
-// Scratch objects nest like a stack (xf_batch_compile_gpu -> xf_batch_compile_dev).
-struct Arena {
-  char *base = nullptr;
-  size_t cap = 0, used = 0, high = 0;  // high = bytes the deepest nesting wanted
-};
-Arena &arena() {
-  static thread_local Arena a;
-  return a;
-}
-
-struct Scratch {
-  size_t mark;
-  std::vector<void *> overflow;  // when the arena was too small: plain allocations
-  size_t spilled = 0;
-  Scratch() : mark(arena().used) {}
-  ~Scratch() {
-    for (void *p : overflow) (void)hipFree(p);
-    Arena &a = arena();
-    a.high = std::max(a.high, a.used + spilled);
-    a.used = mark;
-    if (mark == 0 && a.high > a.cap) {  // outermost scope: grow for the next build
-      if (a.base) (void)hipFree(a.base);
-      a.base = nullptr;
-      a.cap = 0;
-      const size_t want = a.high + a.high / 4;
-      if (hipMalloc((void **)&a.base, want) == hipSuccess) a.cap = want;
-    }
-  }
-  template <typename T>
-  int get(T **p, size_t n) {
-    const size_t bytes = ((std::max<size_t>(n, 1) * sizeof(T)) + 255) & ~(size_t)255;
-    Arena &a = arena();
-    if (a.used + bytes <= a.cap) {
-      *p = (T *)(a.base + a.used);
-      a.used += bytes;
-      return XF_OK;
-    }
-    spilled += bytes;
-    XF_HIP(hipMalloc((void **)p, bytes));
-    overflow.push_back(*p);
-    return XF_OK;
-  }
-};
+using xf::Scratch;
 
 int exclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
   size_t tb = 0;

@@ -1,0 +1,95 @@
+// xf_cells.h — the cell-sorted minibatch ("cells") the LR kernels stream.
+//
+// One array of 4-byte entries, one per nonzero, grouped by CELL = (row window, key chunk):
+//   row window  W <= kWinMax consecutive examples of the minibatch (their fp64 row accumulators
+//               fit a CU's LDS: 17408 x 8 B = 136 KiB),
+//   key chunk   kChunk = 4096 consecutive positions of the INDEX SPACE the batch was compiled
+//               against: state rows of a table on this GPU (mode kCellsTableRows), or the
+//               batch's own sorted-unique-key index (mode kCellsUidx, the multi-GPU worker side,
+//               where the weights arrive as a dense U-array from the owning shards).
+//   entry       (chunk number & 31) << 27 | (row within the window) << 12 | (position within
+//               the chunk)
+// and cellptr[nwin * nchunk + 1], the offsets of the cells in window-major order.  Inside a
+// cell the entries keep the row-major order of the input (the grouping is a stable sort on the
+// cell number), i.e. they are sorted by row.
+//
+// Both sparse products of the step read this one stream:
+//   forward   wx[row] += w[idx]     a workgroup owns a slice of ONE window's entries; the
+//                                   window's row sums live in LDS (fp64 atomics), the gathers
+//                                   of w stay inside one 16 KiB chunk at a time (L1-resident)
+//   gradient  g[idx]  += loss[row]  a workgroup owns ONE chunk (all windows); the chunk's 4096
+//                                   sums live in LDS, the loss gathers of a cell walk the
+//                                   window's rows in ascending order
+// which replaces the CSR (rowptr/uidx), its panel-major copy (pptr/pidx), the key-grouped COO
+// (segptr/coo_row) and the tile lists of the round-1 layout: 4 bytes per nonzero instead of
+// ~20, and no Pull pass (the forward reads the table's weight array in place).
+#ifndef XF_CELLS_H_
+#define XF_CELLS_H_
+
+#include <stdint.h>
+
+#include "xf_common.h"
+
+namespace xf {
+
+#ifndef XF_CHUNK_BITS
+#define XF_CHUNK_BITS 11
+#endif
+#ifndef XF_WIN_MAX
+#define XF_WIN_MAX 17408
+#endif
+constexpr int kChunkBits = XF_CHUNK_BITS;
+constexpr uint32_t kChunk = 1u << kChunkBits;  // index positions per chunk
+constexpr uint32_t kWinMax = XF_WIN_MAX;       // rows per window (136 KiB of fp64 in LDS)
+constexpr uint32_t kRowMask = 0x7FFFu;         // 15 bits of row-in-window
+constexpr int kTagShift = 27;                  // low 5 bits of the chunk number
+constexpr uint32_t kBlk = 1024;                // entries per forward block (blk_cell granule)
+constexpr uint32_t kSliceMax = 8192;           // entries one gradient workgroup takes of a chunk
+constexpr uint32_t kNoDump = 0xFFFFFFFFu;
+
+enum { kCellsTableRows = 0, kCellsUidx = 1 };
+
+}  // namespace xf
+
+struct xf_cells {
+  uint32_t R = 0, NNZ = 0, M = 0;  // rows, nonzeros, size of the index space
+  uint32_t W = 1, nwin = 1, nchunk = 1, ncell = 1, nblk = 0;
+  uint32_t G = 1;                  // forward workgroups per window
+  uint32_t nitems = 0, nsplit_chunks = 0;
+  int mode = xf::kCellsUidx;
+  uint64_t table_uid = 0, epoch = 0;  // kCellsTableRows: valid for this table at this epoch
+  char *blob = nullptr;               // one device allocation
+  size_t blob_bytes = 0;
+  uint32_t *entries = nullptr;      // [NNZ] cells sorted by row (the gradient's stream)
+  uint32_t *entries_k = nullptr;    // [NNZ] the same cells sorted by key (the forward's stream)
+  uint32_t *cellptr = nullptr;      // [ncell + 1]
+  uint32_t *blk_cell = nullptr;     // [nblk + 1] cell of entry kBlk*b; [nblk] = ncell - 1
+  uint32_t *item_chunk = nullptr;   // [nitems]   gradient work items: chunk,
+  uint32_t *item_slice = nullptr;   // [nitems]   slice | nslices << 16,
+  uint32_t *item_dump = nullptr;    // [nitems]   index of the chunk among the split ones
+  uint32_t *split_chunk = nullptr;  // [nsplit_chunks] chunks cut into several items
+  double *gsum = nullptr;           // [nsplit_chunks * kChunk] their key sums (fp64 atomics)
+  uint8_t *gtouched = nullptr;      // [nsplit_chunks * kChunk] 1 = the minibatch holds the key
+  size_t split_bytes = 0;           // gsum + gtouched: cleared before every gradient pass
+};
+
+namespace xf {
+
+// Build the cells of a minibatch on the device.  idx[NNZ]: index-space position of every
+// nonzero in row-major order — map == null: idx[j] = src[j]; else idx[j] = map[src[j]] (the
+// unique-key index of a compiled batch mapped to table rows).  Synchronises `stream`.
+int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
+                const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
+                hipStream_t stream);
+void cells_free(xf_cells *c);
+
+// scratch of the forward: G * nwin * W partial row sums (fp64)
+size_t cells_partial_doubles(const xf_cells *c);
+
+// forward: loss[r] = sigmoid(sum_j w[idx_j]) - label[r]   (lr_worker.cc:121-143)
+int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,
+                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t stream);
+
+}  // namespace xf
+
+#endif  // XF_CELLS_H_

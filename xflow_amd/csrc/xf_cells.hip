@@ -1,0 +1,770 @@
+// xf_cells.hip — the cell-sorted minibatch and the LR kernels that stream it (gfx950).
+//
+// Replaces (paths relative to /root/reference):
+//   key build of LRWorker::update      src/model/lr/lr_worker.cc:146-166  (cells_build)
+//   LRWorker::calculate_loss           src/model/lr/lr_worker.cc:121-143  (k_lr_fwd_cells,
+//                                                                          k_lr_finalize_cells)
+//   LRWorker::calculate_gradient       src/model/lr/lr_worker.cc:100-119  (k_lr_grad_cells)
+//   KVWorker::Push -> FTRL / SGD       src/optimizer/ftrl.h:54-74, sgd.h:52 (fused in the same)
+// Layout and rationale: xf_cells.h.  HBM-bound integer/byte work, no MFMA.
+//
+// Numerics: a row's / a key's sum is accumulated in fp64 (LDS atomics) and rounded to fp32
+// once, where the reference holds an fp32 value.  fp64 addition of fp32 addends is exact —
+// hence independent of the order the atomics land in — as long as the addends of one sum span
+// fewer than 2^(29 - log2 n) in magnitude (n addends); beyond that the LAST BIT of the fp64
+// sum may depend on the order, which changes the fp32 result with probability ~n * 2^-29.
+// The reference's own order inside a key is std::sort's (unspecified, lr_worker.cc:162).
+// Chunks with more than kSliceMax entries (power-law heads) are cut into slices whose partial
+// sums are added in slice order by a second kernel.
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "xf_batch.h"
+#include "xf_cells.h"
+#include "xf_device.h"
+#include "xf_scratch.h"
+
+namespace {
+
+using xf::kBlk;
+using xf::kChunk;
+using xf::kChunkBits;
+using xf::kNoDump;
+using xf::kSliceMax;
+using xf::kWinMax;
+using xf::kRowMask;
+using xf::kTagShift;
+
+constexpr int kBlock = 256;
+constexpr int kFwdBlock = 1024;  // one forward workgroup per CU (its LDS holds a row window)
+constexpr uint32_t kFwdGroups = 256;
+
+inline int grid_for(size_t n, int block = kBlock) {
+  size_t g = (n + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define XF_GRID_STRIDE(i, n)                                                     \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); \
+       i += (size_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------- build
+// (cell number, entry) of every nonzero, row-major.  One wavefront per row.
+__global__ void __launch_bounds__(kBlock)
+k_cell_keys(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ src,
+            const uint32_t *__restrict__ map, uint32_t R, uint32_t W, uint32_t nchunk,
+            uint32_t *__restrict__ cid, uint32_t *__restrict__ ent) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nw) {
+    const uint32_t v = r / W, rin = r - v * W;
+    for (uint32_t j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) {
+      const uint32_t s = src[j];
+      const uint32_t idx = map ? map[s] : s;
+      const uint32_t chunk = idx >> kChunkBits;
+      cid[j] = v * nchunk + chunk;
+      ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
+    }
+  }
+}
+
+// cellptr from the sorted cell numbers: work item j closes the cells between entry j-1's and
+// entry j's (j == n closes the tail)
+__global__ void __launch_bounds__(kBlock)
+k_cellptr(const uint32_t *__restrict__ cid_s, uint32_t n, uint32_t ncell,
+          uint32_t *__restrict__ cellptr) {
+  XF_GRID_STRIDE(j, (size_t)n + 1) {
+    const uint32_t first = j == 0 ? 0u : cid_s[j - 1] + 1;
+    const uint32_t last = j == n ? ncell : cid_s[j];
+    for (uint32_t c = first; c <= last; ++c) cellptr[c] = (uint32_t)j;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_blk_cell(const uint32_t *__restrict__ cid_s, uint32_t nblk, uint32_t ncell,
+           uint32_t *__restrict__ blk_cell) {
+  XF_GRID_STRIDE(b, (size_t)nblk + 1)
+  blk_cell[b] = b < nblk ? cid_s[(size_t)b * kBlk] : ncell - 1;
+}
+
+// gradient work items: chunk c is cut into ceil(n_c / kSliceMax) slices (none when empty)
+__global__ void __launch_bounds__(kBlock)
+k_chunk_slices(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
+               uint32_t *__restrict__ nsl, uint32_t *__restrict__ nsplit) {
+  XF_GRID_STRIDE(c, (size_t)nchunk + 1) {
+    uint32_t n = 0;
+    if (c < nchunk)
+      for (uint32_t v = 0; v < nwin; ++v)
+        n += cellptr[(size_t)v * nchunk + c + 1] - cellptr[(size_t)v * nchunk + c];
+    const uint32_t S = (n + kSliceMax - 1) / kSliceMax;
+    nsl[c] = S;
+    nsplit[c] = S > 1 ? 1u : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
+             const uint32_t *__restrict__ soff, uint32_t nchunk,
+             uint32_t *__restrict__ item_chunk, uint32_t *__restrict__ item_slice,
+             uint32_t *__restrict__ item_dump, uint32_t *__restrict__ split_chunk) {
+  XF_GRID_STRIDE(c, nchunk) {
+    const uint32_t S = nsl[c];
+    for (uint32_t s = 0; s < S; ++s) {
+      const uint32_t i = off[c] + s;
+      item_chunk[i] = (uint32_t)c;
+      item_slice[i] = s | (S << 16);
+      item_dump[i] = S > 1 ? soff[c] : kNoDump;
+    }
+    if (S > 1) split_chunk[soff[c]] = (uint32_t)c;
+  }
+}
+
+int exclusive_scan_u32(xf::Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
+                       hipStream_t s) {
+  size_t tb = 0;
+  XF_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::exclusive_scan(tmp, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+  return XF_OK;
+}
+
+// ------------------------------------------------------------------------------ forward
+// the cell of entry j, known to lie in [lo, hi]: the largest c with cellptr[c] <= j
+__device__ __forceinline__ uint32_t cell_of(const uint32_t *__restrict__ cellptr, uint32_t lo,
+                                            uint32_t hi, uint32_t j) {
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo + 1) / 2;
+    if (cellptr[mid] <= j) lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+
+// Workgroup (v, g) takes the g-th of G slices of window v's entries, cut at multiples of kBlk
+// in the entry stream.  Its 16 wavefronts pull blocks of kBlk entries (kFwdE per lane) off a
+// counter in LDS and keep the NEXT block's index loads in flight while they work on the
+// current one: the kernel is a chain of dependent loads — block bounds -> entries -> weights —
+// and with the row window in LDS only one workgroup fits a CU, so the memory parallelism has to
+// come from inside the wavefront (measured on the config-2 shape: the LDS atomics cost nothing,
+// the weight gathers ~26 us, the bare index stream ~20 us at 4 entries per lane).  The
+// window's row sums live in LDS as fp64; every entry costs one coalesced index load, one 4-byte
+// gather inside the cell's 16 KiB chunk of the weight array and one LDS atomic.  An entry's
+// cell follows from the block's first cell and the 5 chunk-number bits the entry carries; only
+// a block that spans 32 or more chunks (a sparse minibatch on a big table) searches cellptr.
+// The partial row sums of the G workgroups of a window are added by k_lr_finalize_cells.
+constexpr int kFwdE = (int)(kBlk / 64);
+
+struct FwdBlock {
+  uint32_t ent[kFwdE];
+  uint32_t lo, hi;
+};
+
+__device__ __forceinline__ void fwd_load(FwdBlock &B, const uint32_t *__restrict__ entries,
+                                         const uint32_t *__restrict__ blk_cell, uint32_t b,
+                                         uint32_t pb, uint32_t pe, uint32_t lane) {
+  B.lo = blk_cell[b];
+  B.hi = blk_cell[b + 1];
+#pragma unroll
+  for (int q = 0; q < kFwdE; ++q) {
+    const uint32_t j = b * kBlk + q * 64 + lane;
+    B.ent[q] = (j >= pb && j < pe) ? entries[j] : 0xFFFFFFFFu;
+  }
+}
+
+__device__ __forceinline__ void fwd_process(const FwdBlock &B, uint32_t b, uint32_t c0,
+                                            uint32_t nchunk, uint32_t lane,
+                                            const uint32_t *__restrict__ cellptr,
+                                            const float *__restrict__ w, double *wx) {
+  // the block may begin in the window before and end in the one after
+  const uint32_t lo = B.lo < c0 ? c0 : B.lo;
+  const uint32_t hi = B.hi >= c0 + nchunk ? c0 + nchunk - 1 : B.hi;
+  const bool near = hi - lo < 32u;  // wave-uniform
+  float wv[kFwdE];
+#pragma unroll
+  for (int q = 0; q < kFwdE; ++q) {
+    const uint32_t e = B.ent[q];
+    if (e == 0xFFFFFFFFu) continue;
+    const uint32_t cell = near ? lo + (((e >> kTagShift) - (lo - c0)) & 31u)
+                               : cell_of(cellptr, lo, hi, b * kBlk + q * 64 + lane);
+    wv[q] = w[(size_t)(cell - c0) * kChunk + (e & (kChunk - 1))];
+  }
+#pragma unroll
+  for (int q = 0; q < kFwdE; ++q) {
+    const uint32_t e = B.ent[q];
+    if (e != 0xFFFFFFFFu) atomicAdd(&wx[(e >> kChunkBits) & kRowMask], (double)wv[q]);
+  }
+}
+
+__global__ void __launch_bounds__(kFwdBlock)
+k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ cellptr,
+               const uint32_t *__restrict__ blk_cell, uint32_t nchunk, uint32_t W, uint32_t G,
+               const float *__restrict__ w, double *__restrict__ partial) {
+  __shared__ double wx[kWinMax];
+  __shared__ uint32_t next_blk;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t v = blockIdx.x / G, g = blockIdx.x - v * G;
+  for (uint32_t r = tid; r < W; r += kFwdBlock) wx[r] = 0.0;
+  const uint32_t c0 = v * nchunk;
+  const uint32_t wb = cellptr[c0], we = cellptr[c0 + nchunk];
+  const uint64_t n = we - wb;
+  uint32_t pb = g == 0 ? wb : (uint32_t)((wb + n * g / G) & ~(uint64_t)(kBlk - 1));
+  uint32_t pe = g == G - 1 ? we : (uint32_t)((wb + n * (g + 1) / G) & ~(uint64_t)(kBlk - 1));
+  if (pb < wb) pb = wb;
+  if (pe < pb) pe = pb;
+  const uint32_t b_first = pb / kBlk, b_end = pb < pe ? (pe - 1) / kBlk + 1 : b_first;
+  if (tid == 0) next_blk = b_first;
+  __syncthreads();
+  // (one block counter in HBM shared by the window's workgroups instead of a fixed split was
+  // tried against the 1.4x spread between the median and the slowest workgroup: 54 -> 67 us,
+  // the ticket's round trip to L2 sits in the dependent chain)
+  auto grab = [&]() -> uint32_t {  // the wavefront's next block
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(&next_blk, 1u);
+    return (uint32_t)__shfl((int)b, 0);
+  };
+  // Two block buffers that swap roles (no register copies: a copy of the prefetched block
+  // would wait for its loads and undo the prefetch)
+  FwdBlock A, B;
+  uint32_t ba = grab(), bb = 0;
+  if (ba < b_end) fwd_load(A, entries, blk_cell, ba, pb, pe, lane);
+  while (ba < b_end) {
+    bb = grab();
+    if (bb < b_end) fwd_load(B, entries, blk_cell, bb, pb, pe, lane);
+    fwd_process(A, ba, c0, nchunk, lane, cellptr, w, wx);
+    if (bb >= b_end) break;
+    ba = grab();
+    if (ba < b_end) fwd_load(A, entries, blk_cell, ba, pb, pe, lane);
+    fwd_process(B, bb, c0, nchunk, lane, cellptr, w, wx);
+  }
+  __syncthreads();
+  double *out = partial + (size_t)blockIdx.x * W;
+  for (uint32_t r = tid; r < W; r += kFwdBlock) out[r] = wx[r];
+}
+
+// loss[r] = sigmoid(sum of the window workgroups' partial sums of row r) - label.  Four lanes
+// per row, lane q adding the workgroups g = q mod 4; combined as (s0 + s1) + (s2 + s3): a
+// fixed association, the same bits every run.
+__global__ void __launch_bounds__(kBlock)
+k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restrict__ labels,
+                    uint32_t R, uint32_t W, uint32_t G, float *__restrict__ loss,
+                    float *__restrict__ pctr) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = t >> 2, q = t & 3u;
+  double a = 0.0;
+  if (r < R) {
+    const uint32_t v = r / W, rin = r - v * W;
+    const double *p = partial + (size_t)v * G * W + rin;
+    for (uint32_t g = q; g < G; g += 4) a += p[(size_t)g * W];
+  }
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
+  if (r >= R || q != 0) return;
+  const float pr = xf::sigmoid_ref((float)a);  // lr_worker.cc:141, base.h:54-63
+  if (pctr) pctr[r] = pr;
+  if (loss) loss[r] = pr - (float)labels[r];
+}
+
+// ----------------------------------------------------------------------------- gradient
+// One workgroup per work item = (chunk, slice).  The chunk's 4096 key sums live in LDS as
+// fp64; the item walks its share of the chunk's nwin cells: coalesced entry loads, loss
+// gathers that ascend through the window (a cell is sorted by row), one LDS atomic each.
+// Unsplit chunks (all of them unless a chunk holds > kSliceMax entries) finish in place:
+//   MODE 0  g = sum / R (lr_worker.cc:117), then the optimizer step on the key's state row
+//           (ftrl.h:59-74 / sgd.h:52): the Push fused into the gradient, state read and
+//           written once, coalesced, and only for the keys this minibatch touched
+//   MODE 1  g_out[idx] = g (the multi-GPU worker side: gradients travel to the owners)
+// The slices of a split chunk (power-law heads) add their sums into the chunk's accumulators
+// in HBM (fp64 atomics) and k_lr_grad_split_finish does the rest.
+__device__ __forceinline__ void apply_key(const xf::TableDev &T, int opt, size_t row, float g) {
+  if (opt == XF_OPT_FTRL) {
+    float w = T.w[row], nn, z;
+    xf::load_nz(T, row, nn, z);
+    xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+    T.w[row] = w;
+    xf::store_nz(T, row, nn, z);
+  } else {
+    T.w[row] = xf::sgd_step(T.lr, g, T.w[row]);
+  }
+}
+
+// add `val` to acc[k] for every active lane.  Same-address LDS atomics serialise (a wavefront
+// whose lanes all hold one key takes ~1 us for one ds_add_f64), and the head keys of a
+// power-law minibatch fill whole wavefronts.  So: a key that sits in two neighbouring lanes
+// (the cheap test: one cross-lane compare) is summed over all its lanes in registers and lands
+// as ONE atomic; up to three such keys per call, everything else one atomic per lane.
+// `touched` is a byte per key written with plain stores: every writer stores the same 1.
+__device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on, uint32_t k,
+                                         float val) {
+  const unsigned lane = threadIdx.x & 63u;
+  uint32_t kk = on ? k : (0x80000000u | lane);  // inactive lanes: a key nobody else has
+  for (int round = 0; round < 3; ++round) {
+    const unsigned long long cand = __ballot(kk == (uint32_t)__shfl_xor((int)kk, 1));
+    if (!cand) break;  // wave-uniform
+    const int leader = __ffsll((long long)cand) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)kk, leader);
+    const bool mine = kk == k0;
+    double sum = mine ? (double)val : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((int)lane == leader) {
+      atomicAdd(&acc[k0], sum);
+      touched[k0] = 1;
+    }
+    if (mine) kk = 0x80000000u | lane;
+  }
+  if (!(kk & 0x80000000u)) {
+    atomicAdd(&acc[kk], (double)val);
+    touched[kk] = 1;
+  }
+}
+
+#ifndef XF_GRAD_E
+#define XF_GRAD_E 8
+#endif
+constexpr int kGradE = XF_GRAD_E;  // entries per lane and round
+constexpr uint32_t kGradWin = 32;  // windows whose slice bounds fit the LDS table
+
+template <int OPT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
+                const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
+                const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
+                const uint32_t *__restrict__ item_dump, const float *__restrict__ loss,
+                uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
+                uint8_t *__restrict__ gtouched) {
+  __shared__ double acc[kChunk];
+  __shared__ uint8_t touched[kChunk];
+  __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = item_chunk[blockIdx.x];
+  const uint32_t sl = item_slice[blockIdx.x], s = sl & 0xFFFFu, S = sl >> 16;
+  for (uint32_t k = tid; k < kChunk; k += kBlock) {
+    acc[k] = 0.0;
+    touched[k] = 0;
+  }
+  // The item's share of the chunk's nwin cells as ONE index space: windows v0, v0+1, ... side
+  // by side (cum = running entry counts), so that a thread's loads of a round — entries, then
+  // the losses they point at — are all in flight together instead of window after window.
+  for (uint32_t v0 = 0; v0 < nwin; v0 += kGradWin) {
+    const uint32_t nv = min(nwin - v0, kGradWin);
+    __syncthreads();
+    if (tid < nv) {
+      const size_t cell = (size_t)(v0 + tid) * nchunk + c;
+      const uint32_t b = cellptr[cell], e = cellptr[cell + 1];
+      const uint64_t n = e - b;
+      sbase[tid] = b + (uint32_t)(n * s / S);
+      cum[tid + 1] = (uint32_t)(n * (s + 1) / S) - (uint32_t)(n * s / S);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      cum[0] = 0;
+      for (uint32_t v = 0; v < nv; ++v) cum[v + 1] += cum[v];
+    }
+    __syncthreads();
+    const uint32_t total = cum[nv];
+    for (uint32_t p0 = 0; p0 < total; p0 += kBlock * kGradE) {  // workgroup-uniform trip count
+      uint32_t ent[kGradE], vq[kGradE];
+      float l[kGradE];
+      uint32_t v = 0;
+#pragma unroll
+      for (int q = 0; q < kGradE; ++q) {
+        const uint32_t p = p0 + q * kBlock + tid;
+        ent[q] = 0xFFFFFFFFu;
+        vq[q] = 0;
+        if (p < total) {
+          while (p >= cum[v + 1]) ++v;  // p ascends with q: v never goes back
+          vq[q] = v;
+          ent[q] = entries[sbase[v] + (p - cum[v])];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kGradE; ++q)
+        l[q] = ent[q] != 0xFFFFFFFFu
+                   ? loss[(size_t)(v0 + vq[q]) * W + ((ent[q] >> kChunkBits) & kRowMask)]
+                   : 0.0f;
+#pragma unroll
+      for (int q = 0; q < kGradE; ++q)
+        add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), l[q]);
+    }
+  }
+  __syncthreads();
+  if (S > 1) {  // a slice of a split chunk: into the chunk's accumulators in HBM
+    const uint32_t slot = item_dump[blockIdx.x];
+    for (uint32_t k = tid; k < kChunk; k += kBlock)
+      if (touched[k]) {
+        unsafeAtomicAdd(&gsum[(size_t)slot * kChunk + k], acc[k]);
+        gtouched[(size_t)slot * kChunk + k] = 1;
+      }
+    return;
+  }
+  for (uint32_t k = tid; k < kChunk; k += kBlock) {
+    if (!touched[k]) continue;
+    const size_t idx = (size_t)c * kChunk + k;
+    if (idx >= M) continue;
+    const float g = (float)((double)(float)acc[k] / (1.0 * R));  // lr_worker.cc:117
+    if (g_out) g_out[idx] = g;
+    if (MODE == 0) apply_key(T, OPT, idx, g);
+  }
+}
+
+// the keys of the split chunks: one lane per key
+template <int OPT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
+                       const double *__restrict__ gsum, const uint8_t *__restrict__ gtouched,
+                       uint32_t R, uint32_t M, float *__restrict__ g_out) {
+  const uint32_t slot = blockIdx.x / (kChunk / kBlock);
+  const uint32_t k = (blockIdx.x % (kChunk / kBlock)) * kBlock + threadIdx.x;
+  if (!gtouched[(size_t)slot * kChunk + k]) return;
+  const size_t idx = (size_t)split_chunk[slot] * kChunk + k;
+  if (idx >= M) return;
+  const float g = (float)((double)(float)gsum[(size_t)slot * kChunk + k] / (1.0 * R));
+  if (g_out) g_out[idx] = g;
+  if (MODE == 0) apply_key(T, OPT, idx, g);
+}
+
+}  // namespace
+
+namespace xf {
+
+const TableDev &table_dev(const xf_table *t);
+uint64_t table_uid(const xf_table *t);
+uint64_t table_epoch(const xf_table *t);
+int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
+                      hipStream_t s, bool allow_grow);
+
+void cells_free(xf_cells *c) {
+  if (!c) return;
+  if (c->blob) (void)hipFree(c->blob);
+  delete c;
+}
+
+size_t cells_partial_doubles(const xf_cells *c) { return (size_t)c->G * c->nwin * c->W; }
+
+int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
+                const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
+                hipStream_t s) {
+  XF_REQUIRE(out && d_rowptr && (NNZ == 0 || d_src), "cells_build: null argument");
+  xf_cells *c = new xf_cells;
+  c->R = R;
+  c->NNZ = NNZ;
+  c->M = M;
+  c->mode = mode;
+  c->nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+  c->W = std::max<uint32_t>(1, (R + c->nwin - 1) / c->nwin);
+  c->nchunk = std::max<uint32_t>(1, (uint32_t)(((uint64_t)M + kChunk - 1) / kChunk));
+  const uint64_t ncell64 = (uint64_t)c->nwin * c->nchunk;
+  if (ncell64 >= 0x7FFFFFFFull) {
+    delete c;
+    return xf::set_error(XF_EINVAL, "cells_build: %llu cells", (unsigned long long)ncell64);
+  }
+  c->ncell = (uint32_t)ncell64;
+  c->nblk = (NNZ + kBlk - 1) / kBlk;
+  c->G = std::max<uint32_t>(1, kFwdGroups / c->nwin);
+  struct Guard {
+    xf_cells *c;
+    ~Guard() {
+      if (c) cells_free(c);
+    }
+  } guard{c};
+  Scratch sc;
+  uint32_t *cid = nullptr, *ent = nullptr, *cid_s = nullptr, *ent_s = nullptr;
+  XF_TRY(sc.get(&cid, NNZ));
+  XF_TRY(sc.get(&ent, NNZ));
+  XF_TRY(sc.get(&cid_s, NNZ));
+  XF_TRY(sc.get(&ent_s, NNZ));
+  uint32_t *cellptr = nullptr, *blk_cell = nullptr;
+  XF_TRY(sc.get(&cellptr, (size_t)c->ncell + 1));
+  XF_TRY(sc.get(&blk_cell, (size_t)c->nblk + 1));
+  if (NNZ) {
+    hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr,
+                       d_src, d_map, R, c->W, c->nchunk, cid, ent);
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < ncell64) ++bits;
+    size_t tb = 0;
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, ent, ent_s, (size_t)NNZ, 0, bits, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, ent, ent_s, (size_t)NNZ, 0, bits, s));
+  }
+  hipLaunchKernelGGL(k_cellptr, dim3(grid_for((size_t)NNZ + 1)), dim3(kBlock), 0, s, cid_s, NNZ,
+                     c->ncell, cellptr);
+  hipLaunchKernelGGL(k_blk_cell, dim3(grid_for((size_t)c->nblk + 1)), dim3(kBlock), 0, s, cid_s,
+                     c->nblk, c->ncell, blk_cell);
+  // gradient work items
+  const size_t nc1 = (size_t)c->nchunk + 1;
+  uint32_t *nsl = nullptr, *nsplit = nullptr, *off = nullptr, *soff = nullptr;
+  XF_TRY(sc.get(&nsl, nc1));
+  XF_TRY(sc.get(&nsplit, nc1));
+  XF_TRY(sc.get(&off, nc1));
+  XF_TRY(sc.get(&soff, nc1));
+  hipLaunchKernelGGL(k_chunk_slices, dim3(grid_for(nc1)), dim3(kBlock), 0, s, cellptr, c->nchunk,
+                     c->nwin, nsl, nsplit);
+  XF_TRY(exclusive_scan_u32(sc, nsl, off, nc1, s));
+  XF_TRY(exclusive_scan_u32(sc, nsplit, soff, nc1, s));
+  uint32_t totals[2] = {0, 0};
+  XF_HIP(hipMemcpyAsync(&totals[0], off + c->nchunk, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(&totals[1], soff + c->nchunk, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  c->nitems = totals[0];
+  c->nsplit_chunks = totals[1];
+  // the batch's own allocation
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_ent = 0;
+  const size_t o_entk = o_ent + al((size_t)NNZ * 4);
+  const size_t o_cellptr = o_entk + al((size_t)NNZ * 4);
+  const size_t o_blk = o_cellptr + al(((size_t)c->ncell + 1) * 4);
+  const size_t o_ic = o_blk + al(((size_t)c->nblk + 1) * 4);
+  const size_t o_is = o_ic + al((size_t)c->nitems * 4);
+  const size_t o_id = o_is + al((size_t)c->nitems * 4);
+  const size_t o_sc = o_id + al((size_t)c->nitems * 4);
+  const size_t o_gd = o_sc + al((size_t)c->nsplit_chunks * 4);
+  const size_t o_td = o_gd + al((size_t)c->nsplit_chunks * kChunk * 8);
+  const size_t total = o_td + al((size_t)c->nsplit_chunks * kChunk) + 256;
+  c->split_bytes = o_td + al((size_t)c->nsplit_chunks * kChunk) - o_gd;
+  XF_HIP(hipMalloc((void **)&c->blob, total));
+  c->blob_bytes = total;
+  char *d = c->blob;
+  c->entries = (uint32_t *)(d + o_ent);
+  c->entries_k = (uint32_t *)(d + o_entk);
+  c->cellptr = (uint32_t *)(d + o_cellptr);
+  c->blk_cell = (uint32_t *)(d + o_blk);
+  c->item_chunk = (uint32_t *)(d + o_ic);
+  c->item_slice = (uint32_t *)(d + o_is);
+  c->item_dump = (uint32_t *)(d + o_id);
+  c->split_chunk = (uint32_t *)(d + o_sc);
+  c->gsum = (double *)(d + o_gd);
+  c->gtouched = (uint8_t *)(d + o_td);
+  if (NNZ) {
+    XF_HIP(hipMemcpyAsync(c->entries, ent_s, (size_t)NNZ * 4, hipMemcpyDeviceToDevice, s));
+    // the forward's copy: every cell sorted by its entries' low 12 bits (the position within
+    // the chunk), stable, so that neighbouring lanes gather neighbouring weights
+    size_t tb = 0;
+    XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, ent_s, c->entries_k, (size_t)NNZ,
+                                              (unsigned)c->ncell, cellptr, cellptr + 1, 0,
+                                              kChunkBits, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, ent_s, c->entries_k, (size_t)NNZ,
+                                              (unsigned)c->ncell, cellptr, cellptr + 1, 0,
+                                              kChunkBits, s));
+  }
+  XF_HIP(hipMemcpyAsync(c->cellptr, cellptr, ((size_t)c->ncell + 1) * 4, hipMemcpyDeviceToDevice, s));
+  XF_HIP(hipMemcpyAsync(c->blk_cell, blk_cell, ((size_t)c->nblk + 1) * 4, hipMemcpyDeviceToDevice, s));
+  if (c->nitems)
+    hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, nsl, off, soff,
+                       c->nchunk, c->item_chunk, c->item_slice, c->item_dump, c->split_chunk);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  guard.c = nullptr;
+  *out = c;
+  return XF_OK;
+}
+
+int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,
+                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t s) {
+  XF_REQUIRE(c && d_w && d_partial && (d_loss || d_pctr), "cells_lr_forward: null argument");
+  if (c->R == 0) return XF_OK;
+  hipLaunchKernelGGL(k_lr_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->entries_k,
+                     c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, d_w, d_partial);
+  hipLaunchKernelGGL(k_lr_finalize_cells,
+                     dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                     d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+template <int OPT, int MODE>
+static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss, float *d_g,
+                       hipStream_t s) {
+  if (c->nsplit_chunks) XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
+  hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE>), dim3(c->nitems), dim3(kBlock), 0, s, T,
+                     c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                     c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, c->gsum, c->gtouched);
+  if (c->nsplit_chunks)
+    hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
+                       dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
+                       c->split_chunk, c->gsum, c->gtouched, c->R, c->M, d_g);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+// gradient only: g_out[idx] for every index position the minibatch touches
+int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_t s) {
+  XF_REQUIRE(c && d_loss && d_g, "cells_lr_grad: null argument");
+  if (c->nitems == 0) return XF_OK;
+  return launch_grad<XF_OPT_SGD, 1>(c, TableDev{}, d_loss, d_g, s);
+}
+
+// gradient + Push on the table the cells were compiled against (d_g: optional dense copy of
+// the gradients, indexed by state row — the parity hook)
+int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
+                         hipStream_t s) {
+  XF_REQUIRE(c && t && d_loss, "cells_lr_grad_update: null argument");
+  XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update: cells are not table rows");
+  if (c->nitems == 0) return XF_OK;
+  const TableDev &T = table_dev(t);
+  XF_REQUIRE(T.dim == 1, "cells_lr_grad_update: dim must be 1");
+  if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, d_g, s);
+  return launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, d_g, s);
+}
+
+}  // namespace xf
+
+// ---------------------------------------------------------------- cells of a compiled batch
+namespace xf {
+
+// Make b->cells the cells of `b` against table `t`'s current row numbering.  Batches with a
+// key list (xf_batch_compile*): Pull's key -> row resolve (insert on first touch, ftrl.h:56)
+// over the sorted unique keys, then uidx -> row.  Local batches: the retained raw keys are
+// resolved again.  Either way this is where the minibatch's keys enter the table — what the
+// Pull of LRWorker::update does (lr_worker.cc:170).
+int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s) {
+  const uint64_t uid = table_uid(t), ep = table_epoch(t);
+  if (b->cells && b->cells->mode == kCellsTableRows && b->cells->table_uid == uid &&
+      b->cells->epoch == ep)
+    return XF_OK;
+  if (b->cells) {
+    XF_HIP(hipDeviceSynchronize());
+    cells_free(b->cells);
+    b->cells = nullptr;
+  }
+  xf_cells *c = nullptr;
+  if (b->local) {
+    XF_REQUIRE(b->raw_keys || b->NNZ == 0,
+               "this minibatch was compiled against another table (or the table has renumbered "
+               "its rows since) and did not keep its keys: compile it again, or with "
+               "retain_keys = 1");
+    Scratch sc;
+    uint32_t *idx = nullptr;
+    XF_TRY(sc.get(&idx, b->NNZ));
+    XF_TRY(table_resolve_any(t, b->raw_keys, b->NNZ, idx, s, true));
+    const uint64_t M = table_dev(t).max_rows + 1;
+    XF_TRY(cells_build(&c, idx, nullptr, b->raw_rowptr, b->R, b->NNZ, (uint32_t)M,
+                       kCellsTableRows, s));
+  } else {
+    XF_TRY(xf_batch_upload(b, s));
+    if (!b->d_rows_u) XF_HIP(hipMalloc((void **)&b->d_rows_u, std::max<size_t>(b->U, 1) * 4));
+    XF_TRY(xf_table_resolve_dev(t, b->view.ukeys, b->U, b->d_rows_u, s));
+    const uint64_t M = table_dev(t).max_rows + 1;
+    XF_TRY(cells_build(&c, b->view.uidx, b->d_rows_u, b->view.rowptr, b->R, b->NNZ, (uint32_t)M,
+                       kCellsTableRows, s));
+  }
+  c->table_uid = uid;
+  c->epoch = ep;
+  b->cells = c;
+  return XF_OK;
+}
+
+}  // namespace xf
+
+// The key build of LRWorker::update (lr_worker.cc:146-166) for a table on THIS GPU, without
+// the sort: every raw key is resolved straight to its state row (insert on first touch,
+// growing the table when needed) and the nonzeros are grouped into cells by a stable radix
+// pass on (row window, row chunk).  No unique-key list is formed: the key's state row IS its
+// identity, the forward reads the table's weights in place and the gradient pass applies the
+// optimizer step where it sums.  retain_keys: keep a device copy of the raw arrays so that the
+// cells can be rebuilt after xf_table_defrag renumbers the rows.
+extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
+                                          const uint32_t *d_rowptr, const int32_t *d_labels,
+                                          uint32_t R, uint32_t NNZ, int retain_keys,
+                                          void *stream) {
+  XF_REQUIRE(out && t && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
+             "xf_batch_compile_local_dev: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  xf_batch *b = new xf_batch;
+  struct Guard {
+    xf_batch *b;
+    ~Guard() {
+      if (b) xf_batch_free(b);
+    }
+  } guard{b};
+  b->R = R;
+  b->NNZ = NNZ;
+  b->local = true;
+  b->on_device_only = true;
+  // labels (and, when asked, the raw keys / row offsets) in the batch's own allocation
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_lab = 0;
+  const size_t o_rp = o_lab + al((size_t)R * 4);
+  const size_t o_keys = o_rp + al(retain_keys ? ((size_t)R + 1) * 4 : 0);
+  const size_t total = o_keys + al(retain_keys ? (size_t)NNZ * 8 : 0) + 256;
+  XF_HIP(hipMalloc(&b->d_raw, total));
+  b->d_raw_bytes = total;
+  char *d = (char *)b->d_raw;
+  if (R) XF_HIP(hipMemcpyAsync(d + o_lab, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+  b->raw_labels = (const int32_t *)(d + o_lab);
+  if (retain_keys) {
+    XF_HIP(hipMemcpyAsync(d + o_rp, d_rowptr, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, s));
+    if (NNZ) XF_HIP(hipMemcpyAsync(d + o_keys, d_keys, (size_t)NNZ * 8, hipMemcpyDeviceToDevice, s));
+  }
+  {
+    xf::Scratch sc;
+    uint32_t *idx = nullptr;
+    XF_TRY(sc.get(&idx, NNZ));
+    XF_TRY(xf::table_resolve_any(t, d_keys, NNZ, idx, s, true));
+    const uint64_t M = xf::table_dev(t).max_rows + 1;
+    XF_TRY(xf::cells_build(&b->cells, idx, nullptr, d_rowptr, R, NNZ, (uint32_t)M,
+                           xf::kCellsTableRows, s));
+  }
+  b->cells->table_uid = xf::table_uid(t);
+  b->cells->epoch = xf::table_epoch(t);
+  if (retain_keys) {
+    b->raw_rowptr = (const uint32_t *)(d + o_rp);
+    b->raw_keys = (const uint64_t *)(d + o_keys);
+  }
+  guard.b = nullptr;
+  *out = b;
+  return XF_OK;
+}
+
+// host-array front end (the reader's block arrays and a row slice, like xf_batch_compile)
+extern "C" int xf_batch_compile_local(xf_batch **out, xf_table *t, const uint64_t *rowptr,
+                                      const uint64_t *keys, const int32_t *labels,
+                                      size_t row_begin, size_t row_end, int retain_keys,
+                                      void *stream) {
+  XF_REQUIRE(out && t && rowptr && labels && row_end >= row_begin,
+             "xf_batch_compile_local: bad argument");
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(NNZ == 0 || keys, "xf_batch_compile_local: null keys");
+  XF_REQUIRE(R < 0xFFFFFFFFull && NNZ < 0xFFFFFFFFull, "xf_batch_compile_local: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<uint32_t> rp(R + 1);
+  for (size_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+  xf::Scratch sc;
+  uint64_t *d_keys = nullptr;
+  uint32_t *d_rp = nullptr;
+  int32_t *d_lab = nullptr;
+  XF_TRY(sc.get(&d_keys, NNZ));
+  XF_TRY(sc.get(&d_rp, R + 1));
+  XF_TRY(sc.get(&d_lab, R));
+  if (NNZ) XF_HIP(hipMemcpyAsync(d_keys, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_rp, rp.data(), (R + 1) * 4, hipMemcpyHostToDevice, s));
+  if (R) XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return xf_batch_compile_local_dev(out, t, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ,
+                                    retain_keys, stream);
+}
+
+// shape of a batch's cells (tests / bench): out[0..8) = W, nwin, nchunk, G, nitems,
+// 0 (reserved), nsplit_chunks, M
+extern "C" int xf_batch_cells_info(const xf_batch *b, uint32_t *out) {
+  XF_REQUIRE(b && out, "xf_batch_cells_info: null argument");
+  XF_REQUIRE(b->cells, "xf_batch_cells_info: the batch has no cells yet");
+  const xf_cells *c = b->cells;
+  const uint32_t v[8] = {c->W, c->nwin, c->nchunk, c->G, c->nitems, 0, c->nsplit_chunks, c->M};
+  for (int i = 0; i < 8; ++i) out[i] = v[i];
+  return XF_OK;
+}

@@ -26,12 +26,17 @@
 #include <algorithm>
 
 #include "xf_batch.h"
+#include "xf_cells.h"
 #include "xf_common.h"
 #include "xf_device.h"
 
 namespace xf {
 const TableDev &table_dev(const xf_table *t);
 int table_dim(const xf_table *t);
+int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s);
+int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
+                         hipStream_t s);
+int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -1078,6 +1083,13 @@ struct xf_workspace {
   float *loss = nullptr, *pctr = nullptr, *vsum = nullptr;
   void *ks = nullptr;  // FM: per-key (a, b, w) records, 32 B each
   size_t capU = 0, capUK = 0, capR = 0;
+  double *partial = nullptr;  // LR forward: partial row sums of the window workgroups
+  size_t capPartial = 0;
+  float *gdense = nullptr;    // capture mode: gradients indexed by state row
+  size_t capGdense = 0;
+  // capture: keep the step's intermediates per unique key (pulled weights, gradients) for
+  // xf_workspace_fetch — the parity hook.  Off by default: the production step never forms them.
+  bool capture = false;
   uint32_t lastU = 0, lastR = 0;
   // optional per-kernel HIP-event timing (same stream, inside the caller's timed region)
   bool profiling = false;
@@ -1131,7 +1143,8 @@ extern "C" int xf_workspace_create(xf_workspace **out) {
 
 extern "C" int xf_workspace_destroy(xf_workspace *ws) {
   if (!ws) return XF_OK;
-  void *ps[] = {ws->slots, ws->slots2, ws->wu, ws->g, ws->vu, ws->gv, ws->loss, ws->pctr, ws->vsum, ws->ks};
+  void *ps[] = {ws->slots, ws->slots2, ws->wu,   ws->g,  ws->vu,      ws->gv,
+                ws->loss,  ws->pctr,   ws->vsum, ws->ks, ws->partial, ws->gdense};
   for (void *p : ps)
     if (p) hipFree(p);
   for (auto &e : ws->ev)
@@ -1196,22 +1209,57 @@ extern "C" int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long 
   } while (0)
 
 // ---------------------------------------------------------------------------- fused steps
+static int ws_reserve_cells(xf_workspace *ws, const xf_cells *c, bool dense_g) {
+  const size_t need = xf::cells_partial_doubles(c);
+  if (need > ws->capPartial) {
+    if (ws->partial) XF_HIP(hipFree(ws->partial));
+    ws->partial = nullptr;
+    ws->capPartial = 0;
+    XF_HIP(hipMalloc((void **)&ws->partial, (need + need / 8 + 1024) * 8));
+    ws->capPartial = need + need / 8 + 1024;
+  }
+  const size_t gd = dense_g ? (size_t)c->nchunk * xf::kChunk : 0;
+  if (gd > ws->capGdense) {
+    if (ws->gdense) XF_HIP(hipFree(ws->gdense));
+    ws->gdense = nullptr;
+    ws->capGdense = 0;
+    XF_HIP(hipMalloc((void **)&ws->gdense, gd * 4));
+    ws->capGdense = gd;
+  }
+  return XF_OK;
+}
+
+extern "C" int xf_workspace_capture(xf_workspace *ws, int enable) {
+  XF_REQUIRE(ws, "xf_workspace_capture: null workspace");
+  ws->capture = enable != 0;
+  return XF_OK;
+}
+
+// One LRWorker::update (lr_worker.cc:167-176) against a table on this GPU.  The Pull's key ->
+// row resolve (and its insert-on-first-touch) happens once per (minibatch, table row
+// numbering), when the batch's cells are built; a step is then two passes over the cells:
+// forward (reads the table's weights in place) and gradient + Push.
 extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream) {
   XF_REQUIRE(w && b && ws, "xf_lr_step: null argument");
   XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_step: the w table must have dim 1");
-  XF_TRY(xf_batch_upload(b, stream));
+  XF_TRY(xf::ensure_cells(b, w, S(stream)));  // Pull (:170): keys -> state rows, inserts
+  const xf_cells *c = b->cells;
+  const bool cap = ws->capture && !b->local && b->d_rows_u;
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
+  XF_TRY(ws_reserve_cells(ws, c, cap));
   if (ws->profiling) XF_TRY(ws_collect(ws));
-  const xf_dev_batch &v = b->view;
-  ws->lastU = b->U;
+  ws->lastU = cap ? b->U : 0;
   ws->lastR = b->R;
-  XF_BEGIN();  // Pull (lr_worker.cc:170): key -> slot and the weight payload in one pass
-  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, stream));
-  XF_END(kEvResolve);
-  XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, nullptr, stream));  // :172
-  XF_END(kEvForward);  // gradient (:173) + Push (:175) in one pass: the table is on this GPU
-  XF_TRY(xf_lr_grad_update_dev(w, &v, ws->slots, ws->wu, ws->loss, ws->g, stream));
+  const xf::TableDev &T = xf::table_dev(w);
+  const int32_t *labels = b->local ? b->raw_labels : b->view.labels;
+  XF_BEGIN();
+  XF_TRY(xf::cells_lr_forward(c, T.w, labels, ws->partial, ws->loss, nullptr, S(stream)));  // :172
+  XF_END(kEvForward);
+  if (cap) XF_TRY(xf::gather_f32(T.w, b->d_rows_u, b->U, ws->wu, S(stream)));
+  // gradient (:173) + Push (:175) in one pass over the cells
+  XF_TRY(xf::cells_lr_grad_update(c, w, ws->loss, cap ? ws->gdense : nullptr, S(stream)));
   XF_END(kEvGrad);
+  if (cap) XF_TRY(xf::gather_f32(ws->gdense, b->d_rows_u, b->U, ws->g, S(stream)));
   if (ws->profiling) ws->ev_pending = true;
   return XF_OK;
 }
@@ -1220,6 +1268,7 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
                           void *stream) {
   XF_REQUIRE(w && vt && b && ws, "xf_fm_step: null argument");
   XF_REQUIRE(xf::table_dim(w) == 1, "xf_fm_step: the w table must have dim 1");
+  XF_REQUIRE(!b->local, "xf_fm_step: needs a minibatch with a key list (xf_batch_compile*)");
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, stream));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
@@ -1273,11 +1322,13 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
 // reference's test-time Pull does (ftrl.h:56).
 extern "C" int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *pctr_out) {
   XF_REQUIRE(w && b && ws && pctr_out, "xf_lr_predict: null argument");
-  XF_TRY(xf_batch_upload(b, nullptr));
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_predict: the w table must have dim 1");
+  XF_TRY(xf::ensure_cells(b, w, nullptr));
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
-  const xf_dev_batch &v = b->view;
-  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
-  XF_TRY(xf_lr_forward_dev(&v, ws->wu, ws->loss, ws->pctr, nullptr));
+  XF_TRY(ws_reserve_cells(ws, b->cells, false));
+  const int32_t *labels = b->local ? b->raw_labels : b->view.labels;
+  XF_TRY(xf::cells_lr_forward(b->cells, xf::table_dev(w).w, labels, ws->partial, ws->loss,
+                              ws->pctr, nullptr));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
   return xf_table_check(w, nullptr);
 }
@@ -1285,6 +1336,7 @@ extern "C" int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *
 extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
                              float *pctr_out) {
   XF_REQUIRE(w && vt && b && ws && pctr_out, "xf_fm_predict: null argument");
+  XF_REQUIRE(!b->local, "xf_fm_predict: needs a minibatch with a key list (xf_batch_compile*)");
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, nullptr));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
@@ -1302,7 +1354,9 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
 extern "C" int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
                                   size_t R) {
   XF_REQUIRE(ws, "xf_workspace_fetch: null workspace");
-  XF_REQUIRE(U <= ws->lastU && R <= ws->lastR, "xf_workspace_fetch: sizes exceed last step");
+  XF_REQUIRE(R <= ws->lastR && (!(wu || g) || U <= ws->lastU),
+             "xf_workspace_fetch: sizes exceed the last step's (per-key intermediates of an LR "
+             "step exist only after xf_workspace_capture(ws, 1))");
   XF_HIP(hipDeviceSynchronize());
   if (wu && U) XF_HIP(hipMemcpy(wu, ws->wu, U * 4, hipMemcpyDeviceToHost));
   if (loss && R) XF_HIP(hipMemcpy(loss, ws->loss, R * 4, hipMemcpyDeviceToHost));

@@ -31,6 +31,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 #include <vector>
 
@@ -580,6 +581,10 @@ struct xf_table {
   xf_table_config cfg;
   int dev = 0;
   xf::TableDev T{};
+  // identity of the row numbering: `uid` is unique per table object, `epoch` counts the
+  // renumberings (xf_table_defrag).  Row numbers cached outside the table (the cells of a
+  // compiled minibatch, the owner-side rows of a sharded step) are valid for one (uid, epoch).
+  uint64_t uid = 0, epoch = 0;
   // scratch for the host-pointer API
   uint64_t *s_keys = nullptr;
   uint32_t *s_rows = nullptr;
@@ -705,6 +710,10 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
     return xf::set_error(XF_ENOGPU, "xf_table_create: no HIP device (the table lives in HBM)");
   xf_table *t = new xf_table;
   t->cfg = *cfg;
+  {
+    static std::atomic<uint64_t> next_uid{1};
+    t->uid = next_uid.fetch_add(1);
+  }
   XF_HIP(hipGetDevice(&t->dev));
   xf::TableDev &T = t->T;
   T.dim = cfg->dim;
@@ -900,6 +909,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
   N.bkeys = k_sorted.take();
   N.bdir = dir.take();
   T = N;
+  ++t->epoch;  // every row number handed out before this call is stale
   return XF_OK;
 }
 
@@ -1130,8 +1140,74 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
   return xf_table_check(t, nullptr);
 }
 
-// used by xf_model.hip
+// key -> row for ANY device key list (duplicates allowed, any order), inserting the missing
+// keys; with allow_grow the table is first grown (xf_table_reserve) when the keys that may be
+// new would push the load past 0.6.  The raw keys of a minibatch are resolved with this
+// (xf_batch_compile_local_dev).  Synchronises the stream.
 namespace xf {
+int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
+                      hipStream_t s, bool allow_grow) {
+  XF_REQUIRE(t && (n == 0 || (d_keys && d_rows)), "table_resolve_any: null argument");
+  XF_REQUIRE(n < 0xFFFFFFFFull, "table_resolve_any: %zu keys in one call", n);
+  if (n == 0) return XF_OK;
+  size_t maybe_new = n;
+  const bool tiered = t->T.nbase != 0;
+  if (tiered) {
+    if (n > t->miss_cap) {
+      XF_HIP(hipStreamSynchronize(s));
+      if (t->miss) XF_HIP(hipFree(t->miss));
+      t->miss = nullptr;
+      t->miss_cap = 0;
+      const size_t want = n + n / 4 + 1024;
+      XF_HIP(hipMalloc((void **)&t->miss, want * 4));
+      t->miss_cap = want;
+    }
+    if (!t->miss_n) XF_HIP(hipMalloc((void **)&t->miss_n, 8));
+    XF_HIP(hipMemsetAsync(t->miss_n, 0, 8, s));
+    const size_t blocks = std::min<size_t>((n + kBlock - 1) / kBlock, 1u << 16);
+    hipLaunchKernelGGL((k_pull_settled<false, 1, xf::kBaseWin>), dim3((unsigned)blocks),
+                       dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, (float *)nullptr, t->miss,
+                       t->miss_n, (const uint32_t *)nullptr);
+    XF_HIP(hipGetLastError());
+    unsigned long long misses = 0;
+    XF_HIP(hipMemcpyAsync(&misses, t->miss_n, 8, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+    maybe_new = (size_t)misses;
+    if (maybe_new == 0) return XF_OK;
+  }
+  if (allow_grow) {
+    XF_HIP(hipStreamSynchronize(s));
+    xf::TableStat st;
+    XF_TRY(read_stat(t, &st));
+    const uint64_t cap = t->T.cap;
+    if ((st.count + maybe_new) * 10 > cap * 6) {
+      uint64_t want = cap * 2;
+      while ((st.count + maybe_new) * 10 > want * 6) want *= 2;
+      XF_TRY(xf_table_reserve(t, want));
+    }
+  }
+  hipLaunchKernelGGL(k_resolve<false>, dim3(std::min(grid_for(maybe_new), 4096)), dim3(kBlock), 0,
+                     s, t->T, d_keys, n, d_rows, (float *)nullptr,
+                     tiered ? (const uint32_t *)t->miss : (const uint32_t *)nullptr,
+                     tiered ? (const unsigned long long *)t->miss_n
+                            : (const unsigned long long *)nullptr,
+                     (const uint32_t *)nullptr);
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  return XF_OK;
+}
+
+// dst[i] = src[rows[i]] for any float array indexed by state row (parity hook of the cells path)
+int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s) {
+  if (n == 0) return XF_OK;
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(kBlock), 0, s, src, 1, rows, n, dst);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+// used by xf_model.hip / xf_cells.hip
 const TableDev &table_dev(const xf_table *t) { return t->T; }
 int table_dim(const xf_table *t) { return t->T.dim; }
+uint64_t table_uid(const xf_table *t) { return t->uid; }
+uint64_t table_epoch(const xf_table *t) { return t->epoch; }
 }  // namespace xf

@@ -18,6 +18,8 @@ class SingleGpuTrainer:
         self.ws = capi.Workspace()
 
     def compile(self, rowptr, keys, labels):
+        if self.model == "lr":   # sort-free key build against the table (cells)
+            return capi.LocalBatch(self.w, rowptr, keys, labels)
         return capi.Batch(rowptr, keys, labels).upload()
 
     def step(self, batch, stream=None):
