@@ -104,8 +104,10 @@ int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t 
  * straight to its state row in `t` (insert on first touch, ftrl.h:56; the table grows when
  * needed) and the nonzeros are grouped into cells (row window x 4096-row chunk of the state)
  * by a stable radix pass — no unique-key list, the state row is the key's identity.  The
- * result feeds xf_lr_step / xf_lr_predict on `t` only.  retain_keys != 0 keeps the raw arrays
- * on the device so that the batch survives a renumbering of the rows (xf_table_defrag). */
+ * result feeds xf_lr_step / xf_lr_predict on `t` only.  retain_keys != 0 is for minibatches that
+ * are kept and replayed (epochs >= 2): the raw arrays stay on the device so that the batch
+ * survives a renumbering of the rows (xf_table_defrag), and the cells get the key-sorted copy
+ * the forward reads fastest; 0 is for a minibatch that is stepped once and freed. */
 int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
                                const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
                                uint32_t NNZ, int retain_keys, void *stream);

@@ -58,10 +58,11 @@ struct xf_cells {
   uint32_t nitems = 0, nsplit_chunks = 0;
   int mode = xf::kCellsUidx;
   uint64_t table_uid = 0, epoch = 0;  // kCellsTableRows: valid for this table at this epoch
-  char *blob = nullptr;               // one device allocation
-  size_t blob_bytes = 0;
+  char *blob = nullptr, *blob2 = nullptr;  // device allocations: entries + cell offsets; items
+  size_t blob_bytes = 0, blob2_bytes = 0;
   uint32_t *entries = nullptr;      // [NNZ] cells sorted by row (the gradient's stream)
-  uint32_t *entries_k = nullptr;    // [NNZ] the same cells sorted by key (the forward's stream)
+  uint32_t *entries_k = nullptr;    // [NNZ] the same cells sorted by key (the forward's stream;
+                                    //       == entries when the copy was not built)
   uint32_t *cellptr = nullptr;      // [ncell + 1]
   uint32_t *blk_cell = nullptr;     // [nblk + 1] cell of entry kBlk*b; [nblk] = ncell - 1
   uint32_t *item_chunk = nullptr;   // [nitems]   gradient work items: chunk,
@@ -80,7 +81,7 @@ namespace xf {
 // unique-key index of a compiled batch mapped to table rows).  Synchronises `stream`.
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                hipStream_t stream);
+                bool key_sorted_copy, hipStream_t stream);
 void cells_free(xf_cells *c);
 
 // scratch of the forward: G * nwin * W partial row sums (fp64)

@@ -75,15 +75,21 @@ k_cell_keys(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ sr
   }
 }
 
-// cellptr from the sorted cell numbers: work item j closes the cells between entry j-1's and
-// entry j's (j == n closes the tail)
+// cellptr[c] = number of entries in cells < c: a lower bound in the sorted cell numbers per
+// cell (a pass over the entries that closes cells at every change took 80 us for 1e7 entries;
+// 22k searches of 24 steps take 5)
 __global__ void __launch_bounds__(kBlock)
 k_cellptr(const uint32_t *__restrict__ cid_s, uint32_t n, uint32_t ncell,
           uint32_t *__restrict__ cellptr) {
-  XF_GRID_STRIDE(j, (size_t)n + 1) {
-    const uint32_t first = j == 0 ? 0u : cid_s[j - 1] + 1;
-    const uint32_t last = j == n ? ncell : cid_s[j];
-    for (uint32_t c = first; c <= last; ++c) cellptr[c] = (uint32_t)j;
+  XF_GRID_STRIDE(c, (size_t)ncell + 1) {
+    uint32_t lo = 0, hi = n;  // first j with cid_s[j] >= c
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (cid_s[mid] < (uint32_t)c) lo = mid + 1;
+      else
+        hi = mid;
+    }
+    cellptr[c] = lo;
   }
 }
 
@@ -444,7 +450,8 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
 
 void cells_free(xf_cells *c) {
   if (!c) return;
-  if (c->blob) (void)hipFree(c->blob);
+  if (c->blob) blob_free(c->blob, c->blob_bytes);
+  if (c->blob2) blob_free(c->blob2, c->blob2_bytes);
   delete c;
 }
 
@@ -452,7 +459,7 @@ size_t cells_partial_doubles(const xf_cells *c) { return (size_t)c->G * c->nwin 
 
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                hipStream_t s) {
+                bool key_sorted_copy, hipStream_t s) {
   XF_REQUIRE(out && d_rowptr && (NNZ == 0 || d_src), "cells_build: null argument");
   xf_cells *c = new xf_cells;
   c->R = R;
@@ -476,30 +483,54 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
       if (c) cells_free(c);
     }
   } guard{c};
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // the big arrays have known sizes: sorted straight into the batch's own allocation
+  const size_t o_ent = 0;
+  const size_t o_entk = o_ent + al((size_t)NNZ * 4);
+  const size_t o_cellptr = o_entk + al(key_sorted_copy ? (size_t)NNZ * 4 : 0);
+  const size_t o_blk = o_cellptr + al(((size_t)c->ncell + 1) * 4);
+  const size_t total = o_blk + al(((size_t)c->nblk + 1) * 4) + 256;
+  XF_TRY(blob_alloc((void **)&c->blob, total, &c->blob_bytes));
+  c->entries = (uint32_t *)(c->blob + o_ent);
+  c->entries_k = key_sorted_copy ? (uint32_t *)(c->blob + o_entk) : c->entries;
+  c->cellptr = (uint32_t *)(c->blob + o_cellptr);
+  c->blk_cell = (uint32_t *)(c->blob + o_blk);
   Scratch sc;
-  uint32_t *cid = nullptr, *ent = nullptr, *cid_s = nullptr, *ent_s = nullptr;
+  uint32_t *cid = nullptr, *ent = nullptr, *cid_s = nullptr;
   XF_TRY(sc.get(&cid, NNZ));
   XF_TRY(sc.get(&ent, NNZ));
   XF_TRY(sc.get(&cid_s, NNZ));
-  XF_TRY(sc.get(&ent_s, NNZ));
-  uint32_t *cellptr = nullptr, *blk_cell = nullptr;
-  XF_TRY(sc.get(&cellptr, (size_t)c->ncell + 1));
-  XF_TRY(sc.get(&blk_cell, (size_t)c->nblk + 1));
   if (NNZ) {
     hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr,
                        d_src, d_map, R, c->W, c->nchunk, cid, ent);
     int bits = 1;
     while (bits < 32 && (1ull << bits) < ncell64) ++bits;
     size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, ent, ent_s, (size_t)NNZ, 0, bits, s));
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0, bits,
+                                     s));
     void *tmp = nullptr;
     XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, ent, ent_s, (size_t)NNZ, 0, bits, s));
+    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0, bits, s));
   }
-  hipLaunchKernelGGL(k_cellptr, dim3(grid_for((size_t)NNZ + 1)), dim3(kBlock), 0, s, cid_s, NNZ,
-                     c->ncell, cellptr);
+  hipLaunchKernelGGL(k_cellptr, dim3(grid_for((size_t)c->ncell + 1)), dim3(kBlock), 0, s, cid_s,
+                     NNZ, c->ncell, c->cellptr);
   hipLaunchKernelGGL(k_blk_cell, dim3(grid_for((size_t)c->nblk + 1)), dim3(kBlock), 0, s, cid_s,
-                     c->nblk, c->ncell, blk_cell);
+                     c->nblk, c->ncell, c->blk_cell);
+  if (NNZ && key_sorted_copy) {
+    // the forward's copy: every cell sorted by its entries' low bits (the position within
+    // the chunk), stable, so that neighbouring lanes gather neighbouring weights (forward
+    // kernel 58 -> 42 us on the config-2 shape; the segmented sort takes 100 us, so a
+    // minibatch that is stepped once goes without and the forward reads the row-sorted cells)
+    size_t tb = 0;
+    XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, c->entries, c->entries_k, (size_t)NNZ,
+                                              (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
+                                              kChunkBits, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, c->entries, c->entries_k, (size_t)NNZ,
+                                              (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
+                                              kChunkBits, s));
+  }
   // gradient work items
   const size_t nc1 = (size_t)c->nchunk + 1;
   uint32_t *nsl = nullptr, *nsplit = nullptr, *off = nullptr, *soff = nullptr;
@@ -507,8 +538,8 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   XF_TRY(sc.get(&nsplit, nc1));
   XF_TRY(sc.get(&off, nc1));
   XF_TRY(sc.get(&soff, nc1));
-  hipLaunchKernelGGL(k_chunk_slices, dim3(grid_for(nc1)), dim3(kBlock), 0, s, cellptr, c->nchunk,
-                     c->nwin, nsl, nsplit);
+  hipLaunchKernelGGL(k_chunk_slices, dim3(grid_for(nc1)), dim3(kBlock), 0, s, c->cellptr,
+                     c->nchunk, c->nwin, nsl, nsplit);
   XF_TRY(exclusive_scan_u32(sc, nsl, off, nc1, s));
   XF_TRY(exclusive_scan_u32(sc, nsplit, soff, nc1, s));
   uint32_t totals[2] = {0, 0};
@@ -518,49 +549,23 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   XF_HIP(hipStreamSynchronize(s));
   c->nitems = totals[0];
   c->nsplit_chunks = totals[1];
-  // the batch's own allocation
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_ent = 0;
-  const size_t o_entk = o_ent + al((size_t)NNZ * 4);
-  const size_t o_cellptr = o_entk + al((size_t)NNZ * 4);
-  const size_t o_blk = o_cellptr + al(((size_t)c->ncell + 1) * 4);
-  const size_t o_ic = o_blk + al(((size_t)c->nblk + 1) * 4);
+  // ... and the small ones, whose sizes the data decides
+  const size_t o_ic = 0;
   const size_t o_is = o_ic + al((size_t)c->nitems * 4);
   const size_t o_id = o_is + al((size_t)c->nitems * 4);
   const size_t o_sc = o_id + al((size_t)c->nitems * 4);
   const size_t o_gd = o_sc + al((size_t)c->nsplit_chunks * 4);
   const size_t o_td = o_gd + al((size_t)c->nsplit_chunks * kChunk * 8);
-  const size_t total = o_td + al((size_t)c->nsplit_chunks * kChunk) + 256;
+  const size_t total2 = o_td + al((size_t)c->nsplit_chunks * kChunk) + 256;
   c->split_bytes = o_td + al((size_t)c->nsplit_chunks * kChunk) - o_gd;
-  XF_HIP(hipMalloc((void **)&c->blob, total));
-  c->blob_bytes = total;
-  char *d = c->blob;
-  c->entries = (uint32_t *)(d + o_ent);
-  c->entries_k = (uint32_t *)(d + o_entk);
-  c->cellptr = (uint32_t *)(d + o_cellptr);
-  c->blk_cell = (uint32_t *)(d + o_blk);
+  XF_TRY(blob_alloc((void **)&c->blob2, total2, &c->blob2_bytes));
+  char *d = c->blob2;
   c->item_chunk = (uint32_t *)(d + o_ic);
   c->item_slice = (uint32_t *)(d + o_is);
   c->item_dump = (uint32_t *)(d + o_id);
   c->split_chunk = (uint32_t *)(d + o_sc);
   c->gsum = (double *)(d + o_gd);
   c->gtouched = (uint8_t *)(d + o_td);
-  if (NNZ) {
-    XF_HIP(hipMemcpyAsync(c->entries, ent_s, (size_t)NNZ * 4, hipMemcpyDeviceToDevice, s));
-    // the forward's copy: every cell sorted by its entries' low 12 bits (the position within
-    // the chunk), stable, so that neighbouring lanes gather neighbouring weights
-    size_t tb = 0;
-    XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, ent_s, c->entries_k, (size_t)NNZ,
-                                              (unsigned)c->ncell, cellptr, cellptr + 1, 0,
-                                              kChunkBits, s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, ent_s, c->entries_k, (size_t)NNZ,
-                                              (unsigned)c->ncell, cellptr, cellptr + 1, 0,
-                                              kChunkBits, s));
-  }
-  XF_HIP(hipMemcpyAsync(c->cellptr, cellptr, ((size_t)c->ncell + 1) * 4, hipMemcpyDeviceToDevice, s));
-  XF_HIP(hipMemcpyAsync(c->blk_cell, blk_cell, ((size_t)c->nblk + 1) * 4, hipMemcpyDeviceToDevice, s));
   if (c->nitems)
     hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, nsl, off, soff,
                        c->nchunk, c->item_chunk, c->item_slice, c->item_dump, c->split_chunk);
@@ -651,14 +656,14 @@ int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s) {
     XF_TRY(table_resolve_any(t, b->raw_keys, b->NNZ, idx, s, true));
     const uint64_t M = table_dev(t).max_rows + 1;
     XF_TRY(cells_build(&c, idx, nullptr, b->raw_rowptr, b->R, b->NNZ, (uint32_t)M,
-                       kCellsTableRows, s));
+                       kCellsTableRows, true, s));
   } else {
     XF_TRY(xf_batch_upload(b, s));
     if (!b->d_rows_u) XF_HIP(hipMalloc((void **)&b->d_rows_u, std::max<size_t>(b->U, 1) * 4));
     XF_TRY(xf_table_resolve_dev(t, b->view.ukeys, b->U, b->d_rows_u, s));
     const uint64_t M = table_dev(t).max_rows + 1;
     XF_TRY(cells_build(&c, b->view.uidx, b->d_rows_u, b->view.rowptr, b->R, b->NNZ, (uint32_t)M,
-                       kCellsTableRows, s));
+                       kCellsTableRows, true, s));
   }
   c->table_uid = uid;
   c->epoch = ep;
@@ -715,7 +720,7 @@ extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uin
     XF_TRY(xf::table_resolve_any(t, d_keys, NNZ, idx, s, true));
     const uint64_t M = xf::table_dev(t).max_rows + 1;
     XF_TRY(xf::cells_build(&b->cells, idx, nullptr, d_rowptr, R, NNZ, (uint32_t)M,
-                           xf::kCellsTableRows, s));
+                           xf::kCellsTableRows, retain_keys != 0, s));
   }
   b->cells->table_uid = xf::table_uid(t);
   b->cells->epoch = xf::table_epoch(t);

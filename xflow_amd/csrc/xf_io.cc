@@ -269,6 +269,13 @@ static int next_from_cache(xf_reader *r, size_t *rows_out, size_t *nnz_out) {
   if (r->served == r->cache_blocks) return XF_OK;
   uint64_t dims[2];
   bool ok = get(r->cfp, dims, 2);
+  // a block of `cap` text bytes holds at most cap/2 rows ("0\t") and cap/4 tokens ("a:b:c ", and
+  // an empty token repeats the previous one): anything larger is a corrupt or foreign file
+  if (ok && (dims[0] > r->cap / 2 + 1 || dims[1] > r->cap))
+    return xf::set_error(XF_EIO, "%s: block %llu claims %llu rows / %llu nonzeros for %zu-byte "
+                         "blocks (corrupt block cache)", r->cache_path.c_str(),
+                         (unsigned long long)r->served, (unsigned long long)dims[0],
+                         (unsigned long long)dims[1], r->cap);
   if (ok) {
     r->rowptr.resize(dims[0] + 1);
     r->keys.resize(dims[1]);
@@ -281,6 +288,10 @@ static int next_from_cache(xf_reader *r, size_t *rows_out, size_t *nnz_out) {
     return xf::set_error(XF_EIO, "%s: truncated block cache (block %llu of %llu)",
                          r->cache_path.c_str(), (unsigned long long)r->served,
                          (unsigned long long)r->cache_blocks);
+  if (r->rowptr[0] != 0 || r->rowptr[dims[0]] != dims[1] ||
+      !std::is_sorted(r->rowptr.begin(), r->rowptr.end()))
+    return xf::set_error(XF_EIO, "%s: block %llu has inconsistent row offsets (corrupt block "
+                         "cache)", r->cache_path.c_str(), (unsigned long long)r->served);
   ++r->served;
   *rows_out = dims[0];
   if (nnz_out) *nnz_out = dims[1];

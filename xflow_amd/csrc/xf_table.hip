@@ -969,6 +969,10 @@ extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
                                  uint32_t *d_rows, float *d_vals, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_keys && d_rows && d_vals)), "xf_table_pull_dev: null argument");
   XF_REQUIRE(t->T.dim == 1, "xf_table_pull_dev: dim must be 1 (use resolve + gather)");
+  // a lane that finds its key inserted by another lane of the same launch reads w[row] without
+  // waiting for the inserter's first-touch stores: only pre-zeroed rows make that safe
+  XF_REQUIRE(t->T.init_kind == XF_INIT_ZERO,
+             "xf_table_pull_dev: only zero-initialised tables (use resolve + gather)");
   if (n == 0) return XF_OK;
   return launch_resolve<true>(t, d_keys, n, d_rows, d_vals, S(stream));
 }
@@ -1011,7 +1015,8 @@ extern "C" int xf_table_pull_ordered_dev(xf_table *t, const uint64_t *d_keys_sor
                                          float *d_vals, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_keys_sorted && d_order && d_rows)),
              "xf_table_pull_ordered_dev: null argument");
-  XF_REQUIRE(!d_vals || t->T.dim == 1, "xf_table_pull_ordered_dev: values only for dim 1");
+  XF_REQUIRE(!d_vals || (t->T.dim == 1 && t->T.init_kind == XF_INIT_ZERO),
+             "xf_table_pull_ordered_dev: values only for dim-1 zero-initialised tables");
   if (n == 0) return XF_OK;
   if (d_vals) return launch_resolve<true>(t, d_keys_sorted, n, d_rows, d_vals, S(stream), d_order);
   return launch_resolve<false>(t, d_keys_sorted, n, d_rows, nullptr, S(stream), d_order);
@@ -1164,8 +1169,12 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
     }
     if (!t->miss_n) XF_HIP(hipMalloc((void **)&t->miss_n, 8));
     XF_HIP(hipMemsetAsync(t->miss_n, 0, 8, s));
-    const size_t blocks = std::min<size_t>((n + kBlock - 1) / kBlock, 1u << 16);
-    hipLaunchKernelGGL((k_pull_settled<false, 1, xf::kBaseWin>), dim3((unsigned)blocks),
+    // an unsorted list: every lookup is two dependent random reads (directory, key run), so
+    // four keys per lane are in flight (a sorted list sweeps the tier and gains nothing from it)
+    constexpr int kAnyIlp = 4;
+    const size_t chunk = (size_t)kBlock * kAnyIlp;
+    const size_t blocks = std::min<size_t>((n + chunk - 1) / chunk, 1u << 16);
+    hipLaunchKernelGGL((k_pull_settled<false, kAnyIlp, xf::kBaseWin>), dim3((unsigned)blocks),
                        dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, (float *)nullptr, t->miss,
                        t->miss_n, (const uint32_t *)nullptr);
     XF_HIP(hipGetLastError());

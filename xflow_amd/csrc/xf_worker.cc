@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -78,6 +79,12 @@ int Worker::grow_if_needed(size_t incoming) {
   xf_table *ts[2] = {table_w_, table_v_};
   uint64_t cap = 0;
   XF_TRY(xf_table_capacity(table_w_, &cap));
+  if (size_known_stale_) {  // keys came in behind our back (model file): count them once
+    uint64_t n = 0;
+    XF_TRY(xf_table_size(table_w_, &n));
+    seen_upper_ = std::max<uint64_t>(seen_upper_, n);
+    size_known_stale_ = false;
+  }
   if ((seen_upper_ + incoming) * 10 <= cap * 6) {
     seen_upper_ += incoming;
     return XF_OK;
@@ -105,9 +112,14 @@ int Worker::defrag_if_grown() {
   return XF_OK;
 }
 
-// the key build of update() (lr_worker.cc:146-166): on the GPU unless key_build=host
+// the key build of update() (lr_worker.cc:146-166).  LR: straight against the table (raw keys
+// -> state rows -> cells, no sort; the table grows by itself); `keep` = the batch will be
+// replayed in later epochs.  FM (and key_build=host): the sorted-unique-key build.
 int Worker::compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys,
-                    const int32_t *labels, size_t start, size_t end) {
+                    const int32_t *labels, size_t start, size_t end, bool keep) {
+  if (model_ == 0 && key_build_gpu)
+    return xf_batch_compile_local(b, table_w_, rowptr, keys, labels, start, end, keep ? 1 : 0,
+                                  nullptr);
   if (key_build_gpu) return xf_batch_compile_gpu(b, rowptr, keys, labels, start, end, nullptr);
   return xf_batch_compile(b, rowptr, keys, labels, start, end);
 }
@@ -147,6 +159,8 @@ int Worker::batch_training() {
   }
   const double t0 = now_s();
   rows_trained_ = 0;
+  for (xf_batch *b : cache_) xf_batch_free(b);  // a second XFStartTrain starts from the files
+  cache_.clear();
   bool cached = false;
   for (int epoch = 0; epoch < epochs; ++epoch) {
     if (cached) {
@@ -223,7 +237,7 @@ int Worker::batch_training() {
           const size_t start = i * thread_size, end = (i + 1) * thread_size;
           if (end == start) continue;
           xf_batch *b = nullptr;
-          rc = compile(&b, p.rowptr, p.keys, p.labels, start, end);
+          rc = compile(&b, p.rowptr, p.keys, p.labels, start, end, cache_batches != 0);
           if (rc != XF_OK) break;
           rc = update(b);
           if (rc == XF_OK) rc = xf_table_check(table_w_, nullptr);
@@ -280,35 +294,34 @@ int Worker::predict(int rank, int block) {
   const size_t cap = model_ == 0 ? ((size_t)4 << 20) : ((size_t)2 << 20);
   xf_reader *rd = nullptr;
   XF_TRY(open_reader(&rd, test_data_path, cap));
+  struct ReaderGuard {  // every return path closes the reader
+    xf_reader *r;
+    ~ReaderGuard() { xf_reader_close(r); }
+  } rd_guard{rd};
   std::vector<int32_t> all_labels;
   std::vector<float> all_pctr, pctr;
   while (true) {
     size_t rows = 0, nnz = 0;
     const uint64_t *rowptr, *keys;
     const int32_t *fgid, *labels;
-    int rc = xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels);
-    if (rc != XF_OK) {
-      xf_reader_close(rd);
-      return rc;
-    }
+    XF_TRY(xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels));
     if (rows == 0) break;
     const size_t thread_size = rows / core_num;
     for (int i = 0; i < core_num; ++i) {
       const size_t start = i * thread_size, end = (i + 1) * thread_size;
       if (end == start) continue;
       xf_batch *b = nullptr;
-      XF_TRY(compile(&b, rowptr, keys, labels, start, end));
+      XF_TRY(compile(&b, rowptr, keys, labels, start, end, false));
+      struct BatchGuard {  // ... and frees the minibatch
+        xf_batch *b;
+        ~BatchGuard() { xf_batch_free(b); }
+      } b_guard{b};
       pctr.resize(end - start);
       uint32_t U = 0;
       xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
       XF_TRY(grow_if_needed(U));
-      rc = model_ == 0 ? xf_lr_predict(table_w_, b, ws_, pctr.data())
-                       : xf_fm_predict(table_w_, table_v_, b, ws_, pctr.data());
-      xf_batch_free(b);
-      if (rc != XF_OK) {
-        xf_reader_close(rd);
-        return rc;
-      }
+      XF_TRY(model_ == 0 ? xf_lr_predict(table_w_, b, ws_, pctr.data())
+                         : xf_fm_predict(table_w_, table_v_, b, ws_, pctr.data()));
       for (size_t r = 0; r < end - start; ++r) {
         const int label = labels[start + r];
         all_labels.push_back(label);
@@ -317,7 +330,6 @@ int Worker::predict(int rank, int block) {
       }
     }
   }
-  xf_reader_close(rd);
   md.close();
   // Base::calculate_auc (base.h:84-110) and its stdout line
   XF_TRY(xf_auc_logloss(all_labels.data(), all_pctr.data(), all_labels.size(), &logloss_acc_,
@@ -473,6 +485,17 @@ int load_table(FILE *f, xf_table *t, int dim) {
     return xf::set_error(XF_EINVAL, "XFLoadModel: file has dim %llu, table has %d",
                          (unsigned long long)hdr[1], dim);
   const size_t n = (size_t)hdr[0];
+  {  // the header's count must fit what is left of the file (a corrupt or foreign file must
+     // not turn into a giant allocation)
+    const long here = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long end = ftell(f);
+    fseek(f, here, SEEK_SET);
+    if (here < 0 || end < here || (unsigned long long)n * (8ull + 12ull * dim) >
+                                      (unsigned long long)(end - here))
+      return xf::set_error(XF_EIO, "XFLoadModel: the file claims %zu keys but holds %ld bytes",
+                           n, end - here);
+  }
   std::vector<uint64_t> keys(n);
   std::vector<float> w(n * dim), nn(n * dim), z(n * dim);
   if (fread(keys.data(), 8, n, f) != n || fread(w.data(), 4, n * dim, f) != n * dim ||
@@ -504,6 +527,7 @@ extern "C" int XFLoadModel(void *h, const char *path) {
   XF_REQUIRE(h && path, "XFLoadModel: null argument");
   xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
   XF_TRY(wk->ensure_tables());
+  wk->note_external_keys();
   FILE *f = fopen(path, "rb");
   if (!f) return xf::set_error(XF_EIO, "XFLoadModel: cannot open %s", path);
   char magic[8];

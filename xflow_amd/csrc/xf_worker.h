@@ -24,6 +24,8 @@ class Worker {
   int set_param(const char *name, const char *value);
   int get_metric(const char *name, double *value);
   int ensure_tables() { return create_tables(); }
+  // keys entered the tables without passing through grow_if_needed (XFLoadModel)
+  void note_external_keys() { size_known_stale_ = true; }
   xf_table *table_w() { return table_w_; }
   xf_table *table_v() { return table_v_; }
 
@@ -53,11 +55,12 @@ class Worker {
  private:
   int create_tables();
   int compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys, const int32_t *labels,
-              size_t start, size_t end);
+              size_t start, size_t end, bool keep);
   int grow_if_needed(size_t incoming);
   int defrag_if_grown();
   uint64_t keys_at_defrag_ = 0;
   uint64_t seen_upper_ = 0;
+  bool size_known_stale_ = false;
 
   int model_;
   std::string train_file_path, test_file_path;
