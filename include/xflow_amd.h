@@ -314,6 +314,92 @@ int xf_stream_sync(void *stream);
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py) */
 int xf_calib_stream(int kind, size_t bytes, int repeat); /* == ps KVWorker::Wait */
 
+/* ---------------------------------------------------------------- process group       */
+/* One process per GPU.  Replaces ps-lite's postoffice / van as xflow uses them (main.cc:22-47,
+ * scripts/local.sh:3-14) and the transport under KVWorker::Push/Pull: the exchange steps of
+ * the sharded table are all-to-all-v's over RCCL (grouped ncclSend/ncclRecv per peer over
+ * xGMI, asynchronous on the caller's stream).  The bootstrap is a TCP star around rank 0
+ * (ps-lite's scheduler): it carries the ncclUniqueId and the small host-side collectives.
+ * XF_TRANSPORT_HOST stages the exchange through the bootstrap sockets (tests: several ranks on
+ * one GPU, or none). */
+#define XF_TRANSPORT_RCCL 0
+#define XF_TRANSPORT_HOST 1
+typedef struct xf_group xf_group;
+/* rank < 0 / world <= 0 / addr NULL / port <= 0: from the environment — WORLD_SIZE | XF_WORLD |
+ * DMLC_NUM_WORKER; RANK | XF_RANK | DMLC_RANK (absent: ranks are handed out in arrival order,
+ * the process that binds the port first is rank 0, as ps-lite's scheduler numbers its nodes);
+ * MASTER_ADDR | DMLC_PS_ROOT_URI (127.0.0.1); MASTER_PORT | DMLC_PS_ROOT_PORT (29512).
+ * Collective: returns when all `world` processes have joined.  device: this process's GPU —
+ * >= 0 a device index, -1 the current device, -2 by rank (LOCAL_RANK, else rank modulo the
+ * visible devices; ranks handed out on arrival are only known inside this call). */
+int xf_group_create(xf_group **out, int rank, int world, const char *addr, int port,
+                    int transport, int device);
+int xf_group_destroy(xf_group *g);
+int xf_group_info(const xf_group *g, int *rank, int *world, int *transport);
+int xf_group_barrier(xf_group *g);
+/* host-side collectives over the bootstrap (small payloads: counts, flags, metrics) */
+int xf_group_allgather_host(xf_group *g, const void *in, size_t bytes, void *out /* world x */);
+int xf_group_gatherv_host(xf_group *g, const void *in, size_t bytes, void *out_rank0,
+                          const uint64_t *sizes_rank0);
+/* all-to-all-v: send[...] holds one slice per destination rank (send_counts[p] elements of
+ * elem_bytes, in rank order), recv gets one slice per source rank.  RCCL: device pointers,
+ * asynchronous on `stream`.  Host transport: blocking; host_buffers != 0 says the pointers are
+ * host memory (no GPU involved at all). */
+int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t *send_counts, void *recv,
+                       const uint64_t *recv_counts, size_t elem_bytes, int host_buffers,
+                       void *stream);
+
+/* ---------------------------------------------------------------- sharded trainer     */
+/* LRWorker / FMWorker::update across the ranks of a group: the table sharded by key range
+ * (ps-lite's default slicer), examples by worker, one all-to-all-v each way per step (weights
+ * back to the workers, gradients to the owners; the keys travel once, when the minibatch is
+ * compiled).  The owner applies the ranks' pushes of a step in rank order after all pulls.
+ * With a group of one rank (or g == NULL) it is the fused single-shard step. */
+#define XF_SCHEDULE_SEQUENTIAL 0 /* Pull, compute, Push of step t before Pull(t+1) */
+#define XF_SCHEDULE_STALE1 1     /* Push(t) overlaps Pull/forward/gradient of t+1 (one step stale) */
+typedef struct {
+  int32_t model;     /* 0 LR, 1 FM */
+  int32_t optimizer; /* XF_OPT_* */
+  int32_t k;         /* FM factors */
+  int32_t schedule;  /* XF_SCHEDULE_* */
+  uint64_t capacity; /* index positions of THIS rank's shard */
+  uint64_t seed;
+  float alpha, beta, lambda1, lambda2, lr;
+  int32_t host_key_build; /* != 0: the sorted-unique-key build on the host (xf_batch_compile) */
+} xf_sharded_config;
+void xf_sharded_config_default(xf_sharded_config *cfg);
+typedef struct xf_sharded xf_sharded;
+typedef struct xf_sbatch xf_sbatch;
+int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded_config *cfg);
+int xf_sharded_destroy(xf_sharded *st);
+/* COLLECTIVE (every rank, same order): key build + the static part of the exchange */
+int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
+                       const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                       size_t row_end, int keep);
+int xf_sbatch_free(xf_sbatch *b);
+int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
+                   uint64_t *n_owned /* keys of this minibatch (all ranks) this rank owns */);
+/* COLLECTIVE: one update() of every rank; asynchronous on the trainer's stream */
+int xf_sharded_step(xf_sharded *st, xf_sbatch *b);
+/* COLLECTIVE: forward only over this rank's rows (ranks without rows pass an empty minibatch) */
+int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out);
+int xf_sharded_flush(xf_sharded *st);  /* apply an outstanding stale1 Push; synchronises */
+int xf_sharded_defrag(xf_sharded *st); /* local table maintenance (flushes first) */
+int xf_sharded_check(xf_sharded *st);  /* flush + the tables' sticky errors */
+int xf_sharded_set_schedule(xf_sharded *st, int schedule);
+int xf_sharded_tables(xf_sharded *st, xf_table **w, xf_table **v);
+int xf_sharded_stream(xf_sharded *st, void **stream);
+/* ms_sum[6] = owner pull, weights exchange, forward, gradient, gradients exchange, owner
+ * update (HIP events on the step's stream; sequential schedule) */
+int xf_sharded_profile(xf_sharded *st, int enable);
+int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *steps);
+/* Checkpoint of the sharded table (the reference never saves its model): every rank writes
+ * <prefix>.shard-RRRRR-of-NNNNN (key-sorted (key, w, n, z) of its shard), rank 0 also
+ * <prefix>.manifest.  Load reads the shards of ANY saved world size (or a single-GPU model
+ * file saved by XFSaveModel) and keeps the keys this rank owns.  Both COLLECTIVE. */
+int xf_sharded_save(xf_sharded *st, const char *prefix);
+int xf_sharded_load(xf_sharded *st, const char *prefix);
+
 /* ---------------------------------------------------------------- metrics             */
 /* Base::calculate_auc (base.h:84-110): reference-format logloss (mean of y*log2 p +
  * (1-y)*log2(1-p), negative), AUC by descending-pctr rank sum, plus the conventional

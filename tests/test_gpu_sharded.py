@@ -1,0 +1,189 @@
+"""The C++ sharded trainer (xf_sharded_*, xf_group_*) on real hardware.
+
+* several ranks of the real kernels as separate processes on ONE GPU, the exchange staged
+  through the group's host transport (RCCL refuses two ranks per device): sharded tables,
+  owner-side resolve of every source's keys with real duplicates, merged rank-ordered owner
+  updates, a defrag between steps, both schedules — bit-exact against the oracle run on the
+  same schedule (tests/test_sharded_gloo._simulate);
+* the same over RCCL with one rank per GPU, world 2 / 4 / 8, skipped when the box has fewer
+  GPUs (the driver's 8-GPU node runs them);
+* the sharded checkpoint: saved by 2 ranks, loaded by 3 and by 1."""
+import multiprocessing as mp
+import os
+import traceback
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from xflow_amd import capi
+
+from .test_gpu_parity import same
+from .test_group_cpu import free_port
+from .test_sharded_gloo import _data, _simulate
+
+pytestmark = pytest.mark.gpu
+
+
+def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q):
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(rank, world, "127.0.0.1", port, transport,
+                       device=0 if transport == capi.TRANSPORT_HOST else rank)
+        st = capi.Sharded(g, model=model, optimizer=optimizer, k=4, capacity=64,
+                          schedule=schedule, seed=7)
+        alive = []   # freeing a minibatch whose Push is still outstanding would flush it early
+        for s in range(steps):
+            b = st.compile(*_data(rank, s))
+            alive.append(b)
+            assert b.U == len(np.unique(_data(rank, s)[1]))
+            st.step(b)
+            if schedule == "sequential" and s == 1:
+                st.defrag()          # row renumbering between steps must not change a bit
+        st.check()
+        rp, ks, lb = _data(rank, 99)
+        out = {"loss": st.predict(st.compile(rp, ks, lb)) - lb.astype(np.float32)}
+        st.check()
+        for nm, t in (("w", st.w), ("v", st.v)):
+            if t is not None:
+                k, w, n, z = t.export()
+                out.update({nm + "_k": k, nm + "_w": w, nm + "_n": n, nm + "_z": z})
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+        if save:
+            st.save(os.path.join(outdir, "ckpt"))
+        g.barrier()
+        st.close()
+        g.close()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps=4):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=_rank, args=(r, world, port, transport, model, optimizer, schedule,
+                                          steps, str(outdir), save, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    errs = [e for _, e in res if e]
+    assert not errs, errs[0]
+
+
+def _check_against_oracle(world, model, optimizer, schedule, outdir, steps=4):
+    with O.sum_mode(1):
+        w, v, losses = _simulate(world, model, optimizer, steps, schedule)
+    parts = [np.load(os.path.join(str(outdir), "rank%d.npz" % r)) for r in range(world)]
+    for nm, store in (("w", w), ("v", v)):
+        if store is None:
+            continue
+        ks, ws, ns, zs = store.export()
+        for r, p in enumerate(parts):
+            assert all(O.lib().xo_shard_of(int(k), world) == r for k in p[nm + "_k"])
+        k = np.concatenate([p[nm + "_k"] for p in parts])
+        order = np.argsort(k)
+        same(k[order], ks)
+        for f, ref in (("_w", ws), ("_n", ns), ("_z", zs)):
+            same(np.concatenate([p[nm + f] for p in parts])[order].reshape(ref.shape), ref)
+    for r in range(world):
+        same(parts[r]["loss"], losses[r])
+    return w, v
+
+
+@pytest.mark.parametrize("world,model,optimizer,schedule", [
+    (2, "lr", "ftrl", "sequential"), (2, "lr", "ftrl", "stale1"), (3, "lr", "sgd", "stale1"),
+    (3, "fm", "ftrl", "sequential"), (2, "fm", "sgd", "stale1")])
+def test_cpp_sharded_ranks_share_one_gpu(tmp_path, world, model, optimizer, schedule):
+    _run(world, capi.TRANSPORT_HOST, model, optimizer, schedule, tmp_path)
+    _check_against_oracle(world, model, optimizer, schedule, tmp_path)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("model,schedule", [("lr", "sequential"), ("lr", "stale1"),
+                                            ("fm", "stale1")])
+def test_cpp_sharded_over_rccl(tmp_path, world, model, schedule):
+    """one rank per GPU, the exchange over RCCL / xGMI: bit-exact with the same oracle run"""
+    import ctypes as C
+    n = C.c_int(0)
+    capi.check(capi.lib().xf_device_count(C.byref(n)))
+    if n.value < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, n.value))
+    _run(world, capi.TRANSPORT_RCCL, model, "ftrl", schedule, tmp_path)
+    _check_against_oracle(world, model, "ftrl", schedule, tmp_path)
+
+
+def test_rccl_group_of_one_and_the_fused_step():
+    """RCCL itself comes up (dlopen, unique id, communicator) with the one GPU there is, the
+    exchange of a one-rank group is a plain copy, and the trainer over it IS the fused step."""
+    import torch
+    g = capi.Group(0, 1, transport=capi.TRANSPORT_RCCL, device=0)
+    src = torch.arange(1000, dtype=torch.float32, device="cuda")
+    dst = torch.zeros_like(src)
+    g.alltoallv_dev(src.data_ptr(), [1000], dst.data_ptr(), [1000], 4,
+                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 12)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 12)
+    ws = capi.Workspace()
+    for s in range(3):
+        raw = _data(0, s)
+        st.step(st.compile(*raw))
+        capi.lr_step(t, capi.Batch(*raw), ws)
+    st.check()
+    for a, b in zip(st.w.export(), t.export()):
+        same(a, b)
+    raw = _data(0, 99)
+    same(st.predict(st.compile(*raw)), capi.lr_predict(t, capi.Batch(*raw), ws))
+
+
+def _load_rank(rank, world, port, outdir, q):
+    try:
+        g = capi.Group(rank, world, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
+        st = capi.Sharded(g, model="fm", optimizer="ftrl", k=4, capacity=64, seed=7)
+        st.load(os.path.join(outdir, "ckpt"))
+        out = {}
+        for nm, t in (("w", st.w), ("v", st.v)):
+            k, w, n, z = t.export()
+            out.update({nm + "_k": k, nm + "_w": w, nm + "_n": n, nm + "_z": z})
+        np.savez(os.path.join(outdir, "load%d_of_%d.npz" % (rank, world)), **out)
+        g.barrier()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_sharded_checkpoint_reshards_on_load(tmp_path):
+    """saved by 2 ranks (one file per shard + manifest), loaded by 3 ranks and by one"""
+    _run(2, capi.TRANSPORT_HOST, "fm", "ftrl", "sequential", tmp_path, save=True)
+    w, v = _check_against_oracle(2, "fm", "ftrl", "sequential", tmp_path)
+    assert sorted(os.listdir(str(tmp_path)))[:3] == ["ckpt.manifest", "ckpt.shard-00000-of-00002",
+                                                     "ckpt.shard-00001-of-00002"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=_load_rank, args=(r, 3, port, str(tmp_path), q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert not [e for _, e in res if e], [e for _, e in res if e][0]
+    parts = [np.load(str(tmp_path / ("load%d_of_3.npz" % r))) for r in range(3)]
+    one = capi.Sharded(None, model="fm", optimizer="ftrl", k=4, capacity=64, seed=7)
+    one.load(str(tmp_path / "ckpt"))
+    for nm, store, t in (("w", w, one.w), ("v", v, one.v)):
+        ks, ws, ns, zs = store.export()
+        for r, p in enumerate(parts):
+            assert all(O.lib().xo_shard_of(int(k), 3) == r for k in p[nm + "_k"])
+        k = np.concatenate([p[nm + "_k"] for p in parts])
+        order = np.argsort(k)
+        same(k[order], ks)
+        for f, ref in (("_w", ws), ("_n", ns), ("_z", zs)):
+            same(np.concatenate([p[nm + f] for p in parts])[order].reshape(ref.shape), ref)
+        for got, ref in zip(t.export(), (ks, ws, ns, zs)):
+            same(got, ref)

@@ -1,0 +1,81 @@
+"""The process group (xf_group_*) without a GPU: TCP bootstrap, rank assignment, the host-side
+collectives, and the all-to-all-v over the host transport with host buffers — world 2 and 3,
+one OS process per rank.  The RCCL transport itself needs GPUs (tests/test_gpu_group.py)."""
+import multiprocessing as mp
+import socket
+import traceback
+
+import numpy as np
+import pytest
+
+from xflow_amd import capi
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, auto_rank, q):
+    try:
+        g = capi.Group(rank=-1 if auto_rank else rank, world=world, addr="127.0.0.1", port=port,
+                       transport=capi.TRANSPORT_HOST)
+        r = g.rank
+        assert g.world == world and 0 <= r < world
+        g.barrier()
+        # allgather: every rank contributes a small vector
+        got = g.allgather(np.arange(3, dtype=np.int64) + 10 * r)
+        want = np.stack([np.arange(3, dtype=np.int64) + 10 * p for p in range(world)])
+        assert np.array_equal(got, want)
+        # all-to-all-v with ragged, partly empty slices: rank r sends (r + 2p) % 4 items to p
+        counts = np.array([(r + 2 * p) % 4 for p in range(world)], np.uint64)
+        send = np.concatenate([np.full(int(c), 1000 * r + p, np.uint64)
+                               for p, c in enumerate(counts)] + [np.zeros(0, np.uint64)])
+        recv, rc = g.alltoallv_host(send, counts)
+        exp_counts = np.array([(p + 2 * r) % 4 for p in range(world)], np.uint64)
+        assert np.array_equal(rc, exp_counts)
+        exp = np.concatenate([np.full(int(c), 1000 * p + r, np.uint64)
+                              for p, c in enumerate(exp_counts)] + [np.zeros(0, np.uint64)])
+        assert np.array_equal(recv, exp)
+        # gatherv to rank 0
+        mine = np.full(r + 1, float(r), np.float32)
+        allv = g.gatherv(mine)
+        if r == 0:
+            assert np.array_equal(allv, np.concatenate([np.full(p + 1, float(p), np.float32)
+                                                        for p in range(world)]))
+        else:
+            assert allv is None
+        g.barrier()
+        g.close()
+        q.put((rank, r, None))
+    except Exception:
+        q.put((rank, -1, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,auto_rank", [(2, False), (3, False), (3, True)])
+def test_group_host_transport(world, auto_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=_rank_main, args=(r, world, port, auto_rank, q))
+          for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=30)
+    errs = [e for _, _, e in res if e]
+    assert not errs, errs[0]
+    assert sorted(r for _, r, _ in res) == list(range(world))   # every rank handed out once
+
+
+def test_group_world1_and_bad_arguments():
+    g = capi.Group(rank=0, world=1, transport=capi.TRANSPORT_HOST)
+    assert (g.rank, g.world) == (0, 1)
+    g.barrier()
+    recv, rc = g.alltoallv_host(np.arange(5, dtype=np.float32), [5])
+    assert np.array_equal(recv, np.arange(5, dtype=np.float32)) and list(rc) == [5]
+    g.close()
+    with pytest.raises(capi.XFError):
+        capi.Group(rank=3, world=2, transport=capi.TRANSPORT_HOST)

@@ -35,6 +35,13 @@ class TableConfig(C.Structure):
                 ("nshards", C.c_uint32)]
 
 
+class ShardedConfig(C.Structure):
+    _fields_ = [("model", C.c_int32), ("optimizer", C.c_int32), ("k", C.c_int32),
+                ("schedule", C.c_int32), ("capacity", C.c_uint64), ("seed", C.c_uint64),
+                ("alpha", C.c_float), ("beta", C.c_float), ("lambda1", C.c_float),
+                ("lambda2", C.c_float), ("lr", C.c_float), ("host_key_build", C.c_int32)]
+
+
 class DevBatch(C.Structure):
     _fields_ = [("R", C.c_uint32), ("NNZ", C.c_uint32), ("U", C.c_uint32), ("H", C.c_uint32),
                 ("rowptr", vp), ("uidx", vp), ("ukeys", vp), ("segptr", vp), ("coo_row", vp),
@@ -126,6 +133,33 @@ SIGNATURES = {
     "xf_workspace_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "xf_stream_sync": (C.c_int, [vp]),
     "xf_calib_stream": (C.c_int, [C.c_int, C.c_size_t, C.c_int]),
+    "xf_group_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                  C.c_int]),
+    "xf_group_destroy": (C.c_int, [vp]),
+    "xf_group_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "xf_group_barrier": (C.c_int, [vp]),
+    "xf_group_allgather_host": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "xf_group_gatherv_host": (C.c_int, [vp, vp, C.c_size_t, vp, u64p]),
+    "xf_group_alltoallv": (C.c_int, [vp, vp, u64p, vp, u64p, C.c_size_t, C.c_int, vp]),
+    "xf_sharded_config_default": (None, [C.POINTER(ShardedConfig)]),
+    "xf_sharded_create": (C.c_int, [C.POINTER(vp), vp, C.POINTER(ShardedConfig)]),
+    "xf_sharded_destroy": (C.c_int, [vp]),
+    "xf_sharded_compile": (C.c_int, [vp, C.POINTER(vp), u64p, u64p, i32p, C.c_size_t,
+                                     C.c_size_t, C.c_int]),
+    "xf_sbatch_free": (C.c_int, [vp]),
+    "xf_sbatch_dims": (C.c_int, [vp, u32p, u32p, u32p, u64p]),
+    "xf_sharded_step": (C.c_int, [vp, vp]),
+    "xf_sharded_predict": (C.c_int, [vp, vp, f32p]),
+    "xf_sharded_flush": (C.c_int, [vp]),
+    "xf_sharded_defrag": (C.c_int, [vp]),
+    "xf_sharded_check": (C.c_int, [vp]),
+    "xf_sharded_set_schedule": (C.c_int, [vp, C.c_int]),
+    "xf_sharded_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "xf_sharded_stream": (C.c_int, [vp, C.POINTER(vp)]),
+    "xf_sharded_profile": (C.c_int, [vp, C.c_int]),
+    "xf_sharded_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "xf_sharded_save": (C.c_int, [vp, C.c_char_p]),
+    "xf_sharded_load": (C.c_int, [vp, C.c_char_p]),
     "xf_auc_logloss": (C.c_int, [i32p, f32p, C.c_size_t, f32p, f32p, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "XFCreate": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_char_p]),
@@ -532,6 +566,170 @@ def auc_logloss(labels, pctr, acc=0.0):
     check(lib().xf_auc_logloss(_p(labels, i32p), _p(pctr, f32p), len(labels), C.byref(ll),
                                C.byref(auc), C.byref(tp), C.byref(fp), C.byref(nat)))
     return ll.value, auc.value, tp.value, fp.value, nat.value
+
+
+TRANSPORT_RCCL, TRANSPORT_HOST = 0, 1
+
+
+class Group:
+    """The process group of a multi-GPU run (xf_group_*): TCP bootstrap around rank 0, RCCL
+    (or, for tests, host-staged) all-to-all-v."""
+
+    def __init__(self, rank=-1, world=0, addr=None, port=0, transport=TRANSPORT_RCCL, device=-1):
+        """device: >= 0 a GPU index, -1 the current device, -2 by rank (LOCAL_RANK, else rank
+        modulo the visible devices)"""
+        self.h = vp()
+        check(lib().xf_group_create(C.byref(self.h), rank, world,
+                                    addr.encode() if addr else None, port, transport, device))
+        r, w, t = C.c_int(), C.c_int(), C.c_int()
+        check(lib().xf_group_info(self.h, C.byref(r), C.byref(w), C.byref(t)))
+        self.rank, self.world, self.transport = r.value, w.value, t.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xf_group_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def barrier(self):
+        check(lib().xf_group_barrier(self.h))
+
+    def allgather(self, arr):
+        """every rank's (same-shaped) numpy array, stacked along a new first axis"""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, a.dtype)
+        check(lib().xf_group_allgather_host(self.h, a.ctypes.data, a.nbytes, out.ctypes.data))
+        return out
+
+    def gatherv(self, arr):
+        """rank 0 gets the concatenation of every rank's 1-d array, the others None"""
+        a = np.ascontiguousarray(arr)
+        sizes = self.allgather(np.array([a.nbytes], np.uint64)).ravel()
+        out = np.empty(int(sizes.sum()) // a.itemsize, a.dtype) if self.rank == 0 else None
+        check(lib().xf_group_gatherv_host(self.h, a.ctypes.data, a.nbytes,
+                                          out.ctypes.data if out is not None else None,
+                                          _p(sizes, u64p)))
+        return out
+
+    def alltoallv_host(self, send, send_counts):
+        """host arrays through the group (any transport that can move host memory)"""
+        a = np.ascontiguousarray(send)
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(self.allgather(sc)[:, self.rank])
+        out = np.empty(int(rc.sum()), a.dtype)
+        check(lib().xf_group_alltoallv(self.h, a.ctypes.data, _p(sc, u64p), out.ctypes.data,
+                                       _p(rc, u64p), a.itemsize, 1, None))
+        return out, rc
+
+    def alltoallv_dev(self, d_send, send_counts, d_recv, recv_counts, elem_bytes, stream=None):
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        check(lib().xf_group_alltoallv(self.h, d_send, _p(sc, u64p), d_recv, _p(rc, u64p),
+                                       elem_bytes, 0, stream))
+
+
+SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1 = 0, 1
+
+
+class ShardedBatch:
+    def __init__(self, h):
+        self.h = h
+        R, N, U, own = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(lib().xf_sbatch_dims(h, C.byref(R), C.byref(N), C.byref(U), C.byref(own)))
+        self.R, self.NNZ, self.U, self.n_owned = R.value, N.value, U.value, own.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().xf_sbatch_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Sharded:
+    """xf_sharded_*: LRWorker / FMWorker::update across the ranks of a Group (C++ + RCCL; this
+    class only marshals).  group=None: one rank, the fused single-shard step."""
+
+    def __init__(self, group=None, model="lr", optimizer="ftrl", k=10, capacity=1 << 22,
+                 schedule="sequential", seed=0, host_key_build=False, **hyper):
+        require_gpu()
+        c = ShardedConfig()
+        lib().xf_sharded_config_default(C.byref(c))
+        c.model = 0 if model == "lr" else 1
+        c.optimizer = OPT_FTRL if optimizer == "ftrl" else OPT_SGD
+        c.k, c.capacity, c.seed = k, capacity, seed
+        c.schedule = SCHEDULE_STALE1 if schedule == "stale1" else SCHEDULE_SEQUENTIAL
+        c.host_key_build = 1 if host_key_build else 0
+        for name, v in hyper.items():
+            setattr(c, name, v)
+        self.group = group
+        self.model, self.k = model, k
+        self.h = vp()
+        check(lib().xf_sharded_create(C.byref(self.h), group.h if group is not None else None,
+                                      C.byref(c)))
+        w, v = vp(), vp()
+        check(lib().xf_sharded_tables(self.h, C.byref(w), C.byref(v)))
+        self.w = Table.from_handle(w, 1, c.optimizer)
+        self.v = Table.from_handle(v, k, c.optimizer) if v else None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().xf_sharded_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def compile(self, rowptr, keys, labels, row_begin=0, row_end=None, keep=True):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if len(labels) == 0:
+            labels = np.zeros(1, np.int32)       # a non-null pointer for an empty minibatch
+        if row_end is None:
+            row_end = len(rowptr) - 1
+        h = vp()
+        check(lib().xf_sharded_compile(self.h, C.byref(h), _p(rowptr, u64p), _p(keys, u64p),
+                                       _p(labels, i32p), row_begin, row_end, 1 if keep else 0))
+        return ShardedBatch(h)
+
+    def step(self, b):
+        check(lib().xf_sharded_step(self.h, b.h))
+
+    def predict(self, b):
+        out = np.empty(max(b.R, 1), np.float32)
+        check(lib().xf_sharded_predict(self.h, b.h, _p(out, f32p)))
+        return out[:b.R]
+
+    def flush(self):
+        check(lib().xf_sharded_flush(self.h))
+
+    def defrag(self):
+        check(lib().xf_sharded_defrag(self.h))
+
+    def check(self):
+        check(lib().xf_sharded_check(self.h))
+
+    def set_schedule(self, schedule):
+        check(lib().xf_sharded_set_schedule(
+            self.h, SCHEDULE_STALE1 if schedule == "stale1" else SCHEDULE_SEQUENTIAL))
+
+    def save(self, prefix):
+        check(lib().xf_sharded_save(self.h, prefix.encode()))
+
+    def load(self, prefix):
+        check(lib().xf_sharded_load(self.h, prefix.encode()))
+
+    def profile(self, enable):
+        check(lib().xf_sharded_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 6)()
+        steps = C.c_long(0)
+        check(lib().xf_sharded_profile_read(self.h, ms, C.byref(steps)))
+        names = ["owner_pull", "a2a_weights", "forward", "gradient", "a2a_grads", "owner_update"]
+        return {k: ms[i] for i, k in enumerate(names)}, steps.value
 
 
 class XFlow:

@@ -1,0 +1,461 @@
+// xf_group.cc — the process group of a multi-GPU run: one process per GPU, the exchange steps
+// of the sharded table behind the C ABI.
+//
+// Replaces ps-lite's van / postoffice as xflow uses them (src/model/main.cc:22-47:
+// ps::Start / IsWorker / MyRank / Finalize; the launch environment of scripts/local.sh:3-14:
+// DMLC_NUM_WORKER, DMLC_PS_ROOT_URI, DMLC_PS_ROOT_PORT) and the transport under
+// KVWorker::Push/Pull (src/model/lr/lr_worker.cc:170,175): keys / weights / gradients travel
+// to and from the shard that owns them as ONE all-to-all-v per direction.
+//
+// Two layers:
+//   * bootstrap: a TCP star around rank 0 (the process that owns MASTER_ADDR:MASTER_PORT —
+//     what ps-lite's scheduler is to its nodes).  Ranks are given (RANK / DMLC_RANK) or, as in
+//     ps-lite, handed out in arrival order.  Small host-side collectives (barrier, allgather of
+//     counts / flags, the ncclUniqueId broadcast) run over it.
+//   * data path: RCCL over xGMI — grouped ncclSend / ncclRecv per peer on the caller's stream
+//     (xGMI is a full mesh: each peer pair has its own link, an all-to-all is one message per
+//     link).  librccl is opened at run time (dlopen), so the library has no link-time
+//     dependency on it and shares the copy a host program (e.g. torch) may already have mapped.
+//     XF_TRANSPORT_HOST stages the same exchange through the bootstrap sockets instead: for
+//     tests that run several ranks on ONE GPU (RCCL refuses two ranks per device) or none.
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "xf_common.h"
+
+namespace {
+
+// ---- the slice of rccl.h this file uses (the library is dlopen'ed)
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef void *ncclComm_h;
+struct Rccl {
+  void *so = nullptr;
+  int (*GetUniqueId)(ncclUniqueId_t *) = nullptr;
+  int (*CommInitRank)(ncclComm_h *, int, ncclUniqueId_t, int) = nullptr;
+  int (*CommDestroy)(ncclComm_h) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_h, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_h, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+
+int load_rccl(Rccl &r) {
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (r.so) break;
+  }
+  if (!r.so) return xf::set_error(XF_EHIP, "cannot open librccl.so.1: %s", dlerror());
+#define XF_SYM(field, name)                                             \
+  *(void **)(&r.field) = dlsym(r.so, name);                             \
+  if (!r.field) return xf::set_error(XF_EHIP, "librccl has no %s", name)
+  XF_SYM(GetUniqueId, "ncclGetUniqueId");
+  XF_SYM(CommInitRank, "ncclCommInitRank");
+  XF_SYM(CommDestroy, "ncclCommDestroy");
+  XF_SYM(GroupStart, "ncclGroupStart");
+  XF_SYM(GroupEnd, "ncclGroupEnd");
+  XF_SYM(Send, "ncclSend");
+  XF_SYM(Recv, "ncclRecv");
+  XF_SYM(GetErrorString, "ncclGetErrorString");
+#undef XF_SYM
+  return XF_OK;
+}
+
+// ---- sockets
+int send_all(int fd, const void *p, size_t n) {
+  const char *c = (const char *)p;
+  while (n) {
+    const ssize_t k = send(fd, c, n, MSG_NOSIGNAL);
+    if (k < 0) {
+      if (errno == EINTR) continue;
+      return xf::set_error(XF_EIO, "group: send failed: %s", strerror(errno));
+    }
+    c += k;
+    n -= (size_t)k;
+  }
+  return XF_OK;
+}
+
+int recv_all(int fd, void *p, size_t n) {
+  char *c = (char *)p;
+  while (n) {
+    const ssize_t k = recv(fd, c, n, 0);
+    if (k == 0) return xf::set_error(XF_EIO, "group: a peer closed its connection");
+    if (k < 0) {
+      if (errno == EINTR) continue;
+      return xf::set_error(XF_EIO, "group: recv failed: %s", strerror(errno));
+    }
+    c += k;
+    n -= (size_t)k;
+  }
+  return XF_OK;
+}
+
+void tune_socket(int fd) {
+  int one = 1;
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+}
+
+const char *env_first(std::initializer_list<const char *> names) {
+  for (const char *n : names) {
+    const char *v = getenv(n);
+    if (v && *v) return v;
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+struct xf_group {
+  int rank = 0, world = 1, transport = XF_TRANSPORT_RCCL;
+  int listen_fd = -1;
+  std::vector<int> peer;  // rank 0: socket of every other rank; others: peer[0] = rank 0
+  Rccl rccl;
+  ncclComm_h comm = nullptr;
+  std::vector<char> hs, hr;  // host staging of the host transport
+};
+
+namespace {
+
+// rank 0 gathers `bytes` from everybody, everybody gets all of it back
+int allgather_host(xf_group *g, const void *in, size_t bytes, void *out) {
+  char *o = (char *)out;
+  if (g->world == 1) {
+    memcpy(o, in, bytes);
+    return XF_OK;
+  }
+  if (g->rank == 0) {
+    memcpy(o, in, bytes);
+    for (int r = 1; r < g->world; ++r) XF_TRY(recv_all(g->peer[r], o + (size_t)r * bytes, bytes));
+    for (int r = 1; r < g->world; ++r) XF_TRY(send_all(g->peer[r], o, bytes * g->world));
+  } else {
+    XF_TRY(send_all(g->peer[0], in, bytes));
+    XF_TRY(recv_all(g->peer[0], o, bytes * g->world));
+  }
+  return XF_OK;
+}
+
+}  // namespace
+
+// rank < 0 / world <= 0 / addr == NULL / port <= 0: taken from the environment —
+//   world: WORLD_SIZE, XF_WORLD, DMLC_NUM_WORKER      rank: RANK, XF_RANK, DMLC_RANK (absent:
+//   addr:  MASTER_ADDR, DMLC_PS_ROOT_URI (127.0.0.1)         handed out in arrival order,
+//   port:  MASTER_PORT, DMLC_PS_ROOT_PORT (29512)            the process that binds the port
+//                                                            first being rank 0)
+extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *addr, int port,
+                               int transport, int device) {
+  XF_REQUIRE(out, "xf_group_create: null argument");
+  XF_REQUIRE(transport == XF_TRANSPORT_RCCL || transport == XF_TRANSPORT_HOST,
+             "xf_group_create: transport %d", transport);
+  if (world <= 0) {
+    const char *v = env_first({"WORLD_SIZE", "XF_WORLD", "DMLC_NUM_WORKER"});
+    world = v ? atoi(v) : 1;
+  }
+  if (rank < 0) {
+    const char *v = env_first({"RANK", "XF_RANK", "DMLC_RANK"});
+    rank = v ? atoi(v) : -1;
+  }
+  std::string host = addr ? addr : "";
+  if (host.empty()) {
+    const char *v = env_first({"MASTER_ADDR", "DMLC_PS_ROOT_URI"});
+    host = v ? v : "127.0.0.1";
+  }
+  if (port <= 0) {
+    const char *v = env_first({"MASTER_PORT", "DMLC_PS_ROOT_PORT"});
+    port = v ? atoi(v) : 29512;
+  }
+  XF_REQUIRE(world >= 1 && rank < world, "xf_group_create: rank %d of %d", rank, world);
+  xf_group *g = new xf_group;
+  g->world = world;
+  g->transport = transport;
+  struct Guard {
+    xf_group *g;
+    ~Guard() {
+      if (g) xf_group_destroy(g);
+    }
+  } guard{g};
+  if (world == 1) {
+    g->rank = 0;
+  } else {
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, host.c_str(), &sa.sin_addr) != 1) {
+      addrinfo hints{}, *res = nullptr;
+      hints.ai_family = AF_INET;
+      hints.ai_socktype = SOCK_STREAM;
+      if (getaddrinfo(host.c_str(), nullptr, &hints, &res) != 0 || !res)
+        return xf::set_error(XF_EIO, "xf_group_create: cannot resolve %s", host.c_str());
+      sa.sin_addr = ((sockaddr_in *)res->ai_addr)->sin_addr;
+      freeaddrinfo(res);
+    }
+    bool root = rank == 0;
+    if (rank <= 0) {  // rank 0, or "whoever binds first"
+      const int fd = socket(AF_INET, SOCK_STREAM, 0);
+      int one = 1;
+      setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      sockaddr_in any = sa;
+      any.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (bind(fd, (sockaddr *)&any, sizeof(any)) == 0 && listen(fd, world + 8) == 0) {
+        g->listen_fd = fd;
+        root = true;
+      } else {
+        close(fd);
+        if (rank == 0)
+          return xf::set_error(XF_EIO, "xf_group_create: rank 0 cannot listen on port %d: %s",
+                               port, strerror(errno));
+      }
+    }
+    if (root) {
+      g->rank = 0;
+      g->peer.assign(world, -1);
+      int next_auto = 1;
+      std::vector<int> pending;  // connections that asked for "any rank"
+      for (int have = 1; have < world; ++have) {
+        pollfd pf{g->listen_fd, POLLIN, 0};
+        if (poll(&pf, 1, 120000) <= 0)
+          return xf::set_error(XF_EIO, "xf_group_create: %d of %d ranks arrived within 120 s",
+                               have, world);
+        const int fd = accept(g->listen_fd, nullptr, nullptr);
+        if (fd < 0) return xf::set_error(XF_EIO, "xf_group_create: accept: %s", strerror(errno));
+        tune_socket(fd);
+        int32_t want = -1;
+        XF_TRY(recv_all(fd, &want, 4));
+        if (want < 0) {
+          pending.push_back(fd);
+        } else {
+          if (want == 0 || want >= world || g->peer[want] != -1) {
+            close(fd);
+            return xf::set_error(XF_EINVAL, "xf_group_create: rank %d announced twice or out of "
+                                 "range", want);
+          }
+          g->peer[want] = fd;
+        }
+      }
+      for (int fd : pending) {  // arrival order fills the ranks nobody claimed
+        while (next_auto < world && g->peer[next_auto] != -1) ++next_auto;
+        g->peer[next_auto] = fd;
+      }
+      for (int r = 1; r < world; ++r) {
+        const int32_t id[2] = {r, world};
+        XF_TRY(send_all(g->peer[r], id, 8));
+      }
+    } else {
+      int fd = -1;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {  // rank 0 may not be up yet
+        fd = socket(AF_INET, SOCK_STREAM, 0);
+        if (connect(fd, (sockaddr *)&sa, sizeof(sa)) == 0) break;
+        close(fd);
+        fd = -1;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+          return xf::set_error(XF_EIO, "xf_group_create: cannot reach rank 0 at %s:%d: %s",
+                               host.c_str(), port, strerror(errno));
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+      tune_socket(fd);
+      g->peer.assign(1, fd);
+      const int32_t want = rank;
+      XF_TRY(send_all(fd, &want, 4));
+      int32_t id[2] = {0, 0};
+      XF_TRY(recv_all(fd, id, 8));
+      if (id[1] != world)
+        return xf::set_error(XF_EINVAL, "xf_group_create: rank 0 runs a world of %d, this "
+                             "process one of %d", id[1], world);
+      g->rank = id[0];
+    }
+  }
+  // this process's GPU: a given device, the current one (-1), or by rank (-2: LOCAL_RANK, else
+  // rank modulo the visible devices) — ranks may only be known now
+  if (device >= 0 || device == -2) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+      int d = device;
+      if (device == -2) {
+        const char *lr = env_first({"LOCAL_RANK"});
+        d = lr ? atoi(lr) : g->rank % ndev;
+      }
+      XF_REQUIRE(d >= 0 && d < ndev, "xf_group_create: device %d of %d", d, ndev);
+      XF_HIP(hipSetDevice(d));
+    } else if (transport == XF_TRANSPORT_RCCL) {
+      return xf::set_error(XF_ENOGPU, "xf_group_create: no HIP device for the RCCL transport");
+    }
+  }
+  if (transport == XF_TRANSPORT_RCCL) {
+    XF_TRY(load_rccl(g->rccl));
+    std::vector<ncclUniqueId_t> ids(g->world);
+    ncclUniqueId_t mine{};
+    if (g->rank == 0) {
+      const int rc = g->rccl.GetUniqueId(&mine);
+      if (rc) return xf::set_error(XF_EHIP, "ncclGetUniqueId: %s", g->rccl.GetErrorString(rc));
+    }
+    XF_TRY(allgather_host(g, &mine, sizeof(mine), ids.data()));
+    const int rc = g->rccl.CommInitRank(&g->comm, g->world, ids[0], g->rank);
+    if (rc) return xf::set_error(XF_EHIP, "ncclCommInitRank(rank %d of %d): %s", g->rank,
+                                 g->world, g->rccl.GetErrorString(rc));
+  }
+  guard.g = nullptr;
+  *out = g;
+  return XF_OK;
+}
+
+extern "C" int xf_group_destroy(xf_group *g) {
+  if (!g) return XF_OK;
+  if (g->comm && g->rccl.CommDestroy) g->rccl.CommDestroy(g->comm);
+  for (int fd : g->peer)
+    if (fd >= 0) close(fd);
+  if (g->listen_fd >= 0) close(g->listen_fd);
+  delete g;
+  return XF_OK;
+}
+
+extern "C" int xf_group_info(const xf_group *g, int *rank, int *world, int *transport) {
+  XF_REQUIRE(g, "xf_group_info: null group");
+  if (rank) *rank = g->rank;
+  if (world) *world = g->world;
+  if (transport) *transport = g->transport;
+  return XF_OK;
+}
+
+extern "C" int xf_group_allgather_host(xf_group *g, const void *in, size_t bytes, void *out) {
+  XF_REQUIRE(g && (bytes == 0 || (in && out)), "xf_group_allgather_host: null argument");
+  if (bytes == 0) return XF_OK;
+  return allgather_host(g, in, bytes, out);
+}
+
+extern "C" int xf_group_barrier(xf_group *g) {
+  XF_REQUIRE(g, "xf_group_barrier: null group");
+  char a = 0;
+  std::vector<char> all(g->world);
+  return allgather_host(g, &a, 1, all.data());
+}
+
+// rank 0 receives every rank's variable-size blob (sizes[r] bytes each); others get nothing
+extern "C" int xf_group_gatherv_host(xf_group *g, const void *in, size_t bytes, void *out,
+                                     const uint64_t *sizes) {
+  XF_REQUIRE(g, "xf_group_gatherv_host: null group");
+  if (g->rank != 0) return bytes ? send_all(g->peer[0], in, bytes) : XF_OK;
+  XF_REQUIRE(out && sizes, "xf_group_gatherv_host: rank 0 needs the output buffer and sizes");
+  char *o = (char *)out;
+  if (bytes) memcpy(o, in, bytes);
+  size_t off = (size_t)sizes[0];
+  for (int r = 1; r < g->world; ++r) {
+    if (sizes[r]) XF_TRY(recv_all(g->peer[r], o + off, (size_t)sizes[r]));
+    off += (size_t)sizes[r];
+  }
+  return XF_OK;
+}
+
+// The exchange step of the sharded table: rank p's slice send[off_p .. off_p + send_counts[p])
+// goes to rank p, recv is filled in source-rank order (counts in elements of elem_bytes).
+// RCCL: asynchronous on `stream`, the buffers are device memory.  Host transport: blocking;
+// device buffers are staged through the host (host_buffers != 0: they are host memory).
+extern "C" int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t *send_counts,
+                                  void *recv, const uint64_t *recv_counts, size_t elem_bytes,
+                                  int host_buffers, void *stream) {
+  XF_REQUIRE(g && send_counts && recv_counts && elem_bytes, "xf_group_alltoallv: null argument");
+  const int W = g->world;
+  std::vector<size_t> so(W + 1, 0), ro(W + 1, 0);
+  for (int p = 0; p < W; ++p) {
+    so[p + 1] = so[p] + (size_t)send_counts[p] * elem_bytes;
+    ro[p + 1] = ro[p] + (size_t)recv_counts[p] * elem_bytes;
+  }
+  XF_REQUIRE((so[W] == 0 || send) && (ro[W] == 0 || recv), "xf_group_alltoallv: null buffer");
+  XF_REQUIRE(send_counts[g->rank] == recv_counts[g->rank],
+             "xf_group_alltoallv: a rank's slice for itself differs between send and recv");
+  hipStream_t s = (hipStream_t)stream;
+  const char *sb = (const char *)send;
+  char *rb = (char *)recv;
+  if (g->transport == XF_TRANSPORT_RCCL) {
+    XF_REQUIRE(!host_buffers, "xf_group_alltoallv: the RCCL transport moves device memory");
+    const size_t self = so[g->rank + 1] - so[g->rank];
+    if (self)  // the slice that stays: a plain copy, no collective
+      XF_HIP(hipMemcpyAsync(rb + ro[g->rank], sb + so[g->rank], self, hipMemcpyDeviceToDevice, s));
+    if (W == 1) return XF_OK;
+    int rc = g->rccl.GroupStart();
+    for (int p = 0; p < W && !rc; ++p) {
+      if (p == g->rank) continue;
+      if (so[p + 1] > so[p])
+        rc = g->rccl.Send(sb + so[p], so[p + 1] - so[p], kNcclChar, p, g->comm, s);
+      if (!rc && ro[p + 1] > ro[p])
+        rc = g->rccl.Recv(rb + ro[p], ro[p + 1] - ro[p], kNcclChar, p, g->comm, s);
+    }
+    const int rc2 = g->rccl.GroupEnd();
+    if (rc || rc2)
+      return xf::set_error(XF_EHIP, "xf_group_alltoallv: %s",
+                           g->rccl.GetErrorString(rc ? rc : rc2));
+    return XF_OK;
+  }
+  // ---- host transport: through rank 0
+  const void *hsend = send;
+  void *hrecv = recv;
+  if (!host_buffers) {
+    XF_HIP(hipStreamSynchronize(s));
+    g->hs.resize(so[W]);
+    g->hr.resize(ro[W]);
+    if (so[W]) XF_HIP(hipMemcpy(g->hs.data(), send, so[W], hipMemcpyDeviceToHost));
+    hsend = g->hs.data();
+    hrecv = g->hr.data();
+  }
+  const char *hsb = (const char *)hsend;
+  char *hrb = (char *)hrecv;
+  if (W == 1) {
+    if (so[1]) memcpy(hrb, hsb, so[1]);
+  } else if (g->rank == 0) {
+    // everybody's send buffer (with its byte offsets) comes in, every rank's recv buffer goes out
+    std::vector<std::vector<char>> bufs(W);
+    std::vector<std::vector<uint64_t>> offs(W, std::vector<uint64_t>(W + 1));
+    bufs[0].assign(hsb, hsb + so[W]);
+    for (int p = 0; p <= W; ++p) offs[0][p] = so[p];
+    for (int r = 1; r < W; ++r) {
+      XF_TRY(recv_all(g->peer[r], offs[r].data(), (W + 1) * 8));
+      bufs[r].resize((size_t)offs[r][W]);
+      if (offs[r][W]) XF_TRY(recv_all(g->peer[r], bufs[r].data(), bufs[r].size()));
+    }
+    for (int dst = 0; dst < W; ++dst) {
+      std::vector<char> outb;
+      for (int src = 0; src < W; ++src)
+        outb.insert(outb.end(), bufs[src].begin() + offs[src][dst],
+                    bufs[src].begin() + offs[src][dst + 1]);
+      if (dst == 0) {
+        if (outb.size() != ro[W])
+          return xf::set_error(XF_EINVAL, "xf_group_alltoallv: rank 0 expected %zu bytes, the "
+                               "ranks sent it %zu", ro[W], outb.size());
+        if (!outb.empty()) memcpy(hrb, outb.data(), outb.size());
+      } else {
+        const uint64_t n = outb.size();
+        XF_TRY(send_all(g->peer[dst], &n, 8));
+        if (n) XF_TRY(send_all(g->peer[dst], outb.data(), outb.size()));
+      }
+    }
+  } else {
+    std::vector<uint64_t> off(W + 1);
+    for (int p = 0; p <= W; ++p) off[p] = so[p];
+    XF_TRY(send_all(g->peer[0], off.data(), (W + 1) * 8));
+    if (so[W]) XF_TRY(send_all(g->peer[0], hsb, so[W]));
+    uint64_t n = 0;
+    XF_TRY(recv_all(g->peer[0], &n, 8));
+    if (n != ro[W])
+      return xf::set_error(XF_EINVAL, "xf_group_alltoallv: rank %d expected %zu bytes, got %llu",
+                           g->rank, ro[W], (unsigned long long)n);
+    if (n) XF_TRY(recv_all(g->peer[0], hrb, (size_t)n));
+  }
+  if (!host_buffers && ro[W]) XF_HIP(hipMemcpy(recv, g->hr.data(), ro[W], hipMemcpyHostToDevice));
+  return XF_OK;
+}

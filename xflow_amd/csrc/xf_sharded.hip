@@ -1,0 +1,735 @@
+// xf_sharded.hip — LRWorker / FMWorker::update across `world` GPUs, one process per GPU, with
+// the parameter table sharded by key range (gfx950 + RCCL).
+//
+// Replaces ps-lite's worker <-> server routing (src/model/lr/lr_worker.cc:170,175;
+// src/model/fm/fm_worker.cc:228-242): Pull(keys) = keys to their owners, weights back;
+// Push(keys, grads) = gradients to the owners, owner-side FTRL / SGD (ftrl.h:54-74, sgd.h:52).
+// Like ps-lite's default slicer, a SORTED key list splits into one contiguous range per owner
+// (owner = min(key / (UINT64_MAX / N), N-1)), so every exchange is a plain all-to-all-v without
+// permutation (xf_group_alltoallv: grouped ncclSend/ncclRecv over xGMI).
+//
+// What depends only on the minibatch is exchanged ONCE, when it is compiled: the split
+// counts, the keys (so a step moves weights one way and gradients the other, never keys), the
+// order in which the owner walks all sources' keys merged by key, and — cached per table row
+// numbering — the owner-side state rows of those keys (the Pull's resolve).
+//
+// Update semantics with N workers: every worker's gradient is its own optimizer
+// step, scaled by its own 1/R (lr_worker.cc:116-118); the owner applies the N pushes of a
+// step in RANK ORDER after all N pulls — one legal, deterministic serialisation of what
+// ps-lite does asynchronously.  Two schedules:
+//   sequential  Pull, compute, Push of step t finish before Pull(t+1)
+//   stale1      Push(t) runs on a second stream: its gradient exchange overlaps Pull(t+1) on
+//               the owner, its optimizer pass — ordered by events after Pull(t+1) has read
+//               the table and before Pull(t+2) — overlaps the next weights exchange, forward
+//               and gradient.  Weights are exactly one step stale (inside ps-lite's
+//               asynchronous semantics), still deterministic.
+// With world == 1 there is nothing to exchange: the step IS the fused single-shard step
+// (xf_lr_step / xf_fm_step) on a locally compiled minibatch.
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "xf_batch.h"
+#include "xf_cells.h"
+#include "xf_common.h"
+#include "xf_scratch.h"
+
+namespace xf {
+int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_t s);
+uint64_t table_uid(const xf_table *t);
+uint64_t table_epoch(const xf_table *t);
+int table_ensure_room(xf_table *t, size_t incoming);
+}  // namespace xf
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(size_t n) {
+  size_t g = (n + kBlock - 1) / kBlock;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// split[p] = first index of the sorted unique keys that belongs to shard >= p (p = 0..world)
+__global__ void k_owner_split(const uint64_t *__restrict__ ukeys, uint32_t U, uint32_t world,
+                              uint32_t *__restrict__ split) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > world) return;
+  if (p == 0 || p == world) {
+    split[p] = p == 0 ? 0u : U;
+    return;
+  }
+  const uint64_t bound = (UINT64_MAX / world) * p;  // first key of shard p (xf_common.h)
+  uint32_t lo = 0, hi = U;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (ukeys[mid] < bound) lo = mid + 1;
+    else
+      hi = mid;
+  }
+  split[p] = lo;
+}
+
+__global__ void k_iota32(uint32_t *p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (uint32_t)i;
+}
+
+template <typename T>
+struct Dev {
+  T *p = nullptr;
+  size_t n = 0;
+  Dev() = default;
+  Dev(const Dev &) = delete;
+  Dev &operator=(const Dev &) = delete;
+  ~Dev() {
+    if (p) (void)hipFree(p);
+  }
+  int reserve(size_t want) {
+    if (want <= n && p) return XF_OK;
+    if (p) XF_HIP(hipFree(p));
+    p = nullptr;
+    n = 0;
+    XF_HIP(hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T)));
+    n = want;
+    return XF_OK;
+  }
+};
+
+enum { kEvPull = 0, kEvA2aW, kEvForward, kEvGrad, kEvA2aG, kEvUpdate, kEvN };
+
+}  // namespace
+
+// per-step buffers of one minibatch; two sets, used alternately, so that a Push still in
+// flight on the side stream (stale1) never shares a buffer with the next step on this batch
+struct StepBuf {
+  Dev<float> w_send, wu, g, g_recv, loss, vsum;
+  Dev<float> v_send, vu, gv, gv_recv;
+};
+
+struct xf_sbatch {
+  xf_batch *b = nullptr;      // the compiled minibatch (world 1: compiled against the table)
+  xf_cells *cells = nullptr;  // world > 1, LR: the cells over the batch's unique-key index
+  uint32_t R = 0, NNZ = 0, U = 0;
+  std::vector<uint64_t> send_counts, recv_counts;  // per peer: keys I send / keys I own
+  size_t n_recv = 0;
+  Dev<uint64_t> rkeys, rkeys_sorted;  // the keys this rank owns, per source; merged by key
+  Dev<uint32_t> rorder;               // sorted entry i sits at rorder[i] of the per-source layout
+  Dev<uint32_t> rows_w, rows_v;       // their state rows (valid for one table epoch)
+  uint64_t rows_uid = 0, rows_epoch = ~0ull;
+  StepBuf buf[2];
+  int flip = 0;
+  xf_sharded *owner = nullptr;
+};
+
+struct xf_sharded {
+  xf_group *g = nullptr;
+  int rank = 0, world = 1;
+  xf_sharded_config cfg{};
+  xf_table *tw = nullptr, *tv = nullptr;
+  xf_workspace *ws = nullptr;  // world 1: the fused step's scratch
+  uint64_t seen_upper = 0;     // world 1: host-side upper bound on the keys in the table
+  Dev<double> partial;         // LR forward scratch
+  hipStream_t main = nullptr, side = nullptr;
+  hipEvent_t ev_pulled = nullptr, ev_graded = nullptr, ev_applied = nullptr;
+  bool have_applied = false, have_graded = false, have_pulled = false;
+  // stale1: the step whose Push is outstanding
+  xf_sbatch *pending = nullptr;
+  int pending_flip = 0;
+  // per-stage timing (sequential schedule only)
+  bool profiling = false;
+  hipEvent_t pev[kEvN + 1] = {};
+  double ms_sum[kEvN] = {};
+  long steps_timed = 0;
+  bool pev_pending = false;
+};
+
+namespace {
+
+int a2a(xf_sharded *st, const void *send, const std::vector<uint64_t> &sc, void *recv,
+        const std::vector<uint64_t> &rc, size_t elem_bytes, hipStream_t s) {
+  return xf_group_alltoallv(st->g, send, sc.data(), recv, rc.data(), elem_bytes, 0, (void *)s);
+}
+
+int collect_profile(xf_sharded *st) {
+  if (!st->pev_pending) return XF_OK;
+  XF_HIP(hipEventSynchronize(st->pev[kEvN]));
+  for (int i = 0; i < kEvN; ++i) {
+    float ms = 0.f;
+    XF_HIP(hipEventElapsedTime(&ms, st->pev[i], st->pev[i + 1]));
+    st->ms_sum[i] += ms;
+  }
+  ++st->steps_timed;
+  st->pev_pending = false;
+  return XF_OK;
+}
+
+#define XF_MARK(i)                                                                \
+  do {                                                                            \
+    if (st->profiling && st->cfg.schedule == XF_SCHEDULE_SEQUENTIAL)              \
+      XF_HIP(hipEventRecord(st->pev[i], st->main));                               \
+  } while (0)
+
+// owner side of the Pull: state rows of the keys this rank owns (resolved once per row
+// numbering, inserting on first touch — ftrl.h:56) and the weight payload
+int front_pull(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
+  const size_t n = b->n_recv;
+  const bool fm = st->cfg.model == 1;
+  const uint64_t uid = xf::table_uid(st->tw), ep = xf::table_epoch(st->tw);
+  if (b->rows_uid != uid || b->rows_epoch != ep) {
+    XF_TRY(b->rows_w.reserve(n));
+    if (fm) XF_TRY(b->rows_v.reserve(n));
+    if (n) {
+      // every key may be new to this shard: make room first (the table grows by itself)
+      XF_TRY(xf::table_ensure_room(st->tw, n));
+      if (fm) XF_TRY(xf::table_ensure_room(st->tv, n));
+      // all sources' lists in one pass over the shard, visited in key order (the same key may
+      // come from several workers: the table's resolve handles that)
+      XF_TRY(xf_table_pull_ordered_dev(st->tw, b->rkeys_sorted.p, b->rorder.p, n, b->rows_w.p,
+                                       nullptr, s));
+      if (fm)
+        XF_TRY(xf_table_pull_ordered_dev(st->tv, b->rkeys_sorted.p, b->rorder.p, n, b->rows_v.p,
+                                         nullptr, s));
+    }
+    b->rows_uid = uid;
+    b->rows_epoch = ep;
+  }
+  XF_TRY(B.w_send.reserve(n));
+  if (n) XF_TRY(xf_table_gather_dev(st->tw, b->rows_w.p, n, B.w_send.p, s));
+  if (fm) {
+    XF_TRY(B.v_send.reserve(n * st->cfg.k));
+    if (n) XF_TRY(xf_table_gather_dev(st->tv, b->rows_v.p, n, B.v_send.p, s));
+  }
+  return XF_OK;
+}
+
+// weights back to the workers, forward, gradient
+int front_compute(xf_sharded *st, xf_sbatch *b, StepBuf &B, float *d_pctr, bool want_grad,
+                  hipStream_t s) {
+  const bool fm = st->cfg.model == 1;
+  const int k = st->cfg.k;
+  XF_TRY(B.wu.reserve(b->U));
+  XF_TRY(B.loss.reserve(b->R));
+  XF_TRY(a2a(st, B.w_send.p, b->recv_counts, B.wu.p, b->send_counts, 4, s));
+  if (fm) {
+    XF_TRY(B.vu.reserve((size_t)b->U * k));
+    XF_TRY(B.vsum.reserve(b->R));
+    XF_TRY(a2a(st, B.v_send.p, b->recv_counts, B.vu.p, b->send_counts, 4 * (size_t)k, s));
+  }
+  XF_MARK(kEvA2aW + 1);
+  if (!fm) {
+    XF_TRY(st->partial.reserve(xf::cells_partial_doubles(b->cells)));
+    XF_TRY(xf::cells_lr_forward(b->cells, B.wu.p, b->b->view.labels, st->partial.p, B.loss.p,
+                                d_pctr, s));
+    XF_MARK(kEvForward + 1);
+    if (want_grad) {
+      XF_TRY(B.g.reserve(b->U));
+      XF_TRY(xf::cells_lr_grad(b->cells, B.loss.p, B.g.p, s));
+    }
+  } else {
+    XF_TRY(xf_fm_forward_dev(&b->b->view, k, B.wu.p, B.vu.p, B.loss.p, d_pctr, B.vsum.p, s));
+    XF_MARK(kEvForward + 1);
+    if (want_grad) {
+      XF_TRY(B.g.reserve(b->U));
+      XF_TRY(B.gv.reserve((size_t)b->U * k));
+      XF_TRY(xf_fm_grad_dev(&b->b->view, k, B.vu.p, B.vsum.p, B.loss.p, B.g.p, B.gv.p, s));
+    }
+  }
+  XF_MARK(kEvGrad + 1);
+  return XF_OK;
+}
+
+// Push: gradients to the owners (the keys are already there) ...
+int back_exchange(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
+  XF_TRY(B.g_recv.reserve(b->n_recv));
+  XF_TRY(a2a(st, B.g.p, b->send_counts, B.g_recv.p, b->recv_counts, 4, s));
+  if (st->cfg.model == 1) {
+    XF_TRY(B.gv_recv.reserve(b->n_recv * st->cfg.k));
+    XF_TRY(a2a(st, B.gv.p, b->send_counts, B.gv_recv.p, b->recv_counts, 4 * (size_t)st->cfg.k, s));
+  }
+  return XF_OK;
+}
+
+// ... and the owner-side optimizer steps: ONE pass over the shard, a key's pushes applied one
+// after the other in source-rank order
+int back_apply(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
+  if (!b->n_recv) return XF_OK;
+  XF_TRY(xf_table_update_merged_dev(st->tw, b->rkeys_sorted.p, b->rorder.p, b->n_recv,
+                                    b->rows_w.p, B.g_recv.p, s));
+  if (st->cfg.model == 1)
+    XF_TRY(xf_table_update_merged_dev(st->tv, b->rkeys_sorted.p, b->rorder.p, b->n_recv,
+                                      b->rows_v.p, B.gv_recv.p, s));
+  return XF_OK;
+}
+
+int flush_pending(xf_sharded *st) {
+  if (st->pending) {
+    xf_sbatch *pb = st->pending;
+    StepBuf &PB = pb->buf[st->pending_flip];
+    if (st->have_graded) XF_HIP(hipStreamWaitEvent(st->side, st->ev_graded, 0));
+    XF_TRY(back_exchange(st, pb, PB, st->side));
+    if (st->have_pulled) XF_HIP(hipStreamWaitEvent(st->side, st->ev_pulled, 0));
+    XF_TRY(back_apply(st, pb, PB, st->side));
+    XF_HIP(hipEventRecord(st->ev_applied, st->side));
+    st->have_applied = true;
+    st->pending = nullptr;
+  }
+  if (st->have_applied) XF_HIP(hipStreamWaitEvent(st->main, st->ev_applied, 0));
+  return XF_OK;
+}
+
+}  // namespace
+
+extern "C" void xf_sharded_config_default(xf_sharded_config *c) {
+  memset(c, 0, sizeof(*c));
+  c->model = 0;
+  c->optimizer = XF_OPT_FTRL;
+  c->k = 10;                 // fm_worker.h:92
+  c->capacity = 1u << 22;
+  c->alpha = 5e-2f;          // ftrl.h:17-20
+  c->beta = 1.0f;
+  c->lambda1 = 5e-5f;
+  c->lambda2 = 10.0f;
+  c->lr = 0.001f;            // sgd.h:16
+  c->seed = 0;
+  c->schedule = XF_SCHEDULE_SEQUENTIAL;
+}
+
+extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded_config *cfg) {
+  XF_REQUIRE(out && cfg, "xf_sharded_create: null argument");
+  XF_REQUIRE(cfg->model == 0 || cfg->model == 1, "xf_sharded_create: model %d", cfg->model);
+  XF_REQUIRE(cfg->schedule == XF_SCHEDULE_SEQUENTIAL || cfg->schedule == XF_SCHEDULE_STALE1,
+             "xf_sharded_create: schedule %d", cfg->schedule);
+  xf_sharded *st = new xf_sharded;
+  st->g = g;
+  st->cfg = *cfg;
+  if (g) XF_TRY(xf_group_info(g, &st->rank, &st->world, nullptr));
+  struct Guard {
+    xf_sharded *s;
+    ~Guard() {
+      if (s) xf_sharded_destroy(s);
+    }
+  } guard{st};
+  xf_table_config c;
+  xf_table_config_default(&c);
+  c.opt_kind = cfg->optimizer;
+  c.alpha = cfg->alpha;
+  c.beta = cfg->beta;
+  c.lambda1 = cfg->lambda1;
+  c.lambda2 = cfg->lambda2;
+  c.lr = cfg->lr;
+  c.capacity = cfg->capacity;
+  c.shard = (uint32_t)st->rank;
+  c.nshards = (uint32_t)st->world;
+  c.dim = 1;
+  c.init_kind = XF_INIT_ZERO;
+  XF_TRY(xf_table_create(&st->tw, &c));
+  if (cfg->model == 1) {  // server.h:22-31: app 1 serves v
+    c.dim = cfg->k;
+    if (cfg->optimizer == XF_OPT_FTRL) {
+      c.init_kind = XF_INIT_HASHNORM;  // ftrl.h:114-120 (deterministic stand-in)
+      c.seed = cfg->seed;
+    } else {
+      c.init_kind = XF_INIT_CONST;  // sgd.h:67-72
+      c.init_const = 0.001f;
+    }
+    XF_TRY(xf_table_create(&st->tv, &c));
+  }
+  XF_TRY(xf_workspace_create(&st->ws));
+  XF_HIP(hipStreamCreateWithFlags(&st->main, hipStreamNonBlocking));
+  XF_HIP(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+  XF_HIP(hipEventCreateWithFlags(&st->ev_pulled, hipEventDisableTiming));
+  XF_HIP(hipEventCreateWithFlags(&st->ev_graded, hipEventDisableTiming));
+  XF_HIP(hipEventCreateWithFlags(&st->ev_applied, hipEventDisableTiming));
+  guard.s = nullptr;
+  *out = st;
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_destroy(xf_sharded *st) {
+  if (!st) return XF_OK;
+  (void)hipDeviceSynchronize();
+  if (st->ws) xf_workspace_destroy(st->ws);
+  if (st->tw) xf_table_destroy(st->tw);
+  if (st->tv) xf_table_destroy(st->tv);
+  if (st->main) (void)hipStreamDestroy(st->main);
+  if (st->side) (void)hipStreamDestroy(st->side);
+  for (hipEvent_t e : {st->ev_pulled, st->ev_graded, st->ev_applied})
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : st->pev)
+    if (e) (void)hipEventDestroy(e);
+  delete st;
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_tables(xf_sharded *st, xf_table **w, xf_table **v) {
+  XF_REQUIRE(st, "xf_sharded_tables: null trainer");
+  if (w) *w = st->tw;
+  if (v) *v = st->tv;
+  return XF_OK;
+}
+
+extern "C" int xf_sbatch_free(xf_sbatch *b) {
+  if (!b) return XF_OK;
+  // its Push may still be outstanding (stale1): apply it first.  That is an exchange — every
+  // rank frees its minibatches at the same point of the program, as it steps them.
+  if (b->owner && b->owner->pending == b) (void)flush_pending(b->owner);
+  (void)hipDeviceSynchronize();
+  if (b->cells) xf::cells_free(b->cells);
+  if (b->b) xf_batch_free(b->b);
+  delete b;
+  return XF_OK;
+}
+
+extern "C" int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
+                              uint64_t *n_owned) {
+  XF_REQUIRE(b, "xf_sbatch_dims: null batch");
+  if (R) *R = b->R;
+  if (NNZ) *NNZ = b->NNZ;
+  if (U) *U = b->U;
+  if (n_owned) *n_owned = b->n_recv;
+  return XF_OK;
+}
+
+// Compile a minibatch: the key build (lr_worker.cc:146-166) and the static part of the
+// exchange.  COLLECTIVE: every rank of the group calls it, in the same order.  Host arrays
+// (the reader's block arrays and a row slice).  keep != 0: the batch will be replayed.
+extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
+                                  const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                                  size_t row_end, int keep) {
+  XF_REQUIRE(st && out && rowptr && labels && row_end >= row_begin,
+             "xf_sharded_compile: bad argument");
+  xf_sbatch *b = new xf_sbatch;
+  struct Guard {
+    xf_sbatch *b;
+    ~Guard() {
+      if (b) xf_sbatch_free(b);
+    }
+  } guard{b};
+  hipStream_t s = st->main;
+  b->owner = st;
+  if (st->world == 1) {  // one shard: the table is local
+    if (st->cfg.host_key_build)
+      XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
+    else if (st->cfg.model == 0)
+      XF_TRY(xf_batch_compile_local(&b->b, st->tw, rowptr, keys, labels, row_begin, row_end,
+                                    keep, s));
+    else
+      XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
+    XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
+    // batches with a key list insert at step time (the Pull): make room now.  A host-side
+    // upper bound on the key count keeps the exact (synchronising) check rare.
+    if (b->U) {
+      uint64_t cap = 0;
+      XF_TRY(xf_table_capacity(st->tw, &cap));
+      if ((st->seen_upper + b->U) * 10 > cap * 6) {
+        XF_TRY(xf::table_ensure_room(st->tw, b->U));
+        if (st->tv) XF_TRY(xf::table_ensure_room(st->tv, b->U));
+        uint64_t n = 0;
+        XF_TRY(xf_table_size(st->tw, &n));
+        st->seen_upper = n;
+      }
+      st->seen_upper += b->U;
+    }
+    guard.b = nullptr;
+    *out = b;
+    return XF_OK;
+  }
+  if (st->cfg.host_key_build) {
+    XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
+    XF_TRY(xf_batch_upload(b->b, s));
+  } else {
+    XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
+  }
+  XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
+  const xf_dev_batch &v = b->b->view;
+  if (st->cfg.model == 0)  // the LR kernels stream cells over the batch's unique-key index
+    XF_TRY(xf::cells_build(&b->cells, v.uidx, nullptr, v.rowptr, b->R, b->NNZ, b->U,
+                           xf::kCellsUidx, keep != 0, s));
+  // contiguous owner ranges of the sorted unique keys (ps-lite's slicer)
+  const int W = st->world;
+  std::vector<uint32_t> split(W + 1);
+  {
+    xf::Scratch sc;
+    uint32_t *d_split = nullptr;
+    XF_TRY(sc.get(&d_split, (size_t)W + 1));
+    hipLaunchKernelGGL(k_owner_split, dim3((W + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       v.ukeys, b->U, (uint32_t)W, d_split);
+    XF_HIP(hipMemcpyAsync(split.data(), d_split, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+  }
+  b->send_counts.resize(W);
+  for (int p = 0; p < W; ++p) b->send_counts[p] = split[p + 1] - split[p];
+  std::vector<uint64_t> all((size_t)W * W);
+  XF_TRY(xf_group_allgather_host(st->g, b->send_counts.data(), (size_t)W * 8, all.data()));
+  b->recv_counts.resize(W);
+  b->n_recv = 0;
+  for (int p = 0; p < W; ++p) {
+    b->recv_counts[p] = all[(size_t)p * W + st->rank];
+    b->n_recv += (size_t)b->recv_counts[p];
+  }
+  XF_REQUIRE(b->n_recv < 0xFFFFFFFFull, "xf_sharded_compile: %zu keys for one owner", b->n_recv);
+  // the keys travel once, here
+  XF_TRY(b->rkeys.reserve(b->n_recv));
+  XF_TRY(a2a(st, v.ukeys, b->send_counts, b->rkeys.p, b->recv_counts, 8, s));
+  // ... and the owner's walking order: all sources' lists merged by key (stable: a key's
+  // entries stay in source-rank order).  Walking the lists one source after the other would
+  // sweep the shard's index and state once per source.
+  XF_TRY(b->rkeys_sorted.reserve(b->n_recv));
+  XF_TRY(b->rorder.reserve(b->n_recv));
+  if (b->n_recv) {
+    xf::Scratch sc;
+    uint32_t *iota = nullptr;
+    XF_TRY(sc.get(&iota, b->n_recv));
+    hipLaunchKernelGGL(k_iota32, dim3(grid_for(b->n_recv)), dim3(kBlock), 0, s, iota, b->n_recv);
+    size_t tb = 0;
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
+                                     b->n_recv, 0, 64, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
+                                     b->n_recv, 0, 64, s));
+    XF_HIP(hipStreamSynchronize(s));
+  }
+  guard.b = nullptr;
+  *out = b;
+  return XF_OK;
+}
+
+// One LRWorker::update / FMWorker::update of every rank (COLLECTIVE), asynchronous.
+extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
+  XF_REQUIRE(st && b, "xf_sharded_step: null argument");
+  if (st->world == 1) {
+    if (st->cfg.model == 0) return xf_lr_step(st->tw, b->b, st->ws, st->main);
+    return xf_fm_step(st->tw, st->tv, b->b, st->ws, st->main);
+  }
+  if (st->profiling) XF_TRY(collect_profile(st));
+  const int flip = b->flip;
+  b->flip ^= 1;
+  StepBuf &B = b->buf[flip];
+  if (st->cfg.schedule == XF_SCHEDULE_SEQUENTIAL) {
+    XF_MARK(0);
+    XF_TRY(front_pull(st, b, B, st->main));
+    XF_MARK(kEvPull + 1);
+    XF_TRY(front_compute(st, b, B, nullptr, true, st->main));
+    XF_TRY(back_exchange(st, b, B, st->main));
+    XF_MARK(kEvA2aG + 1);
+    XF_TRY(back_apply(st, b, B, st->main));
+    XF_MARK(kEvUpdate + 1);
+    if (st->profiling) st->pev_pending = true;
+    return XF_OK;
+  }
+  // ---- stale1
+  xf_sbatch *pb = st->pending;
+  const int pflip = st->pending_flip;
+  if (st->have_applied)  // the Push of step t-2 is in the table
+    XF_HIP(hipStreamWaitEvent(st->main, st->ev_applied, 0));
+  XF_TRY(front_pull(st, b, B, st->main));  // reads the table before Push(t-1) lands
+  XF_HIP(hipEventRecord(st->ev_pulled, st->main));
+  st->have_pulled = true;
+  if (pb) {
+    StepBuf &PB = pb->buf[pflip];
+    XF_HIP(hipStreamWaitEvent(st->side, st->ev_graded, 0));  // gradient of step t-1 is complete
+    XF_TRY(back_exchange(st, pb, PB, st->side));
+    XF_HIP(hipStreamWaitEvent(st->side, st->ev_pulled, 0));  // do not write while Pull(t) reads
+    XF_TRY(back_apply(st, pb, PB, st->side));
+    XF_HIP(hipEventRecord(st->ev_applied, st->side));
+    st->have_applied = true;
+  }
+  XF_TRY(front_compute(st, b, B, nullptr, true, st->main));
+  XF_HIP(hipEventRecord(st->ev_graded, st->main));
+  st->have_graded = true;
+  st->pending = b;
+  st->pending_flip = flip;
+  return XF_OK;
+}
+
+// apply the outstanding Push of the stale1 schedule (end of training, before export / predict)
+extern "C" int xf_sharded_flush(xf_sharded *st) {
+  XF_REQUIRE(st, "xf_sharded_flush: null trainer");
+  if (st->world > 1) XF_TRY(flush_pending(st));
+  XF_HIP(hipStreamSynchronize(st->main));
+  XF_HIP(hipStreamSynchronize(st->side));
+  return XF_OK;
+}
+
+// forward only over this rank's rows (calculate_pctr, lr_worker.cc:25-71); COLLECTIVE: ranks
+// without rows of their own call it with an empty minibatch and serve the Pulls.  The pulls
+// insert unseen keys, as in the reference (ftrl.h:56).
+extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out) {
+  XF_REQUIRE(st && b && (b->R == 0 || pctr_out), "xf_sharded_predict: null argument");
+  if (st->world == 1) {
+    XF_HIP(hipStreamSynchronize(st->main));
+    if (st->cfg.model == 0) return xf_lr_predict(st->tw, b->b, st->ws, pctr_out);
+    return xf_fm_predict(st->tw, st->tv, b->b, st->ws, pctr_out);
+  }
+  XF_TRY(xf_sharded_flush(st));
+  StepBuf &B = b->buf[b->flip];
+  Dev<float> pctr;
+  XF_TRY(pctr.reserve(b->R));
+  XF_TRY(front_pull(st, b, B, st->main));
+  XF_TRY(front_compute(st, b, B, pctr.p, false, st->main));
+  XF_HIP(hipStreamSynchronize(st->main));
+  if (b->R) XF_HIP(hipMemcpy(pctr_out, pctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
+  return XF_OK;
+}
+
+// renumber this shard's state rows in key order (table maintenance between steps; local to the
+// rank).  Applies an outstanding stale1 Push first: row numbers held by a step in flight would
+// go stale.
+extern "C" int xf_sharded_defrag(xf_sharded *st) {
+  XF_REQUIRE(st, "xf_sharded_defrag: null trainer");
+  XF_TRY(xf_sharded_flush(st));
+  XF_TRY(xf_table_defrag(st->tw));
+  if (st->tv) XF_TRY(xf_table_defrag(st->tv));
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_check(xf_sharded *st) {
+  XF_REQUIRE(st, "xf_sharded_check: null trainer");
+  XF_TRY(xf_sharded_flush(st));
+  XF_TRY(xf_table_check(st->tw, nullptr));
+  if (st->tv) XF_TRY(xf_table_check(st->tv, nullptr));
+  return XF_OK;
+}
+
+// per-stage timing with HIP events on the step's stream (sequential schedule; at world 1 the
+// fused step's own profile): ms_sum[6] = owner pull, weights exchange, forward, gradient,
+// gradients exchange, owner update
+extern "C" int xf_sharded_profile(xf_sharded *st, int enable) {
+  XF_REQUIRE(st, "xf_sharded_profile: null trainer");
+  if (st->world == 1) return xf_workspace_profile(st->ws, enable);
+  if (enable && !st->pev[0])
+    for (auto &e : st->pev) XF_HIP(hipEventCreate(&e));
+  if (!enable) XF_TRY(collect_profile(st));
+  st->profiling = enable != 0;
+  if (enable) {
+    for (auto &m : st->ms_sum) m = 0.0;
+    st->steps_timed = 0;
+    st->pev_pending = false;
+  }
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *steps) {
+  XF_REQUIRE(st && ms_sum && steps, "xf_sharded_profile_read: null argument");
+  if (st->world == 1) {
+    double m5[5];
+    XF_TRY(xf_workspace_profile_read(st->ws, m5, steps));
+    ms_sum[0] = m5[0] + m5[1];
+    ms_sum[1] = 0;
+    ms_sum[2] = m5[2];
+    ms_sum[3] = m5[3];
+    ms_sum[4] = 0;
+    ms_sum[5] = m5[4];
+    return XF_OK;
+  }
+  XF_TRY(collect_profile(st));
+  for (int i = 0; i < kEvN; ++i) ms_sum[i] = st->ms_sum[i];
+  *steps = st->steps_timed;
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_set_schedule(xf_sharded *st, int schedule) {
+  XF_REQUIRE(st && (schedule == XF_SCHEDULE_SEQUENTIAL || schedule == XF_SCHEDULE_STALE1),
+             "xf_sharded_set_schedule: bad argument");
+  XF_TRY(xf_sharded_flush(st));
+  st->cfg.schedule = schedule;
+  return XF_OK;
+}
+
+extern "C" int xf_sharded_stream(xf_sharded *st, void **stream) {
+  XF_REQUIRE(st && stream, "xf_sharded_stream: null argument");
+  *stream = (void *)st->main;
+  return XF_OK;
+}
+
+// ---- checkpoint of the sharded table --------------------------------------------------------
+namespace xf {
+int model_write(const char *path, xf_table *tw, xf_table *tv, int k);
+int model_read(const char *path, xf_table *tw, xf_table *tv, int k, uint32_t shard,
+               uint32_t nshards);
+}  // namespace xf
+
+static std::string shard_path(const char *prefix, int r, int n) {
+  char buf[64];
+  snprintf(buf, sizeof(buf), ".shard-%05d-of-%05d", r, n);
+  return std::string(prefix) + buf;
+}
+
+extern "C" int xf_sharded_save(xf_sharded *st, const char *prefix) {
+  XF_REQUIRE(st && prefix, "xf_sharded_save: null argument");
+  XF_TRY(xf_sharded_flush(st));
+  int rc = xf::model_write(shard_path(prefix, st->rank, st->world).c_str(), st->tw, st->tv,
+                           st->cfg.k);
+  if (rc == XF_OK && st->rank == 0) {
+    const std::string m = std::string(prefix) + ".manifest";
+    FILE *f = fopen(m.c_str(), "w");
+    if (!f) rc = xf::set_error(XF_EIO, "xf_sharded_save: cannot write %s", m.c_str());
+    else {
+      fprintf(f, "xflow_amd sharded model\nshards %d\nmodel %d\nk %d\n", st->world, st->cfg.model,
+              st->cfg.model == 1 ? st->cfg.k : 0);
+      fclose(f);
+    }
+  }
+  // everybody learns whether everybody succeeded
+  int32_t ok = rc == XF_OK ? 1 : 0;
+  if (st->g && st->world > 1) {
+    std::vector<int32_t> all(st->world);
+    XF_TRY(xf_group_allgather_host(st->g, &ok, 4, all.data()));
+    for (int r = 0; r < st->world; ++r)
+      if (!all[r] && rc == XF_OK)
+        rc = xf::set_error(XF_EIO, "xf_sharded_save: rank %d failed to write its shard", r);
+  }
+  return rc;
+}
+
+extern "C" int xf_sharded_load(xf_sharded *st, const char *prefix) {
+  XF_REQUIRE(st && prefix, "xf_sharded_load: null argument");
+  XF_TRY(xf_sharded_flush(st));
+  int saved = 0;
+  {
+    const std::string m = std::string(prefix) + ".manifest";
+    FILE *f = fopen(m.c_str(), "r");
+    if (f) {
+      char line[256];
+      while (fgets(line, sizeof(line), f))
+        if (sscanf(line, "shards %d", &saved) == 1) break;
+      fclose(f);
+      XF_REQUIRE(saved >= 1, "xf_sharded_load: %s names no shard count", m.c_str());
+    }
+  }
+  int rc = XF_OK;
+  if (saved == 0) {  // a single-table model file (XFSaveModel)
+    rc = xf::model_read(prefix, st->tw, st->tv, st->cfg.k, (uint32_t)st->rank,
+                        (uint32_t)st->world);
+  } else {
+    // saved shard s holds keys [span_s * s, span_s * (s+1)): read the ones that overlap mine
+    const uint64_t my_span = UINT64_MAX / st->world, sv_span = UINT64_MAX / saved;
+    const uint64_t my_lo = my_span * st->rank;
+    const uint64_t my_hi = st->rank == st->world - 1 ? UINT64_MAX : my_lo + my_span - 1;
+    for (int s = 0; s < saved && rc == XF_OK; ++s) {
+      const uint64_t lo = sv_span * s, hi = s == saved - 1 ? UINT64_MAX : lo + sv_span - 1;
+      if (hi < my_lo || lo > my_hi) continue;
+      rc = xf::model_read(shard_path(prefix, s, saved).c_str(), st->tw, st->tv, st->cfg.k,
+                          (uint32_t)st->rank, (uint32_t)st->world);
+    }
+  }
+  int32_t ok = rc == XF_OK ? 1 : 0;
+  if (st->g && st->world > 1) {
+    std::vector<int32_t> all(st->world);
+    XF_TRY(xf_group_allgather_host(st->g, &ok, 4, all.data()));
+    for (int r = 0; r < st->world; ++r)
+      if (!all[r] && rc == XF_OK)
+        rc = xf::set_error(XF_EIO, "xf_sharded_load: rank %d failed to read its shard", r);
+  }
+  return rc;
+}

@@ -1206,6 +1206,21 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
   return XF_OK;
 }
 
+// grow the table (xf_table_reserve) when `incoming` more keys would push the load past 0.6.
+// Synchronises the device.
+int table_ensure_room(xf_table *t, size_t incoming) {
+  XF_HIP(hipDeviceSynchronize());
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  const uint64_t cap = t->T.cap;
+  if ((st.count + incoming) * 10 > cap * 6) {
+    uint64_t want = cap * 2;
+    while ((st.count + incoming) * 10 > want * 6) want *= 2;
+    XF_TRY(xf_table_reserve(t, want));
+  }
+  return XF_OK;
+}
+
 // dst[i] = src[rows[i]] for any float array indexed by state row (parity hook of the cells path)
 int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s) {
   if (n == 0) return XF_OK;

@@ -21,7 +21,14 @@
 #include <mutex>
 #include <thread>
 #include <fstream>
+#include <initializer_list>
 #include <iostream>
+
+namespace xf {
+int model_write(const char *path, xf_table *tw, xf_table *tv, int k);
+int model_read(const char *path, xf_table *tw, xf_table *tv, int k, uint32_t shard,
+               uint32_t nshards);
+}  // namespace xf
 
 namespace xflow_amd {
 
@@ -35,69 +42,55 @@ Worker::Worker(int model, const char *train_file, const char *test_file)
       test_file_path(test_file ? test_file : "") {}
 
 Worker::~Worker() {
-  for (xf_batch *b : cache_) xf_batch_free(b);
-  if (ws_) xf_workspace_destroy(ws_);
-  if (table_w_) xf_table_destroy(table_w_);
-  if (table_v_) xf_table_destroy(table_v_);
+  for (xf_sbatch *b : cache_) xf_sbatch_free(b);
+  if (sharded_) xf_sharded_destroy(sharded_);  // owns the tables
+  if (group_) xf_group_destroy(group_);
 }
 
-// xflow::Server (server.h:22-31): app 0 serves w, app 1 serves v; FTRL by default, the
-// SGD handlers are the commented-out alternative (server.h:25,29).
+static const char *env_first(std::initializer_list<const char *> names) {
+  for (const char *n : names) {
+    const char *v = getenv(n);
+    if (v && *v) return v;
+  }
+  return nullptr;
+}
+
+// xflow::Server (server.h:22-31): app 0 serves w, app 1 serves v; FTRL by default, the SGD
+// handlers are the commented-out alternative (server.h:25,29).  ps::Start / MyRank
+// (main.cc:22-47): with more than one worker (world=, or WORLD_SIZE / DMLC_NUM_WORKER in the
+// environment, as scripts/local.sh sets it) this process joins the group — one process per
+// GPU — and its tables are one key-range shard of the parameter table.
 int Worker::create_tables() {
-  if (table_w_) return XF_OK;
-  xf_table_config c;
-  xf_table_config_default(&c);
-  c.opt_kind = optimizer;
+  if (sharded_) return XF_OK;
+  int w = world;
+  if (w <= 0) {
+    const char *v = env_first({"WORLD_SIZE", "XF_WORLD", "DMLC_NUM_WORKER"});
+    w = v ? atoi(v) : 1;
+  }
+  if (w > 1) {
+    XF_TRY(xf_group_create(&group_, rank_given_ ? rank : -1, w, nullptr, 0,
+                           transport_host ? XF_TRANSPORT_HOST : XF_TRANSPORT_RCCL, -2));
+    int r = 0;
+    XF_TRY(xf_group_info(group_, &r, &w, nullptr));
+    rank = r;  // ps::MyRank(): selects <prefix>-%05d (lr_worker.cc:208-210)
+  }
+  world = w;
+  xf_sharded_config c;
+  xf_sharded_config_default(&c);
+  c.model = model_;
+  c.optimizer = optimizer;
+  c.k = v_dim_;
+  c.schedule = schedule;
+  c.capacity = capacity;
+  c.seed = seed;
   c.alpha = alpha;
   c.beta = beta;
   c.lambda1 = lambda1;
   c.lambda2 = lambda2;
   c.lr = learning_rate;
-  c.capacity = capacity;
-  c.dim = 1;
-  c.init_kind = XF_INIT_ZERO;
-  XF_TRY(xf_table_create(&table_w_, &c));
-  if (model_ == 1) {
-    c.dim = v_dim_;
-    if (optimizer == XF_OPT_FTRL) {  // ftrl.h:114-120
-      c.init_kind = XF_INIT_HASHNORM;
-      c.seed = seed;
-    } else {  // sgd.h:67-72
-      c.init_kind = XF_INIT_CONST;
-      c.init_const = 0.001f;
-    }
-    XF_TRY(xf_table_create(&table_v_, &c));
-  }
-  XF_TRY(xf_workspace_create(&ws_));
-  return XF_OK;
-}
-
-// Make room for up to `incoming` new keys before a pull can insert them: keep the load
-// factor <= 0.6.  `seen_upper_` is a host-side upper bound on the key count so that the
-// exact (synchronising) size query only runs when the bound gets close.
-int Worker::grow_if_needed(size_t incoming) {
-  xf_table *ts[2] = {table_w_, table_v_};
-  uint64_t cap = 0;
-  XF_TRY(xf_table_capacity(table_w_, &cap));
-  if (size_known_stale_) {  // keys came in behind our back (model file): count them once
-    uint64_t n = 0;
-    XF_TRY(xf_table_size(table_w_, &n));
-    seen_upper_ = std::max<uint64_t>(seen_upper_, n);
-    size_known_stale_ = false;
-  }
-  if ((seen_upper_ + incoming) * 10 <= cap * 6) {
-    seen_upper_ += incoming;
-    return XF_OK;
-  }
-  uint64_t n = 0;
-  XF_TRY(xf_table_size(table_w_, &n));
-  if ((n + incoming) * 10 > cap * 6) {
-    uint64_t want = cap * 2;
-    while ((n + incoming) * 10 > want * 6) want *= 2;
-    for (xf_table *t : ts)
-      if (t) XF_TRY(xf_table_reserve(t, want));
-  }
-  seen_upper_ = n + incoming;
+  c.host_key_build = key_build_gpu ? 0 : 1;
+  XF_TRY(xf_sharded_create(&sharded_, group_, &c));
+  XF_TRY(xf_sharded_tables(sharded_, &table_w_, &table_v_));
   return XF_OK;
 }
 
@@ -105,33 +98,22 @@ int Worker::defrag_if_grown() {
   uint64_t n = 0;
   XF_TRY(xf_table_size(table_w_, &n));
   if (n > keys_at_defrag_ + keys_at_defrag_ / 20) {  // > 5 % new keys since the last one
-    XF_TRY(xf_table_defrag(table_w_));
-    if (table_v_) XF_TRY(xf_table_defrag(table_v_));
+    XF_TRY(xf_sharded_defrag(sharded_));
     keys_at_defrag_ = n;
   }
   return XF_OK;
 }
 
-// the key build of update() (lr_worker.cc:146-166).  LR: straight against the table (raw keys
-// -> state rows -> cells, no sort; the table grows by itself); `keep` = the batch will be
-// replayed in later epochs.  FM (and key_build=host): the sorted-unique-key build.
-int Worker::compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys,
-                    const int32_t *labels, size_t start, size_t end, bool keep) {
-  if (model_ == 0 && key_build_gpu)
-    return xf_batch_compile_local(b, table_w_, rowptr, keys, labels, start, end, keep ? 1 : 0,
-                                  nullptr);
-  if (key_build_gpu) return xf_batch_compile_gpu(b, rowptr, keys, labels, start, end, nullptr);
-  return xf_batch_compile(b, rowptr, keys, labels, start, end);
-}
-
-// LRWorker::update / FMWorker::update (lr_worker.cc:145-177, fm_worker.cc:204-245)
-int Worker::update(xf_batch *b) {
-  uint32_t U = 0;
-  xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
-  XF_TRY(grow_if_needed(U));
-  if (model_ == 0) XF_TRY(xf_lr_step(table_w_, b, ws_, nullptr));
-  else
-    XF_TRY(xf_fm_step(table_w_, table_v_, b, ws_, nullptr));
+// "does any rank still have a block?" — the ranks' files differ in length, the steps are
+// collective: a rank that has run out keeps stepping empty minibatches until all are done
+int Worker::any_rank(bool mine, bool *any) {
+  *any = mine;
+  if (world <= 1) return XF_OK;
+  const int32_t flag = mine ? 1 : 0;
+  std::vector<int32_t> all(world);
+  XF_TRY(xf_group_allgather_host(group_, &flag, 4, all.data()));
+  for (int32_t f : all)
+    if (f) *any = true;
   return XF_OK;
 }
 
@@ -148,7 +130,9 @@ int Worker::open_reader(xf_reader **rd, const char *path, size_t cap) {
 
 // batch_training (lr_worker.cc:179-205, fm_worker.cc:247-275)
 int Worker::batch_training() {
-  {  // init push of key 0 with a zero gradient (lr_worker.cc:180-182, fm_worker.cc:248-252)
+  // init push of key 0 with a zero gradient (lr_worker.cc:180-182, fm_worker.cc:248-252): on
+  // the shard that owns key 0
+  if (xf_shard_of(0, (uint32_t)world) == (uint32_t)rank) {
     const uint64_t key0 = 0;
     const float zero = 0.0f;
     XF_TRY(xf_table_push(table_w_, &key0, 1, &zero));
@@ -159,21 +143,22 @@ int Worker::batch_training() {
   }
   const double t0 = now_s();
   rows_trained_ = 0;
-  for (xf_batch *b : cache_) xf_batch_free(b);  // a second XFStartTrain starts from the files
+  for (xf_sbatch *b : cache_) xf_sbatch_free(b);  // a second XFStartTrain starts from the files
   cache_.clear();
   bool cached = false;
+  static const uint64_t kNoRows[1] = {0};
   for (int epoch = 0; epoch < epochs; ++epoch) {
     if (cached) {
       // The compiled batches depend only on the file, so later epochs replay them from
       // HBM instead of re-reading and re-sorting the text (the reference re-opens and
-      // re-parses per epoch, lr_worker.cc:184).
-      for (xf_batch *b : cache_) {
-        XF_TRY(update(b));
+      // re-parses per epoch, lr_worker.cc:184).  Every rank holds the same number of them.
+      for (xf_sbatch *b : cache_) {
+        XF_TRY(xf_sharded_step(sharded_, b));
         uint32_t R = 0;
-        xf_batch_dims(b, &R, nullptr, nullptr, nullptr);
+        xf_sbatch_dims(b, &R, nullptr, nullptr, nullptr);
         rows_trained_ += R;
       }
-      XF_TRY(xf_table_check(table_w_, nullptr));
+      XF_TRY(xf_sharded_check(sharded_));
     } else {
       xf_reader *rd = nullptr;
       XF_TRY(open_reader(&rd, train_data_path, (size_t)block_size << 20));
@@ -221,41 +206,56 @@ int Worker::batch_training() {
         }
       });
       int rc = XF_OK;
-      for (int k = 0; rc == XF_OK; k ^= 1) {
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return filled[k] != 0; });
+      bool mine_done = false;
+      for (int k = 0; rc == XF_OK;) {
+        Parsed *p = nullptr;
+        if (!mine_done) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled[k] != 0; });
+          }
+          p = &slot[k];
+          if (p->rc != XF_OK) {
+            rc = xf::set_error(p->rc, "%s", p->err.c_str());
+            break;  // (a parse error ends this rank; its peers time out on the next exchange)
+          }
+          if (p->rows == 0) mine_done = true;
         }
-        Parsed &p = slot[k];
-        if (p.rc != XF_OK) {
-          rc = xf::set_error(p.rc, "%s", p.err.c_str());
-          break;
-        }
-        if (p.rows == 0) break;
-        const size_t thread_size = p.rows / core_num;  // remainder dropped, lr_worker.cc:190
+        bool any = false;
+        rc = any_rank(!mine_done, &any);
+        if (rc != XF_OK || !any) break;
+        const size_t rows = mine_done ? 0 : p->rows;
+        const size_t thread_size = rows / core_num;  // remainder dropped, lr_worker.cc:190
         for (int i = 0; i < core_num && rc == XF_OK; ++i) {
           const size_t start = i * thread_size, end = (i + 1) * thread_size;
-          if (end == start) continue;
-          xf_batch *b = nullptr;
-          rc = compile(&b, p.rowptr, p.keys, p.labels, start, end, cache_batches != 0);
+          if (end == start && world <= 1) continue;
+          xf_sbatch *b = nullptr;
+          // a rank without rows of its own still takes part in the (collective) step
+          rc = end > start ? xf_sharded_compile(sharded_, &b, p->rowptr, p->keys, p->labels,
+                                                start, end, cache_batches != 0)
+                           : xf_sharded_compile(sharded_, &b, kNoRows, nullptr,
+                                                (const int32_t *)kNoRows, 0, 0,
+                                                cache_batches != 0);
           if (rc != XF_OK) break;
-          rc = update(b);
-          if (rc == XF_OK) rc = xf_table_check(table_w_, nullptr);
-          if (rc == XF_OK && table_v_) rc = xf_table_check(table_v_, nullptr);
+          rc = xf_sharded_step(sharded_, b);
+          if (rc == XF_OK) rc = xf_sharded_check(sharded_);
           if (rc != XF_OK) {
-            xf_batch_free(b);
+            xf_sbatch_free(b);
             break;
           }
           rows_trained_ += (long)(end - start);
           if (cache_batches) cache_.push_back(b);
           else
-            xf_batch_free(b);
+            xf_sbatch_free(b);
         }
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          filled[k] = 0;
+        if (!mine_done) {
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            filled[k] = 0;
+          }
+          cv.notify_all();
+          k ^= 1;
         }
-        cv.notify_all();
       }
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -264,64 +264,76 @@ int Worker::batch_training() {
       cv.notify_all();
       parser.join();
       for (auto &p : slot) xf_block_destroy(p.blk);
-      if (rc != XF_OK) {
-        xf_reader_close(rd);
-        return rc;
-      }
       xf_reader_close(rd);
+      if (rc != XF_OK) return rc;
       cached = cache_batches != 0;
     }
     // table maintenance at the epoch boundary: when this epoch inserted a noticeable share of
-    // the keys, renumber the state rows in key order for the epochs that replay them
+    // the keys, renumber the state rows in key order for the epochs that replay them.  The
+    // flush is collective (every rank, every epoch); the defrag itself is local to the shard.
+    XF_TRY(xf_sharded_flush(sharded_));
     if (epoch + 1 < epochs) XF_TRY(defrag_if_grown());
     if ((epoch + 1) % 30 == 0) std::cout << "epoch : " << epoch << std::endl;  // :202
   }
-  XF_TRY(xf_stream_sync(nullptr));
+  XF_TRY(xf_sharded_flush(sharded_));
   train_seconds_ = now_s() - t0;
   return XF_OK;
 }
 
-// predict + calculate_pctr (lr_worker.cc:25-98, fm_worker.cc:25-124)
-int Worker::predict(int rank, int block) {
-  char name[1200];
-  if (pred_path.empty()) snprintf(name, sizeof(name), "pred_%d_%d.txt", rank, block);
-  else
-    snprintf(name, sizeof(name), "%s", pred_path.c_str());
-  std::ofstream md(name);
-  if (!md.is_open()) std::cout << "open pred file failure!" << std::endl;
-  snprintf(test_data_path, sizeof(test_data_path), "%s-%05d", test_file_path.c_str(), rank);
-  // 4 MiB blocks for LR (lr_worker.cc:80), 2 MiB for FM (fm_worker.cc:106)
-  const size_t cap = model_ == 0 ? ((size_t)4 << 20) : ((size_t)2 << 20);
+// predict + calculate_pctr (lr_worker.cc:25-98, fm_worker.cc:25-124).  As in the reference
+// only rank 0 scores its test file (lr_worker.cc:212-215) — against the WHOLE table: the other
+// ranks serve its Pulls (`reader` == false: they step empty minibatches until rank 0 is done).
+int Worker::predict(int rank, int block, bool reader) {
+  std::ofstream md;
   xf_reader *rd = nullptr;
-  XF_TRY(open_reader(&rd, test_data_path, cap));
+  if (reader) {
+    char name[1200];
+    if (pred_path.empty()) snprintf(name, sizeof(name), "pred_%d_%d.txt", rank, block);
+    else
+      snprintf(name, sizeof(name), "%s", pred_path.c_str());
+    md.open(name);
+    if (!md.is_open()) std::cout << "open pred file failure!" << std::endl;
+    snprintf(test_data_path, sizeof(test_data_path), "%s-%05d", test_file_path.c_str(), rank);
+    // 4 MiB blocks for LR (lr_worker.cc:80), 2 MiB for FM (fm_worker.cc:106)
+    const size_t cap = model_ == 0 ? ((size_t)4 << 20) : ((size_t)2 << 20);
+    XF_TRY(open_reader(&rd, test_data_path, cap));
+  }
   struct ReaderGuard {  // every return path closes the reader
     xf_reader *r;
-    ~ReaderGuard() { xf_reader_close(r); }
+    ~ReaderGuard() {
+      if (r) xf_reader_close(r);
+    }
   } rd_guard{rd};
+  static const uint64_t kNoRows[1] = {0};
   std::vector<int32_t> all_labels;
   std::vector<float> all_pctr, pctr;
+  bool mine_done = !reader;
   while (true) {
     size_t rows = 0, nnz = 0;
-    const uint64_t *rowptr, *keys;
-    const int32_t *fgid, *labels;
-    XF_TRY(xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels));
-    if (rows == 0) break;
+    const uint64_t *rowptr = nullptr, *keys = nullptr;
+    const int32_t *fgid = nullptr, *labels = nullptr;
+    if (!mine_done) {
+      XF_TRY(xf_reader_next(rd, &rows, &nnz, &rowptr, &keys, &fgid, &labels));
+      if (rows == 0) mine_done = true;
+    }
+    bool any = false;
+    XF_TRY(any_rank(!mine_done, &any));
+    if (!any) break;
     const size_t thread_size = rows / core_num;
     for (int i = 0; i < core_num; ++i) {
       const size_t start = i * thread_size, end = (i + 1) * thread_size;
-      if (end == start) continue;
-      xf_batch *b = nullptr;
-      XF_TRY(compile(&b, rowptr, keys, labels, start, end, false));
+      if (end == start && world <= 1) continue;
+      xf_sbatch *b = nullptr;
+      if (end > start) XF_TRY(xf_sharded_compile(sharded_, &b, rowptr, keys, labels, start, end, 0));
+      else
+        XF_TRY(xf_sharded_compile(sharded_, &b, kNoRows, nullptr, (const int32_t *)kNoRows, 0, 0,
+                                  0));
       struct BatchGuard {  // ... and frees the minibatch
-        xf_batch *b;
-        ~BatchGuard() { xf_batch_free(b); }
+        xf_sbatch *b;
+        ~BatchGuard() { xf_sbatch_free(b); }
       } b_guard{b};
       pctr.resize(end - start);
-      uint32_t U = 0;
-      xf_batch_dims(b, nullptr, nullptr, &U, nullptr);
-      XF_TRY(grow_if_needed(U));
-      XF_TRY(model_ == 0 ? xf_lr_predict(table_w_, b, ws_, pctr.data())
-                         : xf_fm_predict(table_w_, table_v_, b, ws_, pctr.data()));
+      XF_TRY(xf_sharded_predict(sharded_, b, pctr.data()));
       for (size_t r = 0; r < end - start; ++r) {
         const int label = labels[start + r];
         all_labels.push_back(label);
@@ -330,6 +342,8 @@ int Worker::predict(int rank, int block) {
       }
     }
   }
+  XF_TRY(xf_sharded_check(sharded_));
+  if (!reader) return XF_OK;
   md.close();
   // Base::calculate_auc (base.h:84-110) and its stdout line
   XF_TRY(xf_auc_logloss(all_labels.data(), all_pctr.data(), all_labels.size(), &logloss_acc_,
@@ -355,19 +369,27 @@ int Worker::train() {
     void *self = this;
     XF_TRY(XFSaveModel(self, model_out.c_str()));
   }
-  if (rank == 0) {
-    std::cout << (model_ == 0 ? "LR AUC: " : "FM AUC: ") << std::endl;
-    XF_TRY(predict(rank, 0));
-  }
+  if (rank == 0) std::cout << (model_ == 0 ? "LR AUC: " : "FM AUC: ") << std::endl;
+  if (rank == 0 || world > 1) XF_TRY(predict(rank, 0, rank == 0));
   std::cout << "train end......" << std::endl;
   return XF_OK;
 }
+
+// one worker: one file at `path`; several: one file per shard + a manifest (xf_sharded_save)
+int Worker::save_model(const char *path) {
+  if (world > 1) return xf_sharded_save(sharded_, path);
+  XF_TRY(xf_sharded_flush(sharded_));
+  return xf::model_write(path, table_w_, table_v_, v_dim_);
+}
+
+// a single file or a sharded checkpoint of ANY world size: every rank keeps the keys it owns
+int Worker::load_model(const char *path) { return xf_sharded_load(sharded_, path); }
 
 int Worker::set_param(const char *name, const char *value) {
   XF_REQUIRE(name && value, "XFSetParam: null argument");
   const std::string n = name;
   if (n == "model") {
-    XF_REQUIRE(!table_w_, "XFSetParam: model cannot change after training started");
+    XF_REQUIRE(!sharded_, "XFSetParam: model cannot change after training started");
     model_ = atoi(value);
     XF_REQUIRE(model_ == 0 || model_ == 1, "XFSetParam: model must be 0 (LR) or 1 (FM)");
   } else if (n == "epochs") epochs = atoi(value);
@@ -380,7 +402,21 @@ int Worker::set_param(const char *name, const char *value) {
     else
       return xf::set_error(XF_EINVAL, "XFSetParam: optimizer must be ftrl or sgd");
   } else if (n == "capacity") capacity = strtoull(value, nullptr, 10);
-  else if (n == "rank") rank = atoi(value);
+  else if (n == "rank") {
+    rank = atoi(value);
+    rank_given_ = true;
+  } else if (n == "world") world = atoi(value);
+  else if (n == "transport") {
+    if (!strcmp(value, "rccl")) transport_host = false;
+    else if (!strcmp(value, "host")) transport_host = true;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: transport must be rccl or host");
+  } else if (n == "schedule") {
+    if (!strcmp(value, "sequential")) schedule = XF_SCHEDULE_SEQUENTIAL;
+    else if (!strcmp(value, "stale1")) schedule = XF_SCHEDULE_STALE1;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential or stale1");
+  }
   else if (n == "pred_path") pred_path = value;
   else if (n == "alpha") alpha = (float)atof(value);
   else if (n == "beta") beta = (float)atof(value);
@@ -458,69 +494,12 @@ extern "C" int XFGetMetric(void *h, const char *name, double *value) {
   return reinterpret_cast<xflow_amd::Worker *>(h)->get_metric(name, value);
 }
 
-// ---- model file: the tables' (key, w, n, z) dumps, sorted by key -------------------------
-// (the reference never saves its model; this is the export/import hook with a
-// file format around it)
-namespace {
-const char kMagic[8] = {'X', 'F', 'A', 'M', 'D', '0', '0', '1'};
-
-int save_table(FILE *f, xf_table *t, int dim) {
-  size_t n = 0;
-  XF_TRY(xf_table_export(t, nullptr, nullptr, nullptr, nullptr, 0, &n));
-  std::vector<uint64_t> keys(n);
-  std::vector<float> w(n * dim), nn(n * dim), z(n * dim);
-  if (n) XF_TRY(xf_table_export(t, keys.data(), w.data(), nn.data(), z.data(), n, &n));
-  const uint64_t hdr[2] = {(uint64_t)n, (uint64_t)dim};
-  if (fwrite(hdr, 8, 2, f) != 2 || fwrite(keys.data(), 8, n, f) != n ||
-      fwrite(w.data(), 4, n * dim, f) != n * dim || fwrite(nn.data(), 4, n * dim, f) != n * dim ||
-      fwrite(z.data(), 4, n * dim, f) != n * dim)
-    return xf::set_error(XF_EIO, "XFSaveModel: short write");
-  return XF_OK;
-}
-
-int load_table(FILE *f, xf_table *t, int dim) {
-  uint64_t hdr[2];
-  if (fread(hdr, 8, 2, f) != 2) return xf::set_error(XF_EIO, "XFLoadModel: truncated file");
-  if ((int)hdr[1] != dim)
-    return xf::set_error(XF_EINVAL, "XFLoadModel: file has dim %llu, table has %d",
-                         (unsigned long long)hdr[1], dim);
-  const size_t n = (size_t)hdr[0];
-  {  // the header's count must fit what is left of the file (a corrupt or foreign file must
-     // not turn into a giant allocation)
-    const long here = ftell(f);
-    fseek(f, 0, SEEK_END);
-    const long end = ftell(f);
-    fseek(f, here, SEEK_SET);
-    if (here < 0 || end < here || (unsigned long long)n * (8ull + 12ull * dim) >
-                                      (unsigned long long)(end - here))
-      return xf::set_error(XF_EIO, "XFLoadModel: the file claims %zu keys but holds %ld bytes",
-                           n, end - here);
-  }
-  std::vector<uint64_t> keys(n);
-  std::vector<float> w(n * dim), nn(n * dim), z(n * dim);
-  if (fread(keys.data(), 8, n, f) != n || fread(w.data(), 4, n * dim, f) != n * dim ||
-      fread(nn.data(), 4, n * dim, f) != n * dim || fread(z.data(), 4, n * dim, f) != n * dim)
-    return xf::set_error(XF_EIO, "XFLoadModel: truncated file");
-  uint64_t cap = 0;
-  XF_TRY(xf_table_capacity(t, &cap));
-  if ((uint64_t)n * 10 > cap * 6) XF_TRY(xf_table_reserve(t, (uint64_t)n * 2 + 1024));
-  return xf_table_import(t, keys.data(), n, w.data(), nn.data(), z.data());
-}
-}  // namespace
-
+// ---- model file (xf_modelfile.cc; per shard and resharding on load when the worker is sharded)
 extern "C" int XFSaveModel(void *h, const char *path) {
   XF_REQUIRE(h && path, "XFSaveModel: null argument");
   xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
   XF_REQUIRE(wk->table_w(), "XFSaveModel: nothing trained or loaded yet");
-  FILE *f = fopen(path, "wb");
-  if (!f) return xf::set_error(XF_EIO, "XFSaveModel: cannot open %s", path);
-  const uint64_t nt = wk->table_v() ? 2 : 1;
-  int rc = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&nt, 8, 1, f) == 1 ? XF_OK
-                                                                       : xf::set_error(XF_EIO, "XFSaveModel: short write");
-  if (rc == XF_OK) rc = save_table(f, wk->table_w(), 1);
-  if (rc == XF_OK && wk->table_v()) rc = save_table(f, wk->table_v(), wk->v_dim_);
-  fclose(f);
-  return rc;
+  return wk->save_model(path);
 }
 
 extern "C" int XFLoadModel(void *h, const char *path) {
@@ -528,20 +507,7 @@ extern "C" int XFLoadModel(void *h, const char *path) {
   xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
   XF_TRY(wk->ensure_tables());
   wk->note_external_keys();
-  FILE *f = fopen(path, "rb");
-  if (!f) return xf::set_error(XF_EIO, "XFLoadModel: cannot open %s", path);
-  char magic[8];
-  uint64_t nt = 0;
-  int rc = XF_OK;
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(&nt, 8, 1, f) != 1)
-    rc = xf::set_error(XF_EINVAL, "XFLoadModel: %s is not an xflow_amd model file", path);
-  if (rc == XF_OK && nt != (wk->table_v() ? 2u : 1u))
-    rc = xf::set_error(XF_EINVAL, "XFLoadModel: file holds %llu table(s), worker has %d",
-                       (unsigned long long)nt, wk->table_v() ? 2 : 1);
-  if (rc == XF_OK) rc = load_table(f, wk->table_w(), 1);
-  if (rc == XF_OK && wk->table_v()) rc = load_table(f, wk->table_v(), wk->v_dim_);
-  fclose(f);
-  return rc;
+  return wk->load_model(path);
 }
 
 // score the test file with the current tables (no training): predict + AUC/logloss
@@ -549,7 +515,7 @@ extern "C" int XFPredict(void *h) {
   XF_REQUIRE(h, "XFPredict: null handle");
   xflow_amd::Worker *wk = reinterpret_cast<xflow_amd::Worker *>(h);
   XF_TRY(wk->ensure_tables());
-  return wk->predict(wk->rank, 0);
+  return wk->predict(wk->rank, 0, wk->rank == 0);
 }
 
 extern "C" int XFGetTables(void *h, xf_table **w, xf_table **v) {

@@ -18,22 +18,25 @@ class Worker {
 
   int train();                       // lr_worker.cc:207-217
   int batch_training();              // lr_worker.cc:179-205
-  int update(xf_batch *b);           // lr_worker.cc:145-177
-  int predict(int rank, int block);  // lr_worker.cc:73-98
+  int predict(int rank, int block, bool reader = true);  // lr_worker.cc:73-98
 
   int set_param(const char *name, const char *value);
   int get_metric(const char *name, double *value);
   int ensure_tables() { return create_tables(); }
-  // keys entered the tables without passing through grow_if_needed (XFLoadModel)
-  void note_external_keys() { size_known_stale_ = true; }
+  void note_external_keys() {}  // (the tables count their keys themselves)
   xf_table *table_w() { return table_w_; }
   xf_table *table_v() { return table_v_; }
+  int save_model(const char *path);
+  int load_model(const char *path);
 
  public:
   int epochs = 60;  // lr_worker.h:63
 
   // reference constants, now parameters
-  int rank = 0;
+  int rank = 0;          // ps::MyRank(): given (rank=), from the environment, or handed out
+  int world = 0;         // workers == GPUs; 0: WORLD_SIZE / XF_WORLD / DMLC_NUM_WORKER, else 1
+  bool transport_host = false;           // tests: the exchange through the bootstrap sockets
+  int schedule = XF_SCHEDULE_SEQUENTIAL; // order of Push(t) and Pull(t+1) when world > 1
   int core_num = 1;      // slices per block; 1 = the deterministic reference schedule
   int block_size = 2;    // MiB, lr_worker.h:68
   int v_dim_ = 10;       // fm_worker.h:92
@@ -54,21 +57,19 @@ class Worker {
 
  private:
   int create_tables();
-  int compile(xf_batch **b, const uint64_t *rowptr, const uint64_t *keys, const int32_t *labels,
-              size_t start, size_t end, bool keep);
-  int grow_if_needed(size_t incoming);
   int defrag_if_grown();
+  int any_rank(bool mine, bool *any);
   uint64_t keys_at_defrag_ = 0;
-  uint64_t seen_upper_ = 0;
-  bool size_known_stale_ = false;
+  bool rank_given_ = false;
 
   int model_;
   std::string train_file_path, test_file_path;
   char train_data_path[1200];
   char test_data_path[1200];
+  xf_group *group_ = nullptr;      // ps-lite's postoffice: the other workers
+  xf_sharded *sharded_ = nullptr;  // owns the tables; with one worker: the fused single shard
   xf_table *table_w_ = nullptr, *table_v_ = nullptr;  // kv_w_ / kv_v of the reference
-  xf_workspace *ws_ = nullptr;
-  std::vector<xf_batch *> cache_;
+  std::vector<xf_sbatch *> cache_;
   long rows_trained_ = 0;
   double train_seconds_ = 0.0;
   float logloss_acc_ = 0.0f, auc_ = 0.0f;
