@@ -1,6 +1,9 @@
 // xf_cli.cc — `xflow_lr <train_prefix> <test_prefix> <model 0|1> <epochs> [name=value ...]`
-// Same positional arguments as the reference's entry point (src/model/main.cc:27-44); there
-// are no scheduler/server processes to start: the "server" is the table in HBM.
+// Same positional arguments as the reference's entry point (src/model/main.cc:27-44).  Started
+// by the reference's scripts/local.sh it behaves like this: DMLC_ROLE=scheduler and =server
+// have nothing to do (the "servers" are the key-range shards of the table in the workers' HBM,
+// rank 0 is the rendezvous) and return at once; every DMLC_ROLE=worker is one GPU of a run of
+// DMLC_NUM_WORKER, meeting the others at DMLC_PS_ROOT_URI:DMLC_PS_ROOT_PORT.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,6 +20,13 @@ int main(int argc, char *argv[]) {
               << "LR model example: xflow_lr data/small_train data/small_test 0 100\n"
               << "FM model example: xflow_lr data/small_train data/small_test 1 100\n";
     return 2;
+  }
+  if (const char *role = getenv("DMLC_ROLE")) {  // main.cc:22-26: ps::IsServer / scheduler
+    if (!strcmp(role, "scheduler") || !strcmp(role, "server")) {
+      std::cout << "xflow_lr: no " << role << " process in this build (the table lives in the "
+                << "workers' HBM)" << std::endl;
+      return 0;
+    }
   }
   const int model = argv[3][0] - '0';
   if (model == 2) {
