@@ -54,6 +54,12 @@ def parse_args():
     ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1"],
                     help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped)")
     ap.add_argument("--no-defrag", action="store_true")
+    ap.add_argument("--driver", default="native", choices=["native", "python"],
+                    help="N>1: the C++ sharded trainer over xf_group (default) or the Python "
+                         "driver over torch.distributed")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="N>1: host = stage the exchange through the group's sockets so that "
+                         "several ranks can share one GPU (a functional check, not a benchmark)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
     ap.add_argument("--exp-knob", type=int, default=0)
@@ -253,14 +259,15 @@ def spawn_ranks(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and args.transport == "rccl":
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(have, 1)),
+                   WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
@@ -268,6 +275,72 @@ def spawn_ranks(args):
     rcs = [p.wait() for p in procs]
     if any(rcs):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+class NativeSharded:
+    """The C++ sharded trainer (xf_sharded_* over an xf_group: RCCL all-to-all-v from C++)
+    behind the small interface the timing loop uses."""
+
+    def __init__(self, group, args, schedule, capacity):
+        from xflow_amd import capi
+        self.capi = capi
+        self.group = group
+        self.st = capi.Sharded(group, model=args.model, optimizer=args.optimizer, k=args.k,
+                               capacity=capacity, schedule=schedule, seed=7)
+        self.schedule = schedule
+
+    def compile(self, rowptr, keys, labels):
+        return self.st.compile(rowptr, keys, labels)
+
+    def step(self, b):
+        self.st.step(b)
+
+    def predict(self, b):
+        return self.st.predict(b)
+
+    def check(self):
+        self.st.check()
+
+    def defrag(self):
+        self.st.defrag()
+
+    def profile(self, enable):
+        self.st.profile(enable)
+
+    def profile_read(self):
+        ms, n = self.st.profile_read()
+        ms["resolve"] = ms.pop("owner_pull")      # the names the byte model uses
+        ms["update"] = ms.pop("owner_update")
+        return ms, n
+
+    def flush(self):
+        self.st.flush()
+
+    def set_schedule(self, schedule):
+        self.st.set_schedule(schedule)
+        self.schedule = schedule
+
+
+def make_group(rank, world, local_rank, transport="rccl"):
+    """xf_group over RCCL, with a device-side self-test: every rank sends its number to every
+    peer and checks what arrives.  The bootstrap port sits next to the launcher's
+    (torchrun's own store owns MASTER_PORT)."""
+    import torch
+    from xflow_amd import capi
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29512")) + 23
+    g = capi.Group(rank, world, addr, port,
+                   capi.TRANSPORT_RCCL if transport == "rccl" else capi.TRANSPORT_HOST,
+                   device=local_rank)
+    src = torch.full((world * 4,), float(rank), device="cuda")
+    dst = torch.full((world * 4,), -1.0, device="cuda")
+    g.alltoallv_dev(src.data_ptr(), [4] * world, dst.data_ptr(), [4] * world, 4,
+                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.arange(world, dtype=torch.float32).repeat_interleave(4).cuda()
+    if not torch.equal(dst, want):
+        raise RuntimeError("xf_group self-test: rank %d received %s" % (rank, dst.tolist()))
+    return g
 
 
 def main():
@@ -290,13 +363,21 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     capi.require_gpu()
-    dist = None
-    if world > 1 or args.force_sharded:
+    sharded = world > 1 or args.force_sharded
+    dist = group = None
+    exchange = "none (single shard)"
+    if sharded and args.driver == "native":
+        group = make_group(rank, world, local_rank, args.transport)
+        exchange = "xf_group: grouped ncclSend/ncclRecv (RCCL) from C++, one all-to-all-v each " \
+                   "way" if args.transport == "rccl" else \
+                   "xf_group HOST transport (staged through sockets: functional check only)"
+    elif sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        exchange = "torch.distributed all_to_all_single (RCCL), Python driver"
     if args.exp_knob:
         capi.tune("exp_knob", args.exp_knob)
     if args.panel_slice_kb > 0:
@@ -307,25 +388,40 @@ def main():
     keytab = make_key_table(nkeys_total)
     batches = make_batches(args, rank, nkeys_total, keytab)
 
-    if world == 1 and not args.force_sharded:
-        from xflow_amd.single import SingleGpuTrainer as Trainer
-    else:
-        from xflow_amd.sharded import ShardedTrainer as Trainer
-    sharded = world > 1 or args.force_sharded
     schedule = (args.schedule or "stale1") if sharded else "sequential"
-    kw = {"schedule": schedule} if sharded else {}
-    trainer = Trainer(model=args.model, optimizer=args.optimizer, k=args.k,
-                      capacity=int(args.keys_per_gpu / args.load_factor) + 1024,
-                      rank=rank, world=world, **kw)
+    capacity = int(args.keys_per_gpu / args.load_factor) + 1024
+    if not sharded:
+        from xflow_amd.single import SingleGpuTrainer
+        trainer = SingleGpuTrainer(model=args.model, optimizer=args.optimizer, k=args.k,
+                                   capacity=capacity, rank=rank, world=world)
+    elif group is not None:
+        trainer = NativeSharded(group, args, schedule, capacity)
+    else:
+        from xflow_amd.sharded import ShardedTrainer
+        trainer = ShardedTrainer(model=args.model, optimizer=args.optimizer, k=args.k,
+                                 capacity=capacity, rank=rank, world=world, schedule=schedule)
     compiled = [trainer.compile(*b) for b in batches]
     R = compiled[0].R
     NNZ = int(np.mean([c.NNZ for c in compiled]))
     U = int(np.mean([c.U for c in compiled]))
     if U == 0:   # local batches carry no key list: count the unique keys of two of them
         U = int(np.mean([len(np.unique(b[1])) for b in batches[:2]]))
+    owned = [getattr(c, "n_owned", None) for c in compiled]
+
+    def allmax(x):
+        if group is not None:
+            return float(group.allgather(np.array([x], np.float64)).max())
+        if dist is not None:
+            tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
 
     def barrier():
-        if dist is not None:
+        if group is not None:
+            torch.cuda.synchronize()
+            group.barrier()
+        elif dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -339,9 +435,10 @@ def main():
             trainer.predict(c)
         trainer.check()
         trainer.defrag()
-        if not sharded:
+        if not sharded or group is not None:
             # the defrag renumbered the state rows: a forward-only pass rebuilds every
-            # minibatch's cells against the new numbering, outside the timed region
+            # minibatch's cells (N>1: the owners' cached rows) against the new numbering,
+            # outside the timed region
             for c in compiled:
                 trainer.predict(c)
             trainer.check()
@@ -349,7 +446,7 @@ def main():
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
     barrier()
-    if dist is not None:
+    if sharded:
         # RCCL writes its version banner through C stdio; push it out now so that the JSON
         # line below is the last thing on stdout
         import ctypes
@@ -358,16 +455,21 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.step(compiled[(args.warmup + i) % len(compiled)])
+    if hasattr(trainer, "flush"):
+        trainer.flush()    # the last step's Push (stale1) belongs to the K timed steps
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, ksteps = trainer.profile_read()
     trainer.profile(False)
     trainer.check()
     kernel_timing = "HIP events on the step's stream inside the timed region"
-    if not kern_ms and sharded:
+    if sharded and not any(kern_ms.values()):
         # the overlapped schedule runs two streams: per-kernel events are taken in a short
         # sequential pass after the timed region instead
-        trainer.schedule = "sequential"
+        if hasattr(trainer, "set_schedule"):
+            trainer.set_schedule("sequential")
+        else:
+            trainer.schedule = "sequential"
         trainer.profile(True)
         for i in range(8):
             trainer.step(compiled[i % len(compiled)])
@@ -377,10 +479,7 @@ def main():
         trainer.check()
         kernel_timing = "HIP events in a sequential pass of 8 steps after the timed region " \
                         "(the timed region overlaps two streams)"
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = allmax(dt)
     # the logloss half of BASELINE's metric: a held-out minibatch from the same generator (same
     # ground-truth weights), scored with the tables as the timed steps left them
     try:
@@ -409,9 +508,18 @@ def main():
                                   "parity tests pin"}
     except Exception as e:  # the throughput line must not depend on this extra
         logloss = {"error": str(e)}
+    imbalance = None
+    if group is not None:
+        own = group.allgather(np.array([np.mean([o for o in owned])], np.float64)).ravel()
+        imbalance = {"owned_keys_per_step_by_rank": [float(x) for x in own],
+                     "max_over_mean": float(own.max() / own.mean()) if own.mean() > 0 else None}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        if group is not None:
+            group.barrier()
+            del trainer
+            group.close()
         return
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
     fused = args.model == "lr" and world == 1 and not args.force_sharded
@@ -448,7 +556,8 @@ def main():
                    "distinct_batches": len(compiled),
                    "parallelism": ("key-range sharded table x%d, all-to-all of weights and "
                                    "gradients per step, schedule %s" % (world, schedule))
-                   if sharded else "single shard"},
+                   if sharded else "single shard",
+                   "exchange": exchange, "shard_imbalance": imbalance},
         "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
@@ -483,6 +592,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, batches)
     if dist is not None:
         dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        del trainer
+        group.close()
+    if sharded:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
