@@ -87,6 +87,8 @@ def lib():
     L.xo_auc_logloss.argtypes = [_i32p, _f32p, C.c_size_t, _f32p, _f32p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.xo_set_sum_mode.argtypes = [C.c_int]
+    L.xo_lr_update_slices_mt.restype = C.c_long
+    L.xo_lr_update_slices_mt.argtypes = [C.c_void_p, _u64p, _u64p, _i32p, C.c_size_t, C.c_int]
     L.xo_train.restype = C.c_long
     L.xo_train.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int,
                            C.c_size_t, C.c_int]
@@ -285,6 +287,16 @@ def auc_logloss(labels, pctr, acc=0.0):
     lib().xo_auc_logloss(_ptr(labels, _i32p), _ptr(pctr, _f32p), len(labels), C.byref(ll),
                          C.byref(auc), C.byref(tp), C.byref(fp))
     return ll.value, auc.value, tp.value, fp.value
+
+
+def lr_update_slices_mt(store, rowptr, keys, labels, core_num):
+    """the reference's slice fan-out (lr_worker.cc:186-200) on core_num threads; a timed
+    baseline, not a parity path (the slices' pushes race, as in the reference)"""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    return lib().xo_lr_update_slices_mt(store.h, _ptr(rowptr, _u64p), _ptr(keys, _u64p),
+                                        _ptr(labels, _i32p), len(labels), core_num)
 
 
 def train(model, wstore, vstore, path, epochs, block_bytes=2 << 20, core_num=1):

@@ -29,6 +29,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 /* ======================================================================= a2 */
@@ -689,6 +691,42 @@ extern "C" long xo_train(int model, xo_store *ws, xo_store *vs, const char *trai
     xo_reader_close(rd);
   }
   return consumed;
+}
+
+/* The reference's slice fan-out as a timed baseline (lr_worker.cc:186-200): the block's rows
+ * are cut into core_num slices, each slice's update() — its own key build (the two std::sorts),
+ * Pull, loss, gradient, Push — runs on its own thread (the reference enqueues them on a
+ * ThreadPool of hardware_concurrency() threads and spins until all are done); the server side
+ * is ps-lite's single customer thread, i.e. Pull and Push are served one at a time (a mutex
+ * here).  Not a parity path: the order in which the slices' pushes land is a race in the
+ * reference too. */
+extern "C" long xo_lr_update_slices_mt(xo_store *ws, const uint64_t *rowptr, const uint64_t *keys,
+                                       const int32_t *labels, size_t rows, int core_num) {
+  if (core_num < 1) core_num = 1;
+  const size_t thread_size = rows / (size_t)core_num; /* :190, remainder dropped */
+  std::mutex server;
+  std::vector<std::thread> pool;
+  for (int i = 0; i < core_num; ++i) {
+    const size_t start = i * thread_size, end = (i + 1) * thread_size;
+    if (end == start) continue;
+    pool.emplace_back([=, &server]() {
+      xo_batch *b = xo_batch_build(rowptr, keys, labels, start, end);
+      std::vector<float> w(b->nu), g(b->nu), loss(b->rows);
+      {
+        std::lock_guard<std::mutex> lk(server);
+        xo_store_pull(ws, b->ukeys.data(), b->nu, w.data());
+      }
+      xo_lr_loss(b, w.data(), loss.data(), NULL);
+      xo_lr_grad(b, loss.data(), g.data());
+      {
+        std::lock_guard<std::mutex> lk(server);
+        xo_store_push(ws, b->ukeys.data(), b->nu, g.data());
+      }
+      xo_batch_free(b);
+    });
+  }
+  for (auto &t : pool) t.join();
+  return (long)(thread_size * (size_t)core_num);
 }
 
 extern "C" long xo_predict(int model, xo_store *ws, xo_store *vs, const char *test_path,

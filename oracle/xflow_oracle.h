@@ -135,6 +135,9 @@ void xo_auc_logloss(const int32_t *labels, const float *pctr, size_t n,
  * per epoch re-open + block loop, core_num equal row slices (remainder dropped,
  * lr_worker.cc:190-194), slices applied one after another (a legal serialisation;
  * core_num=1 is the deterministic reference schedule). Returns rows consumed. */
+/* the reference's slice fan-out on core_num threads (timed CPU baseline; lr_worker.cc:186-200) */
+long xo_lr_update_slices_mt(xo_store *w, const uint64_t *rowptr, const uint64_t *keys,
+                            const int32_t *labels, size_t rows, int core_num);
 long xo_train(int model, xo_store *w, xo_store *v, const char *train_path, int epochs,
               size_t block_bytes, int core_num);
 /* lr_worker.cc:25-98 / fm_worker.cc:25-124: forward over the test file; appends to

@@ -1,10 +1,24 @@
 #!/usr/bin/env python3
-"""End-to-end from libsvm-style text through the xflow_lr CLI: synthetic file -> parse (host,
-multi-threaded) -> key build (GPU) -> steps (GPU) -> predict/AUC.  Tuning/measurement aid."""
-import os, subprocess, sys, tempfile, time
+"""End to end through the `xflow_lr` binary on a synthetic libsvm-style file (GPU box):
+text -> multi-threaded block parser (host) -> key build (GPU) -> steps (GPU) -> predict / AUC,
+first epoch from the text, first epoch from the binarized block cache, and the average over 4
+epochs (later epochs replay the compiled minibatches from HBM).  Writes the numbers as JSON
+(profiles/e2e_latest.json is what bench.py quotes as `end_to_end`).
+    python tools/e2e_text.py [rows] [out.json]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows, nnz, K = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, 200, 10_000_000
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "e2e_latest.json")
+nnz, K = 200, 10_000_000
 d = tempfile.mkdtemp()
 rng = np.random.RandomState(0)
 t0 = time.time()
@@ -14,11 +28,54 @@ for name, n in (("train-00000", rows), ("test-00000", rows // 10)):
     with open(os.path.join(d, name), "w") as f:
         for r in range(n):
             f.write("%d\t" % lab[r] + " ".join("%d:%d:1" % (j & 31, v) for j, v in enumerate(fid[r])) + "\n")
-print("generated %d rows (%.0f MB) in %.1f s" % (rows, os.path.getsize(os.path.join(d, "train-00000")) / 1e6, time.time() - t0), flush=True)
-# (first run: cold page cache / first HIP start; block_cache=1 twice: build the cache, use it)
-for epochs, extra in ((1, []), (1, []), (4, []), (1, ["block_cache=1"]), (1, ["block_cache=1"])):
+size_mb = os.path.getsize(os.path.join(d, "train-00000")) / 1e6
+print("generated %d rows (%.0f MB) in %.1f s" % (rows, size_mb, time.time() - t0), flush=True)
+
+
+def run(epochs, extra):
     t0 = time.time()
-    out = subprocess.run([os.path.join(ROOT, "xflow_amd/lib/xflow_lr"), os.path.join(d, "train"), os.path.join(d, "test"),
-                          "0", str(epochs), "block_size_mb=64", "capacity=30000000", "pred_path=" + os.path.join(d, "pred.txt")] + extra,
-                         capture_output=True, text=True)
-    print("epochs=%d %s wall %.2f s :: %s" % (epochs, extra, time.time() - t0, " | ".join(out.stdout.strip().splitlines()[-3:])), out.stderr[-300:], flush=True)
+    out = subprocess.run([os.path.join(ROOT, "xflow_amd/lib/xflow_lr"), os.path.join(d, "train"),
+                          os.path.join(d, "test"), "0", str(epochs), "block_size_mb=64",
+                          "capacity=30000000", "pred_path=" + os.path.join(d, "pred.txt")] + extra,
+                         capture_output=True, text=True,
+                         env=dict(os.environ, XF_TRACE_WORKER="1"))
+    wall = time.time() - t0
+    m = re.search(r"examples/sec \(train loop\): ([0-9.e+]+)", out.stdout)
+    eps = float(m.group(1)) if m else None
+    # per-block timeline (XF_TRACE_WORKER): rows / (wait for the parser + key build + step)
+    blk = re.findall(r"block: (\d+) rows  waited for the parser ([0-9.]+) ms  key build "
+                     r"([0-9.]+) ms  step\+check ([0-9.]+) ms", out.stderr)
+    steady = None
+    if len(blk) > 4:
+        per = sorted(float(w) + float(b) + float(s_) for _, w, b, s_ in blk[2:-1])
+        steady = float(blk[2][0]) / (per[len(per) // 2] * 1e-3)
+    run.steady = steady
+    print("epochs=%d %s wall %.2f s train-loop %s ex/s, median block %s ex/s\n%s" % (
+        epochs, extra, wall, eps, steady, out.stderr[-1200:] if os.environ.get("E2E_TRACE") else ""),
+        flush=True)
+    return eps, wall
+
+
+run(1, [])                                   # cold page cache / first HIP start: not recorded
+text1, w_text = run(1, [])
+text_steady = run.steady
+text4, _ = run(4, [])
+run(1, ["block_cache=1"])                    # builds the cache
+cache1, w_cache = run(1, ["block_cache=1"])  # uses it
+cache_steady = run.steady
+res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, %.0f MB, 64 MiB "
+               "blocks, LR + FTRL, key space 1e7; examples/sec of the train loop (parse + key "
+               "build + steps), predict excluded" % (rows, nnz, size_mb),
+       "host": {"nproc": os.cpu_count()},
+       "first_epoch_from_text": text1, "first_epoch_from_block_cache": cache1,
+       "median_block_rate_from_text": text_steady, "median_block_rate_from_block_cache": cache_steady,
+       "note": "first_epoch_* = rows / wall time of the whole first epoch of a fresh process "
+               "(includes its one-time allocations: pinned block buffers, build arena, table); "
+               "median_block_rate_* = rows of a block / (wait for the parser + key build incl. "
+               "upload + step) for the median block of that epoch",
+       "average_over_4_epochs_from_text": text4,
+       "wall_seconds_incl_predict": {"text_1_epoch": w_text, "cache_1_epoch": w_cache},
+       "measured_by": "tools/e2e_text.py"}
+os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps(res))

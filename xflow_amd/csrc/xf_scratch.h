@@ -47,6 +47,16 @@ struct Scratch {
   int get(T **p, size_t n) {
     const size_t bytes = ((std::max<size_t>(n, 1) * sizeof(T)) + 255) & ~(size_t)255;
     Arena &a = arena();
+    if (a.used == 0 && bytes > a.cap) {
+      // nothing is handed out: size the arena for a whole build now (the first request of a
+      // build is one of its NNZ-sized arrays, a build takes about eight of them) instead of
+      // spilling every request of the first build into its own hipMalloc (50 ms, once)
+      if (a.base) (void)hipFree(a.base);
+      a.base = nullptr;
+      a.cap = 0;
+      const size_t want = std::max(bytes * 10, a.high + a.high / 4);
+      if (hipMalloc((void **)&a.base, want) == hipSuccess) a.cap = want;
+    }
     if (a.used + bytes <= a.cap) {
       *p = (T *)(a.base + a.used);
       a.used += bytes;

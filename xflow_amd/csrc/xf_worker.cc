@@ -207,8 +207,10 @@ int Worker::batch_training() {
       });
       int rc = XF_OK;
       bool mine_done = false;
+      const bool trace = getenv("XF_TRACE_WORKER") != nullptr;  // per-block timeline on stderr
       for (int k = 0; rc == XF_OK;) {
         Parsed *p = nullptr;
+        const double tw0 = now_s();
         if (!mine_done) {
           {
             std::unique_lock<std::mutex> lk(mu);
@@ -225,11 +227,14 @@ int Worker::batch_training() {
         rc = any_rank(!mine_done, &any);
         if (rc != XF_OK || !any) break;
         const size_t rows = mine_done ? 0 : p->rows;
+        const double tw1 = now_s();
+        double t_compile = 0, t_step = 0;
         const size_t thread_size = rows / core_num;  // remainder dropped, lr_worker.cc:190
         for (int i = 0; i < core_num && rc == XF_OK; ++i) {
           const size_t start = i * thread_size, end = (i + 1) * thread_size;
           if (end == start && world <= 1) continue;
           xf_sbatch *b = nullptr;
+          const double tc0 = now_s();
           // a rank without rows of its own still takes part in the (collective) step
           rc = end > start ? xf_sharded_compile(sharded_, &b, p->rowptr, p->keys, p->labels,
                                                 start, end, cache_batches != 0)
@@ -237,8 +242,11 @@ int Worker::batch_training() {
                                                 (const int32_t *)kNoRows, 0, 0,
                                                 cache_batches != 0);
           if (rc != XF_OK) break;
+          const double tc1 = now_s();
           rc = xf_sharded_step(sharded_, b);
           if (rc == XF_OK) rc = xf_sharded_check(sharded_);
+          t_compile += tc1 - tc0;
+          t_step += now_s() - tc1;
           if (rc != XF_OK) {
             xf_sbatch_free(b);
             break;
@@ -248,6 +256,9 @@ int Worker::batch_training() {
           else
             xf_sbatch_free(b);
         }
+        if (trace)
+          fprintf(stderr, "block: %zu rows  waited for the parser %.2f ms  key build %.2f ms  "
+                  "step+check %.2f ms\n", rows, (tw1 - tw0) * 1e3, t_compile * 1e3, t_step * 1e3);
         if (!mine_done) {
           {
             std::lock_guard<std::mutex> lk(mu);
