@@ -62,6 +62,12 @@ def near_state(a, b, rtol=RTOL):
     close(a, b, rtol=rtol, atol=rtol * float(np.sqrt(np.mean(b64 * b64))) + ATOL)
 
 
+def state_distance(a, b):
+    """max |a-b| / (|b| + rms(b)) — the measure near_state bounds"""
+    a64, b64 = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a64 - b64) / (np.abs(b64) + np.sqrt(np.mean(b64 * b64)) + ATOL)))
+
+
 def synth(rng, R, nnz_per_row, nkeys, zipf=None, ragged=False):
     lens = rng.randint(0, 2 * nnz_per_row + 1, size=R) if ragged else np.full(R, nnz_per_row)
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -339,7 +345,9 @@ def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
     for a, e, r in zip(t.export(), s_exact.export(), s_ref.export()):
         same(a, e)                                 # keys and every float: bit-exact
         if a.dtype != np.uint64:
-            near_state(a, r, RTOL_HEAVY if zipf else RTOL)
+            # two trajectories, 4 steps apart (see test_gpu_parity_tight for the one-step,
+            # derived bounds): measured distance <= 4.1e-5 with power-law heads, <= 1e-6 without
+            assert state_distance(a, r) <= (RTOL_HEAVY if zipf else 2 * RTOL)
 
 
 def test_lr_forward_panel_kernel_bit_exact():
@@ -398,10 +406,16 @@ def test_fm_step_state(opt, k):
         for a, e, r in zip(tt.export(), se.export(), sr.export()):
             same(a, e)
             if a.dtype != np.uint64:
-                # reference arithmetic pools v_sum over k x nnz terms in one fp32 accumulator
-                # (fm_worker.cc:178-192): its own rounding noise grows with k; at k = 64 a
-                # power-law step moves single FTRL z coordinates by 4e-4 relative
-                near_state(a, r, RTOL_HEAVY * (20 if k >= 32 else 1))
+                # Two TRAJECTORIES (3 steps, the last one power-law) that start together and
+                # then each follow their own arithmetic: the reference pools v_sum over k x nnz
+                # terms in one fp32 running sum (fm_worker.cc:178-192), whose rounding noise
+                # grows with k and feeds back through the state.  Measured distances
+                # (max |a-r| / (|r| + rms r)) on MI355X: <= 2.0e-5 for k <= 16, 7.0e-5 at
+                # k = 32, 3.9e-4 at k = 64 (FTRL z after the power-law step); asserted at
+                # twice that.  The one-step derivation of the same noise is
+                # tests/test_gpu_parity_tight.py::test_fm_loss_against_reference_arithmetic.
+                d = state_distance(a, r)
+                assert d <= (8e-4 if k >= 64 else 1.5e-4 if k >= 32 else 4e-5), (k, d)
 
 
 def test_predict_matches_oracle_and_inserts_keys():
@@ -605,10 +619,13 @@ def test_sharded_trainer_world1_matches_fused_step():
                     for p, q in zip(x.export(), y.export()):
                         same(p, q)
             data = synth(rng, 300, 25, 9000)
-            pa = a.predict(a.compile(*data)).cpu().numpy()
-            pb = b.predict(b.compile(*data))
+            pa = a.predict(a.compile(*data)).cpu().numpy()     # loss = p - y
+            pb = b.predict(b.compile(*data))                   # p
             ob = O.Batch(*data)
             assert pa.shape == pb.shape == (ob.R,)
+            # both drivers inserted the held-out keys and score them the same way
+            same(pa, (pb.astype(np.float32) - data[2].astype(np.float32)).astype(np.float32))
+            assert len(ta[0]) == len(tb[0])
     finally:
         dist.destroy_process_group()
 
