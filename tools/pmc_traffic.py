@@ -28,6 +28,10 @@ WIDTH = {
     "k_lr_grad": (4, 4), "k_lr_grad_tiled": (4, 4),
     "k_lr_grad_update": (4, 4), "k_lr_grad_heavy": (4, 4), "k_fm_forward": (4, 4),
     "k_fm_grad": (4, 4),
+    # round 2: cells kernels — forward reads 4-byte entries / weights and writes fp64 partials,
+    # finalize reads fp64 partials, gradient reads 4-byte entries / losses / w and 8-byte {n,z}
+    "k_lr_fwd_cells": (4, 8), "k_lr_finalize_cells": (8, 4), "k_lr_grad_cells": (4, 4),
+    "k_lr_grad_split_finish": (8, 4), "k_cell_keys": (4, 4),
 }
 
 

@@ -21,5 +21,6 @@ python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_t
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/step_kernel_stats.csv
 cp $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $OUT/pmc_fetch_counter_collection.csv
 cp $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/pmc_write_counter_collection.csv
+cp $OUT/pmc_traffic.json profiles/pmc_traffic_latest.json 2>/dev/null
 tail -c 1500 $OUT/bench_n1.json
 head -12 $OUT/step_kernel_stats.csv | cut -c1-160
