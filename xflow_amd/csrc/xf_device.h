@@ -17,6 +17,7 @@ constexpr unsigned kErrFull = 1u;
 constexpr unsigned kErrForeignKey = 2u;
 constexpr unsigned kErrDupKey = 4u;
 constexpr int kBaseWin = 4;  // settled-tier keys compared per probe round
+constexpr int kCoarse = 16;  // keys per bucket of the coarse directory
 
 struct TableStat {
   unsigned long long count;  // state rows handed out == keys stored
@@ -46,6 +47,12 @@ struct TableDev {
   uint64_t dmult;         // bucket = mulhi64(key - lo, dmult), clamped to ndir-1
   const uint64_t *bkeys;  // [nbase + kBaseWin] ascending, padded
   const uint32_t *bdir;   // [ndir+1] bdir[b] = keys in buckets < b
+  // a second, COARSE directory over the same keys (kCoarse keys per bucket on average) for key
+  // lists in no order (the raw keys of a minibatch): it is small enough to live in an XCD's L2
+  // (2.5 MB for 1e7 keys), so a lookup costs one HBM access — the keys around the interpolated
+  // position — instead of two
+  uint64_t ncdir, cmult;
+  const uint32_t *cdir;   // [ncdir+1]
   TableStat *stat;
   int dim, init_kind;
   float init_const;

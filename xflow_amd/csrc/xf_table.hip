@@ -312,6 +312,86 @@ k_pull_settled(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
   }
 }
 
+// The settled-tier lookup for key lists in NO order (every raw key of a minibatch, duplicates
+// included): coarse directory (L2-resident) -> the bucket's key run [s, e) -> the position the
+// key would have if the bucket's keys were evenly spaced -> kBaseWin keys around it, then the
+// rest of the bucket if need be.  Misses go to the work list of the insert kernel.
+template <int ILP>
+__global__ void __launch_bounds__(kBlock)
+k_lookup_any(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
+             uint32_t *__restrict__ rows_out, uint32_t *__restrict__ miss,
+             unsigned long long *__restrict__ miss_n) {
+  const size_t chunk = (size_t)kBlock * ILP;
+  for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+    uint64_t key[ILP];
+    uint32_t s[ILP], e[ILP], est[ILP], row[ILP];
+    bool act[ILP], hit[ILP];
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      const size_t i = base + (size_t)q * kBlock + threadIdx.x;
+      act[q] = i < n;
+      key[q] = act[q] ? keys[i] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      hit[q] = false;
+      const bool look = act[q] && key[q] != xf::kEmptyKey && xf::owns(T, key[q]);
+      uint64_t bk = look ? __umul64hi(key[q] - T.lo, T.cmult) : 0;
+      if (bk >= T.ncdir) bk = T.ncdir - 1;
+      s[q] = look ? T.cdir[bk] : 0u;
+      e[q] = look ? T.cdir[bk + 1] : 0u;
+      // fraction of the bucket's key range below the key: the low 64 bits of (key-lo)*cmult
+      const uint64_t frac = (key[q] - T.lo) * T.cmult;
+      const uint32_t len = e[q] - s[q];
+      uint32_t p = s[q] + (uint32_t)__umul64hi(frac, (uint64_t)len);
+      p = p > s[q] + 1 ? p - 2 : s[q];  // the window [p, p + kBaseWin) around the estimate
+      est[q] = p;
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      uint64_t c[xf::kBaseWin];
+#pragma unroll
+      for (int t = 0; t < xf::kBaseWin; ++t) c[t] = T.bkeys[est[q] + t];  // padded: readable
+#pragma unroll
+      for (int t = 0; t < xf::kBaseWin; ++t)
+        if (est[q] + t < e[q] && c[t] == key[q]) {
+          row[q] = est[q] + t;
+          hit[q] = true;
+        }
+      if (!hit[q] && e[q] > s[q]) {  // walk from the window towards the key (sorted run)
+        if (c[0] > key[q]) {
+          for (uint32_t p = est[q]; p > s[q] && !hit[q];) {
+            --p;
+            const uint64_t k2 = T.bkeys[p];
+            if (k2 == key[q]) {
+              row[q] = p;
+              hit[q] = true;
+            }
+            if (k2 < key[q]) break;
+          }
+        } else {
+          for (uint32_t p = est[q] + xf::kBaseWin; p < e[q] && !hit[q]; ++p) {
+            const uint64_t k2 = T.bkeys[p];
+            if (k2 == key[q]) {
+              row[q] = p;
+              hit[q] = true;
+            }
+            if (k2 > key[q]) break;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; ++q) {
+      const size_t i = base + (size_t)q * kBlock + threadIdx.x;
+      if (hit[q]) rows_out[i] = row[q];
+      const bool lost = act[q] && !hit[q];
+      const unsigned long long p = wave_append(miss_n, lost);  // every lane reaches this
+      if (lost) miss[p] = (uint32_t)i;
+    }
+  }
+}
+
 // Pull payload: vals[i][j] = w[row[i]][j] (ftrl.h:75-77).  One element per lane; rows are
 // contiguous so a wave reads 64/dim rows as whole segments.
 __global__ void __launch_bounds__(kBlock)
@@ -569,6 +649,26 @@ k_build_dir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
   }
 }
 
+// the coarse directory: cdir[b] = first rank whose coarse bucket is >= b (a lower bound per
+// bucket: 6e5 searches of 24 steps)
+__global__ void __launch_bounds__(kBlock)
+k_build_cdir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
+             uint32_t *__restrict__ cdir) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b <= T.ncdir; b += stride) {
+    size_t lo = 0, hi = n;  // first r with bucket(skeys[r]) >= b
+    while (lo < hi) {
+      const size_t mid = lo + (hi - lo) / 2;
+      uint64_t bk = __umul64hi(skeys[mid] - T.lo, T.cmult);
+      if (bk >= T.ncdir) bk = T.ncdir - 1;
+      if (bk < b) lo = mid + 1;
+      else
+        hi = mid;
+    }
+    cdir[b] = (uint32_t)lo;
+  }
+}
+
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -733,7 +833,8 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
   void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
-                (void *)t->T.bdir, t->s_keys, t->s_rows, t->s_vals, t->miss, t->miss_n};
+                (void *)t->T.bdir, (void *)t->T.cdir, t->s_keys, t->s_rows, t->s_vals, t->miss,
+                t->miss_n};
   for (void *p : ps)
     if (p) hipFree(p);
   delete t;
@@ -837,7 +938,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
   if (n_idx == 0) return XF_OK;                // nothing arrived since the last defrag
   const size_t elems = ((size_t)T.max_rows + 1) * (size_t)T.dim;
   DevBuf<uint64_t> k_all, k_sorted;
-  DevBuf<uint32_t> r_all, r_sorted, dir;
+  DevBuf<uint32_t> r_all, r_sorted, dir, cdir;
   DevBuf<unsigned long long> d_cnt;
   DevBuf<float> w2;
   DevBuf<float2> nz2;
@@ -887,6 +988,11 @@ extern "C" int xf_table_defrag(xf_table *t) {
   XF_HIP(dir.alloc(N.ndir + 1));
   hipLaunchKernelGGL(k_build_dir, dim3(grid_for(n + 1)), dim3(kBlock), 0, 0, N, k_sorted.p, n,
                      dir.p);
+  N.ncdir = std::max<uint64_t>(1, n / xf::kCoarse);
+  N.cmult = (uint64_t)((((unsigned __int128)N.ncdir) << 64) / T.span);
+  XF_HIP(cdir.alloc(N.ncdir + 1));
+  hipLaunchKernelGGL(k_build_cdir, dim3(grid_for(N.ncdir + 1)), dim3(kBlock), 0, 0, N,
+                     k_sorted.p, n, cdir.p);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
   // everything is built: from here on nothing fails half-way.  Empty the index (the spare
@@ -904,10 +1010,12 @@ extern "C" int xf_table_defrag(xf_table *t) {
   if (T.nz) (void)hipFree(T.nz);
   if (T.bkeys) (void)hipFree((void *)T.bkeys);
   if (T.bdir) (void)hipFree((void *)T.bdir);
+  if (T.cdir) (void)hipFree((void *)T.cdir);
   N.w = w2.take();
   N.nz = T.nz ? nz2.take() : nullptr;
   N.bkeys = k_sorted.take();
   N.bdir = dir.take();
+  N.cdir = cdir.take();
   T = N;
   ++t->epoch;  // every row number handed out before this call is stale
   return XF_OK;
@@ -1174,9 +1282,8 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
     constexpr int kAnyIlp = 4;
     const size_t chunk = (size_t)kBlock * kAnyIlp;
     const size_t blocks = std::min<size_t>((n + chunk - 1) / chunk, 1u << 16);
-    hipLaunchKernelGGL((k_pull_settled<false, kAnyIlp, xf::kBaseWin>), dim3((unsigned)blocks),
-                       dim3(kBlock), 0, s, t->T, d_keys, n, d_rows, (float *)nullptr, t->miss,
-                       t->miss_n, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_lookup_any<kAnyIlp>, dim3((unsigned)blocks), dim3(kBlock), 0, s, t->T,
+                       d_keys, n, d_rows, t->miss, t->miss_n);
     XF_HIP(hipGetLastError());
     unsigned long long misses = 0;
     XF_HIP(hipMemcpyAsync(&misses, t->miss_n, 8, hipMemcpyDeviceToHost, s));
