@@ -139,7 +139,7 @@ int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_pt
 /* tuning knobs (process-wide): "panel_slice_bytes" (default 1.5 MiB: w_u bytes per panel),
  * "min_panel_nnz" (default 4e6: smaller batches keep the plain CSR forward),
  * "parse_threads" (default 64: threads of the block text parser),
- * "batch_pool_blobs" (default 4: device allocations of freed minibatches kept for reuse by
+ * "batch_pool_blobs" (default 8: device allocations of freed minibatches kept for reuse by
  * the next compile/upload; 0 returns every one to the driver) */
 int xf_tune(const char *name, double value);
 /* copy to the current device (async on stream); idempotent */

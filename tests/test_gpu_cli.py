@@ -79,3 +79,25 @@ def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, t
     assert O.format_auc_line(ll, auc, tp, fp) in out.stdout.splitlines()
     pred = np.loadtxt(str(tmp_path / "pred.txt"))
     assert pred.shape == (200, 3) and np.array_equal(pred[:, 2].astype(np.int32), lab)
+
+
+def test_bench_runs_two_ranks_and_reports_them(tmp_path):
+    """`python bench.py --gpus 2` spawns its own ranks (what the driver's scaling run does under
+    torchrun): two ranks share this box's GPU over the host transport, a functional check of the
+    whole N>1 bench path — group, C++ sharded trainer, stale1, the sequential profiling pass, the
+    rank-0 JSON line."""
+    import json
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--transport", "host", "--rows", "3000", "--nnz-per-row", "50",
+                          "--keys-per-gpu", "200000", "--batches", "3", "--steps", "5",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_PORT=str(free_port())))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["unit"] == "examples/sec"
+    assert line["config"]["rows_per_gpu_batch"] == 3000
+    assert len(line["config"]["shard_imbalance"]["owned_keys_per_step_by_rank"]) == 2
+    assert set(line["kernels_ms"]) >= {"a2a_weights", "a2a_grads", "forward", "gradient"}
+    assert abs(line["logloss"]["natural"] - 0.693) < 0.01

@@ -159,7 +159,7 @@ struct Blob {
 };
 std::mutex g_pool_mu;
 std::vector<Blob> g_pool;
-int g_pool_limit = 4;
+int g_pool_limit = 8;
 }  // namespace
 
 int blob_alloc(void **p, size_t bytes, size_t *got) {
@@ -338,7 +338,7 @@ extern "C" int xf_batch_free(xf_batch *b) {
   }
   if (b->d_blob) xf::blob_free(b->d_blob, b->d_blob_bytes);
   if (b->cells) xf::cells_free(b->cells);
-  if (b->d_raw) (void)hipFree(b->d_raw);
+  if (b->d_raw) xf::blob_free(b->d_raw, b->d_raw_bytes);
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);
   delete b;
   return XF_OK;

@@ -704,8 +704,7 @@ extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uin
   const size_t o_rp = o_lab + al((size_t)R * 4);
   const size_t o_keys = o_rp + al(retain_keys ? ((size_t)R + 1) * 4 : 0);
   const size_t total = o_keys + al(retain_keys ? (size_t)NNZ * 8 : 0) + 256;
-  XF_HIP(hipMalloc(&b->d_raw, total));
-  b->d_raw_bytes = total;
+  XF_TRY(xf::blob_alloc(&b->d_raw, total, &b->d_raw_bytes));
   char *d = (char *)b->d_raw;
   if (R) XF_HIP(hipMemcpyAsync(d + o_lab, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
   b->raw_labels = (const int32_t *)(d + o_lab);
