@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--driver", default="native", choices=["native", "python"],
                     help="N>1: the C++ sharded trainer over xf_group (default) or the Python "
                          "driver over torch.distributed")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host"],
                     help="N>1: host = stage the exchange through the group's sockets so that "
                          "several ranks can share one GPU (a functional check, not a benchmark)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -339,7 +339,7 @@ def spawn_ranks(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus and args.transport == "rccl":
+    if have < args.gpus and args.transport != "host":
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -410,8 +410,8 @@ def make_group(rank, world, local_rank, transport="rccl"):
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29512")) + 23
     g = capi.Group(rank, world, addr, port,
-                   capi.TRANSPORT_RCCL if transport == "rccl" else capi.TRANSPORT_HOST,
-                   device=local_rank)
+                   {"rccl": capi.TRANSPORT_RCCL, "host": capi.TRANSPORT_HOST,
+                    "auto": capi.TRANSPORT_AUTO}[transport], device=local_rank)
     src = torch.full((world * 4,), float(rank), device="cuda")
     dst = torch.full((world * 4,), -1.0, device="cuda")
     g.alltoallv_dev(src.data_ptr(), [4] * world, dst.data_ptr(), [4] * world, 4,
@@ -449,8 +449,9 @@ def main():
     if sharded and args.driver == "native":
         group = make_group(rank, world, local_rank, args.transport)
         exchange = "xf_group: grouped ncclSend/ncclRecv (RCCL) from C++, one all-to-all-v each " \
-                   "way" if args.transport == "rccl" else \
-                   "xf_group HOST transport (staged through sockets: functional check only)"
+                   "way" if group.transport == capi.TRANSPORT_RCCL else \
+                   "xf_group HOST transport (staged through sockets: functional check only%s)" \
+                   % ("" if args.transport == "host" else "; RCCL DID NOT COME UP, see stderr")
     elif sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -637,7 +638,10 @@ def main():
                    "parallelism": ("key-range sharded table x%d, all-to-all of weights and "
                                    "gradients per step, schedule %s" % (world, schedule))
                    if sharded else "single shard",
-                   "exchange": exchange, "shard_imbalance": imbalance},
+                   "exchange": exchange,
+                   "transport": (None if group is None else
+                                 "rccl" if group.transport == capi.TRANSPORT_RCCL else "host"),
+                   "shard_imbalance": imbalance},
         "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),

@@ -324,6 +324,10 @@ int xf_calib_stream(int kind, size_t bytes, int repeat); /* == ps KVWorker::Wait
  * one GPU, or none). */
 #define XF_TRANSPORT_RCCL 0
 #define XF_TRANSPORT_HOST 1
+/* RCCL when it comes up on every rank (library, communicator and one all-to-all-v on the device
+ * are checked collectively), otherwise the host transport with a warning on rank 0's stderr;
+ * xf_group_info reports which one the group runs on */
+#define XF_TRANSPORT_AUTO 2
 typedef struct xf_group xf_group;
 /* rank < 0 / world <= 0 / addr NULL / port <= 0: from the environment — WORLD_SIZE | XF_WORLD |
  * DMLC_NUM_WORKER; RANK | XF_RANK | DMLC_RANK (absent: ranks are handed out in arrival order,

@@ -9,6 +9,7 @@
   GPUs (the driver's 8-GPU node runs them);
 * the sharded checkpoint: saved by 2 ranks, loaded by 3 and by 1."""
 import multiprocessing as mp
+import ctypes as C
 import os
 import traceback
 
@@ -28,8 +29,13 @@ pytestmark = pytest.mark.gpu
 def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q):
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ndev = C.c_int(0)
+        capi.check(capi.lib().xf_device_count(C.byref(ndev)))
         g = capi.Group(rank, world, "127.0.0.1", port, transport,
-                       device=0 if transport == capi.TRANSPORT_HOST else rank)
+                       device=0 if transport == capi.TRANSPORT_HOST else rank % ndev.value)
+        if transport == capi.TRANSPORT_AUTO:   # RCCL with a GPU per rank, else the fallback
+            assert g.transport == (capi.TRANSPORT_RCCL if ndev.value >= world
+                                   else capi.TRANSPORT_HOST)
         st = capi.Sharded(g, model=model, optimizer=optimizer, k=4, capacity=64,
                           schedule=schedule, seed=7)
         alive = []   # freeing a minibatch whose Push is still outstanding would flush it early
@@ -114,6 +120,14 @@ def test_cpp_sharded_over_rccl(tmp_path, world, model, schedule):
         pytest.skip("needs %d GPUs, this box has %d" % (world, n.value))
     _run(world, capi.TRANSPORT_RCCL, model, "ftrl", schedule, tmp_path)
     _check_against_oracle(world, model, "ftrl", schedule, tmp_path)
+
+
+def test_auto_transport_agrees_on_every_rank(tmp_path):
+    """XF_TRANSPORT_AUTO at world 2: RCCL when the box has two GPUs; with one, RCCL refuses the
+    communicator (two ranks on one device), the ranks agree on that over the bootstrap and the
+    run goes through the host transport — bit-exact either way, and nobody hangs"""
+    _run(2, capi.TRANSPORT_AUTO, "lr", "ftrl", "stale1", tmp_path)
+    _check_against_oracle(2, "lr", "ftrl", "stale1", tmp_path)
 
 
 def test_rccl_group_of_one_and_the_fused_step():

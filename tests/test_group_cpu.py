@@ -70,6 +70,49 @@ def test_group_host_transport(world, auto_rank):
     assert sorted(r for _, r, _ in res) == list(range(world))   # every rank handed out once
 
 
+def _bring_up_main(rank, world, port, transport, q):
+    try:
+        try:
+            g = capi.Group(rank=rank, world=world, addr="127.0.0.1", port=port,
+                           transport=transport)
+        except capi.XFError as e:
+            q.put((rank, "error", str(e)))
+            return
+        recv, _ = g.alltoallv_host(np.full(world, rank, np.int32), [1] * world)
+        assert list(recv) == list(range(world))
+        q.put((rank, g.transport, None))
+        g.close()
+    except Exception:
+        q.put((rank, "crash", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("transport", ["auto", "rccl"])
+def test_rccl_bring_up_without_gpus_is_collective(transport):
+    """No GPU here, so RCCL cannot come up.  The ranks agree on that over the bootstrap: AUTO
+    lands every rank on the host transport, the strict RCCL transport fails on every rank with
+    the first failing rank's reason — nobody hangs in a half-built communicator."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU behaviour")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    t = capi.TRANSPORT_AUTO if transport == "auto" else capi.TRANSPORT_RCCL
+    ps = [ctx.Process(target=_bring_up_main, args=(r, world, port, t, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=30)
+    assert not [m for _, k, m in res if k == "crash"], res
+    if transport == "auto":
+        assert [k for _, k, _ in res] == [capi.TRANSPORT_HOST] * world, res
+    else:
+        assert [k for _, k, _ in res] == ["error"] * world, res
+        assert all("rank " in m for _, _, m in res), res
+
+
 def test_group_world1_and_bad_arguments():
     g = capi.Group(rank=0, world=1, transport=capi.TRANSPORT_HOST)
     assert (g.rank, g.world) == (0, 1)

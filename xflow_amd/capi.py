@@ -568,7 +568,7 @@ def auc_logloss(labels, pctr, acc=0.0):
     return ll.value, auc.value, tp.value, fp.value, nat.value
 
 
-TRANSPORT_RCCL, TRANSPORT_HOST = 0, 1
+TRANSPORT_RCCL, TRANSPORT_HOST, TRANSPORT_AUTO = 0, 1, 2
 
 
 class Group:

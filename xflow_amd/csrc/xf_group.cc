@@ -158,10 +158,106 @@ int allgather_host(xf_group *g, const void *in, size_t bytes, void *out) {
 //   addr:  MASTER_ADDR, DMLC_PS_ROOT_URI (127.0.0.1)         handed out in arrival order,
 //   port:  MASTER_PORT, DMLC_PS_ROOT_PORT (29512)            the process that binds the port
 //                                                            first being rank 0)
+// every rank's (ok, message) for one bring-up stage; returns XF_OK when all ranks are fine,
+// otherwise the first failing rank's message on every rank
+static int agree(xf_group *g, int my_rc, const std::string &my_msg, std::string *why) {
+  struct Slot {
+    int32_t rc;
+    char msg[252];
+  } mine{};
+  mine.rc = my_rc;
+  snprintf(mine.msg, sizeof(mine.msg), "%s", my_msg.c_str());
+  std::vector<Slot> all(g->world);
+  if (allgather_host(g, &mine, sizeof(mine), all.data()) != XF_OK) {
+    *why = "the bootstrap connection failed";
+    return XF_EIO;
+  }
+  for (int r = 0; r < g->world; ++r)
+    if (all[r].rc != XF_OK) {
+      all[r].msg[sizeof(all[r].msg) - 1] = 0;
+      *why = "rank " + std::to_string(r) + ": " + all[r].msg;
+      return all[r].rc;
+    }
+  return XF_OK;
+}
+
+static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t> &so, char *rb,
+                          const std::vector<size_t> &ro, hipStream_t s);
+
+static int rccl_bring_up(xf_group *g, std::string *why) {
+  // 1. the library
+  int rc = load_rccl(g->rccl);
+  int ndev = 0;
+  if (rc == XF_OK && (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0))
+    rc = xf::set_error(XF_ENOGPU, "no HIP device");
+  XF_TRY(agree(g, rc, rc ? xf_last_error() : "", why));
+  // 2. the communicator
+  std::vector<ncclUniqueId_t> ids(g->world);
+  ncclUniqueId_t mine{};
+  rc = XF_OK;
+  std::string msg;
+  if (g->rank == 0) {
+    const int n = g->rccl.GetUniqueId(&mine);
+    if (n) {
+      rc = XF_EHIP;
+      msg = std::string("ncclGetUniqueId: ") + g->rccl.GetErrorString(n);
+    }
+  }
+  XF_TRY(agree(g, rc, msg, why));
+  if (allgather_host(g, &mine, sizeof(mine), ids.data()) != XF_OK) {
+    *why = "the bootstrap connection failed";
+    return XF_EIO;
+  }
+  {
+    const int n = g->rccl.CommInitRank(&g->comm, g->world, ids[0], g->rank);
+    if (n) {
+      rc = XF_EHIP;
+      msg = std::string("ncclCommInitRank: ") + g->rccl.GetErrorString(n);
+      g->comm = nullptr;
+    }
+  }
+  XF_TRY(agree(g, rc, msg, why));
+  // 3. one exchange on the device: every rank sends its number to every peer
+  const int W = g->world;
+  std::vector<int32_t> h(W * 4, g->rank), back(W * 4, -1);
+  std::vector<size_t> off(W + 1);
+  for (int p = 0; p <= W; ++p) off[p] = (size_t)p * 16;
+  void *ds = nullptr, *dr = nullptr;
+  auto hip_ok = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == XF_OK) {
+      rc = XF_EHIP;
+      msg = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return e == hipSuccess;
+  };
+  if (hip_ok(hipMalloc(&ds, off[W]), "hipMalloc") && hip_ok(hipMalloc(&dr, off[W]), "hipMalloc") &&
+      hip_ok(hipMemcpy(ds, h.data(), off[W], hipMemcpyHostToDevice), "hipMemcpy") &&
+      hip_ok(hipMemset(dr, 0xff, off[W]), "hipMemset")) {
+    if (alltoallv_rccl(g, (const char *)ds, off, (char *)dr, off, nullptr) != XF_OK) {
+      rc = XF_EHIP;
+      msg = xf_last_error();
+    } else if (hip_ok(hipStreamSynchronize(nullptr), "the first all-to-all-v") &&
+               hip_ok(hipMemcpy(back.data(), dr, off[W], hipMemcpyDeviceToHost), "hipMemcpy")) {
+      for (int p = 0; p < W && rc == XF_OK; ++p)
+        for (int q = 0; q < 4; ++q)
+          if (back[p * 4 + q] != p) {
+            rc = XF_EHIP;
+            msg = "the first all-to-all-v delivered " + std::to_string(back[p * 4 + q]) +
+                  " from rank " + std::to_string(p);
+            break;
+          }
+    }
+  }
+  if (ds) (void)hipFree(ds);
+  if (dr) (void)hipFree(dr);
+  return agree(g, rc, msg, why);
+}
+
 extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *addr, int port,
                                int transport, int device) {
   XF_REQUIRE(out, "xf_group_create: null argument");
-  XF_REQUIRE(transport == XF_TRANSPORT_RCCL || transport == XF_TRANSPORT_HOST,
+  XF_REQUIRE(transport == XF_TRANSPORT_RCCL || transport == XF_TRANSPORT_HOST ||
+                 transport == XF_TRANSPORT_AUTO,
              "xf_group_create: transport %d", transport);
   if (world <= 0) {
     const char *v = env_first({"WORLD_SIZE", "XF_WORLD", "DMLC_NUM_WORKER"});
@@ -297,18 +393,24 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
       return xf::set_error(XF_ENOGPU, "xf_group_create: no HIP device for the RCCL transport");
     }
   }
-  if (transport == XF_TRANSPORT_RCCL) {
-    XF_TRY(load_rccl(g->rccl));
-    std::vector<ncclUniqueId_t> ids(g->world);
-    ncclUniqueId_t mine{};
-    if (g->rank == 0) {
-      const int rc = g->rccl.GetUniqueId(&mine);
-      if (rc) return xf::set_error(XF_EHIP, "ncclGetUniqueId: %s", g->rccl.GetErrorString(rc));
+  if (transport != XF_TRANSPORT_HOST) {
+    // RCCL comes up in three stages (library, communicator, one all-to-all-v on the device);
+    // after each one the ranks agree over the bootstrap, so that a failure on one rank is an
+    // error (or, XF_TRANSPORT_AUTO, the host transport) on all of them instead of a hang
+    std::string why;
+    int stage_rc = rccl_bring_up(g, &why);
+    if (stage_rc == XF_OK) {
+      g->transport = XF_TRANSPORT_RCCL;
+    } else if (transport == XF_TRANSPORT_AUTO && stage_rc != XF_EIO) {
+      if (g->comm && g->rccl.CommDestroy) g->rccl.CommDestroy(g->comm);
+      g->comm = nullptr;
+      g->transport = XF_TRANSPORT_HOST;
+      if (g->rank == 0)
+        fprintf(stderr, "xf_group: RCCL is not usable (%s): the exchange is staged through the "
+                "bootstrap sockets\n", why.c_str());
+    } else {
+      return xf::set_error(stage_rc, "xf_group_create: %s", why.c_str());
     }
-    XF_TRY(allgather_host(g, &mine, sizeof(mine), ids.data()));
-    const int rc = g->rccl.CommInitRank(&g->comm, g->world, ids[0], g->rank);
-    if (rc) return xf::set_error(XF_EHIP, "ncclCommInitRank(rank %d of %d): %s", g->rank,
-                                 g->world, g->rccl.GetErrorString(rc));
   }
   guard.g = nullptr;
   *out = g;
@@ -362,6 +464,28 @@ extern "C" int xf_group_gatherv_host(xf_group *g, const void *in, size_t bytes, 
   return XF_OK;
 }
 
+// one grouped ncclSend/ncclRecv per peer with bytes to move; byte offsets so/ro per rank
+static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t> &so, char *rb,
+                          const std::vector<size_t> &ro, hipStream_t s) {
+  const int W = g->world;
+  const size_t self = so[g->rank + 1] - so[g->rank];
+  if (self)  // the slice that stays: a plain copy, no collective
+    XF_HIP(hipMemcpyAsync(rb + ro[g->rank], sb + so[g->rank], self, hipMemcpyDeviceToDevice, s));
+  if (W == 1) return XF_OK;
+  int rc = g->rccl.GroupStart();
+  for (int p = 0; p < W && !rc; ++p) {
+    if (p == g->rank) continue;
+    if (so[p + 1] > so[p])
+      rc = g->rccl.Send(sb + so[p], so[p + 1] - so[p], kNcclChar, p, g->comm, s);
+    if (!rc && ro[p + 1] > ro[p])
+      rc = g->rccl.Recv(rb + ro[p], ro[p + 1] - ro[p], kNcclChar, p, g->comm, s);
+  }
+  const int rc2 = g->rccl.GroupEnd();
+  if (rc || rc2)
+    return xf::set_error(XF_EHIP, "xf_group_alltoallv: %s", g->rccl.GetErrorString(rc ? rc : rc2));
+  return XF_OK;
+}
+
 // The exchange step of the sharded table: rank p's slice send[off_p .. off_p + send_counts[p])
 // goes to rank p, recv is filled in source-rank order (counts in elements of elem_bytes).
 // RCCL: asynchronous on `stream`, the buffers are device memory.  Host transport: blocking;
@@ -384,23 +508,7 @@ extern "C" int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t 
   char *rb = (char *)recv;
   if (g->transport == XF_TRANSPORT_RCCL) {
     XF_REQUIRE(!host_buffers, "xf_group_alltoallv: the RCCL transport moves device memory");
-    const size_t self = so[g->rank + 1] - so[g->rank];
-    if (self)  // the slice that stays: a plain copy, no collective
-      XF_HIP(hipMemcpyAsync(rb + ro[g->rank], sb + so[g->rank], self, hipMemcpyDeviceToDevice, s));
-    if (W == 1) return XF_OK;
-    int rc = g->rccl.GroupStart();
-    for (int p = 0; p < W && !rc; ++p) {
-      if (p == g->rank) continue;
-      if (so[p + 1] > so[p])
-        rc = g->rccl.Send(sb + so[p], so[p + 1] - so[p], kNcclChar, p, g->comm, s);
-      if (!rc && ro[p + 1] > ro[p])
-        rc = g->rccl.Recv(rb + ro[p], ro[p + 1] - ro[p], kNcclChar, p, g->comm, s);
-    }
-    const int rc2 = g->rccl.GroupEnd();
-    if (rc || rc2)
-      return xf::set_error(XF_EHIP, "xf_group_alltoallv: %s",
-                           g->rccl.GetErrorString(rc ? rc : rc2));
-    return XF_OK;
+    return alltoallv_rccl(g, sb, so, rb, ro, s);
   }
   // ---- host transport: through rank 0
   const void *hsend = send;

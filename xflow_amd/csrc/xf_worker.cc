@@ -69,7 +69,7 @@ int Worker::create_tables() {
   }
   if (w > 1) {
     XF_TRY(xf_group_create(&group_, rank_given_ ? rank : -1, w, nullptr, 0,
-                           transport_host ? XF_TRANSPORT_HOST : XF_TRANSPORT_RCCL, -2));
+                           transport, -2));
     int r = 0;
     XF_TRY(xf_group_info(group_, &r, &w, nullptr));
     rank = r;  // ps::MyRank(): selects <prefix>-%05d (lr_worker.cc:208-210)
@@ -418,10 +418,11 @@ int Worker::set_param(const char *name, const char *value) {
     rank_given_ = true;
   } else if (n == "world") world = atoi(value);
   else if (n == "transport") {
-    if (!strcmp(value, "rccl")) transport_host = false;
-    else if (!strcmp(value, "host")) transport_host = true;
+    if (!strcmp(value, "rccl")) transport = XF_TRANSPORT_RCCL;
+    else if (!strcmp(value, "host")) transport = XF_TRANSPORT_HOST;
+    else if (!strcmp(value, "auto")) transport = XF_TRANSPORT_AUTO;
     else
-      return xf::set_error(XF_EINVAL, "XFSetParam: transport must be rccl or host");
+      return xf::set_error(XF_EINVAL, "XFSetParam: transport must be rccl, host or auto");
   } else if (n == "schedule") {
     if (!strcmp(value, "sequential")) schedule = XF_SCHEDULE_SEQUENTIAL;
     else if (!strcmp(value, "stale1")) schedule = XF_SCHEDULE_STALE1;

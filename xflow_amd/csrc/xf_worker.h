@@ -35,7 +35,7 @@ class Worker {
   // reference constants, now parameters
   int rank = 0;          // ps::MyRank(): given (rank=), from the environment, or handed out
   int world = 0;         // workers == GPUs; 0: WORLD_SIZE / XF_WORLD / DMLC_NUM_WORKER, else 1
-  bool transport_host = false;           // tests: the exchange through the bootstrap sockets
+  int transport = 0;                     // XF_TRANSPORT_*: RCCL; host = through the bootstrap sockets (tests)
   int schedule = XF_SCHEDULE_SEQUENTIAL; // order of Push(t) and Pull(t+1) when world > 1
   int core_num = 1;      // slices per block; 1 = the deterministic reference schedule
   int block_size = 2;    // MiB, lr_worker.h:68
