@@ -62,6 +62,10 @@ def parse_args():
                          "several ranks can share one GPU (a functional check, not a benchmark)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N-GPU code path (collectives included) also at N=1")
+    ap.add_argument("--general-path", action="store_true",
+                    help="with --force-sharded at N=1: run the N>1 code path (owner gather, "
+                         "self all-to-all-v, index-mode kernels, merged owner update) instead of "
+                         "the fused step, to time its stages on one GPU")
     ap.add_argument("--exp-knob", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
@@ -121,6 +125,9 @@ def bytes_model(model, k, R, NNZ, U, opt, fused=False, fused_fm=False):
         # w) record per key, the forward gathers one record per nonzero
         per["gather"] = U * (4 + 8 * k + 4 + 32)
         per["forward"] = NNZ * (4 + 32) + R * 12 + 4
+        # the gradient kernel IS gradient + both Pushes: SURVEY 8(d)'s figure for them, grad write
+        # U x 4(1+k) + update U x (1+k) x (4 g + state read + state write)
+        per["gradient"] = U * (1 + k) * (4 + 4 + state)
     if model == "lr":
         # the sharded LR path pulls with the fused resolve+gather kernel (xf_table_pull_dev)
         per["resolve"] = U * (8 + 8 + 4 + 4 + 4)
@@ -444,6 +451,8 @@ def main():
     torch.cuda.set_device(local_rank)
     capi.require_gpu()
     sharded = world > 1 or args.force_sharded
+    if args.general_path:
+        os.environ["XF_SHARDED_GENERAL"] = "1"
     dist = group = None
     exchange = "none (single shard)"
     if sharded and args.driver == "native":
@@ -603,10 +612,12 @@ def main():
             group.close()
         return
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
-    fused = args.model == "lr" and world == 1 and not args.force_sharded
+    # the C++ sharded trainer takes the fused single-shard step at world 1
+    one_shard = world == 1 and not (args.force_sharded and
+                                    (args.general_path or args.driver == "python"))
+    fused = args.model == "lr" and one_shard
     per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused,
-                                    fused_fm=(args.model == "fm" and world == 1 and
-                                              not args.force_sharded))
+                                    fused_fm=(args.model == "fm" and one_shard))
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
     achieved = per[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
@@ -625,7 +636,8 @@ def main():
     dom_note = {"forward": " (+ k_lr_finalize_cells)", "gradient": " (gradient+Push)"}.get(
         dom, "") if fused else ""
     impl = impl_bytes_cells(R, NNZ, U, args.optimizer, compiled[0].cells_info(),
-                            args.keys_per_gpu) if fused else {}
+                            args.keys_per_gpu) \
+        if fused and hasattr(compiled[0], "cells_info") else {}
     out = {
         "metric": "examples/sec", "value": R * world * args.steps / dt, "unit": "examples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -646,7 +658,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
                      "algorithmic_bytes_per_launch": per[dom],
-                     "algorithmic_bytes_source": "SURVEY.md 8(d)" if fused else
+                     "algorithmic_bytes_source": "SURVEY.md 8(d)"
+                     if fused or (args.model == "fm" and one_shard and dom == "gradient") else
                      "this implementation's per-kernel byte model (bench.py: bytes_model)",
                      "avg_launch_ms": avg_ms[dom]},
         "logloss": logloss,
@@ -660,6 +673,12 @@ def main():
                 "implementation_bytes_per_launch": impl.get(k),
                 "traffic": pmc_traffic(names.get(k, k), workload) if fused else None}
             for k in avg_ms if k in per and avg_ms[k] > 0 and per[k] > 0},
+        # SURVEY 8(d)'s forward figure against everything that runs before the gradient
+        "forward_path_survey_8d": (lambda by, ms: {
+            "bytes": by, "ms": ms, "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})(
+            NNZ * (12 + (4 * args.k if args.model == "fm" else 0)) + 8 * R,
+            sum(avg_ms.get(k, 0.0) for k in ("resolve", "gather", "a2a_weights", "forward"))),
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }

@@ -201,3 +201,38 @@ def test_sharded_checkpoint_reshards_on_load(tmp_path):
             same(np.concatenate([p[nm + f] for p in parts])[order].reshape(ref.shape), ref)
         for got, ref in zip(t.export(), (ks, ws, ns, zs)):
             same(got, ref)
+
+
+def test_training_after_a_model_load_grows_the_table(tmp_path):
+    """A loaded model counts towards the table's load: train on unseen keys right after a load
+    that left the table about half full (the host-side bound on the key count has to start from
+    the loaded size, or the exact check comes too late and the insert fails with XF_EFULL)."""
+    rng = np.random.default_rng(5)
+
+    def batch(keys, rows=64, per_row=40):
+        ks = rng.choice(keys, size=rows * per_row).astype(np.uint64)
+        rp = np.arange(rows + 1, dtype=np.uint64) * per_row
+        return rp, ks, rng.integers(0, 2, rows).astype(np.int32)
+
+    pool = rng.choice(1 << 62, size=6000, replace=False).astype(np.uint64)
+    first, later = pool[:2000], pool[2000:]
+    a = capi.Sharded(None, model="fm", optimizer="ftrl", k=4, capacity=4096, seed=7)
+    ba = a.compile(*batch(first, rows=200))
+    a.step(ba)
+    a.check()
+    n_first = len(a.w.export()[0])
+    assert 1800 <= n_first <= 2001                       # about half of 4096 slots
+    a.save(str(tmp_path / "m"))
+    b = capi.Sharded(None, model="fm", optimizer="ftrl", k=4, capacity=4096, seed=7)
+    b.load(str(tmp_path / "m"))
+    seen = set()
+    alive = []
+    for i in range(3):                                   # ~1300 unseen keys per minibatch
+        rp, ks, lb = batch(later[i * 1300:(i + 1) * 1300])
+        seen.update(ks.tolist())
+        mb = b.compile(rp, ks, lb)
+        alive.append(mb)
+        b.step(mb)
+        b.check()                                        # raises on XF_EFULL
+    keys = set(b.w.export()[0].tolist())
+    assert seen <= keys and len(keys) >= n_first + len(seen)

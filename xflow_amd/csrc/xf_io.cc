@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <new>
 #include <utility>
 #include <string>
@@ -598,10 +599,23 @@ extern "C" int xf_reader_next_into(xf_reader *r, xf_block *blk, size_t *rows_out
   return XF_OK;
 }
 
+static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
+                       const uint64_t **keys, const int32_t **fgid, const int32_t **labels);
+
+// no exception crosses the C boundary: the block arrays are (pinned) host allocations
 extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
                               const uint64_t **rowptr, const uint64_t **keys,
                               const int32_t **fgid, const int32_t **labels) {
   XF_REQUIRE(r && rows_out, "xf_reader_next: null argument");
+  try {
+    return reader_next(r, rows_out, nnz_out, rowptr, keys, fgid, labels);
+  } catch (const std::exception &e) {
+    return xf::set_error(XF_EIO, "xf_reader_next: %s (out of host memory for a block?)", e.what());
+  }
+}
+
+static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
+                       const uint64_t **keys, const int32_t **fgid, const int32_t **labels) {
   if (r->cfp) {
     XF_TRY(next_from_cache(r, rows_out, nnz_out));
     if (rowptr) *rowptr = r->rowptr.data();

@@ -408,20 +408,25 @@ __global__ void __launch_bounds__(kBlock)
 k_fm_heavy_finish(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
                   uint32_t H, const double *__restrict__ partial, uint32_t R, int k,
                   float *__restrict__ gw, float *__restrict__ gv) {
-  // one wavefront per heavy key (see k_lr_heavy_finish), one butterfly per factor
-  const uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-  if (h >= H) return;  // wave-uniform
+  // one workgroup per heavy key; a thread is (slice of the key's chunks, column), the columns
+  // being the k factors and the loss sum: partial[chunk][column] is read coalesced, nothing is
+  // shuffled (one wavefront per key with a butterfly per factor took 281 us at k = 64 for the
+  // 2e4 heavy keys of a Zipf minibatch, most of them one chunk long)
+  __shared__ double red[kBlock];
+  const uint32_t h = blockIdx.x;
+  const uint32_t ncol = (uint32_t)k + 1u, nsl = kBlock / ncol;  // k <= XF_HEAVY_KMAX: nsl >= 3
+  const uint32_t col = threadIdx.x % ncol, sl = threadIdx.x / ncol;
   const uint32_t c0 = hch[h], c1 = hch[h + 1], u = heavy[h];
-  for (uint32_t kk = 0; kk <= (uint32_t)k; ++kk) {
-    double acc = 0.0;
-    for (uint32_t c = c0 + lane; c < c1; c += 64) acc += partial[(size_t)c * (k + 1) + kk];
-    acc = group_sum<64>(acc);
-    if (lane == 0) {
-      if (kk < (uint32_t)k) gv[(size_t)u * k + kk] = (float)((double)(float)acc / (1.0 * R));
-      else
-        gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
-    }
-  }
+  double acc = 0.0;
+  if (sl < nsl)
+    for (uint32_t c = c0 + sl; c < c1; c += nsl) acc += partial[(size_t)c * ncol + col];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl != 0) return;
+  for (uint32_t q = 1; q < nsl; ++q) acc += red[q * ncol + col];
+  if (col < (uint32_t)k) gv[(size_t)u * k + col] = (float)((double)(float)acc / (1.0 * R));
+  else
+    gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
 }
 
 // the optimizer step for a listed subset of keys (the heavy ones)
@@ -670,10 +675,14 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
     }
     __syncthreads();
     const uint32_t nel = nk * (uint32_t)k;
-    constexpr int kUn = 2;  // independent (key,factor) items in flight per lane
+    // (key,factor) items in flight per lane.  Everything an item reads from HBM — its factor,
+    // its state row, the w row of the factor-0 lanes — is requested before the first
+    // occurrence loop: with the state loads behind each item's loop a lane sat through three
+    // HBM latencies per two items (k = 16, SGD: 508 us for 1.7 TB/s of state traffic).
+    constexpr int kUn = 4;
     for (uint32_t el0 = tid; el0 < nel; el0 += kBlock * kUn) {
       uint32_t kq[kUn], kk[kUn];
-      float v[kUn];
+      float v[kUn], vn[kUn], vz[kUn];
       size_t to[kUn];
       bool on[kUn];
 #pragma unroll
@@ -688,22 +697,25 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         v[i] = on[i] ? vu[(size_t)(ua + kq[i]) * k + kk[i]] : 0.0f;
         to[i] = (UPDATE && on[i]) ? (size_t)rows_v[ua + kq[i]] * k + kk[i] : 0;
       }
+      if (UPDATE && OPT == XF_OPT_FTRL) {
+#pragma unroll
+        for (int i = 0; i < kUn; ++i) {
+          vn[i] = vz[i] = 0.0f;
+          if (on[i]) xf::load_nz(TV, to[i], vn[i], vz[i]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < kUn; ++i) {
         if (!on[i]) continue;
         const size_t o = (size_t)(ua + kq[i]) * k + kk[i];
-        double accw = 0.0, accv = 0.0;
-        for (uint32_t j = sp[kq[i]]; j < sp[kq[i] + 1]; ++j) {
-          const float l = lv[j];
-          accw += (double)l;
-          accv += (double)(l * (sv[j] - v[i]));
-        }
+        double accv = 0.0;
+        for (uint32_t j = sp[kq[i]]; j < sp[kq[i] + 1]; ++j)
+          accv += (double)(lv[j] * (sv[j] - v[i]));
         const float g = div_by_rows((float)accv, R);
         if (gv) gv[o] = g;
         if (UPDATE) {
           if (OPT == XF_OPT_FTRL) {
-            float w = v[i], nn, z;
-            xf::load_nz(TV, to[i], nn, z);
+            float w = v[i], nn = vn[i], z = vz[i];
             xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g, w, nn, z);
             TV.w[to[i]] = w;
             xf::store_nz(TV, to[i], nn, z);
@@ -711,21 +723,26 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
             TV.w[to[i]] = xf::sgd_step(TV.lr, g, v[i]);
           }
         }
-        if (kk[i] == 0) {
-          const float g1 = div_by_rows((float)(accw * (double)k), R);
-          gw[ua + kq[i]] = g1;
-          if (UPDATE) {
-            const uint32_t rw = rows_w[ua + kq[i]];
-            if (OPT == XF_OPT_FTRL) {
-              float w = wu[ua + kq[i]], nn, z;
-      xf::load_nz(TW, rw, nn, z);
-              xf::ftrl_step(TW.alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
-              TW.w[rw] = w;
-              xf::store_nz(TW, rw, nn, z);
-            } else {
-              TW.w[rw] = xf::sgd_step(TW.lr, g1, wu[ua + kq[i]]);
-            }
-          }
+      }
+    }
+    // the keys' w coordinate (gw = k x the LR gradient, fm_worker.cc:140), one lane per key: as
+    // the factor-0 lanes' job inside the loop above it was four memory instructions per item
+    // with one lane in k active (94 of 590 us at k = 16)
+    for (uint32_t q = tid; q < nk; q += kBlock) {
+      double accw = 0.0;
+      for (uint32_t j = sp[q]; j < sp[q + 1]; ++j) accw += (double)lv[j];
+      const float g1 = div_by_rows((float)(accw * (double)k), R);
+      gw[ua + q] = g1;
+      if (UPDATE) {
+        const uint32_t rw = rows_w[ua + q];
+        if (OPT == XF_OPT_FTRL) {
+          float w = wu[ua + q], nn, z;
+          xf::load_nz(TW, rw, nn, z);
+          xf::ftrl_step(TW.alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
+          TW.w[rw] = w;
+          xf::store_nz(TW, rw, nn, z);
+        } else {
+          TW.w[rw] = xf::sgd_step(TW.lr, g1, wu[ua + q]);
         }
       }
     }
@@ -983,7 +1000,7 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
                          d_vu, k, b->heavy_scratch);
-      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(waves_grid(b->H)), dim3(kBlock), 0,
+      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(b->H), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
     } else {
@@ -1040,7 +1057,7 @@ static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
                          d_vu, k, b->heavy_scratch);
-      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(waves_grid(b->H)), dim3(kBlock), 0,
+      hipLaunchKernelGGL(k_fm_heavy_finish, dim3(b->H), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
     } else {

@@ -29,6 +29,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -133,6 +134,8 @@ struct xf_sbatch {
 struct xf_sharded {
   xf_group *g = nullptr;
   int rank = 0, world = 1;
+  bool fused = true;  // world 1: the fused single-shard step (XF_SHARDED_GENERAL=1 runs the
+                      // exchange path with its self-copies instead: a measuring aid)
   xf_sharded_config cfg{};
   xf_table *tw = nullptr, *tv = nullptr;
   xf_workspace *ws = nullptr;  // world 1: the fused step's scratch
@@ -312,6 +315,10 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
   st->g = g;
   st->cfg = *cfg;
   if (g) XF_TRY(xf_group_info(g, &st->rank, &st->world, nullptr));
+  {
+    const char *e = getenv("XF_SHARDED_GENERAL");
+    st->fused = st->world == 1 && !(g && e && *e == '1');
+  }
   struct Guard {
     xf_sharded *s;
     ~Guard() {
@@ -416,7 +423,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
   } guard{b};
   hipStream_t s = st->main;
   b->owner = st;
-  if (st->world == 1) {  // one shard: the table is local
+  if (st->fused) {  // one shard: the table is local
     if (st->cfg.host_key_build)
       XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
     else if (st->cfg.model == 0)
@@ -507,7 +514,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
 // One LRWorker::update / FMWorker::update of every rank (COLLECTIVE), asynchronous.
 extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
   XF_REQUIRE(st && b, "xf_sharded_step: null argument");
-  if (st->world == 1) {
+  if (st->fused) {
     if (st->cfg.model == 0) return xf_lr_step(st->tw, b->b, st->ws, st->main);
     return xf_fm_step(st->tw, st->tv, b->b, st->ws, st->main);
   }
@@ -555,7 +562,7 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
 // apply the outstanding Push of the stale1 schedule (end of training, before export / predict)
 extern "C" int xf_sharded_flush(xf_sharded *st) {
   XF_REQUIRE(st, "xf_sharded_flush: null trainer");
-  if (st->world > 1) XF_TRY(flush_pending(st));
+  if (!st->fused) XF_TRY(flush_pending(st));
   XF_HIP(hipStreamSynchronize(st->main));
   XF_HIP(hipStreamSynchronize(st->side));
   return XF_OK;
@@ -566,7 +573,7 @@ extern "C" int xf_sharded_flush(xf_sharded *st) {
 // insert unseen keys, as in the reference (ftrl.h:56).
 extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out) {
   XF_REQUIRE(st && b && (b->R == 0 || pctr_out), "xf_sharded_predict: null argument");
-  if (st->world == 1) {
+  if (st->fused) {
     XF_HIP(hipStreamSynchronize(st->main));
     if (st->cfg.model == 0) return xf_lr_predict(st->tw, b->b, st->ws, pctr_out);
     return xf_fm_predict(st->tw, st->tv, b->b, st->ws, pctr_out);
@@ -606,7 +613,7 @@ extern "C" int xf_sharded_check(xf_sharded *st) {
 // gradients exchange, owner update
 extern "C" int xf_sharded_profile(xf_sharded *st, int enable) {
   XF_REQUIRE(st, "xf_sharded_profile: null trainer");
-  if (st->world == 1) return xf_workspace_profile(st->ws, enable);
+  if (st->fused) return xf_workspace_profile(st->ws, enable);
   if (enable && !st->pev[0])
     for (auto &e : st->pev) XF_HIP(hipEventCreate(&e));
   if (!enable) XF_TRY(collect_profile(st));
@@ -621,7 +628,7 @@ extern "C" int xf_sharded_profile(xf_sharded *st, int enable) {
 
 extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *steps) {
   XF_REQUIRE(st && ms_sum && steps, "xf_sharded_profile_read: null argument");
-  if (st->world == 1) {
+  if (st->fused) {
     double m5[5];
     XF_TRY(xf_workspace_profile_read(st->ws, m5, steps));
     ms_sum[0] = m5[0] + m5[1];
@@ -722,6 +729,11 @@ extern "C" int xf_sharded_load(xf_sharded *st, const char *prefix) {
       rc = xf::model_read(shard_path(prefix, s, saved).c_str(), st->tw, st->tv, st->cfg.k,
                           (uint32_t)st->rank, (uint32_t)st->world);
     }
+  }
+  if (rc == XF_OK) {  // the host-side bound on the key count starts from what was loaded
+    uint64_t n = 0;
+    rc = xf_table_size(st->tw, &n);
+    st->seen_upper = n;
   }
   int32_t ok = rc == XF_OK ? 1 : 0;
   if (st->g && st->world > 1) {
