@@ -418,6 +418,38 @@ def test_fm_step_state(opt, k):
                 assert d <= (8e-4 if k >= 64 else 1.5e-4 if k >= 32 else 4e-5), (k, d)
 
 
+@pytest.mark.parametrize("opt,k", [(capi.OPT_FTRL, 8), (capi.OPT_SGD, 10)])
+def test_fm_replayed_minibatches_keep_their_rows_across_growth_and_defrag(opt, k):
+    """an FM minibatch resolves its keys once per row numbering of the two tables: replay three
+    minibatches for three epochs — the tables are re-housed after epoch 0 (xf_table_reserve: rows
+    keep their numbers) and defragmented after epoch 1 (every row moves: the cached rows must be
+    dropped) — bit-exact throughout"""
+    rng = np.random.RandomState(31 + k)
+    init = (capi.INIT_CONST, 0.001) if opt == capi.OPT_SGD else (capi.INIT_HASHNORM, 0.0)
+    tw = capi.Table(opt, 1, capacity=1 << 14)
+    tv = capi.Table(opt, k, init[0], init[1], seed=5, capacity=1 << 14)
+    exact = (O.Store(opt, 1), O.Store(opt, k, init[0], init[1], 5))
+    ws = capi.Workspace()
+    data = [synth(rng, 300, 25, 5000, None, True) for _ in range(3)]
+    gpu = [capi.Batch(*d) for d in data]
+    cpu = [O.Batch(*d) for d in data]
+    for epoch in range(3):
+        for b, ob in zip(gpu, cpu):
+            with O.sum_mode(1):
+                O.fm_update(exact[0], exact[1], ob)
+            capi.fm_step(tw, tv, b, ws)
+        if epoch == 0:
+            tw.reserve(1 << 16)
+            tv.reserve(1 << 15)
+        if epoch == 1:
+            tw.defrag()
+            tv.defrag()
+        for tt, se in ((tw, exact[0]), (tv, exact[1])):
+            tt.check()
+            for a, e in zip(tt.export(), se.export()):
+                same(a, e)
+
+
 def test_predict_matches_oracle_and_inserts_keys():
     rng = np.random.RandomState(9)
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 15)

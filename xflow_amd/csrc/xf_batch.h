@@ -27,6 +27,10 @@ struct xf_batch {
   // numbering (rebuilt when another table or another epoch of it comes along)
   xf_cells *cells = nullptr;
   uint32_t *d_rows_u = nullptr;  // state row of each unique key [U] (batches with a key list)
+  // FM: the unique keys' rows in the w and the v table, valid for one (uid, epoch) of each —
+  // the Pulls of a replayed minibatch resolve nothing
+  uint32_t *d_fm_rows[2] = {nullptr, nullptr};
+  uint64_t fm_uid[2] = {0, 0}, fm_epoch[2] = {0, 0};
   // "local" batches (xf_batch_compile_local_*): no key list at all — the raw keys were resolved
   // straight to state rows.  The raw arrays are kept (device) when the cells must be
   // rebuildable after the table renumbers its rows.

@@ -33,6 +33,8 @@
 namespace xf {
 const TableDev &table_dev(const xf_table *t);
 int table_dim(const xf_table *t);
+uint64_t table_uid(const xf_table *t);
+uint64_t table_epoch(const xf_table *t);
 int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s);
 int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
                          hipStream_t s);
@@ -1293,10 +1295,27 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   const xf_dev_batch &v = b->view;
   ws->lastU = b->U;
   ws->lastR = b->R;
-  // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself
+  // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself — once per
+  // (minibatch, row numbering of the table): rows only move in a defrag, so a replayed
+  // minibatch finds its keys' rows where it left them and only gathers w
   XF_BEGIN();
-  XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, stream));
-  XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, stream));
+  xf_table *tabs[2] = {w, vt};
+  for (int i = 0; i < 2 && v.U; ++i) {
+    const uint64_t uid = xf::table_uid(tabs[i]), ep = xf::table_epoch(tabs[i]);
+    const bool fresh = !b->d_fm_rows[i] || b->fm_uid[i] != uid || b->fm_epoch[i] != ep;
+    if (!b->d_fm_rows[i]) XF_HIP(hipMalloc((void **)&b->d_fm_rows[i], (size_t)v.U * 4));
+    if (fresh) {
+      if (i == 0) XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, b->d_fm_rows[0], ws->wu, stream));
+      else
+        XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, b->d_fm_rows[1], stream));
+      b->fm_uid[i] = uid;
+      b->fm_epoch[i] = ep;
+    } else if (i == 0) {
+      XF_TRY(xf::gather_f32(xf::table_dev(w).w, b->d_fm_rows[0], v.U, ws->wu, S(stream)));
+    }
+  }
+  const uint32_t *rows_w = v.U ? b->d_fm_rows[0] : ws->slots;
+  const uint32_t *rows_v = v.U ? b->d_fm_rows[1] : ws->slots2;
   XF_END(kEvResolve);
   const int dim4 = k / 4;
   const bool scalars = k % 4 == 0 && dim4 <= 16 && (dim4 & (dim4 - 1)) == 0 && v.U && v.R;
@@ -1305,7 +1324,7 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
     const size_t tot = (size_t)v.U * dim4;
     const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
 #define XF_FM_GS(D)                                                                        \
-  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, S(stream), tv, ws->slots2, ws->wu, \
+  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, S(stream), tv, rows_v, ws->wu, \
                      (size_t)v.U, (float4 *)ws->vu, (FmKey *)ws->ks)
     switch (dim4) {
       case 1: XF_FM_GS(1); break;
@@ -1322,13 +1341,13 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
                        v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
     XF_HIP(hipGetLastError());
   } else {
-    XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, stream));
+    XF_TRY(xf_table_gather_dev(vt, rows_v, v.U, ws->vu, stream));
     XF_END(kEvGather);
     XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));
   }
   XF_END(kEvForward);
   // gradient (:238) and the two Pushes (:241-242) in one pass: both tables are on this GPU
-  XF_TRY(fm_grad_update(w, vt, &v, ws->slots, ws->slots2, ws->wu, ws->vu, ws->vsum, ws->loss,
+  XF_TRY(fm_grad_update(w, vt, &v, rows_w, rows_v, ws->wu, ws->vu, ws->vsum, ws->loss,
                         ws->g, ws->gv, false, stream));
   XF_END(kEvGrad);
   if (ws->profiling) ws->ev_pending = true;
