@@ -10,10 +10,10 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 while [ $# -gt 1 ]; do
   name=$1; defs=$2; shift 2
   d=/tmp/xfv_$name; mkdir -p $d
-  for f in xf_table.hip xf_model.hip xf_calib.hip xf_batch_dev.hip xf_cells.hip; do
+  for f in xf_table.hip xf_model.hip xf_calib.hip xf_batch_dev.hip xf_cells.hip xf_sharded.hip; do
     /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c $C/$f -o $d/$f.o &
   done
-  for f in xf_io.cc xf_batch.cc xf_metrics.cc xf_worker.cc; do
+  for f in xf_io.cc xf_batch.cc xf_metrics.cc xf_worker.cc xf_group.cc xf_modelfile.cc; do
     /opt/rocm/bin/hipcc $FLAGS $defs -c $C/$f -o $d/$f.o &
   done
   wait

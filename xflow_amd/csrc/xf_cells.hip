@@ -42,8 +42,14 @@ using xf::kRowMask;
 using xf::kTagShift;
 
 constexpr int kBlock = 256;
-constexpr int kFwdBlock = 1024;  // one forward workgroup per CU (its LDS holds a row window)
-constexpr uint32_t kFwdGroups = 256;
+#ifndef XF_FWD_BLOCK
+#define XF_FWD_BLOCK 1024
+#endif
+#ifndef XF_FWD_GROUPS
+#define XF_FWD_GROUPS 256
+#endif
+constexpr int kFwdBlock = XF_FWD_BLOCK;  // one forward workgroup per CU (its LDS holds a row window)
+constexpr uint32_t kFwdGroups = XF_FWD_GROUPS;  // workgroup slots of the chip at that size
 
 inline int grid_for(size_t n, int block = kBlock) {
   size_t g = (n + block - 1) / block;
@@ -217,7 +223,10 @@ k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict_
   __shared__ double wx[kWinMax];
   __shared__ uint32_t next_blk;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t v = blockIdx.x / G, g = blockIdx.x - v * G;
+  // block b runs on XCD b % 8 (observed placement; a different one only costs speed): group g
+  // of window v is block ((g / 8) * nwin + v) * 8 + g % 8
+  const uint32_t nwin = gridDim.x / G;
+  const uint32_t slot = blockIdx.x >> 3, v = slot % nwin, g = (slot / nwin) * 8 + (blockIdx.x & 7u);
   for (uint32_t r = tid; r < W; r += kFwdBlock) wx[r] = 0.0;
   const uint32_t c0 = v * nchunk;
   const uint32_t wb = cellptr[c0], we = cellptr[c0 + nchunk];
@@ -252,7 +261,7 @@ k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict_
     fwd_process(B, bb, c0, nchunk, lane, cellptr, w, wx);
   }
   __syncthreads();
-  double *out = partial + (size_t)blockIdx.x * W;
+  double *out = partial + ((size_t)v * G + g) * W;
   for (uint32_t r = tid; r < W; r += kFwdBlock) out[r] = wx[r];
 }
 
@@ -476,7 +485,10 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   }
   c->ncell = (uint32_t)ncell64;
   c->nblk = (NNZ + kBlk - 1) / kBlk;
-  c->G = std::max<uint32_t>(1, kFwdGroups / c->nwin);
+  // Groups per window: a multiple of 8 with at most 32 workgroups per XCD (one per CU: the row
+  // window fills the LDS).  Group g of EVERY window runs on XCD g % 8 (k_lr_fwd_cells), so the
+  // windows read a weight range through one L2: once from HBM instead of once per window.
+  c->G = c->nwin <= 32 ? (kFwdGroups / 8 / c->nwin) * 8 : 8;
   struct Guard {
     xf_cells *c;
     ~Guard() {
