@@ -1112,12 +1112,25 @@ struct xf_workspace {
   uint32_t lastU = 0, lastR = 0;
   // optional per-kernel HIP-event timing (same stream, inside the caller's timed region)
   bool profiling = false;
-  hipEvent_t ev[kEvCount + 1] = {};
+  // A ring of event sets: a step records into the oldest set, whose own step finished long
+  // ago — reading it back never makes the host wait for the step just launched (one set meant a
+  // hipEventSynchronize on the previous step before every launch: the host could not run
+  // ahead and every step paid its launch latencies, ~10 us of a 145 us step).
+  static constexpr int kEvSets = 8;
+  struct EvSet {
+    hipEvent_t ev[kEvCount + 1] = {};
+    bool pending = false;
+    int nseg = 0;                 // segments recorded by the step
+    int seg_slot[kEvCount] = {};  // segment k is accounted to ms_sum[seg_slot[k]]
+  } sets[kEvSets];
+  int cur = 0;  // the set the running step records into
+  // every kProfileEvery-th step is the one that records (an event is a barrier packet of its
+  // own on the stream: three per step cost ~2 us of a 136 us step)
+  static constexpr long kProfileEvery = 4;
+  long step_no = 0;
+  bool rec = false;  // this step records
   double ms_sum[kEvCount] = {};
   long steps_timed = 0;
-  bool ev_pending = false;
-  int nseg = 0;                 // segments recorded by the pending step
-  int seg_slot[kEvCount] = {};  // segment k is accounted to ms_sum[seg_slot[k]]
   int nmark = 0;
 };
 
@@ -1166,35 +1179,47 @@ extern "C" int xf_workspace_destroy(xf_workspace *ws) {
                 ws->loss,  ws->pctr,   ws->vsum, ws->ks, ws->partial, ws->gdense};
   for (void *p : ps)
     if (p) hipFree(p);
-  for (auto &e : ws->ev)
-    if (e) hipEventDestroy(e);
+  for (auto &e : ws->sets)
+    for (auto &ev : e.ev)
+      if (ev) hipEventDestroy(ev);
   delete ws;
   return XF_OK;
 }
 
-static int ws_collect(xf_workspace *ws) {  // fold the pending events into the sums
-  if (!ws->ev_pending) return XF_OK;
-  XF_HIP(hipEventSynchronize(ws->ev[ws->nseg]));
-  for (int i = 0; i < ws->nseg; ++i) {
+static int ws_collect_set(xf_workspace *ws, xf_workspace::EvSet &e) {  // fold into the sums
+  if (!e.pending) return XF_OK;
+  XF_HIP(hipEventSynchronize(e.ev[e.nseg]));
+  for (int i = 0; i < e.nseg; ++i) {
     float ms = 0.f;
-    XF_HIP(hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]));
-    ws->ms_sum[ws->seg_slot[i]] += ms;
+    XF_HIP(hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]));
+    ws->ms_sum[e.seg_slot[i]] += ms;
   }
   ++ws->steps_timed;
-  ws->ev_pending = false;
+  e.pending = false;
   return XF_OK;
+}
+static int ws_collect(xf_workspace *ws) {  // every set still pending (end of a timed run)
+  for (auto &e : ws->sets) XF_TRY(ws_collect_set(ws, e));
+  return XF_OK;
+}
+// a step is about to record: take the oldest set
+static int ws_next_set(xf_workspace *ws) {
+  ws->cur = (ws->cur + 1) % xf_workspace::kEvSets;
+  return ws_collect_set(ws, ws->sets[ws->cur]);
 }
 
 extern "C" int xf_workspace_profile(xf_workspace *ws, int enable) {
   XF_REQUIRE(ws, "xf_workspace_profile: null workspace");
-  if (enable && !ws->ev[0])
-    for (auto &e : ws->ev) XF_HIP(hipEventCreate(&e));
+  if (enable && !ws->sets[0].ev[0])
+    for (auto &e : ws->sets)
+      for (auto &ev : e.ev) XF_HIP(hipEventCreate(&ev));
   if (!enable) XF_TRY(ws_collect(ws));
   ws->profiling = enable != 0;
   if (enable) {
     for (auto &m : ws->ms_sum) m = 0.0;
     ws->steps_timed = 0;
-    ws->ev_pending = false;
+    for (auto &e : ws->sets) e.pending = false;
+    ws->step_no = 0;
   }
   return XF_OK;
 }
@@ -1212,18 +1237,18 @@ extern "C" int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long 
 // accounting it to ms_sum[slot], and opens the next one.  One event per boundary.
 #define XF_BEGIN()                                                      \
   do {                                                                  \
-    if (ws->profiling) {                                                \
+    if (ws->rec) {                                                      \
       ws->nmark = 0;                                                    \
-      XF_HIP(hipEventRecord(ws->ev[0], S(stream)));                     \
+      XF_HIP(hipEventRecord(ws->sets[ws->cur].ev[0], S(stream)));       \
     }                                                                   \
   } while (0)
 #define XF_END(slot)                                                    \
   do {                                                                  \
-    if (ws->profiling) {                                                \
-      ws->seg_slot[ws->nmark] = (slot);                                 \
+    if (ws->rec) {                                                      \
+      ws->sets[ws->cur].seg_slot[ws->nmark] = (slot);                   \
       ++ws->nmark;                                                      \
-      XF_HIP(hipEventRecord(ws->ev[ws->nmark], S(stream)));             \
-      ws->nseg = ws->nmark;                                             \
+      XF_HIP(hipEventRecord(ws->sets[ws->cur].ev[ws->nmark], S(stream))); \
+      ws->sets[ws->cur].nseg = ws->nmark;                               \
     }                                                                   \
   } while (0)
 
@@ -1266,7 +1291,8 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   const bool cap = ws->capture && !b->local && b->d_rows_u;
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
   XF_TRY(ws_reserve_cells(ws, c, cap));
-  if (ws->profiling) XF_TRY(ws_collect(ws));
+  ws->rec = ws->profiling && ws->step_no++ % xf_workspace::kProfileEvery == 0;
+  if (ws->rec) XF_TRY(ws_next_set(ws));
   ws->lastU = cap ? b->U : 0;
   ws->lastR = b->R;
   const xf::TableDev &T = xf::table_dev(w);
@@ -1279,7 +1305,7 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   XF_TRY(xf::cells_lr_grad_update(c, w, ws->loss, cap ? ws->gdense : nullptr, S(stream)));
   XF_END(kEvGrad);
   if (cap) XF_TRY(xf::gather_f32(ws->gdense, b->d_rows_u, b->U, ws->g, S(stream)));
-  if (ws->profiling) ws->ev_pending = true;
+  if (ws->rec) ws->sets[ws->cur].pending = true;
   return XF_OK;
 }
 
@@ -1291,7 +1317,8 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, stream));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
-  if (ws->profiling) XF_TRY(ws_collect(ws));
+  ws->rec = ws->profiling && ws->step_no++ % xf_workspace::kProfileEvery == 0;
+  if (ws->rec) XF_TRY(ws_next_set(ws));
   const xf_dev_batch &v = b->view;
   ws->lastU = b->U;
   ws->lastR = b->R;
@@ -1350,7 +1377,7 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   XF_TRY(fm_grad_update(w, vt, &v, rows_w, rows_v, ws->wu, ws->vu, ws->vsum, ws->loss,
                         ws->g, ws->gv, false, stream));
   XF_END(kEvGrad);
-  if (ws->profiling) ws->ev_pending = true;
+  if (ws->rec) ws->sets[ws->cur].pending = true;
   return XF_OK;
 }
 
