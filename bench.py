@@ -232,7 +232,18 @@ def host_description():
                 break
     except OSError:
         pass
-    return {"nproc": os.cpu_count(), "cpu_model": model}
+    quota = None   # the container's CPU allowance (cgroup v2), in CPUs
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    usable = os.cpu_count() or 1
+    if quota and quota >= 1:
+        usable = min(usable, int(quota))
+    return {"nproc": os.cpu_count(), "cpu_model": model, "cgroup_cpu_quota": quota,
+            "usable_cpus": usable}
 
 
 def cpu_baseline(args, batches):
@@ -275,7 +286,7 @@ def cpu_baseline(args, batches):
                      "build included: %.0f examples/sec" % (nb, args.rows, args.nnz_per_row,
                                                            rows / (t_step + t_build))}
     if args.model == "lr":
-        cores = host["nproc"] or 1
+        cores = host["usable_cpus"]   # nproc, or the cgroup's CPU quota when that is smaller
         mstore = O.Store(O.OPT_FTRL if args.optimizer == "ftrl" else O.OPT_SGD, 1)
         t0 = time.perf_counter()
         mrows = 0

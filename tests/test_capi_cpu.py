@@ -534,3 +534,34 @@ def test_bench_byte_model_matches_survey_8d():
         assert survey == NNZ * (12 + 4 * 16) + 8 * R + state * U * 17
     per, _ = bench.bytes_model("fm", 16, R, NNZ, U, "sgd", fused_fm=True)
     assert per["forward"] == NNZ * 36 + R * 12 + 4        # one 32-byte record per nonzero
+
+
+def test_reader_unusual_tokens_take_the_general_path(tmp_path):
+    """The parser's one-pass route only takes `digits:fid:val`; every other token shape goes
+    through the general route.  Both must give what the oracle (and the real reference parser)
+    give: float / signed / zero-padded / ten-digit fgids, empty fid, empty val, extra colons in
+    the val, an empty token (duplicates the previous one), fids longer than 8 bytes, a fid that
+    ends the file (the 8-byte load of the short-fid hash stops at the buffer's end)."""
+    lines = [
+        "1\t1.5:abc:1 -3:77:1 0007:5:2 1234567890:9:1",
+        "0\t7::1 7:5: 3:a:b:c 12:123456789012345:0.5",
+        "1\t4:44:1  5:55:1 6:6:1",                 # two blanks: an empty token
+        "0.3\t000000001:x:1 999999999:yy:2 1e1:z:3 +2:q:1",
+        "1\t9:7",                                  # filled below: the last token ends the file
+    ]
+    lines[-1] = "1\t31:8:1 2:3:4"
+    txt = "\n".join(lines)                         # no trailing newline: "4" is the last byte
+    p = tmp_path / "odd"
+    p.write_text(txt)
+    for cap in (len(max(lines, key=len)) + 3, 4096):
+        mine = list(capi.read_blocks(str(p), cap))
+        sets = [("oracle", list(O.read_blocks(str(p), cap)))]
+        if O.ref_available():
+            sets.append(("reference", list(O.ref_read_blocks(str(p), cap))))
+        for name, other in sets:
+            assert len(mine) == len(other), (name, cap)
+            for a, b in zip(mine, other):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), (name, cap, x, y)
+    rows = sum(len(b[3]) for b in mine)
+    assert rows == len(lines)

@@ -22,12 +22,18 @@ nnz, K = 200, 10_000_000
 d = tempfile.mkdtemp()
 rng = np.random.RandomState(0)
 t0 = time.time()
-for name, n in (("train-00000", rows), ("test-00000", rows // 10)):
-    fid = rng.randint(0, K, size=(n, nnz))
-    lab = rng.randint(0, 2, size=n)
+CHUNK = 100000   # the text is generated once for this many rows and written out repeatedly
+for name, n in (("train-00000", rows), ("test-00000", min(rows // 10, 40000))):
+    m = min(n, CHUNK)
+    fid = rng.randint(0, K, size=(m, nnz))
+    lab = rng.randint(0, 2, size=m)
+    lines = ["%d\t" % lab[r] + " ".join("%d:%d:1" % (j & 31, v) for j, v in enumerate(fid[r])) + "\n"
+             for r in range(m)]
     with open(os.path.join(d, name), "w") as f:
-        for r in range(n):
-            f.write("%d\t" % lab[r] + " ".join("%d:%d:1" % (j & 31, v) for j, v in enumerate(fid[r])) + "\n")
+        left = n
+        while left > 0:
+            f.write("".join(lines[:min(left, m)]))
+            left -= m
 size_mb = os.path.getsize(os.path.join(d, "train-00000")) / 1e6
 print("generated %d rows (%.0f MB) in %.1f s" % (rows, size_mb, time.time() - t0), flush=True)
 
@@ -51,7 +57,9 @@ def run(epochs, extra):
         steady = float(blk[2][0]) / (per[len(per) // 2] * 1e-3)
     run.steady = steady
     print("epochs=%d %s wall %.2f s train-loop %s ex/s, median block %s ex/s\n%s" % (
-        epochs, extra, wall, eps, steady, out.stderr[-1200:] if os.environ.get("E2E_TRACE") else ""),
+        epochs, extra, wall, eps, steady,
+        out.stderr if os.environ.get("E2E_TRACE") == "2" else
+        out.stderr[-1200:] if os.environ.get("E2E_TRACE") else ""),
         flush=True)
     return eps, wall
 
@@ -63,9 +71,10 @@ text4, _ = run(4, [])
 run(1, ["block_cache=1"])                    # builds the cache
 cache1, w_cache = run(1, ["block_cache=1"])  # uses it
 cache_steady = run.steady
-res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, %.0f MB, 64 MiB "
-               "blocks, LR + FTRL, key space 1e7; examples/sec of the train loop (parse + key "
-               "build + steps), predict excluded" % (rows, nnz, size_mb),
+res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, %.0f MB (a "
+               "%d-row random chunk written out repeatedly), 64 MiB blocks, LR + FTRL, key space "
+               "1e7; examples/sec of the train loop (parse + key build + steps), predict "
+               "excluded" % (rows, nnz, size_mb, min(rows, CHUNK)),
        "host": {"nproc": os.cpu_count()},
        "first_epoch_from_text": text1, "first_epoch_from_block_cache": cache1,
        "median_block_rate_from_text": text_steady, "median_block_rate_from_block_cache": cache_steady,

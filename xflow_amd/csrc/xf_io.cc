@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <exception>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <new>
 #include <utility>
 #include <string>
@@ -26,7 +29,40 @@
 
 namespace xf {
 
-static int g_parse_threads = 64;
+// CPUs this process may use at once: the cgroup's CPU quota when there is one (a container
+// with "16 CPUs" on a 256-thread host shows 256 to hardware_concurrency(); 64 parser threads
+// then burn the period's quota in bursts and the kernel parks EVERY thread of the cgroup, the
+// trainer included, until the next period: 30-60 ms stalls every few blocks)
+static int cpu_allowance() {
+  double quota = 0.0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[32] = "";
+    double period = 0.0;
+    if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+      quota = atof(q) / period;
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // v1
+    double q = 0.0, period = 0.0;
+    if (fscanf(g, "%lf", &q) == 1 && q > 0) {
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(h, "%lf", &period) == 1 && period > 0) quota = q / period;
+        fclose(h);
+      }
+    }
+    fclose(g);
+  }
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (quota >= 1.0 && quota < n) n = (int)quota;
+  return n;
+}
+
+// parser threads: at most 64, and two fewer than the CPU allowance (the trainer thread and the
+// parse-ahead thread's own work keep theirs)
+static int g_parse_threads = [] {
+  const int a = cpu_allowance();
+  return std::max(1, std::min(64, a > 4 ? a - 2 : a));
+}();
 int parse_threads() { return g_parse_threads; }
 void set_parse_threads(int n) { g_parse_threads = n < 1 ? 1 : n; }
 
@@ -168,6 +204,13 @@ struct BlockAlloc {
 };
 template <typename T>
 using BlockVec = std::vector<T, BlockAlloc<T>>;
+// resize with headroom: blocks of one file differ by a few rows, and a block that is one row
+// longer than every block before it would otherwise re-pin a whole array (10-20 ms per 40 MB)
+template <typename T>
+static void block_resize(BlockVec<T> &v, size_t n) {
+  if (n > v.capacity()) v.reserve(n + n / 8 + 64);
+  v.resize(n);
+}
 }  // namespace
 
 // what one parser thread produces for its run of lines
@@ -176,6 +219,72 @@ struct Piece {
   std::vector<int32_t> fgid, labels;
   const char *err = nullptr;
   bool hit_nul = false;
+};
+
+// A team of host threads that lives as long as the reader: run(n, f) calls f(0..n-1) on them
+// and returns when all are done.  (Two rounds of 64 std::thread creations per block — parse,
+// then place — were ~4 ms of a 6.5 ms block.)
+class Team {
+ public:
+  ~Team() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  void run(unsigned n, const std::function<void(unsigned)> &f) {
+    if (n <= 1) {
+      if (n) f(0);
+      return;
+    }
+    while (th_.size() < n - 1) {
+      const unsigned id = (unsigned)th_.size() + 1;
+      th_.emplace_back([this, id] { loop(id); });
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &f;
+      n_ = n;
+      left_ = n - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    f(0);  // the caller is member 0
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(unsigned id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)> *f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
+        if (quit_) return;
+        seen = gen_;
+        if (id < n_) f = job_;
+      }
+      if (!f) continue;
+      (*f)(id);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        --left_;
+      }
+      done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)> *job_ = nullptr;
+  unsigned n_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
 };
 
 struct xf_reader {
@@ -193,6 +302,7 @@ struct xf_reader {
   // per-thread pieces, kept between blocks: fresh 100 MB vectors per block meant page faults
   // and munmap under 64 threads every time
   std::vector<Piece> pieces;
+  Team team;
   // block cache (xf_reader_open_cached): either replaying `cfp`, or teeing into `tfp`
   FILE *cfp = nullptr, *tfp = nullptr;
   const char *cmap = nullptr;  // the cache file, mapped
@@ -353,10 +463,10 @@ static int next_from_cache(xf_reader *r, size_t *rows_out, size_t *nnz_out) {
       return xf::set_error(XF_EIO, "%s: truncated block cache (block %llu of %llu)",
                            r->cache_path.c_str(), (unsigned long long)r->served,
                            (unsigned long long)r->cache_blocks);
-    r->rowptr.resize(R + 1);
-    r->keys.resize(N);
-    r->fgid.resize(N);
-    r->labels.resize(R);
+    block_resize(r->rowptr, R + 1);
+    block_resize(r->keys, N);
+    block_resize(r->fgid, N);
+    block_resize(r->labels, R);
     const char *src = r->cmap + r->cpos + 16;
     struct Part {
       void *dst;
@@ -402,10 +512,10 @@ static int next_from_cache(xf_reader *r, size_t *rows_out, size_t *nnz_out) {
                          (unsigned long long)r->served, (unsigned long long)dims[0],
                          (unsigned long long)dims[1], r->cap);
   if (ok) {
-    r->rowptr.resize(dims[0] + 1);
-    r->keys.resize(dims[1]);
-    r->fgid.resize(dims[1]);
-    r->labels.resize(dims[0]);
+    block_resize(r->rowptr, dims[0] + 1);
+    block_resize(r->keys, dims[1]);
+    block_resize(r->fgid, dims[1]);
+    block_resize(r->labels, dims[0]);
     ok = get(r->cfp, r->rowptr.data(), r->rowptr.size()) && get(r->cfp, r->keys.data(), dims[1]) &&
          get(r->cfp, r->fgid.data(), dims[1]) && get(r->cfp, r->labels.data(), dims[0]);
   }
@@ -473,8 +583,28 @@ inline double field_atof(const char *b, const char *e, bool *ok) {
 }
 
 
-// One contiguous run of whole lines (load_data_from_disk.cc:126-208).
-void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
+// xf_hash_bytes for the parser's short fids: the 1..7 tail bytes come from one 8-byte load and a
+// mask when those 8 bytes are inside the buffer (`safe_end`), instead of a variable-size memcpy
+inline uint64_t hash_fid(const char *ptr, size_t len, const char *safe_end) {
+  if (len >= 8 || ptr + 8 > safe_end) return xf_hash_bytes(ptr, len);
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  uint64_t h = 0xc70f6907ull ^ (len * m);
+  if (len) {
+    uint64_t w;
+    memcpy(&w, ptr, 8);
+    w &= ~0ull >> (64 - 8 * len);
+    h = (h ^ w) * m;
+  }
+  h ^= h >> 47;
+  h *= m;
+  h ^= h >> 47;
+  return h;
+}
+
+// One contiguous run of whole lines (load_data_from_disk.cc:126-208).  `safe_end`: the end of
+// the buffer the text sits in (bytes up to there may be read, not interpreted).
+void parse_piece(const char *p, const char *end, bool last_piece, const char *safe_end,
+                 Piece *out) {
   // one reservation per piece instead of reallocating under 64 threads' malloc contention:
   // a token is at least "0:0:0 " (6 bytes), a row at least "0\t0:0:0\n" (8 bytes)
   const size_t bytes = (size_t)(end - p);
@@ -487,12 +617,9 @@ void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
       out->hit_nul = true;
       return;
     }
-    const char *eol = p;
-    const char *tab = nullptr;
-    while (eol < end && *eol != '\n') {
-      if (!tab && *eol == '\t') tab = eol;
-      ++eol;
-    }
+    const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+    if (!eol) eol = end;
+    const char *tab = (const char *)memchr(p, '\t', (size_t)(eol - p));
     if (!tab) {
       out->err = "no '\\t' after the label";
       return;
@@ -512,6 +639,27 @@ void parse_piece(const char *p, const char *end, bool last_piece, Piece *out) {
     // token.  A single blank before '\n' is not a token (:138 ends the row).  Without a
     // previous token in the row the value is stale or uninitialised there: rejected here.
     while (t < eol) {
+      {
+        // the common token, digits ':' fid ':' val: one pass, no second look at any byte.
+        // Anything else (empty token, no colons, a non-digit or long fgid) takes the general
+        // path below, which yields the same values for the tokens this path accepts.
+        const char *q = t;
+        uint32_t fgv = 0;
+        while (q < eol && (unsigned)(*q - '0') <= 9u) fgv = fgv * 10 + (uint32_t)(*q++ - '0');
+        if (q < eol && *q == ':' && q > t && q - t <= 9) {
+          const char *f = q + 1;
+          q = f;
+          while (q < eol && *q != ':' && *q != ' ') ++q;
+          if (q < eol && *q == ':') {
+            const char *c2f = q;
+            while (q < eol && *q != ' ') ++q;
+            out->fgid.push_back((int32_t)fgv);
+            out->keys.push_back(hash_fid(f, (size_t)(c2f - f), safe_end));
+            t = q + 1;
+            continue;
+          }
+        }
+      }
       const char *te = t;
       const char *c1 = nullptr, *c2 = nullptr;
       while (te < eol && *te != ' ') {
@@ -678,14 +826,12 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
     pc.err = nullptr;
     pc.hit_nul = false;
   }
-  if (nt == 1) {
-    parse_piece(cut[0], cut[1], true, &pieces[0]);
-  } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-      th.emplace_back(parse_piece, cut[t], cut[t + 1], cut[t + 1] == end, &pieces[t]);
-    for (auto &x : th) x.join();
-  }
+  // bytes that may be READ beyond a token (the short-fid hash loads 8 at once): the mapping or
+  // the read buffer
+  const char *safe_end = r->map ? r->map + r->map_size : r->buf.data() + r->buf.size();
+  r->team.run(nt, [&](unsigned t) {
+    parse_piece(cut[t], cut[t + 1], cut[t + 1] == end, safe_end, &pieces[t]);
+  });
   // offsets of every piece in the block's arrays, then a parallel copy
   std::vector<size_t> key_off(nt + 1, 0), row_off(nt + 1, 0);
   unsigned used = nt;
@@ -704,10 +850,10 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
     }
   }
   const size_t nkeys = key_off[used], nrows = row_off[used];
-  r->keys.resize(nkeys);
-  r->fgid.resize(nkeys);
-  r->labels.resize(nrows);
-  r->rowptr.resize(nrows + 1);
+  block_resize(r->keys, nkeys);
+  block_resize(r->fgid, nkeys);
+  block_resize(r->labels, nrows);
+  block_resize(r->rowptr, nrows + 1);
   r->rowptr[0] = 0;
   auto place = [&](unsigned t) {
     Piece &pc = pieces[t];
@@ -720,13 +866,7 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
     for (size_t i = 0; i < pc.rowend.size(); ++i)
       r->rowptr[row_off[t] + i + 1] = key_off[t] + pc.rowend[i];
   };
-  if (used == 1) {
-    place(0);
-  } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < used; ++t) th.emplace_back(place, t);
-    for (auto &x : th) x.join();
-  }
+  r->team.run(used, place);
   if (r->map) {
     r->pos += take;
     r->held = 0;

