@@ -29,40 +29,12 @@
 
 namespace xf {
 
-// CPUs this process may use at once: the cgroup's CPU quota when there is one (a container
-// with "16 CPUs" on a 256-thread host shows 256 to hardware_concurrency(); 64 parser threads
-// then burn the period's quota in bursts and the kernel parks EVERY thread of the cgroup, the
-// trainer included, until the next period: 30-60 ms stalls every few blocks)
-static int cpu_allowance() {
-  double quota = 0.0;
-  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
-    char q[32] = "";
-    double period = 0.0;
-    if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
-      quota = atof(q) / period;
-    fclose(f);
-  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // v1
-    double q = 0.0, period = 0.0;
-    if (fscanf(g, "%lf", &q) == 1 && q > 0) {
-      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-        if (fscanf(h, "%lf", &period) == 1 && period > 0) quota = q / period;
-        fclose(h);
-      }
-    }
-    fclose(g);
-  }
-  int n = (int)std::thread::hardware_concurrency();
-  if (n < 1) n = 1;
-  if (quota >= 1.0 && quota < n) n = (int)quota;
-  return n;
-}
-
-// parser threads: at most 64, and two fewer than the CPU allowance (the trainer thread and the
-// parse-ahead thread's own work keep theirs)
-static int g_parse_threads = [] {
-  const int a = cpu_allowance();
-  return std::max(1, std::min(64, a > 4 ? a - 2 : a));
-}();
+// Parser threads.  On a box whose cgroup grants fewer CPUs than it shows (16 of 256 on the GPU
+// boxes) 64 threads burn the period's quota in bursts and get parked for the rest of it — but
+// the parse is then limited by the quota itself (a 64 MiB block costs ~90 thread-ms), and
+// bursting reaches that limit (4.8e6 examples/s end to end) where quota-many threads leave
+// pipeline bubbles (3.2e6): measured both ways, tools/e2e_text.py.
+static int g_parse_threads = 64;
 int parse_threads() { return g_parse_threads; }
 void set_parse_threads(int n) { g_parse_threads = n < 1 ? 1 : n; }
 
