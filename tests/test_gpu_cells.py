@@ -149,3 +149,31 @@ def test_degenerate_local_batches():
     i = int(np.flatnonzero(kk == k[0])[0])
     same(np.array([w[i], n[i], z[i]]), np.array([w2[0], n2[0], z2[0]]))
     t.check()
+
+
+def test_step_profile_samples_without_stalling_and_leaves_the_result_alone():
+    """xf_workspace_profile: every 4th step records HIP events into a ring of event sets (the
+    host never waits for the step it has just launched); the sums cover exactly the recording
+    steps, and a profiled run ends in the same table as an unprofiled one"""
+    rng = np.random.RandomState(3)
+    data = [synth(rng, 400, 30, 6000) for _ in range(3)]
+    tabs = []
+    for prof in (False, True):
+        t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 15)
+        ws = capi.Workspace()
+        bs = [capi.LocalBatch(t, *d) for d in data]
+        if prof:
+            ws.profile(True)
+        for i in range(22):
+            capi.lr_step(t, bs[i % 3], ws)
+        if prof:
+            ms, steps = ws.profile_read()
+            assert steps == 6                      # steps 0, 4, ..., 20
+            assert ms["forward"] > 0 and ms["gradient"] > 0
+            assert ms["resolve"] == 0 and ms["update"] == 0
+            assert ms["forward"] / steps < 5.0 and ms["gradient"] / steps < 5.0   # ms, sane
+            ws.profile(False)
+        t.check()
+        tabs.append(t.export())
+    for a, b in zip(*tabs):
+        same(a, b)
