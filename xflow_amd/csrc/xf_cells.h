@@ -3,11 +3,11 @@
 // One array of 4-byte entries, one per nonzero, grouped by CELL = (row window, key chunk):
 //   row window  W <= kWinMax consecutive examples of the minibatch (their fp64 row accumulators
 //               fit a CU's LDS: 17408 x 8 B = 136 KiB),
-//   key chunk   kChunk = 4096 consecutive positions of the INDEX SPACE the batch was compiled
+//   key chunk   kChunk = 2048 consecutive positions of the INDEX SPACE the batch was compiled
 //               against: state rows of a table on this GPU (mode kCellsTableRows), or the
 //               batch's own sorted-unique-key index (mode kCellsUidx, the multi-GPU worker side,
 //               where the weights arrive as a dense U-array from the owning shards).
-//   entry       (chunk number & 31) << 27 | (row within the window) << 12 | (position within
+//   entry       (chunk number & 31) << 27 | (row within the window) << 11 | (position within
 //               the chunk)
 // and cellptr[nwin * nchunk + 1], the offsets of the cells in window-major order.  Inside a
 // cell the entries keep the row-major order of the input (the grouping is a stable sort on the
@@ -16,8 +16,8 @@
 // Both sparse products of the step read this one stream:
 //   forward   wx[row] += w[idx]     a workgroup owns a slice of ONE window's entries; the
 //                                   window's row sums live in LDS (fp64 atomics), the gathers
-//                                   of w stay inside one 16 KiB chunk at a time (L1-resident)
-//   gradient  g[idx]  += loss[row]  a workgroup owns ONE chunk (all windows); the chunk's 4096
+//                                   of w stay inside one 8 KiB chunk at a time (L1-resident)
+//   gradient  g[idx]  += loss[row]  a workgroup owns ONE chunk (all windows); the chunk's 2048
 //                                   sums live in LDS, the loss gathers of a cell walk the
 //                                   window's rows in ascending order
 // which replaces the CSR (rowptr/uidx), its panel-major copy (pptr/pidx), the key-grouped COO
