@@ -676,6 +676,79 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
       sv[j - j0] = vsum[sid];
     }
     __syncthreads();
+    if constexpr (K > 0 && K % 4 == 0) {
+      // Factor counts that are a multiple of four: a lane's item is FOUR consecutive factors of
+      // a key — one 16-byte load of the factors, two of the (n,z) state, one 16-byte store of
+      // the weights — so that four times the bytes are in flight per lane and the key's
+      // occurrences are read from LDS once per four factors.  (With one factor per lane the
+      // kernel moved its 1.03 GB at 2.7 TB/s: 24 wavefronts x 4 loads x 256 B in flight per CU
+      // against ~2 us of latency.)
+      constexpr uint32_t Q = (uint32_t)(K > 0 ? K : 4) / 4u;
+      const uint32_t nq = nk * Q;
+      constexpr int kUq = 2;  // quads in flight per lane
+      for (uint32_t e0 = tid; e0 < nq; e0 += kBlock * kUq) {
+        uint32_t kq[kUq], qq[kUq];
+        float4 v[kUq], nzA[kUq], nzB[kUq];
+        size_t to[kUq];
+        bool on[kUq];
+#pragma unroll
+        for (int i = 0; i < kUq; ++i) {
+          const uint32_t el = e0 + i * kBlock;
+          on[i] = el < nq;
+          kq[i] = on[i] ? el / Q : 0;
+          qq[i] = on[i] ? el - kq[i] * Q : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < kUq; ++i) {
+          v[i] = on[i] ? *reinterpret_cast<const float4 *>(vu + (size_t)(ua + kq[i]) * K + 4 * qq[i])
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+          to[i] = (UPDATE && on[i]) ? (size_t)rows_v[ua + kq[i]] * K + 4 * qq[i] : 0;
+        }
+        if (UPDATE && OPT == XF_OPT_FTRL) {
+#pragma unroll
+          for (int i = 0; i < kUq; ++i) {
+            nzA[i] = nzB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on[i]) {  // (n0,z0,n1,z1), (n2,z2,n3,z3)
+              nzA[i] = *reinterpret_cast<const float4 *>(TV.nz + to[i]);
+              nzB[i] = *reinterpret_cast<const float4 *>(TV.nz + to[i] + 2);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kUq; ++i) {
+          if (!on[i]) continue;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          for (uint32_t j = sp[kq[i]]; j < sp[kq[i] + 1]; ++j) {
+            const float l = lv[j], sj = sv[j];
+            a0 += (double)(l * (sj - v[i].x));
+            a1 += (double)(l * (sj - v[i].y));
+            a2 += (double)(l * (sj - v[i].z));
+            a3 += (double)(l * (sj - v[i].w));
+          }
+          const float4 g = make_float4(div_by_rows((float)a0, R), div_by_rows((float)a1, R),
+                                       div_by_rows((float)a2, R), div_by_rows((float)a3, R));
+          if (gv)
+            *reinterpret_cast<float4 *>(gv + (size_t)(ua + kq[i]) * K + 4 * qq[i]) = g;
+          if (UPDATE) {
+            float4 w = v[i];
+            if (OPT == XF_OPT_FTRL) {
+              xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g.x, w.x, nzA[i].x, nzA[i].y);
+              xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g.y, w.y, nzA[i].z, nzA[i].w);
+              xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g.z, w.z, nzB[i].x, nzB[i].y);
+              xf::ftrl_step(TV.alpha, TV.beta, TV.lambda1, TV.lambda2, g.w, w.w, nzB[i].z, nzB[i].w);
+              *reinterpret_cast<float4 *>(TV.nz + to[i]) = nzA[i];
+              *reinterpret_cast<float4 *>(TV.nz + to[i] + 2) = nzB[i];
+            } else {
+              w.x = xf::sgd_step(TV.lr, g.x, w.x);
+              w.y = xf::sgd_step(TV.lr, g.y, w.y);
+              w.z = xf::sgd_step(TV.lr, g.z, w.z);
+              w.w = xf::sgd_step(TV.lr, g.w, w.w);
+            }
+            *reinterpret_cast<float4 *>(TV.w + to[i]) = w;
+          }
+        }
+      }
+    } else {
     const uint32_t nel = nk * (uint32_t)k;
     // (key,factor) items in flight per lane.  Everything an item reads from HBM — its factor,
     // its state row, the w row of the factor-0 lanes — is requested before the first
@@ -727,6 +800,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         }
       }
     }
+    }  // K % 4 != 0
     // the keys' w coordinate (gw = k x the LR gradient, fm_worker.cc:140), one lane per key: as
     // the factor-0 lanes' job inside the loop above it was four memory instructions per item
     // with one lane in k active (94 of 590 us at k = 16)
