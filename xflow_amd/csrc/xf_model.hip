@@ -685,7 +685,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
       // against ~2 us of latency.)
       constexpr uint32_t Q = (uint32_t)(K > 0 ? K : 4) / 4u;
       const uint32_t nq = nk * Q;
-      constexpr int kUq = 2;  // quads in flight per lane
+      constexpr int kUq = OPT == XF_OPT_FTRL ? 4 : 2;  // quads in flight per lane (measured)
       for (uint32_t e0 = tid; e0 < nq; e0 += kBlock * kUq) {
         uint32_t kq[kUq], qq[kUq];
         float4 v[kUq], nzA[kUq], nzB[kUq];
