@@ -563,7 +563,9 @@ def main():
     kern_ms, ksteps = trainer.profile_read()
     trainer.profile(False)
     trainer.check()
-    kernel_timing = "HIP events on the step's stream inside the timed region"
+    kernel_timing = "HIP events on the step's stream inside the timed region (every 4th step " \
+                    "records, into a ring of event sets: the host never waits for a step it " \
+                    "has just launched)"
     if sharded and not any(kern_ms.values()):
         # the overlapped schedule runs two streams: per-kernel events are taken in a short
         # sequential pass after the timed region instead

@@ -78,8 +78,9 @@ res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, 
        "host": {"nproc": os.cpu_count()},
        "first_epoch_from_text": text1, "first_epoch_from_block_cache": cache1,
        "median_block_rate_from_text": text_steady, "median_block_rate_from_block_cache": cache_steady,
-       "note": "first_epoch_* = rows / wall time of the whole first epoch of a fresh process "
-               "(includes its one-time allocations: pinned block buffers, build arena, table); "
+       "note": "first_epoch_* = rows / wall time of the training loop of a fresh process that "
+               "runs ONE epoch (its first block still pins the block buffers and sizes the build "
+               "scratch; code loading happens at start-up, before the loop); "
                "median_block_rate_* = rows of a block / (wait for the parser + key build incl. "
                "upload + step) for the median block of that epoch",
        "average_over_4_epochs_from_text": text4,
