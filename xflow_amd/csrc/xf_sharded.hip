@@ -46,6 +46,10 @@ int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
 int table_ensure_room(xf_table *t, size_t incoming);
+int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,
+                    const uint32_t *d_rows, size_t n, uint32_t *d_hrow, hipStream_t s);
+int table_update_heads(xf_table *t, const uint32_t *d_hrow, const uint32_t *d_order, size_t n,
+                       const float *d_grads, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -125,6 +129,7 @@ struct xf_sbatch {
   Dev<uint64_t> rkeys, rkeys_sorted;  // the keys this rank owns, per source; merged by key
   Dev<uint32_t> rorder;               // sorted entry i sits at rorder[i] of the per-source layout
   Dev<uint32_t> rows_w, rows_v;       // their state rows (valid for one table epoch)
+  Dev<uint32_t> hrow_w, hrow_v;       // merged order: row of a key's first entry, else kNotHead
   uint64_t rows_uid = 0, rows_epoch = ~0ull;
   StepBuf buf[2];
   int flip = 0;
@@ -201,6 +206,13 @@ int front_pull(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
       if (fm)
         XF_TRY(xf_table_pull_ordered_dev(st->tv, b->rkeys_sorted.p, b->rorder.p, n, b->rows_v.p,
                                          nullptr, s));
+      // the static part of the Push's merged walk
+      XF_TRY(b->hrow_w.reserve(n));
+      XF_TRY(xf::table_head_rows(b->rkeys_sorted.p, b->rorder.p, b->rows_w.p, n, b->hrow_w.p, s));
+      if (fm) {
+        XF_TRY(b->hrow_v.reserve(n));
+        XF_TRY(xf::table_head_rows(b->rkeys_sorted.p, b->rorder.p, b->rows_v.p, n, b->hrow_v.p, s));
+      }
     }
     b->rows_uid = uid;
     b->rows_epoch = ep;
@@ -265,11 +277,9 @@ int back_exchange(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
 // after the other in source-rank order
 int back_apply(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
   if (!b->n_recv) return XF_OK;
-  XF_TRY(xf_table_update_merged_dev(st->tw, b->rkeys_sorted.p, b->rorder.p, b->n_recv,
-                                    b->rows_w.p, B.g_recv.p, s));
+  XF_TRY(xf::table_update_heads(st->tw, b->hrow_w.p, b->rorder.p, b->n_recv, B.g_recv.p, s));
   if (st->cfg.model == 1)
-    XF_TRY(xf_table_update_merged_dev(st->tv, b->rkeys_sorted.p, b->rorder.p, b->n_recv,
-                                      b->rows_v.p, B.gv_recv.p, s));
+    XF_TRY(xf::table_update_heads(st->tv, b->hrow_v.p, b->rorder.p, b->n_recv, B.gv_recv.p, s));
   return XF_OK;
 }
 
