@@ -548,8 +548,8 @@ k_fm_gather_scalars(const float4 *__restrict__ tv, const uint32_t *__restrict__ 
     const size_t i = on ? e / DIM4 : 0, j = on ? e % DIM4 : 0;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (on) {
-      v = tv[(size_t)rows[i] * DIM4 + j];
-      vu[e] = v;
+      v = tv[(size_t)(rows ? rows[i] : (uint32_t)i) * DIM4 + j];  // rows == null: tv is dense
+      if (vu) vu[e] = v;
     }
     double a = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     double b = (double)(v.x * v.x) + (double)(v.y * v.y) + (double)(v.z * v.z) +
@@ -1041,6 +1041,48 @@ extern "C" int xf_fm_forward_dev(const xf_dev_batch *b, int k, const float *d_wu
   return XF_OK;
 }
 
+// FM forward from dense pulled rows (w_u[U], v_u[U x k]) through the per-key records: one pass
+// over v_u forms (sum_k v, sum_k v^2, w) per key into `d_ks` (U x 32 bytes of caller-owned
+// scratch), the per-nonzero pass gathers one record.  Same sums as xf_fm_forward_dev (exact
+// fp64), a fraction of its time at larger k (k = 64: one 256-byte row per nonzero there).
+// Returns XF_EINVAL-free false when k does not fit the record kernel (the caller falls back).
+namespace xf {
+bool fm_records_fit(int k) {
+  const int dim4 = k / 4;
+  return k % 4 == 0 && dim4 >= 1 && dim4 <= 16 && (dim4 & (dim4 - 1)) == 0;
+}
+size_t fm_record_bytes(size_t U) { return std::max<size_t>(U, 1) * sizeof(FmKey); }
+int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
+                       void *d_ks, float *d_loss, float *d_pctr, float *d_vsum,
+                       hipStream_t s) {
+  XF_REQUIRE(b && d_wu && d_vu && d_ks && d_loss && d_vsum && fm_records_fit(k),
+             "fm_forward_records: bad argument");
+  if (b->R == 0) return XF_OK;
+  const int dim4 = k / 4;
+  const size_t tot = (size_t)b->U * dim4;
+  const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
+#define XF_FM_GS(D)                                                                          \
+  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, s, (const float4 *)d_vu,             \
+                     (const uint32_t *)nullptr, d_wu, (size_t)b->U, (float4 *)nullptr,       \
+                     (FmKey *)d_ks)
+  if (b->U) {
+    switch (dim4) {
+      case 1: XF_FM_GS(1); break;
+      case 2: XF_FM_GS(2); break;
+      case 4: XF_FM_GS(4); break;
+      case 8: XF_FM_GS(8); break;
+      default: XF_FM_GS(16); break;
+    }
+  }
+#undef XF_FM_GS
+  hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(b->R, kBlock / 64)),
+                     dim3(kBlock), 0, s, b->rowptr, b->uidx, (const FmKey *)d_ks, b->labels, b->R,
+                     d_loss, d_pctr, d_vsum);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+}  // namespace xf
+
 extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
                               const float *d_vsum, const float *d_loss, float *d_gw,
                               float *d_gv, void *stream) {
@@ -1481,7 +1523,11 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
   XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, nullptr));
   XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, nullptr));
-  XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, ws->pctr, ws->vsum, nullptr));
+  if (xf::fm_records_fit(k) && v.U)
+    XF_TRY(xf::fm_forward_records(&v, k, ws->wu, ws->vu, ws->ks, ws->loss, ws->pctr, ws->vsum,
+                                  nullptr));
+  else
+    XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, ws->pctr, ws->vsum, nullptr));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
   XF_TRY(xf_table_check(w, nullptr));
   return xf_table_check(vt, nullptr);

@@ -46,6 +46,10 @@ int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
 int table_ensure_room(xf_table *t, size_t incoming);
+bool fm_records_fit(int k);
+size_t fm_record_bytes(size_t U);
+int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
+                       void *d_ks, float *d_loss, float *d_pctr, float *d_vsum, hipStream_t s);
 int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,
                     const uint32_t *d_rows, size_t n, uint32_t *d_hrow, hipStream_t s);
 int table_update_heads(xf_table *t, const uint32_t *d_hrow, const uint32_t *d_order, size_t n,
@@ -117,6 +121,7 @@ enum { kEvPull = 0, kEvA2aW, kEvForward, kEvGrad, kEvA2aG, kEvUpdate, kEvN };
 // flight on the side stream (stale1) never shares a buffer with the next step on this batch
 struct StepBuf {
   Dev<float> w_send, wu, g, g_recv, loss, vsum;
+  Dev<char> ks;  // FM: the per-key records of the forward
   Dev<float> v_send, vu, gv, gv_recv;
 };
 
@@ -250,7 +255,13 @@ int front_compute(xf_sharded *st, xf_sbatch *b, StepBuf &B, float *d_pctr, bool 
       XF_TRY(xf::cells_lr_grad(b->cells, B.loss.p, B.g.p, s));
     }
   } else {
-    XF_TRY(xf_fm_forward_dev(&b->b->view, k, B.wu.p, B.vu.p, B.loss.p, d_pctr, B.vsum.p, s));
+    if (xf::fm_records_fit(k) && b->U) {
+      XF_TRY(B.ks.reserve(xf::fm_record_bytes(b->U)));
+      XF_TRY(xf::fm_forward_records(&b->b->view, k, B.wu.p, B.vu.p, B.ks.p, B.loss.p, d_pctr,
+                                    B.vsum.p, s));
+    } else {
+      XF_TRY(xf_fm_forward_dev(&b->b->view, k, B.wu.p, B.vu.p, B.loss.p, d_pctr, B.vsum.p, s));
+    }
     XF_MARK(kEvForward + 1);
     if (want_grad) {
       XF_TRY(B.g.reserve(b->U));
