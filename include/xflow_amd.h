@@ -361,6 +361,12 @@ int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t *send_count
  * With a group of one rank (or g == NULL) it is the fused single-shard step. */
 #define XF_SCHEDULE_SEQUENTIAL 0 /* Pull, compute, Push of step t before Pull(t+1) */
 #define XF_SCHEDULE_STALE1 1     /* Push(t) overlaps Pull/forward/gradient of t+1 (one step stale) */
+/* LR only.  Owner-compute dataflow: a minibatch's NONZEROS go to the key owners once, when it is
+ * compiled; a step then runs the table-resident forward and gradient + Push at the owners and
+ * exchanges only row-level scalars (fp64 partial row sums to the rows' workers, their losses
+ * back) instead of a weight and a gradient per key.  Same results as XF_SCHEDULE_SEQUENTIAL
+ * (every worker's gradient its own optimizer step, applied in rank order). */
+#define XF_SCHEDULE_OWNER 2
 typedef struct {
   int32_t model;     /* 0 LR, 1 FM */
   int32_t optimizer; /* XF_OPT_* */

@@ -42,9 +42,10 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
         for s in range(steps):
             b = st.compile(*_data(rank, s))
             alive.append(b)
-            assert b.U == len(np.unique(_data(rank, s)[1]))
+            if schedule != "owner":          # (the owner-compute dataflow keeps no key list)
+                assert b.U == len(np.unique(_data(rank, s)[1]))
             st.step(b)
-            if schedule == "sequential" and s == 1:
+            if schedule in ("sequential", "owner") and s == 1:
                 st.defrag()          # row renumbering between steps must not change a bit
         st.check()
         rp, ks, lb = _data(rank, 99)
@@ -120,6 +121,27 @@ def test_cpp_sharded_over_rccl(tmp_path, world, model, schedule):
         pytest.skip("needs %d GPUs, this box has %d" % (world, n.value))
     _run(world, capi.TRANSPORT_RCCL, model, "ftrl", schedule, tmp_path)
     _check_against_oracle(world, model, "ftrl", schedule, tmp_path)
+
+
+@pytest.mark.parametrize("world,optimizer", [(2, "ftrl"), (3, "sgd"), (3, "ftrl")])
+def test_owner_compute_dataflow_ranks_share_one_gpu(tmp_path, world, optimizer):
+    """XF_SCHEDULE_OWNER: the nonzeros go to the key owners when the minibatch is compiled, a
+    step exchanges fp64 partial row sums and losses instead of weights and gradients, the
+    owner applies the workers' gradients in rank order out of one pass over its shard — the
+    same numbers as the sequential schedule of the weight/gradient exchange, bit for bit
+    (tables after 4 steps with a defrag in between, and the forward of a fifth minibatch)"""
+    _run(world, capi.TRANSPORT_HOST, "lr", optimizer, "owner", tmp_path)
+    _check_against_oracle(world, "lr", optimizer, "sequential", tmp_path)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_owner_compute_dataflow_over_rccl(tmp_path, world):
+    n = C.c_int(0)
+    capi.check(capi.lib().xf_device_count(C.byref(n)))
+    if n.value < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, n.value))
+    _run(world, capi.TRANSPORT_RCCL, "lr", "ftrl", "owner", tmp_path)
+    _check_against_oracle(world, "lr", "ftrl", "sequential", tmp_path)
 
 
 def test_auto_transport_agrees_on_every_rank(tmp_path):

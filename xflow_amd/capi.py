@@ -629,7 +629,9 @@ class Group:
                                        elem_bytes, 0, stream))
 
 
-SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1 = 0, 1
+SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1, SCHEDULE_OWNER = 0, 1, 2
+_SCHEDULES = {"sequential": SCHEDULE_SEQUENTIAL, "stale1": SCHEDULE_STALE1,
+              "owner": SCHEDULE_OWNER}
 
 
 class ShardedBatch:
@@ -660,7 +662,7 @@ class Sharded:
         c.model = 0 if model == "lr" else 1
         c.optimizer = OPT_FTRL if optimizer == "ftrl" else OPT_SGD
         c.k, c.capacity, c.seed = k, capacity, seed
-        c.schedule = SCHEDULE_STALE1 if schedule == "stale1" else SCHEDULE_SEQUENTIAL
+        c.schedule = _SCHEDULES[schedule]
         c.host_key_build = 1 if host_key_build else 0
         for name, v in hyper.items():
             setattr(c, name, v)
@@ -713,7 +715,7 @@ class Sharded:
 
     def set_schedule(self, schedule):
         check(lib().xf_sharded_set_schedule(
-            self.h, SCHEDULE_STALE1 if schedule == "stale1" else SCHEDULE_SEQUENTIAL))
+            self.h, _SCHEDULES[schedule]))
 
     def save(self, prefix):
         check(lib().xf_sharded_save(self.h, prefix.encode()))

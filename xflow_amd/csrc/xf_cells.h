@@ -79,9 +79,12 @@ namespace xf {
 // Build the cells of a minibatch on the device.  idx[NNZ]: index-space position of every
 // nonzero in row-major order — map == null: idx[j] = src[j]; else idx[j] = map[src[j]] (the
 // unique-key index of a compiled batch mapped to table rows).  Synchronises `stream`.
+// d_rowid != null: the nonzeros come in any order with their row number (d_rowptr unused, no
+// map); the rows are then numbered window by window by the caller: w_fixed rows per window.
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                bool key_sorted_copy, hipStream_t stream);
+                bool key_sorted_copy, hipStream_t stream, const uint32_t *d_rowid = nullptr,
+                uint32_t w_fixed = 0);
 void cells_free(xf_cells *c);
 
 // scratch of the forward: G * nwin * W partial row sums (fp64)
@@ -90,6 +93,14 @@ size_t cells_partial_doubles(const xf_cells *c);
 // forward: loss[r] = sigmoid(sum_j w[idx_j]) - label[r]   (lr_worker.cc:121-143)
 int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,
                      double *d_partial, float *d_loss, float *d_pctr, hipStream_t stream);
+
+// owner-compute step (xf_sharded.hip): forward up to the fp64 row sums, and the gradient with
+// the Pushes of several workers applied in rank order (see xf_cells.hip)
+int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial,
+                          double *d_rowsum, hipStream_t stream);
+int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
+                                 uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
+                                 double *d_gsum, uint8_t *d_gtouched, hipStream_t stream);
 
 }  // namespace xf
 

@@ -138,6 +138,21 @@ k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
   }
 }
 
+// the same for nonzeros that come with their row number instead of in CSR order (the owner side
+// of the owner-compute step: nonzeros of several workers' minibatches, rows numbered window by
+// window across the workers)
+__global__ void __launch_bounds__(kBlock)
+k_cell_keys_rowid(const uint32_t *__restrict__ rowid, const uint32_t *__restrict__ src, size_t n,
+                  uint32_t W, uint32_t nchunk, uint32_t *__restrict__ cid,
+                  uint32_t *__restrict__ ent) {
+  XF_GRID_STRIDE(j, n) {
+    const uint32_t r = rowid[j], v = r / W, rin = r - v * W;
+    const uint32_t idx = src[j], chunk = idx >> kChunkBits;
+    cid[j] = v * nchunk + chunk;
+    ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
+  }
+}
+
 int exclusive_scan_u32(xf::Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
                        hipStream_t s) {
   size_t tb = 0;
@@ -355,7 +370,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
                 const uint32_t *__restrict__ item_dump, const float *__restrict__ loss,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
-                uint8_t *__restrict__ gtouched) {
+                uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
+                const uint32_t *__restrict__ src_rows, uint32_t nsplit) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
@@ -366,11 +382,21 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
     acc[k] = 0.0;
     touched[k] = 0;
   }
-  // The item's share of the chunk's nwin cells as ONE index space: windows v0, v0+1, ... side
+  // SOURCES (src_win != null, the owner-compute step): the windows are grouped by the worker
+  // whose rows they hold; a key's gradient from worker q is sum/R_q and is its own optimizer
+  // step, the workers' steps applied in rank order — one accumulate + update phase
+  // per worker inside the same pass over the chunk, the state row read and written by the same
+  // thread every phase (it stays in L2 in between).  One source: the whole minibatch.
+  const uint32_t ns = src_win ? nsrc : 1u;
+  for (uint32_t q = 0; q < ns; ++q) {
+  const uint32_t wbeg = src_win ? src_win[q] : 0u, wend = src_win ? src_win[q + 1] : nwin;
+  const uint32_t Rq = src_win ? src_rows[q] : R;
+  if (wbeg == wend) continue;  // workgroup-uniform
+  // The item's share of the chunk's cells as ONE index space: windows v0, v0+1, ... side
   // by side (cum = running entry counts), so that a thread's loads of a round — entries, then
   // the losses they point at — are all in flight together instead of window after window.
-  for (uint32_t v0 = 0; v0 < nwin; v0 += kGradWin) {
-    const uint32_t nv = min(nwin - v0, kGradWin);
+  for (uint32_t v0 = wbeg; v0 < wend; v0 += kGradWin) {
+    const uint32_t nv = min(wend - v0, kGradWin);
     __syncthreads();
     if (tid < nv) {
       const size_t cell = (size_t)(v0 + tid) * nchunk + c;
@@ -413,22 +439,28 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
   }
   __syncthreads();
   if (S > 1) {  // a slice of a split chunk: into the chunk's accumulators in HBM
-    const uint32_t slot = item_dump[blockIdx.x];
+    const size_t slot = (size_t)q * nsplit + item_dump[blockIdx.x];
     for (uint32_t k = tid; k < kChunk; k += kBlock)
       if (touched[k]) {
-        unsafeAtomicAdd(&gsum[(size_t)slot * kChunk + k], acc[k]);
-        gtouched[(size_t)slot * kChunk + k] = 1;
+        unsafeAtomicAdd(&gsum[slot * kChunk + k], acc[k]);
+        gtouched[slot * kChunk + k] = 1;
+        acc[k] = 0.0;
+        touched[k] = 0;
       }
-    return;
+    continue;
   }
   for (uint32_t k = tid; k < kChunk; k += kBlock) {
     if (!touched[k]) continue;
+    const double sum = acc[k];
+    acc[k] = 0.0;
+    touched[k] = 0;
     const size_t idx = (size_t)c * kChunk + k;
     if (idx >= M) continue;
-    const float g = (float)((double)(float)acc[k] / (1.0 * R));  // lr_worker.cc:117
+    const float g = (float)((double)(float)sum / (1.0 * Rq));  // lr_worker.cc:117
     if (g_out) g_out[idx] = g;
     if (MODE == 0) apply_key(T, OPT, idx, g);
   }
+  }  // sources
 }
 
 // the keys of the split chunks: one lane per key
@@ -436,15 +468,20 @@ template <int OPT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
                        const double *__restrict__ gsum, const uint8_t *__restrict__ gtouched,
-                       uint32_t R, uint32_t M, float *__restrict__ g_out) {
+                       uint32_t R, uint32_t M, float *__restrict__ g_out, uint32_t nsrc,
+                       const uint32_t *__restrict__ src_rows, uint32_t nsplit) {
   const uint32_t slot = blockIdx.x / (kChunk / kBlock);
   const uint32_t k = (blockIdx.x % (kChunk / kBlock)) * kBlock + threadIdx.x;
-  if (!gtouched[(size_t)slot * kChunk + k]) return;
   const size_t idx = (size_t)split_chunk[slot] * kChunk + k;
   if (idx >= M) return;
-  const float g = (float)((double)(float)gsum[(size_t)slot * kChunk + k] / (1.0 * R));
-  if (g_out) g_out[idx] = g;
-  if (MODE == 0) apply_key(T, OPT, idx, g);
+  const uint32_t ns = src_rows ? nsrc : 1u;
+  for (uint32_t q = 0; q < ns; ++q) {  // the workers' steps in rank order
+    const size_t o = ((size_t)q * nsplit + slot) * kChunk + k;
+    if (!gtouched[o]) continue;
+    const float g = (float)((double)(float)gsum[o] / (1.0 * (src_rows ? src_rows[q] : R)));
+    if (g_out) g_out[idx] = g;
+    if (MODE == 0) apply_key(T, OPT, idx, g);
+  }
 }
 
 }  // namespace
@@ -468,15 +505,23 @@ size_t cells_partial_doubles(const xf_cells *c) { return (size_t)c->G * c->nwin 
 
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                bool key_sorted_copy, hipStream_t s) {
-  XF_REQUIRE(out && d_rowptr && (NNZ == 0 || d_src), "cells_build: null argument");
+                bool key_sorted_copy, hipStream_t s, const uint32_t *d_rowid, uint32_t w_fixed) {
+  XF_REQUIRE(out && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_src),
+             "cells_build: null argument");
+  XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax && !d_map),
+             "cells_build: row ids need a window size");
   xf_cells *c = new xf_cells;
   c->R = R;
   c->NNZ = NNZ;
   c->M = M;
   c->mode = mode;
-  c->nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
-  c->W = std::max<uint32_t>(1, (R + c->nwin - 1) / c->nwin);
+  if (w_fixed) {  // the caller numbered the rows window by window
+    c->W = w_fixed;
+    c->nwin = std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed);
+  } else {
+    c->nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+    c->W = std::max<uint32_t>(1, (R + c->nwin - 1) / c->nwin);
+  }
   c->nchunk = std::max<uint32_t>(1, (uint32_t)(((uint64_t)M + kChunk - 1) / kChunk));
   const uint64_t ncell64 = (uint64_t)c->nwin * c->nchunk;
   if (ncell64 >= 0x7FFFFFFFull) {
@@ -513,8 +558,12 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   XF_TRY(sc.get(&ent, NNZ));
   XF_TRY(sc.get(&cid_s, NNZ));
   if (NNZ) {
-    hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr,
-                       d_src, d_map, R, c->W, c->nchunk, cid, ent);
+    if (d_rowid)
+      hipLaunchKernelGGL(k_cell_keys_rowid, dim3(grid_for((size_t)NNZ)), dim3(kBlock), 0, s,
+                         d_rowid, d_src, (size_t)NNZ, c->W, c->nchunk, cid, ent);
+    else
+      hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s,
+                         d_rowptr, d_src, d_map, R, c->W, c->nchunk, cid, ent);
     int bits = 1;
     while (bits < 32 && (1ull << bits) < ncell64) ++bits;
     size_t tb = 0;
@@ -601,17 +650,39 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
   return XF_OK;
 }
 
+// sources: the workers whose rows the windows hold (CellSources, owner-compute step); null: one
+struct CellSources {
+  uint32_t n = 0;
+  const uint32_t *d_win = nullptr;   // [n + 1] first window of every worker
+  const uint32_t *d_rows = nullptr;  // [n] rows of every worker's minibatch
+  double *gsum = nullptr;            // [n * nsplit_chunks * kChunk] split chunks' sums per worker
+  uint8_t *gtouched = nullptr;       // [n * nsplit_chunks * kChunk]
+};
+
 template <int OPT, int MODE>
 static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss, float *d_g,
-                       hipStream_t s) {
-  if (c->nsplit_chunks) XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
+                       hipStream_t s, const CellSources *src = nullptr) {
+  double *gsum = src ? src->gsum : c->gsum;
+  uint8_t *gtouched = src ? src->gtouched : c->gtouched;
+  if (c->nsplit_chunks) {
+    if (src) {
+      const size_t cells = (size_t)src->n * c->nsplit_chunks * kChunk;
+      XF_HIP(hipMemsetAsync(gsum, 0, cells * 8, s));
+      XF_HIP(hipMemsetAsync(gtouched, 0, cells, s));
+    } else {
+      XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
+    }
+  }
   hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                      c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
-                     c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, c->gsum, c->gtouched);
+                     c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
+                     src ? src->n : 1u, src ? src->d_win : (const uint32_t *)nullptr,
+                     src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks);
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
-                       c->split_chunk, c->gsum, c->gtouched, c->R, c->M, d_g);
+                       c->split_chunk, gsum, gtouched, c->R, c->M, d_g, src ? src->n : 1u,
+                       src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }
@@ -634,6 +705,64 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
   XF_REQUIRE(T.dim == 1, "cells_lr_grad_update: dim must be 1");
   if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, d_g, s);
   return launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, d_g, s);
+}
+
+// The owner-compute step's gradient + Pushes: the cells hold the rows of `n` workers (windows
+// [d_win[q], d_win[q+1]) are worker q's), d_loss is indexed window * W + row-in-window; every
+// worker's gradient (its sum / d_rows[q]) is its own optimizer step, applied in rank order.
+// d_gsum / d_gtouched: n * nsplit_chunks * kChunk elements of scratch (null when no chunk of
+// the cells is split).
+int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
+                                 uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
+                                 double *d_gsum, uint8_t *d_gtouched, hipStream_t s) {
+  XF_REQUIRE(c && t && d_loss && n && d_win && d_rows, "cells_lr_grad_update_sources: null");
+  XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update_sources: cells are not table rows");
+  XF_REQUIRE(c->nsplit_chunks == 0 || (d_gsum && d_gtouched),
+             "cells_lr_grad_update_sources: no scratch for the split chunks");
+  if (c->nitems == 0) return XF_OK;
+  const TableDev &T = table_dev(t);
+  XF_REQUIRE(T.dim == 1, "cells_lr_grad_update_sources: dim must be 1");
+  CellSources src;
+  src.n = n;
+  src.d_win = d_win;
+  src.d_rows = d_rows;
+  src.gsum = d_gsum;
+  src.gtouched = d_gtouched;
+  if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, nullptr, s, &src);
+  return launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, nullptr, s, &src);
+}
+
+// forward up to the row sums: d_rowsum[window * W + row-in-window] = sum of the row's weights
+// (fp64); the owner-compute step sends them to the rows' workers, who add the owners' sums
+namespace {
+__global__ void __launch_bounds__(kBlock)
+k_sum_partials(const double *__restrict__ partial, uint32_t n, uint32_t W, uint32_t G,
+               double *__restrict__ rowsum) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = t >> 2, q = t & 3u;
+  double a = 0.0;
+  if (r < n) {
+    const uint32_t v = r / W, rin = r - v * W;
+    const double *p = partial + (size_t)v * G * W + rin;
+    for (uint32_t g = q; g < G; g += 4) a += p[(size_t)g * W];
+  }
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
+  if (r < n && q == 0) rowsum[r] = a;
+}
+}  // namespace
+
+int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial,
+                          double *d_rowsum, hipStream_t s) {
+  XF_REQUIRE(c && d_w && d_partial && d_rowsum, "cells_lr_forward_sums: null argument");
+  if (c->R == 0) return XF_OK;
+  hipLaunchKernelGGL(k_lr_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->entries_k,
+                     c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, d_w, d_partial);
+  const uint32_t n = c->nwin * c->W;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)(((size_t)n * 4 + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, s, d_partial, n, c->W, c->G, d_rowsum);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
 }
 
 }  // namespace xf

@@ -39,6 +39,7 @@
 #include "xf_batch.h"
 #include "xf_cells.h"
 #include "xf_common.h"
+#include "xf_device.h"
 #include "xf_scratch.h"
 
 namespace xf {
@@ -46,6 +47,10 @@ int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
 int table_ensure_room(xf_table *t, size_t incoming);
+int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
+                      hipStream_t s, bool allow_grow);
+uint64_t table_row_bound(const xf_table *t);
+const float *table_weights(const xf_table *t);
 bool fm_records_fit(int k);
 size_t fm_record_bytes(size_t U);
 int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
@@ -139,6 +144,22 @@ struct xf_sbatch {
   StepBuf buf[2];
   int flip = 0;
   xf_sharded *owner = nullptr;
+  // ---- XF_SCHEDULE_OWNER: this rank's share of EVERY worker's nonzeros (the ones whose keys it
+  // owns), rows numbered window by window across the workers
+  bool oc = false;
+  uint32_t oW = 1, o_rpad = 0;               // rows per window; windows * oW
+  std::vector<uint32_t> o_rows, o_win;       // per worker: rows of its minibatch; first window
+  std::vector<uint64_t> o_rows64;            // o_rows as exchange counts
+  size_t o_n = 0;                            // nonzeros received
+  Dev<uint64_t> o_keys;                      // their keys (kept: re-resolved after a defrag)
+  Dev<uint32_t> o_rowid;                     // their rows (window-major numbering)
+  Dev<uint32_t> d_win, d_rows, d_rowoff;     // o_win, o_rows, prefix of o_rows on the device
+  Dev<int32_t> d_labels;                     // this worker's labels
+  xf_cells *ocells = nullptr;                // cells over the shard's state rows
+  uint64_t oc_uid = 0, oc_epoch = ~0ull;
+  Dev<double> rowsum, rs_send, rs_recv, gsum;
+  Dev<float> oloss, loss_rep, loss_recv, loss_pad, opctr;
+  Dev<uint8_t> gtouched;
 };
 
 struct xf_sharded {
@@ -187,7 +208,7 @@ int collect_profile(xf_sharded *st) {
 
 #define XF_MARK(i)                                                                \
   do {                                                                            \
-    if (st->profiling && st->cfg.schedule == XF_SCHEDULE_SEQUENTIAL)              \
+    if (st->profiling && st->cfg.schedule != XF_SCHEDULE_STALE1)                  \
       XF_HIP(hipEventRecord(st->pev[i], st->main));                               \
   } while (0)
 
@@ -312,6 +333,257 @@ int flush_pending(xf_sharded *st) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------ XF_SCHEDULE_OWNER
+// rows of worker q, row r  <->  padded number (o_win[q] * W + r): rowoff = prefix of the workers'
+// row counts.  pack: padded -> the workers' rows back to back; pad: the inverse.
+template <typename T, bool PACK>
+__global__ void __launch_bounds__(kBlock)
+k_rows_repack(const T *__restrict__ in, T *__restrict__ out, uint32_t total, uint32_t nsrc,
+              const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ win, uint32_t W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  uint32_t q = 0;
+  while (q + 1 < nsrc && i >= rowoff[q + 1]) ++q;
+  const uint32_t padded = win[q] * W + (i - rowoff[q]);
+  if (PACK) out[i] = in[padded];
+  else
+    out[padded] = in[i];
+}
+
+// received row numbers: worker q's nonzeros sit at [segoff[q], segoff[q+1]); + win[q] * W
+__global__ void __launch_bounds__(kBlock)
+k_rows_to_padded(uint32_t *__restrict__ rowid, size_t n, uint32_t nsrc,
+                 const uint64_t *__restrict__ segoff, const uint32_t *__restrict__ win,
+                 uint32_t W) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (size_t)gridDim.x * blockDim.x) {
+    uint32_t q = 0;
+    while (q + 1 < nsrc && j >= segoff[q + 1]) ++q;
+    rowid[j] += win[q] * W;
+  }
+}
+
+// the worker's side of the forward: add the owners' partial row sums (recv[o * R + r], fp64:
+// exact), then lr_worker.cc:141
+__global__ void __launch_bounds__(kBlock)
+k_owner_finalize(const double *__restrict__ recv, uint32_t nown, uint32_t R,
+                 const int32_t *__restrict__ labels, float *__restrict__ loss,
+                 float *__restrict__ pctr) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double a = 0.0;
+  for (uint32_t o = 0; o < nown; ++o) a += recv[(size_t)o * R + r];
+  const float p = xf::sigmoid_ref((float)a);
+  if (pctr) pctr[r] = p;
+  if (loss) loss[r] = p - (float)labels[r];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_replicate_f32(const float *__restrict__ in, uint32_t n, uint32_t copies,
+                float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n * copies) out[i] = in[i % n];
+}
+
+static int upload_u32(Dev<uint32_t> &d, const std::vector<uint32_t> &h, hipStream_t s) {
+  XF_TRY(d.reserve(h.size()));
+  if (!h.empty())
+    XF_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+  return XF_OK;
+}
+
+// Compile for the owner-compute dataflow: the nonzeros of this worker's rows go to the owners
+// of their keys (once), with the row each belongs to.
+static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
+                         const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                         size_t row_end) {
+  const int W = st->world;
+  XF_REQUIRE(W <= 255, "xf_sharded_compile: owner-compute dataflow with %d workers", W);
+  hipStream_t s = st->main;
+  const uint32_t R = (uint32_t)(row_end - row_begin);
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(NNZ < 0xFFFFFFFFull, "xf_sharded_compile: %zu nonzeros in one minibatch", NNZ);
+  b->oc = true;
+  b->R = R;
+  b->NNZ = (uint32_t)NNZ;
+  b->U = 0;
+  // stable counting sort of the nonzeros by the owner of their key
+  std::vector<uint64_t> cnt(W, 0), off(W + 1, 0);
+  std::vector<uint8_t> own(NNZ);
+  for (size_t j = 0; j < NNZ; ++j) {
+    own[j] = (uint8_t)xf_shard_of(keys[base + j], (uint32_t)W);
+    ++cnt[own[j]];
+  }
+  for (int p = 0; p < W; ++p) off[p + 1] = off[p] + cnt[p];
+  std::vector<uint64_t> sk(NNZ);
+  std::vector<uint32_t> sr(NNZ);
+  {
+    std::vector<uint64_t> at(off.begin(), off.begin() + W);
+    for (uint32_t r = 0; r < R; ++r)
+      for (uint64_t j = rowptr[row_begin + r] - base; j < rowptr[row_begin + r + 1] - base; ++j) {
+        const uint64_t pos = at[own[j]]++;
+        sk[pos] = keys[base + j];
+        sr[pos] = r;
+      }
+  }
+  Dev<uint64_t> d_sk;
+  Dev<uint32_t> d_sr;
+  XF_TRY(d_sk.reserve(NNZ));
+  XF_TRY(d_sr.reserve(NNZ));
+  if (NNZ) {
+    XF_HIP(hipMemcpyAsync(d_sk.p, sk.data(), NNZ * 8, hipMemcpyHostToDevice, s));
+    XF_HIP(hipMemcpyAsync(d_sr.p, sr.data(), NNZ * 4, hipMemcpyHostToDevice, s));
+  }
+  // who sends how much to whom, and how many rows every worker has
+  std::vector<uint64_t> all((size_t)W * W), rows_all(W);
+  XF_TRY(xf_group_allgather_host(st->g, cnt.data(), (size_t)W * 8, all.data()));
+  const uint64_t myR = R;
+  XF_TRY(xf_group_allgather_host(st->g, &myR, 8, rows_all.data()));
+  std::vector<uint64_t> recv(W), segoff(W + 1, 0);
+  for (int p = 0; p < W; ++p) {
+    recv[p] = all[(size_t)p * W + st->rank];
+    segoff[p + 1] = segoff[p] + recv[p];
+  }
+  b->o_n = (size_t)segoff[W];
+  b->n_recv = b->o_n;
+  XF_REQUIRE(b->o_n < 0xFFFFFFFFull, "xf_sharded_compile: %zu nonzeros for one owner", b->o_n);
+  XF_TRY(b->o_keys.reserve(b->o_n));
+  XF_TRY(b->o_rowid.reserve(b->o_n));
+  XF_TRY(a2a(st, d_sk.p, cnt, b->o_keys.p, recv, 8, s));
+  XF_TRY(a2a(st, d_sr.p, cnt, b->o_rowid.p, recv, 4, s));
+  // windows: every worker's rows fill whole windows of one common size
+  uint64_t maxR = 1;
+  for (int p = 0; p < W; ++p) maxR = std::max<uint64_t>(maxR, rows_all[p]);
+  const uint64_t nw = (maxR + xf::kWinMax - 1) / xf::kWinMax;
+  b->oW = (uint32_t)((maxR + nw - 1) / nw);
+  b->o_rows.assign(W, 0);
+  b->o_rows64.assign(W, 0);
+  b->o_win.assign(W + 1, 0);
+  std::vector<uint32_t> rowoff(W + 1, 0);
+  for (int p = 0; p < W; ++p) {
+    b->o_rows[p] = (uint32_t)rows_all[p];
+    b->o_rows64[p] = rows_all[p];
+    b->o_win[p + 1] = b->o_win[p] + (uint32_t)((rows_all[p] + b->oW - 1) / b->oW);
+    rowoff[p + 1] = rowoff[p] + (uint32_t)rows_all[p];
+  }
+  XF_REQUIRE((uint64_t)b->o_win[W] * b->oW < 0x7FFFFFFFull, "xf_sharded_compile: too many rows");
+  b->o_rpad = std::max<uint32_t>(1, b->o_win[W]) * b->oW;
+  XF_TRY(upload_u32(b->d_win, b->o_win, s));
+  XF_TRY(upload_u32(b->d_rows, b->o_rows, s));
+  XF_TRY(upload_u32(b->d_rowoff, rowoff, s));
+  if (b->o_n) {
+    Dev<uint64_t> d_seg;
+    XF_TRY(d_seg.reserve(W + 1));
+    XF_HIP(hipMemcpyAsync(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s, b->o_rowid.p,
+                       b->o_n, (uint32_t)W, d_seg.p, b->d_win.p, b->oW);
+    XF_HIP(hipGetLastError());
+    XF_HIP(hipStreamSynchronize(s));  // d_seg goes out of scope
+  }
+  XF_TRY(b->d_labels.reserve(R));
+  if (R)
+    XF_HIP(hipMemcpyAsync(b->d_labels.p, labels + row_begin, (size_t)R * 4, hipMemcpyHostToDevice,
+                          s));
+  XF_HIP(hipStreamSynchronize(s));  // the host vectors above
+  return XF_OK;
+}
+
+// the cells of the received nonzeros against the shard's current row numbering (keys resolved —
+// inserted on first touch, ftrl.h:56 — here: this is the Pull's key -> row step)
+static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
+  const uint64_t uid = xf::table_uid(st->tw), ep = xf::table_epoch(st->tw);
+  if (b->ocells && b->oc_uid == uid && b->oc_epoch == ep) return XF_OK;
+  hipStream_t s = st->main;
+  if (b->ocells) {
+    XF_HIP(hipStreamSynchronize(s));
+    xf::cells_free(b->ocells);
+    b->ocells = nullptr;
+  }
+  xf::Scratch sc;
+  uint32_t *idx = nullptr;
+  XF_TRY(sc.get(&idx, b->o_n));
+  if (b->o_n) XF_TRY(xf::table_resolve_any(st->tw, b->o_keys.p, b->o_n, idx, s, true));
+  XF_TRY(xf::cells_build(&b->ocells, idx, nullptr, nullptr, b->o_rpad, (uint32_t)b->o_n,
+                         (uint32_t)xf::table_row_bound(st->tw), xf::kCellsTableRows, true, s,
+                         b->o_n ? b->o_rowid.p : nullptr, b->oW));
+  b->ocells->table_uid = uid;
+  b->ocells->epoch = ep;
+  b->oc_uid = uid;
+  b->oc_epoch = ep;
+  const size_t sp = (size_t)st->world * b->ocells->nsplit_chunks * xf::kChunk;
+  XF_TRY(b->gsum.reserve(sp));
+  XF_TRY(b->gtouched.reserve(sp));
+  return XF_OK;
+}
+
+// forward at the owners, row sums to the rows' workers, sigmoid there
+static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_pctr,
+                         hipStream_t s) {
+  const int W = st->world;
+  XF_TRY(ensure_ocells(st, b));
+  const xf_cells *c = b->ocells;
+  XF_TRY(st->partial.reserve(xf::cells_partial_doubles(c)));
+  XF_TRY(b->rowsum.reserve((size_t)c->nwin * c->W));
+  XF_TRY(xf::cells_lr_forward_sums(c, xf::table_weights(st->tw), st->partial.p, b->rowsum.p, s));
+  XF_MARK(1);
+  uint32_t total = 0;
+  for (uint32_t r : b->o_rows) total += r;
+  XF_TRY(b->rs_send.reserve(total));
+  XF_TRY(b->rs_recv.reserve((size_t)W * b->R));
+  if (total)
+    hipLaunchKernelGGL((k_rows_repack<double, true>), dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       b->rowsum.p, b->rs_send.p, total, (uint32_t)W, b->d_rowoff.p, b->d_win.p,
+                       b->oW);
+  XF_HIP(hipGetLastError());
+  const std::vector<uint64_t> mine(W, b->R);
+  XF_TRY(a2a(st, b->rs_send.p, b->o_rows64, b->rs_recv.p, mine, 8, s));
+  if (b->R)
+    hipLaunchKernelGGL(k_owner_finalize, dim3(grid_for(b->R)), dim3(kBlock), 0, s, b->rs_recv.p,
+                       (uint32_t)W, b->R, b->d_labels.p, d_loss, d_pctr);
+  XF_HIP(hipGetLastError());
+  XF_MARK(2);
+  return XF_OK;
+}
+
+// one LRWorker::update of every rank, owner-compute dataflow
+static int step_owner(xf_sharded *st, xf_sbatch *b) {
+  const int W = st->world;
+  hipStream_t s = st->main;
+  XF_REQUIRE(b->oc, "xf_sharded_step: the minibatch was not compiled for the owner-compute "
+             "dataflow");
+  if (st->profiling) XF_TRY(collect_profile(st));
+  XF_MARK(0);
+  XF_TRY(b->oloss.reserve(b->R));
+  XF_TRY(owner_forward(st, b, b->oloss.p, nullptr, s));
+  // the losses to every owner
+  uint32_t total = 0;
+  for (uint32_t r : b->o_rows) total += r;
+  XF_TRY(b->loss_rep.reserve((size_t)W * b->R));
+  XF_TRY(b->loss_recv.reserve(total));
+  XF_TRY(b->loss_pad.reserve(b->o_rpad));
+  if (b->R)
+    hipLaunchKernelGGL(k_replicate_f32, dim3(grid_for((size_t)W * b->R)), dim3(kBlock), 0, s,
+                       b->oloss.p, b->R, (uint32_t)W, b->loss_rep.p);
+  const std::vector<uint64_t> mine(W, b->R);
+  XF_TRY(a2a(st, b->loss_rep.p, mine, b->loss_recv.p, b->o_rows64, 4, s));
+  if (total)
+    hipLaunchKernelGGL((k_rows_repack<float, false>), dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       b->loss_recv.p, b->loss_pad.p, total, (uint32_t)W, b->d_rowoff.p,
+                       b->d_win.p, b->oW);
+  XF_HIP(hipGetLastError());
+  XF_MARK(3);
+  // gradient + the workers' Pushes in rank order, one pass over the shard
+  XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_pad.p, (uint32_t)W,
+                                          b->d_win.p, b->d_rows.p, b->gsum.p, b->gtouched.p, s));
+  XF_MARK(4);
+  XF_MARK(5);
+  XF_MARK(6);
+  if (st->profiling) st->pev_pending = true;
+  return XF_OK;
+}
+
 extern "C" void xf_sharded_config_default(xf_sharded_config *c) {
   memset(c, 0, sizeof(*c));
   c->model = 0;
@@ -330,8 +602,11 @@ extern "C" void xf_sharded_config_default(xf_sharded_config *c) {
 extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded_config *cfg) {
   XF_REQUIRE(out && cfg, "xf_sharded_create: null argument");
   XF_REQUIRE(cfg->model == 0 || cfg->model == 1, "xf_sharded_create: model %d", cfg->model);
-  XF_REQUIRE(cfg->schedule == XF_SCHEDULE_SEQUENTIAL || cfg->schedule == XF_SCHEDULE_STALE1,
+  XF_REQUIRE(cfg->schedule == XF_SCHEDULE_SEQUENTIAL || cfg->schedule == XF_SCHEDULE_STALE1 ||
+                 cfg->schedule == XF_SCHEDULE_OWNER,
              "xf_sharded_create: schedule %d", cfg->schedule);
+  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER || cfg->model == 0,
+             "xf_sharded_create: the owner-compute dataflow is for LR");
   xf_sharded *st = new xf_sharded;
   st->g = g;
   st->cfg = *cfg;
@@ -412,6 +687,7 @@ extern "C" int xf_sbatch_free(xf_sbatch *b) {
   if (b->owner && b->owner->pending == b) (void)flush_pending(b->owner);
   (void)hipDeviceSynchronize();
   if (b->cells) xf::cells_free(b->cells);
+  if (b->ocells) xf::cells_free(b->ocells);
   if (b->b) xf_batch_free(b->b);
   delete b;
   return XF_OK;
@@ -467,6 +743,12 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
       }
       st->seen_upper += b->U;
     }
+    guard.b = nullptr;
+    *out = b;
+    return XF_OK;
+  }
+  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+    XF_TRY(compile_owner(st, b, rowptr, keys, labels, row_begin, row_end));
     guard.b = nullptr;
     *out = b;
     return XF_OK;
@@ -539,6 +821,8 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
     if (st->cfg.model == 0) return xf_lr_step(st->tw, b->b, st->ws, st->main);
     return xf_fm_step(st->tw, st->tv, b->b, st->ws, st->main);
   }
+  if (st->cfg.schedule == XF_SCHEDULE_OWNER) return step_owner(st, b);
+  XF_REQUIRE(!b->oc, "xf_sharded_step: the minibatch was compiled for the owner-compute dataflow");
   if (st->profiling) XF_TRY(collect_profile(st));
   const int flip = b->flip;
   b->flip ^= 1;
@@ -600,6 +884,15 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
     return xf_fm_predict(st->tw, st->tv, b->b, st->ws, pctr_out);
   }
   XF_TRY(xf_sharded_flush(st));
+  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+    XF_REQUIRE(b->oc, "xf_sharded_predict: the minibatch was not compiled for the owner-compute "
+               "dataflow");
+    XF_TRY(b->opctr.reserve(b->R));
+    XF_TRY(owner_forward(st, b, nullptr, b->opctr.p, st->main));
+    XF_HIP(hipStreamSynchronize(st->main));
+    if (b->R) XF_HIP(hipMemcpy(pctr_out, b->opctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
+    return XF_OK;
+  }
   StepBuf &B = b->buf[b->flip];
   Dev<float> pctr;
   XF_TRY(pctr.reserve(b->R));
@@ -662,6 +955,16 @@ extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *ste
   }
   XF_TRY(collect_profile(st));
   for (int i = 0; i < kEvN; ++i) ms_sum[i] = st->ms_sum[i];
+  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+    // recorded in the order of the owner-compute step: forward at the owners | row sums to the
+    // workers + sigmoid | losses to the owners | gradient + Pushes
+    ms_sum[0] = 0;
+    ms_sum[1] = st->ms_sum[1];
+    ms_sum[2] = st->ms_sum[0];
+    ms_sum[3] = st->ms_sum[3];
+    ms_sum[4] = st->ms_sum[2];
+    ms_sum[5] = 0;
+  }
   *steps = st->steps_timed;
   return XF_OK;
 }
@@ -669,6 +972,9 @@ extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *ste
 extern "C" int xf_sharded_set_schedule(xf_sharded *st, int schedule) {
   XF_REQUIRE(st && (schedule == XF_SCHEDULE_SEQUENTIAL || schedule == XF_SCHEDULE_STALE1),
              "xf_sharded_set_schedule: bad argument");
+  XF_REQUIRE(st->cfg.schedule != XF_SCHEDULE_OWNER,
+             "xf_sharded_set_schedule: minibatches compiled for the owner-compute dataflow "
+             "cannot be stepped any other way");
   XF_TRY(xf_sharded_flush(st));
   st->cfg.schedule = schedule;
   return XF_OK;

@@ -1399,6 +1399,8 @@ int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hip
 
 // used by xf_model.hip / xf_cells.hip
 const TableDev &table_dev(const xf_table *t) { return t->T; }
+uint64_t table_row_bound(const xf_table *t) { return t->T.max_rows + 1; }  // > every state row
+const float *table_weights(const xf_table *t) { return t->T.w; }
 int table_dim(const xf_table *t) { return t->T.dim; }
 // static part of the owner's merged update (valid for one row numbering of `t`)
 int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,

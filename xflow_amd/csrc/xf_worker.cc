@@ -469,6 +469,7 @@ int Worker::set_param(const char *name, const char *value) {
   } else if (n == "schedule") {
     if (!strcmp(value, "sequential")) schedule = XF_SCHEDULE_SEQUENTIAL;
     else if (!strcmp(value, "stale1")) schedule = XF_SCHEDULE_STALE1;
+    else if (!strcmp(value, "owner")) schedule = XF_SCHEDULE_OWNER;
     else
       return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential or stale1");
   }
