@@ -51,8 +51,9 @@ def parse_args():
                     help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
     ap.add_argument("--key-build-steps", type=int, default=10,
                     help="extra timed steps that include the GPU key build (0 = skip)")
-    ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1"],
-                    help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped)")
+    ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1", "owner"],
+                    help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped).  "
+                         "owner = the owner-compute dataflow (LR, native driver)")
     ap.add_argument("--no-defrag", action="store_true")
     ap.add_argument("--driver", default="native", choices=["native", "python"],
                     help="N>1: the C++ sharded trainer over xf_group (default) or the Python "
@@ -628,7 +629,8 @@ def main():
     # the C++ sharded trainer takes the fused single-shard step at world 1
     one_shard = world == 1 and not (args.force_sharded and
                                     (args.general_path or args.driver == "python"))
-    fused = args.model == "lr" and one_shard
+    # (the owner-compute dataflow runs the same table-resident kernels at the key owners)
+    fused = args.model == "lr" and (one_shard or schedule == "owner")
     per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused,
                                     fused_fm=(args.model == "fm" and one_shard))
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])

@@ -37,6 +37,10 @@
 
 #include "xf_common.h"
 
+namespace xf {
+int device_copy(void *dst, const void *src, size_t bytes, hipStream_t s);  // xf_table.hip
+}
+
 namespace {
 
 // ---- the slice of rccl.h this file uses (the library is dlopen'ed)
@@ -469,8 +473,8 @@ static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t>
                           const std::vector<size_t> &ro, hipStream_t s) {
   const int W = g->world;
   const size_t self = so[g->rank + 1] - so[g->rank];
-  if (self)  // the slice that stays: a plain copy, no collective
-    XF_HIP(hipMemcpyAsync(rb + ro[g->rank], sb + so[g->rank], self, hipMemcpyDeviceToDevice, s));
+  if (self)  // the slice that stays: a copy kernel on the stream, no collective
+    XF_TRY(xf::device_copy(rb + ro[g->rank], sb + so[g->rank], self, s));
   if (W == 1) return XF_OK;
   int rc = g->rccl.GroupStart();
   for (int p = 0; p < W && !rc; ++p) {

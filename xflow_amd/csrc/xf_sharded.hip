@@ -180,10 +180,19 @@ struct xf_sharded {
   int pending_flip = 0;
   // per-stage timing (sequential schedule only)
   bool profiling = false;
-  hipEvent_t pev[kEvN + 1] = {};
+  // a ring of event sets, every kProfileEvery-th step records: the host never waits for the
+  // step it has just launched (see xf_workspace)
+  static constexpr int kEvSets = 8;
+  static constexpr long kProfileEvery = 4;
+  struct EvSet {
+    hipEvent_t ev[kEvN + 1] = {};
+    bool pending = false;
+  } sets[kEvSets];
+  int cur = 0;
+  long step_no = 0;
+  bool rec = false;
   double ms_sum[kEvN] = {};
   long steps_timed = 0;
-  bool pev_pending = false;
 };
 
 namespace {
@@ -193,23 +202,34 @@ int a2a(xf_sharded *st, const void *send, const std::vector<uint64_t> &sc, void 
   return xf_group_alltoallv(st->g, send, sc.data(), recv, rc.data(), elem_bytes, 0, (void *)s);
 }
 
-int collect_profile(xf_sharded *st) {
-  if (!st->pev_pending) return XF_OK;
-  XF_HIP(hipEventSynchronize(st->pev[kEvN]));
+int collect_set(xf_sharded *st, xf_sharded::EvSet &e) {
+  if (!e.pending) return XF_OK;
+  XF_HIP(hipEventSynchronize(e.ev[kEvN]));
   for (int i = 0; i < kEvN; ++i) {
     float ms = 0.f;
-    XF_HIP(hipEventElapsedTime(&ms, st->pev[i], st->pev[i + 1]));
+    XF_HIP(hipEventElapsedTime(&ms, e.ev[i], e.ev[i + 1]));
     st->ms_sum[i] += ms;
   }
   ++st->steps_timed;
-  st->pev_pending = false;
+  e.pending = false;
   return XF_OK;
+}
+int collect_profile(xf_sharded *st) {  // every set still pending
+  for (auto &e : st->sets) XF_TRY(collect_set(st, e));
+  return XF_OK;
+}
+// a step begins: does it record, and into which set
+int begin_profiled_step(xf_sharded *st) {
+  st->rec = st->profiling && st->cfg.schedule != XF_SCHEDULE_STALE1 &&
+            st->step_no++ % xf_sharded::kProfileEvery == 0;
+  if (!st->rec) return XF_OK;
+  st->cur = (st->cur + 1) % xf_sharded::kEvSets;
+  return collect_set(st, st->sets[st->cur]);
 }
 
 #define XF_MARK(i)                                                                \
   do {                                                                            \
-    if (st->profiling && st->cfg.schedule != XF_SCHEDULE_STALE1)                  \
-      XF_HIP(hipEventRecord(st->pev[i], st->main));                               \
+    if (st->rec) XF_HIP(hipEventRecord(st->sets[st->cur].ev[i], st->main));       \
   } while (0)
 
 // owner side of the Pull: state rows of the keys this rank owns (resolved once per row
@@ -553,7 +573,7 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   hipStream_t s = st->main;
   XF_REQUIRE(b->oc, "xf_sharded_step: the minibatch was not compiled for the owner-compute "
              "dataflow");
-  if (st->profiling) XF_TRY(collect_profile(st));
+  XF_TRY(begin_profiled_step(st));
   XF_MARK(0);
   XF_TRY(b->oloss.reserve(b->R));
   XF_TRY(owner_forward(st, b, b->oloss.p, nullptr, s));
@@ -580,7 +600,7 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   XF_MARK(4);
   XF_MARK(5);
   XF_MARK(6);
-  if (st->profiling) st->pev_pending = true;
+  if (st->rec) st->sets[st->cur].pending = true;
   return XF_OK;
 }
 
@@ -667,8 +687,9 @@ extern "C" int xf_sharded_destroy(xf_sharded *st) {
   if (st->side) (void)hipStreamDestroy(st->side);
   for (hipEvent_t e : {st->ev_pulled, st->ev_graded, st->ev_applied})
     if (e) (void)hipEventDestroy(e);
-  for (auto &e : st->pev)
-    if (e) (void)hipEventDestroy(e);
+  for (auto &e : st->sets)
+    for (auto &ev : e.ev)
+      if (ev) (void)hipEventDestroy(ev);
   delete st;
   return XF_OK;
 }
@@ -823,7 +844,7 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
   }
   if (st->cfg.schedule == XF_SCHEDULE_OWNER) return step_owner(st, b);
   XF_REQUIRE(!b->oc, "xf_sharded_step: the minibatch was compiled for the owner-compute dataflow");
-  if (st->profiling) XF_TRY(collect_profile(st));
+  XF_TRY(begin_profiled_step(st));
   const int flip = b->flip;
   b->flip ^= 1;
   StepBuf &B = b->buf[flip];
@@ -836,7 +857,7 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
     XF_MARK(kEvA2aG + 1);
     XF_TRY(back_apply(st, b, B, st->main));
     XF_MARK(kEvUpdate + 1);
-    if (st->profiling) st->pev_pending = true;
+    if (st->rec) st->sets[st->cur].pending = true;
     return XF_OK;
   }
   // ---- stale1
@@ -928,14 +949,16 @@ extern "C" int xf_sharded_check(xf_sharded *st) {
 extern "C" int xf_sharded_profile(xf_sharded *st, int enable) {
   XF_REQUIRE(st, "xf_sharded_profile: null trainer");
   if (st->fused) return xf_workspace_profile(st->ws, enable);
-  if (enable && !st->pev[0])
-    for (auto &e : st->pev) XF_HIP(hipEventCreate(&e));
+  if (enable && !st->sets[0].ev[0])
+    for (auto &e : st->sets)
+      for (auto &ev : e.ev) XF_HIP(hipEventCreate(&ev));
   if (!enable) XF_TRY(collect_profile(st));
   st->profiling = enable != 0;
   if (enable) {
     for (auto &m : st->ms_sum) m = 0.0;
     st->steps_timed = 0;
-    st->pev_pending = false;
+    st->step_no = 0;
+    for (auto &e : st->sets) e.pending = false;
   }
   return XF_OK;
 }

@@ -40,6 +40,25 @@
 
 namespace {
 
+__global__ void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {  // four loads in flight per lane
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+__global__ void k_copy1(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                        size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 constexpr int kBlock = 256;
 constexpr double kMaxLoad = 0.75;  // state rows allocated per index position
 
@@ -1399,6 +1418,22 @@ int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hip
 
 // used by xf_model.hip / xf_cells.hip
 const TableDev &table_dev(const xf_table *t) { return t->T; }
+// device-to-device copy by a kernel on the caller's stream.  (hipMemcpyAsync picks its engine
+// itself: a 25 MB copy in the middle of a step was seen at 2.3 TB/s — blit kernel — in one run
+// and at 0.27 TB/s with ~80 us of cross-queue waits around it — SDMA — in the next.)
+int device_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return XF_OK;
+  if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15u) == 0) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy16, dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint4 *)src,
+                       (uint4 *)dst, n);
+  } else {
+    hipLaunchKernelGGL(k_copy1, dim3(grid_for(bytes)), dim3(kBlock), 0, s,
+                       (const unsigned char *)src, (unsigned char *)dst, bytes);
+  }
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
 uint64_t table_row_bound(const xf_table *t) { return t->T.max_rows + 1; }  // > every state row
 const float *table_weights(const xf_table *t) { return t->T.w; }
 int table_dim(const xf_table *t) { return t->T.dim; }
