@@ -67,6 +67,8 @@ def parse_args():
                     help="with --force-sharded at N=1: run the N>1 code path (owner gather, "
                          "self all-to-all-v, index-mode kernels, merged owner update) instead of "
                          "the fused step, to time its stages on one GPU")
+    ap.add_argument("--no-owner-leg", action="store_true",
+                    help="N>1: skip the supplementary run of the owner-compute dataflow")
     ap.add_argument("--exp-knob", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
@@ -612,6 +614,55 @@ def main():
                                   "parity tests pin"}
     except Exception as e:  # the throughput line must not depend on this extra
         logloss = {"error": str(e)}
+    # Supplementary leg (N > 1, LR, C++ trainer): the same K steps on the OWNER-COMPUTE dataflow
+    # (XF_SCHEDULE_OWNER: nonzeros at the key owners, row sums and losses exchanged) on a second
+    # trainer over the same group.  Not `value`; every rank takes part; a failure is reported,
+    # not raised (it is symmetric across the ranks: the condition depends on the arguments only).
+    owner_leg = None
+    if group is not None and args.model == "lr" and schedule != "owner" and not args.no_owner_leg \
+            and (world > 1 or args.general_path):
+        try:
+            ot = NativeSharded(group, args, "owner", capacity)
+            oc = [ot.compile(*b) for b in batches]
+            for c in oc:
+                ot.predict(c)
+            ot.check()
+            ot.defrag()
+            for c in oc:
+                ot.predict(c)
+            for i in range(args.warmup):
+                ot.step(oc[i % len(oc)])
+            ot.check()
+            barrier()
+            ot.profile(True)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                ot.step(oc[(args.warmup + i) % len(oc)])
+            ot.flush()
+            barrier()
+            odt = allmax(time.perf_counter() - t0)
+            oms, osteps = ot.profile_read()
+            ot.profile(False)
+            ot.check()
+            onnz = group.allgather(np.array([np.mean([c.n_owned for c in oc])], np.float64)).ravel()
+            owner_leg = {
+                "value": R * world * args.steps / odt, "unit": "examples/sec",
+                "ms_per_step": odt / args.steps * 1e3, "steps": args.steps,
+                "kernels_ms": {k: v / max(osteps, 1) for k, v in
+                               (("forward_at_owners", oms["forward"]),
+                                ("row_sums_to_workers_and_sigmoid", oms["a2a_weights"]),
+                                ("losses_to_owners", oms["a2a_grads"]),
+                                ("gradient_and_pushes_at_owners", oms["gradient"]))},
+                "nonzeros_per_owner_by_rank": [float(x) for x in onnz],
+                "what": "XF_SCHEDULE_OWNER: a minibatch's nonzeros live at the key owners "
+                        "(sent once, when it is compiled); per step the owners run the "
+                        "table-resident forward and gradient+Push and the ranks exchange fp64 "
+                        "partial row sums and losses (~%d bytes per rank and step) instead of "
+                        "a weight and a gradient per key.  Same results as the sequential "
+                        "schedule (tests/test_gpu_sharded.py)" % (12 * R * max(world - 1, 1))}
+            del oc, ot
+        except Exception as e:
+            owner_leg = {"error": str(e)}
     imbalance = None
     if group is not None:
         own = group.allgather(np.array([np.mean([o for o in owned])], np.float64)).ravel()
@@ -694,6 +745,7 @@ def main():
             "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})(
             NNZ * (12 + (4 * args.k if args.model == "fm" else 0)) + 8 * R,
             sum(avg_ms.get(k, 0.0) for k in ("resolve", "gather", "a2a_weights", "forward"))),
+        "owner_compute": owner_leg,
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }

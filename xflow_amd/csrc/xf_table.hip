@@ -1425,7 +1425,8 @@ int device_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return XF_OK;
   if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15u) == 0) {
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(k_copy16, dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint4 *)src,
+    const size_t blocks = std::min<size_t>(std::max<size_t>(n / (kBlock * 4), 1), 4096);
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint4 *)src,
                        (uint4 *)dst, n);
   } else {
     hipLaunchKernelGGL(k_copy1, dim3(grid_for(bytes)), dim3(kBlock), 0, s,
