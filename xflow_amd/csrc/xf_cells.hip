@@ -363,7 +363,7 @@ __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on,
 constexpr int kGradE = XF_GRAD_E;  // entries per lane and round
 constexpr uint32_t kGradWin = 32;  // windows whose slice bounds fit the LDS table
 
-template <int OPT, int MODE>
+template <int OPT, int MODE, bool SRC>
 __global__ void __launch_bounds__(kBlock)
 k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
@@ -387,11 +387,11 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
   // step, the workers' steps applied in rank order — one accumulate + update phase
   // per worker inside the same pass over the chunk, the state row read and written by the same
   // thread every phase (it stays in L2 in between).  One source: the whole minibatch.
-  const uint32_t ns = src_win ? nsrc : 1u;
+  const uint32_t ns = SRC ? nsrc : 1u;
   for (uint32_t q = 0; q < ns; ++q) {
-  const uint32_t wbeg = src_win ? src_win[q] : 0u, wend = src_win ? src_win[q + 1] : nwin;
-  const uint32_t Rq = src_win ? src_rows[q] : R;
-  if (wbeg == wend) continue;  // workgroup-uniform
+  const uint32_t wbeg = SRC ? src_win[q] : 0u, wend = SRC ? src_win[q + 1] : nwin;
+  const uint32_t Rq = SRC ? src_rows[q] : R;
+  if (SRC && wbeg == wend) continue;  // workgroup-uniform
   // The item's share of the chunk's cells as ONE index space: windows v0, v0+1, ... side
   // by side (cum = running entry counts), so that a thread's loads of a round — entries, then
   // the losses they point at — are all in flight together instead of window after window.
@@ -444,16 +444,20 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (touched[k]) {
         unsafeAtomicAdd(&gsum[slot * kChunk + k], acc[k]);
         gtouched[slot * kChunk + k] = 1;
-        acc[k] = 0.0;
-        touched[k] = 0;
+        if (SRC) {
+          acc[k] = 0.0;
+          touched[k] = 0;
+        }
       }
     continue;
   }
   for (uint32_t k = tid; k < kChunk; k += kBlock) {
     if (!touched[k]) continue;
     const double sum = acc[k];
-    acc[k] = 0.0;
-    touched[k] = 0;
+    if (SRC) {  // the next worker's phase starts from zero
+      acc[k] = 0.0;
+      touched[k] = 0;
+    }
     const size_t idx = (size_t)c * kChunk + k;
     if (idx >= M) continue;
     const float g = (float)((double)(float)sum / (1.0 * Rq));  // lr_worker.cc:117
@@ -673,11 +677,16 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
       XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
     }
   }
-  hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE>), dim3(c->nitems), dim3(kBlock), 0, s, T,
-                     c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
-                     c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
-                     src ? src->n : 1u, src ? src->d_win : (const uint32_t *)nullptr,
-                     src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks);
+  if (src)
+    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
+                       c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                       c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
+                       src->n, src->d_win, src->d_rows, c->nsplit_chunks);
+  else
+    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
+                       T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                       c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks);
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
