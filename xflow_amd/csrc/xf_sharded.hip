@@ -476,7 +476,20 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   // windows: every worker's rows fill whole windows of one common size
   uint64_t maxR = 1;
   for (int p = 0; p < W; ++p) maxR = std::max<uint64_t>(maxR, rows_all[p]);
-  const uint64_t nw = (maxR + xf::kWinMax - 1) / xf::kWinMax;
+  // windows per worker: as few as the LDS allows, or up to two more when that fills the chip
+  // better (the forward runs windows x G workgroups, G = 8 * (32 / windows): 8 workers x 3
+  // windows would leave a quarter of the CUs idle, 8 x 4 uses all of them)
+  uint64_t nw = (maxR + xf::kWinMax - 1) / xf::kWinMax;
+  {
+    auto groups = [&](uint64_t per_worker) {
+      const uint64_t total = per_worker * (uint64_t)W;
+      return total <= 32 ? total * ((32 / total) * 8) : (uint64_t)256;
+    };
+    uint64_t best = nw;
+    for (uint64_t c = nw + 1; c <= nw + 2 && c <= maxR; ++c)
+      if (groups(c) > groups(best)) best = c;
+    nw = best;
+  }
   b->oW = (uint32_t)((maxR + nw - 1) / nw);
   b->o_rows.assign(W, 0);
   b->o_rows64.assign(W, 0);
