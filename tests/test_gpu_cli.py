@@ -43,7 +43,8 @@ def test_cli_roles_without_a_process_return_at_once(sample_prefixes):
         assert out.returncode == 0 and "no %s process" % role in out.stdout
 
 
-def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, tmp_path):
+@pytest.mark.parametrize("schedule", ["sequential", "owner"])
+def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, tmp_path, schedule):
     """scripts/local.sh 2 2 xflow_lr ...: worker r trains on small_train-0000r (identical files,
     SURVEY 2 row 18), both shards of the table take both workers' pushes in rank order, rank 0
     scores the test file against the whole table.  Checkpoint (one file per shard) and metric
@@ -52,7 +53,8 @@ def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, t
     ckpt = str(tmp_path / "model")
     env = dict(os.environ, DMLC_PS_ROOT_PORT=str(free_port()))
     out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "local.sh"), "2", "2", CLI, tr, te,
-                          "0", "3", "transport=host", "capacity=256", "model_out=" + ckpt,
+                          "0", "3", "transport=host", "capacity=256", "schedule=" + schedule,
+                          "model_out=" + ckpt,
                           "pred_path=" + str(tmp_path / "pred.txt")],
                          capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout + out.stderr
@@ -101,3 +103,6 @@ def test_bench_runs_two_ranks_and_reports_them(tmp_path):
     assert len(line["config"]["shard_imbalance"]["owned_keys_per_step_by_rank"]) == 2
     assert set(line["kernels_ms"]) >= {"a2a_weights", "a2a_grads", "forward", "gradient"}
     assert abs(line["logloss"]["natural"] - 0.693) < 0.01
+    # the supplementary leg on the owner-compute dataflow ran on both ranks too
+    oc = line["owner_compute"]
+    assert "error" not in oc and oc["value"] > 0 and len(oc["nonzeros_per_owner_by_rank"]) == 2
