@@ -26,7 +26,23 @@ from .test_sharded_gloo import _data, _simulate
 pytestmark = pytest.mark.gpu
 
 
-def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q):
+def _big_data(rank, step):
+    """minibatches big enough for several row windows per worker (17 408 rows fit one), rows per
+    worker that differ, and a key space small enough that chunks of 2048 state rows collect more
+    than 8192 nonzeros (they are cut into slices that meet in per-worker accumulators)"""
+    rng = np.random.RandomState(77 + 1000 * step + rank)
+    R = 20000 + 3000 * rank
+    keytab = capi.hash_decimal_range(0, 50000)
+    lens = rng.randint(0, 13, size=R)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    keys = keytab[np.minimum(rng.zipf(1.3, size=int(lens.sum())) - 1, 49999)
+                  if step % 2 else rng.randint(0, 50000, size=int(lens.sum()))]
+    return rowptr, keys, rng.randint(0, 2, size=R).astype(np.int32)
+
+
+def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q,
+          data="small"):
+    _data = _big_data if data == "big" else globals()["_data"]
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = C.c_int(0)
@@ -66,12 +82,14 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
         q.put((rank, traceback.format_exc()))
 
 
-def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps=4):
+def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps=4,
+         data="small"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     ps = [ctx.Process(target=_rank, args=(r, world, port, transport, model, optimizer, schedule,
-                                          steps, str(outdir), save, q)) for r in range(world)]
+                                          steps, str(outdir), save, q, data))
+          for r in range(world)]
     for p in ps:
         p.start()
     res = [q.get(timeout=300) for _ in ps]
@@ -132,6 +150,35 @@ def test_owner_compute_dataflow_ranks_share_one_gpu(tmp_path, world, optimizer):
     (tables after 4 steps with a defrag in between, and the forward of a fifth minibatch)"""
     _run(world, capi.TRANSPORT_HOST, "lr", optimizer, "owner", tmp_path)
     _check_against_oracle(world, "lr", optimizer, "sequential", tmp_path)
+
+
+@pytest.mark.parametrize("schedule", ["owner", "sequential"])
+def test_several_row_windows_per_worker_and_split_chunks(tmp_path, schedule):
+    """two workers with 20 000 and 23 000 rows: more than one row window each (the owner numbers
+    them window by window, a window belongs to one worker), chunks with more than 8192 nonzeros
+    (slices, per-worker accumulators in HBM, the workers' steps in rank order in the finish
+    kernel), uniform and power-law minibatches — against the oracle on the rank-ordered
+    schedule, both dataflows"""
+    world, steps = 2, 3
+    _run(world, capi.TRANSPORT_HOST, "lr", "ftrl", schedule, tmp_path, steps=steps, data="big")
+    with O.sum_mode(1):
+        w = O.Store(O.OPT_FTRL, 1)
+        for s in range(steps):
+            obs = [O.Batch(*_big_data(r, s)) for r in range(world)]
+            pulled = [w.pull(ob.ukeys) for ob in obs]
+            grads = [ob.lr_grad(ob.lr_loss(pw)[0]) for ob, pw in zip(obs, pulled)]
+            for ob, g in zip(obs, grads):
+                w.push(ob.ukeys, g)
+        parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+        ks, ws, ns, zs = w.export()
+        k = np.concatenate([p["w_k"] for p in parts])
+        order = np.argsort(k)
+        same(k[order], ks)
+        for f, ref in (("w_w", ws), ("w_n", ns), ("w_z", zs)):
+            same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)
+        for r in range(world):
+            ob = O.Batch(*_big_data(r, 99))
+            same(parts[r]["loss"], ob.lr_loss(w.pull(ob.ukeys))[0])
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
