@@ -422,6 +422,30 @@ class NativeSharded:
         self.schedule = schedule
 
 
+def owner_dataflow_smoke(group, args, keytab):
+    """two tiny minibatches through a private trainer on XF_SCHEDULE_OWNER; True when every rank
+    got through (a failure is the same on all ranks: they agree over the bootstrap)"""
+    ok = 1.0
+    try:
+        rng = np.random.RandomState(11 + group.rank)
+        t = NativeSharded(group, args, "owner", 1 << 14)
+        for _ in range(2):
+            rows, nnz = 64, 8
+            rp = np.arange(rows + 1, dtype=np.uint64) * np.uint64(nnz)
+            b = t.compile(rp, keytab[rng.randint(0, len(keytab), size=rows * nnz)],
+                          rng.randint(0, 2, size=rows).astype(np.int32))
+            t.step(b)
+            p = np.asarray(t.predict(b))
+            assert p.shape == (rows,) and np.all((p > 0) & (p <= 1))
+        t.check()
+        del b, t
+    except Exception as e:
+        print("bench.py: owner-compute dataflow not usable on rank %d: %s" % (group.rank, e),
+              file=sys.stderr)
+        ok = 0.0
+    return bool(group.allgather(np.array([ok], np.float64)).min() > 0)
+
+
 def make_group(rank, world, local_rank, transport="rccl"):
     """xf_group over RCCL, with a device-side self-test: every rank sends its number to every
     peer and checks what arrives.  The bootstrap port sits next to the launcher's
@@ -492,8 +516,19 @@ def main():
     keytab = make_key_table(nkeys_total)
     batches = make_batches(args, rank, nkeys_total, keytab)
 
-    schedule = (args.schedule or "stale1") if sharded else "sequential"
     capacity = int(args.keys_per_gpu / args.load_factor) + 1024
+    # N > 1, LR, C++ trainer: `value` is measured on the owner-compute dataflow (nonzeros at the
+    # key owners, row sums and losses exchanged: DESIGN.md 6) when a two-minibatch smoke run of
+    # it succeeds on every rank; the weight/gradient exchange (stale1) is then the supplementary
+    # leg.  FM, the Python driver and --schedule run what they say.
+    if not sharded:
+        schedule = "sequential"
+    elif args.schedule:
+        schedule = args.schedule
+    elif args.model == "lr" and group is not None and owner_dataflow_smoke(group, args, keytab):
+        schedule = "owner"
+    else:
+        schedule = "stale1"
     if not sharded:
         from xflow_amd.single import SingleGpuTrainer
         trainer = SingleGpuTrainer(model=args.model, optimizer=args.optimizer, k=args.k,
@@ -619,10 +654,11 @@ def main():
     # trainer over the same group.  Not `value`; every rank takes part; a failure is reported,
     # not raised (it is symmetric across the ranks: the condition depends on the arguments only).
     owner_leg = None
-    if group is not None and args.model == "lr" and schedule != "owner" and not args.no_owner_leg \
+    other = "stale1" if schedule == "owner" else "owner"
+    if group is not None and args.model == "lr" and not args.no_owner_leg \
             and (world > 1 or args.general_path):
         try:
-            ot = NativeSharded(group, args, "owner", capacity)
+            ot = NativeSharded(group, args, other, capacity)
             oc = [ot.compile(*b) for b in batches]
             for c in oc:
                 ot.predict(c)
@@ -644,22 +680,30 @@ def main():
             oms, osteps = ot.profile_read()
             ot.profile(False)
             ot.check()
-            onnz = group.allgather(np.array([np.mean([c.n_owned for c in oc])], np.float64)).ravel()
-            owner_leg = {
-                "value": R * world * args.steps / odt, "unit": "examples/sec",
-                "ms_per_step": odt / args.steps * 1e3, "steps": args.steps,
-                "kernels_ms": {k: v / max(osteps, 1) for k, v in
-                               (("forward_at_owners", oms["forward"]),
-                                ("row_sums_to_workers_and_sigmoid", oms["a2a_weights"]),
-                                ("losses_to_owners", oms["a2a_grads"]),
-                                ("gradient_and_pushes_at_owners", oms["gradient"]))},
-                "nonzeros_per_owner_by_rank": [float(x) for x in onnz],
-                "what": "XF_SCHEDULE_OWNER: a minibatch's nonzeros live at the key owners "
-                        "(sent once, when it is compiled); per step the owners run the "
-                        "table-resident forward and gradient+Push and the ranks exchange fp64 "
-                        "partial row sums and losses (~%d bytes per rank and step) instead of "
-                        "a weight and a gradient per key.  Same results as the sequential "
-                        "schedule (tests/test_gpu_sharded.py)" % (12 * R * max(world - 1, 1))}
+            leg = {"value": R * world * args.steps / odt, "unit": "examples/sec",
+                   "ms_per_step": odt / args.steps * 1e3, "steps": args.steps}
+            if other == "owner":
+                onnz = group.allgather(
+                    np.array([np.mean([c.n_owned for c in oc])], np.float64)).ravel()
+                leg.update({
+                    "kernels_ms": {k: v / max(osteps, 1) for k, v in
+                                   (("forward_at_owners", oms["forward"]),
+                                    ("row_sums_to_workers_and_sigmoid", oms["a2a_weights"]),
+                                    ("losses_to_owners", oms["a2a_grads"]),
+                                    ("gradient_and_pushes_at_owners", oms["gradient"]))},
+                    "nonzeros_per_owner_by_rank": [float(x) for x in onnz],
+                    "what": "XF_SCHEDULE_OWNER: a minibatch's nonzeros live at the key owners "
+                            "(sent once, when it is compiled); per step the owners run the "
+                            "table-resident forward and gradient+Push and the ranks exchange "
+                            "fp64 partial row sums and losses (~%d bytes per rank and step) "
+                            "instead of a weight and a gradient per key.  Same results as the "
+                            "sequential schedule (tests/test_gpu_sharded.py)"
+                            % (12 * R * max(world - 1, 1))})
+            else:
+                leg["what"] = "the same K steps on north_star's dataflow: weights and " \
+                              "gradients all-to-all-v per step, schedule stale1 (Push(t) on a " \
+                              "second stream)"
+            owner_leg = leg
             del oc, ot
         except Exception as e:
             owner_leg = {"error": str(e)}
@@ -713,8 +757,10 @@ def main():
                    "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
                    "unique_keys_per_gpu_batch": U, "table_load_factor": args.load_factor,
                    "distinct_batches": len(compiled),
-                   "parallelism": ("key-range sharded table x%d, all-to-all of weights and "
-                                   "gradients per step, schedule %s" % (world, schedule))
+                   "parallelism": ("key-range sharded table x%d, %s" % (
+                       world, "owner-compute dataflow: nonzeros at the key owners, fp64 partial "
+                              "row sums and losses all-to-all-v per step" if schedule == "owner"
+                       else "all-to-all of weights and gradients per step, schedule %s" % schedule))
                    if sharded else "single shard",
                    "exchange": exchange,
                    "transport": (None if group is None else
@@ -745,7 +791,7 @@ def main():
             "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})(
             NNZ * (12 + (4 * args.k if args.model == "fm" else 0)) + 8 * R,
             sum(avg_ms.get(k, 0.0) for k in ("resolve", "gather", "a2a_weights", "forward"))),
-        "owner_compute": owner_leg,
+        ("exchange_dataflow" if schedule == "owner" else "owner_compute"): owner_leg,
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }
