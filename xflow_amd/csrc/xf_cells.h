@@ -97,10 +97,12 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
 // owner-compute step (xf_sharded.hip): forward up to the fp64 row sums, and the gradient with
 // the Pushes of several workers applied in rank order (see xf_cells.hip)
 int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial,
+                          const uint32_t *d_out_base, const uint32_t *d_out_rows,
                           double *d_rowsum, hipStream_t stream);
 int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
                                  uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
-                                 double *d_gsum, uint8_t *d_gtouched, hipStream_t stream);
+                                 const uint32_t *d_loss_base, double *d_gsum,
+                                 uint8_t *d_gtouched, hipStream_t stream);
 
 }  // namespace xf
 

@@ -371,7 +371,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ item_dump, const float *__restrict__ loss,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
                 uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
-                const uint32_t *__restrict__ src_rows, uint32_t nsplit) {
+                const uint32_t *__restrict__ src_rows, uint32_t nsplit,
+                const uint32_t *__restrict__ loss_base) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
@@ -430,7 +431,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
 #pragma unroll
       for (int q = 0; q < kGradE; ++q)
         l[q] = ent[q] != 0xFFFFFFFFu
-                   ? loss[(size_t)(v0 + vq[q]) * W + ((ent[q] >> kChunkBits) & kRowMask)]
+                   ? loss[(SRC ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
+                          ((ent[q] >> kChunkBits) & kRowMask)]
                    : 0.0f;
 #pragma unroll
       for (int q = 0; q < kGradE; ++q)
@@ -659,6 +661,7 @@ struct CellSources {
   uint32_t n = 0;
   const uint32_t *d_win = nullptr;   // [n + 1] first window of every worker
   const uint32_t *d_rows = nullptr;  // [n] rows of every worker's minibatch
+  const uint32_t *d_loss_base = nullptr;  // [nwin] where a window's losses start in d_loss
   double *gsum = nullptr;            // [n * nsplit_chunks * kChunk] split chunks' sums per worker
   uint8_t *gtouched = nullptr;       // [n * nsplit_chunks * kChunk]
 };
@@ -681,12 +684,13 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
-                       src->n, src->d_win, src->d_rows, c->nsplit_chunks);
+                       src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base);
   else
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
                        T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks);
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
+                       (const uint32_t *)nullptr);
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
@@ -717,14 +721,17 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
 }
 
 // The owner-compute step's gradient + Pushes: the cells hold the rows of `n` workers (windows
-// [d_win[q], d_win[q+1]) are worker q's), d_loss is indexed window * W + row-in-window; every
+// [d_win[q], d_win[q+1]) are worker q's), the losses of window v start at d_loss[d_loss_base[v]]
+// (the workers' losses back to back, as they arrive); every
 // worker's gradient (its sum / d_rows[q]) is its own optimizer step, applied in rank order.
 // d_gsum / d_gtouched: n * nsplit_chunks * kChunk elements of scratch (null when no chunk of
 // the cells is split).
 int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
                                  uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
-                                 double *d_gsum, uint8_t *d_gtouched, hipStream_t s) {
-  XF_REQUIRE(c && t && d_loss && n && d_win && d_rows, "cells_lr_grad_update_sources: null");
+                                 const uint32_t *d_loss_base, double *d_gsum,
+                                 uint8_t *d_gtouched, hipStream_t s) {
+  XF_REQUIRE(c && t && d_loss && n && d_win && d_rows && d_loss_base,
+             "cells_lr_grad_update_sources: null");
   XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update_sources: cells are not table rows");
   XF_REQUIRE(c->nsplit_chunks == 0 || (d_gsum && d_gtouched),
              "cells_lr_grad_update_sources: no scratch for the split chunks");
@@ -735,6 +742,7 @@ int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const flo
   src.n = n;
   src.d_win = d_win;
   src.d_rows = d_rows;
+  src.d_loss_base = d_loss_base;
   src.gsum = d_gsum;
   src.gtouched = d_gtouched;
   if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, nullptr, s, &src);
@@ -746,30 +754,37 @@ int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const flo
 namespace {
 __global__ void __launch_bounds__(kBlock)
 k_sum_partials(const double *__restrict__ partial, uint32_t n, uint32_t W, uint32_t G,
+               const uint32_t *__restrict__ out_base, const uint32_t *__restrict__ out_rows,
                double *__restrict__ rowsum) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = t >> 2, q = t & 3u;
+  const uint32_t v = r < n ? r / W : 0u, rin = r - v * W;
+  const bool live = r < n && rin < out_rows[v];  // (the last window of a worker is not full)
   double a = 0.0;
-  if (r < n) {
-    const uint32_t v = r / W, rin = r - v * W;
+  if (live) {
     const double *p = partial + (size_t)v * G * W + rin;
     for (uint32_t g = q; g < G; g += 4) a += p[(size_t)g * W];
   }
   a += __shfl_xor(a, 1);
   a += __shfl_xor(a, 2);
-  if (r < n && q == 0) rowsum[r] = a;
+  if (live && q == 0) rowsum[out_base[v] + rin] = a;
 }
 }  // namespace
 
+// d_rowsum[d_out_base[window] + row-in-window] for the first d_out_rows[window] rows of every
+// window: the workers' rows back to back, ready to be sent
 int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial,
+                          const uint32_t *d_out_base, const uint32_t *d_out_rows,
                           double *d_rowsum, hipStream_t s) {
-  XF_REQUIRE(c && d_w && d_partial && d_rowsum, "cells_lr_forward_sums: null argument");
+  XF_REQUIRE(c && d_w && d_partial && d_rowsum && d_out_base && d_out_rows,
+             "cells_lr_forward_sums: null argument");
   if (c->R == 0) return XF_OK;
   hipLaunchKernelGGL(k_lr_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->entries_k,
                      c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, d_w, d_partial);
   const uint32_t n = c->nwin * c->W;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)(((size_t)n * 4 + kBlock - 1) / kBlock)),
-                     dim3(kBlock), 0, s, d_partial, n, c->W, c->G, d_rowsum);
+                     dim3(kBlock), 0, s, d_partial, n, c->W, c->G, d_out_base, d_out_rows,
+                     d_rowsum);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }

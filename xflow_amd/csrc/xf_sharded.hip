@@ -153,12 +153,14 @@ struct xf_sbatch {
   size_t o_n = 0;                            // nonzeros received
   Dev<uint64_t> o_keys;                      // their keys (kept: re-resolved after a defrag)
   Dev<uint32_t> o_rowid;                     // their rows (window-major numbering)
-  Dev<uint32_t> d_win, d_rows, d_rowoff;     // o_win, o_rows, prefix of o_rows on the device
+  Dev<uint32_t> d_win, d_rows;               // o_win, o_rows on the device
+  Dev<uint32_t> d_wbase, d_wrows;            // per window: first row in the back-to-back
+                                             // layout of the workers' rows; rows it holds
   Dev<int32_t> d_labels;                     // this worker's labels
   xf_cells *ocells = nullptr;                // cells over the shard's state rows
   uint64_t oc_uid = 0, oc_epoch = ~0ull;
-  Dev<double> rowsum, rs_send, rs_recv, gsum;
-  Dev<float> oloss, loss_rep, loss_recv, loss_pad, opctr;
+  Dev<double> rs_send, rs_recv, gsum;
+  Dev<float> oloss, loss_rep, loss_recv, opctr;
   Dev<uint8_t> gtouched;
 };
 
@@ -355,22 +357,6 @@ int flush_pending(xf_sharded *st) {
 
 
 // ------------------------------------------------------------------ XF_SCHEDULE_OWNER
-// rows of worker q, row r  <->  padded number (o_win[q] * W + r): rowoff = prefix of the workers'
-// row counts.  pack: padded -> the workers' rows back to back; pad: the inverse.
-template <typename T, bool PACK>
-__global__ void __launch_bounds__(kBlock)
-k_rows_repack(const T *__restrict__ in, T *__restrict__ out, uint32_t total, uint32_t nsrc,
-              const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ win, uint32_t W) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  uint32_t q = 0;
-  while (q + 1 < nsrc && i >= rowoff[q + 1]) ++q;
-  const uint32_t padded = win[q] * W + (i - rowoff[q]);
-  if (PACK) out[i] = in[padded];
-  else
-    out[padded] = in[i];
-}
-
 // received row numbers: worker q's nonzeros sit at [segoff[q], segoff[q+1]); + win[q] * W
 __global__ void __launch_bounds__(kBlock)
 k_rows_to_padded(uint32_t *__restrict__ rowid, size_t n, uint32_t nsrc,
@@ -505,7 +491,17 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   b->o_rpad = std::max<uint32_t>(1, b->o_win[W]) * b->oW;
   XF_TRY(upload_u32(b->d_win, b->o_win, s));
   XF_TRY(upload_u32(b->d_rows, b->o_rows, s));
-  XF_TRY(upload_u32(b->d_rowoff, rowoff, s));
+  {
+    std::vector<uint32_t> wbase(std::max<uint32_t>(1, b->o_win[W]), 0), wrows(wbase.size(), 0);
+    for (int p = 0; p < W; ++p)
+      for (uint32_t v = b->o_win[p]; v < b->o_win[p + 1]; ++v) {
+        const uint32_t first = (v - b->o_win[p]) * b->oW;
+        wbase[v] = rowoff[p] + first;
+        wrows[v] = std::min<uint32_t>(b->oW, b->o_rows[p] - first);
+      }
+    XF_TRY(upload_u32(b->d_wbase, wbase, s));
+    XF_TRY(upload_u32(b->d_wrows, wrows, s));
+  }
   if (b->o_n) {
     Dev<uint64_t> d_seg;
     XF_TRY(d_seg.reserve(W + 1));
@@ -558,18 +554,14 @@ static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_p
   XF_TRY(ensure_ocells(st, b));
   const xf_cells *c = b->ocells;
   XF_TRY(st->partial.reserve(xf::cells_partial_doubles(c)));
-  XF_TRY(b->rowsum.reserve((size_t)c->nwin * c->W));
-  XF_TRY(xf::cells_lr_forward_sums(c, xf::table_weights(st->tw), st->partial.p, b->rowsum.p, s));
-  XF_MARK(1);
   uint32_t total = 0;
   for (uint32_t r : b->o_rows) total += r;
   XF_TRY(b->rs_send.reserve(total));
   XF_TRY(b->rs_recv.reserve((size_t)W * b->R));
-  if (total)
-    hipLaunchKernelGGL((k_rows_repack<double, true>), dim3(grid_for(total)), dim3(kBlock), 0, s,
-                       b->rowsum.p, b->rs_send.p, total, (uint32_t)W, b->d_rowoff.p, b->d_win.p,
-                       b->oW);
-  XF_HIP(hipGetLastError());
+  // the row sums land worker after worker, ready to be sent
+  XF_TRY(xf::cells_lr_forward_sums(c, xf::table_weights(st->tw), st->partial.p, b->d_wbase.p,
+                                   b->d_wrows.p, b->rs_send.p, s));
+  XF_MARK(1);
   const std::vector<uint64_t> mine(W, b->R);
   XF_TRY(a2a(st, b->rs_send.p, b->o_rows64, b->rs_recv.p, mine, 8, s));
   if (b->R)
@@ -595,21 +587,18 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   for (uint32_t r : b->o_rows) total += r;
   XF_TRY(b->loss_rep.reserve((size_t)W * b->R));
   XF_TRY(b->loss_recv.reserve(total));
-  XF_TRY(b->loss_pad.reserve(b->o_rpad));
   if (b->R)
     hipLaunchKernelGGL(k_replicate_f32, dim3(grid_for((size_t)W * b->R)), dim3(kBlock), 0, s,
                        b->oloss.p, b->R, (uint32_t)W, b->loss_rep.p);
   const std::vector<uint64_t> mine(W, b->R);
   XF_TRY(a2a(st, b->loss_rep.p, mine, b->loss_recv.p, b->o_rows64, 4, s));
-  if (total)
-    hipLaunchKernelGGL((k_rows_repack<float, false>), dim3(grid_for(total)), dim3(kBlock), 0, s,
-                       b->loss_recv.p, b->loss_pad.p, total, (uint32_t)W, b->d_rowoff.p,
-                       b->d_win.p, b->oW);
   XF_HIP(hipGetLastError());
   XF_MARK(3);
-  // gradient + the workers' Pushes in rank order, one pass over the shard
-  XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_pad.p, (uint32_t)W,
-                                          b->d_win.p, b->d_rows.p, b->gsum.p, b->gtouched.p, s));
+  // gradient + the workers' Pushes in rank order, one pass over the shard (the losses are read
+  // where they arrived: worker after worker)
+  XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, (uint32_t)W,
+                                          b->d_win.p, b->d_rows.p, b->d_wbase.p, b->gsum.p,
+                                          b->gtouched.p, s));
   XF_MARK(4);
   XF_MARK(5);
   XF_MARK(6);
