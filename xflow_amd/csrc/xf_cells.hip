@@ -293,7 +293,17 @@ k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restric
   if (r < R) {
     const uint32_t v = r / W, rin = r - v * W;
     const double *p = partial + (size_t)v * G * W + rin;
-    for (uint32_t g = q; g < G; g += 4) a += p[(size_t)g * W];
+    // four loads in flight per lane (fp64 sums of fp32 addends: exact in any association)
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    uint32_t g = q;
+    for (; g + 12 < G; g += 16) {
+      a += p[(size_t)g * W];
+      a1 += p[(size_t)(g + 4) * W];
+      a2 += p[(size_t)(g + 8) * W];
+      a3 += p[(size_t)(g + 12) * W];
+    }
+    for (; g < G; g += 4) a += p[(size_t)g * W];
+    a += a1 + (a2 + a3);
   }
   a += __shfl_xor(a, 1);
   a += __shfl_xor(a, 2);
