@@ -916,6 +916,8 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
     if (b->R) XF_HIP(hipMemcpy(pctr_out, b->opctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
     return XF_OK;
   }
+  XF_REQUIRE(!b->oc, "xf_sharded_predict: the minibatch was compiled for the owner-compute "
+             "dataflow");
   StepBuf &B = b->buf[b->flip];
   Dev<float> pctr;
   XF_TRY(pctr.reserve(b->R));
