@@ -305,3 +305,51 @@ def test_training_after_a_model_load_grows_the_table(tmp_path):
         b.check()                                        # raises on XF_EFULL
     keys = set(b.w.export()[0].tolist())
     assert seen <= keys and len(keys) >= n_first + len(seen)
+
+
+def _general_path_rank(port, schedule, outdir, q):
+    try:
+        os.environ["XF_SHARDED_GENERAL"] = "1"      # a world-1 trainer runs the exchange path
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(0, 1, "127.0.0.1", port, capi.TRANSPORT_RCCL, device=0)
+        st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 12, schedule=schedule)
+        alive = []
+        for s in range(3):
+            alive.append(st.compile(*_big_data(0, s)))
+            st.step(alive[-1])
+        st.check()
+        k, w, n, z = st.w.export()
+        rp, ks, lb = _big_data(0, 99)
+        np.savez(os.path.join(outdir, "gp_%s.npz" % schedule), k=k, w=w, n=n, z=z,
+                 p=st.predict(st.compile(rp, ks, lb)))
+        st.close()
+        g.close()
+        q.put(None)
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.parametrize("schedule", ["owner", "sequential"])   # (stale1 is one step stale)
+def test_exchange_code_paths_at_world_one_over_rccl_equal_the_fused_step(tmp_path, schedule):
+    """XF_SHARDED_GENERAL=1: the N > 1 code paths with the one GPU there is, the all-to-all-v
+    through the RCCL transport (a group of one: the self slice) — 20 000-row minibatches (two
+    row windows, split chunks), the table afterwards and a forward pass equal to the fused
+    single-shard trainer's, bit for bit"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_general_path_rank, args=(free_port(), schedule, str(tmp_path), q))
+    p.start()
+    err = q.get(timeout=300)
+    p.join(timeout=60)
+    assert not err, err
+    got = np.load(str(tmp_path / ("gp_%s.npz" % schedule)))
+    one = capi.Sharded(None, model="lr", optimizer="ftrl", capacity=1 << 12)
+    alive = []
+    for s in range(3):
+        alive.append(one.compile(*_big_data(0, s)))
+        one.step(alive[-1])
+    one.check()
+    for a, e in zip((got["k"], got["w"], got["n"], got["z"]), one.w.export()):
+        same(a, e)
+    rp, ks, lb = _big_data(0, 99)
+    same(got["p"], one.predict(one.compile(rp, ks, lb)))
