@@ -392,10 +392,10 @@ k_replicate_f32(const float *__restrict__ in, uint32_t n, uint32_t copies,
   if (i < (size_t)n * copies) out[i] = in[i % n];
 }
 
-static int upload_u32(Dev<uint32_t> &d, const std::vector<uint32_t> &h, hipStream_t s) {
+// (blocking: the small host arrays it is used for are locals of the caller)
+static int upload_u32(Dev<uint32_t> &d, const std::vector<uint32_t> &h, hipStream_t) {
   XF_TRY(d.reserve(h.size()));
-  if (!h.empty())
-    XF_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+  if (!h.empty()) XF_HIP(hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   return XF_OK;
 }
 
@@ -505,7 +505,7 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   if (b->o_n) {
     Dev<uint64_t> d_seg;
     XF_TRY(d_seg.reserve(W + 1));
-    XF_HIP(hipMemcpyAsync(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice, s));
+    XF_HIP(hipMemcpy(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s, b->o_rowid.p,
                        b->o_n, (uint32_t)W, d_seg.p, b->d_win.p, b->oW);
     XF_HIP(hipGetLastError());
