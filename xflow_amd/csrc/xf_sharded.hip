@@ -907,6 +907,7 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
     return xf_fm_predict(st->tw, st->tv, b->b, st->ws, pctr_out);
   }
   XF_TRY(xf_sharded_flush(st));
+  st->rec = false;  // a forward-only pass records no step profile
   if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
     XF_REQUIRE(b->oc, "xf_sharded_predict: the minibatch was not compiled for the owner-compute "
                "dataflow");
