@@ -2,14 +2,17 @@
 """bench.py — examples/sec of the LR+FTRL (or FM) minibatch step on N MI355X.
 
 A "step" is one pass of the hot path over one compiled minibatch that is already resident in
-HBM: Pull (key->slot resolve + weight gather), forward (sigma(sum w)), gradient, Push
-(FTRL update) == one LRWorker::update of the reference (lr_worker.cc:167-176).
+HBM: Pull (the keys' weights), forward (sigma(sum w)), gradient, Push (FTRL update) == one
+LRWorker::update of the reference (lr_worker.cc:167-176).
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic libsvm-shaped data, 10^7 keys,
-200 nnz/row, 5x10^4 rows per minibatch (10^7 nnz), keys = std::hash of decimal strings.
-N>1 (configs[2] shape, weak scaling): every rank runs the same per-GPU minibatch shape,
-the key space grows with N (1.25x10^7 x N ... capped by --keys-per-gpu), keys are sharded by
-the ps-lite range rule and travel to their owner with an RCCL all-to-all.
+200 nnz/row, 5x10^4 rows per minibatch (10^7 nnz), keys = std::hash of decimal strings; the
+fused single-shard step (forward and gradient+Push read and write the table in place).
+N>1 (configs[2] shape, weak scaling): every rank runs the same per-GPU minibatch shape, the key
+space is 1.25x10^7 x N (--keys-per-gpu), the table is sharded by the ps-lite key-range rule, one
+process per GPU, the exchange over RCCL from C++ (xf_group).  LR: `value` on the owner-compute
+dataflow (nonzeros at the key owners, row sums and losses exchanged), the weight/gradient
+all-to-all (stale1) as the supplementary `exchange_dataflow` leg; FM: weights and gradients.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md for the byte model behind `roofline`.
 """
