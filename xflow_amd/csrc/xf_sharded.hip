@@ -357,6 +357,50 @@ int flush_pending(xf_sharded *st) {
 
 
 // ------------------------------------------------------------------ XF_SCHEDULE_OWNER
+// the owner (xf_shard_of) of every nonzero's key, and its row
+__global__ void __launch_bounds__(kBlock)
+k_owner_of(const uint64_t *__restrict__ keys, size_t n, uint32_t world,
+           uint32_t *__restrict__ own) {
+  const uint64_t span = UINT64_MAX / world;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t q = keys[j] / span;
+    own[j] = q < world ? (uint32_t)q : world - 1;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+k_rows_of_nnz(const uint32_t *__restrict__ rowptr, uint32_t R, uint32_t *__restrict__ row_of) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nw)
+    for (uint32_t j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) row_of[j] = r;
+}
+__global__ void __launch_bounds__(kBlock)
+k_take_by_owner(const uint32_t *__restrict__ perm, const uint64_t *__restrict__ keys,
+                const uint32_t *__restrict__ row_of, size_t n, uint64_t *__restrict__ sk,
+                uint32_t *__restrict__ sr) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t j = perm[i];
+    sk[i] = keys[j];
+    sr[i] = row_of[j];
+  }
+}
+// first[p] = first position of the owner-sorted list that belongs to owner >= p (p = 0..world)
+__global__ void k_owner_first(const uint32_t *__restrict__ own_sorted, uint32_t n, uint32_t world,
+                              uint32_t *__restrict__ first) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > world) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (own_sorted[mid] < p) lo = mid + 1;
+    else
+      hi = mid;
+  }
+  first[p] = lo;
+}
+
 // received row numbers: worker q's nonzeros sit at [segoff[q], segoff[q+1]); + win[q] * W
 __global__ void __launch_bounds__(kBlock)
 k_rows_to_padded(uint32_t *__restrict__ rowid, size_t n, uint32_t nsrc,
@@ -415,32 +459,51 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   b->R = R;
   b->NNZ = (uint32_t)NNZ;
   b->U = 0;
-  // stable counting sort of the nonzeros by the owner of their key
-  std::vector<uint64_t> cnt(W, 0), off(W + 1, 0);
-  std::vector<uint8_t> own(NNZ);
-  for (size_t j = 0; j < NNZ; ++j) {
-    own[j] = (uint8_t)xf_shard_of(keys[base + j], (uint32_t)W);
-    ++cnt[own[j]];
-  }
-  for (int p = 0; p < W; ++p) off[p + 1] = off[p] + cnt[p];
-  std::vector<uint64_t> sk(NNZ);
-  std::vector<uint32_t> sr(NNZ);
-  {
-    std::vector<uint64_t> at(off.begin(), off.begin() + W);
-    for (uint32_t r = 0; r < R; ++r)
-      for (uint64_t j = rowptr[row_begin + r] - base; j < rowptr[row_begin + r + 1] - base; ++j) {
-        const uint64_t pos = at[own[j]]++;
-        sk[pos] = keys[base + j];
-        sr[pos] = r;
-      }
-  }
+  // the nonzeros grouped by the owner of their key, row-major order kept within an owner (one
+  // stable radix pass on the owner number), on the device
+  std::vector<uint64_t> cnt(W, 0);
   Dev<uint64_t> d_sk;
   Dev<uint32_t> d_sr;
   XF_TRY(d_sk.reserve(NNZ));
   XF_TRY(d_sr.reserve(NNZ));
   if (NNZ) {
-    XF_HIP(hipMemcpyAsync(d_sk.p, sk.data(), NNZ * 8, hipMemcpyHostToDevice, s));
-    XF_HIP(hipMemcpyAsync(d_sr.p, sr.data(), NNZ * 4, hipMemcpyHostToDevice, s));
+    xf::Scratch sc;
+    uint64_t *d_k = nullptr;
+    uint32_t *d_rp = nullptr, *d_row = nullptr, *d_own = nullptr, *d_own_s = nullptr,
+             *d_iota = nullptr, *d_perm = nullptr, *d_first = nullptr;
+    XF_TRY(sc.get(&d_k, NNZ));
+    XF_TRY(sc.get(&d_rp, (size_t)R + 1));
+    XF_TRY(sc.get(&d_row, NNZ));
+    XF_TRY(sc.get(&d_own, NNZ));
+    XF_TRY(sc.get(&d_own_s, NNZ));
+    XF_TRY(sc.get(&d_iota, NNZ));
+    XF_TRY(sc.get(&d_perm, NNZ));
+    XF_TRY(sc.get(&d_first, (size_t)W + 1));
+    std::vector<uint32_t> rp(R + 1);
+    for (uint32_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+    XF_HIP(hipMemcpyAsync(d_k, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+    XF_HIP(hipMemcpyAsync(d_rp, rp.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rows_of_nnz, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rp, R,
+                       d_row);
+    hipLaunchKernelGGL(k_owner_of, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_k, NNZ, (uint32_t)W,
+                       d_own);
+    hipLaunchKernelGGL(k_iota32, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_iota, NNZ);
+    int bits = 1;
+    while ((1 << bits) < W) ++bits;
+    size_t tb = 0;
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_own, d_own_s, d_iota, d_perm, NNZ, 0, bits, s));
+    void *tmp = nullptr;
+    XF_TRY(sc.get((char **)&tmp, tb));
+    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, d_own, d_own_s, d_iota, d_perm, NNZ, 0, bits, s));
+    hipLaunchKernelGGL(k_take_by_owner, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_perm, d_k, d_row,
+                       NNZ, d_sk.p, d_sr.p);
+    hipLaunchKernelGGL(k_owner_first, dim3((W + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       d_own_s, (uint32_t)NNZ, (uint32_t)W, d_first);
+    XF_HIP(hipGetLastError());
+    std::vector<uint32_t> first(W + 1);
+    XF_HIP(hipMemcpyAsync(first.data(), d_first, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));  // (also: rp and the scratch may go)
+    for (int p = 0; p < W; ++p) cnt[p] = first[p + 1] - first[p];
   }
   // who sends how much to whom, and how many rows every worker has
   std::vector<uint64_t> all((size_t)W * W), rows_all(W);
