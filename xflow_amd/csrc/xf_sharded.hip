@@ -146,7 +146,7 @@ struct xf_sbatch {
   xf_sharded *owner = nullptr;
   // ---- XF_SCHEDULE_OWNER: this rank's share of EVERY worker's nonzeros (the ones whose keys it
   // owns), rows numbered window by window across the workers
-  bool oc = false;
+  bool oc = false, oc_keep = true;           // oc_keep: will be replayed (key-sorted forward copy)
   uint32_t oW = 1, o_rpad = 0;               // rows per window; windows * oW
   std::vector<uint32_t> o_rows, o_win;       // per worker: rows of its minibatch; first window
   std::vector<uint64_t> o_rows64;            // o_rows as exchange counts
@@ -598,8 +598,8 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
   XF_TRY(sc.get(&idx, b->o_n));
   if (b->o_n) XF_TRY(xf::table_resolve_any(st->tw, b->o_keys.p, b->o_n, idx, s, true));
   XF_TRY(xf::cells_build(&b->ocells, idx, nullptr, nullptr, b->o_rpad, (uint32_t)b->o_n,
-                         (uint32_t)xf::table_row_bound(st->tw), xf::kCellsTableRows, true, s,
-                         b->o_n ? b->o_rowid.p : nullptr, b->oW));
+                         (uint32_t)xf::table_row_bound(st->tw), xf::kCellsTableRows, b->oc_keep,
+                         s, b->o_n ? b->o_rowid.p : nullptr, b->oW));
   b->ocells->table_uid = uid;
   b->ocells->epoch = ep;
   b->oc_uid = uid;
@@ -834,6 +834,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     return XF_OK;
   }
   if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+    b->oc_keep = keep != 0;
     XF_TRY(compile_owner(st, b, rowptr, keys, labels, row_begin, row_end));
     guard.b = nullptr;
     *out = b;
