@@ -315,7 +315,7 @@ def _general_path_rank(port, schedule, outdir, q):
         st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 12, schedule=schedule)
         alive = []
         for s in range(3):
-            alive.append(st.compile(*_big_data(0, s)))
+            alive.append(st.compile(*_big_data(0, s), keep=(s != 1)))   # one of them one-shot
             st.step(alive[-1])
         st.check()
         k, w, n, z = st.w.export()
