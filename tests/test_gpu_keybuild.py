@@ -1,0 +1,139 @@
+"""The range-partitioned key build (xf_keybuild.hip) through the C ABI on a real MI355X: raw
+keys -> cells against a table with a settled tier, keys found where the tier's keys sit in LDS,
+first-touch keys as holes + a second segment of cells over the arrival rows.  Every case is
+checked three ways: against the oracle's exact-sum mode (bit for bit), against the general
+build of the same minibatches (table probe per nonzero + radix sort: tune exp_knob = 77), and
+through the shape the build reports (segments)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from xflow_amd import capi
+
+from .test_gpu_parity import same, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    capi.require_gpu()
+
+
+def general_path(on):
+    capi.tune("exp_knob", 77 if on else 0)
+
+
+def steps_vs_oracle(t, s, raws, ws, steps, retain=True, defrag_at=None):
+    obs = [O.Batch(*x) for x in raws]
+    segs = []
+    bs = []
+    for i in range(steps):
+        ob = obs[i % len(obs)]
+        if retain:
+            if i < len(raws):
+                bs.append(capi.LocalBatch(t, *raws[i]))
+            b = bs[i % len(bs)]
+        else:
+            b = capi.LocalBatch(t, *raws[i % len(raws)], retain_keys=False)
+        with O.sum_mode(1):
+            loss_ex, _ = ob.lr_loss(s.pull(ob.ukeys))
+            O.lr_update(s, ob)
+        capi.lr_step(t, b, ws)
+        segs.append(b.cells_info()["segments"])
+        same(ws.fetch_loss(b.R), loss_ex)
+        if defrag_at is not None and i == defrag_at:
+            t.defrag()
+    t.check()
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)
+    return segs
+
+
+@pytest.mark.parametrize("R,nnz,nkeys,zipf,ragged", [
+    (3000, 40, 30000, None, False),      # one window, 15 chunks, 4 super-chunks
+    (40000, 25, 300000, None, True),     # three windows, ragged / empty rows, 37 super-chunks
+    (30000, 40, 100000, 1.15, True),     # power-law heads: split chunks, a heavy super-chunk
+    (20000, 3, 50000, None, False),      # short rows: many rows per scatter tile
+])
+def test_settled_keys_new_keys_and_the_general_build_agree(R, nnz, nkeys, zipf, ragged):
+    rng = np.random.RandomState(R + nnz)
+    ws = capi.Workspace()
+    raws = [synth(rng, R, nnz, nkeys, zipf, ragged) for _ in range(4)]
+    tabs = []
+    for general in (False, True):
+        general_path(general)
+        try:
+            t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 20)
+            s = O.Store(O.OPT_FTRL, 1)
+            t.push(np.array([0], np.uint64), np.zeros(1, np.float32))   # lr_worker.cc:180-182
+            s.push(np.array([0], np.uint64), np.zeros(1, np.float32))
+            # minibatch 0 goes in through the general path (no settled tier yet) ...
+            segs = steps_vs_oracle(t, s, raws[:1], ws, 1, defrag_at=0)
+            assert segs == [1]
+            # ... minibatches 1-3 meet a settled tier that holds some of their keys: holes +
+            # an arrival segment; after the second defrag everything is settled
+            segs = steps_vs_oracle(t, s, raws[1:], ws, 7, defrag_at=3)
+            if not general:
+                assert segs[0] == 2 and segs[-1] == 1, segs
+            tabs.append(t.export())
+        finally:
+            general_path(False)
+    for a, b in zip(*tabs):
+        same(a, b)
+
+
+def test_one_shot_minibatches_on_a_growing_table():
+    """retain_keys = 0 (no key-sorted copy, cells built once), a table that must grow while the
+    arrival segment goes in, keys that are not hashes (a run of integers: every key-range guess
+    is wrong, the boundary search and the directory must not care)"""
+    rng = np.random.RandomState(9)
+    t = capi.Table(capi.OPT_SGD, 1, capacity=4096)
+    s = O.Store(O.OPT_SGD, 1)
+    ws = capi.Workspace()
+    R, nnz = 2000, 30
+    rowptr = (np.arange(R + 1) * nnz).astype(np.uint64)
+    for step in range(5):
+        hi = 9000 * (step + 1)
+        keys = rng.randint(0, hi, size=R * nnz).astype(np.uint64) + np.uint64(1 << 40)
+        if step == 3:
+            keys[::97] = np.uint64(2**64 - 1)           # the reserved key value
+            keys[5::101] = np.uint64(3)                 # below every settled key
+        labels = rng.randint(0, 2, size=R).astype(np.int32)
+        b = capi.LocalBatch(t, rowptr, keys, labels, retain_keys=False)
+        ob = O.Batch(rowptr, keys, labels)
+        with O.sum_mode(1):
+            loss_ex, _ = ob.lr_loss(s.pull(ob.ukeys))
+            O.lr_update(s, ob)
+        capi.lr_step(t, b, ws)
+        same(ws.fetch_loss(R), loss_ex)
+        assert b.cells_info()["segments"] == (1 if step == 0 else 2)
+        t.defrag()
+    t.check()
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)
+    assert t.capacity > 4096
+
+
+def test_predict_and_replay_after_a_renumbering():
+    """a retained minibatch is rebuilt by the same path when the table renumbers its rows"""
+    rng = np.random.RandomState(2)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)
+    s = O.Store(O.OPT_FTRL, 1)
+    ws = capi.Workspace()
+    raws = [synth(rng, 5000, 20, 60000) for _ in range(2)]
+    obs = [O.Batch(*x) for x in raws]
+    bs = [capi.LocalBatch(t, *x) for x in raws]
+    for ob in obs:
+        s.pull(ob.ukeys)
+    for i in range(6):
+        with O.sum_mode(1):
+            O.lr_update(s, obs[i % 2])
+        capi.lr_step(t, bs[i % 2], ws)
+        if i in (1, 3):
+            t.defrag()
+    assert bs[0].cells_info()["segments"] == 1
+    with O.sum_mode(1):
+        same(capi.lr_predict(t, bs[1], ws), obs[1].lr_loss(s.pull(obs[1].ukeys))[1])
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)

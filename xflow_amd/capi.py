@@ -394,7 +394,7 @@ class LocalBatch:
 def cells_info(batch):
     out = (C.c_uint32 * 8)()
     check(lib().xf_batch_cells_info(batch.h, out))
-    names = ["W", "nwin", "nchunk", "G", "nitems", "reserved", "nsplit_chunks", "M"]
+    names = ["W", "nwin", "nchunk", "G", "nitems", "segments", "nsplit_chunks", "M"]
     return dict(zip(names, list(out)))
 
 

@@ -55,6 +55,13 @@ struct xf_cells {
   uint32_t R = 0, NNZ = 0, M = 0;  // rows, nonzeros, size of the index space
   uint32_t W = 1, nwin = 1, nchunk = 1, ncell = 1, nblk = 0;
   uint32_t G = 1;                  // forward workgroups per window
+  // A batch's cells may come in SEGMENTS (xf_keybuild.hip): a chain of xf_cells over the same
+  // rows (same W, nwin, G) and disjoint sets of state rows.  Segment chunk numbers are local:
+  // chunk c of a segment is chunk chunk0 + c of the index space (M stays the bound of the
+  // whole index space).  The forward adds the segments' row sums, the gradient pass runs once
+  // per segment.
+  uint32_t chunk0 = 0;
+  xf_cells *next = nullptr;
   uint32_t nitems = 0, nsplit_chunks = 0;
   int mode = xf::kCellsUidx;
   uint64_t table_uid = 0, epoch = 0;  // kCellsTableRows: valid for this table at this epoch
@@ -65,6 +72,7 @@ struct xf_cells {
                                     //       == entries when the copy was not built)
   uint32_t *cellptr = nullptr;      // [ncell + 1]
   uint32_t *blk_cell = nullptr;     // [nblk + 1] cell of entry kBlk*b; [nblk] = ncell - 1
+  uint32_t *plan = nullptr;         // [3 * (nchunk + 1)] slices per chunk and their two scans
   uint32_t *item_chunk = nullptr;   // [nitems]   gradient work items: chunk,
   uint32_t *item_slice = nullptr;   // [nitems]   slice | nslices << 16,
   uint32_t *item_dump = nullptr;    // [nitems]   index of the chunk among the split ones
@@ -81,11 +89,29 @@ namespace xf {
 // unique-key index of a compiled batch mapped to table rows).  Synchronises `stream`.
 // d_rowid != null: the nonzeros come in any order with their row number (d_rowptr unused, no
 // map); the rows are then numbered window by window by the caller: w_fixed rows per window.
+// chunk0 != 0: a segment over the chunks from chunk0 on (every position is >= chunk0 * kChunk).
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
                 bool key_sorted_copy, hipStream_t stream, const uint32_t *d_rowid = nullptr,
-                uint32_t w_fixed = 0);
-void cells_free(xf_cells *c);
+                uint32_t w_fixed = 0, uint32_t chunk0 = 0);
+void cells_free(xf_cells *c);  // the whole chain
+
+// The key build of LRWorker::update (lr_worker.cc:146-166) against table `t` on this GPU,
+// raw keys in, cells out (xf_keybuild.hip): the keys' state rows are found — and first-touch
+// keys inserted (ftrl.h:56) — on the way.  Nonzeros in CSR order (d_rowptr) or with their row
+// numbers (d_rowid, rows numbered window by window, w_fixed rows per window).  Synchronises
+// `stream`.
+int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
+                      const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
+                      uint32_t NNZ, bool key_sorted_copy, uint32_t w_fixed, hipStream_t stream);
+
+// pieces of cells_build shared with the keyed build
+int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
+                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0);
+int cells_plan_items(xf_cells *c, hipStream_t stream);            // after cellptr is final
+int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t stream);
+int cells_key_sorted_copy(xf_cells *c, hipStream_t stream);
+uint32_t cells_split_chunks(const xf_cells *c);  // over the chain
 
 // scratch of the forward: G * nwin * W partial row sums (fp64)
 size_t cells_partial_doubles(const xf_cells *c);

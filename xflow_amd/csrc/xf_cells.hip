@@ -66,7 +66,7 @@ inline int grid_for(size_t n, int block = kBlock) {
 __global__ void __launch_bounds__(kBlock)
 k_cell_keys(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ src,
             const uint32_t *__restrict__ map, uint32_t R, uint32_t W, uint32_t nchunk,
-            uint32_t *__restrict__ cid, uint32_t *__restrict__ ent) {
+            uint32_t chunk0, uint32_t *__restrict__ cid, uint32_t *__restrict__ ent) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t nw = gridDim.x * (kBlock / 64);
   for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nw) {
@@ -74,7 +74,7 @@ k_cell_keys(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ sr
     for (uint32_t j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) {
       const uint32_t s = src[j];
       const uint32_t idx = map ? map[s] : s;
-      const uint32_t chunk = idx >> kChunkBits;
+      const uint32_t chunk = (idx >> kChunkBits) - chunk0;
       cid[j] = v * nchunk + chunk;
       ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
     }
@@ -106,18 +106,62 @@ k_blk_cell(const uint32_t *__restrict__ cid_s, uint32_t nblk, uint32_t ncell,
   blk_cell[b] = b < nblk ? cid_s[(size_t)b * kBlk] : ncell - 1;
 }
 
-// gradient work items: chunk c is cut into ceil(n_c / kSliceMax) slices (none when empty)
-__global__ void __launch_bounds__(kBlock)
-k_chunk_slices(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
-               uint32_t *__restrict__ nsl, uint32_t *__restrict__ nsplit) {
-  XF_GRID_STRIDE(c, (size_t)nchunk + 1) {
+// gradient work items: chunk c is cut into ceil(n_c / kSliceMax) slices (none when empty).
+// One workgroup: slices per chunk, their exclusive scan (off: first item of the chunk) and the
+// scan of the "is split" flags (soff: index among the split chunks); totals in [nchunk].
+constexpr int kPlanBlock = 1024;
+__global__ void __launch_bounds__(kPlanBlock)
+k_plan_items(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
+             uint32_t *__restrict__ nsl, uint32_t *__restrict__ off,
+             uint32_t *__restrict__ soff) {
+  __shared__ uint32_t wsum[2][kPlanBlock / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t per = (nchunk + kPlanBlock - 1) / kPlanBlock;
+  const uint32_t c0 = min(tid * per, nchunk), c1 = min(c0 + per, nchunk);
+  auto slices = [&](uint32_t c) -> uint32_t {
     uint32_t n = 0;
-    if (c < nchunk)
-      for (uint32_t v = 0; v < nwin; ++v)
-        n += cellptr[(size_t)v * nchunk + c + 1] - cellptr[(size_t)v * nchunk + c];
-    const uint32_t S = (n + kSliceMax - 1) / kSliceMax;
+    for (uint32_t v = 0; v < nwin; ++v)
+      n += cellptr[(size_t)v * nchunk + c + 1] - cellptr[(size_t)v * nchunk + c];
+    return (n + kSliceMax - 1) / kSliceMax;
+  };
+  uint32_t a = 0, b = 0;
+  for (uint32_t c = c0; c < c1; ++c) {
+    const uint32_t S = slices(c);
+    a += S;
+    b += S > 1 ? 1u : 0u;
+  }
+  uint32_t ia = a, ib = b;  // inclusive scan over the threads
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+    if ((int)lane >= o) {
+      ia += ta;
+      ib += tb;
+    }
+  }
+  if (lane == 63) {
+    wsum[0][wave] = ia;
+    wsum[1][wave] = ib;
+  }
+  __syncthreads();
+  uint32_t ba = 0, bb = 0;
+  for (uint32_t w = 0; w < wave; ++w) {
+    ba += wsum[0][w];
+    bb += wsum[1][w];
+  }
+  uint32_t ea = ba + ia - a, eb = bb + ib - b;  // exclusive prefix of this thread's range
+  for (uint32_t c = c0; c < c1; ++c) {
+    const uint32_t S = slices(c);  // (recomputed: a reload of nsl[] would wait for the stores)
     nsl[c] = S;
-    nsplit[c] = S > 1 ? 1u : 0u;
+    off[c] = ea;
+    soff[c] = eb;
+    ea += S;
+    eb += S > 1 ? 1u : 0u;
+  }
+  if (tid == kPlanBlock - 1) {
+    nsl[nchunk] = 0;
+    off[nchunk] = ba + ia;
+    soff[nchunk] = bb + ib;
   }
 }
 
@@ -143,24 +187,14 @@ k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
 // window across the workers)
 __global__ void __launch_bounds__(kBlock)
 k_cell_keys_rowid(const uint32_t *__restrict__ rowid, const uint32_t *__restrict__ src, size_t n,
-                  uint32_t W, uint32_t nchunk, uint32_t *__restrict__ cid,
+                  uint32_t W, uint32_t nchunk, uint32_t chunk0, uint32_t *__restrict__ cid,
                   uint32_t *__restrict__ ent) {
   XF_GRID_STRIDE(j, n) {
     const uint32_t r = rowid[j], v = r / W, rin = r - v * W;
-    const uint32_t idx = src[j], chunk = idx >> kChunkBits;
+    const uint32_t idx = src[j], chunk = (idx >> kChunkBits) - chunk0;
     cid[j] = v * nchunk + chunk;
     ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
   }
-}
-
-int exclusive_scan_u32(xf::Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
-                       hipStream_t s) {
-  size_t tb = 0;
-  XF_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
-  void *tmp = nullptr;
-  XF_TRY(sc.get((char **)&tmp, tb));
-  XF_HIP(rocprim::exclusive_scan(tmp, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
-  return XF_OK;
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -234,7 +268,7 @@ __device__ __forceinline__ void fwd_process(const FwdBlock &B, uint32_t b, uint3
 __global__ void __launch_bounds__(kFwdBlock)
 k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ cellptr,
                const uint32_t *__restrict__ blk_cell, uint32_t nchunk, uint32_t W, uint32_t G,
-               const float *__restrict__ w, double *__restrict__ partial) {
+               const float *__restrict__ w, double *__restrict__ partial, int accumulate) {
   __shared__ double wx[kWinMax];
   __shared__ uint32_t next_blk;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -242,7 +276,9 @@ k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict_
   // of window v is block ((g / 8) * nwin + v) * 8 + g % 8
   const uint32_t nwin = gridDim.x / G;
   const uint32_t slot = blockIdx.x >> 3, v = slot % nwin, g = (slot / nwin) * 8 + (blockIdx.x & 7u);
-  for (uint32_t r = tid; r < W; r += kFwdBlock) wx[r] = 0.0;
+  // (a later segment of the batch's cells starts from the sums of the segments before it)
+  double *out = partial + ((size_t)v * G + g) * W;
+  for (uint32_t r = tid; r < W; r += kFwdBlock) wx[r] = accumulate ? out[r] : 0.0;
   const uint32_t c0 = v * nchunk;
   const uint32_t wb = cellptr[c0], we = cellptr[c0 + nchunk];
   const uint64_t n = we - wb;
@@ -276,7 +312,6 @@ k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict_
     fwd_process(B, bb, c0, nchunk, lane, cellptr, w, wx);
   }
   __syncthreads();
-  double *out = partial + ((size_t)v * G + g) * W;
   for (uint32_t r = tid; r < W; r += kFwdBlock) out[r] = wx[r];
 }
 
@@ -382,7 +417,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
                 uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
                 const uint32_t *__restrict__ src_rows, uint32_t nsplit,
-                const uint32_t *__restrict__ loss_base) {
+                const uint32_t *__restrict__ loss_base, uint32_t chunk0) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
@@ -470,7 +505,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       acc[k] = 0.0;
       touched[k] = 0;
     }
-    const size_t idx = (size_t)c * kChunk + k;
+    const size_t idx = (size_t)(chunk0 + c) * kChunk + k;
     if (idx >= M) continue;
     const float g = (float)((double)(float)sum / (1.0 * Rq));  // lr_worker.cc:117
     if (g_out) g_out[idx] = g;
@@ -485,10 +520,10 @@ __global__ void __launch_bounds__(kBlock)
 k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
                        const double *__restrict__ gsum, const uint8_t *__restrict__ gtouched,
                        uint32_t R, uint32_t M, float *__restrict__ g_out, uint32_t nsrc,
-                       const uint32_t *__restrict__ src_rows, uint32_t nsplit) {
+                       const uint32_t *__restrict__ src_rows, uint32_t nsplit, uint32_t chunk0) {
   const uint32_t slot = blockIdx.x / (kChunk / kBlock);
   const uint32_t k = (blockIdx.x % (kChunk / kBlock)) * kBlock + threadIdx.x;
-  const size_t idx = (size_t)split_chunk[slot] * kChunk + k;
+  const size_t idx = (size_t)(chunk0 + split_chunk[slot]) * kChunk + k;
   if (idx >= M) return;
   const uint32_t ns = src_rows ? nsrc : 1u;
   for (uint32_t q = 0; q < ns; ++q) {  // the workers' steps in rank order
@@ -511,26 +546,35 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
                       hipStream_t s, bool allow_grow);
 
 void cells_free(xf_cells *c) {
-  if (!c) return;
-  if (c->blob) blob_free(c->blob, c->blob_bytes);
-  if (c->blob2) blob_free(c->blob2, c->blob2_bytes);
-  delete c;
+  while (c) {
+    xf_cells *n = c->next;
+    if (c->blob) blob_free(c->blob, c->blob_bytes);
+    if (c->blob2) blob_free(c->blob2, c->blob2_bytes);
+    delete c;
+    c = n;
+  }
 }
 
 size_t cells_partial_doubles(const xf_cells *c) { return (size_t)c->G * c->nwin * c->W; }
 
-int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
-                const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                bool key_sorted_copy, hipStream_t s, const uint32_t *d_rowid, uint32_t w_fixed) {
-  XF_REQUIRE(out && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_src),
-             "cells_build: null argument");
-  XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax && !d_map),
-             "cells_build: row ids need a window size");
+uint32_t cells_split_chunks(const xf_cells *c) {
+  uint32_t n = 0;
+  for (; c; c = c->next) n += c->nsplit_chunks;
+  return n;
+}
+
+// geometry + the allocation whose size the shape decides: entries (two copies when the
+// key-sorted one is wanted), cellptr, blk_cell, the item plan
+int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
+                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0) {
+  XF_REQUIRE(out, "cells_alloc: null argument");
+  XF_REQUIRE(w_fixed <= kWinMax, "cells_alloc: %u rows per window", w_fixed);
   xf_cells *c = new xf_cells;
   c->R = R;
   c->NNZ = NNZ;
   c->M = M;
   c->mode = mode;
+  c->chunk0 = chunk0;
   if (w_fixed) {  // the caller numbered the rows window by window
     c->W = w_fixed;
     c->nwin = std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed);
@@ -538,11 +582,12 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
     c->nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
     c->W = std::max<uint32_t>(1, (R + c->nwin - 1) / c->nwin);
   }
-  c->nchunk = std::max<uint32_t>(1, (uint32_t)(((uint64_t)M + kChunk - 1) / kChunk));
+  const uint64_t nchunk_all = std::max<uint64_t>(1, ((uint64_t)M + kChunk - 1) / kChunk);
+  c->nchunk = (uint32_t)std::max<uint64_t>(1, nchunk_all > chunk0 ? nchunk_all - chunk0 : 1);
   const uint64_t ncell64 = (uint64_t)c->nwin * c->nchunk;
   if (ncell64 >= 0x7FFFFFFFull) {
     delete c;
-    return xf::set_error(XF_EINVAL, "cells_build: %llu cells", (unsigned long long)ncell64);
+    return xf::set_error(XF_EINVAL, "cells: %llu cells", (unsigned long long)ncell64);
   }
   c->ncell = (uint32_t)ncell64;
   c->nblk = (NNZ + kBlk - 1) / kBlk;
@@ -550,83 +595,63 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   // window fills the LDS).  Group g of EVERY window runs on XCD g % 8 (k_lr_fwd_cells), so the
   // windows read a weight range through one L2: once from HBM instead of once per window.
   c->G = c->nwin <= 32 ? (kFwdGroups / 8 / c->nwin) * 8 : 8;
-  struct Guard {
-    xf_cells *c;
-    ~Guard() {
-      if (c) cells_free(c);
-    }
-  } guard{c};
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  // the big arrays have known sizes: sorted straight into the batch's own allocation
   const size_t o_ent = 0;
   const size_t o_entk = o_ent + al((size_t)NNZ * 4);
   const size_t o_cellptr = o_entk + al(key_sorted_copy ? (size_t)NNZ * 4 : 0);
   const size_t o_blk = o_cellptr + al(((size_t)c->ncell + 1) * 4);
-  const size_t total = o_blk + al(((size_t)c->nblk + 1) * 4) + 256;
-  XF_TRY(blob_alloc((void **)&c->blob, total, &c->blob_bytes));
+  const size_t o_plan = o_blk + al(((size_t)c->nblk + 1) * 4);
+  const size_t total = o_plan + al(3 * ((size_t)c->nchunk + 1) * 4) + 256;
+  int rc = blob_alloc((void **)&c->blob, total, &c->blob_bytes);
+  if (rc != XF_OK) {
+    delete c;
+    return rc;
+  }
   c->entries = (uint32_t *)(c->blob + o_ent);
   c->entries_k = key_sorted_copy ? (uint32_t *)(c->blob + o_entk) : c->entries;
   c->cellptr = (uint32_t *)(c->blob + o_cellptr);
   c->blk_cell = (uint32_t *)(c->blob + o_blk);
+  c->plan = (uint32_t *)(c->blob + o_plan);
+  *out = c;
+  return XF_OK;
+}
+
+// the forward's copy: every cell sorted by its entries' low bits (the position within the
+// chunk), stable, so that neighbouring lanes gather neighbouring weights (forward kernel
+// 58 -> 42 us on the config-2 shape; the segmented sort takes 100 us, so a minibatch that is
+// stepped once goes without and the forward reads the row-sorted cells)
+int cells_key_sorted_copy(xf_cells *c, hipStream_t s) {
+  if (!c->NNZ || c->entries_k == c->entries) return XF_OK;
   Scratch sc;
-  uint32_t *cid = nullptr, *ent = nullptr, *cid_s = nullptr;
-  XF_TRY(sc.get(&cid, NNZ));
-  XF_TRY(sc.get(&ent, NNZ));
-  XF_TRY(sc.get(&cid_s, NNZ));
-  if (NNZ) {
-    if (d_rowid)
-      hipLaunchKernelGGL(k_cell_keys_rowid, dim3(grid_for((size_t)NNZ)), dim3(kBlock), 0, s,
-                         d_rowid, d_src, (size_t)NNZ, c->W, c->nchunk, cid, ent);
-    else
-      hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s,
-                         d_rowptr, d_src, d_map, R, c->W, c->nchunk, cid, ent);
-    int bits = 1;
-    while (bits < 32 && (1ull << bits) < ncell64) ++bits;
-    size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0, bits,
-                                     s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0, bits, s));
-  }
-  hipLaunchKernelGGL(k_cellptr, dim3(grid_for((size_t)c->ncell + 1)), dim3(kBlock), 0, s, cid_s,
-                     NNZ, c->ncell, c->cellptr);
-  hipLaunchKernelGGL(k_blk_cell, dim3(grid_for((size_t)c->nblk + 1)), dim3(kBlock), 0, s, cid_s,
-                     c->nblk, c->ncell, c->blk_cell);
-  if (NNZ && key_sorted_copy) {
-    // the forward's copy: every cell sorted by its entries' low bits (the position within
-    // the chunk), stable, so that neighbouring lanes gather neighbouring weights (forward
-    // kernel 58 -> 42 us on the config-2 shape; the segmented sort takes 100 us, so a
-    // minibatch that is stepped once goes without and the forward reads the row-sorted cells)
-    size_t tb = 0;
-    XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, c->entries, c->entries_k, (size_t)NNZ,
-                                              (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
-                                              kChunkBits, s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, c->entries, c->entries_k, (size_t)NNZ,
-                                              (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
-                                              kChunkBits, s));
-  }
-  // gradient work items
+  size_t tb = 0;
+  XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, c->entries, c->entries_k,
+                                            (size_t)c->NNZ, (unsigned)c->ncell, c->cellptr,
+                                            c->cellptr + 1, 0, kChunkBits, s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, c->entries, c->entries_k, (size_t)c->NNZ,
+                                            (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
+                                            kChunkBits, s));
+  XF_HIP(hipStreamSynchronize(s));  // the scratch goes back
+  return XF_OK;
+}
+
+// gradient work items, part 1 (on the device, into the cells' own allocation): slices per
+// chunk and their scans; the totals are plan[2*(nchunk+1) - 1] (items) and plan[3*(nchunk+1) - 1]
+// (split chunks)
+int cells_plan_items(xf_cells *c, hipStream_t s) {
   const size_t nc1 = (size_t)c->nchunk + 1;
-  uint32_t *nsl = nullptr, *nsplit = nullptr, *off = nullptr, *soff = nullptr;
-  XF_TRY(sc.get(&nsl, nc1));
-  XF_TRY(sc.get(&nsplit, nc1));
-  XF_TRY(sc.get(&off, nc1));
-  XF_TRY(sc.get(&soff, nc1));
-  hipLaunchKernelGGL(k_chunk_slices, dim3(grid_for(nc1)), dim3(kBlock), 0, s, c->cellptr,
-                     c->nchunk, c->nwin, nsl, nsplit);
-  XF_TRY(exclusive_scan_u32(sc, nsl, off, nc1, s));
-  XF_TRY(exclusive_scan_u32(sc, nsplit, soff, nc1, s));
-  uint32_t totals[2] = {0, 0};
-  XF_HIP(hipMemcpyAsync(&totals[0], off + c->nchunk, 4, hipMemcpyDeviceToHost, s));
-  XF_HIP(hipMemcpyAsync(&totals[1], soff + c->nchunk, 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(kPlanBlock), 0, s, c->cellptr, c->nchunk,
+                     c->nwin, c->plan, c->plan + nc1, c->plan + 2 * nc1);
   XF_HIP(hipGetLastError());
-  XF_HIP(hipStreamSynchronize(s));
-  c->nitems = totals[0];
-  c->nsplit_chunks = totals[1];
-  // ... and the small ones, whose sizes the data decides
+  return XF_OK;
+}
+
+// part 2, once the host knows the totals: the item lists and the split chunks' accumulators
+int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t s) {
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  c->nitems = nitems;
+  c->nsplit_chunks = nsplit;
   const size_t o_ic = 0;
   const size_t o_is = o_ic + al((size_t)c->nitems * 4);
   const size_t o_id = o_is + al((size_t)c->nitems * 4);
@@ -643,10 +668,68 @@ int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
   c->split_chunk = (uint32_t *)(d + o_sc);
   c->gsum = (double *)(d + o_gd);
   c->gtouched = (uint8_t *)(d + o_td);
+  const size_t nc1 = (size_t)c->nchunk + 1;
   if (c->nitems)
-    hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, nsl, off, soff,
-                       c->nchunk, c->item_chunk, c->item_slice, c->item_dump, c->split_chunk);
+    hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, c->plan,
+                       c->plan + nc1, c->plan + 2 * nc1, c->nchunk, c->item_chunk,
+                       c->item_slice, c->item_dump, c->split_chunk);
   XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
+                const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
+                bool key_sorted_copy, hipStream_t s, const uint32_t *d_rowid, uint32_t w_fixed,
+                uint32_t chunk0) {
+  XF_REQUIRE(out && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_src),
+             "cells_build: null argument");
+  XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax && !d_map),
+             "cells_build: row ids need a window size");
+  xf_cells *c = nullptr;
+  XF_TRY(cells_alloc(&c, R, NNZ, M, mode, key_sorted_copy, w_fixed, chunk0));
+  struct Guard {
+    xf_cells *c;
+    ~Guard() {
+      if (c) cells_free(c);
+    }
+  } guard{c};
+  {
+    Scratch sc;
+    uint32_t *cid = nullptr, *ent = nullptr, *cid_s = nullptr;
+    XF_TRY(sc.get(&cid, NNZ));
+    XF_TRY(sc.get(&ent, NNZ));
+    XF_TRY(sc.get(&cid_s, NNZ));
+    if (NNZ) {
+      if (d_rowid)
+        hipLaunchKernelGGL(k_cell_keys_rowid, dim3(grid_for((size_t)NNZ)), dim3(kBlock), 0, s,
+                           d_rowid, d_src, (size_t)NNZ, c->W, c->nchunk, chunk0, cid, ent);
+      else
+        hipLaunchKernelGGL(k_cell_keys, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s,
+                           d_rowptr, d_src, d_map, R, c->W, c->nchunk, chunk0, cid, ent);
+      int bits = 1;
+      while (bits < 32 && (1ull << bits) < (uint64_t)c->ncell) ++bits;
+      size_t tb = 0;
+      XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0,
+                                       bits, s));
+      void *tmp = nullptr;
+      XF_TRY(sc.get((char **)&tmp, tb));
+      XF_HIP(rocprim::radix_sort_pairs(tmp, tb, cid, cid_s, ent, c->entries, (size_t)NNZ, 0, bits,
+                                       s));
+    }
+    hipLaunchKernelGGL(k_cellptr, dim3(grid_for((size_t)c->ncell + 1)), dim3(kBlock), 0, s, cid_s,
+                       NNZ, c->ncell, c->cellptr);
+    hipLaunchKernelGGL(k_blk_cell, dim3(grid_for((size_t)c->nblk + 1)), dim3(kBlock), 0, s, cid_s,
+                       c->nblk, c->ncell, c->blk_cell);
+    XF_TRY(cells_plan_items(c, s));
+    uint32_t totals[2] = {0, 0};
+    const size_t nc1 = (size_t)c->nchunk + 1;
+    XF_HIP(hipMemcpyAsync(&totals[0], c->plan + 2 * nc1 - 1, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipMemcpyAsync(&totals[1], c->plan + 3 * nc1 - 1, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipGetLastError());
+    XF_HIP(hipStreamSynchronize(s));
+    XF_TRY(cells_fill_items(c, totals[0], totals[1], s));
+  }
+  XF_TRY(cells_key_sorted_copy(c, s));
   XF_HIP(hipStreamSynchronize(s));
   guard.c = nullptr;
   *out = c;
@@ -657,8 +740,11 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
                      double *d_partial, float *d_loss, float *d_pctr, hipStream_t s) {
   XF_REQUIRE(c && d_w && d_partial && (d_loss || d_pctr), "cells_lr_forward: null argument");
   if (c->R == 0) return XF_OK;
-  hipLaunchKernelGGL(k_lr_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->entries_k,
-                     c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, d_w, d_partial);
+  int acc = 0;
+  for (const xf_cells *q = c; q; q = q->next, acc = 1)
+    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->entries_k,
+                       q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
+                       d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);
   hipLaunchKernelGGL(k_lr_finalize_cells,
                      dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                      d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
@@ -679,6 +765,7 @@ struct CellSources {
 template <int OPT, int MODE>
 static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss, float *d_g,
                        hipStream_t s, const CellSources *src = nullptr) {
+  if (c->nitems == 0) return XF_OK;
   double *gsum = src ? src->gsum : c->gsum;
   uint8_t *gtouched = src ? src->gtouched : c->gtouched;
   if (c->nsplit_chunks) {
@@ -694,18 +781,20 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
-                       src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base);
+                       src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
+                       c->chunk0);
   else
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
                        T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
                        (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
-                       (const uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, c->chunk0);
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
                        c->split_chunk, gsum, gtouched, c->R, c->M, d_g, src ? src->n : 1u,
-                       src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks);
+                       src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks,
+                       c->chunk0);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }
@@ -713,8 +802,8 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
 // gradient only: g_out[idx] for every index position the minibatch touches
 int cells_lr_grad(const xf_cells *c, const float *d_loss, float *d_g, hipStream_t s) {
   XF_REQUIRE(c && d_loss && d_g, "cells_lr_grad: null argument");
-  if (c->nitems == 0) return XF_OK;
-  return launch_grad<XF_OPT_SGD, 1>(c, TableDev{}, d_loss, d_g, s);
+  for (; c; c = c->next) XF_TRY((launch_grad<XF_OPT_SGD, 1>(c, TableDev{}, d_loss, d_g, s)));
+  return XF_OK;
 }
 
 // gradient + Push on the table the cells were compiled against (d_g: optional dense copy of
@@ -723,19 +812,22 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
                          hipStream_t s) {
   XF_REQUIRE(c && t && d_loss, "cells_lr_grad_update: null argument");
   XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update: cells are not table rows");
-  if (c->nitems == 0) return XF_OK;
   const TableDev &T = table_dev(t);
   XF_REQUIRE(T.dim == 1, "cells_lr_grad_update: dim must be 1");
-  if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, d_g, s);
-  return launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, d_g, s);
+  for (; c; c = c->next) {
+    if (T.nz != nullptr) XF_TRY((launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, d_g, s)));
+    else
+      XF_TRY((launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, d_g, s)));
+  }
+  return XF_OK;
 }
 
 // The owner-compute step's gradient + Pushes: the cells hold the rows of `n` workers (windows
 // [d_win[q], d_win[q+1]) are worker q's), the losses of window v start at d_loss[d_loss_base[v]]
 // (the workers' losses back to back, as they arrive); every
 // worker's gradient (its sum / d_rows[q]) is its own optimizer step, applied in rank order.
-// d_gsum / d_gtouched: n * nsplit_chunks * kChunk elements of scratch (null when no chunk of
-// the cells is split).
+// d_gsum / d_gtouched: n * cells_split_chunks(c) * kChunk elements of scratch (null when no
+// chunk of the cells is split).
 int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
                                  uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
                                  const uint32_t *d_loss_base, double *d_gsum,
@@ -743,20 +835,25 @@ int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const flo
   XF_REQUIRE(c && t && d_loss && n && d_win && d_rows && d_loss_base,
              "cells_lr_grad_update_sources: null");
   XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update_sources: cells are not table rows");
-  XF_REQUIRE(c->nsplit_chunks == 0 || (d_gsum && d_gtouched),
+  XF_REQUIRE(cells_split_chunks(c) == 0 || (d_gsum && d_gtouched),
              "cells_lr_grad_update_sources: no scratch for the split chunks");
-  if (c->nitems == 0) return XF_OK;
   const TableDev &T = table_dev(t);
   XF_REQUIRE(T.dim == 1, "cells_lr_grad_update_sources: dim must be 1");
-  CellSources src;
-  src.n = n;
-  src.d_win = d_win;
-  src.d_rows = d_rows;
-  src.d_loss_base = d_loss_base;
-  src.gsum = d_gsum;
-  src.gtouched = d_gtouched;
-  if (T.nz != nullptr) return launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, nullptr, s, &src);
-  return launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, nullptr, s, &src);
+  size_t used = 0;  // split chunks of the segments before this one
+  for (; c; c = c->next) {
+    CellSources src;
+    src.n = n;
+    src.d_win = d_win;
+    src.d_rows = d_rows;
+    src.d_loss_base = d_loss_base;
+    src.gsum = d_gsum ? d_gsum + (size_t)n * used * kChunk : nullptr;
+    src.gtouched = d_gtouched ? d_gtouched + (size_t)n * used * kChunk : nullptr;
+    used += c->nsplit_chunks;
+    if (T.nz != nullptr) XF_TRY((launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, nullptr, s, &src)));
+    else
+      XF_TRY((launch_grad<XF_OPT_SGD, 0>(c, T, d_loss, nullptr, s, &src)));
+  }
+  return XF_OK;
 }
 
 // forward up to the row sums: d_rowsum[window * W + row-in-window] = sum of the row's weights
@@ -789,8 +886,11 @@ int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial
   XF_REQUIRE(c && d_w && d_partial && d_rowsum && d_out_base && d_out_rows,
              "cells_lr_forward_sums: null argument");
   if (c->R == 0) return XF_OK;
-  hipLaunchKernelGGL(k_lr_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->entries_k,
-                     c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, d_w, d_partial);
+  int acc = 0;
+  for (const xf_cells *q = c; q; q = q->next, acc = 1)
+    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->entries_k,
+                       q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
+                       d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);
   const uint32_t n = c->nwin * c->W;
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)(((size_t)n * 4 + kBlock - 1) / kBlock)),
                      dim3(kBlock), 0, s, d_partial, n, c->W, c->G, d_out_base, d_out_rows,
@@ -825,13 +925,8 @@ int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s) {
                "this minibatch was compiled against another table (or the table has renumbered "
                "its rows since) and did not keep its keys: compile it again, or with "
                "retain_keys = 1");
-    Scratch sc;
-    uint32_t *idx = nullptr;
-    XF_TRY(sc.get(&idx, b->NNZ));
-    XF_TRY(table_resolve_any(t, b->raw_keys, b->NNZ, idx, s, true));
-    const uint64_t M = table_dev(t).max_rows + 1;
-    XF_TRY(cells_build(&c, idx, nullptr, b->raw_rowptr, b->R, b->NNZ, (uint32_t)M,
-                       kCellsTableRows, true, s));
+    XF_TRY(cells_build_keyed(&c, t, b->raw_keys, b->raw_rowptr, nullptr, b->R, b->NNZ, true, 0,
+                             s));
   } else {
     XF_TRY(xf_batch_upload(b, s));
     if (!b->d_rows_u) XF_HIP(hipMalloc((void **)&b->d_rows_u, std::max<size_t>(b->U, 1) * 4));
@@ -887,15 +982,8 @@ extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uin
     XF_HIP(hipMemcpyAsync(d + o_rp, d_rowptr, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, s));
     if (NNZ) XF_HIP(hipMemcpyAsync(d + o_keys, d_keys, (size_t)NNZ * 8, hipMemcpyDeviceToDevice, s));
   }
-  {
-    xf::Scratch sc;
-    uint32_t *idx = nullptr;
-    XF_TRY(sc.get(&idx, NNZ));
-    XF_TRY(xf::table_resolve_any(t, d_keys, NNZ, idx, s, true));
-    const uint64_t M = xf::table_dev(t).max_rows + 1;
-    XF_TRY(xf::cells_build(&b->cells, idx, nullptr, d_rowptr, R, NNZ, (uint32_t)M,
-                           xf::kCellsTableRows, retain_keys != 0, s));
-  }
+  XF_TRY(xf::cells_build_keyed(&b->cells, t, d_keys, d_rowptr, nullptr, R, NNZ, retain_keys != 0,
+                               0, s));
   b->cells->table_uid = xf::table_uid(t);
   b->cells->epoch = xf::table_epoch(t);
   if (retain_keys) {
@@ -938,12 +1026,19 @@ extern "C" int xf_batch_compile_local(xf_batch **out, xf_table *t, const uint64_
 }
 
 // shape of a batch's cells (tests / bench): out[0..8) = W, nwin, nchunk, G, nitems,
-// 0 (reserved), nsplit_chunks, M
+// segments, nsplit_chunks, M
 extern "C" int xf_batch_cells_info(const xf_batch *b, uint32_t *out) {
   XF_REQUIRE(b && out, "xf_batch_cells_info: null argument");
   XF_REQUIRE(b->cells, "xf_batch_cells_info: the batch has no cells yet");
   const xf_cells *c = b->cells;
-  const uint32_t v[8] = {c->W, c->nwin, c->nchunk, c->G, c->nitems, 0, c->nsplit_chunks, c->M};
+  uint32_t nchunk = 0, nitems = 0, nseg = 0;
+  for (const xf_cells *q = c; q; q = q->next) {  // the segments of the batch's cells
+    nchunk = std::max(nchunk, q->chunk0 + q->nchunk);
+    nitems += q->nitems;
+    ++nseg;
+  }
+  const uint32_t v[8] = {c->W, c->nwin, nchunk, c->G, nitems, nseg, xf::cells_split_chunks(c),
+                         c->M};
   for (int i = 0; i < 8; ++i) out[i] = v[i];
   return XF_OK;
 }

@@ -1,0 +1,1211 @@
+// xf_keybuild.hip — the key build of LRWorker::update (src/model/lr/lr_worker.cc:146-166 of
+// /root/reference) plus the key -> state row step of its Pull (lr_worker.cc:170, ftrl.h:56),
+// raw keys in, cells (xf_cells.h) out, for a table that has a settled tier (gfx950).
+//
+// The reference sorts (fid, row) by fid and walks the sorted list against the sorted unique
+// keys.  A sort of 1e7 64-bit keys is ~1 ms on this GPU and a random probe of the table per
+// nonzero moves a 128-byte line for an 8-byte key (round 2: 2.2 GB and 300 us per minibatch).
+// Here the nonzeros are PARTITIONED by key range instead, and the lookup happens where the
+// table's keys of that range sit in LDS:
+//
+//   the settled tier holds the table's keys sorted, key of rank r = state row r; chunk c of the
+//   index space (kChunk rows) is therefore a key RANGE [bkeys[c * kChunk], bkeys[(c+1) * kChunk)),
+//   a super-chunk S is kSC chunks (8192 keys = 64 KiB of LDS).
+//
+//   k_kb_hist     nonzeros per cell (row window, chunk) and per (workgroup, super-chunk): the
+//                 chunk of a key from the chunk boundaries and their directory (in LDS),
+//                 counted in LDS histograms
+//   k_kb_scan     cellptr (window-major scan of the cell counts), the gradient's work items,
+//                 where every scatter workgroup's records of every super-chunk begin
+//   k_kb_scatter  (key, row) records grouped by super-chunk: a tile of 8192 nonzeros is
+//                 grouped in LDS and leaves in runs of neighbouring records (one partition pass
+//                 into ~1200 buckets, no atomics on memory)
+//   k_kb_resolve  one workgroup per super-chunk: its 8192 keys and a directory over them in
+//                 LDS, every record finds its key there (position = state row), takes the next
+//                 slot of its cell and becomes a 4-byte entry
+//
+// Keys the settled tier does not hold (new since the last xf_table_defrag, or the reserved key
+// value) leave a hole in their cell (an entry the kernels skip) and go to a miss list; they are
+// inserted by the general path (table_resolve_any) and form a second SEGMENT of the batch's
+// cells (xf_cells::next) over the arrival rows.  In the steady state (every key settled) the
+// list is empty and the build is four streaming passes and ONE host synchronisation.
+// HBM-bound integer work, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "xf_batch.h"
+#include "xf_cells.h"
+#include "xf_device.h"
+#include "xf_scratch.h"
+
+namespace xf {
+const TableDev &table_dev(const xf_table *t);
+void **table_aux(xf_table *t, uint64_t **epoch);
+uint64_t table_epoch(const xf_table *t);
+int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
+                      hipStream_t s, bool allow_grow);
+}  // namespace xf
+
+namespace {
+
+using xf::kBlk;
+using xf::kChunk;
+using xf::kChunkBits;
+using xf::kTagShift;
+
+constexpr int kKb = 1024;                        // threads of the workgroups here
+#ifndef XF_KB_SC_SHIFT
+#define XF_KB_SC_SHIFT 2
+#endif
+constexpr int kSCShift = XF_KB_SC_SHIFT;
+constexpr uint32_t kSC = 1u << kSCShift;         // chunks per super-chunk
+constexpr uint32_t kSCKeys = kSC * kChunk;       // keys per super-chunk (in LDS: 8 B each)
+constexpr uint32_t kDirMax = kSCKeys / 2;        // buckets of a super-chunk's directory
+constexpr uint32_t kDirStride = kDirMax + 8;     // u16 per super-chunk in the aux allocation
+#ifndef XF_KB_TILE
+#define XF_KB_TILE 8192
+#endif
+constexpr uint32_t kTile = XF_KB_TILE;           // nonzeros per scatter tile
+constexpr uint32_t kPart = 32768;                // records per resolve work item
+constexpr uint32_t kBatch = 8192;                // ... taken into registers at a time
+constexpr uint32_t kRowSeg = 1024;               // row offsets a scatter tile keeps in LDS
+constexpr uint32_t kHole = 0xFFFFFFFFu;          // an entry the step kernels skip
+constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kDynMax = kLdsMax - 1024;       // dynamic LDS a kernel here may ask for
+constexpr uint32_t kRinBits = 15;                // record row = window << 15 | row in window
+constexpr uint32_t kLocalCells = 1024;           // cell cursors a resolve item keeps in LDS
+
+// Ranges of the key space and the directory that finds a key's range with two LDS reads: range
+// r begins at key bnd[r]; bucket(key) = mulhi32((key - lo) >> 32, mult) cuts the shard's key span
+// into as many equal buckets as there are ranges (32-bit arithmetic: a 64-bit mulhi is six
+// quarter-rate multiplies, and the histogram pass is VALU-bound); dir[b] = number of ranges
+// that begin in buckets < b.
+// A key of bucket b lies in range dir[b] - 1 + (ranges that begin in bucket b at or below it):
+// the keys are uniform hashes, a bucket holds one boundary, sometimes none or two.
+struct KbRanges {
+  const uint64_t *bnd;   // [n]
+  const uint16_t *dir;   // [n + 1]
+  uint32_t n;
+  uint32_t mult;
+};
+
+// a record of the scatter: key and window << 15 | row in window, 12 bytes, one store / one load
+struct __attribute__((packed, aligned(4))) Rec3 {
+  uint32_t klo, khi, rp;
+};
+
+// what the host reads back after the build (one copy)
+struct KbSummary {
+  unsigned long long miss;
+  uint32_t nitems, nsplit;
+};
+
+struct KbArgs {
+  const uint64_t *keys;
+  const uint32_t *rowptr, *rowid;  // one of the two
+  uint32_t R, NNZ, W, nwin;
+  uint32_t cA, nS, ntile;          // chunks / super-chunks of the settled tier; scatter tiles
+  uint32_t span, nW;               // nonzeros per histogram / scatter workgroup; workgroups
+  uint32_t nbase;
+  const uint64_t *bkeys;           // the tier's keys, ascending; chunk c begins at bkeys[c << 11]
+  uint64_t lo;
+  KbRanges ch, sc;                 // chunks, super-chunks
+  const uint16_t *sdirs;           // [nS * kDirStride] directory of every super-chunk's keys
+  const uint64_t *smult;           // [nS] its bucket multiplier
+  uint32_t *hist;                  // [nwin * cA]
+  uint32_t *cellptr;               // [nwin * cA + 1]
+  uint32_t *cellcur;               // [nwin * cA] next free slot of every cell
+  uint32_t *scount;                // [nS] records of every super-chunk
+  uint32_t *sstart;                // [nS + 1] first record of every super-chunk
+  uint32_t *wgcnt;                 // [nW * nS] records of workgroup w for super-chunk S; scanned
+                                   // over w: where the workgroup's share of S begins
+  uint32_t *tile_r0;               // [ntile] row of every tile's first nonzero (CSR input)
+  uint32_t *plan;                  // the cells' item plan (xf_cells::plan)
+  uint32_t *blk_cell;              // the cells' blk_cell
+  uint32_t *items;                 // resolve work items: super-chunk | part << 16
+  uint32_t *nitems;                // their number
+  uint32_t flags;                  // experiments (exp_knob)
+  Rec3 *rec;                       // [NNZ] records, grouped by super-chunk
+  uint32_t *entries;               // [NNZ] the cells
+  uint64_t *missK;                 // [NNZ] miss list: key,
+  uint32_t *missR;                 // [NNZ]            row
+  KbSummary *sum;                  // device copy
+  unsigned long long *dbg;         // phase timestamps (tools/kb_timeline.py), or null
+};
+#define KB_T(slot)                                                                   \
+  do {                                                                               \
+    if (a.dbg && threadIdx.x == 0) dbg_base[(slot)] = wall_clock64();                \
+  } while (0)
+constexpr int kDbgSlots = 24;
+
+__device__ __forceinline__ uint32_t kb_bucket(uint64_t key, uint64_t lo, uint32_t mult,
+                                              uint32_t n) {
+  return key < lo ? 0u : min(__umulhi((uint32_t)((key - lo) >> 32), mult), n - 1);
+}
+// the bucket of a key inside one super-chunk (k_kb_sdir): sm = multiplier | shift << 32
+__device__ __forceinline__ uint32_t kb_sbucket(uint64_t key, uint64_t kfirst, uint64_t sm,
+                                               uint32_t nb) {
+  if (key < kfirst) return 0u;
+  const uint64_t d = (key - kfirst) >> (uint32_t)(sm >> 32);
+  return d > 0xFFFFFFFFull ? nb - 1 : min(__umulhi((uint32_t)d, (uint32_t)sm), nb - 1);
+}
+// the number of ranges that begin at or below `key`, from its bucket's directory pair [s, e) and
+// the bucket's first two boundaries (x0 = bnd[s], x1 = bnd[s + 1], read by the caller for all
+// its keys at once)
+template <typename B>
+__device__ __forceinline__ uint32_t kb_count(const B &bnd, uint32_t s, uint32_t e, uint64_t x0,
+                                             uint64_t x1, uint64_t key) {
+  uint32_t r = s + ((s < e && x0 <= key) ? 1u : 0u) + ((s + 1 < e && x1 <= key) ? 1u : 0u);
+  if (e - s > 2 && r == s + 2)
+    while (r < e && bnd(r) <= key) ++r;
+  return r;
+}
+// ... and the range the key lies in (keys below every boundary count as range 0)
+template <typename B>
+__device__ __forceinline__ uint32_t kb_range(const B &bnd, uint32_t s, uint32_t e, uint64_t x0,
+                                             uint64_t x1, uint64_t key) {
+  const uint32_t r = kb_count(bnd, s, e, x0, x1, key);
+  return r ? r - 1 : 0u;
+}
+
+// bnd / dir of the chunks or the super-chunks of a settled tier (one launch per table epoch)
+__global__ void __launch_bounds__(256)
+k_kb_index(const uint64_t *__restrict__ bkeys, uint64_t lo, uint32_t n, int shift, uint32_t mult,
+           uint64_t *__restrict__ bnd, uint16_t *__restrict__ dir) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r < n) bnd[r] = bkeys[(size_t)r << shift];
+  const uint32_t first = r == 0 ? 0u : kb_bucket(bkeys[(size_t)(r - 1) << shift], lo, mult, n) + 1;
+  const uint32_t last = r == n ? n : kb_bucket(bkeys[(size_t)r << shift], lo, mult, n);
+  for (uint32_t b = first; b <= last; ++b) dir[b] = (uint16_t)r;
+}
+
+// The directory of one super-chunk's keys (one workgroup per super-chunk, once per table
+// epoch): a linear map of the super-chunk's key range onto nk / 2 buckets, dir[b] = first
+// position whose key lies in a bucket >= b (kb_sbucket: any monotone map does as long as the
+// look-up uses the same).
+__global__ void __launch_bounds__(256)
+k_kb_sdir(const uint64_t *__restrict__ bkeys, uint32_t nbase, uint16_t *__restrict__ sdirs,
+          uint64_t *__restrict__ smult) {
+  const uint32_t S = blockIdx.x, k0 = S * kSCKeys, nk = min(kSCKeys, nbase - k0);
+  const uint64_t *__restrict__ lk = bkeys + k0;
+  uint16_t *__restrict__ dir = sdirs + (size_t)S * kDirStride;
+  const uint64_t kfirst = lk[0], range = lk[nk - 1] - kfirst;
+  const uint32_t nb = max(nk / 2, 1u);
+  // the key range shifted into 32 bits; multiplier = nb * 2^32 / (shifted range + 1)
+  const uint32_t sh = range >> 32 ? 32u - (uint32_t)__clzll((long long)range) : 0u;
+  const uint64_t m = ((uint64_t)nb << 32) / ((range >> sh) + 1);
+  const uint64_t sm = (m > 0xFFFFFFFFull ? 0xFFFFFFFFull : m) | ((uint64_t)sh << 32);
+  if (threadIdx.x == 0) smult[S] = sm;
+  auto bucket = [&](uint64_t key) -> uint32_t { return kb_sbucket(key, kfirst, sm, nb); };
+  for (uint32_t i = threadIdx.x; i < nk; i += blockDim.x) {
+    const uint32_t bi = bucket(lk[i]);
+    const uint32_t bp = i ? bucket(lk[i - 1]) + 1 : 0u;
+    for (uint32_t b = bp; b <= bi; ++b) dir[b] = (uint16_t)i;
+    if (i == nk - 1)
+      for (uint32_t b = bi + 1; b <= nb; ++b) dir[b] = (uint16_t)nk;
+  }
+}
+
+// the largest r in [0, n) with p[r] <= j (p ascending, p[0] <= j), found by ONE wavefront: 64
+// probes per round instead of a chain of log2(n) dependent loads
+__device__ __forceinline__ uint32_t wave_last_le(const uint32_t *__restrict__ p, uint32_t n,
+                                                 uint32_t j) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {  // wave-uniform
+    const uint32_t step = (hi - lo + 63) / 64;
+    const uint32_t i = lo + lane * step;
+    const bool le = i < hi && p[i] <= j;  // monotone over the lanes, lane 0 true
+    const uint32_t k = (uint32_t)__popcll(__ballot(le)) - 1u;
+    lo += k * step;
+    hi = min(hi, lo + step);
+  }
+  return lo;
+}
+
+// the window of entry j (CSR order): the largest v with rowptr[min(v * W, R)] <= j
+__device__ __forceinline__ uint32_t window_of_entry(const uint32_t *__restrict__ rowptr,
+                                                    uint32_t R, uint32_t W, uint32_t nwin,
+                                                    uint32_t j) {
+  uint32_t a = 0, b = nwin;
+  while (b - a > 1) {
+    const uint32_t m = a + (b - a) / 2;
+    if (rowptr[min((uint64_t)m * W, (uint64_t)R)] <= j) a = m;
+    else
+      b = m;
+  }
+  return a;
+}
+
+// a workgroup barrier that orders LDS accesses only: __syncthreads() also waits for the
+// wavefront's outstanding global loads and stores (its fence), which is exactly what a
+// prefetch in flight across the barrier must not be made to do
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool LDS_ONLY = false>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *wsum, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += t;
+  }
+  if (LDS_ONLY) lds_barrier();  // wsum may still be read from the previous call
+  else
+    __syncthreads();
+  if (lane == 63) wsum[wave] = inc;
+  if (LDS_ONLY) lds_barrier();
+  else
+    __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < kKb / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return base + inc - x;
+}
+
+// ------------------------------------------------------------------------------ histogram
+// Workgroup w takes the nonzeros [w * span, (w + 1) * span), span a multiple of kTile (the same
+// workgroup of the scatter takes the same nonzeros).  hist[v * cA + c] = nonzeros of window v
+// whose key falls into chunk c; wgcnt[w * nS + S] = nonzeros of the workgroup whose key falls
+// into super-chunk S; tile_r0[t] = the row of the first nonzero of tile t (CSR input).  The
+// counts of a window gather in LDS and are flushed when the workgroup's nonzeros move on to
+// the next window (CSR input: windows are ranges of nonzeros; with row ids the first nonzero's
+// window is the one in LDS and the others' counts go straight to memory).
+__host__ __device__ inline size_t hist_lds_bytes(uint32_t cA, uint32_t nS, bool ldsb) {
+  return (ldsb ? (size_t)cA * 8 + ((size_t)cA * 4 + 7) / 8 * 8 : 0) + (size_t)cA * 4 +
+         (size_t)nS * 4;
+}
+
+template <bool ROWID, bool LDSB>
+__global__ void __launch_bounds__(kKb)
+k_kb_hist(KbArgs a) {
+  extern __shared__ uint64_t smem[];
+  uint64_t *lb = smem;
+  uint32_t *ld2 = (uint32_t *)(smem + a.cA);  // dir[b] | dir[b + 1] << 16: one read per key
+  uint32_t *lh = (uint32_t *)(smem + (LDSB ? a.cA + ((size_t)a.cA + 1) / 2 : 0));
+  uint32_t *ls = lh + a.cA;
+  __shared__ uint32_t s_v, s_end;
+  const uint32_t tid = threadIdx.x;
+  unsigned long long *dbg_base = a.dbg ? a.dbg + (size_t)blockIdx.x * kDbgSlots : nullptr;
+  KB_T(0);
+  const uint32_t e0 = blockIdx.x * a.span, e1 = min(e0 + a.span, a.NNZ);
+  const uint64_t *__restrict__ keys = a.keys;
+  const uint64_t *__restrict__ gb = a.ch.bnd;
+  const uint16_t *__restrict__ gd = a.ch.dir;
+  constexpr int E = 4;
+  constexpr uint32_t kRound = kKb * E;
+  // two register sets of keys that swap roles: the next round's keys are on their way while
+  // this round's are counted (no register copies: a copy would wait for the loads)
+  auto load_keys = [&](uint64_t *key, uint32_t j0) {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t j = j0 + q * kKb + tid;
+      key[q] = j < e1 ? keys[j] : 0;
+    }
+  };
+  uint64_t keyA[E], keyB[E];
+  load_keys(keyA, e0);
+  if (LDSB) {
+    for (uint32_t c = tid; c < a.cA; c += kKb) {
+      lb[c] = gb[c];
+      ld2[c] = (uint32_t)gd[c] | ((uint32_t)gd[c + 1] << 16);
+    }
+  }
+  for (uint32_t c = tid; c < a.cA; c += kKb) lh[c] = 0;
+  for (uint32_t S = tid; S < a.nS; S += kKb) ls[S] = 0;
+  if (tid == 0) {
+    if (ROWID) {
+      s_v = a.rowid[e0] / a.W;
+      s_end = e1;
+    } else {
+      const uint32_t v = window_of_entry(a.rowptr, a.R, a.W, a.nwin, e0);
+      s_v = v;
+      s_end = v + 1 < a.nwin ? a.rowptr[min((uint64_t)(v + 1) * a.W, (uint64_t)a.R)] : a.NNZ;
+    }
+  }
+  if (!ROWID) {  // a wavefront per tile of the workgroup: the row of the tile's first nonzero
+    const uint32_t wave = tid >> 6, ntl = (e1 - e0 + kTile - 1) / kTile;
+    for (uint32_t k = wave; k < ntl; k += kKb / 64) {
+      const uint32_t r = wave_last_le(a.rowptr, a.R, e0 + k * kTile);
+      if ((tid & 63u) == 0) a.tile_r0[e0 / kTile + k] = r;
+    }
+  }
+  __syncthreads();
+  KB_T(1);
+  uint32_t v0 = s_v, wend = min(s_end, e1);  // the window in LDS; its nonzeros end at wend
+  auto bnd = [&](uint32_t c) -> uint64_t { return LDSB ? lb[c] : gb[c]; };
+  auto dir2 = [&](uint32_t b) -> uint32_t {
+    return LDSB ? ld2[b] : (uint32_t)gd[b] | ((uint32_t)gd[b + 1] << 16);
+  };
+  auto process = [&](const uint64_t *key, uint32_t j0) {
+    if (!ROWID && j0 >= wend) {  // (workgroup-uniform) the nonzeros have left the window
+      __syncthreads();
+      for (uint32_t c = tid; c < a.cA; c += kKb) {
+        const uint32_t n = lh[c];
+        if (n) {
+          atomicAdd(&a.hist[(size_t)v0 * a.cA + c], n);
+          atomicAdd(&ls[c >> kSCShift], n);
+        }
+        lh[c] = 0;
+      }
+      if (tid == 0) {
+        const uint32_t v = window_of_entry(a.rowptr, a.R, a.W, a.nwin, j0);
+        s_v = v;
+        s_end = v + 1 < a.nwin ? a.rowptr[min((uint64_t)(v + 1) * a.W, (uint64_t)a.R)] : a.NNZ;
+      }
+      __syncthreads();
+      v0 = s_v;
+      wend = min(s_end, e1);
+    }
+    uint64_t x0[E], x1[E];
+    uint32_t dp[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) dp[q] = dir2(kb_bucket(key[q], a.lo, a.ch.mult, a.cA));
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      x0[q] = bnd(min(dp[q] & 0xFFFFu, a.cA - 1));
+      x1[q] = bnd(min((dp[q] & 0xFFFFu) + 1, a.cA - 1));
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t j = j0 + q * kKb + tid;
+      if (j >= e1) continue;
+      const uint32_t c = kb_range(bnd, dp[q] & 0xFFFFu, dp[q] >> 16, x0[q], x1[q], key[q]);
+      bool in_lds;
+      uint32_t v = v0;
+      if (ROWID) {
+        v = a.rowid[j] / a.W;
+        in_lds = v == v0;
+      } else {
+        in_lds = j < wend;  // (a round that straddles the window's end: its tail, rare)
+        if (!in_lds) v = window_of_entry(a.rowptr, a.R, a.W, a.nwin, j);
+      }
+      if (a.flags & 64) continue;
+      if (in_lds) {
+        atomicAdd(&lh[c], 1u);
+      } else {
+        atomicAdd(&a.hist[(size_t)v * a.cA + c], 1u);
+        atomicAdd(&ls[c >> kSCShift], 1u);
+      }
+    }
+  };
+  for (uint32_t j0 = e0; j0 < e1; j0 += 2 * kRound) {
+    if (j0 + kRound < e1) load_keys(keyB, j0 + kRound);
+    process(keyA, j0);
+    if (j0 + kRound >= e1) break;
+    if (j0 + 2 * kRound < e1) load_keys(keyA, j0 + 2 * kRound);
+    process(keyB, j0 + kRound);
+  }
+  KB_T(2);
+  __syncthreads();
+  KB_T(3);
+  if (!(a.flags & 1))
+    for (uint32_t c = tid; c < a.cA; c += kKb) {
+      const uint32_t n = lh[c];
+      if (n) {
+        atomicAdd(&a.hist[(size_t)v0 * a.cA + c], n);
+        atomicAdd(&ls[c >> kSCShift], n);
+      }
+    }
+  __syncthreads();
+  uint32_t *__restrict__ out = a.wgcnt + (size_t)blockIdx.x * a.nS;
+  for (uint32_t S = tid; S < a.nS; S += kKb) out[S] = ls[S];
+  KB_T(4);
+}
+
+// ----------------------------------------------------------------------------------- scan
+// Workgroup 0: cellptr = exclusive scan of hist (window-major), cellcur = its copy (the resolve
+// hands out the slots of a cell of a split super-chunk from it).  Workgroup 1: the gradient's
+// work items (what k_plan_items of xf_cells.hip computes, from the histogram).  The other
+// workgroups: one wavefront per super-chunk S, exclusive scan of wgcnt[. * nS + S] over the
+// scatter workgroups (where workgroup w's records of S begin, relative to the super-chunk's
+// first record) and scount[S] = the super-chunk's records.
+// The scans of workgroups 0 and 1 go through LDS in pieces of kScanPiece elements: coalesced
+// loads in, a thread scans 16 neighbouring elements (17-word stride: no bank conflicts),
+// coalesced stores out.
+constexpr uint32_t kScanPiece = 16 * kKb;
+__device__ __forceinline__ uint32_t sp(uint32_t i) { return i + (i >> 4); }
+
+template <typename F>
+__device__ __forceinline__ uint32_t staged_excl_scan(F in, uint32_t n, uint32_t *__restrict__ o1,
+                                                     uint32_t *__restrict__ o2, uint32_t *sbuf,
+                                                     uint32_t *wsum) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += kScanPiece) {
+    const uint32_t m = min(kScanPiece, n - base);
+    for (uint32_t i = tid; i < kScanPiece; i += kKb) sbuf[sp(i)] = i < m ? in(base + i) : 0u;
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += sbuf[sp(tid * 16 + k)];
+    uint32_t total;
+    uint32_t run = carry + block_excl_scan(sum, wsum, &total);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t x = sbuf[sp(tid * 16 + k)];
+      sbuf[sp(tid * 16 + k)] = run;
+      run += x;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += kKb) {
+      const uint32_t x = sbuf[sp(i)];
+      o1[base + i] = x;
+      if (o2) o2[base + i] = x;
+    }
+    carry += total;
+    __syncthreads();
+  }
+  return carry;
+}
+
+__global__ void __launch_bounds__(kKb)
+k_kb_scan(KbArgs a) {
+  __shared__ uint32_t sbuf[kScanPiece + kScanPiece / 16];
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t *__restrict__ hist = a.hist;
+  if (blockIdx.x > 1) {
+    const uint32_t S = (blockIdx.x - 2) * (kKb / 64) + (tid >> 6), lane = tid & 63u;
+    if (S >= a.nS) return;
+    uint32_t *__restrict__ col = a.wgcnt + S;
+    uint32_t carry = 0;
+    for (uint32_t w0 = 0; w0 < a.nW; w0 += 64) {
+      const uint32_t w = w0 + lane;
+      const uint32_t x = w < a.nW ? col[(size_t)w * a.nS] : 0u;
+      uint32_t inc = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += y;
+      }
+      if (w < a.nW) col[(size_t)w * a.nS] = carry + inc - x;
+      carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) a.scount[S] = carry;
+    return;
+  }
+  if (blockIdx.x == 1) {  // slices per chunk, first item of every chunk, index among the split
+    const size_t nc1 = (size_t)a.cA + 1;
+    uint32_t *__restrict__ nsl = a.plan, *__restrict__ off = a.plan + nc1,
+                          *__restrict__ soff = a.plan + 2 * nc1;
+    auto slices = [&](uint32_t c) -> uint32_t {
+      uint32_t n = 0;
+      for (uint32_t v = 0; v < a.nwin; ++v) n += hist[(size_t)v * a.cA + c];
+      return (n + xf::kSliceMax - 1) / xf::kSliceMax;
+    };
+    for (uint32_t c = tid; c < a.cA; c += kKb) nsl[c] = slices(c);
+    if (tid == 0) nsl[a.cA] = 0;
+    const uint32_t ta = staged_excl_scan(slices, a.cA, off, nullptr, sbuf, wsum);
+    const uint32_t tb = staged_excl_scan([&](uint32_t c) { return slices(c) > 1 ? 1u : 0u; },
+                                         a.cA, soff, nullptr, sbuf, wsum);
+    if (tid == 0) {
+      off[a.cA] = ta;
+      soff[a.cA] = tb;
+      a.sum->nitems = ta;
+      a.sum->nsplit = tb;
+    }
+    return;
+  }
+  const uint32_t ncell = a.nwin * a.cA;
+  const uint32_t total =
+      staged_excl_scan([&](uint32_t c) { return hist[c]; }, ncell, a.cellptr, a.cellcur, sbuf, wsum);
+  if (tid == 0) a.cellptr[ncell] = total;
+}
+
+// -------------------------------------------------------------------------------- scatter
+// Workgroup w walks the tiles of its nonzeros (the histogram's split).  Per tile of kTile
+// nonzeros: every nonzero's super-chunk (boundaries and their directory in LDS) and its rank
+// among the tile's nonzeros of that super-chunk (an LDS counter); the records laid out by
+// super-chunk in LDS and written out in that order — neighbouring lanes write neighbouring
+// records — to the workgroup's share of every super-chunk's record space (from the scan, moved
+// on tile by tile: no atomics on memory, same-address ones serialise at ~0.1 us each).  A
+// thread takes kTile / 1024 consecutive nonzeros (one row search, then a walk); the next tile's
+// keys are on their way while this one's records are written.  Workgroup 0 also leaves
+// sstart[] and the resolve's work items in memory.
+struct ScatterLds {
+  uint64_t *sb, *stK;
+  uint32_t *cnt, *lofs, *base, *stR, *rowseg, *sd2, *tr;
+  uint16_t *stB;
+};
+constexpr uint32_t kMaxSub = 32;  // tiles per scatter workgroup
+__host__ __device__ inline size_t scatter_lds_bytes(uint32_t nS) {
+  return (size_t)nS * 8 + (size_t)kTile * 8 +
+         ((size_t)nS * 4 + 1 + kTile + 2 * (kRowSeg + 2) + kMaxSub + 2) * 4 + (size_t)kTile * 2;
+}
+
+template <bool ROWID>
+__global__ void __launch_bounds__(kKb)
+k_kb_scatter(KbArgs a) {
+  extern __shared__ uint64_t smem[];
+  ScatterLds L;
+  L.sb = smem;
+  L.stK = L.sb + a.nS;
+  L.cnt = (uint32_t *)(L.stK + kTile);
+  L.lofs = L.cnt + a.nS;
+  L.base = L.lofs + a.nS + 1;
+  L.sd2 = L.base + a.nS;  // dir[b] | dir[b + 1] << 16
+  L.stR = L.sd2 + a.nS;
+  L.rowseg = L.stR + kTile;  // two buffers: this tile's and the next one's
+  L.tr = L.rowseg + 2 * (kRowSeg + 2);
+  L.stB = (uint16_t *)(L.tr + kMaxSub + 2);
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t tid = threadIdx.x;
+  unsigned long long *dbg_base =
+      a.dbg ? a.dbg + ((size_t)a.nW + blockIdx.x) * kDbgSlots : nullptr;
+  KB_T(0);
+  int dslot = 1;
+  const uint32_t w0 = blockIdx.x * a.span, w1 = min(w0 + a.span, a.NNZ);
+  const uint32_t ntl = (w1 - w0 + kTile - 1) / kTile;  // <= kMaxSub
+  const uint64_t *__restrict__ keys = a.keys;
+  const uint32_t *__restrict__ rowptr = a.rowptr;
+  Rec3 *__restrict__ rec = a.rec;
+  constexpr int E = (int)(kTile / kKb);
+  static_assert(E % 4 == 0, "a thread's keys are read in pairs and looked up four at a time");
+  static_assert(kTile <= 8192, "rank and super-chunk share a word: 13 bits of rank");
+  static_assert(kRowSeg + 2 <= 2 * kKb, "a thread stages two row offsets");
+  auto load_keys = [&](uint32_t e0, uint64_t *key) {  // keys[e0 + tid * E .. + E), 0 past w1
+    const uint32_t j0 = e0 + tid * E;
+    if (j0 + E <= w1 && ((uintptr_t)(keys + j0) & 15u) == 0) {
+#pragma unroll
+      for (int q = 0; q < E; q += 2) {
+        const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(keys + j0 + q);
+        key[q] = t.x;
+        key[q + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < E; ++q) key[q] = j0 + q < w1 ? keys[j0 + q] : 0;
+    }
+  };
+  uint64_t key[E], nkey[E];
+  load_keys(w0, key);
+  {
+    const uint64_t *__restrict__ gb = a.sc.bnd;
+    const uint16_t *__restrict__ gd = a.sc.dir;
+    const uint32_t *__restrict__ wc = a.wgcnt + (size_t)blockIdx.x * a.nS;
+    const uint32_t *__restrict__ cn = a.scount;
+    for (uint32_t S = tid; S < a.nS; S += kKb) {
+      L.sb[S] = gb[S];
+      L.sd2[S] = (uint32_t)gd[S] | ((uint32_t)gd[S + 1] << 16);
+    }
+    if (!ROWID)  // the first row of every tile of the workgroup, and of the tile after them
+      for (uint32_t k = tid; k <= ntl; k += kKb) {
+        const uint32_t t = w0 / kTile + k;
+        L.tr[k] = t < a.ntile ? a.tile_r0[t] : a.R - 1;
+      }
+    // sstart = exclusive scan of the super-chunks' record counts
+    const uint32_t per = (a.nS + kKb - 1) / kKb;
+    const uint32_t s0 = min(tid * per, a.nS), s1 = min(s0 + per, a.nS);
+    uint32_t sum = 0, nit = 0;
+    for (uint32_t S = s0; S < s1; ++S) {
+      const uint32_t n = cn[S];
+      sum += n;
+      nit += (n + kPart - 1) / kPart;
+    }
+    uint32_t total, itotal = 0;
+    uint32_t run = block_excl_scan(sum, wsum, &total);
+    uint32_t irun = blockIdx.x == 0 ? block_excl_scan(nit, wsum, &itotal) : 0u;
+    for (uint32_t S = s0; S < s1; ++S) {
+      const uint32_t n = cn[S];
+      L.base[S] = run + wc[S];
+      if (blockIdx.x == 0) {
+        a.sstart[S] = run;
+        const uint32_t parts = (n + kPart - 1) / kPart;
+        for (uint32_t q = 0; q < parts; ++q) a.items[irun + q] = S | (q << 16);
+        irun += parts;
+      }
+      run += n;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      a.sstart[a.nS] = total;
+      *a.nitems = itotal;
+    }
+  }
+  __syncthreads();
+  // rowptr[r0 .. r1 + 1] of the rows tile k touches go into row-offset buffer k & 1 (when they
+  // fit: nseg <= kRowSeg + 2; else the tile searches rowptr in memory)
+  auto seg_of = [&](uint32_t k, uint32_t *r0, uint32_t *nseg) {
+    *r0 = L.tr[k];
+    *nseg = L.tr[k + 1] - L.tr[k] + 2;
+  };
+  if (!ROWID) {
+    uint32_t r0, nseg;
+    seg_of(0, &r0, &nseg);
+    if (nseg <= kRowSeg + 2)
+      for (uint32_t i = tid; i < nseg; i += kKb) L.rowseg[i] = rowptr[r0 + i];
+  }
+  auto bnd = [&](uint32_t S) -> uint64_t { return L.sb[S]; };
+  KB_T(dslot++);
+  for (uint32_t k = 0; k < ntl; ++k) {
+    const uint32_t e0 = w0 + k * kTile, n = min(kTile, w1 - e0);
+    const bool more = k + 1 < ntl;
+    uint32_t r0 = 0, nseg = 0, nr0 = 0, nnseg = 0, nrs[2] = {0, 0};
+    if (!ROWID) seg_of(k, &r0, &nseg);
+    const bool seg_lds = !ROWID && nseg <= kRowSeg + 2;
+    const uint32_t *seg = L.rowseg + (k & 1) * (kRowSeg + 2);
+    // the next tile's keys and row offsets: issued now, taken over (registers / LDS) before this
+    // tile's records are stored — loads and stores retire through one in-order counter, a wait
+    // for a load issued after the stores would drain the stores
+    if (more) {
+      load_keys(e0 + kTile, nkey);
+      if (!ROWID) {
+        seg_of(k + 1, &nr0, &nnseg);
+        if (nnseg <= kRowSeg + 2) {
+          if (tid < nnseg) nrs[0] = rowptr[nr0 + tid];
+          if (tid + kKb < nnseg) nrs[1] = rowptr[nr0 + tid + kKb];
+        }
+      }
+    }
+    for (uint32_t S = tid; S < a.nS; S += kKb) L.cnt[S] = 0;
+    lds_barrier();
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    uint32_t rp[E], sr[E];  // sr = super-chunk << 13 | rank among the tile's nonzeros of it
+#pragma unroll
+    for (int h = 0; h < E; h += 4) {  // (four at a time: the registers)
+      uint64_t x0[4], x1[4];
+      uint32_t dp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dp[q] = L.sd2[kb_bucket(key[h + q], a.lo, a.sc.mult, a.nS)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        x0[q] = L.sb[min(dp[q] & 0xFFFFu, a.nS - 1)];
+        x1[q] = L.sb[min((dp[q] & 0xFFFFu) + 1, a.nS - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        sr[h + q] = kb_range(bnd, dp[q] & 0xFFFFu, dp[q] >> 16, x0[q], x1[q], key[h + q]);
+    }
+    const uint32_t i0 = tid * E;  // the thread's first nonzero of the tile
+    if (i0 < n) {
+      if (ROWID) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const uint32_t r = i0 + q < n ? a.rowid[e0 + i0 + q] : 0u;
+          const uint32_t v = r / a.W;
+          rp[q] = (v << kRinBits) | (r - v * a.W);
+        }
+      } else {
+        const uint32_t j0 = e0 + i0;
+        uint32_t lo = 0, hi = nseg - 1;  // the last r in the segment with rowptr[r] <= j0
+        uint32_t next;                   // rowptr[row + 1]
+        if (seg_lds) {
+          while (hi - lo > 1) {
+            const uint32_t m = lo + (hi - lo) / 2;
+            if (seg[m] <= j0) lo = m;
+            else
+              hi = m;
+          }
+          next = seg[lo + 1];
+        } else {
+          while (hi - lo > 1) {
+            const uint32_t m = lo + (hi - lo) / 2;
+            if (rowptr[r0 + m] <= j0) lo = m;
+            else
+              hi = m;
+          }
+          next = rowptr[r0 + lo + 1];
+        }
+        uint32_t row = r0 + lo;
+        uint32_t v = row / a.W, rin = row - v * a.W;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const uint32_t j = j0 + q;
+          while (j >= next && row + 1 < a.R) {  // (rows without nonzeros are stepped over)
+            ++row;
+            next = seg_lds ? seg[row + 1 - r0] : rowptr[row + 1];
+            if (++rin == a.W) {
+              rin = 0;
+              ++v;
+            }
+          }
+          rp[q] = (v << kRinBits) | rin;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        sr[q] = (sr[q] << 13) | (i0 + q < n ? atomicAdd(&L.cnt[sr[q]], 1u) : 0u);
+    }
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    lds_barrier();
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    {  // lofs = exclusive scan of cnt
+      const uint32_t per = (a.nS + kKb - 1) / kKb;
+      const uint32_t s0 = min(tid * per, a.nS), s1 = min(s0 + per, a.nS);
+      uint32_t sum = 0;
+      for (uint32_t S = s0; S < s1; ++S) sum += L.cnt[S];
+      uint32_t total;
+      uint32_t run = block_excl_scan<true>(sum, wsum, &total);
+      for (uint32_t S = s0; S < s1; ++S) {
+        L.lofs[S] = run;
+        run += L.cnt[S];
+      }
+    }
+    lds_barrier();
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      if (i0 + q >= n) continue;
+      const uint32_t S = sr[q] >> 13, p = L.lofs[S] + (sr[q] & 8191u);
+      L.stK[p] = key[q];
+      L.stR[p] = rp[q];
+      L.stB[p] = (uint16_t)S;
+    }
+    if (more) {  // take the prefetch over: the loads were issued a tile's work ago
+#pragma unroll
+      for (int q = 0; q < E; ++q) key[q] = nkey[q];
+      if (!ROWID && nnseg <= kRowSeg + 2) {
+        uint32_t *nseg_buf = L.rowseg + ((k + 1) & 1) * (kRowSeg + 2);
+        if (tid < nnseg) nseg_buf[tid] = nrs[0];
+        if (tid + kKb < nnseg) nseg_buf[tid + kKb] = nrs[1];
+      }
+    }
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    lds_barrier();
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    if (!(a.flags & 2))
+      for (uint32_t i = tid; i < n; i += kKb) {
+        const uint32_t S = L.stB[i];
+        const uint64_t kk = L.stK[i];
+        rec[L.base[S] + (i - L.lofs[S])] = Rec3{(uint32_t)kk, (uint32_t)(kk >> 32), L.stR[i]};
+      }
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    lds_barrier();
+    if (dslot < kDbgSlots - 8) KB_T(dslot++);
+    for (uint32_t S = tid; S < a.nS; S += kKb) L.base[S] += L.cnt[S];
+  }
+  KB_T(kDbgSlots - 1);
+}
+
+// -------------------------------------------------------------------------------- resolve
+// Work item = up to kPart records of one super-chunk, whose keys sit in LDS with the
+// directory over them (k_kb_sdir).  A record finds its key with the directory pair and the
+// bucket's first two keys (a plain binary search would put the 64 lanes' probes of its first
+// steps on ONE bank: 130 us of bank conflicts per minibatch); the position IS the state row.
+// It takes the next free slot of its cell (lanes of a wavefront that fill the same cell share
+// one atomic — on a cursor in LDS when the item has the super-chunk to itself) and becomes
+// entry = tag | row in window | position in chunk.  A key the tier does not hold leaves a hole
+// and joins the miss list.  The workgroups beyond the last item compute blk_cell.
+constexpr int kRes = 512;  // threads per resolve workgroup (two of them per CU)
+__global__ void __launch_bounds__(kRes, 4)
+k_kb_resolve(KbArgs a) {
+  __shared__ uint64_t lk[kSCKeys];
+  __shared__ uint16_t dir[kDirStride];
+  __shared__ uint32_t lcur[kLocalCells];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t nitems = *a.nitems;
+  if (blockIdx.x >= nitems) {  // blk_cell[b] = the largest cell with cellptr[cell] <= kBlk * b
+    const uint32_t ncell = a.nwin * a.cA, nblk = (a.NNZ + kBlk - 1) / kBlk;
+    const uint32_t spare = gridDim.x - nitems;
+    for (uint32_t b = (blockIdx.x - nitems) * kRes + tid; b <= nblk; b += spare * kRes) {
+      uint32_t lo = 0, hi = ncell;  // cellptr[0] = 0
+      if (b == nblk) lo = ncell - 1;
+      else
+        while (hi - lo > 1) {
+          const uint32_t m = lo + (hi - lo) / 2;
+          if (a.cellptr[m] <= b * kBlk) lo = m;
+          else
+            hi = m;
+        }
+      a.blk_cell[b] = lo;
+    }
+    return;
+  }
+  unsigned long long *dbg_base =
+      a.dbg ? a.dbg + ((size_t)2 * a.nW + blockIdx.x) * kDbgSlots : nullptr;
+  KB_T(0);
+  int dslot = 2;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t sb = a.sstart[S], se = a.sstart[S + 1];
+  const uint32_t rb = sb + part * kPart, re = min(se, rb + kPart);
+  const uint32_t k0 = S * kSCKeys, nk = min(kSCKeys, a.nbase - k0);
+  const uint32_t nb = max(nk / 2, 1u);
+  const bool local = se - sb <= kPart && a.nwin * kSC <= kLocalCells;  // workgroup-uniform
+  uint32_t *__restrict__ entries = a.entries;
+  constexpr int E = 4, kRounds = (int)(kBatch / (kRes * E));
+  // A batch of kBatch records goes into registers at once (16 per thread): the rounds below end
+  // in scattered stores, and on this GPU loads and stores retire through one in-order counter —
+  // a wait for a load issued after a round's stores would drain the stores
+  Rec3 rec[kRounds * E];
+  auto load_batch = [&](uint32_t b0) {
+    const Rec3 *__restrict__ src = a.rec + b0;
+#pragma unroll
+    for (int q = 0; q < kRounds * E; ++q) {
+      const uint32_t i = q * kRes + tid;
+      rec[q] = i < re - b0 ? src[i] : Rec3{0u, 0u, 0u};
+    }
+  };
+  load_batch(rb);
+  {
+    const ulonglong2 *__restrict__ src = (const ulonglong2 *)(a.bkeys + k0);  // 16-byte aligned
+    for (uint32_t i = tid; i < (nk + 1) / 2; i += kRes) {  // (bkeys is padded past nbase)
+      const ulonglong2 t = src[i];
+      lk[2 * i] = t.x;
+      lk[2 * i + 1] = t.y;
+    }
+    const uint32_t *__restrict__ gd = (const uint32_t *)(a.sdirs + (size_t)S * kDirStride);
+    uint32_t *ld = (uint32_t *)dir;
+    for (uint32_t i = tid; i < (nb + 2 + 1) / 2; i += kRes) ld[i] = gd[i];
+    if (local)
+      for (uint32_t i = tid; i < a.nwin * kSC; i += kRes) {
+        const uint32_t c = (S << kSCShift) + (i & (kSC - 1));
+        lcur[i] = c < a.cA ? a.cellptr[(size_t)(i >> kSCShift) * a.cA + c] : 0u;
+      }
+  }
+  const uint64_t sm = a.smult[S];
+  __syncthreads();
+  KB_T(1);
+  const uint64_t kfirst = lk[0];
+  auto lkf = [&](uint32_t i) -> uint64_t { return lk[i]; };
+  for (uint32_t b0 = rb; b0 < re; b0 += kBatch) {
+  if (b0 != rb) load_batch(b0);  // (an item of a heavy super-chunk: several batches)
+#pragma unroll
+  for (int g = 0; g < kRounds; ++g) {
+    const uint32_t i0 = b0 + g * kRes * E;
+    if (i0 >= re) break;  // workgroup-uniform
+    if (dslot < kDbgSlots - 4) KB_T(dslot++);
+    uint64_t key[E], x0[E], x1[E];
+    uint32_t rp[E], cell[E], ent[E], ds[E], de[E];
+    bool ok[E], miss[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      ok[q] = i0 + q * kRes + tid < re;
+      key[q] = (uint64_t)rec[g * E + q].klo | ((uint64_t)rec[g * E + q].khi << 32);
+      rp[q] = rec[g * E + q].rp;
+      const uint32_t b = kb_sbucket(key[q], kfirst, sm, nb);
+      ds[q] = dir[b];
+      de[q] = dir[b + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      x0[q] = lk[min(ds[q], nk - 1)];
+      x1[q] = lk[min(ds[q] + 1, nk - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      // ub = number of the super-chunk's keys <= key
+      uint32_t ub = key[q] < kfirst ? 0u : kb_count(lkf, ds[q], de[q], x0[q], x1[q], key[q]);
+      if (a.flags & 8) ub = 1;
+      const uint32_t p = ub ? ub - 1 : 0u;  // the largest position with lk <= key
+      const bool found = ok[q] && ub > 0 && lk[p] == key[q];
+      const uint32_t cl = p >> kChunkBits, c = (S << kSCShift) + cl;
+      const uint32_t v = rp[q] >> kRinBits, rin = rp[q] & ((1u << kRinBits) - 1u);
+      cell[q] = local ? (v << kSCShift) + cl : v * a.cA + c;
+      ent[q] = found ? ((c & 31u) << kTagShift) | (rin << kChunkBits) | (p & (kChunk - 1))
+                     : kHole;
+      miss[q] = ok[q] && !found && !(a.flags & 8);
+    }
+    if (dslot < kDbgSlots - 4) KB_T(dslot++);
+    if (a.flags & 4) {
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if (ok[q]) entries[i0 + q * kRes + tid] = ent[q];
+      continue;
+    }
+    // slots: the lanes of the wavefront that fill the same cell share one atomic.  A
+    // wavefront's records mostly come from one row window: one ballot per chunk of the
+    // super-chunk settles those, a loop over the remaining cells the rest
+    unsigned long long same[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      same[q] = 0;
+      unsigned long long todo = __ballot(ok[q]);
+      if (!todo) continue;  // wave-uniform
+      const int l0 = __ffsll((long long)todo) - 1;
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cell[q], l0) & ~(kSC - 1);
+      if (local) {  // cell = window * kSC + chunk: the first lane's window
+#pragma unroll
+        for (uint32_t cl = 0; cl < kSC; ++cl) {
+          const bool mine = ok[q] && cell[q] == w0 + cl;
+          const unsigned long long m = __ballot(mine);
+          if (mine) same[q] = m;
+          todo &= ~m;
+        }
+      }
+      while (todo) {  // wave-uniform
+        const int l = __ffsll((long long)todo) - 1;
+        const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell[q], l);
+        const unsigned long long m = __ballot(ok[q] && cell[q] == lc);
+        if (ok[q] && cell[q] == lc) same[q] = m;
+        todo &= ~m;
+      }
+    }
+    uint32_t base[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      base[q] = 0;
+      if (ok[q] && (int)lane == __ffsll((long long)same[q]) - 1) {
+        const uint32_t k = (uint32_t)__popcll(same[q]);
+        base[q] = local ? atomicAdd(&lcur[cell[q]], k) : atomicAdd(&a.cellcur[cell[q]], k);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int leader = same[q] ? __ffsll((long long)same[q]) - 1 : 0;
+      const uint32_t b0 = (uint32_t)__shfl((int)base[q], leader);
+      if (ok[q]) entries[b0 + __popcll(same[q] & ((1ull << lane) - 1ull))] = ent[q];
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const unsigned long long m = __ballot(miss[q]);
+      if (!m) continue;  // wave-uniform
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned long long at = 0;
+      if ((int)lane == leader) at = atomicAdd(&a.sum->miss, (unsigned long long)__popcll(m));
+      at = __shfl(at, leader) + __popcll(m & ((1ull << lane) - 1ull));
+      if (miss[q]) {
+        a.missK[at] = key[q];
+        a.missR[at] = (rp[q] >> kRinBits) * a.W + (rp[q] & ((1u << kRinBits) - 1u));
+      }
+    }
+  }
+  }
+  KB_T(kDbgSlots - 1);
+}
+
+}  // namespace
+
+namespace xf {
+
+static KbSummary *summary_buf() {
+  static thread_local KbSummary *p = nullptr;
+  if (!p && hipHostMalloc((void **)&p, sizeof(KbSummary)) != hipSuccess) p = nullptr;
+  return p;
+}
+
+// phase timestamps of the last keyed build (exp_knob 200 turns them on): [hist workgroups |
+// scatter workgroups | resolve workgroups] x kDbgSlots, wall_clock64 ticks (10 ns)
+static unsigned long long *g_dbg = nullptr;
+static size_t g_dbg_n = 0, g_dbg_used = 0;
+static uint32_t g_dbg_shape[3] = {0, 0, 0};
+
+static int general_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
+                         const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
+                         uint32_t NNZ, bool ksc, uint32_t w_fixed, hipStream_t s) {
+  Scratch sc;
+  uint32_t *idx = nullptr;
+  XF_TRY(sc.get(&idx, NNZ));
+  if (NNZ) XF_TRY(table_resolve_any(t, d_keys, NNZ, idx, s, true));
+  const uint64_t M = table_dev(t).max_rows + 1;
+  return cells_build(out, idx, nullptr, d_rowptr, R, NNZ, (uint32_t)M, kCellsTableRows, ksc, s,
+                     NNZ ? d_rowid : nullptr, w_fixed);
+}
+
+// the chunk / super-chunk boundaries of the table's settled tier, their directories and the
+// directories over every super-chunk's keys: one device allocation kept with the table,
+// rebuilt when the tier changes (xf_table_defrag)
+static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, KbArgs *a,
+                    hipStream_t s) {
+  uint64_t *ep = nullptr;
+  void **slot = table_aux(t, &ep);
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_cb = 0, o_sb = o_cb + al((size_t)cA * 8), o_sm = o_sb + al((size_t)nS * 8);
+  const size_t o_cd = o_sm + al((size_t)nS * 8), o_sd = o_cd + al(((size_t)cA + 1) * 2);
+  const size_t o_sdirs = o_sd + al(((size_t)nS + 1) * 2);
+  const size_t total = o_sdirs + al((size_t)nS * kDirStride * 2);
+  KbRanges *ch = &a->ch, *sc = &a->sc;
+  ch->n = cA;
+  sc->n = nS;
+  auto mult32 = [&](uint32_t n) -> uint32_t {
+    const uint64_t m = ((uint64_t)n << 32) / ((T.span >> 32) + 1);
+    return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFull);
+  };
+  ch->mult = mult32(cA);
+  sc->mult = mult32(nS);
+  const bool fresh = !*slot || *ep != table_epoch(t);
+  if (fresh) {
+    if (*slot) {
+      XF_HIP(hipDeviceSynchronize());
+      XF_HIP(hipFree(*slot));
+      *slot = nullptr;
+    }
+    XF_HIP(hipMalloc(slot, total));
+    *ep = table_epoch(t);
+  }
+  char *d = (char *)*slot;
+  ch->bnd = (const uint64_t *)(d + o_cb);
+  ch->dir = (const uint16_t *)(d + o_cd);
+  sc->bnd = (const uint64_t *)(d + o_sb);
+  sc->dir = (const uint16_t *)(d + o_sd);
+  a->smult = (const uint64_t *)(d + o_sm);
+  a->sdirs = (const uint16_t *)(d + o_sdirs);
+  if (fresh) {
+    hipLaunchKernelGGL(k_kb_index, dim3((cA + 256) / 256), dim3(256), 0, s, T.bkeys, T.lo, cA,
+                       kChunkBits, ch->mult, (uint64_t *)ch->bnd, (uint16_t *)ch->dir);
+    hipLaunchKernelGGL(k_kb_index, dim3((nS + 256) / 256), dim3(256), 0, s, T.bkeys, T.lo, nS,
+                       kChunkBits + kSCShift, sc->mult, (uint64_t *)sc->bnd, (uint16_t *)sc->dir);
+    hipLaunchKernelGGL(k_kb_sdir, dim3(nS), dim3(256), 0, s, T.bkeys, (uint32_t)T.nbase,
+                       (uint16_t *)a->sdirs, (uint64_t *)a->smult);
+    XF_HIP(hipGetLastError());
+  }
+  return XF_OK;
+}
+
+int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
+                      const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
+                      uint32_t NNZ, bool ksc, uint32_t w_fixed, hipStream_t s) {
+  XF_REQUIRE(out && t && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_keys),
+             "cells_build_keyed: null argument");
+  XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax),
+             "cells_build_keyed: row ids need a window size");
+  const TableDev T = table_dev(t);
+  const uint64_t cA64 = (T.nbase + kChunk - 1) / kChunk;
+  const uint64_t nS64 = (cA64 + kSC - 1) / kSC;
+  const uint32_t nwin = w_fixed ? std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed)
+                                : std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+  KbSummary *sum = summary_buf();
+  const bool fits = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
+                    sum != nullptr && cA64 < 0xFFFFu &&
+                    scatter_lds_bytes((uint32_t)nS64) <= kDynMax &&
+                    hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax &&
+                    cA64 * nwin < (1ull << 22) && exp_knob() != 77;
+  if (!fits) return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
+  const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
+  // segment A: the settled tier's rows [0, nbase)
+  xf_cells *c = nullptr;
+  XF_TRY(cells_alloc(&c, R, NNZ, (uint32_t)T.nbase, kCellsTableRows, ksc, w_fixed, 0));
+  struct Guard {
+    xf_cells *c;
+    ~Guard() {
+      if (c) cells_free(c);
+    }
+  } guard{c};
+  XF_REQUIRE(c->nchunk == cA && c->nwin == nwin, "cells_build_keyed: geometry");
+  unsigned long long misses = 0;
+  Scratch sc;  // (outlives the miss path below: the list lives in it)
+  KbArgs a{};
+  {
+    a.keys = d_keys;
+    a.rowptr = d_rowid ? nullptr : d_rowptr;
+    a.rowid = d_rowid;
+    a.R = R;
+    a.NNZ = NNZ;
+    a.W = c->W;
+    a.nwin = nwin;
+    a.cA = cA;
+    a.nS = nS;
+    a.ntile = (NNZ + kTile - 1) / kTile;
+    a.nbase = (uint32_t)T.nbase;
+    a.bkeys = T.bkeys;
+    a.lo = T.lo;
+    XF_TRY(kb_index(t, T, cA, nS, &a, s));
+    a.cellptr = c->cellptr;
+    a.entries = c->entries;
+    a.plan = c->plan;
+    a.blk_cell = c->blk_cell;
+    const size_t ncell = (size_t)nwin * cA;
+    const unsigned max_items = nS + NNZ / kPart + 1;  // >= sum over S of ceil(n_S / kPart)
+    // as many histogram / scatter workgroups as the GPU has CUs (one round), whole tiles each
+    const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
+    XF_REQUIRE(sub <= kMaxSub, "cells_build_keyed: %u nonzeros in one minibatch", NNZ);
+    a.span = sub * kTile;
+    a.nW = (a.ntile + sub - 1) / sub;
+    uint32_t *small = nullptr;
+    const size_t n_zero = 4 + ncell;  // the summary and the histogram: cleared together
+    const size_t n_small = n_zero + ncell + (size_t)nS * 2 + 1 + max_items + 1 +
+                           (size_t)a.nW * nS + a.ntile + 1;
+    XF_TRY(sc.get(&small, n_small));
+    a.sum = (KbSummary *)small;
+    a.hist = small + 4;
+    a.cellcur = a.hist + ncell;
+    a.scount = a.cellcur + ncell;
+    a.sstart = a.scount + nS;
+    a.items = a.sstart + nS + 1;
+    a.nitems = a.items + max_items;
+    a.wgcnt = a.nitems + 1;
+    a.tile_r0 = a.wgcnt + (size_t)a.nW * nS;
+    a.flags = exp_knob() >= 100 && exp_knob() < 200 ? (uint32_t)(exp_knob() - 100) : 0u;
+    if (exp_knob() == 200) {
+      const size_t need = ((size_t)2 * a.nW + max_items) * kDbgSlots;
+      if (need > g_dbg_n) {
+        if (g_dbg) (void)hipFree(g_dbg);
+        g_dbg = nullptr;
+        XF_HIP(hipMalloc((void **)&g_dbg, need * 8));
+        g_dbg_n = need;
+      }
+      XF_HIP(hipMemsetAsync(g_dbg, 0, need * 8, s));
+      a.dbg = g_dbg;
+      g_dbg_used = need;
+      g_dbg_shape[0] = a.nW;
+      g_dbg_shape[1] = a.nW;
+      g_dbg_shape[2] = max_items;
+    }
+    XF_TRY(sc.get(&a.rec, NNZ));
+    XF_TRY(sc.get(&a.missK, NNZ));
+    XF_TRY(sc.get(&a.missR, NNZ));
+    XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
+    const bool ldsb = hist_lds_bytes(cA, nS, true) <= kDynMax;
+    const size_t hl = hist_lds_bytes(cA, nS, ldsb);
+#define XF_KB_LAUNCH(kern, grid, lds)                                                          \
+  do {                                                                                         \
+    static bool attr_done = false;                                                             \
+    if (!attr_done) {                                                                          \
+      XF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)kDynMax));                                               \
+      attr_done = true;                                                                        \
+    }                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kKb), lds, s, a);                                \
+  } while (0)
+    if (d_rowid) {
+      if (ldsb) XF_KB_LAUNCH((k_kb_hist<true, true>), a.nW, hl);
+      else
+        XF_KB_LAUNCH((k_kb_hist<true, false>), a.nW, hl);
+    } else {
+      if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl);
+      else
+        XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
+    }
+    hipLaunchKernelGGL(k_kb_scan, dim3(2 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
+    if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true>), a.nW, scatter_lds_bytes(nS));
+    else
+      XF_KB_LAUNCH((k_kb_scatter<false>), a.nW, scatter_lds_bytes(nS));
+    hipLaunchKernelGGL(k_kb_resolve, dim3(max_items), dim3(kRes), 0, s, a);
+#undef XF_KB_LAUNCH
+    XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
+    XF_HIP(hipGetLastError());
+    XF_HIP(hipStreamSynchronize(s));  // the one synchronisation of the steady state
+    misses = sum->miss;
+    XF_TRY(cells_fill_items(c, sum->nitems, sum->nsplit, s));
+  }
+  XF_TRY(cells_key_sorted_copy(c, s));
+  if (misses) {
+    // segment B: the keys the tier did not hold, through the general path (insert on first
+    // touch), over the rows from the tier's last chunk on
+    XF_REQUIRE(misses <= NNZ, "cells_build_keyed: miss list");
+    Scratch sc2;
+    uint32_t *idx = nullptr;
+    XF_TRY(sc2.get(&idx, (size_t)misses));
+    XF_TRY(table_resolve_any(t, a.missK, (size_t)misses, idx, s, true));
+    const uint64_t M = table_dev(t).max_rows + 1;
+    XF_TRY(cells_build(&c->next, idx, nullptr, nullptr, R, (uint32_t)misses, (uint32_t)M,
+                       kCellsTableRows, ksc, s, a.missR, c->W, (uint32_t)(T.nbase >> kChunkBits)));
+    XF_REQUIRE(c->next->nwin == c->nwin && c->next->G == c->G, "cells_build_keyed: segments");
+  }
+  // (every kernel that reads the scratch has finished: the synchronisation above, or the
+  // general build's own)
+  guard.c = nullptr;
+  *out = c;
+  return XF_OK;
+}
+
+}  // namespace xf
+
+// diagnostics (tools/kb_timeline.py): the phase timestamps of the last keyed build made with
+// exp_knob = 200; shape[3] = workgroups of the three kernels, slots per workgroup returned
+extern "C" int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape) {
+  XF_REQUIRE(out && shape, "xf_kb_debug_read: null argument");
+  XF_HIP(hipDeviceSynchronize());
+  const size_t n = std::min(cap, xf::g_dbg_used);
+  if (n) XF_HIP(hipMemcpy(out, xf::g_dbg, n * 8, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3; ++i) shape[i] = xf::g_dbg_shape[i];
+  return kDbgSlots;
+}

@@ -593,18 +593,14 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
     xf::cells_free(b->ocells);
     b->ocells = nullptr;
   }
-  xf::Scratch sc;
-  uint32_t *idx = nullptr;
-  XF_TRY(sc.get(&idx, b->o_n));
-  if (b->o_n) XF_TRY(xf::table_resolve_any(st->tw, b->o_keys.p, b->o_n, idx, s, true));
-  XF_TRY(xf::cells_build(&b->ocells, idx, nullptr, nullptr, b->o_rpad, (uint32_t)b->o_n,
-                         (uint32_t)xf::table_row_bound(st->tw), xf::kCellsTableRows, b->oc_keep,
-                         s, b->o_n ? b->o_rowid.p : nullptr, b->oW));
+  XF_TRY(xf::cells_build_keyed(&b->ocells, st->tw, b->o_keys.p, nullptr,
+                               b->o_n ? b->o_rowid.p : nullptr, b->o_rpad, (uint32_t)b->o_n,
+                               b->oc_keep, b->oW, s));
   b->ocells->table_uid = uid;
   b->ocells->epoch = ep;
   b->oc_uid = uid;
   b->oc_epoch = ep;
-  const size_t sp = (size_t)st->world * b->ocells->nsplit_chunks * xf::kChunk;
+  const size_t sp = (size_t)st->world * xf::cells_split_chunks(b->ocells) * xf::kChunk;
   XF_TRY(b->gsum.reserve(sp));
   XF_TRY(b->gtouched.reserve(sp));
   return XF_OK;

@@ -774,6 +774,10 @@ struct xf_table {
   uint32_t *miss = nullptr;
   unsigned long long *miss_n = nullptr;
   size_t miss_cap = 0;
+  // one device allocation derived from the settled tier by another module (xf_keybuild.hip:
+  // chunk boundaries and their directories), valid for `aux_epoch`; freed with the table
+  void *aux = nullptr;
+  uint64_t aux_epoch = ~0ull;
 };
 
 static void refresh_hyper(xf_table *t) {
@@ -914,7 +918,7 @@ extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
   void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
                 (void *)t->T.bdir, (void *)t->T.cdir, t->s_keys, t->s_rows, t->s_vals, t->miss,
-                t->miss_n};
+                t->miss_n, t->aux};
   for (void *p : ps)
     if (p) hipFree(p);
   delete t;
@@ -1419,6 +1423,10 @@ int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hip
 
 // used by xf_model.hip / xf_cells.hip
 const TableDev &table_dev(const xf_table *t) { return t->T; }
+void **table_aux(xf_table *t, uint64_t **epoch) {
+  *epoch = &t->aux_epoch;
+  return &t->aux;
+}
 // device-to-device copy by a kernel on the caller's stream.  (hipMemcpyAsync picks its engine
 // itself: a 25 MB copy in the middle of a step was seen at 2.3 TB/s — blit kernel — in one run
 // and at 0.27 TB/s with ~80 us of cross-queue waits around it — SDMA — in the next.)
