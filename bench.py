@@ -72,6 +72,9 @@ def parse_args():
                          "the fused step, to time its stages on one GPU")
     ap.add_argument("--no-owner-leg", action="store_true",
                     help="N>1: skip the supplementary run of the owner-compute dataflow")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="blocks of K steps timed again after the official one (median / min / "
+                         "max of ms_per_step are reported next to it)")
     ap.add_argument("--exp-knob", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
@@ -155,12 +158,19 @@ def impl_bytes_cells(R, NNZ, U, opt, info, table_rows):
     return {"forward": NNZ * 8 + 2 * partial + R * 8, "gradient": NNZ * 8 + U * state}
 
 
+PMC_PROFILE = os.path.join("profiles", "pmc_traffic_latest.json")
+PMC_SOURCE = "committed profile %s (rocprofv3 --pmc passes of an earlier run of this workload: " \
+             "FETCH_SIZE / WRITE_SIZE need their own profiled runs), NOT measured by this run" \
+             % PMC_PROFILE
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE need separate profiled runs, so bench.py
-    cannot measure them itself).  Only used when the profile was taken on this workload."""
+    cannot measure them itself).  Only used when the profile was taken on this workload; the
+    JSON line says where the number comes from (`traffic_source`)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        d = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
     except (OSError, ValueError):
         return None
     if d.get("workload") != workload:
@@ -172,9 +182,10 @@ def pmc_traffic(kernel, workload):
 
 
 def with_key_build(args, trainer, batches):
-    """Supplementary figure (not `value`): the whole LRWorker::update including its key build
-    (lr_worker.cc:146-166) per step — raw CSR keys resident in HBM, xf_batch_compile_local_dev
-    (keys -> state rows, cells by a stable radix pass) and then the step, nothing cached."""
+    """The whole LRWorker::update including its key build (lr_worker.cc:146-166) per step — raw
+    CSR keys resident in HBM, xf_batch_compile_local_dev (the range-partitioned key build of
+    xf_keybuild.hip: keys -> state rows where the table's keys of that range sit in LDS, cells
+    as they go) and then the step, nothing cached.  Reported next to `value` at top level."""
     import ctypes as C
     import torch
     from xflow_amd import capi
@@ -193,19 +204,53 @@ def with_key_build(args, trainer, batches):
         capi.check(L.xf_lr_step(trainer.w.h, h, trainer.ws.h, None))
         capi.stream_sync()
         L.xf_batch_free(h)
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    per = []
+    for rep in range(max(1, args.repeats // 2)):
+        t0 = time.perf_counter()
+        for i in range(args.key_build_steps):
+            one(i)
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / args.key_build_steps)
+    dt = per[0]
+    return {"value": args.rows / dt, "unit": "examples/sec",
+            "ms_per_step": dt * 1e3, "steps": args.key_build_steps,
+            "ms_per_step_repeats": spread([x * 1e3 for x in per]),
+            "what": "key build on the GPU (xf_keybuild.hip: histogram / scan / scatter by key "
+                    "range / resolve in LDS against the table's settled tier) + the step, per "
+                    "minibatch, raw keys resident in HBM, nothing cached"}
+
+
+def with_key_build_sharded(args, trainer, batches, R, world, barrier, allmax):
+    """N > 1: xf_sharded_compile (COLLECTIVE: the owner-compute compile sends the nonzeros to
+    the key owners, who build their cells) + the step, per minibatch, nothing cached.  The
+    compile takes the reader's HOST arrays (here: pageable numpy memory), so the upload of the
+    raw keys is inside this figure."""
+    n = max(2, args.key_build_steps // 2)
+
+    def one(i):
+        b = trainer.compile(*batches[i % len(batches)])
+        trainer.step(b)
+        trainer.check()
+        del b
     for i in range(2):
         one(i)
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
-    for i in range(args.key_build_steps):
+    for i in range(n):
         one(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"value": args.rows * args.key_build_steps / dt, "unit": "examples/sec",
-            "ms_per_step": dt / args.key_build_steps * 1e3, "steps": args.key_build_steps,
-            "what": "key build on the GPU (raw keys -> state rows through the table's settled "
-                    "tier, then a stable radix pass into cells) + the step, per minibatch, raw "
-                    "keys resident in HBM, nothing cached"}
+    barrier()
+    dt = allmax(time.perf_counter() - t0) / n
+    return {"value": R * world / dt, "unit": "examples/sec", "ms_per_step": dt * 1e3, "steps": n,
+            "what": "xf_sharded_compile from host arrays (upload of the raw keys included) + "
+                    "the step on the dataflow of `value`, per minibatch, nothing cached"}
+
+
+def spread(ms):
+    ms = sorted(ms)
+    return {"median": ms[len(ms) // 2], "min": ms[0], "max": ms[-1], "n": len(ms)}
 
 
 def stream_copy_gbs():
@@ -285,8 +330,12 @@ def cpu_baseline(args, batches):
         t_step += t2 - t1
         rows += ob.R
     host = host_description()
+    try:   # the GPU path on the same minibatches from an empty table: same table at the end?
+        parity = gpu_vs_oracle(args, batches[:nb], store, vstore)
+    except Exception as e:   # the throughput line must not depend on this extra
+        parity = {"error": str(e)}
     out = {"value": rows / t_step, "unit": "examples/sec", "cores": 1, "kind": "port",
-           "host": host,
+           "host": host, "gpu_vs_oracle": parity,
            "sample": "%d minibatch(es) of %d rows x %d nnz, oracle update() after the key "
                      "build, -O2, 1 thread; with the reference's per-slice std::sort key "
                      "build included: %.0f examples/sec" % (nb, args.rows, args.nnz_per_row,
@@ -305,6 +354,59 @@ def cpu_baseline(args, batches):
                       "(lr_worker.cc:186-200): %d slices, each slice's update() incl. its key "
                       "build on its own thread, Pull/Push serialised (ps-lite's single server "
                       "thread)" % (nb, cores)}
+    return out
+
+
+def gpu_vs_oracle(args, batches, store, vstore):
+    """The minibatches the oracle has just been timed on, through the GPU path from an empty
+    table (one table maintenance step in between, as between epochs), and the two final tables
+    side by side: same keys, largest absolute / relative difference of the state.  The oracle
+    ran in the reference's own arithmetic (fp32 running sums in its order); the tolerance
+    north_star names is 1e-6 relative."""
+    from xflow_amd import capi
+    fm = args.model == "fm"
+    opt = capi.OPT_FTRL if (args.optimizer or ("sgd" if fm else "ftrl")) == "ftrl" else capi.OPT_SGD
+    cap = int(args.keys_per_gpu / args.load_factor) + 1024
+    tw = capi.Table(opt, 1, capacity=cap)
+    tv = None
+    if fm:
+        tv = capi.Table(opt, args.k, capi.INIT_HASHNORM if opt == capi.OPT_FTRL else
+                        capi.INIT_CONST, 0.001, seed=7, capacity=cap)
+    ws = capi.Workspace()
+    for i, (rowptr, keys, labels) in enumerate(batches):
+        if fm:
+            b = capi.Batch(rowptr, keys, labels, on_gpu=True)
+            capi.fm_step(tw, tv, b, ws)
+        else:
+            b = capi.LocalBatch(tw, rowptr, keys, labels, retain_keys=False)
+            capi.lr_step(tw, b, ws)
+        tw.check()
+        del b
+        if i == 0 and len(batches) > 1:
+            tw.defrag()
+            if tv is not None:
+                tv.defrag()
+    out = {"minibatches": len(batches), "what": "final tables, GPU path vs the timed oracle "
+           "(reference arithmetic), after the same minibatches from empty tables"}
+    for name, t, st in (("w", tw, store), ("v", tv, vstore)):
+        if t is None:
+            continue
+        g, o = t.export(), st.export()
+        same_keys = bool(np.array_equal(g[0], o[0]))
+        d = {"keys": int(len(g[0])), "same_keys": same_keys}
+        if same_keys:
+            # per state array: largest |gpu - oracle|, and the same over (|oracle| + rms(oracle))
+            # — the measure the parity tests bound by 1e-6 (a weight next to the L1 threshold
+            # is z - lambda1 after cancellation: its own relative error says nothing)
+            for fld, a, r in zip(("w", "n", "z"), g[1:], o[1:]):
+                a, r = np.asarray(a, np.float64).ravel(), np.asarray(r, np.float64).ravel()
+                if len(a) == 0 or not np.any(r):
+                    continue
+                diff = np.abs(a - r)
+                rms = float(np.sqrt(np.mean(r * r)))
+                d[fld] = {"max_abs_diff": float(diff.max()), "rms": rms,
+                          "max_diff_over_abs_plus_rms": float((diff / (np.abs(r) + rms)).max())}
+        out[name] = d
     return out
 
 
@@ -604,9 +706,23 @@ def main():
     kern_ms, ksteps = trainer.profile_read()
     trainer.profile(False)
     trainer.check()
+    # the same K-step block again, `--repeats` times: how far `ms_per_step` of ONE block is
+    # from the typical one (profiling off here: no event packets in the stream)
+    rep_ms = []
+    for rep in range(args.repeats):
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step(compiled[(args.warmup + i) % len(compiled)])
+        if hasattr(trainer, "flush"):
+            trainer.flush()
+        barrier()
+        rep_ms.append(allmax(time.perf_counter() - t1) / args.steps * 1e3)
+    trainer.check()
     kernel_timing = "HIP events on the step's stream inside the timed region (every 4th step " \
                     "records, into a ring of event sets: the host never waits for a step it " \
-                    "has just launched)"
+                    "has just launched; the averages are over those sampled steps, so their " \
+                    "sum need not equal ms_per_step to the microsecond)"
     if sharded and not any(kern_ms.values()):
         # the overlapped schedule runs two streams: per-kernel events are taken in a short
         # sequential pass after the timed region instead
@@ -710,6 +826,13 @@ def main():
             del oc, ot
         except Exception as e:
             owner_leg = {"error": str(e)}
+    wkb_sharded = None
+    if group is not None and world > 1 and args.model == "lr" and args.key_build_steps > 0:
+        try:   # (collective: every rank; a failure is symmetric)
+            wkb_sharded = with_key_build_sharded(args, trainer, batches, R, world, barrier,
+                                                 allmax)
+        except Exception as e:
+            wkb_sharded = {"error": str(e)}
     imbalance = None
     if group is not None:
         own = group.allgather(np.array([np.mean([o for o in owned])], np.float64)).ravel()
@@ -754,7 +877,12 @@ def main():
     out = {
         "metric": "examples/sec", "value": R * world * args.steps / dt, "unit": "examples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_per_step,
+        "ms_per_step_repeats": (dict(spread(rep_ms), what="the same K-step block timed %d more "
+                                     "times after the official one, profiling events off"
+                                     % len(rep_ms)) if rep_ms else None),
+        "value_with_key_build": None, "ms_per_step_with_key_build": None,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
@@ -772,6 +900,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
+                     "traffic_source": PMC_SOURCE,
                      "algorithmic_bytes_per_launch": per[dom],
                      "algorithmic_bytes_source": "SURVEY.md 8(d)"
                      if fused or (args.model == "fm" and one_shard and dom == "gradient") else
@@ -804,6 +933,11 @@ def main():
         out["roofline"]["frac_of_measured_copy"] = achieved / copy if copy > 0 else None
     if world == 1 and not args.force_sharded and args.model == "lr" and args.key_build_steps > 0:
         out["with_key_build"] = with_key_build(args, trainer, batches)
+    if wkb_sharded is not None:
+        out["with_key_build"] = wkb_sharded
+    if out.get("with_key_build") and "value" in out["with_key_build"]:
+        out["value_with_key_build"] = out["with_key_build"]["value"]
+        out["ms_per_step_with_key_build"] = out["with_key_build"]["ms_per_step"]
     if args.pmc_calibrate:
         for kind in range(6):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
@@ -816,6 +950,8 @@ def main():
             out["logloss"]["learning_check"] = {"error": str(e)}
     try:   # end to end from text / from the binarized block cache: tools/e2e_text.py's last run
         out["end_to_end"] = json.load(open(os.path.join(ROOT, "profiles", "e2e_latest.json")))
+        out["end_to_end"]["source"] = "committed profile profiles/e2e_latest.json (an earlier " \
+                                      "run of tools/e2e_text.py), NOT measured by this run"
     except (OSError, ValueError):
         out["end_to_end"] = None
     if dist is not None:
