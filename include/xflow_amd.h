@@ -352,6 +352,19 @@ int xf_group_gatherv_host(xf_group *g, const void *in, size_t bytes, void *out_r
 int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t *send_counts, void *recv,
                        const uint64_t *recv_counts, size_t elem_bytes, int host_buffers,
                        void *stream);
+/* The same on one of the group's XF_GROUP_CHANNELS communicators (xf_group_alltoallv = channel
+ * 0).  RCCL serialises the work of one communicator and needs every rank to enqueue on it in
+ * the same order: exchanges that a rank issues from two streams independently of each other
+ * (the sharded trainer's stale1 schedule) take a channel per stream.  Every rank must use the
+ * same channel for the same exchange. */
+#define XF_GROUP_CHANNELS 2
+int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
+                          const uint64_t *send_counts, void *recv, const uint64_t *recv_counts,
+                          size_t elem_bytes, int host_buffers, void *stream);
+
+/* COLLECTIVE diagnostic: both channels driven at the same time from two streams of every rank
+ * (grouped send / recv of `bytes` bytes with every rank, this one included), results checked. */
+int xf_group_selftest(xf_group *g, size_t bytes);
 
 /* ---------------------------------------------------------------- sharded trainer     */
 /* LRWorker / FMWorker::update across the ranks of a group: the table sharded by key range

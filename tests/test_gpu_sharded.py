@@ -210,6 +210,15 @@ def test_rccl_group_of_one_and_the_fused_step():
                     torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(src, dst)
+    # the group's two communicators (the side stream of the stale1 schedule has its own), both
+    # driven at the same time from two streams: ncclSend / ncclRecv to this very rank
+    g.selftest(1 << 20)
+    side = torch.cuda.Stream()
+    dst2 = torch.zeros_like(src)
+    g.alltoallv_dev(src.data_ptr(), [1000], dst2.data_ptr(), [1000], 4, side.cuda_stream,
+                    channel=1)
+    side.synchronize()
+    assert torch.equal(src, dst2)
     st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 12)
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 12)
     ws = capi.Workspace()

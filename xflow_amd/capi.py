@@ -141,6 +141,9 @@ SIGNATURES = {
     "xf_group_allgather_host": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "xf_group_gatherv_host": (C.c_int, [vp, vp, C.c_size_t, vp, u64p]),
     "xf_group_alltoallv": (C.c_int, [vp, vp, u64p, vp, u64p, C.c_size_t, C.c_int, vp]),
+    "xf_group_alltoallv_ch": (C.c_int, [vp, C.c_int, vp, u64p, vp, u64p, C.c_size_t, C.c_int,
+                                        vp]),
+    "xf_group_selftest": (C.c_int, [vp, C.c_size_t]),
     "xf_sharded_config_default": (None, [C.POINTER(ShardedConfig)]),
     "xf_sharded_create": (C.c_int, [C.POINTER(vp), vp, C.POINTER(ShardedConfig)]),
     "xf_sharded_destroy": (C.c_int, [vp]),
@@ -622,11 +625,16 @@ class Group:
                                        _p(rc, u64p), a.itemsize, 1, None))
         return out, rc
 
-    def alltoallv_dev(self, d_send, send_counts, d_recv, recv_counts, elem_bytes, stream=None):
+    def alltoallv_dev(self, d_send, send_counts, d_recv, recv_counts, elem_bytes, stream=None,
+                      channel=0):
         sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
         rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
-        check(lib().xf_group_alltoallv(self.h, d_send, _p(sc, u64p), d_recv, _p(rc, u64p),
-                                       elem_bytes, 0, stream))
+        check(lib().xf_group_alltoallv_ch(self.h, channel, d_send, _p(sc, u64p), d_recv,
+                                          _p(rc, u64p), elem_bytes, 0, stream))
+
+    def selftest(self, nbytes=1 << 20):
+        """COLLECTIVE: both RCCL communicators driven at once from two streams"""
+        check(lib().xf_group_selftest(self.h, nbytes))
 
 
 SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1, SCHEDULE_OWNER = 0, 1, 2

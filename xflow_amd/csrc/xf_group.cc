@@ -131,7 +131,11 @@ struct xf_group {
   int listen_fd = -1;
   std::vector<int> peer;  // rank 0: socket of every other rank; others: peer[0] = rank 0
   Rccl rccl;
-  ncclComm_h comm = nullptr;
+  // two communicators ("channels"): RCCL serialises the work of ONE communicator and must see
+  // every rank enqueue on it in the same order, so work that two streams of a rank issue
+  // independently (the sharded trainer's stale1 schedule: Push(t) on a side stream under
+  // Pull(t+1)) gets a communicator per stream
+  ncclComm_h comm[XF_GROUP_CHANNELS] = {nullptr, nullptr};
   std::vector<char> hs, hr;  // host staging of the host transport
 };
 
@@ -185,8 +189,14 @@ static int agree(xf_group *g, int my_rc, const std::string &my_msg, std::string 
   return XF_OK;
 }
 
-static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t> &so, char *rb,
-                          const std::vector<size_t> &ro, hipStream_t s);
+static int alltoallv_rccl(xf_group *g, int ch, const char *sb, const std::vector<size_t> &so,
+                          char *rb, const std::vector<size_t> &ro, hipStream_t s);
+static void destroy_comms(xf_group *g) {
+  for (ncclComm_h &c : g->comm) {
+    if (c && g->rccl.CommDestroy) g->rccl.CommDestroy(c);
+    c = nullptr;
+  }
+}
 
 static int rccl_bring_up(xf_group *g, std::string *why) {
   // 1. the library
@@ -195,32 +205,32 @@ static int rccl_bring_up(xf_group *g, std::string *why) {
   if (rc == XF_OK && (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0))
     rc = xf::set_error(XF_ENOGPU, "no HIP device");
   XF_TRY(agree(g, rc, rc ? xf_last_error() : "", why));
-  // 2. the communicator
-  std::vector<ncclUniqueId_t> ids(g->world);
-  ncclUniqueId_t mine{};
+  // 2. the communicators, one per channel
   rc = XF_OK;
   std::string msg;
-  if (g->rank == 0) {
-    const int n = g->rccl.GetUniqueId(&mine);
-    if (n) {
-      rc = XF_EHIP;
-      msg = std::string("ncclGetUniqueId: ") + g->rccl.GetErrorString(n);
+  for (int ch = 0; ch < XF_GROUP_CHANNELS; ++ch) {
+    std::vector<ncclUniqueId_t> ids(g->world);
+    ncclUniqueId_t mine{};
+    if (g->rank == 0 && rc == XF_OK) {
+      const int n = g->rccl.GetUniqueId(&mine);
+      if (n) {
+        rc = XF_EHIP;
+        msg = std::string("ncclGetUniqueId: ") + g->rccl.GetErrorString(n);
+      }
     }
-  }
-  XF_TRY(agree(g, rc, msg, why));
-  if (allgather_host(g, &mine, sizeof(mine), ids.data()) != XF_OK) {
-    *why = "the bootstrap connection failed";
-    return XF_EIO;
-  }
-  {
-    const int n = g->rccl.CommInitRank(&g->comm, g->world, ids[0], g->rank);
+    XF_TRY(agree(g, rc, msg, why));
+    if (allgather_host(g, &mine, sizeof(mine), ids.data()) != XF_OK) {
+      *why = "the bootstrap connection failed";
+      return XF_EIO;
+    }
+    const int n = g->rccl.CommInitRank(&g->comm[ch], g->world, ids[0], g->rank);
     if (n) {
       rc = XF_EHIP;
       msg = std::string("ncclCommInitRank: ") + g->rccl.GetErrorString(n);
-      g->comm = nullptr;
+      g->comm[ch] = nullptr;
     }
+    XF_TRY(agree(g, rc, msg, why));
   }
-  XF_TRY(agree(g, rc, msg, why));
   // 3. one exchange on the device: every rank sends its number to every peer
   const int W = g->world;
   std::vector<int32_t> h(W * 4, g->rank), back(W * 4, -1);
@@ -237,19 +247,22 @@ static int rccl_bring_up(xf_group *g, std::string *why) {
   if (hip_ok(hipMalloc(&ds, off[W]), "hipMalloc") && hip_ok(hipMalloc(&dr, off[W]), "hipMalloc") &&
       hip_ok(hipMemcpy(ds, h.data(), off[W], hipMemcpyHostToDevice), "hipMemcpy") &&
       hip_ok(hipMemset(dr, 0xff, off[W]), "hipMemset")) {
-    if (alltoallv_rccl(g, (const char *)ds, off, (char *)dr, off, nullptr) != XF_OK) {
-      rc = XF_EHIP;
-      msg = xf_last_error();
-    } else if (hip_ok(hipStreamSynchronize(nullptr), "the first all-to-all-v") &&
-               hip_ok(hipMemcpy(back.data(), dr, off[W], hipMemcpyDeviceToHost), "hipMemcpy")) {
-      for (int p = 0; p < W && rc == XF_OK; ++p)
-        for (int q = 0; q < 4; ++q)
-          if (back[p * 4 + q] != p) {
-            rc = XF_EHIP;
-            msg = "the first all-to-all-v delivered " + std::to_string(back[p * 4 + q]) +
-                  " from rank " + std::to_string(p);
-            break;
-          }
+    for (int ch = 0; ch < XF_GROUP_CHANNELS && rc == XF_OK; ++ch) {
+      if (!hip_ok(hipMemset(dr, 0xff, off[W]), "hipMemset")) break;
+      if (alltoallv_rccl(g, ch, (const char *)ds, off, (char *)dr, off, nullptr) != XF_OK) {
+        rc = XF_EHIP;
+        msg = xf_last_error();
+      } else if (hip_ok(hipStreamSynchronize(nullptr), "the first all-to-all-v") &&
+                 hip_ok(hipMemcpy(back.data(), dr, off[W], hipMemcpyDeviceToHost), "hipMemcpy")) {
+        for (int p = 0; p < W && rc == XF_OK; ++p)
+          for (int q = 0; q < 4; ++q)
+            if (back[p * 4 + q] != p) {
+              rc = XF_EHIP;
+              msg = "the first all-to-all-v (channel " + std::to_string(ch) + ") delivered " +
+                    std::to_string(back[p * 4 + q]) + " from rank " + std::to_string(p);
+              break;
+            }
+      }
     }
   }
   if (ds) (void)hipFree(ds);
@@ -406,8 +419,7 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
     if (stage_rc == XF_OK) {
       g->transport = XF_TRANSPORT_RCCL;
     } else if (transport == XF_TRANSPORT_AUTO && stage_rc != XF_EIO) {
-      if (g->comm && g->rccl.CommDestroy) g->rccl.CommDestroy(g->comm);
-      g->comm = nullptr;
+      destroy_comms(g);
       g->transport = XF_TRANSPORT_HOST;
       if (g->rank == 0)
         fprintf(stderr, "xf_group: RCCL is not usable (%s): the exchange is staged through the "
@@ -423,7 +435,7 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
 
 extern "C" int xf_group_destroy(xf_group *g) {
   if (!g) return XF_OK;
-  if (g->comm && g->rccl.CommDestroy) g->rccl.CommDestroy(g->comm);
+  destroy_comms(g);
   for (int fd : g->peer)
     if (fd >= 0) close(fd);
   if (g->listen_fd >= 0) close(g->listen_fd);
@@ -469,8 +481,8 @@ extern "C" int xf_group_gatherv_host(xf_group *g, const void *in, size_t bytes, 
 }
 
 // one grouped ncclSend/ncclRecv per peer with bytes to move; byte offsets so/ro per rank
-static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t> &so, char *rb,
-                          const std::vector<size_t> &ro, hipStream_t s) {
+static int alltoallv_rccl(xf_group *g, int ch, const char *sb, const std::vector<size_t> &so,
+                          char *rb, const std::vector<size_t> &ro, hipStream_t s) {
   const int W = g->world;
   const size_t self = so[g->rank + 1] - so[g->rank];
   if (self)  // the slice that stays: a copy kernel on the stream, no collective
@@ -480,14 +492,69 @@ static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t>
   for (int p = 0; p < W && !rc; ++p) {
     if (p == g->rank) continue;
     if (so[p + 1] > so[p])
-      rc = g->rccl.Send(sb + so[p], so[p + 1] - so[p], kNcclChar, p, g->comm, s);
+      rc = g->rccl.Send(sb + so[p], so[p + 1] - so[p], kNcclChar, p, g->comm[ch], s);
     if (!rc && ro[p + 1] > ro[p])
-      rc = g->rccl.Recv(rb + ro[p], ro[p + 1] - ro[p], kNcclChar, p, g->comm, s);
+      rc = g->rccl.Recv(rb + ro[p], ro[p + 1] - ro[p], kNcclChar, p, g->comm[ch], s);
   }
   const int rc2 = g->rccl.GroupEnd();
   if (rc || rc2)
     return xf::set_error(XF_EHIP, "xf_group_alltoallv: %s", g->rccl.GetErrorString(rc ? rc : rc2));
   return XF_OK;
+}
+
+// Both channels at once: on two streams of this rank, one per communicator, a grouped
+// ncclSend / ncclRecv of `bytes` bytes with EVERY rank — this one included, so that a group of
+// one drives RCCL too — then both streams are waited for and what arrived is checked.
+// Collective.  RCCL transport only (the host transport has nothing to overlap).
+extern "C" int xf_group_selftest(xf_group *g, size_t bytes) {
+  XF_REQUIRE(g && bytes >= 4 && bytes % 4 == 0, "xf_group_selftest: bad argument");
+  if (g->transport != XF_TRANSPORT_RCCL) return XF_OK;
+  const int W = g->world;
+  const size_t n = bytes / 4;
+  hipStream_t st[XF_GROUP_CHANNELS] = {};
+  uint32_t *ds[XF_GROUP_CHANNELS] = {}, *dr[XF_GROUP_CHANNELS] = {};
+  std::vector<uint32_t> h(n * W), back(n * W);
+  int rc = XF_OK;
+  auto fail = [&](const char *what, const char *why) {
+    if (rc == XF_OK) rc = xf::set_error(XF_EHIP, "xf_group_selftest: %s: %s", what, why);
+  };
+  for (int ch = 0; ch < XF_GROUP_CHANNELS && rc == XF_OK; ++ch) {
+    for (int p = 0; p < W; ++p)
+      for (size_t i = 0; i < n; ++i) h[p * n + i] = (uint32_t)(g->rank * 1000003 + ch * 7 + p);
+    hipError_t e = hipStreamCreateWithFlags(&st[ch], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&ds[ch], bytes * W);
+    if (e == hipSuccess) e = hipMalloc((void **)&dr[ch], bytes * W);
+    if (e == hipSuccess) e = hipMemcpy(ds[ch], h.data(), bytes * W, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dr[ch], 0xff, bytes * W);
+    if (e != hipSuccess) fail("set-up", hipGetErrorString(e));
+  }
+  // enqueue on both communicators before waiting for either
+  for (int ch = 0; ch < XF_GROUP_CHANNELS && rc == XF_OK; ++ch) {
+    int r = g->rccl.GroupStart();
+    for (int p = 0; p < W && !r; ++p) {
+      r = g->rccl.Send(ds[ch] + (size_t)p * n, bytes, kNcclChar, p, g->comm[ch], st[ch]);
+      if (!r) r = g->rccl.Recv(dr[ch] + (size_t)p * n, bytes, kNcclChar, p, g->comm[ch], st[ch]);
+    }
+    const int r2 = g->rccl.GroupEnd();
+    if (r || r2) fail("send/recv", g->rccl.GetErrorString(r ? r : r2));
+  }
+  for (int ch = 0; ch < XF_GROUP_CHANNELS; ++ch) {
+    if (rc == XF_OK) {
+      hipError_t e = hipStreamSynchronize(st[ch]);
+      if (e == hipSuccess) e = hipMemcpy(back.data(), dr[ch], bytes * W, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) fail("wait", hipGetErrorString(e));
+      for (int p = 0; p < W && rc == XF_OK; ++p)
+        for (size_t i = 0; i < n; ++i)
+          if (back[p * n + i] != (uint32_t)(p * 1000003 + ch * 7 + g->rank)) {
+            fail("data", "a slice arrived with the wrong contents");
+            break;
+          }
+    }
+    if (ds[ch]) (void)hipFree(ds[ch]);
+    if (dr[ch]) (void)hipFree(dr[ch]);
+    if (st[ch]) (void)hipStreamDestroy(st[ch]);
+  }
+  return rc;
 }
 
 // The exchange step of the sharded table: rank p's slice send[off_p .. off_p + send_counts[p])
@@ -497,7 +564,17 @@ static int alltoallv_rccl(xf_group *g, const char *sb, const std::vector<size_t>
 extern "C" int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t *send_counts,
                                   void *recv, const uint64_t *recv_counts, size_t elem_bytes,
                                   int host_buffers, void *stream) {
+  return xf_group_alltoallv_ch(g, 0, send, send_counts, recv, recv_counts, elem_bytes,
+                               host_buffers, stream);
+}
+
+extern "C" int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
+                                     const uint64_t *send_counts, void *recv,
+                                     const uint64_t *recv_counts, size_t elem_bytes,
+                                     int host_buffers, void *stream) {
   XF_REQUIRE(g && send_counts && recv_counts && elem_bytes, "xf_group_alltoallv: null argument");
+  XF_REQUIRE(channel >= 0 && channel < XF_GROUP_CHANNELS, "xf_group_alltoallv: channel %d",
+             channel);
   const int W = g->world;
   std::vector<size_t> so(W + 1, 0), ro(W + 1, 0);
   for (int p = 0; p < W; ++p) {
@@ -512,7 +589,7 @@ extern "C" int xf_group_alltoallv(xf_group *g, const void *send, const uint64_t 
   char *rb = (char *)recv;
   if (g->transport == XF_TRANSPORT_RCCL) {
     XF_REQUIRE(!host_buffers, "xf_group_alltoallv: the RCCL transport moves device memory");
-    return alltoallv_rccl(g, sb, so, rb, ro, s);
+    return alltoallv_rccl(g, channel, sb, so, rb, ro, s);
   }
   // ---- host transport: through rank 0
   const void *hsend = send;

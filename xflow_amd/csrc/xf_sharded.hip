@@ -33,7 +33,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "xf_batch.h"
@@ -199,9 +201,44 @@ struct xf_sharded {
 
 namespace {
 
+// exchanges on the side stream (stale1: Push(t) under Pull(t+1)) go over the group's second
+// communicator: one communicator driven from two streams would serialise them, and the ranks'
+// enqueue orders on it could differ
 int a2a(xf_sharded *st, const void *send, const std::vector<uint64_t> &sc, void *recv,
         const std::vector<uint64_t> &rc, size_t elem_bytes, hipStream_t s) {
-  return xf_group_alltoallv(st->g, send, sc.data(), recv, rc.data(), elem_bytes, 0, (void *)s);
+  return xf_group_alltoallv_ch(st->g, s == st->side ? 1 : 0, send, sc.data(), recv, rc.data(),
+                               elem_bytes, 0, (void *)s);
+}
+
+// Wait for a stream that may hold a collective.  A peer that has failed (or an exchange the
+// ranks entered in different orders) would leave hipStreamSynchronize waiting forever: with
+// more than one rank the stream is polled instead, and after XF_COLLECTIVE_TIMEOUT_S seconds
+// (default 300) the call returns XF_EIO on this rank — every rank of a stuck exchange gets there.
+int wait_stream(xf_sharded *st, hipStream_t s) {
+  if (st->world <= 1) {
+    XF_HIP(hipStreamSynchronize(s));
+    return XF_OK;
+  }
+  static const double limit = [] {
+    const char *v = getenv("XF_COLLECTIVE_TIMEOUT_S");
+    const double x = v ? atof(v) : 0.0;
+    return x > 0 ? x : 300.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return XF_OK;
+    if (e != hipErrorNotReady) XF_HIP(e);
+    if (spins > 4096) {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+      const double dt =
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > limit)
+        return xf::set_error(XF_EIO, "rank %d: the work on a stream with a collective did not "
+                             "finish within %.0f s (a peer has failed, or the ranks entered an "
+                             "exchange in different orders)", st->rank, limit);
+    }
+  }
 }
 
 int collect_set(xf_sharded *st, xf_sharded::EvSet &e) {
@@ -502,7 +539,7 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
     XF_HIP(hipGetLastError());
     std::vector<uint32_t> first(W + 1);
     XF_HIP(hipMemcpyAsync(first.data(), d_first, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
-    XF_HIP(hipStreamSynchronize(s));  // (also: rp and the scratch may go)
+    XF_TRY(wait_stream(st, s));  // (also: rp and the scratch may go)
     for (int p = 0; p < W; ++p) cnt[p] = first[p + 1] - first[p];
   }
   // who sends how much to whom, and how many rows every worker has
@@ -572,13 +609,13 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
     hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s, b->o_rowid.p,
                        b->o_n, (uint32_t)W, d_seg.p, b->d_win.p, b->oW);
     XF_HIP(hipGetLastError());
-    XF_HIP(hipStreamSynchronize(s));  // d_seg goes out of scope
+    XF_TRY(wait_stream(st, s));  // d_seg goes out of scope
   }
   XF_TRY(b->d_labels.reserve(R));
   if (R)
     XF_HIP(hipMemcpyAsync(b->d_labels.p, labels + row_begin, (size_t)R * 4, hipMemcpyHostToDevice,
                           s));
-  XF_HIP(hipStreamSynchronize(s));  // the host vectors above
+  XF_TRY(wait_stream(st, s));  // the host vectors above
   return XF_OK;
 }
 
@@ -589,7 +626,7 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
   if (b->ocells && b->oc_uid == uid && b->oc_epoch == ep) return XF_OK;
   hipStream_t s = st->main;
   if (b->ocells) {
-    XF_HIP(hipStreamSynchronize(s));
+    XF_TRY(wait_stream(st, s));
     xf::cells_free(b->ocells);
     b->ocells = nullptr;
   }
@@ -857,7 +894,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     hipLaunchKernelGGL(k_owner_split, dim3((W + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        v.ukeys, b->U, (uint32_t)W, d_split);
     XF_HIP(hipMemcpyAsync(split.data(), d_split, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
-    XF_HIP(hipStreamSynchronize(s));
+    XF_TRY(wait_stream(st, s));
   }
   b->send_counts.resize(W);
   for (int p = 0; p < W; ++p) b->send_counts[p] = split[p + 1] - split[p];
@@ -890,7 +927,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     XF_TRY(sc.get((char **)&tmp, tb));
     XF_HIP(rocprim::radix_sort_pairs(tmp, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
                                      b->n_recv, 0, 64, s));
-    XF_HIP(hipStreamSynchronize(s));
+    XF_TRY(wait_stream(st, s));
   }
   guard.b = nullptr;
   *out = b;
@@ -951,8 +988,8 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
 extern "C" int xf_sharded_flush(xf_sharded *st) {
   XF_REQUIRE(st, "xf_sharded_flush: null trainer");
   if (!st->fused) XF_TRY(flush_pending(st));
-  XF_HIP(hipStreamSynchronize(st->main));
-  XF_HIP(hipStreamSynchronize(st->side));
+  XF_TRY(wait_stream(st, st->main));
+  XF_TRY(wait_stream(st, st->side));
   return XF_OK;
 }
 
@@ -962,7 +999,7 @@ extern "C" int xf_sharded_flush(xf_sharded *st) {
 extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out) {
   XF_REQUIRE(st && b && (b->R == 0 || pctr_out), "xf_sharded_predict: null argument");
   if (st->fused) {
-    XF_HIP(hipStreamSynchronize(st->main));
+    XF_TRY(wait_stream(st, st->main));
     if (st->cfg.model == 0) return xf_lr_predict(st->tw, b->b, st->ws, pctr_out);
     return xf_fm_predict(st->tw, st->tv, b->b, st->ws, pctr_out);
   }
@@ -973,7 +1010,7 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
                "dataflow");
     XF_TRY(b->opctr.reserve(b->R));
     XF_TRY(owner_forward(st, b, nullptr, b->opctr.p, st->main));
-    XF_HIP(hipStreamSynchronize(st->main));
+    XF_TRY(wait_stream(st, st->main));
     if (b->R) XF_HIP(hipMemcpy(pctr_out, b->opctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
     return XF_OK;
   }
@@ -984,7 +1021,7 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
   XF_TRY(pctr.reserve(b->R));
   XF_TRY(front_pull(st, b, B, st->main));
   XF_TRY(front_compute(st, b, B, pctr.p, false, st->main));
-  XF_HIP(hipStreamSynchronize(st->main));
+  XF_TRY(wait_stream(st, st->main));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, pctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
   return XF_OK;
 }
