@@ -108,3 +108,35 @@ def test_bench_runs_two_ranks_and_reports_them(tmp_path):
     assert "owner-compute" in line["config"]["parallelism"]
     ex = line["exchange_dataflow"]
     assert "error" not in ex and ex["value"] > 0
+
+
+def test_one_worker_save_over_a_sharded_checkpoint_is_what_loads(sample_prefixes, tmp_path):
+    """A sharded checkpoint (shard files + manifest) and then a single-table model saved under
+    the SAME name: the later save is what a load must see (the stale manifest used to send the
+    load to the old shard files)."""
+    import numpy as np
+    train, test = sample_prefixes
+    path = str(tmp_path / "model")
+    rng = np.random.default_rng(1)
+    old = capi.Sharded(None, model="lr", optimizer="ftrl", capacity=1 << 12)
+    ks = rng.choice(1 << 62, size=640).astype(np.uint64)
+    old.step(old.compile(np.arange(65, dtype=np.uint64) * 10, ks,
+                         rng.integers(0, 2, 64).astype(np.int32)))
+    old.check()
+    old.save(path)                                   # model.shard-00000-of-00001 + manifest
+    assert os.path.exists(path + ".manifest")
+    x = capi.XFlow(train, test, epochs=2)
+    x.train()
+    x.save(path)                                     # one worker: one file at `path`
+    assert not os.path.exists(path + ".manifest")
+    new = capi.Sharded(None, model="lr", optimizer="ftrl", capacity=1 << 12)
+    new.load(path)
+    assert len(new.w.export()[0]) == 877             # the sample data's keys, not the 640
+    # ... and with a manifest that is older than the single file the single file still wins
+    old.save(path + "2")
+    x.save(path + "2")
+    open(path + "2.manifest", "w").write("xflow_amd sharded model\nshards 1\nmodel 0\nk 0\n")
+    os.utime(path + "2.manifest", (1, 1))
+    newer = capi.Sharded(None, model="lr", optimizer="ftrl", capacity=1 << 12)
+    newer.load(path + "2")
+    assert len(newer.w.export()[0]) == 877

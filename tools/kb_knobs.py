@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--step", action="store_true", help="also run the LR step per minibatch")
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
     a = ap.parse_args()
     import torch
     args = argparse.Namespace(seed=20260926, rows=a.rows, nnz_per_row=a.nnz_per_row,
@@ -77,6 +79,13 @@ def main():
                           "nitems": info[4]}), flush=True)
     capi.tune("exp_knob", 0)
     tr.check()
+    if a.pmc_calibrate:
+        for kind in range(6):
+            capi.check(L.xf_calib_stream(kind, 1 << 30, 3))
+    print(json.dumps({"config": {"workload": "key build: LR+FTRL, %d keys settled, %d rows x %d "
+                                 "nnz per minibatch%s" % (a.keys, a.rows, a.nnz_per_row,
+                                                          ", zipf %.2f" % a.zipf if a.zipf else
+                                                          ", uniform")}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,10 @@ WIDTH = {
     # finalize reads fp64 partials, gradient reads 4-byte entries / losses / w and 8-byte {n,z}
     "k_lr_fwd_cells": (4, 8), "k_lr_finalize_cells": (8, 4), "k_lr_grad_cells": (4, 4),
     "k_lr_grad_split_finish": (8, 4), "k_cell_keys": (4, 4),
+    # round 3: the keyed build — histogram reads 8-byte keys; scatter reads keys 16 bytes per
+    # lane and writes 12-byte records (priced with the 16-byte calibration); resolve reads
+    # 12-byte records and the table's keys 16 bytes per lane and writes 4-byte entries
+    "k_kb_hist": (8, 4), "k_kb_scatter": (16, 16), "k_kb_resolve": (16, 4), "k_kb_scan": (4, 4),
 }
 
 

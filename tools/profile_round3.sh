@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 evidence in one go (GPU box, repo root): the default bench line, rocprofv3 kernel
+# stats of the step and of the key-build loop, bench lines of the other workloads.
+#   bash tools/profile_round3.sh gpurun_out/r03
+set -u
+OUT=$1
+R=$PWD
+mkdir -p $OUT
+python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- \
+    python $R/bench.py --no-cpu-baseline --key-build-steps 0 --repeats 0 > $R/$OUT/stats.json 2> $R/$OUT/stats.err
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kbstats -- \
+    python $R/tools/kb_knobs.py --knobs 0 --iters 24 --step > $R/$OUT/kbstats.txt 2>&1
+cd $R
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/step_kernel_stats.csv
+cp $(find $OUT/kbstats -name "*kernel_stats.csv" | head -1) $OUT/key_build_kernel_stats.csv
+python bench.py --zipf 1.1 --no-cpu-baseline > $OUT/bench_zipf11.json 2> $OUT/bench_zipf11.err
+python bench.py --model fm --k 16 --optimizer sgd --no-cpu-baseline --repeats 3 > $OUT/bench_fm16_sgd.json 2> $OUT/bench_fm16_sgd.err
+python bench.py --model fm --k 64 --optimizer ftrl --zipf 1.1 --no-cpu-baseline --repeats 3 > $OUT/bench_fm64_ftrl_zipf11.json 2> $OUT/bench_fm64_ftrl_zipf11.err
+python bench.py --rows 400000 --nnz-per-row 25 --keys-per-gpu 12500000 --force-sharded --general-path --schedule owner --no-cpu-baseline --repeats 3 > $OUT/bench_n8_shard_shape_owner.json 2> $OUT/n8.err
+python bench.py --rows 400000 --nnz-per-row 25 --keys-per-gpu 12500000 --no-cpu-baseline --repeats 3 > $OUT/bench_n8_shard_shape_fused.json 2> $OUT/n8f.err
+for f in bench_n1 bench_zipf11 bench_fm16_sgd bench_fm64_ftrl_zipf11 bench_n8_shard_shape_owner bench_n8_shard_shape_fused; do
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1])
+    print("$f", "%.4g ex/s" % d["value"], "%.4f ms" % d["ms_per_step"], d.get("ms_per_step_repeats") and "median %.4f" % d["ms_per_step_repeats"]["median"], {k: round(v*1e3,1) for k,v in d["kernels_ms"].items() if v}, "wkb", d.get("ms_per_step_with_key_build"))
+except Exception as e:
+    print("$f", "FAILED", e)
+PY
+done
+rm -rf $OUT/stats $OUT/kbstats

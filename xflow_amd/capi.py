@@ -643,8 +643,11 @@ _SCHEDULES = {"sequential": SCHEDULE_SEQUENTIAL, "stale1": SCHEDULE_STALE1,
 
 
 class ShardedBatch:
-    def __init__(self, h):
+    def __init__(self, h, owner=None):
         self.h = h
+        # xf_sbatch_free looks at the trainer that compiled the minibatch (an outstanding
+        # stale1 Push): the trainer must outlive its minibatches
+        self._owner = owner
         R, N, U, own = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(lib().xf_sbatch_dims(h, C.byref(R), C.byref(N), C.byref(U), C.byref(own)))
         self.R, self.NNZ, self.U, self.n_owned = R.value, N.value, U.value, own.value
@@ -702,7 +705,7 @@ class Sharded:
         h = vp()
         check(lib().xf_sharded_compile(self.h, C.byref(h), _p(rowptr, u64p), _p(keys, u64p),
                                        _p(labels, i32p), row_begin, row_end, 1 if keep else 0))
-        return ShardedBatch(h)
+        return ShardedBatch(h, self)
 
     def step(self, b):
         check(lib().xf_sharded_step(self.h, b.h))

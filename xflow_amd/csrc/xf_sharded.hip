@@ -31,6 +31,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1157,7 +1158,15 @@ extern "C" int xf_sharded_load(xf_sharded *st, const char *prefix) {
   int saved = 0;
   {
     const std::string m = std::string(prefix) + ".manifest";
-    FILE *f = fopen(m.c_str(), "r");
+    // a single-table model file of the same name that is NEWER than the manifest wins (a
+    // one-worker save after a several-worker one; Worker::save_model also removes the manifest)
+    struct stat sm, sf;
+    const bool single_newer = stat(m.c_str(), &sm) == 0 && stat(prefix, &sf) == 0 &&
+                              S_ISREG(sf.st_mode) &&
+                              (sf.st_mtim.tv_sec > sm.st_mtim.tv_sec ||
+                               (sf.st_mtim.tv_sec == sm.st_mtim.tv_sec &&
+                                sf.st_mtim.tv_nsec > sm.st_mtim.tv_nsec));
+    FILE *f = single_newer ? nullptr : fopen(m.c_str(), "r");
     if (f) {
       char line[256];
       while (fgets(line, sizeof(line), f))

@@ -9,6 +9,8 @@
 // but every Pull / Push / loss / gradient runs on the GPU through the extern "C" shim
 // (xf_table_*, xf_lr_step, xf_fm_step).  What stays on the host is what north_star keeps
 // there: the libsvm-format block reader and the per-block key build.
+#include <unistd.h>
+
 #include "xf_worker.h"
 
 #include <math.h>
@@ -433,7 +435,11 @@ int Worker::train() {
 int Worker::save_model(const char *path) {
   if (world > 1) return xf_sharded_save(sharded_, path);
   XF_TRY(xf_sharded_flush(sharded_));
-  return xf::model_write(path, table_w_, table_v_, v_dim_);
+  XF_TRY(xf::model_write(path, table_w_, table_v_, v_dim_));
+  // a sharded checkpoint saved under the same name earlier is stale now: without this its
+  // manifest would send a later load to the old shard files
+  (void)unlink((std::string(path) + ".manifest").c_str());
+  return XF_OK;
 }
 
 // a single file or a sharded checkpoint of ANY world size: every rank keeps the keys it owns
@@ -471,7 +477,7 @@ int Worker::set_param(const char *name, const char *value) {
     else if (!strcmp(value, "stale1")) schedule = XF_SCHEDULE_STALE1;
     else if (!strcmp(value, "owner")) schedule = XF_SCHEDULE_OWNER;
     else
-      return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential or stale1");
+      return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential, stale1 or owner");
   }
   else if (n == "pred_path") pred_path = value;
   else if (n == "alpha") alpha = (float)atof(value);
