@@ -478,16 +478,35 @@ k_kb_scan(KbArgs a) {
     if (S >= a.nS) return;
     uint32_t *__restrict__ col = a.wgcnt + S;
     uint32_t carry = 0;
-    for (uint32_t w0 = 0; w0 < a.nW; w0 += 64) {
-      const uint32_t w = w0 + lane;
-      const uint32_t x = w < a.nW ? col[(size_t)w * a.nS] : 0u;
-      uint32_t inc = x;
+    constexpr int kCol = 4;  // 256 scatter workgroups at most: every load of the column first
+    uint32_t x[kCol];
+#pragma unroll
+    for (int q = 0; q < kCol; ++q) {
+      const uint32_t w = q * 64 + lane;
+      x[q] = w < a.nW ? col[(size_t)w * a.nS] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kCol; ++q) {
+      const uint32_t w = q * 64 + lane;
+      uint32_t inc = x[q];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t y = __shfl_up(inc, o);
         if ((int)lane >= o) inc += y;
       }
-      if (w < a.nW) col[(size_t)w * a.nS] = carry + inc - x;
+      if (w < a.nW) col[(size_t)w * a.nS] = carry + inc - x[q];
+      carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    for (uint32_t w0 = kCol * 64; w0 < a.nW; w0 += 64) {  // (more workgroups than that: never)
+      const uint32_t w = w0 + lane;
+      const uint32_t y0 = w < a.nW ? col[(size_t)w * a.nS] : 0u;
+      uint32_t inc = y0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += y;
+      }
+      if (w < a.nW) col[(size_t)w * a.nS] = carry + inc - y0;
       carry += (uint32_t)__shfl((int)inc, 63);
     }
     if (lane == 0) a.scount[S] = carry;
@@ -495,8 +514,7 @@ k_kb_scan(KbArgs a) {
   }
   if (blockIdx.x == 1) {  // slices per chunk, first item of every chunk, index among the split
     const size_t nc1 = (size_t)a.cA + 1;
-    uint32_t *__restrict__ nsl = a.plan, *__restrict__ off = a.plan + nc1,
-                          *__restrict__ soff = a.plan + 2 * nc1;
+    uint32_t *nsl = a.plan, *off = a.plan + nc1, *soff = a.plan + 2 * nc1;
     auto slices = [&](uint32_t c) -> uint32_t {
       uint32_t n = 0;
       for (uint32_t v = 0; v < a.nwin; ++v) n += hist[(size_t)v * a.cA + c];
@@ -504,9 +522,29 @@ k_kb_scan(KbArgs a) {
     };
     for (uint32_t c = tid; c < a.cA; c += kKb) nsl[c] = slices(c);
     if (tid == 0) nsl[a.cA] = 0;
-    const uint32_t ta = staged_excl_scan(slices, a.cA, off, nullptr, sbuf, wsum);
-    const uint32_t tb = staged_excl_scan([&](uint32_t c) { return slices(c) > 1 ? 1u : 0u; },
-                                         a.cA, soff, nullptr, sbuf, wsum);
+    __syncthreads();  // (its fence: the slices are in L2 before this workgroup reads them back)
+    const volatile uint32_t *vn = nsl;
+    // both scans in one pass: the slices' prefix in a word's low 20 bits, the split chunks'
+    // in its high 12, whenever both fit (else one pass each)
+    uint32_t ta, tb;
+    const bool packed = a.cA < (1u << 12) && a.NNZ / xf::kSliceMax + a.cA < (1u << 20);
+    if (packed) {
+      const uint32_t t = staged_excl_scan(
+          [&](uint32_t c) { const uint32_t S = vn[c]; return S | ((S > 1 ? 1u : 0u) << 20); },
+          a.cA, off, nullptr, sbuf, wsum);
+      for (uint32_t c = tid; c < a.cA; c += kKb) {  // (this thread's own elements: unpack)
+        const uint32_t v = ((const volatile uint32_t *)off)[c];
+        off[c] = v & 0xFFFFFu;
+        soff[c] = v >> 20;
+      }
+      ta = t & 0xFFFFFu;
+      tb = t >> 20;
+    } else {
+      ta = staged_excl_scan([&](uint32_t c) { return (uint32_t)vn[c]; }, a.cA, off, nullptr, sbuf,
+                            wsum);
+      tb = staged_excl_scan([&](uint32_t c) { return vn[c] > 1 ? 1u : 0u; }, a.cA, soff, nullptr,
+                            sbuf, wsum);
+    }
     if (tid == 0) {
       off[a.cA] = ta;
       soff[a.cA] = tb;
@@ -912,47 +950,55 @@ k_kb_resolve(KbArgs a) {
       continue;
     }
     // slots: the lanes of the wavefront that fill the same cell share one atomic.  A
-    // wavefront's records mostly come from one row window: one ballot per chunk of the
-    // super-chunk settles those, a loop over the remaining cells the rest
-    unsigned long long same[E];
+    // wavefront's records mostly come from ONE row window, i.e. from the kSC cells of that
+    // window: kSC ballots (wave-uniform masks and counts), lane cl adds cell cl's count to the
+    // cell's cursor, every lane takes its base from that lane.  Records of other windows
+    // (where the tiles of two windows meet) go through a loop over their cells.
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-      same[q] = 0;
       unsigned long long todo = __ballot(ok[q]);
       if (!todo) continue;  // wave-uniform
-      const int l0 = __ffsll((long long)todo) - 1;
-      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cell[q], l0) & ~(kSC - 1);
+      uint32_t slot = 0;
+      bool placed = false;
       if (local) {  // cell = window * kSC + chunk: the first lane's window
+        const int l0 = __ffsll((long long)todo) - 1;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)cell[q], l0) & ~(kSC - 1);
+        const uint32_t cl = cell[q] - w0;  // < kSC for the lanes of that window
+        const bool in_w = ok[q] && cl < kSC;
+        unsigned long long mine = 0;
+        uint32_t cnt = 0;  // on lane i < kSC: records of the wavefront for cell w0 + i
 #pragma unroll
-        for (uint32_t cl = 0; cl < kSC; ++cl) {
-          const bool mine = ok[q] && cell[q] == w0 + cl;
-          const unsigned long long m = __ballot(mine);
-          if (mine) same[q] = m;
+        for (uint32_t i = 0; i < kSC; ++i) {
+          const unsigned long long m = __ballot(in_w && cl == i);
+          if (cl == i) mine = m;
+          if (lane == i) cnt = (uint32_t)__popcll(m);
           todo &= ~m;
         }
+        uint32_t base = 0;
+        if (lane < kSC && cnt) base = atomicAdd(&lcur[w0 + lane], cnt);
+        const uint32_t b0 = (uint32_t)__shfl((int)base, (int)(in_w ? cl : 0u));
+        if (in_w) {
+          slot = b0 + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+          placed = true;
+        }
       }
-      while (todo) {  // wave-uniform
+      while (todo) {  // wave-uniform: the cells not settled above, one at a time
         const int l = __ffsll((long long)todo) - 1;
         const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell[q], l);
-        const unsigned long long m = __ballot(ok[q] && cell[q] == lc);
-        if (ok[q] && cell[q] == lc) same[q] = m;
+        const bool me = ok[q] && !placed && cell[q] == lc;
+        const unsigned long long m = __ballot(me);
+        uint32_t base = 0;
+        if ((int)lane == l)
+          base = local ? atomicAdd(&lcur[lc], (uint32_t)__popcll(m))
+                       : atomicAdd(&a.cellcur[lc], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+        if (me) {
+          slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          placed = true;
+        }
         todo &= ~m;
       }
-    }
-    uint32_t base[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      base[q] = 0;
-      if (ok[q] && (int)lane == __ffsll((long long)same[q]) - 1) {
-        const uint32_t k = (uint32_t)__popcll(same[q]);
-        base[q] = local ? atomicAdd(&lcur[cell[q]], k) : atomicAdd(&a.cellcur[cell[q]], k);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const int leader = same[q] ? __ffsll((long long)same[q]) - 1 : 0;
-      const uint32_t b0 = (uint32_t)__shfl((int)base[q], leader);
-      if (ok[q]) entries[b0 + __popcll(same[q] & ((1ull << lane) - 1ull))] = ent[q];
+      if (ok[q]) entries[slot] = ent[q];
     }
 #pragma unroll
     for (int q = 0; q < E; ++q) {

@@ -119,10 +119,14 @@ int Worker::create_tables() {
   return XF_OK;
 }
 
-int Worker::defrag_if_grown() {
+// percent: settle the table when more than that share of its keys has arrived since the last
+// time (5 at the epoch boundaries; inside the first epoch, one worker: 30 — the key build of
+// the blocks still to come finds settled keys where they sit in LDS, arrival keys by a probe
+// per nonzero, and a defrag is a sort of the table's keys)
+int Worker::defrag_if_grown(int percent) {
   uint64_t n = 0;
   XF_TRY(xf_table_size(table_w_, &n));
-  if (n > keys_at_defrag_ + keys_at_defrag_ / 20) {  // > 5 % new keys since the last one
+  if (n > keys_at_defrag_ + keys_at_defrag_ / 100 * percent + (percent > 5 ? 4096 : 0)) {
     XF_TRY(xf_sharded_defrag(sharded_));
     keys_at_defrag_ = n;
   }
@@ -291,6 +295,9 @@ int Worker::batch_training() {
           else
             xf_sbatch_free(b);
         }
+        // (the table's maintenance step inside an epoch: local to the shard, but its flush is
+        // collective — one worker only)
+        if (rc == XF_OK && world <= 1 && model_ == 0) rc = defrag_if_grown(30);
         if (trace)
           fprintf(stderr, "block: %zu rows  waited for the parser %.2f ms  key build %.2f ms  "
                   "step+check %.2f ms\n", rows, (tw1 - tw0) * 1e3, t_compile * 1e3, t_step * 1e3);
@@ -326,7 +333,7 @@ int Worker::batch_training() {
     // flush is collective (every rank, every epoch); the defrag itself is local to the shard.
     const double tf0 = now_s();
     XF_TRY(xf_sharded_flush(sharded_));
-    if (epoch + 1 < epochs) XF_TRY(defrag_if_grown());
+    if (epoch + 1 < epochs) XF_TRY(defrag_if_grown(5));
     if (getenv("XF_TRACE_WORKER"))
       fprintf(stderr, "epoch %d: flush + table maintenance %.2f ms\n", epoch, (now_s() - tf0) * 1e3);
     if ((epoch + 1) % 30 == 0) std::cout << "epoch : " << epoch << std::endl;  // :202

@@ -58,7 +58,7 @@ class Worker {
 
  private:
   int create_tables();
-  int defrag_if_grown();
+  int defrag_if_grown(int percent);
   int any_rank(bool mine, bool *any);
   uint64_t keys_at_defrag_ = 0;
   bool rank_given_ = false;
