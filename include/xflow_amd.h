@@ -366,6 +366,11 @@ int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
  * (grouped send / recv of `bytes` bytes with every rank, this one included), results checked. */
 int xf_group_selftest(xf_group *g, size_t bytes);
 
+/* Diagnostic (tools/kb_timeline.py): wall_clock64 stamps of the phases of the last keyed build
+ * made with xf_tune("exp_knob", 200): [histogram | scatter | resolve] workgroups x slots;
+ * returns the slots per workgroup, shape[3] = workgroups per kernel. */
+int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape);
+
 /* ---------------------------------------------------------------- sharded trainer     */
 /* LRWorker / FMWorker::update across the ranks of a group: the table sharded by key range
  * (ps-lite's default slicer), examples by worker, one all-to-all-v each way per step (weights
