@@ -35,8 +35,6 @@ def main():
     tr.defrag()
     del comp
     L = capi.lib()
-    L.xf_kb_debug_read.restype = C.c_int
-    L.xf_kb_debug_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_size_t, C.POINTER(C.c_uint32)]
     rowptr, keys, labels = batches[0]
     k = torch.from_numpy(keys.view(np.int64)).cuda()
     rp = torch.from_numpy(rowptr.astype(np.uint32).view(np.int32)).cuda()

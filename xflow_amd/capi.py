@@ -144,6 +144,7 @@ SIGNATURES = {
     "xf_group_alltoallv_ch": (C.c_int, [vp, C.c_int, vp, u64p, vp, u64p, C.c_size_t, C.c_int,
                                         vp]),
     "xf_group_selftest": (C.c_int, [vp, C.c_size_t]),
+    "xf_kb_debug_read": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_size_t, u32p]),
     "xf_sharded_config_default": (None, [C.POINTER(ShardedConfig)]),
     "xf_sharded_create": (C.c_int, [C.POINTER(vp), vp, C.POINTER(ShardedConfig)]),
     "xf_sharded_destroy": (C.c_int, [vp]),
