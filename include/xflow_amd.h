@@ -300,6 +300,16 @@ int xf_fm_predict(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws,
  * forms them: the forward reads the table in place, the gradient is consumed where it is
  * summed).  Needs a minibatch with a key list (xf_batch_compile*). */
 int xf_workspace_capture(xf_workspace *ws, int enable);
+/* Parity mode of the forward (xf_lr_step / xf_fm_step / xf_*_predict with this workspace):
+ *   XF_PARITY_EXACT_SUMS       (default) row sums accumulated in fp64 and rounded once
+ *   XF_PARITY_REFERENCE_ORDER  fp32 running sums in the reference's own order (ascending fid,
+ *                              lr_worker.cc:127-138; FM: k-outer pooled sums, fm_worker.cc:
+ *                              166-192): the loss equals the reference arithmetic's bit for
+ *                              bit.  One thread per example: a checking mode, ~100x slower.
+ *                              Needs a minibatch with a key list (xf_batch_compile*). */
+#define XF_PARITY_EXACT_SUMS 0
+#define XF_PARITY_REFERENCE_ORDER 1
+int xf_workspace_parity(xf_workspace *ws, int mode);
 /* copies of the last step's intermediates to host (parity hook): any pointer may be NULL */
 int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, float *g, size_t U,
                        size_t R);
@@ -415,6 +425,9 @@ int xf_sharded_flush(xf_sharded *st);  /* apply an outstanding stale1 Push; sync
 int xf_sharded_defrag(xf_sharded *st); /* local table maintenance (flushes first) */
 int xf_sharded_check(xf_sharded *st);  /* flush + the tables' sticky errors */
 int xf_sharded_set_schedule(xf_sharded *st, int schedule);
+/* the parity mode of the forward (xf_workspace_parity) for a one-rank trainer whose minibatches
+ * carry a key list (host_key_build, or FM) */
+int xf_sharded_set_parity(xf_sharded *st, int mode);
 int xf_sharded_tables(xf_sharded *st, xf_table **w, xf_table **v);
 int xf_sharded_stream(xf_sharded *st, void **stream);
 /* ms_sum[6] = owner pull, weights exchange, forward, gradient, gradients exchange, owner
@@ -445,6 +458,8 @@ int XFStartTrain(void **h);
 int XFDestroy(void **h);
 /* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
  *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host)
+ *        parity(exact|reference_order: the forward's row sums in the reference's own fp32
+ *        order — one worker, checking mode)
  *        model_in model_out (model file to load before / save after training)
  *        block_cache(0|1) block_cache_dir (binarized block cache of the text files) */
 int XFSetParam(void *h, const char *name, const char *value);

@@ -85,6 +85,7 @@ SIGNATURES = {
                                          C.c_size_t, C.c_int, vp]),
     "xf_batch_cells_info": (C.c_int, [vp, u32p]),
     "xf_workspace_capture": (C.c_int, [vp, C.c_int]),
+    "xf_workspace_parity": (C.c_int, [vp, C.c_int]),
     "xf_batch_dims": (C.c_int, [vp, u32p, u32p, u32p, u32p]),
     "xf_batch_host": (C.c_int, [vp, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(u32p),
                                 C.POINTER(u32p), C.POINTER(u32p), C.POINTER(i32p),
@@ -158,6 +159,7 @@ SIGNATURES = {
     "xf_sharded_defrag": (C.c_int, [vp]),
     "xf_sharded_check": (C.c_int, [vp]),
     "xf_sharded_set_schedule": (C.c_int, [vp, C.c_int]),
+    "xf_sharded_set_parity": (C.c_int, [vp, C.c_int]),
     "xf_sharded_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "xf_sharded_stream": (C.c_int, [vp, C.POINTER(vp)]),
     "xf_sharded_profile": (C.c_int, [vp, C.c_int]),
@@ -513,6 +515,11 @@ class Workspace:
                 self.h = None
         except Exception:
             pass
+
+    def parity(self, mode):
+        """'exact' (default) or 'reference_order' (fp32 running row sums in the reference's
+        order: slow, for checking)"""
+        check(lib().xf_workspace_parity(self.h, {"exact": 0, "reference_order": 1}[mode]))
 
     def fetch(self, U, R):
         wu = np.empty(U, np.float32)

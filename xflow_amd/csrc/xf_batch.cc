@@ -332,7 +332,7 @@ void cells_free(xf_cells *c);
 
 extern "C" int xf_batch_free(xf_batch *b) {
   if (!b) return XF_OK;
-  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0]) {
+  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0] || b->d_uidx_sorted) {
     // kernels still running on the batch must finish first (hipFree used to imply that)
     (void)hipDeviceSynchronize();
   }
@@ -340,6 +340,7 @@ extern "C" int xf_batch_free(xf_batch *b) {
   if (b->cells) xf::cells_free(b->cells);
   if (b->d_raw) xf::blob_free(b->d_raw, b->d_raw_bytes);
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);
+  if (b->d_uidx_sorted) (void)hipFree(b->d_uidx_sorted);
   for (uint32_t *r : b->d_fm_rows)
     if (r) (void)hipFree(r);
   delete b;

@@ -27,6 +27,9 @@ struct xf_batch {
   // numbering (rebuilt when another table or another epoch of it comes along)
   xf_cells *cells = nullptr;
   uint32_t *d_rows_u = nullptr;  // state row of each unique key [U] (batches with a key list)
+  // parity mode "reference order": every row's unique-key indices in ascending order (= in
+  // ascending fid: the order of the reference's merge-join, lr_worker.cc:127-138), built once
+  uint32_t *d_uidx_sorted = nullptr;
   // FM: the unique keys' rows in the w and the v table, valid for one (uid, epoch) of each —
   // the Pulls of a replayed minibatch resolve nothing
   uint32_t *d_fm_rows[2] = {nullptr, nullptr};

@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -495,3 +496,29 @@ extern "C" int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, cons
   XF_HIP(hipStreamSynchronize(s));
   return xf_batch_compile_dev(out, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ, stream);
 }
+
+// every row's unique-key indices in ascending order (parity mode "reference order": ascending
+// index = ascending fid, the order the reference's merge-join adds a row's weights in).  Built
+// once per minibatch, on the device, from the uploaded CSR view.
+namespace xf {
+int batch_sorted_uidx(xf_batch *b, hipStream_t s) {
+  XF_REQUIRE(b && !b->local, "reference-order parity mode needs a minibatch with a key list "
+             "(xf_batch_compile*)");
+  if (b->d_uidx_sorted || b->NNZ == 0) return XF_OK;
+  XF_TRY(xf_batch_upload(b, s));
+  const xf_dev_batch &v = b->view;
+  XF_HIP(hipMalloc((void **)&b->d_uidx_sorted, (size_t)b->NNZ * 4));
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (uint64_t)std::max<uint32_t>(b->U, 1)) ++bits;
+  Scratch sc;
+  size_t tb = 0;
+  XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, v.uidx, b->d_uidx_sorted, (size_t)b->NNZ,
+                                            (unsigned)b->R, v.rowptr, v.rowptr + 1, 0, bits, s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, v.uidx, b->d_uidx_sorted, (size_t)b->NNZ,
+                                            (unsigned)b->R, v.rowptr, v.rowptr + 1, 0, bits, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return XF_OK;
+}
+}  // namespace xf

@@ -39,6 +39,7 @@ int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s);
 int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
                          hipStream_t s);
 int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s);
+int batch_sorted_uidx(xf_batch *b, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -902,6 +903,55 @@ inline int blocks_for_groups(uint32_t n_items, int items_per_block) {
 
 }  // namespace
 
+// ------------------------------------------------ reference-order forward (parity mode 1)
+// The reference accumulates a row's sum as an fp32 running sum while it walks the nonzeros in
+// ascending fid (the merge-join of lr_worker.cc:127-138 over the sorted all_keys; FM:
+// fm_worker.cc:166-192, the second-order sums k-outer and pooled over k).  These kernels do
+// exactly that, one thread per example over the row's unique-key indices in ascending order:
+// the loss is then bit for bit the reference arithmetic's (the oracle's mode 0).  Slow on
+// purpose (one lane walks a row); a checking mode, not the product path.
+__global__ void __launch_bounds__(kBlock)
+k_lr_forward_reforder(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ us,
+                      const uint32_t *__restrict__ rows_u, const float *__restrict__ w,
+                      const int32_t *__restrict__ labels, uint32_t R, float *__restrict__ loss,
+                      float *__restrict__ pctr) {
+#pragma clang fp contract(off)
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float wx = 0.0f;
+  for (uint32_t j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+    const uint32_t u = us[j];
+    wx += w[rows_u ? rows_u[u] : u];  // lr_worker.cc:132
+  }
+  const float p = xf::sigmoid_ref(wx);  // :141
+  if (pctr) pctr[r] = p;
+  if (loss) loss[r] = p - (float)labels[r];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fm_forward_reforder(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ us,
+                      const float *__restrict__ wu, const float *__restrict__ vu, int k,
+                      const int32_t *__restrict__ labels, uint32_t R, float *__restrict__ loss,
+                      float *__restrict__ pctr, float *__restrict__ vsum_out) {
+#pragma clang fp contract(off)
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t b = rowptr[r], e = rowptr[r + 1];
+  float wx = 0.0f, vs = 0.0f, vp = 0.0f;
+  for (uint32_t j = b; j < e; ++j) wx += wu[us[j]];  // fm_worker.cc:166-176
+  for (int kk = 0; kk < k; ++kk)                      // :177-192, k outer
+    for (uint32_t j = b; j < e; ++j) {
+      const float v = vu[(size_t)us[j] * k + kk];
+      vs += v;
+      vp += v * v;
+    }
+  const float vy = vs * vs - vp;              // :193-196
+  const float p = xf::sigmoid_ref(wx + vy);   // :198-201
+  if (pctr) pctr[r] = p;
+  if (loss) loss[r] = p - (float)labels[r];
+  vsum_out[r] = vs;
+}
+
 // ------------------------------------------------------------------------ C entry points
 extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
                                  float *d_pctr, void *stream) {
@@ -1225,6 +1275,9 @@ struct xf_workspace {
   // capture: keep the step's intermediates per unique key (pulled weights, gradients) for
   // xf_workspace_fetch — the parity hook.  Off by default: the production step never forms them.
   bool capture = false;
+  // parity mode: 0 = row / key sums exact in fp64 (the production path); 1 = "reference order":
+  // the forward's row sums as fp32 running sums in the reference's own order (slow kernels)
+  int parity = 0;
   uint32_t lastU = 0, lastR = 0;
   // optional per-kernel HIP-event timing (same stream, inside the caller's timed region)
   bool profiling = false;
@@ -1389,6 +1442,37 @@ static int ws_reserve_cells(xf_workspace *ws, const xf_cells *c, bool dense_g) {
   return XF_OK;
 }
 
+extern "C" int xf_workspace_parity(xf_workspace *ws, int mode) {
+  XF_REQUIRE(ws && (mode == XF_PARITY_EXACT_SUMS || mode == XF_PARITY_REFERENCE_ORDER),
+             "xf_workspace_parity: bad argument");
+  ws->parity = mode;
+  return XF_OK;
+}
+
+// the LR forward of parity mode 1 for a minibatch with a key list whose rows are resolved
+static int lr_forward_reforder(xf_table *w, xf_batch *b, float *loss, float *pctr,
+                               hipStream_t s) {
+  XF_TRY(xf::batch_sorted_uidx(b, s));
+  if (b->R == 0) return XF_OK;
+  XF_REQUIRE(b->d_rows_u || b->U == 0, "reference-order forward: the keys' rows are not resolved");
+  hipLaunchKernelGGL(k_lr_forward_reforder, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     s, b->view.rowptr, b->d_uidx_sorted, b->d_rows_u, xf::table_dev(w).w,
+                     b->view.labels, b->R, loss, pctr);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+static int fm_forward_reforder(xf_batch *b, int k, const float *wu, const float *vu, float *loss,
+                               float *pctr, float *vsum, hipStream_t s) {
+  XF_TRY(xf::batch_sorted_uidx(b, s));
+  if (b->R == 0) return XF_OK;
+  hipLaunchKernelGGL(k_fm_forward_reforder, dim3((b->R + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     s, b->view.rowptr, b->d_uidx_sorted, wu, vu, k, b->view.labels, b->R, loss,
+                     pctr, vsum);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
 extern "C" int xf_workspace_capture(xf_workspace *ws, int enable) {
   XF_REQUIRE(ws, "xf_workspace_capture: null workspace");
   ws->capture = enable != 0;
@@ -1414,7 +1498,10 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   const xf::TableDev &T = xf::table_dev(w);
   const int32_t *labels = b->local ? b->raw_labels : b->view.labels;
   XF_BEGIN();
-  XF_TRY(xf::cells_lr_forward(c, T.w, labels, ws->partial, ws->loss, nullptr, S(stream)));  // :172
+  if (ws->parity == XF_PARITY_REFERENCE_ORDER)
+    XF_TRY(lr_forward_reforder(w, b, ws->loss, nullptr, S(stream)));
+  else
+    XF_TRY(xf::cells_lr_forward(c, T.w, labels, ws->partial, ws->loss, nullptr, S(stream)));  // :172
   XF_END(kEvForward);
   if (cap) XF_TRY(xf::gather_f32(T.w, b->d_rows_u, b->U, ws->wu, S(stream)));
   // gradient (:173) + Push (:175) in one pass over the cells
@@ -1479,14 +1566,20 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
 #undef XF_FM_GS
     XF_HIP(hipGetLastError());
     XF_END(kEvGather);
-    hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
-                       dim3(kBlock), 0, S(stream), v.rowptr, v.uidx, (const FmKey *)ws->ks,
-                       v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
+    if (ws->parity == XF_PARITY_REFERENCE_ORDER)
+      XF_TRY(fm_forward_reforder(b, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, S(stream)));
+    else
+      hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                         dim3(kBlock), 0, S(stream), v.rowptr, v.uidx, (const FmKey *)ws->ks,
+                         v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
     XF_HIP(hipGetLastError());
   } else {
     XF_TRY(xf_table_gather_dev(vt, rows_v, v.U, ws->vu, stream));
     XF_END(kEvGather);
-    XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));
+    if (ws->parity == XF_PARITY_REFERENCE_ORDER)
+      XF_TRY(fm_forward_reforder(b, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, S(stream)));
+    else
+      XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));
   }
   XF_END(kEvForward);
   // gradient (:238) and the two Pushes (:241-242) in one pass: both tables are on this GPU
@@ -1506,8 +1599,11 @@ extern "C" int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
   XF_TRY(ws_reserve_cells(ws, b->cells, false));
   const int32_t *labels = b->local ? b->raw_labels : b->view.labels;
-  XF_TRY(xf::cells_lr_forward(b->cells, xf::table_dev(w).w, labels, ws->partial, ws->loss,
-                              ws->pctr, nullptr));
+  if (ws->parity == XF_PARITY_REFERENCE_ORDER)
+    XF_TRY(lr_forward_reforder(w, b, ws->loss, ws->pctr, nullptr));
+  else
+    XF_TRY(xf::cells_lr_forward(b->cells, xf::table_dev(w).w, labels, ws->partial, ws->loss,
+                                ws->pctr, nullptr));
   if (b->R) XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
   return xf_table_check(w, nullptr);
 }
@@ -1523,7 +1619,9 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
   XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, nullptr));
   XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, nullptr));
-  if (xf::fm_records_fit(k) && v.U)
+  if (ws->parity == XF_PARITY_REFERENCE_ORDER)
+    XF_TRY(fm_forward_reforder(b, k, ws->wu, ws->vu, ws->loss, ws->pctr, ws->vsum, nullptr));
+  else if (xf::fm_records_fit(k) && v.U)
     XF_TRY(xf::fm_forward_records(&v, k, ws->wu, ws->vu, ws->ks, ws->loss, ws->pctr, ws->vsum,
                                   nullptr));
   else

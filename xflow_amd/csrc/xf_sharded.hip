@@ -1106,6 +1106,15 @@ extern "C" int xf_sharded_set_schedule(xf_sharded *st, int schedule) {
   return XF_OK;
 }
 
+extern "C" int xf_sharded_set_parity(xf_sharded *st, int mode) {
+  XF_REQUIRE(st, "xf_sharded_set_parity: null trainer");
+  XF_REQUIRE(st->fused && st->ws, "xf_sharded_set_parity: one rank only (the fused step)");
+  XF_REQUIRE(mode == XF_PARITY_EXACT_SUMS || st->cfg.model == 1 || st->cfg.host_key_build,
+             "xf_sharded_set_parity: the reference-order forward needs minibatches with a key "
+             "list (host_key_build)");
+  return xf_workspace_parity(st->ws, mode);
+}
+
 extern "C" int xf_sharded_stream(xf_sharded *st, void **stream) {
   XF_REQUIRE(st && stream, "xf_sharded_stream: null argument");
   *stream = (void *)st->main;

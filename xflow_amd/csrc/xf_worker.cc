@@ -93,8 +93,9 @@ int Worker::create_tables() {
   c.lambda1 = lambda1;
   c.lambda2 = lambda2;
   c.lr = learning_rate;
-  c.host_key_build = key_build_gpu ? 0 : 1;
+  c.host_key_build = key_build_gpu && parity == XF_PARITY_EXACT_SUMS ? 0 : 1;
   XF_TRY(xf_sharded_create(&sharded_, group_, &c));
+  if (parity != XF_PARITY_EXACT_SUMS) XF_TRY(xf_sharded_set_parity(sharded_, parity));
   XF_TRY(xf_sharded_tables(sharded_, &table_w_, &table_v_));
   // One update() and one predict of a two-row minibatch on a private single-shard trainer: the
   // first launch of a kernel loads its code object and the builders size their scratch on first
@@ -499,7 +500,12 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "block_cache_dir") block_cache_dir = value;
   else if (n == "model_in") model_in = value;
   else if (n == "model_out") model_out = value;
-  else if (n == "key_build") {
+  else if (n == "parity") {
+    if (!strcmp(value, "exact")) parity = XF_PARITY_EXACT_SUMS;
+    else if (!strcmp(value, "reference_order")) parity = XF_PARITY_REFERENCE_ORDER;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: parity must be exact or reference_order");
+  } else if (n == "key_build") {
     if (!strcmp(value, "gpu")) key_build_gpu = true;
     else if (!strcmp(value, "host")) key_build_gpu = false;
     else

@@ -48,6 +48,7 @@ class Worker {
   uint64_t seed = 0;
   int cache_batches = 1;
   bool key_build_gpu = true;  // key build of update() on the GPU (xf_batch_compile_gpu)
+  int parity = 0;             // XF_PARITY_*: the forward's row sums (one worker)
   std::string pred_path;
   std::string model_in, model_out;  // load before / save after training (model file)
   // binarized block cache of the text files (xf_reader_open_cached): 0 = off; the cache
