@@ -376,6 +376,10 @@ int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
  * (grouped send / recv of `bytes` bytes with every rank, this one included), results checked. */
 int xf_group_selftest(xf_group *g, size_t bytes);
 
+/* The hash of the sources this library was built from (xflow_amd/build.py: source_hash); the
+ * Python binding refuses a library whose hash differs from the sources next to it. */
+const char *xf_source_hash(void);
+
 /* Diagnostic (tools/kb_timeline.py): wall_clock64 stamps of the phases of the last keyed build
  * made with xf_tune("exp_knob", 200): [histogram | scatter | resolve] workgroups x slots;
  * returns the slots per workgroup, shape[3] = workgroups per kernel. */

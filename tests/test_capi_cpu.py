@@ -565,3 +565,11 @@ def test_reader_unusual_tokens_take_the_general_path(tmp_path):
                     assert np.array_equal(x, y), (name, cap, x, y)
     rows = sum(len(b[3]) for b in mine)
     assert rows == len(lines)
+
+
+def test_library_names_the_sources_it_was_built_from():
+    """xf_source_hash: a prebuilt libxflow_amd.so that does not match the sources next to it is
+    refused on load (file times do not survive the snapshot to the GPU box)."""
+    from xflow_amd import build
+    assert capi.lib().xf_source_hash().decode() == build.source_hash()
+    assert len(build.source_hash()) == 32

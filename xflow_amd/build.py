@@ -28,6 +28,21 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """sha256 over every source the library is built from (csrc/*, include/xflow_amd.h), in
+    name order: compiled into the library (xf_source_hash) and checked when it is loaded, so
+    that a stale prebuilt .so cannot stand in for newer sources unnoticed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                   if f.endswith((".hip", ".cc", ".h")))
+    files.append(os.path.join(ROOT, "include", "xflow_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:32]
+
+
 def _stale(target, sources):
     if not os.path.exists(target):
         return True
@@ -37,13 +52,28 @@ def _stale(target, sources):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _built_hash():
+    """the source hash compiled into the library on disk ("" when there is none)"""
+    try:
+        import ctypes
+        L = ctypes.CDLL(LIB)
+        L.xf_source_hash.restype = ctypes.c_char_p
+        return L.xf_source_hash().decode()
+    except (OSError, AttributeError):
+        return ""
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    if force or _stale(LIB, srcs):
+    if force or _stale(LIB, srcs) or _built_hash() != source_hash():
         objs = []
         procs = []
-        for s in srcs:
+        stamp = os.path.join(LIBDIR, "xf_source_hash.cc")
+        with open(stamp, "w") as f:   # (generated: the only place the hash is compiled in)
+            f.write('extern "C" const char *xf_source_hash(void) { return "%s"; }\n'
+                    % source_hash())
+        for s in srcs + [stamp]:
             o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
             objs.append(o)
             cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + \

@@ -84,6 +84,7 @@ SIGNATURES = {
     "xf_batch_compile_local": (C.c_int, [C.POINTER(vp), vp, u64p, u64p, i32p, C.c_size_t,
                                          C.c_size_t, C.c_int, vp]),
     "xf_batch_cells_info": (C.c_int, [vp, u32p]),
+    "xf_source_hash": (C.c_char_p, []),
     "xf_workspace_capture": (C.c_int, [vp, C.c_int]),
     "xf_workspace_parity": (C.c_int, [vp, C.c_int]),
     "xf_batch_dims": (C.c_int, [vp, u32p, u32p, u32p, u32p]),
@@ -219,6 +220,15 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        # the library says which sources it was built from: a prebuilt .so that is older than
+        # the sources next to it (file times do not survive a snapshot) is an error, not a
+        # silent stand-in.  XF_LIB (an experiment's variant build) is taken as it is.
+        if "XF_LIB" not in os.environ:
+            from . import build as _build
+            built, want = L.xf_source_hash().decode(), _build.source_hash()
+            if built != want:
+                raise XFError("libxflow_amd.so was built from other sources (library %s, "
+                              "sources %s): run `python -m xflow_amd.build`" % (built, want))
         _lib = L
     return _lib
 
