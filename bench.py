@@ -45,6 +45,10 @@ def parse_args():
                          "1.25x10^7 at N>1 (configs[2]: 10^8 keys over 8 GPUs)")
     ap.add_argument("--batches", type=int, default=8, help="distinct minibatches cycled")
     ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--capacity", type=int, default=0,
+                    help="index positions of a GPU's table at the start (default: keys per GPU / "
+                         "load factor).  A power-law stream over a huge key space touches few "
+                         "keys: start small, the table grows on first touch")
     ap.add_argument("--zipf", type=float, default=0.0)
     ap.add_argument("--cpu-baseline-batches", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,6 +74,8 @@ def parse_args():
                     help="with --force-sharded at N=1: run the N>1 code path (owner gather, "
                          "self all-to-all-v, index-mode kernels, merged owner update) instead of "
                          "the fused step, to time its stages on one GPU")
+    ap.add_argument("--no-fm-leg", action="store_true",
+                    help="N=1 LR: skip the FM k=16 + SGD figure (configs[3]) of the JSON line")
     ap.add_argument("--no-owner-leg", action="store_true",
                     help="N>1: skip the supplementary run of the owner-compute dataflow")
     ap.add_argument("--repeats", type=int, default=10,
@@ -246,6 +252,50 @@ def with_key_build_sharded(args, trainer, batches, R, world, barrier, allmax):
     return {"value": R * world / dt, "unit": "examples/sec", "ms_per_step": dt * 1e3, "steps": n,
             "what": "xf_sharded_compile from host arrays (upload of the raw keys included) + "
                     "the step on the dataflow of `value`, per minibatch, nothing cached"}
+
+
+def fm_leg(args, batches):
+    """BASELINE configs[3] next to the LR line (same row shape, same keys): FM k = 16 + SGD on
+    one GPU, compiled minibatches replayed from HBM like `value`.  Reference form of FM (pooled
+    second-order sums, fm_worker.cc:126-202).  Not `value`."""
+    import torch
+    from xflow_amd.single import SingleGpuTrainer
+    k, nb = 16, min(4, len(batches))
+    cap = int(args.keys_per_gpu / args.load_factor) + 1024
+    tr = SingleGpuTrainer(model="fm", optimizer="sgd", k=k, capacity=cap)
+    comp = [tr.compile(*b) for b in batches[:nb]]
+    for c in comp:
+        tr.predict(c)
+    tr.check()
+    tr.defrag()
+    for i in range(4):
+        tr.step(comp[i % nb])
+    tr.check()
+    torch.cuda.synchronize()
+    steps = 12
+    tr.profile(True)
+    per = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(comp[i % nb])
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / steps * 1e3)
+    ms, n = tr.profile_read()
+    tr.profile(False)
+    tr.check()
+    R, NNZ = comp[0].R, int(np.mean([c.NNZ for c in comp]))
+    U = int(np.mean([c.U for c in comp]))
+    _, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
+    return {"workload": "FM(k=16)+SGD, %d keys, %d rows x %d nnz per minibatch, uniform "
+                        "(BASELINE configs[3])" % (args.keys_per_gpu, args.rows, args.nnz_per_row),
+            "value": R / (per[0] * 1e-3), "unit": "examples/sec", "ms_per_step": per[0],
+            "ms_per_step_repeats": spread(per), "steps": steps,
+            "kernels_ms": {kk: v / max(n, 1) for kk, v in ms.items()},
+            "step_bytes_survey_8d": survey,
+            "step_gbs_survey_8d": survey / (per[0] * 1e-3) / 1e9,
+            "frac_of_hbm_peak_survey_8d": survey / (per[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "fm_mode": "reference (pooled-over-k sums, no 1/2: fm_worker.cc:178-196)"}
 
 
 def spread(ms):
@@ -621,7 +671,7 @@ def main():
     keytab = make_key_table(nkeys_total)
     batches = make_batches(args, rank, nkeys_total, keytab)
 
-    capacity = int(args.keys_per_gpu / args.load_factor) + 1024
+    capacity = args.capacity or int(args.keys_per_gpu / args.load_factor) + 1024
     # N > 1, LR, C++ trainer: `value` is measured on the owner-compute dataflow (nonzeros at the
     # key owners, row sums and losses exchanged: DESIGN.md 6) when a two-minibatch smoke run of
     # it succeeds on every rank; the weight/gradient exchange (stale1) is then the supplementary
@@ -847,6 +897,14 @@ def main():
             group.close()
         return
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
+    touched = None   # keys the table holds after the run (state is allocated on first touch)
+    try:
+        if not sharded:
+            touched = len(trainer.w)
+        elif group is not None:
+            touched = len(trainer.st.w)
+    except Exception:
+        pass
     # the C++ sharded trainer takes the fused single-shard step at world 1
     one_shard = world == 1 and not (args.force_sharded and
                                     (args.general_path or args.driver == "python"))
@@ -888,6 +946,7 @@ def main():
                    "rows_per_gpu_batch": R, "nnz_per_gpu_batch": NNZ,
                    "unique_keys_per_gpu_batch": U, "table_load_factor": args.load_factor,
                    "distinct_batches": len(compiled),
+                   "table_keys_touched": touched,
                    "parallelism": ("key-range sharded table x%d, %s" % (
                        world, "owner-compute dataflow: nonzeros at the key owners, fp64 partial "
                               "row sums and losses all-to-all-v per step" if schedule == "owner"
@@ -938,6 +997,13 @@ def main():
     if out.get("with_key_build") and "value" in out["with_key_build"]:
         out["value_with_key_build"] = out["with_key_build"]["value"]
         out["ms_per_step_with_key_build"] = out["with_key_build"]["ms_per_step"]
+    if world == 1 and not args.force_sharded and args.model == "lr" and not args.no_fm_leg:
+        del compiled, trainer      # (the FM tables want the memory's bandwidth to themselves)
+        trainer = None
+        try:
+            out["fm"] = fm_leg(args, batches)
+        except Exception as e:   # the LR line must not depend on this extra
+            out["fm"] = {"error": str(e)}
     if args.pmc_calibrate:
         for kind in range(6):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))

@@ -882,7 +882,6 @@ k_kb_resolve(KbArgs a) {
       rec[q] = i < re - b0 ? src[i] : Rec3{0u, 0u, 0u};
     }
   };
-  load_batch(rb);
   {
     const ulonglong2 *__restrict__ src = (const ulonglong2 *)(a.bkeys + k0);  // 16-byte aligned
     for (uint32_t i = tid; i < (nk + 1) / 2; i += kRes) {  // (bkeys is padded past nbase)
@@ -900,7 +899,10 @@ k_kb_resolve(KbArgs a) {
       }
   }
   const uint64_t sm = a.smult[S];
-  __syncthreads();
+  // the records after the keys: loads come back in order, the look-ups of the first round can
+  // start when the keys and the first records are there, the other records still on their way
+  load_batch(rb);
+  lds_barrier();
   KB_T(1);
   const uint64_t kfirst = lk[0];
   auto lkf = [&](uint32_t i) -> uint64_t { return lk[i]; };
