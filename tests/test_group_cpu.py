@@ -122,3 +122,39 @@ def test_group_world1_and_bad_arguments():
     g.close()
     with pytest.raises(capi.XFError):
         capi.Group(rank=3, world=2, transport=capi.TRANSPORT_HOST)
+
+
+def _stray(port, q):
+    """a connection that is not a rank: keeps trying until rank 0 listens, says the wrong thing"""
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=1) as c:
+                c.sendall(b"GET / HT")          # 8 bytes, not the group's hello
+                time.sleep(0.5)
+            q.put("sent")
+            return
+        except OSError:
+            time.sleep(0.02)
+    q.put("never connected")
+
+
+def test_a_stray_connection_does_not_take_a_rank():
+    """rank 0 checks a magic word in every hello: something else that connects to the
+    rendezvous port is dropped, the group still forms with its real ranks"""
+    ctx = mp.get_context("spawn")
+    q, sq = ctx.Queue(), ctx.Queue()
+    port = free_port()
+    stray = ctx.Process(target=_stray, args=(port, sq))
+    r0 = ctx.Process(target=_rank_main, args=(0, 2, port, False, q))
+    r0.start()
+    stray.start()
+    assert sq.get(timeout=90) == "sent"
+    r1 = ctx.Process(target=_rank_main, args=(1, 2, port, False, q))
+    r1.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in (r0, r1, stray):
+        p.join(timeout=30)
+    errs = [e for _, _, e in res if e]
+    assert not errs, errs[0]

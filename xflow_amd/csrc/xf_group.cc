@@ -58,6 +58,7 @@ struct Rccl {
   const char *(*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+constexpr int32_t kHelloMagic = 0x78664731;  // "xfG1": first word of a rank's hello and of its answer
 
 int load_rccl(Rccl &r) {
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -323,8 +324,8 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
       const int fd = socket(AF_INET, SOCK_STREAM, 0);
       int one = 1;
       setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      // the rendezvous address itself (127.0.0.1 stays on this host), not every interface
       sockaddr_in any = sa;
-      any.sin_addr.s_addr = htonl(INADDR_ANY);
       if (bind(fd, (sockaddr *)&any, sizeof(any)) == 0 && listen(fd, world + 8) == 0) {
         g->listen_fd = fd;
         root = true;
@@ -348,13 +349,25 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
         const int fd = accept(g->listen_fd, nullptr, nullptr);
         if (fd < 0) return xf::set_error(XF_EIO, "xf_group_create: accept: %s", strerror(errno));
         tune_socket(fd);
-        int32_t want = -1;
-        XF_TRY(recv_all(fd, &want, 4));
+        // the hello: a magic word and the rank asked for, within 10 s — a stray connection
+        // (a port scanner, another service's client) is dropped instead of holding the group up
+        timeval tv{10, 0};
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        int32_t hello[2] = {0, -1};
+        if (recv_all(fd, hello, 8) != XF_OK || hello[0] != kHelloMagic) {
+          close(fd);
+          --have;
+          continue;
+        }
+        timeval none{0, 0};
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof(none));
+        const int32_t want = hello[1];
         if (want < 0) {
           pending.push_back(fd);
         } else {
           if (want == 0 || want >= world || g->peer[want] != -1) {
             close(fd);
+            for (int p : pending) close(p);
             return xf::set_error(XF_EINVAL, "xf_group_create: rank %d announced twice or out of "
                                  "range", want);
           }
@@ -366,8 +379,8 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
         g->peer[next_auto] = fd;
       }
       for (int r = 1; r < world; ++r) {
-        const int32_t id[2] = {r, world};
-        XF_TRY(send_all(g->peer[r], id, 8));
+        const int32_t id[3] = {r, world, kHelloMagic};
+        XF_TRY(send_all(g->peer[r], id, 12));
       }
     } else {
       int fd = -1;
@@ -384,10 +397,13 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
       }
       tune_socket(fd);
       g->peer.assign(1, fd);
-      const int32_t want = rank;
-      XF_TRY(send_all(fd, &want, 4));
-      int32_t id[2] = {0, 0};
-      XF_TRY(recv_all(fd, id, 8));
+      const int32_t hello[2] = {kHelloMagic, rank};
+      XF_TRY(send_all(fd, hello, 8));
+      int32_t id[3] = {0, 0, 0};
+      XF_TRY(recv_all(fd, id, 12));
+      if (id[2] != kHelloMagic)
+        return xf::set_error(XF_EIO, "xf_group_create: %s:%d answers, but it is not an xf_group "
+                             "rank 0 (is the port taken by another service?)", host.c_str(), port);
       if (id[1] != world)
         return xf::set_error(XF_EINVAL, "xf_group_create: rank 0 runs a world of %d, this "
                              "process one of %d", id[1], world);
@@ -614,6 +630,10 @@ extern "C" int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
     for (int p = 0; p <= W; ++p) offs[0][p] = so[p];
     for (int r = 1; r < W; ++r) {
       XF_TRY(recv_all(g->peer[r], offs[r].data(), (W + 1) * 8));
+      for (int p = 0; p < W; ++p)
+        if (offs[r][p] > offs[r][p + 1] || offs[r][0] != 0 || offs[r][W] > (1ull << 40))
+          return xf::set_error(XF_EINVAL, "xf_group_alltoallv: rank %d sent slice offsets that "
+                               "do not ascend", r);
       bufs[r].resize((size_t)offs[r][W]);
       if (offs[r][W]) XF_TRY(recv_all(g->peer[r], bufs[r].data(), bufs[r].size()));
     }

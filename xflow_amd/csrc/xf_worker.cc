@@ -9,6 +9,7 @@
 // but every Pull / Push / loss / gradient runs on the GPU through the extern "C" shim
 // (xf_table_*, xf_lr_step, xf_fm_step).  What stays on the host is what north_star keeps
 // there: the libsvm-format block reader and the per-block key build.
+#include <hip/hip_runtime_api.h>
 #include <unistd.h>
 
 #include "xf_worker.h"
@@ -226,7 +227,13 @@ int Worker::batch_training() {
       std::condition_variable cv;
       int filled[2] = {0, 0};  // 0 = free for the parser, 1 = parsed, waiting for the trainer
       bool stop = false;
-      std::thread parser([&] {
+      int trainer_dev = 0;
+      (void)hipGetDevice(&trainer_dev);
+      std::thread parser([&, trainer_dev] {
+        // the block arrays are page-locked by this thread: on the trainer's GPU, not on
+        // device 0 (the current device is per thread; every rank of a node would otherwise
+        // create a context on GPU 0)
+        (void)hipSetDevice(trainer_dev);
         for (int k = 0;; k ^= 1) {
           {
             std::unique_lock<std::mutex> lk(mu);
@@ -322,7 +329,11 @@ int Worker::batch_training() {
       // that is writing the block cache finishes the file when it closes: that one now)
       if (writes_cache) xf_reader_close(rd);
       else
+      {
+        for (std::thread &t : closers_) t.join();  // (the previous epoch's: long done)
+        closers_.clear();
         closers_.emplace_back([rd] { xf_reader_close(rd); });
+      }
       if (trace)
         fprintf(stderr, "epoch %d: blocks done after %.2f ms, reader and block buffers released "
                 "in %.2f ms\n", epoch, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);
