@@ -137,3 +137,44 @@ def test_predict_and_replay_after_a_renumbering():
         same(capi.lr_predict(t, bs[1], ws), obs[1].lr_loss(s.pull(obs[1].ukeys))[1])
     for a, e in zip(t.export(), s.export()):
         same(a, e)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_keyed_and_general_builds_give_the_same_table(seed):
+    """random minibatch shapes (rows, row lengths, key space, skew, empty rows, windows), a
+    random share of the keys settled before: the range-partitioned build and the general build
+    end in the same table and the same predictions, bit for bit"""
+    rng = np.random.RandomState(1000 + seed)
+    R = int(rng.choice([37, 600, 5000, 18000, 36000]))
+    nnz = int(rng.choice([1, 3, 17, 60]))
+    nkeys = int(rng.choice([2500, 9000, 70000, 400000]))
+    zipf = [None, 1.1, 1.6][rng.randint(3)]
+    ragged = bool(rng.randint(2))
+    opt = [capi.OPT_FTRL, capi.OPT_SGD][rng.randint(2)]
+    raws = [synth(rng, R, nnz, nkeys, zipf, ragged) for _ in range(3)]
+    # the keys settled beforehand: a random share of the key space (plus none / all)
+    share = [0.0, 0.3, 0.9, 1.0][rng.randint(4)]
+    pre = np.array([O.hash_str(str(i)) for i in range(nkeys)], np.uint64)
+    pre = np.sort(pre[rng.rand(nkeys) < share]) if share < 1.0 else np.sort(pre)
+    outs = []
+    for general in (False, True):
+        general_path(general)
+        try:
+            t = capi.Table(opt, 1, capacity=2 * len(pre) + 4096)   # (the compiles grow it)
+            ws = capi.Workspace()
+            if len(pre):
+                t.pull(pre)                    # inserts
+                t.defrag()
+            bs = [capi.LocalBatch(t, *x) for x in raws]   # kept: rebuilt after the defrag
+            for i in range(4):
+                capi.lr_step(t, bs[i % 3] if i % 3 != 0 else capi.LocalBatch(t, *raws[0],
+                                                                            retain_keys=False), ws)
+                if i == 1:
+                    t.defrag()
+            t.check()
+            outs.append((t.export(), capi.lr_predict(t, bs[1], ws)))
+        finally:
+            general_path(False)
+    for a, b in zip(outs[0][0], outs[1][0]):
+        same(a, b)
+    same(outs[0][1], outs[1][1])
