@@ -573,7 +573,7 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
       return total <= 32 ? total * ((32 / total) * 8) : (uint64_t)256;
     };
     uint64_t best = nw;
-    for (uint64_t c = nw + 1; c <= nw + 2 && c <= maxR; ++c)
+    for (uint64_t c = nw + 1; (c <= nw + 2 || c * (uint64_t)W <= 32) && c <= maxR; ++c)
       if (groups(c) > groups(best)) best = c;
     nw = best;
   }
