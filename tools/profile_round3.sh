@@ -9,7 +9,7 @@ mkdir -p $OUT
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- \
-    python $R/bench.py --no-cpu-baseline --key-build-steps 0 --repeats 0 > $R/$OUT/stats.json 2> $R/$OUT/stats.err
+    python $R/bench.py --no-cpu-baseline --key-build-steps 0 --repeats 0 --no-fm-leg > $R/$OUT/stats.json 2> $R/$OUT/stats.err
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kbstats -- \
     python $R/tools/kb_knobs.py --knobs 0 --iters 24 --step > $R/$OUT/kbstats.txt 2>&1
 cd $R
@@ -31,3 +31,24 @@ except Exception as e:
 PY
 done
 rm -rf $OUT/stats $OUT/kbstats
+# the step's PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, in-run stream calibration)
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_$c -- \
+      python $R/bench.py --steps 6 --warmup 8 --no-cpu-baseline --key-build-steps 0 --repeats 0 --no-fm-leg --pmc-calibrate \
+      > $R/$OUT/pmc_$c.json 2> $R/$OUT/pmc_$c.err
+done
+cd $R
+python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc_traffic.json
+cp $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $OUT/pmc_fetch_counter_collection.csv
+cp $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/pmc_write_counter_collection.csv
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+python - <<PY
+import json
+d=json.load(open("$OUT/pmc_traffic.json"))
+print(d["workload"]); print(d["calibration_true_bytes_per_counted_byte"])
+for k,e in d["kernels"].items():
+    if "k_lr" in k:
+        print("%-40s fetch %7.1f MB  write %7.1f MB  traffic %7.1f MB  %6.1f us" % (k[:40], e["fetch_corrected"]/1e6, e["write_corrected"]/1e6, e["traffic"]/1e6, e["median_us_under_pmc"]))
+PY
+bash tools/pmc_keybuild.sh $OUT 2>&1 | tail -9
