@@ -24,6 +24,11 @@
 //                 LDS, every record finds its key there (position = state row), takes the next
 //                 slot of its cell and becomes a 4-byte entry
 //
+// Limits (beyond them the general build runs: a probe of the table per nonzero + a radix sort):
+// the scatter's per-super-chunk arrays must fit the LDS next to its 8192-record stage — about
+// 1900 super-chunks = 1.5e7 settled keys per GPU (configs[1]: 1e7, configs[2]: 1.25e7 per GPU);
+// 6.7e7 nonzeros per minibatch; 4e6 cells.
+//
 // Keys the settled tier does not hold (new since the last xf_table_defrag, or the reserved key
 // value) leave a hole in their cell (an entry the kernels skip) and go to a miss list; they are
 // inserted by the general path (table_resolve_any) and form a second SEGMENT of the batch's
@@ -1115,7 +1120,9 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                     sum != nullptr && cA64 < 0xFFFFu &&
                     scatter_lds_bytes((uint32_t)nS64) <= kDynMax &&
                     hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax &&
-                    cA64 * nwin < (1ull << 22) && exp_knob() != 77;
+                    cA64 * nwin < (1ull << 22) &&
+                    ((uint64_t)NNZ + kTile - 1) / kTile <= (uint64_t)kMaxSub * 256 &&
+                    exp_knob() != 77;
   if (!fits) return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
   const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
   // segment A: the settled tier's rows [0, nbase)
