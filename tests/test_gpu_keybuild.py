@@ -178,3 +178,40 @@ def test_random_shapes_keyed_and_general_builds_give_the_same_table(seed):
     for a, b in zip(outs[0][0], outs[1][0]):
         same(a, b)
     same(outs[0][1], outs[1][1])
+
+
+def test_a_table_beyond_the_full_tile_limit_takes_half_tiles():
+    """2e7 settled keys = 2442 super-chunks: their per-tile arrays do not fit the LDS next to a
+    full 8192-record stage, the scatter runs with 4096-record tiles; same losses and
+    predictions as the general build"""
+    n = 20_000_000
+    keys = capi.hash_decimal_range(0, n)
+    rng = np.random.RandomState(4)
+    R, nnz = 20000, 50
+    rowptr = (np.arange(R + 1) * nnz).astype(np.uint64)
+    fid = rng.randint(0, n + 5000, size=R * nnz)           # a few keys beyond the settled ones
+    extra = capi.hash_decimal_range(n, 5000)
+    bk = np.where(fid < n, keys[np.minimum(fid, n - 1)], extra[np.maximum(fid - n, 0)])
+    labels = rng.randint(0, 2, size=R).astype(np.int32)
+    outs = []
+    for general in (False, True):
+        general_path(general)
+        try:
+            t = capi.Table(capi.OPT_FTRL, 1, capacity=2 * n + 4096)
+            ws = capi.Workspace()
+            srt = np.sort(keys)
+            for i in range(0, n, 4_000_000):
+                t.pull(srt[i:i + 4_000_000])               # inserts
+            t.defrag()
+            b = capi.LocalBatch(t, rowptr, bk, labels)
+            if not general:
+                assert b.cells_info()["segments"] == 2
+            capi.lr_step(t, b, ws)
+            capi.lr_step(t, b, ws)
+            outs.append((ws.fetch_loss(R), capi.lr_predict(t, b, ws)))
+            t.check()
+            del b, t
+        finally:
+            general_path(False)
+    same(outs[0][0], outs[1][0])
+    same(outs[0][1], outs[1][1])

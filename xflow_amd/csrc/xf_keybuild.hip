@@ -25,9 +25,10 @@
 //                 slot of its cell and becomes a 4-byte entry
 //
 // Limits (beyond them the general build runs: a probe of the table per nonzero + a radix sort):
-// the scatter's per-super-chunk arrays must fit the LDS next to its 8192-record stage — about
-// 1900 super-chunks = 1.5e7 settled keys per GPU (configs[1]: 1e7, configs[2]: 1.25e7 per GPU);
-// 6.7e7 nonzeros per minibatch; 4e6 cells.
+// the scatter's per-super-chunk arrays must fit the LDS next to its stage of records (8192 per
+// tile up to ~1900 super-chunks = 1.5e7 settled keys per GPU — configs[1]: 1e7, configs[2]:
+// 1.25e7 per GPU — 4096 per tile up to ~4200 = 3.4e7 keys); 3.3e7 nonzeros per minibatch;
+// 4e6 cells.
 //
 // Keys the settled tier does not hold (new since the last xf_table_defrag, or the reserved key
 // value) leave a hole in their cell (an entry the kernels skip) and go to a miss list; they are
@@ -112,6 +113,7 @@ struct KbArgs {
   uint32_t R, NNZ, W, nwin;
   uint32_t cA, nS, ntile;          // chunks / super-chunks of the settled tier; scatter tiles
   uint32_t span, nW;               // nonzeros per histogram / scatter workgroup; workgroups
+  uint32_t tile;                   // nonzeros per scatter tile: kTile, or less for big tables
   uint32_t nbase;
   const uint64_t *bkeys;           // the tier's keys, ascending; chunk c begins at bkeys[c << 11]
   uint64_t lo;
@@ -337,10 +339,10 @@ k_kb_hist(KbArgs a) {
     }
   }
   if (!ROWID) {  // a wavefront per tile of the workgroup: the row of the tile's first nonzero
-    const uint32_t wave = tid >> 6, ntl = (e1 - e0 + kTile - 1) / kTile;
+    const uint32_t wave = tid >> 6, ntl = (e1 - e0 + a.tile - 1) / a.tile;
     for (uint32_t k = wave; k < ntl; k += kKb / 64) {
-      const uint32_t r = wave_last_le(a.rowptr, a.R, e0 + k * kTile);
-      if ((tid & 63u) == 0) a.tile_r0[e0 / kTile + k] = r;
+      const uint32_t r = wave_last_le(a.rowptr, a.R, e0 + k * a.tile);
+      if ((tid & 63u) == 0) a.tile_r0[e0 / a.tile + k] = r;
     }
   }
   __syncthreads();
@@ -580,24 +582,27 @@ struct ScatterLds {
   uint16_t *stB;
 };
 constexpr uint32_t kMaxSub = 32;  // tiles per scatter workgroup
-__host__ __device__ inline size_t scatter_lds_bytes(uint32_t nS) {
-  return (size_t)nS * 8 + (size_t)kTile * 8 +
-         ((size_t)nS * 4 + 1 + kTile + 2 * (kRowSeg + 2) + kMaxSub + 2) * 4 + (size_t)kTile * 2;
+__host__ __device__ inline size_t scatter_lds_bytes(uint32_t nS, uint32_t tile) {
+  return (size_t)nS * 8 + (size_t)tile * 8 +
+         ((size_t)nS * 4 + 1 + tile + 2 * (kRowSeg + 2) + kMaxSub + 2) * 4 + (size_t)tile * 2;
 }
 
-template <bool ROWID>
+// TILE: kTile, or a half / a quarter of it when the table has so many super-chunks that their
+// per-tile arrays would not fit the LDS next to a full stage (shorter runs of records, more
+// barriers per nonzero: a big table's price)
+template <bool ROWID, uint32_t TILE>
 __global__ void __launch_bounds__(kKb)
 k_kb_scatter(KbArgs a) {
   extern __shared__ uint64_t smem[];
   ScatterLds L;
   L.sb = smem;
   L.stK = L.sb + a.nS;
-  L.cnt = (uint32_t *)(L.stK + kTile);
+  L.cnt = (uint32_t *)(L.stK + TILE);
   L.lofs = L.cnt + a.nS;
   L.base = L.lofs + a.nS + 1;
   L.sd2 = L.base + a.nS;  // dir[b] | dir[b + 1] << 16
   L.stR = L.sd2 + a.nS;
-  L.rowseg = L.stR + kTile;  // two buffers: this tile's and the next one's
+  L.rowseg = L.stR + TILE;  // two buffers: this tile's and the next one's
   L.tr = L.rowseg + 2 * (kRowSeg + 2);
   L.stB = (uint16_t *)(L.tr + kMaxSub + 2);
   __shared__ uint32_t wsum[kKb / 64];
@@ -607,13 +612,13 @@ k_kb_scatter(KbArgs a) {
   KB_T(0);
   int dslot = 1;
   const uint32_t w0 = blockIdx.x * a.span, w1 = min(w0 + a.span, a.NNZ);
-  const uint32_t ntl = (w1 - w0 + kTile - 1) / kTile;  // <= kMaxSub
+  const uint32_t ntl = (w1 - w0 + TILE - 1) / TILE;  // <= kMaxSub
   const uint64_t *__restrict__ keys = a.keys;
   const uint32_t *__restrict__ rowptr = a.rowptr;
   Rec3 *__restrict__ rec = a.rec;
-  constexpr int E = (int)(kTile / kKb);
+  constexpr int E = (int)(TILE / kKb);
   static_assert(E % 4 == 0, "a thread's keys are read in pairs and looked up four at a time");
-  static_assert(kTile <= 8192, "rank and super-chunk share a word: 13 bits of rank");
+  static_assert(TILE <= 8192 && TILE >= 4 * kKb, "rank and super-chunk share a word: 13 bits of rank");
   static_assert(kRowSeg + 2 <= 2 * kKb, "a thread stages two row offsets");
   auto load_keys = [&](uint32_t e0, uint64_t *key) {  // keys[e0 + tid * E .. + E), 0 past w1
     const uint32_t j0 = e0 + tid * E;
@@ -642,7 +647,7 @@ k_kb_scatter(KbArgs a) {
     }
     if (!ROWID)  // the first row of every tile of the workgroup, and of the tile after them
       for (uint32_t k = tid; k <= ntl; k += kKb) {
-        const uint32_t t = w0 / kTile + k;
+        const uint32_t t = w0 / TILE + k;
         L.tr[k] = t < a.ntile ? a.tile_r0[t] : a.R - 1;
       }
     // sstart = exclusive scan of the super-chunks' record counts
@@ -689,7 +694,7 @@ k_kb_scatter(KbArgs a) {
   auto bnd = [&](uint32_t S) -> uint64_t { return L.sb[S]; };
   KB_T(dslot++);
   for (uint32_t k = 0; k < ntl; ++k) {
-    const uint32_t e0 = w0 + k * kTile, n = min(kTile, w1 - e0);
+    const uint32_t e0 = w0 + k * TILE, n = min(TILE, w1 - e0);
     const bool more = k + 1 < ntl;
     uint32_t r0 = 0, nseg = 0, nr0 = 0, nnseg = 0, nrs[2] = {0, 0};
     if (!ROWID) seg_of(k, &r0, &nseg);
@@ -699,7 +704,7 @@ k_kb_scatter(KbArgs a) {
     // tile's records are stored — loads and stores retire through one in-order counter, a wait
     // for a load issued after the stores would drain the stores
     if (more) {
-      load_keys(e0 + kTile, nkey);
+      load_keys(e0 + TILE, nkey);
       if (!ROWID) {
         seg_of(k + 1, &nr0, &nnseg);
         if (nnseg <= kRowSeg + 2) {
@@ -1118,10 +1123,10 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   KbSummary *sum = summary_buf();
   const bool fits = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
                     sum != nullptr && cA64 < 0xFFFFu &&
-                    scatter_lds_bytes((uint32_t)nS64) <= kDynMax &&
+                    scatter_lds_bytes((uint32_t)nS64, kTile / 2) <= kDynMax &&
                     hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax &&
                     cA64 * nwin < (1ull << 22) &&
-                    ((uint64_t)NNZ + kTile - 1) / kTile <= (uint64_t)kMaxSub * 256 &&
+                    ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256 &&
                     exp_knob() != 77;
   if (!fits) return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
   const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
@@ -1148,7 +1153,8 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     a.nwin = nwin;
     a.cA = cA;
     a.nS = nS;
-    a.ntile = (NNZ + kTile - 1) / kTile;
+    a.tile = scatter_lds_bytes(nS, kTile) <= kDynMax ? kTile : kTile / 2;
+    a.ntile = (NNZ + a.tile - 1) / a.tile;
     a.nbase = (uint32_t)T.nbase;
     a.bkeys = T.bkeys;
     a.lo = T.lo;
@@ -1162,7 +1168,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     // as many histogram / scatter workgroups as the GPU has CUs (one round), whole tiles each
     const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
     XF_REQUIRE(sub <= kMaxSub, "cells_build_keyed: %u nonzeros in one minibatch", NNZ);
-    a.span = sub * kTile;
+    a.span = sub * a.tile;
     a.nW = (a.ntile + sub - 1) / sub;
     uint32_t *small = nullptr;
     const size_t n_zero = 4 + ncell;  // the summary and the histogram: cleared together
@@ -1220,9 +1226,16 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
         XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
     }
     hipLaunchKernelGGL(k_kb_scan, dim3(2 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
-    if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true>), a.nW, scatter_lds_bytes(nS));
-    else
-      XF_KB_LAUNCH((k_kb_scatter<false>), a.nW, scatter_lds_bytes(nS));
+    const size_t sl = scatter_lds_bytes(nS, a.tile);
+    if (a.tile == kTile) {
+      if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile>), a.nW, sl);
+      else
+        XF_KB_LAUNCH((k_kb_scatter<false, kTile>), a.nW, sl);
+    } else {
+      if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile / 2>), a.nW, sl);
+      else
+        XF_KB_LAUNCH((k_kb_scatter<false, kTile / 2>), a.nW, sl);
+    }
     hipLaunchKernelGGL(k_kb_resolve, dim3(max_items), dim3(kRes), 0, s, a);
 #undef XF_KB_LAUNCH
     XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
