@@ -408,7 +408,17 @@ typedef struct {
   uint64_t seed;
   float alpha, beta, lambda1, lambda2, lr;
   int32_t host_key_build; /* != 0: the sorted-unique-key build on the host (xf_batch_compile) */
+  /* How the owner applies the ranks' pushes of one step:
+   *   XF_UPDATE_RANK_ORDERED  every worker's gradient (its sum / its R) is its own optimizer
+   *                           step, applied in rank order — one legal ps-lite interleaving
+   *   XF_UPDATE_SUM_THEN_STEP the workers' sums added, ONE step with 1 / (all rows): the result
+   *                           of one update() on the concatenation of the ranks' minibatches,
+   *                           whatever the number of GPUs (XF_SCHEDULE_OWNER only: there the
+   *                           sums meet exactly, in fp64) */
+  int32_t update_rule;
 } xf_sharded_config;
+#define XF_UPDATE_RANK_ORDERED 0
+#define XF_UPDATE_SUM_THEN_STEP 1
 void xf_sharded_config_default(xf_sharded_config *cfg);
 typedef struct xf_sharded xf_sharded;
 typedef struct xf_sbatch xf_sbatch;
@@ -462,6 +472,7 @@ int XFStartTrain(void **h);
 int XFDestroy(void **h);
 /* names: model(0 LR,1 FM) epochs block_size_mb core_num k optimizer(ftrl|sgd) capacity
  *        rank pred_path alpha beta lambda1 lambda2 lr seed cache_batches key_build(gpu|host)
+ *        update(rank_ordered|sum_then_step: with schedule=owner)
  *        parity(exact|reference_order: the forward's row sums in the reference's own fp32
  *        order — one worker, checking mode)
  *        model_in model_out (model file to load before / save after training)

@@ -41,7 +41,7 @@ def _big_data(rank, step):
 
 
 def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q,
-          data="small"):
+          data="small", update="rank_ordered"):
     _data = _big_data if data == "big" else globals()["_data"]
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -53,7 +53,7 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
             assert g.transport == (capi.TRANSPORT_RCCL if ndev.value >= world
                                    else capi.TRANSPORT_HOST)
         st = capi.Sharded(g, model=model, optimizer=optimizer, k=4, capacity=64,
-                          schedule=schedule, seed=7)
+                          schedule=schedule, seed=7, update=update)
         alive = []   # freeing a minibatch whose Push is still outstanding would flush it early
         for s in range(steps):
             b = st.compile(*_data(rank, s))
@@ -83,12 +83,12 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
 
 
 def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps=4,
-         data="small"):
+         data="small", update="rank_ordered"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     ps = [ctx.Process(target=_rank, args=(r, world, port, transport, model, optimizer, schedule,
-                                          steps, str(outdir), save, q, data))
+                                          steps, str(outdir), save, q, data, update))
           for r in range(world)]
     for p in ps:
         p.start()
@@ -178,6 +178,52 @@ def test_several_row_windows_per_worker_and_split_chunks(tmp_path, schedule):
             same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)
         for r in range(world):
             ob = O.Batch(*_big_data(r, 99))
+            same(parts[r]["loss"], ob.lr_loss(w.pull(ob.ukeys))[0])
+
+
+@pytest.mark.parametrize("world,optimizer,data", [(2, "ftrl", "small"), (3, "sgd", "small"),
+                                                  (2, "ftrl", "big")])
+def test_sum_then_step_is_one_update_on_the_concatenated_minibatch(tmp_path, world, optimizer,
+                                                                   data):
+    """XF_UPDATE_SUM_THEN_STEP on the owner-compute dataflow: the workers' per-key
+    sums meet at the owner in fp64 and become ONE optimizer step with 1 / (all rows) — the table
+    after every step is what a single LRWorker::update on the ranks' minibatches laid end to end
+    gives, bit for bit, whatever the number of GPUs (and what one GPU gives on that
+    concatenation)."""
+    steps = 3
+    gen = _big_data if data == "big" else _data
+    _run(world, capi.TRANSPORT_HOST, "lr", optimizer, "owner", tmp_path, steps=steps, data=data,
+         update="sum_then_step")
+
+    def concat(step):
+        parts = [gen(r, step) for r in range(world)]
+        rowptr = [np.zeros(1, np.uint64)]
+        for rp, _, _ in parts:
+            rowptr.append(rp[1:] + rowptr[-1][-1])
+        return (np.concatenate(rowptr), np.concatenate([p[1] for p in parts]),
+                np.concatenate([p[2] for p in parts]))
+    oo, go = (O.OPT_FTRL, capi.OPT_FTRL) if optimizer == "ftrl" else (O.OPT_SGD, capi.OPT_SGD)
+    w = O.Store(oo, 1)
+    t = capi.Table(go, 1, capacity=1 << 18)
+    ws = capi.Workspace()
+    with O.sum_mode(1):
+        for s in range(steps):
+            raw = concat(s)
+            O.lr_update(w, O.Batch(*raw))
+            capi.lr_step(t, capi.LocalBatch(t, *raw, retain_keys=False), ws)
+            if s == 1:
+                t.defrag()
+        parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+        ks, wv, ns, zs = w.export()
+        k = np.concatenate([p["w_k"] for p in parts])
+        order = np.argsort(k)
+        same(k[order], ks)
+        for f, ref in (("w_w", wv), ("w_n", ns), ("w_z", zs)):
+            same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)
+        for a, e in zip(t.export(), w.export()):       # ... and the single GPU agrees
+            same(a, e)
+        for r in range(world):
+            ob = O.Batch(*gen(r, 99))
             same(parts[r]["loss"], ob.lr_loss(w.pull(ob.ukeys))[0])
 
 

@@ -39,7 +39,8 @@ class ShardedConfig(C.Structure):
     _fields_ = [("model", C.c_int32), ("optimizer", C.c_int32), ("k", C.c_int32),
                 ("schedule", C.c_int32), ("capacity", C.c_uint64), ("seed", C.c_uint64),
                 ("alpha", C.c_float), ("beta", C.c_float), ("lambda1", C.c_float),
-                ("lambda2", C.c_float), ("lr", C.c_float), ("host_key_build", C.c_int32)]
+                ("lambda2", C.c_float), ("lr", C.c_float), ("host_key_build", C.c_int32),
+                ("update_rule", C.c_int32)]
 
 
 class DevBatch(C.Structure):
@@ -684,7 +685,8 @@ class Sharded:
     class only marshals).  group=None: one rank, the fused single-shard step."""
 
     def __init__(self, group=None, model="lr", optimizer="ftrl", k=10, capacity=1 << 22,
-                 schedule="sequential", seed=0, host_key_build=False, **hyper):
+                 schedule="sequential", seed=0, host_key_build=False, update="rank_ordered",
+                 **hyper):
         require_gpu()
         c = ShardedConfig()
         lib().xf_sharded_config_default(C.byref(c))
@@ -693,6 +695,7 @@ class Sharded:
         c.k, c.capacity, c.seed = k, capacity, seed
         c.schedule = _SCHEDULES[schedule]
         c.host_key_build = 1 if host_key_build else 0
+        c.update_rule = {"rank_ordered": 0, "sum_then_step": 1}[update]
         for name, v in hyper.items():
             setattr(c, name, v)
         self.group = group

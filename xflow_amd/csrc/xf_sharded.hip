@@ -157,6 +157,7 @@ struct xf_sbatch {
   Dev<uint64_t> o_keys;                      // their keys (kept: re-resolved after a defrag)
   Dev<uint32_t> o_rowid;                     // their rows (window-major numbering)
   Dev<uint32_t> d_win, d_rows;               // o_win, o_rows on the device
+  Dev<uint32_t> d_win1, d_rows1;             // {0, windows}, {all rows}: sum_then_step
   Dev<uint32_t> d_wbase, d_wrows;            // per window: first row in the back-to-back
                                              // layout of the workers' rows; rows it holds
   Dev<int32_t> d_labels;                     // this worker's labels
@@ -592,6 +593,11 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   b->o_rpad = std::max<uint32_t>(1, b->o_win[W]) * b->oW;
   XF_TRY(upload_u32(b->d_win, b->o_win, s));
   XF_TRY(upload_u32(b->d_rows, b->o_rows, s));
+  {  // all workers as ONE source (XF_UPDATE_SUM_THEN_STEP)
+    const std::vector<uint32_t> win1{0u, b->o_win[W]}, rows1{rowoff[W]};
+    XF_TRY(upload_u32(b->d_win1, win1, s));
+    XF_TRY(upload_u32(b->d_rows1, rows1, s));
+  }
   {
     std::vector<uint32_t> wbase(std::max<uint32_t>(1, b->o_win[W]), 0), wrows(wbase.size(), 0);
     for (int p = 0; p < W; ++p)
@@ -693,9 +699,14 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   XF_MARK(3);
   // gradient + the workers' Pushes in rank order, one pass over the shard (the losses are read
   // where they arrived: worker after worker)
-  XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, (uint32_t)W,
-                                          b->d_win.p, b->d_rows.p, b->d_wbase.p, b->gsum.p,
-                                          b->gtouched.p, s));
+  if (st->cfg.update_rule == XF_UPDATE_SUM_THEN_STEP)  // one source: every row of the step
+    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, 1u, b->d_win1.p,
+                                            b->d_rows1.p, b->d_wbase.p, b->gsum.p,
+                                            b->gtouched.p, s));
+  else
+    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, (uint32_t)W,
+                                            b->d_win.p, b->d_rows.p, b->d_wbase.p, b->gsum.p,
+                                            b->gtouched.p, s));
   XF_MARK(4);
   XF_MARK(5);
   XF_MARK(6);
@@ -724,6 +735,11 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
   XF_REQUIRE(cfg->schedule == XF_SCHEDULE_SEQUENTIAL || cfg->schedule == XF_SCHEDULE_STALE1 ||
                  cfg->schedule == XF_SCHEDULE_OWNER,
              "xf_sharded_create: schedule %d", cfg->schedule);
+  XF_REQUIRE(cfg->update_rule == XF_UPDATE_RANK_ORDERED ||
+                 (cfg->update_rule == XF_UPDATE_SUM_THEN_STEP &&
+                  cfg->schedule == XF_SCHEDULE_OWNER),
+             "xf_sharded_create: update_rule %d (sum_then_step needs the owner-compute dataflow: "
+             "there the workers' sums meet exactly)", cfg->update_rule);
   XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER || cfg->model == 0,
              "xf_sharded_create: the owner-compute dataflow is for LR");
   xf_sharded *st = new xf_sharded;

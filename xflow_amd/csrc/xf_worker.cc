@@ -95,6 +95,7 @@ int Worker::create_tables() {
   c.lambda2 = lambda2;
   c.lr = learning_rate;
   c.host_key_build = key_build_gpu && parity == XF_PARITY_EXACT_SUMS ? 0 : 1;
+  c.update_rule = update_rule;
   XF_TRY(xf_sharded_create(&sharded_, group_, &c));
   if (parity != XF_PARITY_EXACT_SUMS) XF_TRY(xf_sharded_set_parity(sharded_, parity));
   XF_TRY(xf_sharded_tables(sharded_, &table_w_, &table_v_));
@@ -511,7 +512,12 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "block_cache_dir") block_cache_dir = value;
   else if (n == "model_in") model_in = value;
   else if (n == "model_out") model_out = value;
-  else if (n == "parity") {
+  else if (n == "update") {
+    if (!strcmp(value, "rank_ordered")) update_rule = XF_UPDATE_RANK_ORDERED;
+    else if (!strcmp(value, "sum_then_step")) update_rule = XF_UPDATE_SUM_THEN_STEP;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: update must be rank_ordered or sum_then_step");
+  } else if (n == "parity") {
     if (!strcmp(value, "exact")) parity = XF_PARITY_EXACT_SUMS;
     else if (!strcmp(value, "reference_order")) parity = XF_PARITY_REFERENCE_ORDER;
     else

@@ -49,6 +49,7 @@ class Worker {
   int cache_batches = 1;
   bool key_build_gpu = true;  // key build of update() on the GPU (xf_batch_compile_gpu)
   int parity = 0;             // XF_PARITY_*: the forward's row sums (one worker)
+  int update_rule = 0;        // XF_UPDATE_*: how an owner applies the workers' pushes of a step
   std::string pred_path;
   std::string model_in, model_out;  // load before / save after training (model file)
   // binarized block cache of the text files (xf_reader_open_cached): 0 = off; the cache
