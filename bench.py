@@ -298,6 +298,51 @@ def fm_leg(args, batches):
             "fm_mode": "reference (pooled-over-k sums, no 1/2: fm_worker.cc:178-196)"}
 
 
+def fm_leg_sharded(args, batches, group, world, barrier, allmax):
+    """N > 1: FM k = 16 + SGD on the owner-compute dataflow with XF_UPDATE_SUM_THEN_STEP (the
+    only update rule FM has there): a minibatch's nonzeros live at the key owners, per step the
+    owners send their fp64 shares of the three row sums (24 B per row and owner), get (loss,
+    v_sum) back (8 B), and run ONE gradient pass + optimizer step per key over all ranks' rows.
+    The weight / gradient exchange would move U x (k + 1) x 4 B each way instead.  Not
+    `value`."""
+    import argparse as _ap
+    import torch
+    k, nb = 16, min(4, len(batches))
+    a = _ap.Namespace(model="fm", optimizer="sgd", k=k)
+    cap = int(args.keys_per_gpu / args.load_factor) + 1024
+    tr = NativeSharded(group, a, "owner", cap)
+    comp = [tr.compile(*b) for b in batches[:nb]]
+    for c in comp:
+        tr.predict(c)
+    tr.check()
+    tr.defrag()
+    for i in range(4):
+        tr.step(comp[i % nb])
+    tr.check()
+    steps = 12
+    per = []
+    for rep in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(comp[i % nb])
+        tr.flush()
+        torch.cuda.synchronize()
+        barrier()
+        per.append(allmax(time.perf_counter() - t0) / steps * 1e3)
+    tr.check()
+    R = comp[0].R
+    out = {"workload": "FM(k=16)+SGD, %d keys per GPU, %d rows x %d nnz per minibatch and GPU, "
+                       "uniform (BASELINE configs[4]'s model on this run's shard shape)"
+                       % (args.keys_per_gpu, args.rows, args.nnz_per_row),
+           "dataflow": "owner-compute, update_rule sum_then_step",
+           "value": R * world / (per[0] * 1e-3), "unit": "examples/sec",
+           "ms_per_step": per[0], "ms_per_step_repeats": spread(per), "steps": steps,
+           "fm_mode": "reference (pooled-over-k sums, no 1/2: fm_worker.cc:178-196)"}
+    del comp, tr
+    return out
+
+
 def spread(ms):
     ms = sorted(ms)
     return {"median": ms[len(ms) // 2], "min": ms[0], "max": ms[-1], "n": len(ms)}
@@ -537,12 +582,15 @@ class NativeSharded:
     """The C++ sharded trainer (xf_sharded_* over an xf_group: RCCL all-to-all-v from C++)
     behind the small interface the timing loop uses."""
 
-    def __init__(self, group, args, schedule, capacity):
+    def __init__(self, group, args, schedule, capacity, update=None):
         from xflow_amd import capi
         self.capi = capi
         self.group = group
+        # FM on the owner-compute dataflow exists as sum_then_step only (DESIGN.md 6)
+        self.update = update or ("sum_then_step" if args.model == "fm" and schedule == "owner"
+                                 else "rank_ordered")
         self.st = capi.Sharded(group, model=args.model, optimizer=args.optimizer, k=args.k,
-                               capacity=capacity, schedule=schedule, seed=7)
+                               capacity=capacity, schedule=schedule, seed=7, update=self.update)
         self.schedule = schedule
 
     def compile(self, rowptr, keys, labels):
@@ -997,6 +1045,18 @@ def main():
     if out.get("with_key_build") and "value" in out["with_key_build"]:
         out["value_with_key_build"] = out["with_key_build"]["value"]
         out["ms_per_step_with_key_build"] = out["with_key_build"]["ms_per_step"]
+    if world > 1 and group is not None and args.model == "lr" and not args.no_fm_leg:
+        del compiled, trainer
+        trainer = None
+        err = None
+        try:
+            leg = fm_leg_sharded(args, batches, group, world, barrier, allmax)
+        except Exception as e:   # the LR line must not depend on this extra
+            err, leg = str(e), None
+        # (a failure on any rank is every rank's: they agree before going on)
+        if group.allgather(np.array([0.0 if err is None else 1.0], np.float64)).max() > 0:
+            leg = {"error": err or "another rank failed"}
+        out["fm"] = leg
     if world == 1 and not args.force_sharded and args.model == "lr" and not args.no_fm_leg:
         del compiled, trainer      # (the FM tables want the memory's bandwidth to themselves)
         trainer = None

@@ -108,6 +108,9 @@ def test_bench_runs_two_ranks_and_reports_them(tmp_path):
     assert "owner-compute" in line["config"]["parallelism"]
     ex = line["exchange_dataflow"]
     assert "error" not in ex and ex["value"] > 0
+    # FM over both ranks on the owner-compute dataflow (sum_then_step)
+    fm = line["fm"]
+    assert "error" not in fm and fm["value"] > 0 and "sum_then_step" in fm["dataflow"]
 
 
 def test_one_worker_save_over_a_sharded_checkpoint_is_what_loads(sample_prefixes, tmp_path):

@@ -41,7 +41,7 @@ def _big_data(rank, step):
 
 
 def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdir, save, q,
-          data="small", update="rank_ordered"):
+          data="small", update="rank_ordered", k=4):
     _data = _big_data if data == "big" else globals()["_data"]
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -52,7 +52,7 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
         if transport == capi.TRANSPORT_AUTO:   # RCCL with a GPU per rank, else the fallback
             assert g.transport == (capi.TRANSPORT_RCCL if ndev.value >= world
                                    else capi.TRANSPORT_HOST)
-        st = capi.Sharded(g, model=model, optimizer=optimizer, k=4, capacity=64,
+        st = capi.Sharded(g, model=model, optimizer=optimizer, k=k, capacity=64,
                           schedule=schedule, seed=7, update=update)
         alive = []   # freeing a minibatch whose Push is still outstanding would flush it early
         for s in range(steps):
@@ -83,12 +83,12 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
 
 
 def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps=4,
-         data="small", update="rank_ordered"):
+         data="small", update="rank_ordered", k=4):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
     ps = [ctx.Process(target=_rank, args=(r, world, port, transport, model, optimizer, schedule,
-                                          steps, str(outdir), save, q, data, update))
+                                          steps, str(outdir), save, q, data, update, k))
           for r in range(world)]
     for p in ps:
         p.start()
@@ -225,6 +225,63 @@ def test_sum_then_step_is_one_update_on_the_concatenated_minibatch(tmp_path, wor
         for r in range(world):
             ob = O.Batch(*gen(r, 99))
             same(parts[r]["loss"], ob.lr_loss(w.pull(ob.ukeys))[0])
+
+
+@pytest.mark.parametrize("world,optimizer,k,data", [(2, "ftrl", 4, "small"), (3, "sgd", 10, "small"),
+                                                    (2, "ftrl", 16, "big")])
+def test_fm_on_the_owner_compute_dataflow(tmp_path, world, optimizer, k, data):
+    """FM with XF_UPDATE_SUM_THEN_STEP on the owner-compute dataflow: the owners' shares of the
+    three row sums (wx, v_sum, v_pow_sum) meet at the rows' worker in fp64, (loss, v_sum) go
+    back, every key gets one gradient pass over all workers' rows and one optimizer step on w
+    and on v — what one FMWorker::update on the ranks' minibatches laid end to end gives, bit for
+    bit (oracle, exact sums), and what one GPU gives on that concatenation."""
+    steps = 3
+    gen = _big_data if data == "big" else _data
+    _run(world, capi.TRANSPORT_HOST, "fm", optimizer, "owner", tmp_path, steps=steps, data=data,
+         update="sum_then_step", k=k)
+
+    def concat(step):
+        parts = [gen(r, step) for r in range(world)]
+        rowptr = [np.zeros(1, np.uint64)]
+        for rp, _, _ in parts:
+            rowptr.append(rp[1:] + rowptr[-1][-1])
+        return (np.concatenate(rowptr), np.concatenate([p[1] for p in parts]),
+                np.concatenate([p[2] for p in parts]))
+    ftrl = optimizer == "ftrl"
+    oo, go = (O.OPT_FTRL, capi.OPT_FTRL) if ftrl else (O.OPT_SGD, capi.OPT_SGD)
+    oi, gi = (O.INIT_HASHNORM, capi.INIT_HASHNORM) if ftrl else (O.INIT_CONST, capi.INIT_CONST)
+    sw, sv = O.Store(oo, 1), O.Store(oo, k, oi, 0.001, 7)
+    tw = capi.Table(go, 1, capacity=1 << 18)
+    tv = capi.Table(go, k, gi, 0.001, seed=7, capacity=1 << 18)
+    ws = capi.Workspace()
+    with O.sum_mode(1):
+        for s in range(steps):
+            raw = concat(s)
+            O.fm_update(sw, sv, O.Batch(*raw))
+            capi.fm_step(tw, tv, capi.Batch(*raw), ws)
+            if s == 1:
+                tw.defrag()
+                tv.defrag()
+        parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+        for nm, store, t in (("w", sw, tw), ("v", sv, tv)):
+            ks, wv, ns, zs = store.export()
+            kk = np.concatenate([p[nm + "_k"] for p in parts])
+            order = np.argsort(kk)
+            same(kk[order], ks)
+            for f, ref in (("_w", wv), ("_n", ns), ("_z", zs)):
+                same(np.concatenate([p[nm + f] for p in parts])[order].reshape(ref.shape), ref)
+            for a, e in zip(t.export(), store.export()):   # ... and the single GPU agrees
+                same(a, e)
+        for r in range(world):
+            ob = O.Batch(*gen(r, 99))
+            same(parts[r]["loss"], ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))[0])
+
+
+def test_fm_on_the_owner_compute_dataflow_needs_sum_then_step():
+    g = capi.Group(0, 1, "127.0.0.1", free_port(), capi.TRANSPORT_HOST, device=0)
+    with pytest.raises(capi.XFError, match="sum_then_step"):
+        capi.Sharded(g, model="fm", optimizer="ftrl", k=4, schedule="owner")
+    g.close()
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

@@ -1512,23 +1512,12 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   return XF_OK;
 }
 
-extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
-                          void *stream) {
-  XF_REQUIRE(w && vt && b && ws, "xf_fm_step: null argument");
-  XF_REQUIRE(xf::table_dim(w) == 1, "xf_fm_step: the w table must have dim 1");
-  XF_REQUIRE(!b->local, "xf_fm_step: needs a minibatch with a key list (xf_batch_compile*)");
-  const int k = xf::table_dim(vt);
-  XF_TRY(xf_batch_upload(b, stream));
-  XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
-  ws->rec = ws->profiling && ws->step_no++ % xf_workspace::kProfileEvery == 0;
-  if (ws->rec) XF_TRY(ws_next_set(ws));
+// two Pulls (fm_worker.cc:228,231): each table resolves the key list itself — once per
+// (minibatch, row numbering of the table): rows only move in a defrag, so a replayed
+// minibatch finds its keys' rows where it left them and only gathers w
+static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                           void *stream) {
   const xf_dev_batch &v = b->view;
-  ws->lastU = b->U;
-  ws->lastR = b->R;
-  // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself — once per
-  // (minibatch, row numbering of the table): rows only move in a defrag, so a replayed
-  // minibatch finds its keys' rows where it left them and only gathers w
-  XF_BEGIN();
   xf_table *tabs[2] = {w, vt};
   for (int i = 0; i < 2 && v.U; ++i) {
     const uint64_t uid = xf::table_uid(tabs[i]), ep = xf::table_epoch(tabs[i]);
@@ -1544,6 +1533,24 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
       XF_TRY(xf::gather_f32(xf::table_dev(w).w, b->d_fm_rows[0], v.U, ws->wu, S(stream)));
     }
   }
+  return XF_OK;
+}
+
+extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                          void *stream) {
+  XF_REQUIRE(w && vt && b && ws, "xf_fm_step: null argument");
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_fm_step: the w table must have dim 1");
+  XF_REQUIRE(!b->local, "xf_fm_step: needs a minibatch with a key list (xf_batch_compile*)");
+  const int k = xf::table_dim(vt);
+  XF_TRY(xf_batch_upload(b, stream));
+  XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
+  ws->rec = ws->profiling && ws->step_no++ % xf_workspace::kProfileEvery == 0;
+  if (ws->rec) XF_TRY(ws_next_set(ws));
+  const xf_dev_batch &v = b->view;
+  ws->lastU = b->U;
+  ws->lastR = b->R;
+  XF_BEGIN();
+  XF_TRY(fm_resolve_rows(w, vt, b, ws, stream));
   const uint32_t *rows_w = v.U ? b->d_fm_rows[0] : ws->slots;
   const uint32_t *rows_v = v.U ? b->d_fm_rows[1] : ws->slots2;
   XF_END(kEvResolve);
@@ -1589,6 +1596,124 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   if (ws->rec) ws->sets[ws->cur].pending = true;
   return XF_OK;
 }
+
+// ------------------------------------------------ FM at the owner of a share of the keys
+// Sharded owner-compute dataflow (xf_sharded.hip): `b` holds the nonzeros of EVERY worker's
+// rows whose keys this GPU owns, rows numbered worker after worker.  The forward's three row
+// sums (fm_worker.cc:166-192: wx, v_sum, v_pow_sum) are sums over the row's keys, so every
+// owner forms its share — exactly, in fp64 — and the rows' worker adds the shares before the
+// rounding steps of :194-199.
+__global__ void __launch_bounds__(kBlock)
+k_fm_key_scalars_any(const float *__restrict__ vu, const float *__restrict__ wu, uint32_t U,
+                     int k, FmKey *__restrict__ ks) {
+#pragma clang fp contract(off)
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  double a = 0.0, b = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const float v = vu[(size_t)u * k + j];
+    a += (double)v;
+    b += (double)(v * v);  // fp32 product, as fm_worker.cc:187
+  }
+  FmKey q;
+  q.a = a;
+  q.b = b;
+  q.w = wu[u];
+  q.pad[0] = q.pad[1] = q.pad[2] = 0.f;
+  ks[u] = q;
+}
+
+// one wavefront per row: out[3 r .. 3 r + 2] = this owner's share of (wx, v_sum, v_pow_sum)
+__global__ void __launch_bounds__(kBlock)
+k_fm_row_partials(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ uidx,
+                  const FmKey *__restrict__ ks, uint32_t R, double *__restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (kBlock / 64);
+  for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nwaves) {
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    double wx = 0.0, vs = 0.0, vp = 0.0;
+    for (uint32_t j0 = b + lane; j0 < e; j0 += 64 * 4) {
+      uint32_t ui[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ui[i] = j0 + 64 * i < e ? uidx[j0 + 64 * i] : 0xFFFFFFFFu;
+      FmKey q[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ui[i] != 0xFFFFFFFFu) q[i] = ks[ui[i]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ui[i] != 0xFFFFFFFFu) {
+          wx += (double)q[i].w;
+          vs += q[i].a;
+          vp += q[i].b;
+        }
+    }
+    wx = group_sum<64>(wx);
+    vs = group_sum<64>(vs);
+    vp = group_sum<64>(vp);
+    if (lane == 0) {
+      out[(size_t)r * 3 + 0] = wx;
+      out[(size_t)r * 3 + 1] = vs;
+      out[(size_t)r * 3 + 2] = vp;
+    }
+  }
+}
+
+namespace xf {
+// the owner's Pull (key -> row once per row numbering, rows gathered) and its share of the
+// row sums: d_part[3 * b->R]
+int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, double *d_part,
+                      hipStream_t s) {
+  XF_REQUIRE(w && vt && b && ws && d_part && !b->local, "fm_owner_partials: bad argument");
+  const int k = xf::table_dim(vt);
+  XF_TRY(xf_batch_upload(b, s));
+  XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
+  const xf_dev_batch &v = b->view;
+  if (!v.R) return XF_OK;
+  if (!v.U) {
+    XF_HIP(hipMemsetAsync(d_part, 0, (size_t)v.R * 24, s));
+    return XF_OK;
+  }
+  XF_TRY(fm_resolve_rows(w, vt, b, ws, s));
+  const int dim4 = k / 4;
+  if (fm_records_fit(k)) {
+    const float4 *tv = (const float4 *)xf::table_dev(vt).w;
+    const size_t tot = (size_t)v.U * dim4;
+    const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
+#define XF_FM_GS(D)                                                                         \
+  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, s, tv, b->d_fm_rows[1], ws->wu,     \
+                     (size_t)v.U, (float4 *)ws->vu, (FmKey *)ws->ks)
+    switch (dim4) {
+      case 1: XF_FM_GS(1); break;
+      case 2: XF_FM_GS(2); break;
+      case 4: XF_FM_GS(4); break;
+      case 8: XF_FM_GS(8); break;
+      default: XF_FM_GS(16); break;
+    }
+#undef XF_FM_GS
+  } else {
+    XF_TRY(xf_table_gather_dev(vt, b->d_fm_rows[1], v.U, ws->vu, s));
+    hipLaunchKernelGGL(k_fm_key_scalars_any, dim3((v.U + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       s, ws->vu, ws->wu, v.U, k, (FmKey *)ws->ks);
+  }
+  hipLaunchKernelGGL(k_fm_row_partials, dim3(blocks_for_groups(v.R, kBlock / 64)), dim3(kBlock),
+                     0, s, v.rowptr, v.uidx, (const FmKey *)ws->ks, v.R, d_part);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+
+// gradient (fm_worker.cc:126-157) over all the rows at once and the two Pushes (:241-242), with
+// the rows' (loss, v_sum) as their workers formed them.  Uses the rows pulled by
+// fm_owner_partials of the same step (ws->wu, ws->vu).
+int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                         const float *d_loss, const float *d_vsum, hipStream_t s) {
+  XF_REQUIRE(w && vt && b && ws && d_loss && d_vsum, "fm_owner_grad_update: bad argument");
+  const xf_dev_batch &v = b->view;
+  if (!v.U || !v.R) return XF_OK;
+  return fm_grad_update(w, vt, &v, b->d_fm_rows[0], b->d_fm_rows[1], ws->wu, ws->vu, d_vsum,
+                        d_loss, ws->g, ws->gv, false, s);
+}
+}  // namespace xf
 
 // forward only: calculate_pctr (lr_worker.cc:25-71).  The pull inserts unseen keys, as the
 // reference's test-time Pull does (ftrl.h:56).

@@ -56,6 +56,10 @@ uint64_t table_row_bound(const xf_table *t);
 const float *table_weights(const xf_table *t);
 bool fm_records_fit(int k);
 size_t fm_record_bytes(size_t U);
+int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, double *d_part,
+                      hipStream_t s);
+int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                         const float *d_loss, const float *d_vsum, hipStream_t s);
 int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
                        void *d_ks, float *d_loss, float *d_pctr, float *d_vsum, hipStream_t s);
 int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,
@@ -166,6 +170,10 @@ struct xf_sbatch {
   Dev<double> rs_send, rs_recv, gsum;
   Dev<float> oloss, loss_rep, loss_recv, opctr;
   Dev<uint8_t> gtouched;
+  // FM (sum_then_step): b = the received nonzeros as one minibatch with a key list, rows
+  // numbered worker after worker; (loss, v_sum) pairs of the rows
+  uint32_t o_total = 0;                      // rows of all workers
+  Dev<float> lv, lv_rep, lv_recv, vsum_recv;
 };
 
 struct xf_sharded {
@@ -475,6 +483,54 @@ k_replicate_f32(const float *__restrict__ in, uint32_t n, uint32_t copies,
   if (i < (size_t)n * copies) out[i] = in[i % n];
 }
 
+// rowptr of rows whose nonzeros arrive in ascending row order (empty rows allowed)
+__global__ void __launch_bounds__(kBlock)
+k_rowptr_of_sorted_rows(const uint32_t *__restrict__ rowid, uint32_t n, uint32_t R,
+                        uint32_t *__restrict__ rowptr) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j <= n;
+       j += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t lo = j == 0 ? 0u : rowid[j - 1] + 1;  // rows (prev, cur] begin at j
+    const uint32_t hi = j == n ? R : rowid[j];
+    for (uint32_t r = lo; r <= hi; ++r) rowptr[r] = (uint32_t)j;
+  }
+}
+
+// FM: the worker's side of the forward.  recv[(o * R + r) * 3 ..] = owner o's share of the
+// row's (wx, v_sum, v_pow_sum), fp64: their sums are the row's exact sums; then
+// fm_worker.cc:194-199.  lv[r] = (loss, v_sum) for the owners' gradient.
+__global__ void __launch_bounds__(kBlock)
+k_owner_finalize_fm(const double *__restrict__ recv, uint32_t nown, uint32_t R,
+                    const int32_t *__restrict__ labels, float *__restrict__ loss,
+                    float *__restrict__ pctr, float2 *__restrict__ lv) {
+#pragma clang fp contract(off)
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double wx = 0.0, vs = 0.0, vp = 0.0;
+  for (uint32_t o = 0; o < nown; ++o) {
+    const double *q = recv + ((size_t)o * R + r) * 3;
+    wx += q[0];
+    vs += q[1];
+    vp += q[2];
+  }
+  const float vsf = (float)vs, vpf = (float)vp;
+  const float vy = vsf * vsf - vpf;
+  const float p = xf::sigmoid_ref((float)wx + vy);
+  const float l = p - (float)labels[r];
+  if (pctr) pctr[r] = p;
+  if (loss) loss[r] = l;
+  if (lv) lv[r] = make_float2(l, vsf);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_split_pairs(const float2 *__restrict__ in, uint32_t n, float *__restrict__ a,
+              float *__restrict__ b) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float2 q = in[i];
+  a[i] = q.x;
+  b[i] = q.y;
+}
+
 // (blocking: the small host arrays it is used for are locals of the caller)
 static int upload_u32(Dev<uint32_t> &d, const std::vector<uint32_t> &h, hipStream_t) {
   XF_TRY(d.reserve(h.size()));
@@ -609,7 +665,35 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
     XF_TRY(upload_u32(b->d_wbase, wbase, s));
     XF_TRY(upload_u32(b->d_wrows, wrows, s));
   }
-  if (b->o_n) {
+  b->o_total = rowoff[W];
+  if (st->cfg.model == 1) {
+    // FM: the received nonzeros become one minibatch with a key list (the owner's two tables
+    // resolve it), rows numbered worker after worker — they arrive in that order
+    if (b->o_n) {
+      Dev<uint64_t> d_seg;
+      Dev<uint32_t> d_off, d_rp;
+      Dev<int32_t> d_lab;
+      XF_TRY(d_seg.reserve(W + 1));
+      XF_TRY(d_rp.reserve((size_t)b->o_total + 1));
+      XF_TRY(d_lab.reserve(b->o_total));
+      XF_HIP(hipMemcpy(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice));
+      XF_TRY(upload_u32(d_off, rowoff, s));
+      hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s,
+                         b->o_rowid.p, b->o_n, (uint32_t)W, d_seg.p, d_off.p, 1u);
+      hipLaunchKernelGGL(k_rowptr_of_sorted_rows, dim3(grid_for(b->o_n + 1)), dim3(kBlock), 0, s,
+                         b->o_rowid.p, (uint32_t)b->o_n, b->o_total, d_rp.p);
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipMemsetAsync(d_lab.p, 0, (size_t)b->o_total * 4, s));  // (labels stay with the
+                                                                      // rows' workers)
+      XF_TRY(xf_batch_compile_dev(&b->b, b->o_keys.p, d_rp.p, d_lab.p, b->o_total,
+                                  (uint32_t)b->o_n, s));
+      XF_TRY(wait_stream(st, s));
+      XF_TRY(xf_batch_dims(b->b, nullptr, nullptr, &b->U, nullptr));
+      // first-touch keys are inserted by the step's Pull: room for all of them now
+      XF_TRY(xf::table_ensure_room(st->tw, b->U));
+      XF_TRY(xf::table_ensure_room(st->tv, b->U));
+    }
+  } else if (b->o_n) {
     Dev<uint64_t> d_seg;
     XF_TRY(d_seg.reserve(W + 1));
     XF_HIP(hipMemcpy(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice));
@@ -675,12 +759,15 @@ static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_p
   return XF_OK;
 }
 
+static int step_owner_fm(xf_sharded *st, xf_sbatch *b);
+
 // one LRWorker::update of every rank, owner-compute dataflow
 static int step_owner(xf_sharded *st, xf_sbatch *b) {
   const int W = st->world;
   hipStream_t s = st->main;
   XF_REQUIRE(b->oc, "xf_sharded_step: the minibatch was not compiled for the owner-compute "
              "dataflow");
+  if (st->cfg.model == 1) return step_owner_fm(st, b);
   XF_TRY(begin_profiled_step(st));
   XF_MARK(0);
   XF_TRY(b->oloss.reserve(b->R));
@@ -714,6 +801,62 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   return XF_OK;
 }
 
+// ---- FM on the owner-compute dataflow (sum_then_step): the owners' shares of the three row
+// sums to the rows' workers, (loss, v_sum) back, one gradient + optimizer step per key over all
+// the rows of the step
+static int owner_forward_fm(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_pctr,
+                            float2 *d_lv, hipStream_t s) {
+  const int W = st->world;
+  XF_TRY(b->rs_send.reserve((size_t)b->o_total * 3));
+  XF_TRY(b->rs_recv.reserve((size_t)W * b->R * 3));
+  if (b->b)
+    XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->b, st->ws, b->rs_send.p, s));
+  else if (b->o_total)
+    XF_HIP(hipMemsetAsync(b->rs_send.p, 0, (size_t)b->o_total * 24, s));
+  XF_MARK(1);
+  const std::vector<uint64_t> mine(W, b->R);
+  XF_TRY(a2a(st, b->rs_send.p, b->o_rows64, b->rs_recv.p, mine, 24, s));
+  if (b->R)
+    hipLaunchKernelGGL(k_owner_finalize_fm, dim3(grid_for(b->R)), dim3(kBlock), 0, s,
+                       b->rs_recv.p, (uint32_t)W, b->R, b->d_labels.p, d_loss, d_pctr, d_lv);
+  XF_HIP(hipGetLastError());
+  XF_MARK(2);
+  return XF_OK;
+}
+
+static int step_owner_fm(xf_sharded *st, xf_sbatch *b) {
+  const int W = st->world;
+  hipStream_t s = st->main;
+  XF_TRY(begin_profiled_step(st));
+  XF_MARK(0);
+  XF_TRY(b->oloss.reserve(b->R));
+  XF_TRY(b->lv.reserve((size_t)b->R * 2));
+  XF_TRY(owner_forward_fm(st, b, b->oloss.p, nullptr, (float2 *)b->lv.p, s));
+  XF_TRY(b->lv_rep.reserve((size_t)W * b->R * 2));
+  XF_TRY(b->lv_recv.reserve((size_t)b->o_total * 2));
+  XF_TRY(b->loss_recv.reserve(b->o_total));
+  XF_TRY(b->vsum_recv.reserve(b->o_total));
+  if (b->R)
+    hipLaunchKernelGGL(k_replicate_f32, dim3(grid_for((size_t)W * b->R * 2)), dim3(kBlock), 0, s,
+                       b->lv.p, b->R * 2, (uint32_t)W, b->lv_rep.p);
+  const std::vector<uint64_t> mine(W, b->R);
+  XF_TRY(a2a(st, b->lv_rep.p, mine, b->lv_recv.p, b->o_rows64, 8, s));
+  if (b->o_total)
+    hipLaunchKernelGGL(k_split_pairs, dim3(grid_for(b->o_total)), dim3(kBlock), 0, s,
+                       (const float2 *)b->lv_recv.p, b->o_total, b->loss_recv.p,
+                       b->vsum_recv.p);
+  XF_HIP(hipGetLastError());
+  XF_MARK(3);
+  if (b->b)
+    XF_TRY(xf::fm_owner_grad_update(st->tw, st->tv, b->b, st->ws, b->loss_recv.p,
+                                    b->vsum_recv.p, s));
+  XF_MARK(4);
+  XF_MARK(5);
+  XF_MARK(6);
+  if (st->rec) st->sets[st->cur].pending = true;
+  return XF_OK;
+}
+
 extern "C" void xf_sharded_config_default(xf_sharded_config *c) {
   memset(c, 0, sizeof(*c));
   c->model = 0;
@@ -740,8 +883,11 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
                   cfg->schedule == XF_SCHEDULE_OWNER),
              "xf_sharded_create: update_rule %d (sum_then_step needs the owner-compute dataflow: "
              "there the workers' sums meet exactly)", cfg->update_rule);
-  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER || cfg->model == 0,
-             "xf_sharded_create: the owner-compute dataflow is for LR");
+  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER || cfg->model == 0 ||
+                 cfg->update_rule == XF_UPDATE_SUM_THEN_STEP,
+             "xf_sharded_create: FM on the owner-compute dataflow needs update_rule "
+             "sum_then_step (one gradient pass over all workers' rows; the per-worker Pushes of "
+             "the reference order run on the sequential / stale1 dataflows)");
   xf_sharded *st = new xf_sharded;
   st->g = g;
   st->cfg = *cfg;
@@ -1026,7 +1172,10 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
     XF_REQUIRE(b->oc, "xf_sharded_predict: the minibatch was not compiled for the owner-compute "
                "dataflow");
     XF_TRY(b->opctr.reserve(b->R));
-    XF_TRY(owner_forward(st, b, nullptr, b->opctr.p, st->main));
+    if (st->cfg.model == 1)
+      XF_TRY(owner_forward_fm(st, b, nullptr, b->opctr.p, nullptr, st->main));
+    else
+      XF_TRY(owner_forward(st, b, nullptr, b->opctr.p, st->main));
     XF_TRY(wait_stream(st, st->main));
     if (b->R) XF_HIP(hipMemcpy(pctr_out, b->opctr.p, (size_t)b->R * 4, hipMemcpyDeviceToHost));
     return XF_OK;
