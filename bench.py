@@ -60,7 +60,7 @@ def parse_args():
                     help="extra timed steps that include the GPU key build (0 = skip)")
     ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1", "owner"],
                     help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped).  "
-                         "owner = the owner-compute dataflow (LR, native driver)")
+                         "owner = the owner-compute dataflow (native driver; FM: sum_then_step)")
     ap.add_argument("--no-defrag", action="store_true")
     ap.add_argument("--driver", default="native", choices=["native", "python"],
                     help="N>1: the C++ sharded trainer over xf_group (default) or the Python "
