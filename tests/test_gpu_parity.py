@@ -450,6 +450,68 @@ def test_fm_replayed_minibatches_keep_their_rows_across_growth_and_defrag(opt, k
                 same(a, e)
 
 
+@pytest.mark.parametrize("opt,k", [(capi.OPT_SGD, 4), (capi.OPT_SGD, 16), (capi.OPT_FTRL, 16),
+                                   (capi.OPT_FTRL, 64)])
+def test_fm_table_resident_records_follow_every_writer(opt, k):
+    """k in {4, 8, 16, 32, 64}: the forward's per-key records (sum_k v, sum_k v^2, w) live at the
+    v table's rows and are rewritten by the fused gradient + Push kernel; a replayed minibatch
+    rebuilds them only when it has to.  Everything that can make them stale happens here between
+    the steps of three replayed minibatches with shared (and power-law: heavy) keys: steps of the
+    other minibatches, a Push and an import from outside, a step on the unfused path (capture),
+    a predict that inserts keys, tables re-housed in a larger allocation, a defrag — the tables
+    stay equal to the oracle's (exact sums) bit for bit after every step."""
+    rng = np.random.RandomState(200 + k)
+    init = (capi.INIT_CONST, 0.001) if opt == capi.OPT_SGD else (capi.INIT_HASHNORM, 0.0)
+    tw = capi.Table(opt, 1, capacity=1 << 14)
+    tv = capi.Table(opt, k, init[0], init[1], seed=5, capacity=1 << 14)
+    sw, sv = O.Store(opt, 1), O.Store(opt, k, init[0], init[1], 5)
+    ws, wcap = capi.Workspace(), capi.Workspace(capture=True)
+    data = [synth(rng, 400, 30, 6000, z, True) for z in (None, 1.2, 1.4)]
+    gpu = [capi.Batch(*d) for d in data]
+    cpu = [O.Batch(*d) for d in data]
+    assert gpu[2].H > 0                                  # heavy keys: the wave-per-key path
+    extra = synth(rng, 200, 20, 9000)
+
+    def agree():
+        for tt, st in ((tw, sw), (tv, sv)):
+            tt.check()
+            for a, e in zip(tt.export(), st.export()):
+                same(a, e)
+
+    step = 0
+    for epoch in range(4):
+        for i in (0, 1, 2, 1):
+            with O.sum_mode(1):
+                O.fm_update(sw, sv, cpu[i])
+            capi.fm_step(tw, tv, gpu[i], wcap if step == 6 else ws)
+            step += 1
+            if step in (3, 9):                           # a Push from outside, to both tables
+                ks = cpu[0].ukeys[::7]
+                gw = (rng.randn(len(ks)) * 0.01).astype(np.float32)
+                gv = (rng.randn(len(ks), k) * 0.01).astype(np.float32)
+                tw.push(ks, gw)
+                sw.push(ks, gw)
+                tv.push(ks, gv)
+                sv.push(ks, gv)
+            if step == 5:                                # a predict that inserts unseen keys
+                with O.sum_mode(1):
+                    ob = O.Batch(*extra)
+                    same(capi.fm_predict(tw, tv, capi.Batch(*extra), ws),
+                         ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))[1])
+            agree()
+        if epoch == 0:                                   # re-housed: the state is reallocated
+            tw.reserve(1 << 16)
+            tv.reserve(1 << 16)
+        if epoch == 1:
+            tw.defrag()
+            tv.defrag()
+        if epoch == 2:                                   # weights replaced wholesale
+            kk, w_, n_, z_ = tv.export()
+            w2 = (w_ * np.float32(0.5)).astype(np.float32)
+            tv.import_(kk, w2)
+            sv.import_(kk, w2)
+
+
 def test_predict_matches_oracle_and_inserts_keys():
     rng = np.random.RandomState(9)
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 15)

@@ -148,7 +148,7 @@ def test_fm_full_size_properties(opt, k, zipf):
     o = capi.OPT_SGD if opt == "sgd" else capi.OPT_FTRL
     tw = capi.Table(o, 1, capacity=1 << 24)
     tv = capi.Table(o, k, capi.INIT_CONST, 0.0, capacity=1 << 24)   # v = 0 on first touch
-    ws = capi.Workspace()
+    ws = capi.Workspace(capture=True)      # per-key intermediates wanted: the unfused-records path
     uk = b.host()["ukeys"]
     # (1) linearity: w = 0, v = c everywhere -> v_sum = k*nnz*c, v_pow_sum = k*nnz*c^2 in every
     #     row (exact: c a power of two), p identical in all rows = sigmoid(v_sum^2 - v_pow_sum)
@@ -176,6 +176,22 @@ def test_fm_full_size_properties(opt, k, zipf):
     # (4) idempotent key set; state of the factor table has one row per key too
     capi.fm_step(tw, tv, b, ws)
     assert len(tw) == U and len(tv) == U
+    # (5) the production path (no capture: the forward's per-key records live at the v table's
+    #     rows and are rewritten by the gradient + Push kernel; the first step builds them, the
+    #     second finds them) ends in the same two tables, bit for bit
+    tw2 = capi.Table(o, 1, capacity=1 << 24)
+    tv2 = capi.Table(o, k, capi.INIT_CONST, 0.0, capacity=1 << 24)
+    tw2.import_(uk, np.zeros(U, np.float32))
+    tv2.import_(uk, np.full((U, k), c, np.float32))
+    ws2 = capi.Workspace()
+    b2 = capi.Batch(rowptr, keys, labels)
+    capi.fm_step(tw2, tv2, b2, ws2)
+    capi.fm_step(tw2, tv2, b2, ws2)
+    with pytest.raises(capi.XFError, match="capture"):
+        ws2.fetch(U, R)
+    for t1, t2 in ((tw, tw2), (tv, tv2)):
+        for a, e in zip(t2.export(), t1.export()):
+            same(a, e)
 
 
 @pytest.mark.parametrize("k,zipf", [(16, None), (64, 1.2)])

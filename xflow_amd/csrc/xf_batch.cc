@@ -343,6 +343,7 @@ extern "C" int xf_batch_free(xf_batch *b) {
   if (b->d_uidx_sorted) (void)hipFree(b->d_uidx_sorted);
   for (uint32_t *r : b->d_fm_rows)
     if (r) (void)hipFree(r);
+  if (b->d_fm_ridx) (void)hipFree(b->d_fm_ridx);
   delete b;
   return XF_OK;
 }

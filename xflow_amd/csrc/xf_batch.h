@@ -34,6 +34,13 @@ struct xf_batch {
   // the Pulls of a replayed minibatch resolve nothing
   uint32_t *d_fm_rows[2] = {nullptr, nullptr};
   uint64_t fm_uid[2] = {0, 0}, fm_epoch[2] = {0, 0};
+  // FM with the per-key records kept next to the v table's rows (xf_model.hip): the v row of
+  // every nonzero's key [NNZ] (valid with d_fm_rows[1]); what the records of this minibatch's
+  // keys were last brought up to date against (records allocation, foreign writes to w and v)
+  uint32_t *d_fm_ridx = nullptr;
+  uint64_t fm_ridx_uid = 0, fm_ridx_epoch = ~0ull;
+  uint64_t fm_rec_gen = 0, fm_rec_writes[2] = {~0ull, ~0ull};
+  bool fm_rec_ok = false;
   // "local" batches (xf_batch_compile_local_*): no key list at all — the raw keys were resolved
   // straight to state rows.  The raw arrays are kept (device) when the cells must be
   // rebuildable after the table renumbers its rows.

@@ -540,6 +540,7 @@ k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
 namespace xf {
 
 const TableDev &table_dev(const xf_table *t);
+void table_note_write(xf_table *t);
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
 int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
@@ -814,6 +815,7 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
   XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update: cells are not table rows");
   const TableDev &T = table_dev(t);
   XF_REQUIRE(T.dim == 1, "cells_lr_grad_update: dim must be 1");
+  table_note_write(const_cast<xf_table *>(t));
   for (; c; c = c->next) {
     if (T.nz != nullptr) XF_TRY((launch_grad<XF_OPT_FTRL, 0>(c, T, d_loss, d_g, s)));
     else
@@ -839,6 +841,7 @@ int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const flo
              "cells_lr_grad_update_sources: no scratch for the split chunks");
   const TableDev &T = table_dev(t);
   XF_REQUIRE(T.dim == 1, "cells_lr_grad_update_sources: dim must be 1");
+  table_note_write(const_cast<xf_table *>(t));
   size_t used = 0;  // split chunks of the segments before this one
   for (; c; c = c->next) {
     CellSources src;

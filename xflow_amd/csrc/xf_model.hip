@@ -35,6 +35,9 @@ const TableDev &table_dev(const xf_table *t);
 int table_dim(const xf_table *t);
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
+int table_records(xf_table *t, size_t row_bytes, uint64_t tag, void **rec, uint64_t *gen);
+uint64_t table_writes(const xf_table *t);
+void table_note_write(xf_table *t);
 int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s);
 int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
                          hipStream_t s);
@@ -534,8 +537,9 @@ struct __attribute__((aligned(32))) FmKey {
 template <int DIM4>  // floats per factor row / 4; a power of two <= 16
 __global__ void __launch_bounds__(kBlock)
 k_fm_gather_scalars(const float4 *__restrict__ tv, const uint32_t *__restrict__ rows,
-                    const float *__restrict__ wu, size_t n, float4 *__restrict__ vu,
-                    FmKey *__restrict__ ks) {
+                    const float *__restrict__ wu, const uint32_t *__restrict__ wrows, size_t n,
+                    float4 *__restrict__ vu, FmKey *__restrict__ ks,
+                    const uint32_t *__restrict__ orows) {
 #pragma clang fp contract(off)
   const size_t total = n * DIM4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -564,9 +568,9 @@ k_fm_gather_scalars(const float4 *__restrict__ tv, const uint32_t *__restrict__ 
       FmKey q;
       q.a = a;
       q.b = b;
-      q.w = wu[i];
+      q.w = wu[wrows ? wrows[i] : (uint32_t)i];  // wrows: wu is the w table's weight column
       q.pad[0] = q.pad[1] = q.pad[2] = 0.f;
-      ks[i] = q;
+      ks[orows ? orows[i] : (uint32_t)i] = q;    // orows: the records sit at the keys' v rows
     }
   }
 }
@@ -652,7 +656,13 @@ k_fm_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_
 // runs come out of LDS.  UPDATE: the lane then applies the optimizer step to its coordinate
 // of the key's v row (the pulled value IS the current weight: nothing touched the row since
 // the Pull) and, for factor 0, to the key's w row.
-template <int OPT, bool UPDATE, int K /* compile-time factor count, 0 = use k_rt */>
+// REC (with UPDATE, K % 4 == 0): nothing was pulled into scratch — a lane reads its factors
+// from the v table's rows (and the key's w from the w table), and after the optimizer step the
+// key's lanes leave the forward's record (sum_k v, sum_k v^2, w) of the NEW weights at the
+// key's v row: the factors are in registers here, the next forward of any minibatch finds the
+// records up to date and no pass over the factor rows precedes it.
+template <int OPT, bool UPDATE, int K /* compile-time factor count, 0 = use k_rt */,
+          bool REC = false>
 __global__ void __launch_bounds__(kBlock)
 k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ tile_ptr,
                 uint32_t ntiles, const uint32_t *__restrict__ segptr,
@@ -660,8 +670,9 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
                 const float *__restrict__ vsum, const float *__restrict__ wu,
                 const float *__restrict__ vu, const uint32_t *__restrict__ rows_w,
                 const uint32_t *__restrict__ rows_v, uint32_t R, int k_rt,
-                float *__restrict__ gw, float *__restrict__ gv) {
+                float *__restrict__ gw, float *__restrict__ gv, FmKey *__restrict__ rec) {
 #pragma clang fp contract(off)
+  static_assert(!REC || (UPDATE && K > 0 && K % 4 == 0), "REC needs the fused quad path");
   __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
   __shared__ uint32_t sp[XF_TILE_KEYS + 1];
   const int k = K > 0 ? K : k_rt;  // a constant for the common factor counts: no divisions
@@ -687,6 +698,11 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
       constexpr uint32_t Q = (uint32_t)(K > 0 ? K : 4) / 4u;
       const uint32_t nq = nk * Q;
       constexpr int kUq = OPT == XF_OPT_FTRL ? 4 : 2;  // quads in flight per lane (measured)
+      // REC: the key's w coordinate is the job of ONE of its quad lanes (the second, when there
+      // is one), so that the record leaves as one full 32-byte sector from neighbouring lanes:
+      // (a, b) from the first lane, (w, 0, 0, 0) from the w lane.  (Written as 16 + 4 bytes at
+      // different times the records cost 150 us of the kernel's 480: partial sectors.)
+      constexpr uint32_t kWLane = Q > 1 ? 1u : 0u;
       for (uint32_t e0 = tid; e0 < nq; e0 += kBlock * kUq) {
         uint32_t kq[kUq], qq[kUq];
         float4 v[kUq], nzA[kUq], nzB[kUq];
@@ -700,10 +716,30 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
           qq[i] = on[i] ? el - kq[i] * Q : 0;
         }
 #pragma unroll
-        for (int i = 0; i < kUq; ++i) {
-          v[i] = on[i] ? *reinterpret_cast<const float4 *>(vu + (size_t)(ua + kq[i]) * K + 4 * qq[i])
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < kUq; ++i)
           to[i] = (UPDATE && on[i]) ? (size_t)rows_v[ua + kq[i]] * K + 4 * qq[i] : 0;
+#pragma unroll
+        for (int i = 0; i < kUq; ++i) {
+          const float *src = REC ? TV.w + to[i] : vu + (size_t)(ua + kq[i]) * K + 4 * qq[i];
+          v[i] = on[i] ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        [[maybe_unused]] bool wl[kUq];
+        [[maybe_unused]] uint32_t rw[kUq];
+        [[maybe_unused]] float ww[kUq], wn[kUq], wz[kUq];
+        if constexpr (REC) {
+#pragma unroll
+          for (int i = 0; i < kUq; ++i) {
+            wl[i] = on[i] && qq[i] == kWLane;
+            rw[i] = wl[i] ? rows_w[ua + kq[i]] : 0;
+          }
+#pragma unroll
+          for (int i = 0; i < kUq; ++i) {
+            ww[i] = wn[i] = wz[i] = 0.f;
+            if (wl[i]) {
+              ww[i] = TW.w[rw[i]];
+              if (OPT == XF_OPT_FTRL) xf::load_nz(TW, rw[i], wn[i], wz[i]);
+            }
+          }
         }
         if (UPDATE && OPT == XF_OPT_FTRL) {
 #pragma unroll
@@ -719,8 +755,10 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         for (int i = 0; i < kUq; ++i) {
           if (!on[i]) continue;
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          [[maybe_unused]] double aw = 0.0;
           for (uint32_t j = sp[kq[i]]; j < sp[kq[i] + 1]; ++j) {
             const float l = lv[j], sj = sv[j];
+            if constexpr (REC) aw += (double)l;
             a0 += (double)(l * (sj - v[i].x));
             a1 += (double)(l * (sj - v[i].y));
             a2 += (double)(l * (sj - v[i].z));
@@ -746,6 +784,30 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
               w.w = xf::sgd_step(TV.lr, g.w, w.w);
             }
             *reinterpret_cast<float4 *>(TV.w + to[i]) = w;
+            if constexpr (REC) {  // the same sums, in the same order, as k_fm_gather_scalars
+              double ra = (double)w.x + (double)w.y + (double)w.z + (double)w.w;
+              double rb = (double)(w.x * w.x) + (double)(w.y * w.y) + (double)(w.z * w.z) +
+                          (double)(w.w * w.w);
+#pragma unroll
+              for (int off = (int)Q / 2; off > 0; off >>= 1) {
+                ra += __shfl_xor(ra, off, (int)Q);
+                rb += __shfl_xor(rb, off, (int)Q);
+              }
+              FmKey *rk = &rec[to[i] / K];
+              if (qq[i] == 0) *reinterpret_cast<double2 *>(rk) = make_double2(ra, rb);
+              if (wl[i]) {  // the key's w coordinate (gw = k x the LR gradient, fm_worker.cc:140)
+                const float g1 = div_by_rows((float)(aw * (double)K), R);
+                float w1 = ww[i];
+                if (OPT == XF_OPT_FTRL) {
+                  xf::ftrl_step(TW.alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w1, wn[i], wz[i]);
+                  xf::store_nz(TW, rw[i], wn[i], wz[i]);
+                } else {
+                  w1 = xf::sgd_step(TW.lr, g1, w1);
+                }
+                TW.w[rw[i]] = w1;
+                *reinterpret_cast<float4 *>(&rk->w) = make_float4(w1, 0.f, 0.f, 0.f);
+              }
+            }
           }
         }
       }
@@ -805,6 +867,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
     // the keys' w coordinate (gw = k x the LR gradient, fm_worker.cc:140), one lane per key: as
     // the factor-0 lanes' job inside the loop above it was four memory instructions per item
     // with one lane in k active (94 of 590 us at k = 16)
+    if constexpr (!REC)
     for (uint32_t q = tid; q < nk; q += kBlock) {
       double accw = 0.0;
       for (uint32_t j = sp[q]; j < sp[q + 1]; ++j) accw += (double)lv[j];
@@ -1113,8 +1176,8 @@ int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const fl
   const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
 #define XF_FM_GS(D)                                                                          \
   hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, s, (const float4 *)d_vu,             \
-                     (const uint32_t *)nullptr, d_wu, (size_t)b->U, (float4 *)nullptr,       \
-                     (FmKey *)d_ks)
+                     (const uint32_t *)nullptr, d_wu, (const uint32_t *)nullptr,             \
+                     (size_t)b->U, (float4 *)nullptr, (FmKey *)d_ks, (const uint32_t *)nullptr)
   if (b->U) {
     switch (dim4) {
       case 1: XF_FM_GS(1); break;
@@ -1145,7 +1208,7 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
                      dim3(kBlock), 0, S(stream), xf::TableDev{}, xf::TableDev{}, b->tile_ptr, \
                      b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, (const float *)nullptr, \
                      d_vu, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b->R, k, d_gw, \
-                     d_gv)
+                     d_gv, (FmKey *)nullptr)
     switch (k) {
       case 8: XF_FM_GRAD(8); break;
       case 10: XF_FM_GRAD(10); break;
@@ -1183,13 +1246,61 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
 
 // FM gradient fused with the two Pushes, for tables on this GPU (single shard).  rows_w /
 // rows_v as returned by the Pulls of b->ukeys; gw, gv are still written (parity hook).
+// REC mode, heavy keys (their gradient is reduced by kernels of their own that read the pulled
+// rows from scratch): pull just those keys' rows into their places of d_wu / d_vu ...
+__global__ void __launch_bounds__(kBlock)
+k_fm_pull_listed(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ list, uint32_t H,
+                 const uint32_t *__restrict__ rows_w, const uint32_t *__restrict__ rows_v,
+                 float *__restrict__ wu, float *__restrict__ vu) {
+  const int k = TV.dim;
+  const size_t total = (size_t)H * k;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t u = list[e / k], kk = (uint32_t)(e % k);
+    vu[(size_t)u * k + kk] = TV.w[(size_t)rows_v[u] * k + kk];
+    if (kk == 0) wu[u] = TW.w[rows_w[u]];
+  }
+}
+// ... and, after their optimizer steps, bring their records up to date: the sums of
+// k_fm_gather_scalars in its order (four factors in sequence, then the pairwise tree)
+__global__ void __launch_bounds__(kBlock)
+k_fm_records_listed(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ list,
+                    uint32_t H, const uint32_t *__restrict__ rows_w,
+                    const uint32_t *__restrict__ rows_v, FmKey *__restrict__ rec) {
+#pragma clang fp contract(off)
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const uint32_t u = list[h], rv = rows_v[u];
+  const int dim4 = TV.dim / 4;  // a power of two <= 16
+  double a[16], b[16];
+  for (int j = 0; j < dim4; ++j) {
+    const float4 v = *reinterpret_cast<const float4 *>(TV.w + (size_t)rv * TV.dim + 4 * j);
+    a[j] = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    b[j] = (double)(v.x * v.x) + (double)(v.y * v.y) + (double)(v.z * v.z) +
+           (double)(v.w * v.w);
+  }
+  for (int off = dim4 / 2; off > 0; off >>= 1)
+    for (int j = 0; j < off; ++j) {
+      a[j] += a[j + off];
+      b[j] += b[j + off];
+    }
+  FmKey q;
+  q.a = a[0];
+  q.b = b[0];
+  q.w = TW.w[rows_w[u]];
+  q.pad[0] = q.pad[1] = q.pad[2] = 0.f;
+  rec[rv] = q;
+}
+
 // store_gv = false: the per-coordinate gradients of the tiled keys stay in registers (they
 // are consumed by the fused Push); d_gv then only carries the heavy keys' rows between the
 // chunk reduction and their optimizer step.  U x k x 4 bytes less to write per step.
+// rec != null: REC mode of k_fm_grad_tiled (d_wu / d_vu are scratch for the heavy keys only).
 static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
-                          const uint32_t *d_rows_w, const uint32_t *d_rows_v, const float *d_wu,
-                          const float *d_vu, const float *d_vsum, const float *d_loss,
-                          float *d_gw, float *d_gv, bool store_gv, void *stream) {
+                          const uint32_t *d_rows_w, const uint32_t *d_rows_v, float *d_wu,
+                          float *d_vu, const float *d_vsum, const float *d_loss,
+                          float *d_gw, float *d_gv, bool store_gv, void *stream,
+                          FmKey *rec = nullptr) {
   XF_REQUIRE(tw && tv && b && d_rows_w && d_rows_v && d_wu && d_vu && d_vsum && d_loss && d_gw &&
                  d_gv, "xf_fm_grad_update_dev: null argument");
   if (b->U == 0) return XF_OK;
@@ -1199,10 +1310,41 @@ static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
   XF_REQUIRE((TW.nz != nullptr) == ftrl, "xf_fm_grad_update_dev: w and v use different optimizers");
   XF_REQUIRE(b->ntiles && b->tile_ptr, "xf_fm_grad_update_dev: batch has no gradient tiles");
   const dim3 gt(tile_grid(b->ntiles)), blk(kBlock);
+  if (rec) {
+    XF_REQUIRE(!store_gv && (k == 4 || k == 8 || k == 16 || k == 32 || k == 64),
+               "fm_grad_update: per-row records with k = %d", k);
+    if (b->H)
+      hipLaunchKernelGGL(k_fm_pull_listed, dim3(blocks_for_groups(b->H * k, kBlock)), blk, 0,
+                         S(stream), TW, TV, b->heavy, b->H, d_rows_w, d_rows_v, d_wu, d_vu);
+#define XF_FM_GR(OPTV, KK)                                                                     \
+  hipLaunchKernelGGL((k_fm_grad_tiled<OPTV, true, KK, true>), gt, blk, 0, S(stream), TW, TV,    \
+                     b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu, \
+                     d_rows_w, d_rows_v, b->R, k, d_gw, (float *)nullptr, rec)
+#define XF_FM_GR_K(OPTV)                       \
+  switch (k) {                                 \
+    case 4: XF_FM_GR(OPTV, 4); break;          \
+    case 8: XF_FM_GR(OPTV, 8); break;          \
+    case 16: XF_FM_GR(OPTV, 16); break;        \
+    case 32: XF_FM_GR(OPTV, 32); break;        \
+    default: XF_FM_GR(OPTV, 64); break;        \
+  }
+    if (ftrl) {
+      XF_FM_GR_K(XF_OPT_FTRL)
+    } else {
+      XF_FM_GR_K(XF_OPT_SGD)
+    }
+#undef XF_FM_GR_K
+#undef XF_FM_GR
+  } else {
+  // (weights written without the per-row records following them: whoever keeps records of
+  // these tables' rows must rebuild them)
+  xf::table_note_write(tw);
+  xf::table_note_write(tv);
 #define XF_FM_GU(OPTV, KK)                                                                     \
   hipLaunchKernelGGL((k_fm_grad_tiled<OPTV, true, KK>), gt, blk, 0, S(stream), TW, TV,          \
                      b->tile_ptr, b->ntiles, b->segptr, b->coo_row, d_loss, d_vsum, d_wu, d_vu, \
-                     d_rows_w, d_rows_v, b->R, k, d_gw, store_gv ? d_gv : (float *)nullptr)
+                     d_rows_w, d_rows_v, b->R, k, d_gw, store_gv ? d_gv : (float *)nullptr,     \
+                     (FmKey *)nullptr)
 #define XF_FM_GU_K(OPTV)                       \
   switch (k) {                                 \
     case 8: XF_FM_GU(OPTV, 8); break;          \
@@ -1219,6 +1361,7 @@ static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
   }
 #undef XF_FM_GU_K
 #undef XF_FM_GU
+  }
   XF_HIP(hipGetLastError());
   if (b->H) {
     if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {
@@ -1246,6 +1389,9 @@ static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
       hipLaunchKernelGGL(k_update_listed_rows<XF_OPT_SGD>, gk, blk, 0, S(stream), TV, b->heavy,
                          b->H, d_rows_v, d_gv);
     }
+    if (rec)
+      hipLaunchKernelGGL(k_fm_records_listed, gh, blk, 0, S(stream), TW, TV, b->heavy, b->H,
+                         d_rows_w, d_rows_v, rec);
     XF_HIP(hipGetLastError());
   }
   return XF_OK;
@@ -1255,8 +1401,8 @@ extern "C" int xf_fm_grad_update_dev(xf_table *tw, xf_table *tv, const xf_dev_ba
                                      const uint32_t *d_rows_w, const uint32_t *d_rows_v,
                                      const float *d_wu, const float *d_vu, const float *d_vsum,
                                      const float *d_loss, float *d_gw, float *d_gv, void *stream) {
-  return fm_grad_update(tw, tv, b, d_rows_w, d_rows_v, d_wu, d_vu, d_vsum, d_loss, d_gw, d_gv,
-                        true, stream);
+  return fm_grad_update(tw, tv, b, d_rows_w, d_rows_v, const_cast<float *>(d_wu),
+                        const_cast<float *>(d_vu), d_vsum, d_loss, d_gw, d_gv, true, stream);
 }
 
 // ---------------------------------------------------------------------------- workspace
@@ -1267,6 +1413,7 @@ struct xf_workspace {
   float *wu = nullptr, *g = nullptr, *vu = nullptr, *gv = nullptr;
   float *loss = nullptr, *pctr = nullptr, *vsum = nullptr;
   void *ks = nullptr;  // FM: per-key (a, b, w) records, 32 B each
+  void *owner_rec = nullptr;  // fm_owner_partials -> fm_owner_grad_update: the v table's records
   size_t capU = 0, capUK = 0, capR = 0;
   double *partial = nullptr;  // LR forward: partial row sums of the window workgroups
   size_t capPartial = 0;
@@ -1515,8 +1662,10 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
 // two Pulls (fm_worker.cc:228,231): each table resolves the key list itself — once per
 // (minibatch, row numbering of the table): rows only move in a defrag, so a replayed
 // minibatch finds its keys' rows where it left them and only gathers w
+// want_w = false: the caller reads w where it lives (only a first resolve pulls it anyway);
+// *any_fresh: a table resolved the list anew (first use, or its rows were renumbered)
 static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
-                           void *stream) {
+                           void *stream, bool want_w = true, bool *any_fresh = nullptr) {
   const xf_dev_batch &v = b->view;
   xf_table *tabs[2] = {w, vt};
   for (int i = 0; i < 2 && v.U; ++i) {
@@ -1529,10 +1678,85 @@ static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace 
         XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, b->d_fm_rows[1], stream));
       b->fm_uid[i] = uid;
       b->fm_epoch[i] = ep;
-    } else if (i == 0) {
+      if (any_fresh) *any_fresh = true;
+    } else if (i == 0 && want_w) {
       XF_TRY(xf::gather_f32(xf::table_dev(w).w, b->d_fm_rows[0], v.U, ws->wu, S(stream)));
     }
   }
+  return XF_OK;
+}
+
+// ---- the forward's per-key records kept at the v table's rows ("REC mode")
+// The step below used to begin with a pass over the minibatch's factor rows (gather U x k x 4 B,
+// write them to scratch with the 32-byte records: 1.2 GB, ~205 us at k = 16) although the only
+// thing that changes a row between two steps is the gradient + Push kernel — which has the new
+// factors in registers.  So the records live in an array of the v table (one per state row),
+// that kernel rewrites the records of the keys it steps, the forward gathers records by the
+// nonzeros' v rows, and the gradient kernel reads its factors from the table: no scratch copy
+// of the rows, no pass before the forward.  The records of a minibatch's keys are rebuilt from
+// the tables (k_fm_gather_scalars, to the rows) when they cannot be trusted: first use of the
+// minibatch, a renumbering, a reallocation of the table's state, or any weight write by code
+// that does not maintain them (xf_table_update*, import, the unfused paths) since this
+// minibatch last looked.  XF_FM_TABLE_RECORDS=0 turns the mode off (a measuring aid).
+static bool fm_table_records_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("XF_FM_TABLE_RECORDS");
+    return !(e && *e == '0');
+  }();
+  return on;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fm_ridx(const uint32_t *__restrict__ uidx, const uint32_t *__restrict__ rows_v, size_t n,
+          uint32_t *__restrict__ ridx) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (size_t)gridDim.x * blockDim.x)
+    ridx[j] = rows_v[uidx[j]];
+}
+
+// brings the records of b's keys up to date if needed; *rec_out = the v table's records
+static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh, int k,
+                              FmKey **rec_out, void *stream) {
+  const xf_dev_batch &v = b->view;
+  void *recp = nullptr;
+  uint64_t gen = 0;
+  XF_TRY(xf::table_records(vt, sizeof(FmKey), xf::table_uid(w), &recp, &gen));
+  const uint64_t uidv = xf::table_uid(vt), epv = xf::table_epoch(vt);
+  if (!b->d_fm_ridx || b->fm_ridx_uid != uidv || b->fm_ridx_epoch != epv) {
+    if (!b->d_fm_ridx) XF_HIP(hipMalloc((void **)&b->d_fm_ridx, (size_t)v.NNZ * 4));
+    hipLaunchKernelGGL(k_fm_ridx, dim3(blocks_for_groups(v.NNZ, kBlock)), dim3(kBlock), 0,
+                       S(stream), v.uidx, b->d_fm_rows[1], (size_t)v.NNZ, b->d_fm_ridx);
+    XF_HIP(hipGetLastError());
+    b->fm_ridx_uid = uidv;
+    b->fm_ridx_epoch = epv;
+    fresh = true;
+  }
+  const uint64_t w0 = xf::table_writes(w), w1 = xf::table_writes(vt);
+  if (fresh || !b->fm_rec_ok || b->fm_rec_gen != gen || b->fm_rec_writes[0] != w0 ||
+      b->fm_rec_writes[1] != w1) {
+    const int dim4 = k / 4;
+    const float4 *tv = (const float4 *)xf::table_dev(vt).w;
+    const size_t tot = (size_t)v.U * dim4;
+    const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
+#define XF_FM_GS(D)                                                                           \
+  hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, S(stream), tv, b->d_fm_rows[1],       \
+                     xf::table_dev(w).w, b->d_fm_rows[0], (size_t)v.U, (float4 *)nullptr,     \
+                     (FmKey *)recp, b->d_fm_rows[1])
+    switch (dim4) {
+      case 1: XF_FM_GS(1); break;
+      case 2: XF_FM_GS(2); break;
+      case 4: XF_FM_GS(4); break;
+      case 8: XF_FM_GS(8); break;
+      default: XF_FM_GS(16); break;
+    }
+#undef XF_FM_GS
+    XF_HIP(hipGetLastError());
+    b->fm_rec_ok = true;
+    b->fm_rec_gen = gen;
+    b->fm_rec_writes[0] = w0;
+    b->fm_rec_writes[1] = w1;
+  }
+  *rec_out = (FmKey *)recp;
   return XF_OK;
 }
 
@@ -1550,9 +1774,28 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   ws->lastU = b->U;
   ws->lastR = b->R;
   XF_BEGIN();
-  XF_TRY(fm_resolve_rows(w, vt, b, ws, stream));
+  const bool recmode = fm_table_records_enabled() && xf::fm_records_fit(k) && !ws->capture &&
+                       ws->parity == XF_PARITY_EXACT_SUMS && v.U && v.R;
+  bool fresh = false;
+  XF_TRY(fm_resolve_rows(w, vt, b, ws, stream, !recmode, &fresh));
   const uint32_t *rows_w = v.U ? b->d_fm_rows[0] : ws->slots;
   const uint32_t *rows_v = v.U ? b->d_fm_rows[1] : ws->slots2;
+  if (recmode) {
+    ws->lastU = 0;  // no per-key intermediates in scratch (xf_workspace_capture keeps them)
+    FmKey *rec = nullptr;
+    XF_TRY(fm_prepare_records(w, vt, b, fresh, k, &rec, stream));
+    XF_END(kEvResolve);
+    hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), v.rowptr, b->d_fm_ridx, (const FmKey *)rec,
+                       v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
+    XF_HIP(hipGetLastError());
+    XF_END(kEvForward);
+    XF_TRY(fm_grad_update(w, vt, &v, rows_w, rows_v, ws->wu, ws->vu, ws->vsum, ws->loss, ws->g,
+                          ws->gv, false, stream, rec));
+    XF_END(kEvGrad);
+    if (ws->rec) ws->sets[ws->cur].pending = true;
+    return XF_OK;
+  }
   XF_END(kEvResolve);
   const int dim4 = k / 4;
   const bool scalars = k % 4 == 0 && dim4 <= 16 && (dim4 & (dim4 - 1)) == 0 && v.U && v.R;
@@ -1562,7 +1805,8 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
     const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
 #define XF_FM_GS(D)                                                                        \
   hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, S(stream), tv, rows_v, ws->wu, \
-                     (size_t)v.U, (float4 *)ws->vu, (FmKey *)ws->ks)
+                     (const uint32_t *)nullptr, (size_t)v.U, (float4 *)ws->vu,          \
+                     (FmKey *)ws->ks, (const uint32_t *)nullptr)
     switch (dim4) {
       case 1: XF_FM_GS(1); break;
       case 2: XF_FM_GS(2); break;
@@ -1674,7 +1918,21 @@ int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, 
     XF_HIP(hipMemsetAsync(d_part, 0, (size_t)v.R * 24, s));
     return XF_OK;
   }
-  XF_TRY(fm_resolve_rows(w, vt, b, ws, s));
+  const bool recmode = fm_table_records_enabled() && fm_records_fit(k) && !ws->capture &&
+                       ws->parity == XF_PARITY_EXACT_SUMS;
+  bool fresh = false;
+  XF_TRY(fm_resolve_rows(w, vt, b, ws, s, !recmode, &fresh));
+  ws->owner_rec = nullptr;
+  if (recmode) {  // records at the v table's rows, kept up to date by the gradient + Push kernel
+    FmKey *rec = nullptr;
+    XF_TRY(fm_prepare_records(w, vt, b, fresh, k, &rec, s));
+    hipLaunchKernelGGL(k_fm_row_partials, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                       dim3(kBlock), 0, s, v.rowptr, b->d_fm_ridx, (const FmKey *)rec, v.R,
+                       d_part);
+    XF_HIP(hipGetLastError());
+    ws->owner_rec = rec;
+    return XF_OK;
+  }
   const int dim4 = k / 4;
   if (fm_records_fit(k)) {
     const float4 *tv = (const float4 *)xf::table_dev(vt).w;
@@ -1682,7 +1940,8 @@ int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, 
     const dim3 g((unsigned)std::min<size_t>((tot + kBlock - 1) / kBlock, 8192)), blk(kBlock);
 #define XF_FM_GS(D)                                                                         \
   hipLaunchKernelGGL(k_fm_gather_scalars<D>, g, blk, 0, s, tv, b->d_fm_rows[1], ws->wu,     \
-                     (size_t)v.U, (float4 *)ws->vu, (FmKey *)ws->ks)
+                     (const uint32_t *)nullptr, (size_t)v.U, (float4 *)ws->vu,              \
+                     (FmKey *)ws->ks, (const uint32_t *)nullptr)
     switch (dim4) {
       case 1: XF_FM_GS(1); break;
       case 2: XF_FM_GS(2); break;
@@ -1711,7 +1970,7 @@ int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *w
   const xf_dev_batch &v = b->view;
   if (!v.U || !v.R) return XF_OK;
   return fm_grad_update(w, vt, &v, b->d_fm_rows[0], b->d_fm_rows[1], ws->wu, ws->vu, d_vsum,
-                        d_loss, ws->g, ws->gv, false, s);
+                        d_loss, ws->g, ws->gv, false, s, (FmKey *)ws->owner_rec);
 }
 }  // namespace xf
 
@@ -1761,7 +2020,7 @@ extern "C" int xf_workspace_fetch(xf_workspace *ws, float *wu, float *loss, floa
                                   size_t R) {
   XF_REQUIRE(ws, "xf_workspace_fetch: null workspace");
   XF_REQUIRE(R <= ws->lastR && (!(wu || g) || U <= ws->lastU),
-             "xf_workspace_fetch: sizes exceed the last step's (per-key intermediates of an LR "
+             "xf_workspace_fetch: sizes exceed the last step's (per-key intermediates of a "
              "step exist only after xf_workspace_capture(ws, 1))");
   XF_HIP(hipDeviceSynchronize());
   if (wu && U) XF_HIP(hipMemcpy(wu, ws->wu, U * 4, hipMemcpyDeviceToHost));

@@ -778,6 +778,13 @@ struct xf_table {
   // chunk boundaries and their directories), valid for `aux_epoch`; freed with the table
   void *aux = nullptr;
   uint64_t aux_epoch = ~0ull;
+  // a second derived allocation: a fixed-size record per state row, owned by xf_model.hip (the
+  // FM forward's per-key (sum_k v, sum_k v^2, w) next to the factors they come from), and what
+  // its validity hangs on: `rec_gen` counts (re)allocations, `writes` the weight writes by
+  // anything that does not keep the records up to date
+  void *rec = nullptr;
+  size_t rec_rows = 0, rec_row_bytes = 0;
+  uint64_t rec_gen = 0, rec_tag = 0, writes = 0;
 };
 
 static void refresh_hyper(xf_table *t) {
@@ -918,7 +925,7 @@ extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
   void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
                 (void *)t->T.bdir, (void *)t->T.cdir, t->s_keys, t->s_rows, t->s_vals, t->miss,
-                t->miss_n, t->aux};
+                t->miss_n, t->aux, t->rec};
   for (void *p : ps)
     if (p) hipFree(p);
   delete t;
@@ -1189,6 +1196,7 @@ extern "C" int xf_table_update_dev(xf_table *t, const uint32_t *d_rows, size_t n
                                    const float *d_grads, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_rows && d_grads)), "xf_table_update_dev: null argument");
   if (n == 0) return XF_OK;
+  ++t->writes;
   const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
   if (t->cfg.opt_kind == XF_OPT_FTRL)
     hipLaunchKernelGGL(k_update<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_rows, n, d_grads);
@@ -1221,6 +1229,7 @@ extern "C" int xf_table_update_merged_dev(xf_table *t, const uint64_t *d_keys_so
   XF_REQUIRE(t && (n == 0 || (d_keys_sorted && d_order && d_rows && d_grads)),
              "xf_table_update_merged_dev: null argument");
   if (n == 0) return XF_OK;
+  ++t->writes;
   const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
   if (t->cfg.opt_kind == XF_OPT_FTRL)
     hipLaunchKernelGGL(k_update_merged<XF_OPT_FTRL>, g, b, 0, S(stream), t->T, d_keys_sorted,
@@ -1319,6 +1328,7 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
                                const float *n_, const float *z_) {
   XF_REQUIRE(t && (n == 0 || keys), "xf_table_import: null argument");
   if (n == 0) return XF_OK;
+  ++t->writes;
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
   XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
@@ -1461,6 +1471,7 @@ int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,
 int table_update_heads(xf_table *t, const uint32_t *d_hrow, const uint32_t *d_order, size_t n,
                        const float *d_grads, hipStream_t s) {
   if (n == 0) return XF_OK;
+  ++t->writes;
   const dim3 g(grid_for(n * t->T.dim)), b(kBlock);
   if (t->cfg.opt_kind == XF_OPT_FTRL)
     hipLaunchKernelGGL(k_update_heads<XF_OPT_FTRL>, g, b, 0, s, t->T, d_hrow, d_order, n, d_grads);
@@ -1471,4 +1482,29 @@ int table_update_heads(xf_table *t, const uint32_t *d_hrow, const uint32_t *d_or
 }
 uint64_t table_uid(const xf_table *t) { return t->uid; }
 uint64_t table_epoch(const xf_table *t) { return t->epoch; }
+// the per-row records of another module: `row_bytes` per state row, (re)allocated — contents
+// undefined, *gen changed — whenever the state has been reallocated since the last call or the
+// caller's `tag` (what else the records were derived from) is another one
+int table_records(xf_table *t, size_t row_bytes, uint64_t tag, void **rec, uint64_t *gen) {
+  const size_t rows = (size_t)t->T.max_rows + 1;
+  if (t->rec && t->rec_tag != tag) ++t->rec_gen;
+  t->rec_tag = tag;
+  if (!t->rec || t->rec_rows != rows || t->rec_row_bytes != row_bytes) {
+    if (t->rec) {
+      XF_HIP(hipDeviceSynchronize());  // (a step that still reads the old records)
+      XF_HIP(hipFree(t->rec));
+      t->rec = nullptr;
+    }
+    XF_HIP(hipMalloc(&t->rec, rows * row_bytes));
+    t->rec_rows = rows;
+    t->rec_row_bytes = row_bytes;
+    ++t->rec_gen;
+  }
+  *rec = t->rec;
+  *gen = t->rec_gen;
+  return XF_OK;
+}
+// weight writes so far by code that does not maintain the records; table_note_write: one more
+uint64_t table_writes(const xf_table *t) { return t->writes; }
+void table_note_write(xf_table *t) { ++t->writes; }
 }  // namespace xf
