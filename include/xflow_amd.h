@@ -88,6 +88,14 @@ typedef struct xf_table xf_table;
 #define XF_HEAVY_SEG 64
 #define XF_TILE_NNZ 2048
 #define XF_TILE_KEYS 2048
+/* gradient tiles are much smaller than forward tiles: a gradient workgroup goes through
+ * load -> barrier -> sum -> store once per tile and waits on memory in between, so what counts
+ * is how many independent tiles a CU has in flight (FM k = 16, 1e7 occurrences: 482 us with
+ * 2048-occurrence tiles, 402 / 340 / 324 us with 1024 / 512 / 256). */
+#ifndef XF_GRAD_TILE_NNZ /* (overridable at build time: experiments) */
+#define XF_GRAD_TILE_NNZ 256
+#endif
+#define XF_GRAD_TILE_KEYS XF_GRAD_TILE_NNZ
 #define XF_HEAVY_KMAX 64
 typedef struct xf_batch xf_batch; /* host arrays + (after upload) device mirror */
 int xf_batch_compile(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
@@ -172,7 +180,7 @@ typedef struct {
   const uint32_t *fwd_panel_first; /* P+1 */
   uint32_t fwd_grid, pad3_;
   /* gradient tiles: tile t covers keys [tile_ptr[t], tile_ptr[t+1]) whose occurrences
-   * (<= XF_TILE_NNZ of them, <= XF_TILE_KEYS keys) are staged through LDS by one
+   * (<= XF_GRAD_TILE_NNZ of them, <= XF_GRAD_TILE_KEYS keys) are staged through LDS by one
    * workgroup; a heavy key (> XF_HEAVY_SEG occurrences) is a tile of its own, skipped by
    * the tile kernel and handled by the wave-per-key path. */
   uint32_t ntiles, n_heavy_chunks;

@@ -221,7 +221,7 @@ k_lr_grad_heavy(const uint32_t *__restrict__ heavy, uint32_t H,
 // memory, so what matters is how many tiles a CU keeps in flight: __launch_bounds__(256, 5)
 // holds the allocation at 96 VGPRs = 5 workgroups per CU (124 -> 111 us on the config-2
 // shape); 6+ need spills and 512/1024-thread tiles were slower (131 / 152 us).
-constexpr int kKeysPerThread = XF_TILE_KEYS / kBlock;
+constexpr int kKeysPerThread = (XF_GRAD_TILE_KEYS + kBlock - 1) / kBlock;
 
 template <int OPT, bool UPDATE>
 __global__ void __launch_bounds__(kBlock, 5)
@@ -230,8 +230,8 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
                 const float *__restrict__ loss, const uint32_t *__restrict__ slots,
                 const float *__restrict__ wu /* pulled weights == current w, or null */,
                 uint32_t R, float *__restrict__ g_out) {
-  __shared__ float vals[XF_TILE_NNZ];
-  __shared__ uint32_t sp[XF_TILE_KEYS + 1];
+  __shared__ float vals[XF_GRAD_TILE_NNZ];
+  __shared__ uint32_t sp[XF_GRAD_TILE_KEYS + 1];
   const uint32_t tid = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t ua = tile_ptr[tile], ub = tile_ptr[tile + 1];
@@ -242,7 +242,7 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
     // trips, not one per dependent pointer: (1) the tile's bounds above; (2) everything
     // addressed by them — occurrence rows, key offsets, state-row numbers, pulled weights;
     // (3) everything addressed by round 2 — the loss gathers and the {n,z} words.
-    constexpr int kOccPerThread = XF_TILE_NNZ / kBlock;
+    constexpr int kOccPerThread = (XF_GRAD_TILE_NNZ + kBlock - 1) / kBlock;
     uint32_t orow[kOccPerThread];
 #pragma unroll
     for (int q = 0; q < kOccPerThread; ++q) {
@@ -673,8 +673,8 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
                 float *__restrict__ gw, float *__restrict__ gv, FmKey *__restrict__ rec) {
 #pragma clang fp contract(off)
   static_assert(!REC || (UPDATE && K > 0 && K % 4 == 0), "REC needs the fused quad path");
-  __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
-  __shared__ uint32_t sp[XF_TILE_KEYS + 1];
+  __shared__ float lv[XF_GRAD_TILE_NNZ], sv[XF_GRAD_TILE_NNZ];
+  __shared__ uint32_t sp[XF_GRAD_TILE_KEYS + 1];
   const int k = K > 0 ? K : k_rt;  // a constant for the common factor counts: no divisions
   const uint32_t tid = threadIdx.x;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

@@ -18,9 +18,10 @@ namespace xf {
 
 // ---- gradient tiles: runs of consecutive keys -------------------------------------------
 // All keys of a tile start inside one quantum of the occurrence stream and none is heavy, so
-// a tile holds < kGradQuantum + XF_HEAVY_SEG = XF_TILE_NNZ occurrences and <= kGradQuantum
+// a tile holds < kGradQuantum + XF_HEAVY_SEG = XF_GRAD_TILE_NNZ occurrences and <= kGradQuantum
 // keys.  A heavy key (> XF_HEAVY_SEG occurrences) is a tile of its own.
-constexpr uint32_t kGradQuantum = XF_TILE_NNZ - XF_HEAVY_SEG;
+static_assert(XF_GRAD_TILE_NNZ > XF_HEAVY_SEG, "a gradient tile must hold any light key");
+constexpr uint32_t kGradQuantum = XF_GRAD_TILE_NNZ - XF_HEAVY_SEG;
 
 XF_HD inline bool grad_tile_starts_at(const uint32_t *segptr, uint32_t u) {
   if (u == 0) return true;
