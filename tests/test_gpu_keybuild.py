@@ -215,3 +215,28 @@ def test_a_table_beyond_the_full_tile_limit_takes_half_tiles():
             general_path(False)
     same(outs[0][0], outs[1][0])
     same(outs[0][1], outs[1][1])
+
+
+def test_table_growth_is_sized_by_distinct_new_keys():
+    """a minibatch of 10^6 nonzeros over 2 * 10^4 keys meets a table with room for them: the
+    growth decision counts the distinct new keys, not the nonzeros (which would have taken a
+    65 536-position table to 4 M positions) — untiered (first minibatch) and against a settled
+    tier alike; a table that really is too small still grows"""
+    rng = np.random.RandomState(5)
+    ws = capi.Workspace()
+    for settled in (False, True):
+        t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 16)
+        if settled:
+            t.pull(capi.hash_decimal_range(100000, 3000))
+            t.defrag()
+        raw = synth(rng, 20000, 50, 20000)
+        b = capi.LocalBatch(t, *raw)
+        assert t.capacity == 1 << 16, t.capacity
+        capi.lr_step(t, b, ws)
+        t.check()
+        assert len(t) == len(np.unique(raw[1])) + (3000 if settled else 0)
+        raw = synth(rng, 20000, 50, 200000)          # ~2e5 distinct keys: now it must grow
+        b2 = capi.LocalBatch(t, *raw)
+        assert t.capacity > 1 << 16
+        capi.lr_step(t, b2, ws)
+        t.check()

@@ -661,9 +661,17 @@ k_fm_grad(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo_
 // key's lanes leave the forward's record (sum_k v, sum_k v^2, w) of the NEW weights at the
 // key's v row: the factors are in registers here, the next forward of any minibatch finds the
 // records up to date and no pass over the factor rows precedes it.
+// waves per SIMD the register allocation must allow.  SGD: 86 registers unbounded = 5 tiles per
+// CU; 80 = 6 tiles is 8 % faster, 64 = 8 tiles spills and is slower.  FTRL (166 registers: the
+// (n, z) state of four quads in flight) loses more to spills than it gains (k = 64: 0.84 ->
+// 0.93 ms at 4 waves).
+#ifndef XF_FMG_SGD_WAVES
+#define XF_FMG_SGD_WAVES 6
+#define XF_FMG_FTRL_WAVES 1
+#endif
 template <int OPT, bool UPDATE, int K /* compile-time factor count, 0 = use k_rt */,
           bool REC = false>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, OPT == XF_OPT_SGD ? XF_FMG_SGD_WAVES : XF_FMG_FTRL_WAVES)
 k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ tile_ptr,
                 uint32_t ntiles, const uint32_t *__restrict__ segptr,
                 const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
@@ -681,13 +689,6 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
     const uint32_t ua = tile_ptr[tile], ub = tile_ptr[tile + 1], nk = ub - ua;
     const uint32_t j0 = segptr[ua], j1 = segptr[ub];
     if (nk == 1 && j1 - j0 > XF_HEAVY_SEG) continue;  // heavy key: k_fm_grad_heavy
-    for (uint32_t q = tid; q <= nk; q += kBlock) sp[q] = segptr[ua + q] - j0;
-    for (uint32_t j = j0 + tid; j < j1; j += kBlock) {
-      const uint32_t sid = coo_row[j];
-      lv[j - j0] = loss[sid];
-      sv[j - j0] = vsum[sid];
-    }
-    __syncthreads();
     if constexpr (K > 0 && K % 4 == 0) {
       // Factor counts that are a multiple of four: a lane's item is FOUR consecutive factors of
       // a key — one 16-byte load of the factors, two of the (n,z) state, one 16-byte store of
@@ -703,11 +704,16 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
       // (a, b) from the first lane, (w, 0, 0, 0) from the w lane.  (Written as 16 + 4 bytes at
       // different times the records cost 150 us of the kernel's 480: partial sectors.)
       constexpr uint32_t kWLane = Q > 1 ? 1u : 0u;
-      for (uint32_t e0 = tid; e0 < nq; e0 += kBlock * kUq) {
-        uint32_t kq[kUq], qq[kUq];
-        float4 v[kUq], nzA[kUq], nzB[kUq];
-        size_t to[kUq];
-        bool on[kUq];
+      uint32_t kq[kUq], qq[kUq];
+      float4 v[kUq], nzA[kUq], nzB[kUq];
+      size_t to[kUq];
+      bool on[kUq];
+      [[maybe_unused]] bool wl[kUq];
+      [[maybe_unused]] uint32_t rw[kUq];
+      [[maybe_unused]] float ww[kUq], wn[kUq], wz[kUq];
+      // a batch of kUq quads per lane, in two halves: what depends on the tile's bounds only
+      // (which quads, their rows) ...
+      auto batch_rows = [&](uint32_t e0) {
 #pragma unroll
         for (int i = 0; i < kUq; ++i) {
           const uint32_t el = e0 + i * kBlock;
@@ -718,28 +724,20 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
 #pragma unroll
         for (int i = 0; i < kUq; ++i)
           to[i] = (UPDATE && on[i]) ? (size_t)rows_v[ua + kq[i]] * K + 4 * qq[i] : 0;
-#pragma unroll
-        for (int i = 0; i < kUq; ++i) {
-          const float *src = REC ? TV.w + to[i] : vu + (size_t)(ua + kq[i]) * K + 4 * qq[i];
-          v[i] = on[i] ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        [[maybe_unused]] bool wl[kUq];
-        [[maybe_unused]] uint32_t rw[kUq];
-        [[maybe_unused]] float ww[kUq], wn[kUq], wz[kUq];
         if constexpr (REC) {
 #pragma unroll
           for (int i = 0; i < kUq; ++i) {
             wl[i] = on[i] && qq[i] == kWLane;
             rw[i] = wl[i] ? rows_w[ua + kq[i]] : 0;
           }
+        }
+      };
+      // ... and what is addressed by that: the factors, their state, the key's w
+      auto batch_state = [&]() {
 #pragma unroll
-          for (int i = 0; i < kUq; ++i) {
-            ww[i] = wn[i] = wz[i] = 0.f;
-            if (wl[i]) {
-              ww[i] = TW.w[rw[i]];
-              if (OPT == XF_OPT_FTRL) xf::load_nz(TW, rw[i], wn[i], wz[i]);
-            }
-          }
+        for (int i = 0; i < kUq; ++i) {
+          const float *src = REC ? TV.w + to[i] : vu + (size_t)(ua + kq[i]) * K + 4 * qq[i];
+          v[i] = on[i] ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (UPDATE && OPT == XF_OPT_FTRL) {
 #pragma unroll
@@ -751,6 +749,19 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
             }
           }
         }
+        if constexpr (REC) {
+#pragma unroll
+          for (int i = 0; i < kUq; ++i) {
+            ww[i] = wn[i] = wz[i] = 0.f;
+            if (wl[i]) {
+              ww[i] = TW.w[rw[i]];
+              if (OPT == XF_OPT_FTRL) xf::load_nz(TW, rw[i], wn[i], wz[i]);
+            }
+          }
+        }
+      };
+      // the sums out of LDS, the optimizer steps, the stores
+      auto batch_finish = [&]() {
 #pragma unroll
         for (int i = 0; i < kUq; ++i) {
           if (!on[i]) continue;
@@ -810,8 +821,41 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
             }
           }
         }
+      };
+      // The tile is a chain of dependent memory round trips (bounds -> rows / occurrence rows
+      // -> factors / (loss, v_sum) -> stores) and a CU holds only eight tiles: the first
+      // batch's rows and state are requested next to the occurrences, ahead of the barrier, so
+      // that the two chains run side by side instead of one after the other.
+      batch_rows(tid);
+      for (uint32_t q = tid; q <= nk; q += kBlock) sp[q] = segptr[ua + q] - j0;
+      uint32_t sid0 = 0;
+      const bool occ0 = j0 + tid < j1;
+      if (occ0) sid0 = coo_row[j0 + tid];
+      batch_state();
+      if (occ0) {
+        lv[tid] = loss[sid0];
+        sv[tid] = vsum[sid0];
+      }
+      for (uint32_t j = j0 + tid + kBlock; j < j1; j += kBlock) {  // (tiles beyond one pass)
+        const uint32_t sid = coo_row[j];
+        lv[j - j0] = loss[sid];
+        sv[j - j0] = vsum[sid];
+      }
+      __syncthreads();
+      batch_finish();
+      for (uint32_t e0 = tid + kBlock * kUq; e0 < nq; e0 += kBlock * kUq) {
+        batch_rows(e0);
+        batch_state();
+        batch_finish();
       }
     } else {
+    for (uint32_t q = tid; q <= nk; q += kBlock) sp[q] = segptr[ua + q] - j0;
+    for (uint32_t j = j0 + tid; j < j1; j += kBlock) {
+      const uint32_t sid = coo_row[j];
+      lv[j - j0] = loss[sid];
+      sv[j - j0] = vsum[sid];
+    }
+    __syncthreads();
     const uint32_t nel = nk * (uint32_t)k;
     // (key,factor) items in flight per lane.  Everything an item reads from HBM — its factor,
     // its state row, the w row of the factor-0 lanes — is requested before the first

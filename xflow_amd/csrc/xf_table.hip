@@ -37,6 +37,7 @@
 
 #include "xf_common.h"
 #include "xf_device.h"
+#include "xf_scratch.h"
 
 namespace {
 
@@ -1347,6 +1348,52 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
   return xf_table_check(t, nullptr);
 }
 
+// keys[i] (or keys[list[i]]) for i < n into out
+__global__ void __launch_bounds__(kBlock)
+k_take_keys(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ list, size_t n,
+            uint64_t *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = keys[list ? list[i] : i];
+}
+// number of positions of a sorted list that start a run
+__global__ void __launch_bounds__(kBlock)
+k_count_heads(const uint64_t *__restrict__ sorted, size_t n, unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    c += (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// distinct keys among keys[list[0..n)) (list == null: keys[0..n)): one radix sort.  Only run
+// when a table is about to be grown on the strength of a count that includes duplicates.
+static int count_distinct(const uint64_t *d_keys, const uint32_t *d_list, size_t n,
+                          hipStream_t s, size_t *out) {
+  xf::Scratch sc;
+  uint64_t *a = nullptr, *b = nullptr;
+  unsigned long long *d_c = nullptr;
+  XF_TRY(sc.get(&a, n));
+  XF_TRY(sc.get(&b, n));
+  XF_TRY(sc.get(&d_c, 1));
+  hipLaunchKernelGGL(k_take_keys, dim3(grid_for(n)), dim3(kBlock), 0, s, d_keys, d_list, n, a);
+  size_t tb = 0;
+  XF_HIP(rocprim::radix_sort_keys(nullptr, tb, a, b, n, 0, 64, s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::radix_sort_keys(tmp, tb, a, b, n, 0, 64, s));
+  XF_HIP(hipMemsetAsync(d_c, 0, 8, s));
+  hipLaunchKernelGGL(k_count_heads, dim3(std::min(grid_for(n), 1024)), dim3(kBlock), 0, s, b, n,
+                     d_c);
+  XF_HIP(hipGetLastError());
+  unsigned long long c = 0;
+  XF_HIP(hipMemcpyAsync(&c, d_c, 8, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipStreamSynchronize(s));
+  *out = (size_t)c;
+  return XF_OK;
+}
+
 // key -> row for ANY device key list (duplicates allowed, any order), inserting the missing
 // keys; with allow_grow the table is first grown (xf_table_reserve) when the keys that may be
 // new would push the load past 0.6.  The raw keys of a minibatch are resolved with this
@@ -1392,9 +1439,19 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
     XF_TRY(read_stat(t, &st));
     const uint64_t cap = t->T.cap;
     if ((st.count + maybe_new) * 10 > cap * 6) {
-      uint64_t want = cap * 2;
-      while ((st.count + maybe_new) * 10 > want * 6) want *= 2;
-      XF_TRY(xf_table_reserve(t, want));
+      // `maybe_new` counts nonzeros, duplicates included (a 1e7-nonzero minibatch over 1e6
+      // keys would grow a 4M table to 32M positions): before growing, count the distinct ones
+      size_t distinct = maybe_new;
+      if (tiered) {
+        XF_TRY(count_distinct(d_keys, t->miss, maybe_new, s, &distinct));
+      } else {
+        XF_TRY(count_distinct(d_keys, nullptr, n, s, &distinct));
+      }
+      if ((st.count + distinct) * 10 > cap * 6) {
+        uint64_t want = cap * 2;
+        while ((st.count + distinct) * 10 > want * 6) want *= 2;
+        XF_TRY(xf_table_reserve(t, want));
+      }
     }
   }
   hipLaunchKernelGGL(k_resolve<false>, dim3(std::min(grid_for(maybe_new), 4096)), dim3(kBlock), 0,
