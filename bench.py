@@ -257,7 +257,11 @@ def with_key_build_sharded(args, trainer, batches, R, world, barrier, allmax):
 def fm_leg(args, batches):
     """BASELINE configs[3] next to the LR line (same row shape, same keys): FM k = 16 + SGD on
     one GPU, compiled minibatches replayed from HBM like `value`.  Reference form of FM (pooled
-    second-order sums, fm_worker.cc:126-202).  Not `value`."""
+    second-order sums, fm_worker.cc:126-202).  Not `value`.  The forward's per-key records live
+    at the factor table's rows and are kept up to date by the gradient + Push kernel (DESIGN.md
+    3): a replayed minibatch's step has no pass over its factor rows before the forward;
+    `ms_first_step_of_a_minibatch` is what a minibatch's FIRST step costs (both tables resolve
+    its key list, its records are rebuilt from the tables)."""
     import torch
     from xflow_amd.single import SingleGpuTrainer
     k, nb = 16, min(4, len(batches))
@@ -284,6 +288,16 @@ def fm_leg(args, batches):
     ms, n = tr.profile_read()
     tr.profile(False)
     tr.check()
+    first = []
+    for b in batches[:nb]:               # fresh compiles of the same minibatches: first steps
+        c = tr.compile(*b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.step(c)
+        torch.cuda.synchronize()
+        first.append((time.perf_counter() - t0) * 1e3)
+        del c
+    tr.check()
     R, NNZ = comp[0].R, int(np.mean([c.NNZ for c in comp]))
     U = int(np.mean([c.U for c in comp]))
     _, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
@@ -291,6 +305,7 @@ def fm_leg(args, batches):
                         "(BASELINE configs[3])" % (args.keys_per_gpu, args.rows, args.nnz_per_row),
             "value": R / (per[0] * 1e-3), "unit": "examples/sec", "ms_per_step": per[0],
             "ms_per_step_repeats": spread(per), "steps": steps,
+            "ms_first_step_of_a_minibatch": float(np.median(first)),
             "kernels_ms": {kk: v / max(n, 1) for kk, v in ms.items()},
             "step_bytes_survey_8d": survey,
             "step_gbs_survey_8d": survey / (per[0] * 1e-3) / 1e9,
@@ -310,15 +325,21 @@ def fm_leg_sharded(args, batches, group, world, barrier, allmax):
     k, nb = 16, min(4, len(batches))
     a = _ap.Namespace(model="fm", optimizer="sgd", k=k)
     cap = int(args.keys_per_gpu / args.load_factor) + 1024
+    dbg = (lambda m: print("fm_leg_sharded[%d]: %s" % (group.rank, m), file=sys.stderr,
+                            flush=True)) if os.environ.get("XF_BENCH_DEBUG") else (lambda m: None)
     tr = NativeSharded(group, a, "owner", cap)
+    dbg("created")
     comp = [tr.compile(*b) for b in batches[:nb]]
+    dbg("compiled")
     for c in comp:
         tr.predict(c)
+    dbg("predicted")
     tr.check()
     tr.defrag()
     for i in range(4):
         tr.step(comp[i % nb])
     tr.check()
+    dbg("warmed up")
     steps = 12
     per = []
     for rep in range(3):
@@ -936,6 +957,16 @@ def main():
         own = group.allgather(np.array([np.mean([o for o in owned])], np.float64)).ravel()
         imbalance = {"owned_keys_per_step_by_rank": [float(x) for x in own],
                      "max_over_mean": float(own.max() / own.mean()) if own.mean() > 0 else None}
+    fm_sharded = None
+    if world > 1 and group is not None and args.model == "lr" and not args.no_fm_leg:
+        err = None   # (collective: every rank, before the ranks other than 0 leave)
+        try:
+            fm_sharded = fm_leg_sharded(args, batches, group, world, barrier, allmax)
+        except Exception as e:   # the LR line must not depend on this extra
+            err = str(e)
+        # (a failure on any rank is every rank's: they agree before going on)
+        if group.allgather(np.array([0.0 if err is None else 1.0], np.float64)).max() > 0:
+            fm_sharded = {"error": err or "another rank failed"}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -1045,18 +1076,8 @@ def main():
     if out.get("with_key_build") and "value" in out["with_key_build"]:
         out["value_with_key_build"] = out["with_key_build"]["value"]
         out["ms_per_step_with_key_build"] = out["with_key_build"]["ms_per_step"]
-    if world > 1 and group is not None and args.model == "lr" and not args.no_fm_leg:
-        del compiled, trainer
-        trainer = None
-        err = None
-        try:
-            leg = fm_leg_sharded(args, batches, group, world, barrier, allmax)
-        except Exception as e:   # the LR line must not depend on this extra
-            err, leg = str(e), None
-        # (a failure on any rank is every rank's: they agree before going on)
-        if group.allgather(np.array([0.0 if err is None else 1.0], np.float64)).max() > 0:
-            leg = {"error": err or "another rank failed"}
-        out["fm"] = leg
+    if fm_sharded is not None:
+        out["fm"] = fm_sharded
     if world == 1 and not args.force_sharded and args.model == "lr" and not args.no_fm_leg:
         del compiled, trainer      # (the FM tables want the memory's bandwidth to themselves)
         trainer = None

@@ -56,7 +56,7 @@ def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, t
                           "0", "3", "transport=host", "capacity=256", "schedule=" + schedule,
                           "model_out=" + ckpt,
                           "pred_path=" + str(tmp_path / "pred.txt")],
-                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+                         capture_output=True, text=True, timeout=240, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout + out.stderr
     assert sorted(ln for ln in out.stdout.splitlines() if ln.startswith("my rank")) == \
         ["my rank is = 0", "my rank is = 1"]
@@ -93,8 +93,9 @@ def test_bench_runs_two_ranks_and_reports_them(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
                           "--transport", "host", "--rows", "3000", "--nnz-per-row", "50",
                           "--keys-per-gpu", "200000", "--batches", "3", "--steps", "5",
-                          "--warmup", "2"], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, MASTER_PORT=str(free_port())))
+                          "--warmup", "2"], capture_output=True, text=True, timeout=240,
+                         env=dict(os.environ, MASTER_PORT=str(free_port()),
+                                  XF_COLLECTIVE_TIMEOUT_S="60"))
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"

@@ -92,7 +92,7 @@ def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps
           for r in range(world)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=300) for _ in ps]
+    res = [q.get(timeout=180) for _ in ps]
     for p in ps:
         p.join(timeout=60)
     errs = [e for _, e in res if e]
@@ -364,7 +364,7 @@ def test_sharded_checkpoint_reshards_on_load(tmp_path):
     ps = [ctx.Process(target=_load_rank, args=(r, 3, port, str(tmp_path), q)) for r in range(3)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=300) for _ in ps]
+    res = [q.get(timeout=180) for _ in ps]
     for p in ps:
         p.join(timeout=60)
     assert not [e for _, e in res if e], [e for _, e in res if e][0]
@@ -451,7 +451,7 @@ def test_exchange_code_paths_at_world_one_over_rccl_equal_the_fused_step(tmp_pat
     q = ctx.Queue()
     p = ctx.Process(target=_general_path_rank, args=(free_port(), schedule, str(tmp_path), q))
     p.start()
-    err = q.get(timeout=300)
+    err = q.get(timeout=180)
     p.join(timeout=60)
     assert not err, err
     got = np.load(str(tmp_path / ("gp_%s.npz" % schedule)))

@@ -26,6 +26,11 @@ def main():
         out = bench.fm_leg(args, batches)
         out["exp_knob"] = knob
         print(json.dumps(out), flush=True)
+    if args.pmc_calibrate:   # known byte counts for the rocprofv3 --pmc passes
+        import ctypes  # noqa: F401
+        for kind in range(6):
+            capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
+        print(json.dumps({"config": {"workload": out["workload"]}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,9 @@ WIDTH = {
     # lane and writes 12-byte records (priced with the 16-byte calibration); resolve reads
     # 12-byte records and the table's keys 16 bytes per lane and writes 4-byte entries
     "k_kb_hist": (8, 4), "k_kb_scatter": (16, 16), "k_kb_resolve": (16, 4), "k_kb_scan": (4, 4),
+    # FM: factor rows / records move as 16-byte accesses
+    "k_fm_gather_scalars": (16, 16), "k_fm_forward_scalars": (16, 4), "k_fm_grad_tiled": (16, 16),
+    "k_fm_row_partials": (16, 8), "k_fm_ridx": (4, 4),
 }
 
 
