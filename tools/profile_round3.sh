@@ -31,6 +31,29 @@ except Exception as e:
 PY
 done
 rm -rf $OUT/stats $OUT/kbstats
+# FM: the fm leg's kernels (rocprofv3 stats), its HBM traffic (two PMC passes), the FM step through
+# the owner-compute exchange path at world 1, configs[4]'s shard shape
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/fmstats -- \
+    python $R/tools/fm_leg.py --batches 4 > $R/$OUT/fm_leg.json 2> $R/$OUT/fm_leg.err
+cd $R
+cp $(find $OUT/fmstats -name "*kernel_stats.csv" | head -1) $OUT/fm_kernel_stats.csv
+rm -rf $OUT/fmstats
+FMLEG=1 bash tools/pmc_fm_traffic.sh $OUT/pmc_fm 2>&1 | tail -6
+cp $OUT/pmc_fm/pmc_traffic.json $OUT/pmc_traffic_fm16_sgd.json
+rm -rf $OUT/pmc_fm
+python bench.py --force-sharded --general-path --model fm --k 16 --optimizer sgd --schedule owner --batches 4 --no-cpu-baseline --repeats 3 > $OUT/bench_fm16_sgd_owner_exchange_path.json 2> $OUT/fmo.err
+python bench.py --model fm --k 64 --optimizer ftrl --zipf 1.1 --keys-per-gpu 125000000 --capacity 64000000 --no-cpu-baseline --repeats 3 > $OUT/bench_cfg4_shard_shape_fm64_ftrl_zipf11_125Mkeys.json 2> $OUT/cfg4.err
+for f in bench_fm16_sgd_owner_exchange_path bench_cfg4_shard_shape_fm64_ftrl_zipf11_125Mkeys; do
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1])
+    print("$f", "%.4g ex/s" % d["value"], "%.4f ms" % d["ms_per_step"], {k: round(v*1e3,1) for k,v in d["kernels_ms"].items() if v}, d["config"].get("table_keys_touched"))
+except Exception as e:
+    print("$f", "FAILED", e)
+PY
+done
 # the step's PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, in-run stream calibration)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
