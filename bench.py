@@ -202,22 +202,37 @@ def with_key_build(args, trainer, batches):
                     torch.from_numpy(rowptr.astype(np.uint32).view(np.int32)).cuda(),
                     torch.from_numpy(labels).cuda(), len(labels), len(keys)))
 
+    prev = [None]
+
     def one(i):
+        # one stream, in order: the key build of minibatch i queues behind the step of
+        # minibatch i-1 (the host does not wait for a step before it starts on the next
+        # minibatch; the build's own synchronisation — it needs the item counts — is the only
+        # one), and minibatch i-1 is freed once that has returned
         k, rp, lb, R, NNZ = raw[i % len(raw)]
         h = capi.vp()
         capi.check(L.xf_batch_compile_local_dev(C.byref(h), trainer.w.h, k.data_ptr(),
                                                 rp.data_ptr(), lb.data_ptr(), R, NNZ, 0, None))
+        if prev[0] is not None:
+            L.xf_batch_free(prev[0])
         capi.check(L.xf_lr_step(trainer.w.h, h, trainer.ws.h, None))
+        prev[0] = h
+
+    def drain():
         capi.stream_sync()
-        L.xf_batch_free(h)
+        if prev[0] is not None:
+            L.xf_batch_free(prev[0])
+            prev[0] = None
     for i in range(3):
         one(i)
+    drain()
     torch.cuda.synchronize()
     per = []
     for rep in range(max(1, args.repeats // 2)):
         t0 = time.perf_counter()
         for i in range(args.key_build_steps):
             one(i)
+        drain()
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / args.key_build_steps)
     dt = per[0]
