@@ -980,15 +980,21 @@ def main():
         except Exception as e:   # the LR line must not depend on this extra
             err = str(e)
         # (a failure on any rank is every rank's: they agree before going on)
-        if group.allgather(np.array([0.0 if err is None else 1.0], np.float64)).max() > 0:
-            fm_sharded = {"error": err or "another rank failed"}
+        try:
+            if group.allgather(np.array([0.0 if err is None else 1.0], np.float64)).max() > 0:
+                fm_sharded = {"error": err or "another rank failed"}
+        except Exception as e:   # a rank is gone: the LR line is still this run's result
+            fm_sharded = {"error": "%s; then: %s" % (err, e)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         if group is not None:
-            group.barrier()
-            del trainer
-            group.close()
+            try:
+                group.barrier()
+                del trainer
+                group.close()
+            except Exception as e:
+                print("bench.py: rank %d teardown: %s" % (rank, e), file=sys.stderr)
         return
     avg_ms = {k: v / max(ksteps, 1) for k, v in kern_ms.items()}
     touched = None   # keys the table holds after the run (state is allocated on first touch)
@@ -1119,9 +1125,12 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if group is not None:
-        group.barrier()
-        del trainer
-        group.close()
+        try:
+            group.barrier()
+            del trainer
+            group.close()
+        except Exception as e:   # (a rank that failed in an extra leg: the line still goes out)
+            print("bench.py: teardown: %s" % e, file=sys.stderr)
     if sharded:
         import ctypes
         ctypes.CDLL(None).fflush(None)
