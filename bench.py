@@ -316,7 +316,25 @@ def fm_leg(args, batches):
     R, NNZ = comp[0].R, int(np.mean([c.NNZ for c in comp]))
     U = int(np.mean([c.U for c in comp]))
     _, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
-    return {"workload": "FM(k=16)+SGD, %d keys, %d rows x %d nnz per minibatch, uniform "
+    pmc = None   # the step's HBM traffic as the PMC passes of an earlier run measured it
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic_fm16_sgd.json")))
+        by = sum(e["traffic"] for kk, e in prof["kernels"].items()
+                 if kk.startswith(("k_fm_forward_scalars", "k_fm_grad_tiled")))
+        same = (args.rows, args.nnz_per_row, args.keys_per_gpu) == (50000, 200, 10_000_000) \
+            and not args.zipf
+        if by > 0 and same:
+            pmc = {"bytes_per_step": by, "gbs": by / (per[0] * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": by / (per[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "over_survey_8d": by / survey,
+                   "source": "committed profile profiles/r03/pmc_traffic_fm16_sgd.json (rocprofv3 "
+                             "--pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                             "leg: forward + gradient & Pushes kernels), NOT measured by this run; "
+                             "the time is this run's"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"step_traffic_pmc": pmc,
+            "workload": "FM(k=16)+SGD, %d keys, %d rows x %d nnz per minibatch, uniform "
                         "(BASELINE configs[3])" % (args.keys_per_gpu, args.rows, args.nnz_per_row),
             "value": R / (per[0] * 1e-3), "unit": "examples/sec", "ms_per_step": per[0],
             "ms_per_step_repeats": spread(per), "steps": steps,
