@@ -318,6 +318,24 @@ __device__ __forceinline__ uint32_t heavy_of_chunk(const uint32_t *__restrict__ 
   return lo;
 }
 
+// the same by a whole wavefront: 64 probes per round (three dependent loads for any H up to
+// 2^18 instead of log2 H; every lane returns the answer)
+__device__ __forceinline__ uint32_t heavy_of_chunk_wave(const uint32_t *__restrict__ hch,
+                                                        uint32_t H, uint32_t c) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t lo = 0, hi = H;
+  while (hi - lo > 1) {
+    const uint32_t step = (hi - lo + 63u) / 64u;
+    const uint32_t idx = lo + lane * step;
+    const bool ok = idx < hi && hch[idx] <= c;  // a prefix of the lanes (hch ascends; lane 0)
+    const unsigned long long m = __ballot(ok);
+    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m | 1ull);
+    lo += top * step;
+    hi = min(hi, lo + step);
+  }
+  return lo;
+}
+
 __device__ __forceinline__ double block_sum(double v, double *red) {
   v = group_sum<64>(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -378,35 +396,72 @@ k_lr_heavy_finish(xf::TableDev T, const uint32_t *__restrict__ heavy,
 }
 
 // FM: per chunk and factor kk the sum of loss*(v_sum - v[u,kk]) (fp32 products, fm_worker.cc:141),
-// plus the plain loss sum in slot k.  partial is [chunk][k+1].
+// plus the plain loss sum in column k.  partial is [chunk][k+1].  A thread is (slice of the
+// chunk's occurrences, column): its column's factor in a register, the occurrences read from
+// LDS as broadcasts, one LDS round to add the slices.  (One wavefront per column with a
+// butterfly per column cost ~50 instructions per (chunk, column) whatever the chunk's length —
+// and most heavy keys of a power-law minibatch have 65..300 occurrences: 217 us at k = 64.)
+// A key of ONE chunk is finished here (gw, gv: what k_fm_heavy_finish would write).
 __global__ void __launch_bounds__(kBlock)
 k_fm_heavy_partial(const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ hch,
                    uint32_t H, const uint32_t *__restrict__ segptr,
                    const uint32_t *__restrict__ coo_row, const float *__restrict__ loss,
                    const float *__restrict__ vsum, const float *__restrict__ vu, int k,
-                   double *__restrict__ partial) {
+                   double *__restrict__ partial, uint32_t R, float *__restrict__ gw,
+                   float *__restrict__ gv) {
 #pragma clang fp contract(off)
   __shared__ float lv[XF_TILE_NNZ], sv[XF_TILE_NNZ];
+  __shared__ double red[kBlock];
   const uint32_t c = blockIdx.x;
-  const uint32_t h = heavy_of_chunk(hch, H, c);
+  const uint32_t h = heavy_of_chunk_wave(hch, H, c);
   const uint32_t u = heavy[h];
   const uint32_t b = segptr[u] + (c - hch[h]) * XF_TILE_NNZ;
   const uint32_t e = min(segptr[u + 1], b + XF_TILE_NNZ);
   const uint32_t n = e - b;
+  const uint32_t ncol = (uint32_t)k + 1u, nsl = kBlock / ncol;  // k <= XF_HEAVY_KMAX: nsl >= 3
+  const uint32_t col = threadIdx.x % ncol, sl = threadIdx.x / ncol;
+  const bool fac = col < (uint32_t)k;
+  const float v = (sl < nsl && fac) ? vu[(size_t)u * k + col] : 0.0f;
   for (uint32_t j = threadIdx.x; j < n; j += kBlock) {
     const uint32_t sid = coo_row[b + j];
     lv[j] = loss[sid];
     sv[j] = vsum[sid];
   }
   __syncthreads();
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t kk = wave; kk <= (uint32_t)k; kk += kBlock / 64) {  // kk == k: the loss sum
-    const float v = kk < (uint32_t)k ? vu[(size_t)u * k + kk] : 0.0f;
-    double acc = 0.0;
-    for (uint32_t j = lane; j < n; j += 64)
-      acc += kk < (uint32_t)k ? (double)(lv[j] * (sv[j] - v)) : (double)lv[j];
-    acc = group_sum<64>(acc);
-    if (lane == 0) partial[(size_t)c * (k + 1) + kk] = acc;
+  double acc = 0.0;
+  if (sl < nsl) {
+    // four occurrences per round, four independent sums (one dependent chain of LDS reads and
+    // fp64 adds per occurrence was the kernel's time), joined in a fixed order
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    uint32_t j = sl;
+    for (; j + 3 * nsl < n; j += 4 * nsl) {
+      const float l0 = lv[j], l1 = lv[j + nsl], l2 = lv[j + 2 * nsl], l3 = lv[j + 3 * nsl];
+      if (fac) {
+        const float s0 = sv[j], s1 = sv[j + nsl], s2 = sv[j + 2 * nsl], s3 = sv[j + 3 * nsl];
+        a0 += (double)(l0 * (s0 - v));
+        a1 += (double)(l1 * (s1 - v));
+        a2 += (double)(l2 * (s2 - v));
+        a3 += (double)(l3 * (s3 - v));
+      } else {
+        a0 += (double)l0;
+        a1 += (double)l1;
+        a2 += (double)l2;
+        a3 += (double)l3;
+      }
+    }
+    for (; j < n; j += nsl) a0 += fac ? (double)(lv[j] * (sv[j] - v)) : (double)lv[j];
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl != 0) return;
+  for (uint32_t q = 1; q < nsl; ++q) acc += red[q * ncol + col];
+  if (hch[h + 1] - hch[h] == 1) {  // the key's only chunk
+    if (fac) gv[(size_t)u * k + col] = (float)((double)(float)acc / (1.0 * R));
+    else
+      gw[u] = (float)((double)(float)(acc * (double)k) / (1.0 * R));
+  } else {
+    partial[(size_t)c * ncol + col] = acc;
   }
 }
 
@@ -423,9 +478,21 @@ k_fm_heavy_finish(const uint32_t *__restrict__ heavy, const uint32_t *__restrict
   const uint32_t ncol = (uint32_t)k + 1u, nsl = kBlock / ncol;  // k <= XF_HEAVY_KMAX: nsl >= 3
   const uint32_t col = threadIdx.x % ncol, sl = threadIdx.x / ncol;
   const uint32_t c0 = hch[h], c1 = hch[h + 1], u = heavy[h];
+  if (c1 - c0 == 1) return;  // finished by k_fm_heavy_partial (workgroup-uniform)
   double acc = 0.0;
-  if (sl < nsl)
-    for (uint32_t c = c0 + sl; c < c1; c += nsl) acc += partial[(size_t)c * ncol + col];
+  if (sl < nsl) {
+    // (the head key of a power-law minibatch owns hundreds of chunks: eight loads in flight —
+    // one dependent load after the other was 78 us for that one key — added in chunk order)
+    uint32_t c = c0 + sl;
+    for (; c + 7 * nsl < c1; c += 8 * nsl) {
+      double p[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = partial[(size_t)(c + i * nsl) * ncol + col];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += p[i];
+    }
+    for (; c < c1; c += nsl) acc += partial[(size_t)c * ncol + col];
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (sl != 0) return;
@@ -1274,7 +1341,7 @@ extern "C" int xf_fm_grad_dev(const xf_dev_batch *b, int k, const float *d_vu,
     if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
-                         d_vu, k, b->heavy_scratch);
+                         d_vu, k, b->heavy_scratch, b->R, d_gw, d_gv);
       hipLaunchKernelGGL(k_fm_heavy_finish, dim3(b->H), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
@@ -1411,7 +1478,7 @@ static int fm_grad_update(xf_table *tw, xf_table *tv, const xf_dev_batch *b,
     if (b->heavy_chunk_ptr && b->heavy_scratch && k <= XF_HEAVY_KMAX) {
       hipLaunchKernelGGL(k_fm_heavy_partial, dim3(b->n_heavy_chunks), dim3(kBlock), 0, S(stream),
                          b->heavy, b->heavy_chunk_ptr, b->H, b->segptr, b->coo_row, d_loss, d_vsum,
-                         d_vu, k, b->heavy_scratch);
+                         d_vu, k, b->heavy_scratch, b->R, d_gw, d_gv);
       hipLaunchKernelGGL(k_fm_heavy_finish, dim3(b->H), dim3(kBlock), 0,
                          S(stream), b->heavy, b->heavy_chunk_ptr, b->H, b->heavy_scratch, b->R, k,
                          d_gw, d_gv);
