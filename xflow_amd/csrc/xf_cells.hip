@@ -405,11 +405,17 @@ __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on,
 #ifndef XF_GRAD_E
 #define XF_GRAD_E 8
 #endif
+// waves / SIMD the multi-source variant's registers must allow: unbounded the compiler takes
+// 176 (2 waves: 451 us for the pass of an owner of 8 workers), 5 -> 85 registers, 6 -> 80 with
+// 24 bytes of scratch per lane (245 us)
+#ifndef XF_GRAD_MULTI_WAVES
+#define XF_GRAD_MULTI_WAVES 6
+#endif
 constexpr int kGradE = XF_GRAD_E;  // entries per lane and round
 constexpr uint32_t kGradWin = 32;  // windows whose slice bounds fit the LDS table
 
-template <int OPT, int MODE, bool SRC>
-__global__ void __launch_bounds__(kBlock)
+template <int OPT, int MODE, bool SRC, bool MULTI = false /* SRC with more than one source */>
+__global__ void __launch_bounds__(kBlock, MULTI ? XF_GRAD_MULTI_WAVES : 1)
 k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
                 const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
@@ -433,6 +439,106 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
   // step, the workers' steps applied in rank order — one accumulate + update phase
   // per worker inside the same pass over the chunk, the state row read and written by the same
   // thread every phase (it stays in L2 in between).  One source: the whole minibatch.
+  if constexpr (SRC && MULTI && MODE == 0) {
+    // Several sources, an unsplit chunk whose entries fit one round of registers.  Taken source
+    // after source (the general loop below) the pass of an owner of 8 workers took 403 us for
+    // what one source does in 115: per source and chunk a chain of cell bounds -> entries ->
+    // losses, four barriers, and a state row that is loaded right after the previous source's
+    // store to it.  Here the loads of ALL sources' entries and losses go out together, the
+    // state of every key the chunk touches is loaded ONCE into its thread's registers (a
+    // thread owns keys tid, tid + 256, ...), the sources' phases only add in LDS and step
+    // registers, and the state is stored once.  Same sums, same order of the steps.
+    __shared__ uint8_t wsrc[kGradWin];
+    __shared__ uint8_t any[kChunk];
+    if (S == 1 && nwin <= kGradWin && nsrc > 1 && !g_out) {  // workgroup-uniform
+      for (uint32_t k = tid; k < kChunk; k += kBlock) any[k] = 0;
+      __syncthreads();
+      if (tid < nwin) {
+        const size_t cell = (size_t)tid * nchunk + c;
+        const uint32_t b = cellptr[cell], e = cellptr[cell + 1];
+        sbase[tid] = b;
+        cum[tid + 1] = e - b;
+        uint32_t q = 0;
+        while (q + 1 < nsrc && tid >= src_win[q + 1]) ++q;
+        wsrc[tid] = (uint8_t)q;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        cum[0] = 0;
+        for (uint32_t v = 0; v < nwin; ++v) cum[v + 1] += cum[v];
+      }
+      __syncthreads();
+      const uint32_t total = cum[nwin];
+      if (total <= kBlock * kGradE) {  // workgroup-uniform
+        constexpr int kOwn = (int)(kChunk / kBlock);  // keys per thread
+        // per entry: the key's place in the chunk and its source in ONE register, the loss in
+        // another (the pass lives on its occupancy: every register counts)
+        uint32_t ek[kGradE];
+        float l[kGradE];
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < kGradE; ++q) {
+          const uint32_t p = q * kBlock + tid;
+          ek[q] = 0xFFFFFFFFu;
+          l[q] = 0.0f;
+          if (p < total) {
+            while (p >= cum[v + 1]) ++v;  // p ascends with q: v never goes back
+            const uint32_t e = entries[sbase[v] + (p - cum[v])];
+            if (e != 0xFFFFFFFFu) {  // (a hole: the key went to the arrival segment)
+              l[q] = loss[(size_t)loss_base[v] + ((e >> kChunkBits) & kRowMask)];
+              ek[q] = (e & (kChunk - 1)) | ((uint32_t)wsrc[v] << 16);
+              any[e & (kChunk - 1)] = 1;
+            }
+          }
+        }
+        __syncthreads();
+        const size_t idx0 = (size_t)(chunk0 + c) * kChunk + tid;
+        float sw[kOwn], sn[kOwn], sz[kOwn];
+#pragma unroll
+        for (int i = 0; i < kOwn; ++i) {
+          sw[i] = sn[i] = sz[i] = 0.0f;
+          if (any[tid + i * kBlock] && idx0 + i * kBlock < M) {
+            sw[i] = T.w[idx0 + i * kBlock];
+            if (OPT == XF_OPT_FTRL) xf::load_nz(T, idx0 + i * kBlock, sn[i], sz[i]);
+          }
+        }
+        for (uint32_t q = 0; q < nsrc; ++q) {
+          // source q's entries are the positions [pb, pe) of the index space: register slots
+          // pb / kBlock .. (pe - 1) / kBlock of every thread (one or two of the eight)
+          const uint32_t pb = cum[src_win[q]], pe = cum[src_win[q + 1]];
+          if (pb == pe) continue;  // workgroup-uniform: nothing of this worker in the chunk
+          const int ib = (int)(pb / kBlock), ie = (int)((pe - 1) / kBlock);
+#pragma unroll
+          for (int i = 0; i < kGradE; ++i)
+            if (i >= ib && i <= ie)  // workgroup-uniform
+              add_keys(acc, touched, (ek[i] >> 16) == q, ek[i] & (kChunk - 1), l[i]);
+          __syncthreads();
+          const float rq = (float)src_rows[q];
+#pragma unroll
+          for (int i = 0; i < kOwn; ++i) {
+            const uint32_t k = tid + i * kBlock;
+            if (!touched[k]) continue;
+            const double sum = acc[k];
+            acc[k] = 0.0;  // the next worker's phase starts from zero
+            touched[k] = 0;
+            const float g = (float)((double)(float)sum / (1.0 * (double)rq));  // lr_worker.cc:117
+            if (OPT == XF_OPT_FTRL)
+              xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+            else
+              sw[i] = xf::sgd_step(T.lr, g, sw[i]);
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < kOwn; ++i)
+          if (any[tid + i * kBlock] && idx0 + i * kBlock < M) {
+            T.w[idx0 + i * kBlock] = sw[i];
+            if (OPT == XF_OPT_FTRL) xf::store_nz(T, idx0 + i * kBlock, sn[i], sz[i]);
+          }
+        return;
+      }
+    }
+  }
   const uint32_t ns = SRC ? nsrc : 1u;
   for (uint32_t q = 0; q < ns; ++q) {
   const uint32_t wbeg = SRC ? src_win[q] : 0u, wend = SRC ? src_win[q + 1] : nwin;
@@ -778,7 +884,13 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
       XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
     }
   }
-  if (src)
+  if (src && src->n > 1)  // (its own instantiation: 87 registers instead of 58)
+    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true, true>), dim3(c->nitems), dim3(kBlock), 0,
+                       s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                       c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
+                       src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
+                       c->chunk0);
+  else if (src)
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,

@@ -162,6 +162,8 @@ struct xf_sbatch {
   Dev<uint32_t> o_rowid;                     // their rows (window-major numbering)
   Dev<uint32_t> d_win, d_rows;               // o_win, o_rows on the device
   Dev<uint32_t> d_win1, d_rows1;             // {0, windows}, {all rows}: sum_then_step
+  Dev<uint32_t> d_winT, d_rowsT;             // measuring aid (XF_OWNER_TIMING_SOURCES, world 1)
+  uint32_t nT = 0;
   Dev<uint32_t> d_wbase, d_wrows;            // per window: first row in the back-to-back
                                              // layout of the workers' rows; rows it holds
   Dev<int32_t> d_labels;                     // this worker's labels
@@ -654,6 +656,22 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
     XF_TRY(upload_u32(b->d_win1, win1, s));
     XF_TRY(upload_u32(b->d_rows1, rows1, s));
   }
+  if (const char *e = getenv("XF_OWNER_TIMING_SOURCES")) {
+    // MEASURING AID, one rank only: the gradient + Push pass as an owner of n workers runs it —
+    // this rank's windows dealt out to n pretended workers, each its own optimizer step.  The
+    // arithmetic is not that of one LRWorker::update any more: for timing the pass on one GPU.
+    const uint32_t n = (uint32_t)atoi(e), nw = b->o_win[W];
+    if (W == 1 && n > 1 && nw >= n) {
+      std::vector<uint32_t> winT(n + 1), rowsT(n);
+      for (uint32_t q = 0; q <= n; ++q) winT[q] = (uint32_t)((uint64_t)nw * q / n);
+      for (uint32_t q = 0; q < n; ++q)
+        rowsT[q] = std::min<uint32_t>(rowoff[W], winT[q + 1] * b->oW) -
+                   std::min<uint32_t>(rowoff[W], winT[q] * b->oW);
+      XF_TRY(upload_u32(b->d_winT, winT, s));
+      XF_TRY(upload_u32(b->d_rowsT, rowsT, s));
+      b->nT = n;
+    }
+  }
   {
     std::vector<uint32_t> wbase(std::max<uint32_t>(1, b->o_win[W]), 0), wrows(wbase.size(), 0);
     for (int p = 0; p < W; ++p)
@@ -728,7 +746,8 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
   b->ocells->epoch = ep;
   b->oc_uid = uid;
   b->oc_epoch = ep;
-  const size_t sp = (size_t)st->world * xf::cells_split_chunks(b->ocells) * xf::kChunk;
+  const size_t sp = (size_t)std::max<uint32_t>((uint32_t)st->world, b->nT) *
+                    xf::cells_split_chunks(b->ocells) * xf::kChunk;
   XF_TRY(b->gsum.reserve(sp));
   XF_TRY(b->gtouched.reserve(sp));
   return XF_OK;
@@ -786,7 +805,11 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   XF_MARK(3);
   // gradient + the workers' Pushes in rank order, one pass over the shard (the losses are read
   // where they arrived: worker after worker)
-  if (st->cfg.update_rule == XF_UPDATE_SUM_THEN_STEP)  // one source: every row of the step
+  if (b->nT)  // (XF_OWNER_TIMING_SOURCES)
+    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, b->nT,
+                                            b->d_winT.p, b->d_rowsT.p, b->d_wbase.p, b->gsum.p,
+                                            b->gtouched.p, s));
+  else if (st->cfg.update_rule == XF_UPDATE_SUM_THEN_STEP)  // one source: every row of the step
     XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, 1u, b->d_win1.p,
                                             b->d_rows1.p, b->d_wbase.p, b->gsum.p,
                                             b->gtouched.p, s));

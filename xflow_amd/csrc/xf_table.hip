@@ -53,6 +53,18 @@ __global__ void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
   }
   for (; i < n; i += stride) dst[i] = src[i];
 }
+__global__ void k_copy4(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const uint32_t a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
 __global__ void k_copy1(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
                         size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1504,6 +1516,12 @@ int device_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
     const size_t blocks = std::min<size_t>(std::max<size_t>(n / (kBlock * 4), 1), 4096);
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint4 *)src,
                        (uint4 *)dst, n);
+  } else if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 3u) == 0) {
+    // (float / index lists of odd length: one byte per lane moved 25 MB in 53 us)
+    const size_t n = bytes / 4;
+    const size_t blocks = std::min<size_t>(std::max<size_t>(n / (kBlock * 4), 1), 4096);
+    hipLaunchKernelGGL(k_copy4, dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                       (const uint32_t *)src, (uint32_t *)dst, n);
   } else {
     hipLaunchKernelGGL(k_copy1, dim3(grid_for(bytes)), dim3(kBlock), 0, s,
                        (const unsigned char *)src, (unsigned char *)dst, bytes);
