@@ -978,6 +978,40 @@ def main():
             del oc, ot
         except Exception as e:
             owner_leg = {"error": str(e)}
+    # Second supplementary leg (N > 1, owner-compute dataflow): the same K steps with
+    # update_rule = sum_then_step — ONE optimizer step per key over all ranks' rows (one
+    # LRWorker::update on the ranks' minibatches laid end to end) instead of one per rank.  The
+    # owner's gradient + Push pass then is the one-source pass whatever N.  Not `value`.
+    sum_leg = None
+    if group is not None and args.model == "lr" and schedule == "owner" and world > 1 \
+            and not args.no_owner_leg:
+        try:
+            st2 = NativeSharded(group, args, "owner", capacity, update="sum_then_step")
+            sc2 = [st2.compile(*b) for b in batches]
+            for c in sc2:
+                st2.predict(c)
+            st2.check()
+            st2.defrag()
+            for i in range(args.warmup):
+                st2.step(sc2[i % len(sc2)])
+            st2.check()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                st2.step(sc2[(args.warmup + i) % len(sc2)])
+            st2.flush()
+            barrier()
+            sdt = allmax(time.perf_counter() - t0)
+            st2.check()
+            sum_leg = {"value": R * world * args.steps / sdt, "unit": "examples/sec",
+                       "ms_per_step": sdt / args.steps * 1e3, "steps": args.steps,
+                       "what": "XF_SCHEDULE_OWNER with XF_UPDATE_SUM_THEN_STEP: the ranks' per-key "
+                               "sums meet at the owner, one optimizer step per key with 1 / (all "
+                               "rows); `value` above applies every rank's gradient as its own "
+                               "step, in rank order (the reference's ps-lite semantics)"}
+            del sc2, st2
+        except Exception as e:
+            sum_leg = {"error": str(e)}
     wkb_sharded = None
     if group is not None and world > 1 and args.model == "lr" and args.key_build_steps > 0:
         try:   # (collective: every rank; a failure is symmetric)
@@ -1101,6 +1135,7 @@ def main():
             NNZ * (12 + (4 * args.k if args.model == "fm" else 0)) + 8 * R,
             sum(avg_ms.get(k, 0.0) for k in ("resolve", "gather", "a2a_weights", "forward"))),
         ("exchange_dataflow" if schedule == "owner" else "owner_compute"): owner_leg,
+        "owner_compute_sum_then_step": sum_leg,
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,
     }

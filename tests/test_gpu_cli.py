@@ -109,6 +109,8 @@ def test_bench_runs_two_ranks_and_reports_them(tmp_path):
     assert "owner-compute" in line["config"]["parallelism"]
     ex = line["exchange_dataflow"]
     assert "error" not in ex and ex["value"] > 0
+    st = line["owner_compute_sum_then_step"]
+    assert "error" not in st and st["value"] > 0
     # FM over both ranks on the owner-compute dataflow (sum_then_step)
     fm = line["fm"]
     assert "error" not in fm and fm["value"] > 0 and "sum_then_step" in fm["dataflow"]
