@@ -765,7 +765,17 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
       // against ~2 us of latency.)
       constexpr uint32_t Q = (uint32_t)(K > 0 ? K : 4) / 4u;
       const uint32_t nq = nk * Q;
-      constexpr int kUq = OPT == XF_OPT_FTRL ? 4 : 2;  // quads in flight per lane (measured)
+      // quads in flight per lane.  With 2048-occurrence tiles FTRL wanted four (its (n, z)
+      // state makes a quad 48 bytes of loads); with 256-occurrence tiles the registers are
+      // worth more as occupancy: k = 64 + FTRL power-law 0.73 / 0.68 / 0.60 ms at 4 / 2 / 1
+      // (166 / 112 / fewer registers)
+#ifndef XF_FMG_FTRL_UQ
+#define XF_FMG_FTRL_UQ 1
+#endif
+#ifndef XF_FMG_SGD_UQ
+#define XF_FMG_SGD_UQ 2
+#endif
+      constexpr int kUq = OPT == XF_OPT_FTRL ? XF_FMG_FTRL_UQ : XF_FMG_SGD_UQ;
       // REC: the key's w coordinate is the job of ONE of its quad lanes (the second, when there
       // is one), so that the record leaves as one full 32-byte sector from neighbouring lanes:
       // (a, b) from the first lane, (w, 0, 0, 0) from the w lane.  (Written as 16 + 4 bytes at
