@@ -296,14 +296,21 @@ int xf_workspace_destroy(xf_workspace *ws);
 /* One LRWorker::update (lr_worker.cc:167-176) on a single-shard table, device-resident:
  * pull(resolve+gather) -> loss -> gradient -> push(update).  Asynchronous. */
 int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream);
-/* One FMWorker::update (fm_worker.cc:226-242). */
+/* One FMWorker::update (fm_worker.cc:226-242).  For k in {4, 8, 16, 32, 64} the forward's
+ * per-key records (sum_k v, sum_k v^2, w) are kept in an array next to v's state rows and are
+ * rewritten by the step's gradient + Push kernel; a minibatch that is stepped again starts with
+ * the forward.  Other writers of w or v (xf_table_push / _update* / _import, a defrag, a step
+ * with capture or a parity mode on) are noticed through the tables' write counters: the
+ * minibatch's records are rebuilt on its next step.  Per-key intermediates (xf_workspace_fetch
+ * of w_u / g) exist only with xf_workspace_capture.  Environment: XF_FM_TABLE_RECORDS=0 turns
+ * the records off (the step then gathers the factor rows before every forward). */
 int xf_fm_step(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws, void *stream);
 /* forward only (calculate_pctr, lr_worker.cc:25-71 / fm_worker.cc:25-95): pulls (and so
  * inserts) the batch's keys, writes R probabilities to host `pctr_out`.  Blocking. */
 int xf_lr_predict(xf_table *w, xf_batch *b, xf_workspace *ws, float *pctr_out);
 int xf_fm_predict(xf_table *w, xf_table *v, xf_batch *b, xf_workspace *ws,
                   float *pctr_out);
-/* parity hook of the LR step: when enabled, the step also stores the pulled weights and the
+/* parity hook of the LR / FM step: when enabled, the step also stores the pulled weights and the
  * gradients per unique key of the minibatch for xf_workspace_fetch (the production step never
  * forms them: the forward reads the table in place, the gradient is consumed where it is
  * summed).  Needs a minibatch with a key list (xf_batch_compile*). */
