@@ -31,8 +31,8 @@ for r in csv.DictReader(open(f)):
     us = float(r["AverageNs"]) / 1e3
     mb = e["traffic"] / 1e6 if e else float("nan")
     rows.append((float(r["TotalDurationNs"]), name, int(r["Calls"]), us, mb,
-                 mb / us / 1e6 * 1e6 / 1e3 if us > 0 and e else float("nan")))
+                 mb / us if us > 0 and e else float("nan")))   # MB per us = TB/s
 print("%-46s %6s %10s %10s %8s" % ("kernel", "calls", "avg us", "MB/launch", "TB/s"))
 for _, name, calls, us, mb, tbs in sorted(rows, reverse=True)[:24]:
-    print("%-46s %6d %10.1f %10.1f %8.2f" % (name[:46], calls, us, mb, tbs / 1e3 if tbs == tbs else tbs))
+    print("%-46s %6d %10.1f %10.1f %8.2f" % (name[:46], calls, us, mb, tbs))
 PY
