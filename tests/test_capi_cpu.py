@@ -573,3 +573,29 @@ def test_library_names_the_sources_it_was_built_from():
     from xflow_amd import build
     assert capi.lib().xf_source_hash().decode() == build.source_hash()
     assert len(build.source_hash()) == 32
+
+
+def test_worker_parameters_are_validated_without_a_gpu():
+    """XFCreate / XFSetParam (the worker's host side: main.cc's argv + the extra knobs): values
+    are checked when they are set, by name, with the reason in xf_last_error; training is what
+    needs the GPU (XFStartTrain fails loudly without one: test below)."""
+    import ctypes as C
+    L = capi.lib()
+    h = capi.vp()
+    assert L.XFCreate(C.byref(h), b"/nonexistent/train", b"/nonexistent/test") == 0
+    try:
+        good = [("model", "1"), ("k", "16"), ("optimizer", "sgd"), ("optimizer", "ftrl"),
+                ("epochs", "3"), ("schedule", "sequential"), ("schedule", "stale1"),
+                ("schedule", "owner"), ("update", "rank_ordered"), ("update", "sum_then_step"),
+                ("parity", "exact"), ("parity", "reference_order"), ("transport", "host")]
+        for n, v in good:
+            assert L.XFSetParam(h, n.encode(), v.encode()) == 0, (n, v, L.xf_last_error())
+        bad = [("schedule", "bogus", "sequential, stale1 or owner"),
+               ("update", "x", "rank_ordered or sum_then_step"),
+               ("optimizer", "adam", "ftrl or sgd"), ("model", "2", "0 (LR) or 1 (FM)"),
+               ("nope", "1", "unknown parameter")]
+        for n, v, why in bad:
+            assert L.XFSetParam(h, n.encode(), v.encode()) != 0, (n, v)
+            assert why in L.xf_last_error().decode()
+    finally:
+        L.XFDestroy(h)
