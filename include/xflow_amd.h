@@ -364,6 +364,10 @@ typedef struct xf_group xf_group;
 int xf_group_create(xf_group **out, int rank, int world, const char *addr, int port,
                     int transport, int device);
 int xf_group_destroy(xf_group *g);
+/* Give up on the group's communicators (ncclCommAbort): work of theirs stuck on a stream — a
+ * peer has died — ends; device exchanges fail with XF_EIO afterwards.  The sharded trainer calls
+ * it when a stream wait exceeds XF_COLLECTIVE_TIMEOUT_S. */
+int xf_group_abort(xf_group *g);
 int xf_group_info(const xf_group *g, int *rank, int *world, int *transport);
 int xf_group_barrier(xf_group *g);
 /* host-side collectives over the bootstrap (small payloads: counts, flags, metrics) */

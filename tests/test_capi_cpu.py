@@ -575,6 +575,25 @@ def test_library_names_the_sources_it_was_built_from():
     assert len(build.source_hash()) == 32
 
 
+def test_build_reads_the_built_hash_without_loading_the_library():
+    """build.py decides "rebuild or not" from a sidecar file written at link time, never by
+    dlopen-ing the library: a probe left mapped would make glibc hand the OLD handle to the
+    load after a rebuild (same path), and the binding would then refuse it for the rest of the
+    process.  The sidecar names the library by content, so a stale one counts as unknown."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from xflow_amd import build\n"
+            "assert build._built_hash() == build.source_hash(), 'sidecar does not match'\n"
+            "assert 'libxflow_amd' not in open('/proc/self/maps').read(), 'library was mapped'\n"
+            "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+    from xflow_amd import build
+    src, libsha = open(build.HASH_FILE).read().split()
+    assert libsha == build._file_sha(build.LIB)
+
+
 def test_worker_parameters_are_validated_without_a_gpu():
     """XFCreate / XFSetParam (the worker's host side: main.cc's argv + the extra knobs): values
     are checked when they are set, by name, with the reason in xf_last_error; training is what

@@ -52,14 +52,31 @@ def _stale(target, sources):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HASH_FILE = os.path.join(LIBDIR, "xf_source_hash.txt")
+
+
+def _file_sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()[:32]
+
+
 def _built_hash():
-    """the source hash compiled into the library on disk ("" when there is none)"""
+    """the source hash of the library on disk ("" when unknown).  Read from the sidecar file
+    written when the library was linked — NOT by loading the library: glibc hands a second
+    dlopen of the same path the handle it already has, so a probe that stays mapped would make
+    the rebuilt file unloadable in this process (and would map /opt/rocm's HIP runtime before
+    capi has preloaded torch's).  The sidecar names the library file it belongs to by content
+    (file times do not survive a snapshot): one that names another file counts as unknown and
+    forces a rebuild."""
     try:
-        import ctypes
-        L = ctypes.CDLL(LIB)
-        L.xf_source_hash.restype = ctypes.c_char_p
-        return L.xf_source_hash().decode()
-    except (OSError, AttributeError):
+        with open(HASH_FILE) as f:
+            src, libsha = f.read().split()
+        return src if libsha == _file_sha(LIB) else ""
+    except (OSError, ValueError):
         return ""
 
 
@@ -88,6 +105,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(HASH_FILE, "w") as f:   # after the link: never older than the library
+            f.write("%s %s\n" % (source_hash(), _file_sha(LIB)))
     cli_src = os.path.join(CSRC, "xf_cli.cc")
     if force or _stale(CLI, [cli_src, LIB]):
         cmd = [_hipcc()] + FLAGS + [cli_src, "-o", CLI, "-L" + LIBDIR, "-lxflow_amd",

@@ -139,6 +139,7 @@ SIGNATURES = {
     "xf_group_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                   C.c_int]),
     "xf_group_destroy": (C.c_int, [vp]),
+    "xf_group_abort": (C.c_int, [vp]),
     "xf_group_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "xf_group_barrier": (C.c_int, [vp]),
     "xf_group_allgather_host": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -12,6 +12,7 @@
 #include "xf_batch.h"
 #include "xf_tiling.h"
 
+#include <atomic>
 #include <string.h>
 
 #include <algorithm>
@@ -222,6 +223,9 @@ namespace xf {
 static int g_exp_knob = 0;
 int exp_knob() { return g_exp_knob; }
 void set_exp_knob(int v) { g_exp_knob = v; }
+static std::atomic<bool> g_device_poisoned{false};
+bool device_poisoned() { return g_device_poisoned.load(std::memory_order_relaxed); }
+void scratch_poison() { g_device_poisoned.store(true); }
 }  // namespace xf
 
 extern "C" int xf_tune(const char *name, double value) {

@@ -14,6 +14,12 @@ namespace xf {
 int set_error(int code, const char *fmt, ...);
 int parse_threads();
 void set_parse_threads(int n);
+// A stream of this process holds work that will never finish (a collective whose peer died):
+// device memory must not be freed any more — hipFree would wait for that work, or release what
+// queued kernels still write.  Set once by the sharded trainer's stream wait on a time-out;
+// Scratch and the trainer's Dev<> buffers leak their memory from then on.
+bool device_poisoned();
+void scratch_poison();
 int exp_knob();
 void set_exp_knob(int v);
 

@@ -51,6 +51,7 @@ struct Rccl {
   int (*GetUniqueId)(ncclUniqueId_t *) = nullptr;
   int (*CommInitRank)(ncclComm_h *, int, ncclUniqueId_t, int) = nullptr;
   int (*CommDestroy)(ncclComm_h) = nullptr;
+  int (*CommAbort)(ncclComm_h) = nullptr;  // (optional symbol)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_h, hipStream_t) = nullptr;
@@ -79,6 +80,7 @@ int load_rccl(Rccl &r) {
   XF_SYM(Recv, "ncclRecv");
   XF_SYM(GetErrorString, "ncclGetErrorString");
 #undef XF_SYM
+  *(void **)(&r.CommAbort) = dlsym(r.so, "ncclCommAbort");
   return XF_OK;
 }
 
@@ -138,6 +140,7 @@ struct xf_group {
   // Pull(t+1)) gets a communicator per stream
   ncclComm_h comm[XF_GROUP_CHANNELS] = {nullptr, nullptr};
   std::vector<char> hs, hr;  // host staging of the host transport
+  bool aborted = false;      // xf_group_abort: no device exchange any more
 };
 
 namespace {
@@ -324,8 +327,14 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
       const int fd = socket(AF_INET, SOCK_STREAM, 0);
       int one = 1;
       setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-      // the rendezvous address itself (127.0.0.1 stays on this host), not every interface
+      // A loopback rendezvous address stays on this host, and an explicit numeric address is
+      // taken at its word; a NAME is not: it may resolve to a loopback alias on this host
+      // (127.0.1.1 in /etc/hosts) or to another interface than the peers reach, so rank 0
+      // then listens on every interface (the hello's magic word turns strays away).
       sockaddr_in any = sa;
+      const bool numeric = inet_pton(AF_INET, host.c_str(), &any.sin_addr) == 1;
+      any.sin_addr = sa.sin_addr;
+      if (!numeric) any.sin_addr.s_addr = htonl(INADDR_ANY);
       if (bind(fd, (sockaddr *)&any, sizeof(any)) == 0 && listen(fd, world + 8) == 0) {
         g->listen_fd = fd;
         root = true;
@@ -446,6 +455,19 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
   }
   guard.g = nullptr;
   *out = g;
+  return XF_OK;
+}
+
+// Give up on the communicators: work of theirs that is stuck on a stream (a peer has died) is
+// made to end.  The group keeps its sockets; device exchanges fail from here on.
+extern "C" int xf_group_abort(xf_group *g) {
+  XF_REQUIRE(g, "xf_group_abort: null group");
+  for (ncclComm_h &c : g->comm) {
+    if (c && g->rccl.CommAbort) g->rccl.CommAbort(c);
+    c = nullptr;  // (without ncclCommAbort the communicator is leaked, never destroyed: a
+                  // destroy would wait for the stuck work)
+  }
+  g->aborted = true;
   return XF_OK;
 }
 
@@ -603,6 +625,8 @@ extern "C" int xf_group_alltoallv_ch(xf_group *g, int channel, const void *send,
   hipStream_t s = (hipStream_t)stream;
   const char *sb = (const char *)send;
   char *rb = (char *)recv;
+  if (g->aborted)
+    return xf::set_error(XF_EIO, "xf_group_alltoallv: the group's communicators were aborted");
   if (g->transport == XF_TRANSPORT_RCCL) {
     XF_REQUIRE(!host_buffers, "xf_group_alltoallv: the RCCL transport moves device memory");
     return alltoallv_rccl(g, channel, sb, so, rb, ro, s);

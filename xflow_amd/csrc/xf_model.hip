@@ -1699,7 +1699,11 @@ static int ws_reserve_cells(xf_workspace *ws, const xf_cells *c, bool dense_g) {
     XF_HIP(hipMalloc((void **)&ws->partial, (need + need / 8 + 1024) * 8));
     ws->capPartial = need + need / 8 + 1024;
   }
-  const size_t gd = dense_g ? (size_t)c->nchunk * xf::kChunk : 0;
+  // (the gradient pass writes g at (chunk0 + chunk) * kChunk + k for every segment of the chain)
+  size_t gd = 0;
+  if (dense_g)
+    for (const xf_cells *q = c; q; q = q->next)
+      gd = std::max(gd, ((size_t)q->chunk0 + q->nchunk) * xf::kChunk);
   if (gd > ws->capGdense) {
     if (ws->gdense) XF_HIP(hipFree(ws->gdense));
     ws->gdense = nullptr;

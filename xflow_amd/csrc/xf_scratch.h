@@ -31,8 +31,12 @@ struct Scratch {
   Scratch(const Scratch &) = delete;
   Scratch &operator=(const Scratch &) = delete;
   ~Scratch() {
-    for (void *p : overflow) (void)hipFree(p);
     Arena &a = arena();
+    if (device_poisoned()) {  // (xf_common.h: leak, do not wait for a stuck stream)
+      a.used = mark;
+      return;
+    }
+    for (void *p : overflow) (void)hipFree(p);
     a.high = std::max(a.high, a.used + spilled);
     a.used = mark;
     if (mark == 0 && a.high > a.cap) {  // outermost scope: grow for the next build

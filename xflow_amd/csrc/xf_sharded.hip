@@ -112,7 +112,7 @@ struct Dev {
   Dev(const Dev &) = delete;
   Dev &operator=(const Dev &) = delete;
   ~Dev() {
-    if (p) (void)hipFree(p);
+    if (p && !xf::device_poisoned()) (void)hipFree(p);  // (poisoned: leaked, see wait_stream)
   }
   int reserve(size_t want) {
     if (want <= n && p) return XF_OK;
@@ -181,6 +181,7 @@ struct xf_sbatch {
 struct xf_sharded {
   xf_group *g = nullptr;
   int rank = 0, world = 1;
+  bool poisoned = false;  // a stream wait timed out: every later call fails fast
   bool fused = true;  // world 1: the fused single-shard step (XF_SHARDED_GENERAL=1 runs the
                       // exchange path with its self-copies instead: a measuring aid)
   xf_sharded_config cfg{};
@@ -245,10 +246,20 @@ int wait_stream(xf_sharded *st, hipStream_t s) {
       std::this_thread::sleep_for(std::chrono::microseconds(50));
       const double dt =
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (dt > limit)
+      if (dt > limit) {
+        // The stream still holds the stuck collective and whatever was queued behind it: the
+        // callers' device scratch must not be freed under it (hipFree would wait for it — the
+        // hang again — or release memory that queued kernels write).  The trainer is poisoned:
+        // the communicators are aborted so that the stuck kernels end, scratch is leaked from
+        // here on (xf::scratch_poison) and every later call fails fast.
+        st->poisoned = true;
+        xf::scratch_poison();
+        xf_group_abort(st->g);
         return xf::set_error(XF_EIO, "rank %d: the work on a stream with a collective did not "
                              "finish within %.0f s (a peer has failed, or the ranks entered an "
-                             "exchange in different orders)", st->rank, limit);
+                             "exchange in different orders); this trainer is unusable now",
+                             st->rank, limit);
+      }
     }
   }
 }
@@ -662,6 +673,13 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
     // arithmetic is not that of one LRWorker::update any more: for timing the pass on one GPU.
     const uint32_t n = (uint32_t)atoi(e), nw = b->o_win[W];
     if (W == 1 && n > 1 && nw >= n) {
+      static bool said = false;
+      if (!said) {
+        said = true;
+        fprintf(stderr, "xflow_amd: XF_OWNER_TIMING_SOURCES=%u — a measuring aid: this rank's rows "
+                "are dealt out to %u pretended workers and every key takes %u optimizer steps; "
+                "the results are NOT those of LRWorker::update\n", n, n, n);
+      }
       std::vector<uint32_t> winT(n + 1), rowsT(n);
       for (uint32_t q = 0; q <= n; ++q) winT[q] = (uint32_t)((uint64_t)nw * q / n);
       for (uint32_t q = 0; q < n; ++q)
@@ -880,6 +898,14 @@ static int step_owner_fm(xf_sharded *st, xf_sbatch *b) {
   return XF_OK;
 }
 
+// a trainer whose stream wait timed out (wait_stream) holds stuck work: nothing runs on it again
+#define XF_ALIVE(st)                                                                         \
+  do {                                                                                       \
+    if ((st)->poisoned)                                                                      \
+      return xf::set_error(XF_EIO, "this trainer is unusable: an earlier wait for a stream " \
+                           "with a collective timed out (destroy it and the group)");        \
+  } while (0)
+
 extern "C" void xf_sharded_config_default(xf_sharded_config *c) {
   memset(c, 0, sizeof(*c));
   c->model = 0;
@@ -963,6 +989,7 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
 
 extern "C" int xf_sharded_destroy(xf_sharded *st) {
   if (!st) return XF_OK;
+  if (st->poisoned) return XF_OK;  // stuck work on its streams: everything it owns is leaked
   (void)hipDeviceSynchronize();
   if (st->ws) xf_workspace_destroy(st->ws);
   if (st->tw) xf_table_destroy(st->tw);
@@ -1016,6 +1043,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
                                   size_t row_end, int keep) {
   XF_REQUIRE(st && out && rowptr && labels && row_end >= row_begin,
              "xf_sharded_compile: bad argument");
+  XF_ALIVE(st);
   xf_sbatch *b = new xf_sbatch;
   struct Guard {
     xf_sbatch *b;
@@ -1123,6 +1151,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
 // One LRWorker::update / FMWorker::update of every rank (COLLECTIVE), asynchronous.
 extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
   XF_REQUIRE(st && b, "xf_sharded_step: null argument");
+  XF_ALIVE(st);
   if (st->fused) {
     if (st->cfg.model == 0) return xf_lr_step(st->tw, b->b, st->ws, st->main);
     return xf_fm_step(st->tw, st->tv, b->b, st->ws, st->main);
@@ -1173,6 +1202,7 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
 // apply the outstanding Push of the stale1 schedule (end of training, before export / predict)
 extern "C" int xf_sharded_flush(xf_sharded *st) {
   XF_REQUIRE(st, "xf_sharded_flush: null trainer");
+  XF_ALIVE(st);
   if (!st->fused) XF_TRY(flush_pending(st));
   XF_TRY(wait_stream(st, st->main));
   XF_TRY(wait_stream(st, st->side));
@@ -1184,6 +1214,7 @@ extern "C" int xf_sharded_flush(xf_sharded *st) {
 // insert unseen keys, as in the reference (ftrl.h:56).
 extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out) {
   XF_REQUIRE(st && b && (b->R == 0 || pctr_out), "xf_sharded_predict: null argument");
+  XF_ALIVE(st);
   if (st->fused) {
     XF_TRY(wait_stream(st, st->main));
     if (st->cfg.model == 0) return xf_lr_predict(st->tw, b->b, st->ws, pctr_out);
