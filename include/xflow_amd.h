@@ -47,6 +47,8 @@ int xf_device_count(int *count);
 uint64_t xf_hash_bytes(const void *ptr, size_t len);
 /* out[i] = hash of the decimal string of (start + i): synthetic fids "0","1",... */
 int xf_hash_decimal_range(uint64_t start, size_t n, uint64_t *out);
+/* out[i] = hash of the decimal string of ids[i] */
+int xf_hash_decimal_ids(const uint64_t *ids, size_t n, uint64_t *out);
 /* ps-lite default key-range owner: min(key / (UINT64_MAX / nshards), nshards-1) */
 uint32_t xf_shard_of(uint64_t key, uint32_t nshards);
 

@@ -64,6 +64,8 @@ def lib():
     L.xo_store_set_sgd.argtypes = [C.c_void_p, C.c_float]
     L.xo_store_size.restype = C.c_size_t
     L.xo_store_size.argtypes = [C.c_void_p]
+    L.xo_store_reserve.restype = None
+    L.xo_store_reserve.argtypes = [C.c_void_p, C.c_size_t]
     L.xo_store_pull.argtypes = [C.c_void_p, _u64p, C.c_size_t, _f32p]
     L.xo_store_push.argtypes = [C.c_void_p, _u64p, C.c_size_t, _f32p]
     L.xo_store_export.argtypes = [C.c_void_p, _u64p, _f32p, _f32p, _f32p]
@@ -171,6 +173,9 @@ class Store:
 
     def __len__(self):
         return int(lib().xo_store_size(self.h))
+
+    def reserve(self, nkeys):
+        lib().xo_store_reserve(self.h, int(nkeys))
 
     def pull(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

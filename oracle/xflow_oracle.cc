@@ -360,10 +360,15 @@ extern "C" void xo_store_push(xo_store *s, const uint64_t *keys, size_t nk,
 extern "C" void xo_store_export(const xo_store *s, uint64_t *keys, float *w, float *nn,
                                 float *z) {
   const size_t ne = s->ekeys.size();
-  std::vector<size_t> order(ne);
-  for (size_t i = 0; i < ne; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(),
-            [s](size_t a, size_t b) { return s->ekeys[a] < s->ekeys[b]; });
+  /* (key, entry) pairs sorted by key: keys are unique, so the order is the key order whatever
+   * the sort does with ties; sorting the pairs instead of entry numbers through an indirect
+   * comparison matters at 10^8 entries only */
+  std::vector<std::pair<uint64_t, uint32_t> > kv(ne);
+  for (size_t i = 0; i < ne; ++i) kv[i] = std::make_pair(s->ekeys[i], (uint32_t)i);
+  std::sort(kv.begin(), kv.end());
+  std::vector<uint32_t> order(ne);
+  for (size_t i = 0; i < ne; ++i) order[i] = kv[i].second;
+  std::vector<std::pair<uint64_t, uint32_t> >().swap(kv);
   for (size_t i = 0; i < ne; ++i) {
     const size_t e = order[i];
     keys[i] = s->ekeys[e];
@@ -373,6 +378,17 @@ extern "C" void xo_store_export(const xo_store *s, uint64_t *keys, float *w, flo
       if (z) z[i * s->dim + j] = s->z[e * s->dim + j];
     }
   }
+}
+
+/* room for `n` keys without a rehash on the way (test-harness convenience: a 10^8-key run) */
+extern "C" void xo_store_reserve(xo_store *s, size_t n) {
+  size_t cap = s->hkeys.size();
+  while (cap < 2 * (n + 1)) cap *= 2;
+  if (cap != s->hkeys.size()) xo_store_rehash(s, cap);
+  s->ekeys.reserve(n);
+  s->w.reserve(n * s->dim);
+  s->n.reserve(n * s->dim);
+  s->z.reserve(n * s->dim);
 }
 
 extern "C" void xo_store_import(xo_store *s, const uint64_t *keys, size_t nk,

@@ -62,6 +62,7 @@ void xo_store_destroy(xo_store *s);
 void xo_store_set_ftrl(xo_store *s, float alpha, float beta, float l1, float l2);
 void xo_store_set_sgd(xo_store *s, float lr);
 size_t xo_store_size(const xo_store *s);
+void xo_store_reserve(xo_store *s, size_t nkeys); /* no rehash up to nkeys (harness aid) */
 /* pull branch: ftrl.h:49-52,75-77 / sgd.h — inserts missing keys (ftrl.h:56) */
 void xo_store_pull(xo_store *s, const uint64_t *keys, size_t n, float *out);
 /* push branch: ftrl.h:54-74 / sgd.h:52,96 */

@@ -66,6 +66,39 @@ def test_local_batches_match_the_oracle(R, nnz, nkeys, zipf, ragged, cap):
         same(capi.lr_predict(t, bs[1], ws), obs[1].lr_loss(s.pull(obs[1].ukeys))[1])
 
 
+@pytest.mark.parametrize("knob", [300, 301, 302, 304, 305, 306, 399])
+@pytest.mark.parametrize("opt", ["ftrl", "sgd"])
+def test_every_variant_of_the_gradient_kernel_gives_the_oracle_table(knob, opt):
+    """k_lr_grad_dense (the steady-state gradient + Push: one fp32 division for sum / R, the
+    touched keys compacted per wavefront / the state rows prefetched / 512 threads per chunk)
+    in every instantiation, and the general kernel alone (399): three windows, split and unsplit
+    chunks side by side (power law), holes and an arrival segment after the defrag — the table
+    bit for bit the exact-sum oracle's after every variant."""
+    rng = np.random.RandomState(11)
+    oo, go = (O.OPT_FTRL, capi.OPT_FTRL) if opt == "ftrl" else (O.OPT_SGD, capi.OPT_SGD)
+    t, s = capi.Table(go, 1, capacity=1 << 19), O.Store(oo, 1)
+    ws = capi.Workspace()
+    raw = [synth(rng, 40000, 30, 120000, 1.2 if i % 2 else None, True) for i in range(3)]
+    obs = [O.Batch(*x) for x in raw]
+    capi.tune("exp_knob", knob)
+    try:
+        for i in range(4):
+            b = capi.LocalBatch(t, *raw[i % 3], retain_keys=False)
+            if i == 1:
+                assert b.cells_info()["nsplit_chunks"] > 0
+            with O.sum_mode(1):
+                O.lr_update(s, obs[i % 3])
+            capi.lr_step(t, b, ws)
+            t.check()
+            del b
+            if i == 1:
+                t.defrag()
+    finally:
+        capi.tune("exp_knob", 0)
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)
+
+
 def test_local_and_keyed_batches_give_the_same_table():
     """xf_batch_compile (sorted unique keys, then cells through the key list) and
     xf_batch_compile_local (raw keys straight to rows) are two builds of the same step."""

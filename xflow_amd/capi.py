@@ -62,6 +62,7 @@ SIGNATURES = {
     "xf_hash_bytes": (C.c_uint64, [C.c_char_p, C.c_size_t]),
     "xf_shard_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "xf_hash_decimal_range": (C.c_int, [C.c_uint64, C.c_size_t, u64p]),
+    "xf_hash_decimal_ids": (C.c_int, [u64p, C.c_size_t, u64p]),
     "xf_reader_open": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t]),
     "xf_reader_open_cached": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_char_p,
                                         C.POINTER(C.c_int)]),
@@ -264,6 +265,14 @@ def tune(name, value):
 def hash_decimal_range(start, n):
     out = np.empty(n, dtype=np.uint64)
     check(lib().xf_hash_decimal_range(start, n, _p(out, u64p)))
+    return out
+
+
+def hash_decimal_ids(ids):
+    """hash of the decimal string of every id (io.h:53 on str(id))"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    out = np.empty(len(ids), dtype=np.uint64)
+    check(lib().xf_hash_decimal_ids(_p(ids, u64p), len(ids), _p(out, u64p)))
     return out
 
 

@@ -423,13 +423,14 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
                 uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
                 const uint32_t *__restrict__ src_rows, uint32_t nsplit,
-                const uint32_t *__restrict__ loss_base, uint32_t chunk0) {
+                const uint32_t *__restrict__ loss_base, uint32_t chunk0, uint32_t only_split) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
   const uint32_t tid = threadIdx.x;
   const uint32_t c = item_chunk[blockIdx.x];
   const uint32_t sl = item_slice[blockIdx.x], s = sl & 0xFFFFu, S = sl >> 16;
+  if (only_split && S == 1) return;  // (k_lr_grad_dense has taken the unsplit chunks)
   for (uint32_t k = tid; k < kChunk; k += kBlock) {
     acc[k] = 0.0;
     touched[k] = 0;
@@ -513,7 +514,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
             if (i >= ib && i <= ie)  // workgroup-uniform
               add_keys(acc, touched, (ek[i] >> 16) == q, ek[i] & (kChunk - 1), l[i]);
           __syncthreads();
-          const float rq = (float)src_rows[q];
+          const uint32_t rq = src_rows[q];
 #pragma unroll
           for (int i = 0; i < kOwn; ++i) {
             const uint32_t k = tid + i * kBlock;
@@ -521,7 +522,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
             const double sum = acc[k];
             acc[k] = 0.0;  // the next worker's phase starts from zero
             touched[k] = 0;
-            const float g = (float)((double)(float)sum / (1.0 * (double)rq));  // lr_worker.cc:117
+            const float g = xf::div_by_rows((float)sum, rq);  // lr_worker.cc:117
             if (OPT == XF_OPT_FTRL)
               xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
             else
@@ -613,11 +614,150 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
     }
     const size_t idx = (size_t)(chunk0 + c) * kChunk + k;
     if (idx >= M) continue;
-    const float g = (float)((double)(float)sum / (1.0 * Rq));  // lr_worker.cc:117
+    const float g = xf::div_by_rows((float)sum, Rq);  // lr_worker.cc:117
     if (g_out) g_out[idx] = g;
     if (MODE == 0) apply_key(T, OPT, idx, g);
   }
   }  // sources
+}
+
+// ---- the gradient + Push of the steady state: ONE source, an unsplit chunk, at most kDenseWin
+// row windows (config 2: three) — the launch that takes most of the LR step.  What the general
+// kernel above spends there (ISA count, 58 registers): ~140 VALU instructions per optimizer step
+// (two correctly rounded square roots, three correctly rounded divisions) + an fp64 division for
+// sum / R, executed for EVERY 64 rows of the chunk with the ~63 % of the lanes whose key the
+// minibatch touched — ~760 cycles x 156 000 wavefront iterations / 1024 SIMDs ~ 48 us of pure
+// issue time in a 78 us kernel; the accumulate phase another ~13 us (window search in LDS per
+// entry, 64-bit address arithmetic).  The kernel is VALU-bound, not HBM-bound.  Here:
+//   * g = sum / R as ONE fp32 division (div_by_rows: the same number as the reference's double
+//     division for R < 2^24);
+//   * kDenseCompact: after the sums are complete every wavefront compacts the touched keys of
+//     its share of the chunk into a list in LDS and steps them with all lanes busy;
+//   * the cell bounds of the <= 4 windows in registers (scalar loads): no LDS table, no serial
+//     scan, two barriers fewer, window of an entry = two compares;
+//   * kDensePrefetch (instead of the compaction): the chunk's state rows requested before the
+//     entries, so that the optimizer steps find them in registers;
+//   * kDenseWide: 512 threads per chunk.
+// Same sums (fp64 LDS atomics: exact, any order), same step (ftrl_step / sgd_step): the table
+// bits of the general kernel (tests/test_gpu_cells.py runs every variant against it).
+constexpr uint32_t kDenseWin = 4;
+enum { kDenseCompact = 1, kDensePrefetch = 2, kDenseWide = 4 };
+#ifndef XF_GRAD_DENSE_VAR
+#define XF_GRAD_DENSE_VAR 1
+#endif
+
+template <int OPT, int VAR>
+__global__ void __launch_bounds__((VAR & kDenseWide) ? 512 : 256)
+k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
+                const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
+                const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
+                const float *__restrict__ loss, uint32_t R, uint32_t M, uint32_t chunk0) {
+  constexpr int NT = (VAR & kDenseWide) ? 512 : 256;
+  constexpr int kOwn = (int)(kChunk / NT);  // keys per thread = entries per lane and round
+  constexpr int NW = NT / 64;
+  constexpr uint32_t KW = kChunk / NW;      // keys per wavefront in the compaction
+  constexpr bool COMPACT = (VAR & kDenseCompact) != 0;
+  constexpr bool PREFETCH = !COMPACT && (VAR & kDensePrefetch) != 0;
+  __shared__ double acc[kChunk];
+  __shared__ uint8_t touched[kChunk];
+  __shared__ uint16_t list[COMPACT ? kChunk : 1];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = item_chunk[blockIdx.x];
+  if ((item_slice[blockIdx.x] >> 16) != 1u) return;  // a split chunk: the general kernel's
+  const size_t row0 = (size_t)(chunk0 + c) * kChunk;
+  float sw[kOwn], sn[kOwn], sz[kOwn];
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+      sw[i] = sn[i] = sz[i] = 0.0f;
+      if (row0 + tid + i * NT < M) {
+        sw[i] = T.w[row0 + tid + i * NT];
+        if (OPT == XF_OPT_FTRL) xf::load_nz(T, row0 + tid + i * NT, sn[i], sz[i]);
+      }
+    }
+  }
+  // the chunk's cells: window v holds entries [cb[v], cb[v] + (cum[v + 1] - cum[v]))
+  uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0, c1 = 0, c2 = 0, c3 = 0, total = 0;
+  {
+    uint32_t b, e;
+    b = cellptr[c], e = cellptr[c + 1], cb0 = b, c1 = e - b, c2 = c3 = total = c1;
+    if (nwin > 1) b = cellptr[(size_t)nchunk + c], e = cellptr[(size_t)nchunk + c + 1], cb1 = b,
+                  c2 = c1 + (e - b), c3 = total = c2;
+    if (nwin > 2) b = cellptr[2 * (size_t)nchunk + c], e = cellptr[2 * (size_t)nchunk + c + 1],
+                  cb2 = b, c3 = c2 + (e - b), total = c3;
+    if (nwin > 3) b = cellptr[3 * (size_t)nchunk + c], e = cellptr[3 * (size_t)nchunk + c + 1],
+                  cb3 = b, total = c3 + (e - b);
+  }
+#pragma unroll
+  for (int i = 0; i < kOwn; ++i) acc[tid + i * NT] = 0.0;
+  if (tid < kChunk / 4) ((uint32_t *)touched)[tid] = 0u;
+  if (NT < (int)(kChunk / 4) && tid + NT < kChunk / 4) ((uint32_t *)touched)[tid + NT] = 0u;
+  __syncthreads();
+  for (uint32_t p0 = 0; p0 < total; p0 += NT * kOwn) {  // workgroup-uniform trip count
+    uint32_t ent[kOwn], lidx[kOwn];
+    float l[kOwn];
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q) {
+      const uint32_t p = p0 + q * NT + tid;
+      ent[q] = 0xFFFFFFFFu;
+      lidx[q] = 0;
+      if (p < total) {
+        const uint32_t j = p < c1 ? cb0 + p : p < c2 ? cb1 + (p - c1) : p < c3 ? cb2 + (p - c2)
+                                                                               : cb3 + (p - c3);
+        lidx[q] = p < c1 ? 0u : p < c2 ? W : p < c3 ? 2u * W : 3u * W;
+        ent[q] = entries[j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q)
+      l[q] = ent[q] != 0xFFFFFFFFu ? loss[lidx[q] + ((ent[q] >> kChunkBits) & kRowMask)] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q)
+      add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), l[q]);
+  }
+  __syncthreads();
+  if constexpr (COMPACT) {
+    // wavefront w lists the touched keys among [w * KW, (w + 1) * KW), ascending, in its own
+    // part of `list` (LDS operations of one wavefront execute in order: no barrier), then takes
+    // them 64 at a time
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint16_t *wl = list + wave * KW;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < KW; j += 64) {
+      const uint32_t k = wave * KW + j + lane;
+      const bool t = touched[k] != 0 && row0 + k < M;
+      const unsigned long long m = __ballot(t);
+      if (t) wl[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+      cnt += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t p = lane; p < cnt; p += 64) {
+      const uint32_t k = wl[p];
+      const float g = xf::div_by_rows((float)acc[k], R);  // lr_worker.cc:117
+      apply_key(T, OPT, row0 + k, g);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+      const uint32_t k = tid + i * NT;
+      if (!touched[k] || row0 + k >= M) continue;
+      const float g = xf::div_by_rows((float)acc[k], R);  // lr_worker.cc:117
+      if constexpr (PREFETCH) {
+        if (OPT == XF_OPT_FTRL) {
+          xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+          T.w[row0 + k] = sw[i];
+          xf::store_nz(T, row0 + k, sn[i], sz[i]);
+        } else {
+          T.w[row0 + k] = xf::sgd_step(T.lr, g, sw[i]);
+        }
+      } else {
+        apply_key(T, OPT, row0 + k, g);
+      }
+    }
+  }
 }
 
 // the keys of the split chunks: one lane per key
@@ -635,7 +775,7 @@ k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
   for (uint32_t q = 0; q < ns; ++q) {  // the workers' steps in rank order
     const size_t o = ((size_t)q * nsplit + slot) * kChunk + k;
     if (!gtouched[o]) continue;
-    const float g = (float)((double)(float)gsum[o] / (1.0 * (src_rows ? src_rows[q] : R)));
+    const float g = xf::div_by_rows((float)gsum[o], src_rows ? src_rows[q] : R);
     if (g_out) g_out[idx] = g;
     if (MODE == 0) apply_key(T, OPT, idx, g);
   }
@@ -889,19 +1029,52 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                        s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                        src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0);
+                       c->chunk0, 0u);
   else if (src)
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                        src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0);
-  else
-    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
-                       T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
-                       c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
-                       (const uint32_t *)nullptr, c->chunk0);
+                       c->chunk0, 0u);
+  else {
+    // one source: the unsplit chunks go to k_lr_grad_dense (gradient + Push, no dense copy of
+    // the gradients wanted, few windows), the general kernel keeps the split ones
+    bool dense = false;
+    if constexpr (MODE == 0) {
+      if (!d_g && c->nwin <= kDenseWin) {
+        int var = XF_GRAD_DENSE_VAR;
+        const int knob = exp_knob();
+        if (knob >= 300 && knob < 308) var = knob - 300;  // (experiments: tools/cells_knobs.py)
+        dense = knob != 399;                               // 399: the general kernel alone
+        if (dense) {
+#define XF_DENSE(V)                                                                              \
+  case V:                                                                                        \
+    hipLaunchKernelGGL((k_lr_grad_dense<OPT, V>), dim3(c->nitems),                               \
+                       dim3(((V) & kDenseWide) ? 512 : 256), 0, s, T, c->entries, c->cellptr,    \
+                       c->nchunk, c->nwin, c->W, c->item_chunk, c->item_slice, d_loss, c->R,     \
+                       c->M, c->chunk0);                                                         \
+    break
+          switch (var) {
+            XF_DENSE(0);
+            XF_DENSE(1);
+            XF_DENSE(2);
+            XF_DENSE(4);
+            XF_DENSE(5);
+            XF_DENSE(6);
+            default:
+              return xf::set_error(XF_EINVAL, "gradient kernel variant %d", var);
+          }
+#undef XF_DENSE
+        }
+      }
+    }
+    if (!dense || c->nsplit_chunks)
+      hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
+                         T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                         c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
+                         (const uint32_t *)nullptr, c->chunk0, dense ? 1u : 0u);
+  }
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,

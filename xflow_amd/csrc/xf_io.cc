@@ -120,6 +120,35 @@ extern "C" int xf_hash_decimal_range(uint64_t start, size_t n, uint64_t *out) {
   return XF_OK;
 }
 
+// out[i] = hash of the decimal string of ids[i] (key spaces too large for a table of every
+// hash: 10^9 fids drawn from a power law)
+extern "C" int xf_hash_decimal_ids(const uint64_t *ids, size_t n, uint64_t *out) {
+  XF_REQUIRE((ids && out) || n == 0, "xf_hash_decimal_ids: null argument");
+  auto run = [=](size_t lo, size_t hi) {
+    char buf[24], tmp[24];
+    for (size_t i = lo; i < hi; ++i) {
+      uint64_t v = ids[i];
+      int len = 0;
+      do {
+        tmp[len++] = (char)('0' + v % 10);
+        v /= 10;
+      } while (v);
+      for (int j = 0; j < len; ++j) buf[j] = tmp[len - 1 - j];
+      out[i] = xf_hash_bytes(buf, (size_t)len);
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;
+  if (nt < 2 || n < (1u << 16)) {
+    run(0, n);
+    return XF_OK;
+  }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) th.emplace_back(run, n * t / nt, n * (t + 1) / nt);
+  for (auto &x : th) x.join();
+  return XF_OK;
+}
+
 extern "C" uint32_t xf_shard_of(uint64_t key, uint32_t nshards) {
   if (nshards <= 1) return 0;
   const uint64_t s = key / (UINT64_MAX / nshards);

@@ -50,19 +50,7 @@ namespace {
 constexpr int kBlock = 256;
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
-// x / R exactly as the reference computes it — `float /= 1.0 * line_num`, i.e. the fp32 value
-// divided in double and rounded back to fp32 (lr_worker.cc:117, fm_worker.cc:150-156) — at the
-// price of an fp32 division: for x an fp32 number and R an integer below 2^24 the exact
-// quotient is either a float midpoint or at least 2^-49 (relative) away from one, far more
-// than the 2^-53 the intermediate double rounding can move it, so rounding the double
-// quotient to float gives the correctly rounded fp32 quotient, which is what x / (float)R
-// is (hipcc keeps fp32 division correctly rounded).  One fp64 division per (key, factor) was a
-// fifth of the FM gradient kernel.
-__device__ __forceinline__ float div_by_rows(float x, uint32_t R) {
-#pragma clang fp contract(off)
-  if (R < (1u << 24)) return x / (float)R;
-  return (float)((double)x / (1.0 * R));
-}
+using xf::div_by_rows;  // xf_device.h
 
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
