@@ -8,12 +8,14 @@ produces: pulled weights, loss, gradients, and the full (w, n, z) state after se
 steps.
 
 Against the oracle's REFERENCE-ARITHMETIC mode (fp32 running sums in the reference's
-std::sort order, lr_worker.cc:162 — itself only one of several legal roundings, the order
-within a key being unspecified): north_star's 1e-6 relative on loss, pulled weights and
-gradients element-wise, and 1e-6 on the weights/state measured against |value| + rms of the
-state vector (coordinates whose z cancels to ~0 have no element-wise condition number).
-Keys with thousands of occurrences per minibatch (power-law heads) carry the reference's own
-fp32 accumulation noise, ~sqrt(n)*2^-24: that case states its bound (RTOL_HEAVY)."""
+std::sort order, lr_worker.cc:162): the same steps run a second time in the product's parity
+mode XF_PARITY_REFERENCE_ORDER, which forms those very sums in that very order — every float
+bit for bit again, power-law heads and k = 64 included (round 4; there is no heavy-key
+tolerance any more).  The production path itself (exact sums) is additionally held to
+north_star's 1e-6 relative against the reference arithmetic where the reference's own fp32
+accumulation noise is below that (uniform minibatches): loss, pulled weights and gradients
+element-wise, the state against |value| + rms of the state vector (coordinates whose z
+cancels to ~0 have no element-wise condition number)."""
 import os
 
 import numpy as np
@@ -26,7 +28,6 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6        # north_star: "within 1e-6 relative on the float loss/weights"
 ATOL = 1e-9        # floor for values that are ~0
-RTOL_HEAVY = 1e-4  # reference-arithmetic noise for keys summed over >1e3 mixed-sign rows (see docstring)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -316,9 +317,12 @@ def test_export_import_roundtrip():
 def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
     rng = np.random.RandomState(R)
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)
+    t_par = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)   # stepped in parity mode
     s_ref = O.Store(O.OPT_FTRL, 1)      # reference arithmetic (fp32 running sums)
     s_exact = O.Store(O.OPT_FTRL, 1)    # exact-sum mode
     ws = capi.Workspace(capture=True)
+    ws_par = capi.Workspace(capture=True)
+    ws_par.parity("reference_order")
     for step in range(4):
         rowptr, keys, labels = synth(rng, R, nnz, nkeys, zipf, ragged)
         b = capi.Batch(rowptr, keys, labels)
@@ -339,15 +343,20 @@ def test_lr_step_intermediates_and_state(R, nnz, nkeys, zipf, ragged):
         same(wu, w_ex)
         same(loss, loss_ex)
         same(g, g_ex)
-        near_state(wu, w_ref, RTOL_HEAVY if zipf else RTOL)
-        close(loss, loss_ref, rtol=RTOL_HEAVY if zipf else RTOL)
-        near_state(g, g_ref, RTOL_HEAVY if zipf else RTOL)   # sums of mixed-sign losses
-    for a, e, r in zip(t.export(), s_exact.export(), s_ref.export()):
+        capi.lr_step(t_par, b, ws_par)             # the reference's own sums, its own state
+        wu_p, loss_p, g_p = ws_par.fetch(b.U, b.R)
+        same(wu_p, w_ref)
+        same(loss_p, loss_ref)
+        same(g_p, g_ref)
+        if not zipf:   # the production path against the reference arithmetic: north_star's 1e-6
+            near_state(wu, w_ref, RTOL)
+            close(loss, loss_ref, rtol=RTOL)
+            near_state(g, g_ref, RTOL)
+    for a, e, p, r in zip(t.export(), s_exact.export(), t_par.export(), s_ref.export()):
         same(a, e)                                 # keys and every float: bit-exact
-        if a.dtype != np.uint64:
-            # two trajectories, 4 steps apart (see test_gpu_parity_tight for the one-step,
-            # derived bounds): measured distance <= 4.1e-5 with power-law heads, <= 1e-6 without
-            assert state_distance(a, r) <= (RTOL_HEAVY if zipf else 2 * RTOL)
+        same(p, r)                                 # ... and so is the reference-order mode
+        if a.dtype != np.uint64 and not zipf:
+            assert state_distance(a, r) <= 2 * RTOL
 
 
 def test_lr_forward_panel_kernel_bit_exact():
@@ -392,7 +401,11 @@ def test_fm_step_state(opt, k):
     tv = capi.Table(opt, k, init[0], init[1], seed=99, capacity=1 << 16)
     ref = (O.Store(opt, 1), O.Store(opt, k, init[0], init[1], 99))
     exact = (O.Store(opt, 1), O.Store(opt, k, init[0], init[1], 99))
+    pw = capi.Table(opt, 1, capacity=1 << 16)                      # stepped in parity mode
+    pv = capi.Table(opt, k, init[0], init[1], seed=99, capacity=1 << 16)
     ws = capi.Workspace()
+    ws_par = capi.Workspace()
+    ws_par.parity("reference_order")
     for step in range(3):
         heavy = step == 2
         rowptr, keys, labels = synth(rng, 500, 30, 4000, 1.3 if heavy else None, True)
@@ -402,20 +415,15 @@ def test_fm_step_state(opt, k):
         with O.sum_mode(1):
             O.fm_update(exact[0], exact[1], ob)
         capi.fm_step(tw, tv, b, ws)
-    for tt, se, sr in ((tw, exact[0], ref[0]), (tv, exact[1], ref[1])):
-        for a, e, r in zip(tt.export(), se.export(), sr.export()):
+        capi.fm_step(pw, pv, b, ws_par)
+    # two trajectories that start together and each follow their own arithmetic: the production
+    # path the exact sums', the parity mode the reference's (the pooled fp32 running sums of
+    # fm_worker.cc:178-192, whose noise grows with k: the two oracles are up to 4e-4 apart at
+    # k = 64 after these three steps) — each equal to its oracle bit for bit
+    for tt, tp, se, sr in ((tw, pw, exact[0], ref[0]), (tv, pv, exact[1], ref[1])):
+        for a, p, e, r in zip(tt.export(), tp.export(), se.export(), sr.export()):
             same(a, e)
-            if a.dtype != np.uint64:
-                # Two TRAJECTORIES (3 steps, the last one power-law) that start together and
-                # then each follow their own arithmetic: the reference pools v_sum over k x nnz
-                # terms in one fp32 running sum (fm_worker.cc:178-192), whose rounding noise
-                # grows with k and feeds back through the state.  Measured distances
-                # (max |a-r| / (|r| + rms r)) on MI355X: <= 2.0e-5 for k <= 16, 7.0e-5 at
-                # k = 32, 3.9e-4 at k = 64 (FTRL z after the power-law step); asserted at
-                # twice that.  The one-step derivation of the same noise is
-                # tests/test_gpu_parity_tight.py::test_fm_loss_against_reference_arithmetic.
-                d = state_distance(a, r)
-                assert d <= (8e-4 if k >= 64 else 1.5e-4 if k >= 32 else 4e-5), (k, d)
+            same(p, r)
 
 
 @pytest.mark.parametrize("opt,k", [(capi.OPT_FTRL, 8), (capi.OPT_SGD, 10)])
@@ -590,10 +598,15 @@ def test_worker_fm_sgd_and_small_blocks(sample_prefixes, tmp_path):
             same(gw[1], sw.export()[1])
             assert (np.float32(x.metric("logloss_ref")), np.float32(x.metric("auc"))) == \
                 (np.float32(ll), np.float32(auc))
-        else:           # reference arithmetic
-            near_state(gv[1], sv.export()[1], RTOL_HEAVY)
-            near_state(gw[1], sw.export()[1], RTOL_HEAVY)
-            close([x.metric("logloss_ref"), x.metric("auc")], [ll, auc], rtol=1e-5)
+        else:           # reference arithmetic: the worker in its parity mode, bit for bit too
+            xp = capi.XFlow(tr, te, model=1, optimizer="sgd", epochs=3, k=10, capacity=4096,
+                            parity="reference_order", pred_path=str(tmp_path / "pp.txt"))
+            xp.train()
+            pwh, pvh = xp.tables()
+            same(capi.Table.from_handle(pvh, 10, capi.OPT_SGD).export()[1], sv.export()[1])
+            same(capi.Table.from_handle(pwh, 1, capi.OPT_SGD).export()[1], sw.export()[1])
+            assert (np.float32(xp.metric("logloss_ref")), np.float32(xp.metric("auc"))) == \
+                (np.float32(ll), np.float32(auc))
 
 
 def test_worker_core_num_slices_and_growth(sample_prefixes, tmp_path):

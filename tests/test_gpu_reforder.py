@@ -1,10 +1,12 @@
 """Parity mode XF_PARITY_REFERENCE_ORDER on the GPU: the forward's row sums as fp32 running sums
 in the reference's own order (ascending fid, lr_worker.cc:127-138; FM: the k-outer pooled sums
-of fm_worker.cc:166-192).  The row sums' order is fully specified by the reference, so in this
-mode loss and pctr equal the oracle's REFERENCE-ARITHMETIC mode bit for bit — no tolerance.
-(The per-key gradient sums stay fp64: the reference's order inside a key is std::sort's.)
-Both sides start every step from the same state, so that one step's forward is compared
-alone."""
+of fm_worker.cc:166-192), and (round 4) the per-key gradient sums as fp32 running sums in the
+order the reference's own key build leaves a key's occurrences — std::sort of the row-major
+all_keys by fid (lr_worker.cc:150-162), run on the host once per minibatch.  In this mode loss,
+pctr, the gradients and the whole (w, n, z) state equal the oracle's REFERENCE-ARITHMETIC mode
+bit for bit over whole trajectories, power-law minibatches included — no tolerance anywhere.
+The first two tests compare one step's forward alone (same state imported on both sides before
+every step); the trajectory tests never re-synchronise."""
 import numpy as np
 import pytest
 
@@ -41,10 +43,41 @@ def test_lr_loss_is_the_reference_arithmetic_bit_for_bit(R, nnz, nkeys, zipf, ra
         capi.lr_step(t, b, ws)
         same(ws.fetch_loss(R), loss_ref)
         O.lr_update(s, ob)
-        # (the Push saw the reference's losses; its per-key sums are exact instead of the
-        # reference's fp32 running sums in std::sort's order: that difference has its derived
-        # per-key bound in test_gpu_parity_tight.py and is not this test's subject)
     t.check()
+
+
+@pytest.mark.parametrize("opt", ["ftrl", "sgd"])
+@pytest.mark.parametrize("R,nnz,nkeys,zipf,ragged", [
+    (3000, 200, 50000, None, False),
+    (30000, 40, 100000, 1.15, True),        # head keys with ~10^5 occurrences: long fp32 chains
+    (4000, 100, 3000, 1.05, True),          # large weights
+])
+def test_lr_trajectory_is_the_reference_arithmetic_bit_for_bit(R, nnz, nkeys, zipf, ragged, opt):
+    """six steps, three distinct minibatches replayed, a defrag in the middle, nothing
+    re-synchronised: gradients after every step and the final (w, n, z) table equal the
+    oracle's reference arithmetic (mode 0: fp32 running sums in the reference's orders)"""
+    rng = np.random.RandomState(R + nnz + 1)
+    go, oo = (capi.OPT_SGD, O.OPT_SGD) if opt == "sgd" else (capi.OPT_FTRL, O.OPT_FTRL)
+    t, s = capi.Table(go, 1, capacity=1 << 18), O.Store(oo, 1)
+    ws = capi.Workspace(capture=True)
+    ws.parity("reference_order")
+    raw = [synth(rng, R, nnz, nkeys, zipf, ragged) for _ in range(3)]
+    obs, bs = [O.Batch(*x) for x in raw], [capi.Batch(*x) for x in raw]
+    assert O.lib().xo_get_sum_mode() == 0
+    for step in range(6):
+        ob, b = obs[step % 3], bs[step % 3]
+        loss_ref, _ = ob.lr_loss(s.pull(ob.ukeys))
+        g_ref = ob.lr_grad(loss_ref)
+        O.lr_update(s, ob)
+        capi.lr_step(t, b, ws)
+        w_u, loss, g = ws.fetch(ob.U, R)
+        same(loss, loss_ref)
+        same(g, g_ref)
+        if step == 2:
+            t.defrag()
+    t.check()
+    for a, e in zip(t.export(), s.export()):
+        same(a, e)
 
 
 @pytest.mark.parametrize("k,opt", [(4, "sgd"), (16, "sgd"), (10, "ftrl"), (64, "ftrl")])
@@ -71,6 +104,40 @@ def test_fm_loss_is_the_reference_arithmetic_bit_for_bit(k, opt):
         O.fm_update(sw, sv, ob)
     tw.check()
     tv.check()
+
+
+@pytest.mark.parametrize("k,opt", [(4, "sgd"), (16, "sgd"), (10, "ftrl"), (64, "ftrl"),
+                                   (80, "sgd")])
+def test_fm_trajectory_is_the_reference_arithmetic_bit_for_bit(k, opt):
+    """FM: gw (the key's losses summed k times over, fm_worker.cc:140) and gv in the reference's
+    order and precision; both tables after five steps on uniform and power-law minibatches, a
+    defrag in between, equal the oracle's reference arithmetic"""
+    rng = np.random.RandomState(100 + k)
+    go, oo = (capi.OPT_SGD, O.OPT_SGD) if opt == "sgd" else (capi.OPT_FTRL, O.OPT_FTRL)
+    gi, oi = (capi.INIT_CONST, O.INIT_CONST) if opt == "sgd" else (capi.INIT_HASHNORM,
+                                                                    O.INIT_HASHNORM)
+    tw = capi.Table(go, 1, capacity=1 << 16)
+    tv = capi.Table(go, k, gi, 0.001, seed=7, capacity=1 << 16)
+    sw, sv = O.Store(oo, 1), O.Store(oo, k, oi, 0.001, 7)
+    ws = capi.Workspace()
+    ws.parity("reference_order")
+    R = 1500
+    raw = [synth(rng, R, 40, 8000, 1.3 if i % 2 else None, True) for i in range(2)]
+    obs, bs = [O.Batch(*x) for x in raw], [capi.Batch(*x) for x in raw]
+    for step in range(5):
+        ob, b = obs[step % 2], bs[step % 2]
+        loss_ref, _, _ = ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))
+        O.fm_update(sw, sv, ob)
+        capi.fm_step(tw, tv, b, ws)
+        same(ws.fetch_loss(R), loss_ref)
+        if step == 1:
+            tw.defrag()
+            tv.defrag()
+    tw.check()
+    tv.check()
+    for t, st in ((tw, sw), (tv, sv)):
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
 
 
 def test_worker_end_to_end_in_reference_order(sample_prefixes, tmp_path):

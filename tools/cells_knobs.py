@@ -20,9 +20,10 @@ def main():
     ap.add_argument("--zipf", type=float, default=0.0)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--signal-keys", type=int, default=0)
     a = ap.parse_args()
     args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=a.batches,
-                              zipf=a.zipf)
+                              zipf=a.zipf, signal_keys=a.signal_keys, keys_per_gpu=10_000_000)
     nkeys = 10_000_000
     keytab = capi.hash_decimal_range(0, nkeys)
     batches = bench.make_batches(args, 0, nkeys, keytab)

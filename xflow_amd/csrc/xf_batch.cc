@@ -336,7 +336,8 @@ void cells_free(xf_cells *c);
 
 extern "C" int xf_batch_free(xf_batch *b) {
   if (!b) return XF_OK;
-  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0] || b->d_uidx_sorted) {
+  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0] || b->d_uidx_sorted ||
+      b->d_ref_coo) {
     // kernels still running on the batch must finish first (hipFree used to imply that)
     (void)hipDeviceSynchronize();
   }
@@ -345,6 +346,7 @@ extern "C" int xf_batch_free(xf_batch *b) {
   if (b->d_raw) xf::blob_free(b->d_raw, b->d_raw_bytes);
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);
   if (b->d_uidx_sorted) (void)hipFree(b->d_uidx_sorted);
+  if (b->d_ref_coo) (void)hipFree(b->d_ref_coo);
   for (uint32_t *r : b->d_fm_rows)
     if (r) (void)hipFree(r);
   if (b->d_fm_ridx) (void)hipFree(b->d_fm_ridx);

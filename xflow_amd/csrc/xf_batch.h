@@ -30,6 +30,10 @@ struct xf_batch {
   // parity mode "reference order": every row's unique-key indices in ascending order (= in
   // ascending fid: the order of the reference's merge-join, lr_worker.cc:127-138), built once
   uint32_t *d_uidx_sorted = nullptr;
+  // ... and, for the gradient, the rows of every key's occurrences in the order the reference's
+  // own key build leaves them (std::sort by fid of the row-major all_keys, lr_worker.cc:150-162):
+  // [NNZ], grouped by key like view.coo_row (view.segptr holds the offsets)
+  uint32_t *d_ref_coo = nullptr;
   // FM: the unique keys' rows in the w and the v table, valid for one (uid, epoch) of each —
   // the Pulls of a replayed minibatch resolve nothing
   uint32_t *d_fm_rows[2] = {nullptr, nullptr};

@@ -521,4 +521,45 @@ int batch_sorted_uidx(xf_batch *b, hipStream_t s) {
   XF_HIP(hipStreamSynchronize(s));
   return XF_OK;
 }
+
+// The same mode, gradient side.  calculate_gradient (lr_worker.cc:104-118; FM: fm_worker.cc:
+// 134-148) adds a key's losses into an fp32 sum in the order the key's occurrences have in
+// all_keys AFTER `std::sort(all_keys.begin(), all_keys.end(), sort_finder)` (lr_worker.cc:162),
+// and sort_finder compares fids only (base.h:71-73): among equal fids the order is whatever
+// libstdc++'s introsort makes of this very input — all_keys filled row by row, sid = the row's
+// number in the slice (:150-161).  That order is reproduced by running that sort, on the host,
+// once per minibatch: over (unique-key index, sid) pairs — the key list ascends, so every
+// comparison has the outcome it has on the fids, and std::sort's moves depend on nothing else —
+// in the element layout of Base::sample_key.  Slow on purpose (a checking mode).
+int batch_reference_coo(xf_batch *b, hipStream_t s) {
+  XF_REQUIRE(b && !b->local, "reference-order parity mode needs a minibatch with a key list "
+             "(xf_batch_compile*)");
+  if (b->d_ref_coo || b->NNZ == 0) return XF_OK;
+  XF_TRY(xf_batch_upload(b, s));
+  if (b->on_device_only) XF_TRY(xf_batch_download(b));
+  struct SampleKey {  // base.h:65-69
+    size_t fgid;
+    size_t fid;
+    int sid;
+  };
+  std::vector<SampleKey> all_keys;
+  all_keys.reserve(b->NNZ);
+  for (uint32_t row = 0; row < b->R; ++row) {  // lr_worker.cc:150-161
+    SampleKey sk;
+    sk.fgid = 0;
+    sk.sid = (int)row;
+    for (uint32_t j = b->rowptr[row]; j < b->rowptr[row + 1]; ++j) {
+      sk.fid = b->uidx[j];
+      all_keys.push_back(sk);
+    }
+  }
+  std::sort(all_keys.begin(), all_keys.end(),
+            [](const SampleKey &a, const SampleKey &c) { return a.fid < c.fid; });  // :162
+  std::vector<uint32_t> coo(b->NNZ);
+  for (size_t j = 0; j < all_keys.size(); ++j) coo[j] = (uint32_t)all_keys[j].sid;
+  XF_HIP(hipMalloc((void **)&b->d_ref_coo, (size_t)b->NNZ * 4));
+  XF_HIP(hipMemcpyAsync(b->d_ref_coo, coo.data(), (size_t)b->NNZ * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return XF_OK;
+}
 }  // namespace xf

@@ -7,8 +7,8 @@
 //               against: state rows of a table on this GPU (mode kCellsTableRows), or the
 //               batch's own sorted-unique-key index (mode kCellsUidx, the multi-GPU worker side,
 //               where the weights arrive as a dense U-array from the owning shards).
-//   entry       (chunk number & 31) << 27 | (row within the window) << 11 | (position within
-//               the chunk)
+//   entry       (chunk number & kTagMask) << kTagShift | (row within the window) << kChunkBits |
+//               (position within the chunk)          [2048-position chunks: & 31, << 27, << 11]
 // and cellptr[nwin * nchunk + 1], the offsets of the cells in window-major order.  Inside a
 // cell the entries keep the row-major order of the input (the grouping is a stable sort on the
 // cell number), i.e. they are sorted by row.
@@ -42,9 +42,14 @@ constexpr int kChunkBits = XF_CHUNK_BITS;
 constexpr uint32_t kChunk = 1u << kChunkBits;  // index positions per chunk
 constexpr uint32_t kWinMax = XF_WIN_MAX;       // rows per window (136 KiB of fp64 in LDS)
 constexpr uint32_t kRowMask = 0x7FFFu;         // 15 bits of row-in-window
-constexpr int kTagShift = 27;                  // low 5 bits of the chunk number
+// the low bits of the chunk number ride in the bits the row and the position leave free: 5 of
+// them up to 4096-position chunks, 4 with 8192
+constexpr int kTagShift = kChunkBits + 15 > 27 ? kChunkBits + 15 : 27;
+constexpr uint32_t kTagMask = (1u << (32 - kTagShift)) - 1u;
+static_assert(kChunkBits >= 8 && kChunkBits <= 13, "chunk of 256 .. 8192 index positions");
 constexpr uint32_t kBlk = 1024;                // entries per forward block (blk_cell granule)
-constexpr uint32_t kSliceMax = 8192;           // entries one gradient workgroup takes of a chunk
+// entries one gradient workgroup takes of a chunk (a chunk with more is cut into slices)
+constexpr uint32_t kSliceMax = 4 * kChunk > 8192 ? 4 * kChunk : 8192;
 constexpr uint32_t kNoDump = 0xFFFFFFFFu;
 
 enum { kCellsTableRows = 0, kCellsUidx = 1 };

@@ -40,6 +40,7 @@ using xf::kSliceMax;
 using xf::kWinMax;
 using xf::kRowMask;
 using xf::kTagShift;
+using xf::kTagMask;
 
 constexpr int kBlock = 256;
 #ifndef XF_FWD_BLOCK
@@ -76,7 +77,7 @@ k_cell_keys(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ sr
       const uint32_t idx = map ? map[s] : s;
       const uint32_t chunk = (idx >> kChunkBits) - chunk0;
       cid[j] = v * nchunk + chunk;
-      ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
+      ent[j] = ((chunk & kTagMask) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
     }
   }
 }
@@ -193,7 +194,7 @@ k_cell_keys_rowid(const uint32_t *__restrict__ rowid, const uint32_t *__restrict
     const uint32_t r = rowid[j], v = r / W, rin = r - v * W;
     const uint32_t idx = src[j], chunk = (idx >> kChunkBits) - chunk0;
     cid[j] = v * nchunk + chunk;
-    ent[j] = ((chunk & 31u) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
+    ent[j] = ((chunk & kTagMask) << kTagShift) | (rin << kChunkBits) | (idx & (kChunk - 1));
   }
 }
 
@@ -248,13 +249,13 @@ __device__ __forceinline__ void fwd_process(const FwdBlock &B, uint32_t b, uint3
   // the block may begin in the window before and end in the one after
   const uint32_t lo = B.lo < c0 ? c0 : B.lo;
   const uint32_t hi = B.hi >= c0 + nchunk ? c0 + nchunk - 1 : B.hi;
-  const bool near = hi - lo < 32u;  // wave-uniform
+  const bool near = hi - lo <= kTagMask;  // wave-uniform
   float wv[kFwdE];
 #pragma unroll
   for (int q = 0; q < kFwdE; ++q) {
     const uint32_t e = B.ent[q];
     if (e == 0xFFFFFFFFu) continue;
-    const uint32_t cell = near ? lo + (((e >> kTagShift) - (lo - c0)) & 31u)
+    const uint32_t cell = near ? lo + (((e >> kTagShift) - (lo - c0)) & kTagMask)
                                : cell_of(cellptr, lo, hi, b * kBlk + q * 64 + lane);
     wv[q] = w[(size_t)(cell - c0) * kChunk + (e & (kChunk - 1))];
   }
@@ -415,7 +416,7 @@ constexpr int kGradE = XF_GRAD_E;  // entries per lane and round
 constexpr uint32_t kGradWin = 32;  // windows whose slice bounds fit the LDS table
 
 template <int OPT, int MODE, bool SRC, bool MULTI = false /* SRC with more than one source */>
-__global__ void __launch_bounds__(kBlock, MULTI ? XF_GRAD_MULTI_WAVES : 1)
+__global__ void __launch_bounds__(kBlock, MULTI ? XF_GRAD_MULTI_WAVES : SRC ? 1 : 6)
 k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
                 const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
@@ -423,14 +424,13 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
                 uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
                 const uint32_t *__restrict__ src_rows, uint32_t nsplit,
-                const uint32_t *__restrict__ loss_base, uint32_t chunk0, uint32_t only_split) {
+                const uint32_t *__restrict__ loss_base, uint32_t chunk0) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
   const uint32_t tid = threadIdx.x;
   const uint32_t c = item_chunk[blockIdx.x];
   const uint32_t sl = item_slice[blockIdx.x], s = sl & 0xFFFFu, S = sl >> 16;
-  if (only_split && S == 1) return;  // (k_lr_grad_dense has taken the unsplit chunks)
   for (uint32_t k = tid; k < kChunk; k += kBlock) {
     acc[k] = 0.0;
     touched[k] = 0;
@@ -605,23 +605,66 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       }
     continue;
   }
-  for (uint32_t k = tid; k < kChunk; k += kBlock) {
-    if (!touched[k]) continue;
-    const double sum = acc[k];
-    if (SRC) {  // the next worker's phase starts from zero
-      acc[k] = 0.0;
+  // eight keys per thread at a time in three sweeps — every state row requested, stepped,
+  // stored (k_lr_grad_dense below says why: row after row the stores keep the next row's loads
+  // from being issued early, one dependent trip to memory per key)
+  const size_t row0 = (size_t)(chunk0 + c) * kChunk;
+  if constexpr (SRC) {  // (several phases per chunk: the row-after-row loop keeps the registers
+                        // of the multi-source pass where they were)
+    for (uint32_t k = tid; k < kChunk; k += kBlock) {
+      if (!touched[k]) continue;
+      const double sum = acc[k];
+      acc[k] = 0.0;  // the next worker's phase starts from zero
       touched[k] = 0;
+      if (row0 + k >= M) continue;
+      const float g = xf::div_by_rows((float)sum, Rq);  // lr_worker.cc:117
+      if (g_out) g_out[row0 + k] = g;
+      if (MODE == 0) apply_key(T, OPT, row0 + k, g);
     }
-    const size_t idx = (size_t)(chunk0 + c) * kChunk + k;
-    if (idx >= M) continue;
-    const float g = xf::div_by_rows((float)sum, Rq);  // lr_worker.cc:117
-    if (g_out) g_out[idx] = g;
-    if (MODE == 0) apply_key(T, OPT, idx, g);
+  } else
+  for (uint32_t kb = 0; kb < kChunk; kb += kBlock * 8) {
+    bool t[8];
+    float g[8], sw[8], sn[8], sz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t k = kb + i * kBlock + tid;
+      t[i] = k < kChunk && touched[k] != 0;
+      g[i] = 0.0f;
+      if (t[i]) {
+        g[i] = xf::div_by_rows((float)acc[k], Rq);  // lr_worker.cc:117
+        t[i] = row0 + k < M;
+      }
+      if (MODE == 0) {  // (an idle slot loads the chunk's first row: no load under a branch)
+        const size_t r = t[i] ? row0 + k : row0;
+        sw[i] = T.w[r];
+        sn[i] = sz[i] = 0.0f;
+        if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (!t[i]) continue;
+      if (g_out) g_out[row0 + kb + i * kBlock + tid] = g[i];
+      if (MODE == 0) {
+        if (OPT == XF_OPT_FTRL)
+          xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
+        else
+          sw[i] = xf::sgd_step(T.lr, g[i], sw[i]);
+      }
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!t[i]) continue;
+        T.w[row0 + kb + i * kBlock + tid] = sw[i];
+        if (OPT == XF_OPT_FTRL) xf::store_nz(T, row0 + kb + i * kBlock + tid, sn[i], sz[i]);
+      }
+    }
   }
   }  // sources
 }
 
-// ---- the gradient + Push of the steady state: ONE source, an unsplit chunk, at most kDenseWin
+// ---- the gradient + Push of the steady state: ONE source, no split chunk, at most kDenseWin
 // row windows (config 2: three) — the launch that takes most of the LR step.  What the general
 // kernel above spends there (ISA count, 58 registers): ~140 VALU instructions per optimizer step
 // (two correctly rounded square roots, three correctly rounded divisions) + an fp64 division for
@@ -641,43 +684,72 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
 // Same sums (fp64 LDS atomics: exact, any order), same step (ftrl_step / sgd_step): the table
 // bits of the general kernel (tests/test_gpu_cells.py runs every variant against it).
 constexpr uint32_t kDenseWin = 4;
-enum { kDenseCompact = 1, kDensePrefetch = 2, kDenseWide = 4 };
+enum { kDenseCompact = 1, kDensePrefetch = 2, kDenseWide = 4,
+       // timing experiments only (WRONG results; reachable through exp_knob, never by default):
+       kDiagNoStore = 8,    // the optimizer steps run, nothing is stored
+       kDiagNoUpdate = 16,  // accumulate phase alone
+       kDiagNoAccum = 32,   // update phase alone (every row of the chunk takes a step, g = 0)
+       kDiagCopy = 64,      // with kDiagNoAccum: the state is loaded and stored, no arithmetic
+       kDenseFullStore = 128,    // every row of the chunk is stored back, touched or not (whole
+                                 // lines instead of byte-masked ones; same table afterwards)
+       kDenseQuad = 256 };       // four chunks per workgroup (see the kernel)
 #ifndef XF_GRAD_DENSE_VAR
-#define XF_GRAD_DENSE_VAR 1
+#define XF_GRAD_DENSE_VAR 128
 #endif
 
+// a chunk's team: 8 keys per thread (kDenseWide: 4), at most 1024 threads
+constexpr int dense_team(int var) {
+  return (int)kChunk / ((var & kDenseWide) ? 4 : 8) > 1024 ? 1024
+         : (int)kChunk / ((var & kDenseWide) ? 4 : 8) < 64 ? 64
+                                                            : (int)kChunk / ((var & kDenseWide) ? 4 : 8);
+}
+constexpr int dense_threads(int var) {
+  return dense_team(var) * ((var & kDenseQuad) ? 4 : 1) > 1024 ? 1024
+                                                               : dense_team(var) * ((var & kDenseQuad) ? 4 : 1);
+}
+
 template <int OPT, int VAR>
-__global__ void __launch_bounds__((VAR & kDenseWide) ? 512 : 256)
+__global__ void __launch_bounds__(dense_threads(VAR),
+                                  (VAR & kDenseCompact) ? 1 : 6 /* <= 80 registers */)
 k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
-                const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
-                const float *__restrict__ loss, uint32_t R, uint32_t M, uint32_t chunk0) {
-  constexpr int NT = (VAR & kDenseWide) ? 512 : 256;
+                const uint32_t *__restrict__ item_chunk, const float *__restrict__ loss,
+                uint32_t R, uint32_t M, uint32_t chunk0, uint32_t nitems) {
+  constexpr int NT = dense_team(VAR);                 // threads of a chunk's team
+  constexpr int SUB = (VAR & kDenseQuad) && NT * 4 <= 1024 ? 4 : 1;  // chunks per workgroup
   constexpr int kOwn = (int)(kChunk / NT);  // keys per thread = entries per lane and round
   constexpr int NW = NT / 64;
   constexpr uint32_t KW = kChunk / NW;      // keys per wavefront in the compaction
   constexpr bool COMPACT = (VAR & kDenseCompact) != 0;
   constexpr bool PREFETCH = !COMPACT && (VAR & kDensePrefetch) != 0;
-  __shared__ double acc[kChunk];
-  __shared__ uint8_t touched[kChunk];
-  __shared__ uint16_t list[COMPACT ? kChunk : 1];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t c = item_chunk[blockIdx.x];
-  if ((item_slice[blockIdx.x] >> 16) != 1u) return;  // a split chunk: the general kernel's
+  __shared__ double acc_all[SUB * kChunk];
+  __shared__ uint8_t touched_all[SUB * kChunk];
+  __shared__ uint16_t list_all[COMPACT ? SUB * kChunk : 1];
+  // kDenseQuad: four teams, four consecutive chunks, one workgroup.  The teams walk the row
+  // windows' losses side by side, so a line of losses that one team's gather brings into the
+  // CU's L1 serves the other three (the L1's misses in flight x their latency is what bounds
+  // this kernel: 6.0 M read requests to L2 per launch, 4.4 M of them loss gathers).
+  const uint32_t team = SUB > 1 ? threadIdx.x / NT : 0u, tid = SUB > 1 ? threadIdx.x % NT : threadIdx.x;
+  double *acc = acc_all + team * kChunk;
+  uint8_t *touched = touched_all + team * kChunk;
+  uint16_t *list = list_all + (COMPACT ? team * kChunk : 0);
+  const uint32_t item = blockIdx.x * SUB + team;
+  const bool live = item < nitems;  // (the last workgroup's spare teams only keep the barriers)
+  const uint32_t c = item_chunk[live ? item : blockIdx.x * SUB];  // (no chunk is split)
   const size_t row0 = (size_t)(chunk0 + c) * kChunk;
+  if (!live) M = 0;  // no row of a spare team is in range: nothing accumulated, nothing stored
   float sw[kOwn], sn[kOwn], sz[kOwn];
   if constexpr (PREFETCH) {
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
-      sw[i] = sn[i] = sz[i] = 0.0f;
-      if (row0 + tid + i * NT < M) {
-        sw[i] = T.w[row0 + tid + i * NT];
-        if (OPT == XF_OPT_FTRL) xf::load_nz(T, row0 + tid + i * NT, sn[i], sz[i]);
-      }
+      const size_t r = row0 + tid + i * NT < M ? row0 + tid + i * NT : row0;
+      sw[i] = T.w[r];
+      sn[i] = sz[i] = 0.0f;
+      if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
     }
   }
   // the chunk's cells: window v holds entries [cb[v], cb[v] + (cum[v + 1] - cum[v]))
-  uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0, c1 = 0, c2 = 0, c3 = 0, total = 0;
+  uint32_t cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0, c1 = 0, c2 = 0, c3 = 0, total = 0;  // NOLINT
   {
     uint32_t b, e;
     b = cellptr[c], e = cellptr[c + 1], cb0 = b, c1 = e - b, c2 = c3 = total = c1;
@@ -693,6 +765,11 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
   if (tid < kChunk / 4) ((uint32_t *)touched)[tid] = 0u;
   if (NT < (int)(kChunk / 4) && tid + NT < kChunk / 4) ((uint32_t *)touched)[tid + NT] = 0u;
   __syncthreads();
+  if (!live) total = 0;
+  if constexpr (VAR & kDiagNoAccum) {
+    total = 0;
+    for (uint32_t k = tid; k < kChunk; k += NT) touched[k] = 1;
+  }
   for (uint32_t p0 = 0; p0 < total; p0 += NT * kOwn) {  // workgroup-uniform trip count
     uint32_t ent[kOwn], lidx[kOwn];
     float l[kOwn];
@@ -716,10 +793,19 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), l[q]);
   }
   __syncthreads();
+  if constexpr (VAR & kDiagNoUpdate) {
+    if (acc[tid] == 12345.0) T.w[row0] = 0.0f;  // (keeps the sums alive)
+    return;
+  }
+  // The optimizer steps in three sweeps — request every state row, step, store — so that a
+  // thread's rows are all in flight together.  (Row after row — load, step, store, next — the
+  // stores to T.w keep the compiler from moving the next row's loads up: eight dependent trips
+  // to memory per thread, 10 of the ~35 us a workgroup lived.)
   if constexpr (COMPACT) {
     // wavefront w lists the touched keys among [w * KW, (w + 1) * KW), ascending, in its own
     // part of `list` (LDS operations of one wavefront execute in order: no barrier), then takes
-    // them 64 at a time
+    // them 64 at a time with every lane busy
+    constexpr int kSlots = (int)(KW / 64);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint16_t *wl = list + wave * KW;
     uint32_t cnt = 0;
@@ -734,28 +820,71 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t p = lane; p < cnt; p += 64) {
-      const uint32_t k = wl[p];
-      const float g = xf::div_by_rows((float)acc[k], R);  // lr_worker.cc:117
-      apply_key(T, OPT, row0 + k, g);
+    uint32_t kk[kSlots];
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+      const uint32_t p = lane + 64u * i;
+      kk[i] = p < cnt ? (uint32_t)wl[p] : 0xFFFFFFFFu;
+      // (an idle slot loads the chunk's first row: a load under a branch would have to be
+      // waited for where the branch ends, one slot after the other)
+      const size_t r = row0 + (kk[i] != 0xFFFFFFFFu ? kk[i] : 0u);
+      sw[i] = T.w[r];
+      sn[i] = sz[i] = 0.0f;
+      if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+      if (kk[i] == 0xFFFFFFFFu) continue;
+      const float g = xf::div_by_rows((float)acc[kk[i]], R);  // lr_worker.cc:117
+      if (OPT == XF_OPT_FTRL)
+        xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+      else
+        sw[i] = xf::sgd_step(T.lr, g, sw[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+      if (kk[i] == 0xFFFFFFFFu) continue;
+      T.w[row0 + kk[i]] = sw[i];
+      if (OPT == XF_OPT_FTRL) xf::store_nz(T, row0 + kk[i], sn[i], sz[i]);
     }
   } else {
+    bool t[kOwn];
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
       const uint32_t k = tid + i * NT;
-      if (!touched[k] || row0 + k >= M) continue;
-      const float g = xf::div_by_rows((float)acc[k], R);  // lr_worker.cc:117
-      if constexpr (PREFETCH) {
-        if (OPT == XF_OPT_FTRL) {
-          xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
-          T.w[row0 + k] = sw[i];
-          xf::store_nz(T, row0 + k, sn[i], sz[i]);
-        } else {
-          T.w[row0 + k] = xf::sgd_step(T.lr, g, sw[i]);
-        }
-      } else {
-        apply_key(T, OPT, row0 + k, g);
+      t[i] = touched[k] != 0 && row0 + k < M;
+      if constexpr (!PREFETCH) {  // (unconditional, see above; row0 itself is below M)
+        const size_t r = (t[i] || ((VAR & kDenseFullStore) && row0 + k < M)) ? row0 + k : row0;
+        sw[i] = T.w[r];
+        sn[i] = sz[i] = 0.0f;
+        if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+      if (!t[i] || (VAR & kDiagCopy)) continue;
+      const float g = xf::div_by_rows((float)acc[tid + i * NT], R);  // lr_worker.cc:117
+      if (OPT == XF_OPT_FTRL)
+        xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+      else
+        sw[i] = xf::sgd_step(T.lr, g, sw[i]);
+    }
+    if constexpr (VAR & kDiagNoStore) {
+      float x = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kOwn; ++i) x += sw[i] + sn[i] + sz[i];
+      if (x == 12345.0f) T.w[row0] = x;  // (keeps the steps alive)
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+      if constexpr (VAR & kDenseFullStore) {
+        if (row0 + tid + i * NT >= M) continue;
+      } else {
+        if (!t[i]) continue;
+      }
+      T.w[row0 + tid + i * NT] = sw[i];
+      if (OPT == XF_OPT_FTRL) xf::store_nz(T, row0 + tid + i * NT, sn[i], sz[i]);
     }
   }
 }
@@ -1029,30 +1158,35 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                        s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                        src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0, 0u);
+                       c->chunk0);
   else if (src)
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                        src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0, 0u);
+                       c->chunk0);
   else {
     // one source: the unsplit chunks go to k_lr_grad_dense (gradient + Push, no dense copy of
     // the gradients wanted, few windows), the general kernel keeps the split ones
     bool dense = false;
     if constexpr (MODE == 0) {
-      if (!d_g && c->nwin <= kDenseWin) {
+      // (a minibatch with split chunks stays with the general kernel: its long unsplit chunks
+      // and the slices of the split ones share one launch there; two launches one after the other
+      // add their tails — Zipf 1.1: 118 us instead of 88)
+      if (!d_g && c->nwin <= kDenseWin && c->nsplit_chunks == 0) {
         int var = XF_GRAD_DENSE_VAR;
         const int knob = exp_knob();
-        if (knob >= 300 && knob < 308) var = knob - 300;  // (experiments: tools/cells_knobs.py)
-        dense = knob != 399;                               // 399: the general kernel alone
+        if (knob >= 300 && knob < 812) var = knob - 300;  // (experiments: tools/cells_knobs.py)
+        dense = knob != 299;                               // 299: the general kernel alone
         if (dense) {
 #define XF_DENSE(V)                                                                              \
   case V:                                                                                        \
-    hipLaunchKernelGGL((k_lr_grad_dense<OPT, V>), dim3(c->nitems),                               \
-                       dim3(((V) & kDenseWide) ? 512 : 256), 0, s, T, c->entries, c->cellptr,    \
-                       c->nchunk, c->nwin, c->W, c->item_chunk, c->item_slice, d_loss, c->R,     \
-                       c->M, c->chunk0);                                                         \
+    hipLaunchKernelGGL((k_lr_grad_dense<OPT, V>),                                                \
+                       dim3(((V) & kDenseQuad) && dense_team(V) * 4 <= 1024 ? (c->nitems + 3) / 4 \
+                                                                            : c->nitems),        \
+                       dim3(dense_threads(V)), 0,                                                \
+                       s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
+                       d_loss, c->R, c->M, c->chunk0, c->nitems);                                \
     break
           switch (var) {
             XF_DENSE(0);
@@ -1061,6 +1195,20 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
             XF_DENSE(4);
             XF_DENSE(5);
             XF_DENSE(6);
+            XF_DENSE(8);        // timing experiments (wrong results)
+            XF_DENSE(16);
+            XF_DENSE(32);
+            XF_DENSE(32 + 64);
+            XF_DENSE(32 + 8);
+            XF_DENSE(128);
+            XF_DENSE(128 + 4);
+            XF_DENSE(256);
+            XF_DENSE(256 + 128);
+            XF_DENSE(256 + 1);
+            XF_DENSE(256 + 16);
+            XF_DENSE(4 + 16);
+            XF_DENSE(4 + 32);
+            XF_DENSE(4 + 32 + 64);
             default:
               return xf::set_error(XF_EINVAL, "gradient kernel variant %d", var);
           }
@@ -1068,12 +1216,12 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
         }
       }
     }
-    if (!dense || c->nsplit_chunks)
+    if (!dense)
       hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
                          T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                          c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
                          (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
-                         (const uint32_t *)nullptr, c->chunk0, dense ? 1u : 0u);
+                         (const uint32_t *)nullptr, c->chunk0);
   }
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),

@@ -950,7 +950,7 @@ k_kb_resolve(KbArgs a) {
       const uint32_t cl = p >> kChunkBits, c = (S << kSCShift) + cl;
       const uint32_t v = rp[q] >> kRinBits, rin = rp[q] & ((1u << kRinBits) - 1u);
       cell[q] = local ? (v << kSCShift) + cl : v * a.cA + c;
-      ent[q] = found ? ((c & 31u) << kTagShift) | (rin << kChunkBits) | (p & (kChunk - 1))
+      ent[q] = found ? ((c & xf::kTagMask) << kTagShift) | (rin << kChunkBits) | (p & (kChunk - 1))
                      : kHole;
       miss[q] = ok[q] && !found && !(a.flags & 8);
     }

@@ -43,6 +43,7 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
                          hipStream_t s);
 int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s);
 int batch_sorted_uidx(xf_batch *b, hipStream_t s);
+int batch_reference_coo(xf_batch *b, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -1124,6 +1125,72 @@ k_fm_forward_reforder(const uint32_t *__restrict__ rowptr, const uint32_t *__res
   vsum_out[r] = vs;
 }
 
+// ------------------------------------------------ reference-order gradient (parity mode 1)
+// calculate_gradient as written: a key's gradient is an fp32 running sum over its occurrences
+// in the order of the sorted all_keys (xf_batch_dev.hip: batch_reference_coo has that order),
+// then `/= 1.0 * rows` (lr_worker.cc:104-118).  One wavefront per key: it fetches 64
+// occurrences at a time and adds them one after the other (the adds are the dependent chain,
+// the loads are not).  The optimizer step on the result is the ordinary Push
+// (xf_table_update_dev), so g, w, n, z equal the oracle's reference arithmetic bit for bit.
+__global__ void __launch_bounds__(kBlock)
+k_lr_grad_reforder(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo,
+                   const float *__restrict__ loss, uint32_t U, uint32_t R,
+                   float *__restrict__ g_out) {
+#pragma clang fp contract(off)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t u = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; u < U; u += nw) {
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    float acc = 0.0f;  // push_gradient starts at 0 (lr_worker.cc:168)
+    for (uint32_t j0 = b; j0 < e; j0 += 64) {
+      const uint32_t n = min(64u, e - j0);
+      const float v = lane < n ? loss[coo[j0 + lane]] : 0.0f;
+      for (uint32_t i = 0; i < n; ++i) acc = acc + __shfl(v, (int)i);  // :111
+    }
+    if (lane == 0) g_out[u] = div_by_rows(acc, R);  // :117
+  }
+}
+
+// fm_worker.cc:134-156: k outer; inside it every occurrence adds loss[sid] to gw (so gw runs
+// through the key's occurrences k times) and loss[sid] * (v_sum[sid] - v[i,k]) to gv[i,k].
+// One wavefront per key, lane = factor (k > 64: in rounds of 64); the gw chain is carried by
+// every lane alike.
+__global__ void __launch_bounds__(kBlock)
+k_fm_grad_reforder(const uint32_t *__restrict__ segptr, const uint32_t *__restrict__ coo,
+                   const float *__restrict__ loss, const float *__restrict__ vsum,
+                   const float *__restrict__ vu, int k, uint32_t U, uint32_t R,
+                   float *__restrict__ gw_out, float *__restrict__ gv_out) {
+#pragma clang fp contract(off)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nw = gridDim.x * (kBlock / 64);
+  for (uint32_t u = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; u < U; u += nw) {
+    const uint32_t b = segptr[u], e = segptr[u + 1];
+    float gw = 0.0f;
+    for (int k0 = 0; k0 < k; k0 += 64) {
+      const int kk = k0 + (int)lane;
+      const float vk = kk < k ? vu[(size_t)u * k + kk] : 0.0f;
+      float gv = 0.0f;
+      for (uint32_t j0 = b; j0 < e; j0 += 64) {
+        const uint32_t n = min(64u, e - j0);
+        const uint32_t sid = lane < n ? coo[j0 + lane] : 0u;
+        const float l = lane < n ? loss[sid] : 0.0f, vs = lane < n ? vsum[sid] : 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+          const float li = __shfl(l, (int)i), vi = __shfl(vs, (int)i);
+          gv = gv + li * (vi - vk);  // :141-142
+        }
+      }
+      if (kk < k) gv_out[(size_t)u * k + kk] = div_by_rows(gv, R);  // :153-155
+    }
+    for (int kk = 0; kk < k; ++kk)  // :140, once per factor
+      for (uint32_t j0 = b; j0 < e; j0 += 64) {
+        const uint32_t n = min(64u, e - j0);
+        const float l = lane < n ? loss[coo[j0 + lane]] : 0.0f;
+        for (uint32_t i = 0; i < n; ++i) gw = gw + __shfl(l, (int)i);
+      }
+    if (lane == 0) gw_out[u] = div_by_rows(gw, R);  // :150-152
+  }
+}
+
 // ------------------------------------------------------------------------ C entry points
 extern "C" int xf_lr_forward_dev(const xf_dev_batch *b, const float *d_wu, float *d_loss,
                                  float *d_pctr, void *stream) {
@@ -1764,6 +1831,20 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
     XF_TRY(xf::cells_lr_forward(c, T.w, labels, ws->partial, ws->loss, nullptr, S(stream)));  // :172
   XF_END(kEvForward);
   if (cap) XF_TRY(xf::gather_f32(T.w, b->d_rows_u, b->U, ws->wu, S(stream)));
+  if (ws->parity == XF_PARITY_REFERENCE_ORDER) {
+    // the reference's own fp32 running sums per key, then the Push as the server does it
+    XF_TRY(xf::batch_reference_coo(b, S(stream)));
+    if (b->U) {
+      hipLaunchKernelGGL(k_lr_grad_reforder, dim3(blocks_for_groups(b->U, kBlock / 64)),
+                         dim3(kBlock), 0, S(stream), b->view.segptr, b->d_ref_coo, ws->loss, b->U,
+                         b->R, ws->g);  // :173
+      XF_HIP(hipGetLastError());
+      XF_TRY(xf_table_update_dev(w, b->d_rows_u, b->U, ws->g, stream));  // :175
+    }
+    XF_END(kEvGrad);
+    if (ws->rec) ws->sets[ws->cur].pending = true;
+    return XF_OK;
+  }
   // gradient (:173) + Push (:175) in one pass over the cells
   XF_TRY(xf::cells_lr_grad_update(c, w, ws->loss, cap ? ws->gdense : nullptr, S(stream)));
   XF_END(kEvGrad);
@@ -1946,6 +2027,19 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
       XF_TRY(xf_fm_forward_dev(&v, k, ws->wu, ws->vu, ws->loss, nullptr, ws->vsum, stream));
   }
   XF_END(kEvForward);
+  if (ws->parity == XF_PARITY_REFERENCE_ORDER && v.U) {
+    // the reference's own fp32 running sums per key and factor, then the two Pushes
+    XF_TRY(xf::batch_reference_coo(b, S(stream)));
+    hipLaunchKernelGGL(k_fm_grad_reforder, dim3(blocks_for_groups(v.U, kBlock / 64)), dim3(kBlock),
+                       0, S(stream), v.segptr, b->d_ref_coo, ws->loss, ws->vsum, ws->vu, k, v.U,
+                       v.R, ws->g, ws->gv);  // :238
+    XF_HIP(hipGetLastError());
+    XF_TRY(xf_table_update_dev(w, rows_w, v.U, ws->g, stream));    // :241
+    XF_TRY(xf_table_update_dev(vt, rows_v, v.U, ws->gv, stream));  // :242
+    XF_END(kEvGrad);
+    if (ws->rec) ws->sets[ws->cur].pending = true;
+    return XF_OK;
+  }
   // gradient (:238) and the two Pushes (:241-242) in one pass: both tables are on this GPU
   XF_TRY(fm_grad_update(w, vt, &v, rows_w, rows_v, ws->wu, ws->vu, ws->vsum, ws->loss,
                         ws->g, ws->gv, false, stream));
