@@ -1225,7 +1225,7 @@ def main():
         except Exception as e:   # the LR line must not depend on this extra
             out["fm"] = {"error": str(e)}
     if args.pmc_calibrate:
-        for kind in range(6):
+        for kind in range(10):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, batches, held)

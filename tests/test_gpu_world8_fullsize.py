@@ -38,7 +38,7 @@ ROWS = int(os.environ.get("XF_WORLD8_ROWS", "50000"))
 # configs[4]: the GLOBAL minibatch is north_star's 10^7 nonzeros (8 ranks x 6250 rows x 200;
 # "per-GPU sub-batch 1.25*10^6 nnz (global 10^7)") — the oracle's
 # k = 64 passes over 8 x 10^7 nonzeros per step would take ten minutes of CPU
-ROWS_FM = int(os.environ.get("XF_WORLD8_FM_ROWS", str(max(1, ROWS // 8))))
+ROWS_FM = int(os.environ.get("XF_WORLD8_FM_ROWS", str(ROWS)))
 NNZ = 200
 STEPS = 2
 

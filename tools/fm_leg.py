@@ -28,7 +28,7 @@ def main():
         print(json.dumps(out), flush=True)
     if args.pmc_calibrate:   # known byte counts for the rocprofv3 --pmc passes
         import ctypes  # noqa: F401
-        for kind in range(6):
+        for kind in range(10):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
         print(json.dumps({"config": {"workload": out["workload"]}}), flush=True)
 

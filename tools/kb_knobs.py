@@ -80,7 +80,7 @@ def main():
     capi.tune("exp_knob", 0)
     tr.check()
     if a.pmc_calibrate:
-        for kind in range(6):
+        for kind in range(10):
             capi.check(L.xf_calib_stream(kind, 1 << 30, 3))
     print(json.dumps({"config": {"workload": "key build: LR+FTRL, %d keys settled, %d rows x %d "
                                  "nnz per minibatch%s" % (a.keys, a.rows, a.nnz_per_row,

@@ -32,12 +32,40 @@ __global__ void __launch_bounds__(256) k_calib_write(T *__restrict__ p, size_t n
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+// Gathers with a known footprint: unit u (BYTES bytes, BYTES-aligned) of the buffer is read
+// exactly once per launch, the units in a pseudo-random order (a bijection of [0, n) when n is
+// a power of two: an odd multiplier), LANES lanes of a wavefront sharing a unit.  One unit per
+// 128-byte line (STRIDE = 128) for the 4-byte gather: every line is touched once and 4 of its
+// bytes are used — what a divergent gather of weights / losses does to the memory system.
+template <int BYTES, int STRIDE>
+__global__ void __launch_bounds__(256) k_calib_gather(const unsigned char *__restrict__ p, size_t n,
+                                                      unsigned long long *sink) {
+  constexpr int LANES = BYTES >= 16 ? BYTES / 16 : 1;   // lanes per unit (16 bytes each)
+  constexpr int PER = BYTES >= 16 ? 16 : BYTES;         // bytes per lane
+  const size_t stride = (size_t)gridDim.x * blockDim.x / LANES;
+  unsigned long long acc = 0;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES; i < n; i += stride) {
+    const size_t u = (i * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull) & (n - 1);
+    const unsigned char *q = p + u * STRIDE + (threadIdx.x % LANES) * PER;
+    if constexpr (PER == 16) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(q);
+      acc += v.x + v.y + v.z + v.w;
+    } else {
+      acc += *reinterpret_cast<const unsigned int *>(q);
+    }
+  }
+  if (acc == 0x123456789abcdefull) *sink = acc;
+}
+
 }  // namespace
 
 // kind: 0 read 4 B/lane, 1 read 8 B/lane, 2 read 16 B/lane, 3 write 4 B/lane, 4 write 8 B/lane,
-// 5 write 16 B/lane.  Streams `bytes` bytes of an internal scratch buffer `repeat` times.
+// 5 write 16 B/lane: streams `bytes` bytes of an internal scratch buffer `repeat` times.
+// 6 gather 4 B from every 128-byte line, 7 gather 32-byte records, 8 gather 64-byte rows,
+// 9 gather 256-byte rows: every unit of the buffer (its largest power-of-two part) once, in
+// a pseudo-random order.
 extern "C" int xf_calib_stream(int kind, size_t bytes, int repeat) {
-  XF_REQUIRE(kind >= 0 && kind <= 5 && bytes >= 4096 && repeat >= 1, "xf_calib_stream: bad argument");
+  XF_REQUIRE(kind >= 0 && kind <= 9 && bytes >= 4096 && repeat >= 1, "xf_calib_stream: bad argument");
   static void *buf = nullptr;
   static size_t cap = 0;
   static unsigned long long *sink = nullptr;
@@ -58,6 +86,15 @@ extern "C" int xf_calib_stream(int kind, size_t bytes, int repeat) {
       case 3: hipLaunchKernelGGL(k_calib_write<uint32_t>, g, b, 0, 0, (uint32_t *)buf, bytes / 4, 7u); break;
       case 4: hipLaunchKernelGGL(k_calib_write<uint64_t>, g, b, 0, 0, (uint64_t *)buf, bytes / 8, (uint64_t)7); break;
       case 5: hipLaunchKernelGGL(k_calib_write<uint4>, g, b, 0, 0, (uint4 *)buf, bytes / 16, make_uint4(7, 7, 7, 7)); break;
+      default: {
+        size_t pow2 = 4096;
+        while (pow2 * 2 <= bytes) pow2 *= 2;
+        const unsigned char *q = (const unsigned char *)buf;
+        if (kind == 6) hipLaunchKernelGGL((k_calib_gather<4, 128>), g, b, 0, 0, q, pow2 / 128, sink);
+        if (kind == 7) hipLaunchKernelGGL((k_calib_gather<32, 32>), g, b, 0, 0, q, pow2 / 32, sink);
+        if (kind == 8) hipLaunchKernelGGL((k_calib_gather<64, 64>), g, b, 0, 0, q, pow2 / 64, sink);
+        if (kind == 9) hipLaunchKernelGGL((k_calib_gather<256, 256>), g, b, 0, 0, q, pow2 / 256, sink);
+      }
     }
     XF_HIP(hipGetLastError());
   }
