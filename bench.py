@@ -64,7 +64,7 @@ def parse_args():
                     help="after the run, stream known byte counts (for rocprofv3 --pmc passes)")
     ap.add_argument("--key-build-steps", type=int, default=10,
                     help="extra timed steps that include the GPU key build (0 = skip)")
-    ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1", "owner"],
+    ap.add_argument("--schedule", default=None, choices=[None, "sequential", "stale1", "owner", "owner_stale1"],
                     help="N>1: order of Push(t) and Pull(t+1); default stale1 (overlapped).  "
                          "owner = the owner-compute dataflow (native driver; FM: sum_then_step)")
     ap.add_argument("--no-defrag", action="store_true")
@@ -684,7 +684,8 @@ class NativeSharded:
         self.capi = capi
         self.group = group
         # FM on the owner-compute dataflow exists as sum_then_step only
-        self.update = update or ("sum_then_step" if args.model == "fm" and schedule == "owner"
+        self.update = update or ("sum_then_step" if args.model == "fm" and
+                                 schedule.startswith("owner")
                                  else "rank_ordered")
         self.st = capi.Sharded(group, model=args.model, optimizer=args.optimizer, k=args.k,
                                capacity=capacity, schedule=schedule, seed=7, update=self.update)
@@ -826,9 +827,12 @@ def main():
     elif args.schedule:
         schedule = args.schedule
     elif args.model == "lr" and group is not None and owner_dataflow_smoke(group, args, keytab):
-        schedule = "owner"
+        # ... overlapped (north_star: the Pushes of a step on a second HIP stream under the next
+        # step's exchanges); the same K steps without the overlap are timed after it
+        schedule = "owner_stale1"
     else:
         schedule = "stale1"
+    owner_df = schedule.startswith("owner")
     if not sharded:
         from xflow_amd.single import SingleGpuTrainer
         trainer = SingleGpuTrainer(model=args.model, optimizer=args.optimizer, k=args.k,
@@ -941,6 +945,7 @@ def main():
         barrier()
         rep_ms.append(allmax(time.perf_counter() - t1) / args.steps * 1e3)
     trainer.check()
+    unoverlapped_ms = None
     kernel_timing = "HIP events on the step's stream inside the timed region (every 4th step " \
                     "records, into a ring of event sets: the host never waits for a step it " \
                     "has just launched; the averages are over those sampled steps, so their " \
@@ -949,7 +954,7 @@ def main():
         # the overlapped schedule runs two streams: per-kernel events are taken in a short
         # sequential pass after the timed region instead
         if hasattr(trainer, "set_schedule"):
-            trainer.set_schedule("sequential")
+            trainer.set_schedule("owner" if owner_df else "sequential")
         else:
             trainer.schedule = "sequential"
         trainer.profile(True)
@@ -961,6 +966,15 @@ def main():
         trainer.check()
         kernel_timing = "HIP events in a sequential pass of 8 steps after the timed region " \
                         "(the timed region overlaps two streams)"
+        if owner_df:   # the same K steps without the overlap (not `value`)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                trainer.step(compiled[(args.warmup + i) % len(compiled)])
+            trainer.flush()
+            barrier()
+            unoverlapped_ms = allmax(time.perf_counter() - t1) / args.steps * 1e3
+            trainer.check()
     dt = allmax(dt)
     # ... and after the last step (warm-up + the K timed steps + the repeats)
     steps_trained = args.warmup + args.steps * (1 + args.repeats)
@@ -987,7 +1001,7 @@ def main():
     # trainer over the same group.  Not `value`; every rank takes part; a failure is reported,
     # not raised (it is symmetric across the ranks: the condition depends on the arguments only).
     owner_leg = None
-    other = "stale1" if schedule == "owner" else "owner"
+    other = "stale1" if owner_df else "owner"
     if group is not None and args.model == "lr" and not args.no_owner_leg \
             and (world > 1 or args.general_path):
         try:
@@ -1045,7 +1059,7 @@ def main():
     # LRWorker::update on the ranks' minibatches laid end to end) instead of one per rank.  The
     # owner's gradient + Push pass then is the one-source pass whatever N.  Not `value`.
     sum_leg = None
-    if group is not None and args.model == "lr" and schedule == "owner" and world > 1 \
+    if group is not None and args.model == "lr" and owner_df and world > 1 \
             and not args.no_owner_leg:
         try:
             st2 = NativeSharded(group, args, "owner", capacity, update="sum_then_step")
@@ -1123,7 +1137,7 @@ def main():
     one_shard = world == 1 and not (args.force_sharded and
                                     (args.general_path or args.driver == "python"))
     # (the owner-compute dataflow runs the same table-resident kernels at the key owners)
-    fused = args.model == "lr" and (one_shard or schedule == "owner")
+    fused = args.model == "lr" and (one_shard or owner_df)
     per, survey_bytes = bytes_model(args.model, args.k, R, NNZ, U, args.optimizer, fused,
                                     fused_fm=(args.model == "fm" and one_shard))
     dom = max((k for k in avg_ms if k in per), key=lambda k: avg_ms[k])
@@ -1166,7 +1180,10 @@ def main():
                    "table_keys_touched": touched,
                    "parallelism": ("key-range sharded table x%d, %s" % (
                        world, "owner-compute dataflow: nonzeros at the key owners, fp64 partial "
-                              "row sums and losses all-to-all-v per step" if schedule == "owner"
+                              "row sums and losses all-to-all-v per step%s" % (
+                                  "; gradient + Pushes of step t on a second HIP stream under the "
+                                  "exchanges of step t+1 (weights one step stale)"
+                                  if schedule == "owner_stale1" else "") if owner_df
                        else "all-to-all of weights and gradients per step, schedule %s" % schedule))
                    if sharded else "single shard",
                    "exchange": exchange,
@@ -1199,7 +1216,8 @@ def main():
             "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})(
             NNZ * (12 + (4 * args.k if args.model == "fm" else 0)) + 8 * R,
             sum(avg_ms.get(k, 0.0) for k in ("resolve", "gather", "a2a_weights", "forward"))),
-        ("exchange_dataflow" if schedule == "owner" else "owner_compute"): owner_leg,
+        ("exchange_dataflow" if owner_df else "owner_compute"): owner_leg,
+        "owner_compute_without_overlap_ms_per_step": unoverlapped_ms,
         "owner_compute_sum_then_step": sum_leg,
         "step_bytes_survey_8d": survey_bytes,
         "step_gbs_survey_8d": survey_bytes / (ms_per_step * 1e-3) / 1e9,

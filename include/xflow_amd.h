@@ -421,6 +421,14 @@ int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape);
  * back) instead of a weight and a gradient per key.  Same results as XF_SCHEDULE_SEQUENTIAL
  * (every worker's gradient its own optimizer step, applied in rank order). */
 #define XF_SCHEDULE_OWNER 2
+/* The owner-compute dataflow with the gradient + Pushes of step t on a second HIP stream under
+ * the exchanges of step t+1 (north_star: "overlapped with the next batch's forward on a second
+ * HIP stream"): forward(t+1) reads the table BEFORE the Pushes of step t land, they are applied
+ * while the row sums and losses of step t+1 travel, and forward(t+2) waits for them — weights
+ * exactly one step stale, deterministic (events order the table's reader and writer), inside
+ * ps-lite's asynchronous semantics; the results of XF_SCHEDULE_STALE1.  Same compiled
+ * minibatches as XF_SCHEDULE_OWNER (xf_sharded_set_schedule switches between the two). */
+#define XF_SCHEDULE_OWNER_STALE1 3
 typedef struct {
   int32_t model;     /* 0 LR, 1 FM */
   int32_t optimizer; /* XF_OPT_* */
@@ -435,8 +443,8 @@ typedef struct {
    *                           step, applied in rank order — one legal ps-lite interleaving
    *   XF_UPDATE_SUM_THEN_STEP the workers' sums added, ONE step with 1 / (all rows): the result
    *                           of one update() on the concatenation of the ranks' minibatches,
-   *                           whatever the number of GPUs (XF_SCHEDULE_OWNER only: there the
-   *                           sums meet exactly, in fp64) */
+   *                           whatever the number of GPUs (XF_SCHEDULE_OWNER / _OWNER_STALE1
+   *                           only: there the sums meet exactly, in fp64) */
   int32_t update_rule;
 } xf_sharded_config;
 #define XF_UPDATE_RANK_ORDERED 0

@@ -58,7 +58,7 @@ def _rank(rank, world, port, transport, model, optimizer, schedule, steps, outdi
         for s in range(steps):
             b = st.compile(*_data(rank, s))
             alive.append(b)
-            if schedule != "owner":          # (the owner-compute dataflow keeps no key list)
+            if not schedule.startswith("owner"):   # (the owner-compute dataflow keeps no key list)
                 assert b.U == len(np.unique(_data(rank, s)[1]))
             st.step(b)
             if schedule in ("sequential", "owner") and s == 1:
@@ -150,6 +150,40 @@ def test_owner_compute_dataflow_ranks_share_one_gpu(tmp_path, world, optimizer):
     (tables after 4 steps with a defrag in between, and the forward of a fifth minibatch)"""
     _run(world, capi.TRANSPORT_HOST, "lr", optimizer, "owner", tmp_path)
     _check_against_oracle(world, "lr", optimizer, "sequential", tmp_path)
+
+
+@pytest.mark.parametrize("world,optimizer,data", [(2, "ftrl", "small"), (3, "sgd", "small"),
+                                                  (2, "ftrl", "big")])
+def test_owner_compute_dataflow_overlapped(tmp_path, world, optimizer, data):
+    """XF_SCHEDULE_OWNER_STALE1: the gradient + Pushes of step t on a second HIP stream under the
+    row-sum / loss exchanges of step t+1; forward(t+1) reads the table before they land, events
+    order the reader and the writer — weights exactly one step stale: the numbers of the stale1
+    schedule of the weight / gradient exchange and of the oracle run of that rule (every worker
+    pulls before the previous step's pushes are applied in rank order), bit for bit."""
+    steps = 4
+    _run(world, capi.TRANSPORT_HOST, "lr", optimizer, "owner_stale1", tmp_path, steps=steps,
+         data=data)
+    if data == "small":
+        _check_against_oracle(world, "lr", optimizer, "stale1", tmp_path, steps=steps)
+        return
+    with O.sum_mode(1):
+        w = O.Store(O.OPT_FTRL, 1)
+        outstanding = []
+        for s in range(steps):
+            obs = [O.Batch(*_big_data(r, s)) for r in range(world)]
+            pulled = [w.pull(ob.ukeys) for ob in obs]
+            for ob, g in outstanding:            # step s-1's pushes land after step s's pulls
+                w.push(ob.ukeys, g)
+            outstanding = [(ob, ob.lr_grad(ob.lr_loss(pw)[0])) for ob, pw in zip(obs, pulled)]
+        for ob, g in outstanding:
+            w.push(ob.ukeys, g)
+        parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+        ks, ws, ns, zs = w.export()
+        k = np.concatenate([p["w_k"] for p in parts])
+        order = np.argsort(k)
+        same(k[order], ks)
+        for f, ref in (("w_w", ws), ("w_n", ns), ("w_z", zs)):
+            same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)
 
 
 @pytest.mark.parametrize("schedule", ["owner", "sequential"])

@@ -666,9 +666,9 @@ class Group:
         check(lib().xf_group_selftest(self.h, nbytes))
 
 
-SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1, SCHEDULE_OWNER = 0, 1, 2
+SCHEDULE_SEQUENTIAL, SCHEDULE_STALE1, SCHEDULE_OWNER, SCHEDULE_OWNER_STALE1 = 0, 1, 2, 3
 _SCHEDULES = {"sequential": SCHEDULE_SEQUENTIAL, "stale1": SCHEDULE_STALE1,
-              "owner": SCHEDULE_OWNER}
+              "owner": SCHEDULE_OWNER, "owner_stale1": SCHEDULE_OWNER_STALE1}
 
 
 class ShardedBatch:

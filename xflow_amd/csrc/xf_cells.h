@@ -133,7 +133,8 @@ int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial
 int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
                                  uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
                                  const uint32_t *d_loss_base, double *d_gsum,
-                                 uint8_t *d_gtouched, hipStream_t stream);
+                                 uint8_t *d_gtouched, hipStream_t stream,
+                                 uint32_t rows_if_one = 0 /* n == 1: d_rows[0], for the host */);
 
 }  // namespace xf
 

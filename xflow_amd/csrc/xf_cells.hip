@@ -583,7 +583,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
 #pragma unroll
       for (int q = 0; q < kGradE; ++q)
         l[q] = ent[q] != 0xFFFFFFFFu
-                   ? loss[(SRC ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
+                   ? loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
                           ((ent[q] >> kChunkBits) & kRowMask)]
                    : 0.0f;
 #pragma unroll
@@ -1134,6 +1134,7 @@ struct CellSources {
   const uint32_t *d_win = nullptr;   // [n + 1] first window of every worker
   const uint32_t *d_rows = nullptr;  // [n] rows of every worker's minibatch
   const uint32_t *d_loss_base = nullptr;  // [nwin] where a window's losses start in d_loss
+  uint32_t rows_host = 0;            // n == 1: the source's rows (all workers'), known on the host
   double *gsum = nullptr;            // [n * nsplit_chunks * kChunk] split chunks' sums per worker
   uint8_t *gtouched = nullptr;       // [n * nsplit_chunks * kChunk]
 };
@@ -1152,6 +1153,23 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     } else {
       XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
     }
+  }
+  if (src && src->n == 1 && src->rows_host) {
+    // ONE source (sum_then_step, or a group of one): the plain instantiation — its optimizer
+    // steps in three sweeps — with the windows' losses where the exchange left them and the
+    // row count of all workers together
+    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, false>), dim3(c->nitems), dim3(kBlock), 0, s,
+                       T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                       c->item_slice, c->item_dump, d_loss, src->rows_host, c->M, d_g, gsum,
+                       gtouched, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       c->nsplit_chunks, src->d_loss_base, c->chunk0);
+    if (c->nsplit_chunks)
+      hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
+                         dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
+                         c->split_chunk, gsum, gtouched, src->rows_host, c->M, d_g, 1u,
+                         (const uint32_t *)nullptr, c->nsplit_chunks, c->chunk0);
+    XF_HIP(hipGetLastError());
+    return XF_OK;
   }
   if (src && src->n > 1)  // (its own instantiation: 87 registers instead of 58)
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true, true>), dim3(c->nitems), dim3(kBlock), 0,
@@ -1266,7 +1284,7 @@ int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_lo
 int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const float *d_loss,
                                  uint32_t n, const uint32_t *d_win, const uint32_t *d_rows,
                                  const uint32_t *d_loss_base, double *d_gsum,
-                                 uint8_t *d_gtouched, hipStream_t s) {
+                                 uint8_t *d_gtouched, hipStream_t s, uint32_t rows_if_one) {
   XF_REQUIRE(c && t && d_loss && n && d_win && d_rows && d_loss_base,
              "cells_lr_grad_update_sources: null");
   XF_REQUIRE(c->mode == kCellsTableRows, "cells_lr_grad_update_sources: cells are not table rows");
@@ -1282,6 +1300,7 @@ int cells_lr_grad_update_sources(const xf_cells *c, const xf_table *t, const flo
     src.d_win = d_win;
     src.d_rows = d_rows;
     src.d_loss_base = d_loss_base;
+    src.rows_host = n == 1 ? rows_if_one : 0u;
     src.gsum = d_gsum ? d_gsum + (size_t)n * used * kChunk : nullptr;
     src.gtouched = d_gtouched ? d_gtouched + (size_t)n * used * kChunk : nullptr;
     used += c->nsplit_chunks;

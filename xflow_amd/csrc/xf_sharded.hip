@@ -171,10 +171,13 @@ struct xf_sbatch {
   uint64_t oc_uid = 0, oc_epoch = ~0ull;
   Dev<double> rs_send, rs_recv, gsum;
   Dev<float> oloss, loss_rep, loss_recv, opctr;
+  Dev<float> loss_recv2;                     // owner_stale1: the gradient pass of step t reads one
+  int oflip = 0;                             // buffer while the losses of step t+1 arrive in the other
   Dev<uint8_t> gtouched;
   // FM (sum_then_step): b = the received nonzeros as one minibatch with a key list, rows
   // numbered worker after worker; (loss, v_sum) pairs of the rows
   uint32_t o_total = 0;                      // rows of all workers
+  uint32_t o_rows_all = 0;                   // the same, LR (rows1 on the host)
   Dev<float> lv, lv_rep, lv_recv, vsum_recv;
 };
 
@@ -281,8 +284,15 @@ int collect_profile(xf_sharded *st) {  // every set still pending
   return XF_OK;
 }
 // a step begins: does it record, and into which set
+inline bool owner_dataflow(int schedule) {
+  return schedule == XF_SCHEDULE_OWNER || schedule == XF_SCHEDULE_OWNER_STALE1;
+}
+inline bool overlapped(int schedule) {  // two streams: no per-stage events
+  return schedule == XF_SCHEDULE_STALE1 || schedule == XF_SCHEDULE_OWNER_STALE1;
+}
+
 int begin_profiled_step(xf_sharded *st) {
-  st->rec = st->profiling && st->cfg.schedule != XF_SCHEDULE_STALE1 &&
+  st->rec = st->profiling && !overlapped(st->cfg.schedule) &&
             st->step_no++ % xf_sharded::kProfileEvery == 0;
   if (!st->rec) return XF_OK;
   st->cur = (st->cur + 1) % xf_sharded::kEvSets;
@@ -397,7 +407,10 @@ int back_apply(xf_sharded *st, xf_sbatch *b, StepBuf &B, hipStream_t s) {
   return XF_OK;
 }
 
+int owner_flush_pending(xf_sharded *st);
+
 int flush_pending(xf_sharded *st) {
+  if (st->cfg.schedule == XF_SCHEDULE_OWNER_STALE1) return owner_flush_pending(st);
   if (st->pending) {
     xf_sbatch *pb = st->pending;
     StepBuf &PB = pb->buf[st->pending_flip];
@@ -664,6 +677,7 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   XF_TRY(upload_u32(b->d_rows, b->o_rows, s));
   {  // all workers as ONE source (XF_UPDATE_SUM_THEN_STEP)
     const std::vector<uint32_t> win1{0u, b->o_win[W]}, rows1{rowoff[W]};
+    b->o_rows_all = rowoff[W];
     XF_TRY(upload_u32(b->d_win1, win1, s));
     XF_TRY(upload_u32(b->d_rows1, rows1, s));
   }
@@ -773,7 +787,7 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
 
 // forward at the owners, row sums to the rows' workers, sigmoid there
 static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_pctr,
-                         hipStream_t s) {
+                         hipStream_t s, hipEvent_t table_read = nullptr) {
   const int W = st->world;
   XF_TRY(ensure_ocells(st, b));
   const xf_cells *c = b->ocells;
@@ -785,6 +799,7 @@ static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_p
   // the row sums land worker after worker, ready to be sent
   XF_TRY(xf::cells_lr_forward_sums(c, xf::table_weights(st->tw), st->partial.p, b->d_wbase.p,
                                    b->d_wrows.p, b->rs_send.p, s));
+  if (table_read) XF_HIP(hipEventRecord(table_read, s));  // (the weights are not read after this)
   XF_MARK(1);
   const std::vector<uint64_t> mine(W, b->R);
   XF_TRY(a2a(st, b->rs_send.p, b->o_rows64, b->rs_recv.p, mine, 8, s));
@@ -798,6 +813,45 @@ static int owner_forward(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_p
 
 static int step_owner_fm(xf_sharded *st, xf_sbatch *b);
 
+// gradient + the workers' Pushes in rank order, one pass over the shard (the losses are read
+// where they arrived: worker after worker)
+static int owner_grad(xf_sharded *st, xf_sbatch *b, const float *d_loss_recv, hipStream_t s) {
+  if (b->nT)  // (XF_OWNER_TIMING_SOURCES)
+    return xf::cells_lr_grad_update_sources(b->ocells, st->tw, d_loss_recv, b->nT, b->d_winT.p,
+                                            b->d_rowsT.p, b->d_wbase.p, b->gsum.p,
+                                            b->gtouched.p, s);
+  if (st->cfg.update_rule == XF_UPDATE_SUM_THEN_STEP)  // one source: every row of the step
+    return xf::cells_lr_grad_update_sources(b->ocells, st->tw, d_loss_recv, 1u, b->d_win1.p,
+                                            b->d_rows1.p, b->d_wbase.p, b->gsum.p,
+                                            b->gtouched.p, s, b->o_rows_all);
+  return xf::cells_lr_grad_update_sources(b->ocells, st->tw, d_loss_recv, (uint32_t)st->world,
+                                          b->d_win.p, b->d_rows.p, b->d_wbase.p, b->gsum.p,
+                                          b->gtouched.p, s, st->world == 1 ? b->o_rows_all : 0u);
+}
+
+// owner_stale1: the outstanding gradient + Pushes (step t-1) on the side stream, once the
+// losses of that step have arrived (ev_graded) and the forward of step t has read the weights
+// (ev_pulled)
+static int owner_apply_pending(xf_sharded *st) {
+  xf_sbatch *pb = st->pending;
+  if (!pb) return XF_OK;
+  if (st->have_graded) XF_HIP(hipStreamWaitEvent(st->side, st->ev_graded, 0));
+  if (st->have_pulled) XF_HIP(hipStreamWaitEvent(st->side, st->ev_pulled, 0));
+  XF_TRY(owner_grad(st, pb, (st->pending_flip ? pb->loss_recv2 : pb->loss_recv).p, st->side));
+  XF_HIP(hipEventRecord(st->ev_applied, st->side));
+  st->have_applied = true;
+  st->pending = nullptr;
+  return XF_OK;
+}
+
+namespace {
+int owner_flush_pending(xf_sharded *st) {
+  XF_TRY(owner_apply_pending(st));
+  if (st->have_applied) XF_HIP(hipStreamWaitEvent(st->main, st->ev_applied, 0));
+  return XF_OK;
+}
+}  // namespace
+
 // one LRWorker::update of every rank, owner-compute dataflow
 static int step_owner(xf_sharded *st, xf_sbatch *b) {
   const int W = st->world;
@@ -805,36 +859,45 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
   XF_REQUIRE(b->oc, "xf_sharded_step: the minibatch was not compiled for the owner-compute "
              "dataflow");
   if (st->cfg.model == 1) return step_owner_fm(st, b);
+  const bool stale = st->cfg.schedule == XF_SCHEDULE_OWNER_STALE1;
   XF_TRY(begin_profiled_step(st));
   XF_MARK(0);
   XF_TRY(b->oloss.reserve(b->R));
-  XF_TRY(owner_forward(st, b, b->oloss.p, nullptr, s));
-  // the losses to every owner
   uint32_t total = 0;
   for (uint32_t r : b->o_rows) total += r;
+  const int flip = stale ? b->oflip : 0;
+  if (stale) b->oflip ^= 1;
+  Dev<float> &lrecv = flip ? b->loss_recv2 : b->loss_recv;
   XF_TRY(b->loss_rep.reserve((size_t)W * b->R));
-  XF_TRY(b->loss_recv.reserve(total));
+  XF_TRY(lrecv.reserve(total));
+  if (stale) {
+    // forward(t) sees the table with the Pushes of step t-2 (ev_applied) and without those of
+    // step t-1, which start on the side stream as soon as forward(t) has read the weights and
+    // run under this step's two exchanges
+    if (st->have_applied) XF_HIP(hipStreamWaitEvent(s, st->ev_applied, 0));
+    XF_TRY(ensure_ocells(st, b));  // (may rebuild cells: before the event that frees the table)
+    XF_TRY(owner_forward(st, b, b->oloss.p, nullptr, s, st->ev_pulled));
+    st->have_pulled = true;
+    XF_TRY(owner_apply_pending(st));
+  } else {
+    XF_TRY(owner_forward(st, b, b->oloss.p, nullptr, s));
+  }
+  // the losses to every owner
   if (b->R)
     hipLaunchKernelGGL(k_replicate_f32, dim3(grid_for((size_t)W * b->R)), dim3(kBlock), 0, s,
                        b->oloss.p, b->R, (uint32_t)W, b->loss_rep.p);
   const std::vector<uint64_t> mine(W, b->R);
-  XF_TRY(a2a(st, b->loss_rep.p, mine, b->loss_recv.p, b->o_rows64, 4, s));
+  XF_TRY(a2a(st, b->loss_rep.p, mine, lrecv.p, b->o_rows64, 4, s));
   XF_HIP(hipGetLastError());
   XF_MARK(3);
-  // gradient + the workers' Pushes in rank order, one pass over the shard (the losses are read
-  // where they arrived: worker after worker)
-  if (b->nT)  // (XF_OWNER_TIMING_SOURCES)
-    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, b->nT,
-                                            b->d_winT.p, b->d_rowsT.p, b->d_wbase.p, b->gsum.p,
-                                            b->gtouched.p, s));
-  else if (st->cfg.update_rule == XF_UPDATE_SUM_THEN_STEP)  // one source: every row of the step
-    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, 1u, b->d_win1.p,
-                                            b->d_rows1.p, b->d_wbase.p, b->gsum.p,
-                                            b->gtouched.p, s));
-  else
-    XF_TRY(xf::cells_lr_grad_update_sources(b->ocells, st->tw, b->loss_recv.p, (uint32_t)W,
-                                            b->d_win.p, b->d_rows.p, b->d_wbase.p, b->gsum.p,
-                                            b->gtouched.p, s));
+  if (stale) {
+    XF_HIP(hipEventRecord(st->ev_graded, s));  // the losses of step t are here
+    st->have_graded = true;
+    st->pending = b;
+    st->pending_flip = flip;
+    return XF_OK;
+  }
+  XF_TRY(owner_grad(st, b, lrecv.p, s));
   XF_MARK(4);
   XF_MARK(5);
   XF_MARK(6);
@@ -925,18 +988,19 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
   XF_REQUIRE(out && cfg, "xf_sharded_create: null argument");
   XF_REQUIRE(cfg->model == 0 || cfg->model == 1, "xf_sharded_create: model %d", cfg->model);
   XF_REQUIRE(cfg->schedule == XF_SCHEDULE_SEQUENTIAL || cfg->schedule == XF_SCHEDULE_STALE1 ||
-                 cfg->schedule == XF_SCHEDULE_OWNER,
+                 owner_dataflow(cfg->schedule),
              "xf_sharded_create: schedule %d", cfg->schedule);
   XF_REQUIRE(cfg->update_rule == XF_UPDATE_RANK_ORDERED ||
-                 (cfg->update_rule == XF_UPDATE_SUM_THEN_STEP &&
-                  cfg->schedule == XF_SCHEDULE_OWNER),
+                 (cfg->update_rule == XF_UPDATE_SUM_THEN_STEP && owner_dataflow(cfg->schedule)),
              "xf_sharded_create: update_rule %d (sum_then_step needs the owner-compute dataflow: "
              "there the workers' sums meet exactly)", cfg->update_rule);
-  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER || cfg->model == 0 ||
+  XF_REQUIRE(!owner_dataflow(cfg->schedule) || cfg->model == 0 ||
                  cfg->update_rule == XF_UPDATE_SUM_THEN_STEP,
              "xf_sharded_create: FM on the owner-compute dataflow needs update_rule "
              "sum_then_step (one gradient pass over all workers' rows; the per-worker Pushes of "
              "the reference order run on the sequential / stale1 dataflows)");
+  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER_STALE1 || cfg->model == 0,
+             "xf_sharded_create: owner_stale1 is the LR step (FM: schedule owner)");
   xf_sharded *st = new xf_sharded;
   st->g = g;
   st->cfg = *cfg;
@@ -1080,7 +1144,7 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     *out = b;
     return XF_OK;
   }
-  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+  if (owner_dataflow(st->cfg.schedule)) {
     b->oc_keep = keep != 0;
     XF_TRY(compile_owner(st, b, rowptr, keys, labels, row_begin, row_end));
     guard.b = nullptr;
@@ -1156,7 +1220,7 @@ extern "C" int xf_sharded_step(xf_sharded *st, xf_sbatch *b) {
     if (st->cfg.model == 0) return xf_lr_step(st->tw, b->b, st->ws, st->main);
     return xf_fm_step(st->tw, st->tv, b->b, st->ws, st->main);
   }
-  if (st->cfg.schedule == XF_SCHEDULE_OWNER) return step_owner(st, b);
+  if (owner_dataflow(st->cfg.schedule)) return step_owner(st, b);
   XF_REQUIRE(!b->oc, "xf_sharded_step: the minibatch was compiled for the owner-compute dataflow");
   XF_TRY(begin_profiled_step(st));
   const int flip = b->flip;
@@ -1222,7 +1286,7 @@ extern "C" int xf_sharded_predict(xf_sharded *st, xf_sbatch *b, float *pctr_out)
   }
   XF_TRY(xf_sharded_flush(st));
   st->rec = false;  // a forward-only pass records no step profile
-  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+  if (owner_dataflow(st->cfg.schedule)) {
     XF_REQUIRE(b->oc, "xf_sharded_predict: the minibatch was not compiled for the owner-compute "
                "dataflow");
     XF_TRY(b->opctr.reserve(b->R));
@@ -1300,7 +1364,7 @@ extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *ste
   }
   XF_TRY(collect_profile(st));
   for (int i = 0; i < kEvN; ++i) ms_sum[i] = st->ms_sum[i];
-  if (st->cfg.schedule == XF_SCHEDULE_OWNER) {
+  if (owner_dataflow(st->cfg.schedule)) {
     // recorded in the order of the owner-compute step: forward at the owners | row sums to the
     // workers + sigmoid | losses to the owners | gradient + Pushes
     ms_sum[0] = 0;
@@ -1315,11 +1379,14 @@ extern "C" int xf_sharded_profile_read(xf_sharded *st, double *ms_sum, long *ste
 }
 
 extern "C" int xf_sharded_set_schedule(xf_sharded *st, int schedule) {
-  XF_REQUIRE(st && (schedule == XF_SCHEDULE_SEQUENTIAL || schedule == XF_SCHEDULE_STALE1),
+  XF_REQUIRE(st && (schedule == XF_SCHEDULE_SEQUENTIAL || schedule == XF_SCHEDULE_STALE1 ||
+                    owner_dataflow(schedule)),
              "xf_sharded_set_schedule: bad argument");
-  XF_REQUIRE(st->cfg.schedule != XF_SCHEDULE_OWNER,
+  XF_REQUIRE(owner_dataflow(st->cfg.schedule) == owner_dataflow(schedule),
              "xf_sharded_set_schedule: minibatches compiled for the owner-compute dataflow "
-             "cannot be stepped any other way");
+             "cannot be stepped on the weight / gradient exchange, nor the other way round");
+  XF_REQUIRE(st->cfg.model == 0 || schedule != XF_SCHEDULE_OWNER_STALE1,
+             "xf_sharded_set_schedule: owner_stale1 is the LR step");
   XF_TRY(xf_sharded_flush(st));
   st->cfg.schedule = schedule;
   return XF_OK;

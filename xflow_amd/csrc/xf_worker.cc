@@ -496,8 +496,10 @@ int Worker::set_param(const char *name, const char *value) {
     if (!strcmp(value, "sequential")) schedule = XF_SCHEDULE_SEQUENTIAL;
     else if (!strcmp(value, "stale1")) schedule = XF_SCHEDULE_STALE1;
     else if (!strcmp(value, "owner")) schedule = XF_SCHEDULE_OWNER;
+    else if (!strcmp(value, "owner_stale1")) schedule = XF_SCHEDULE_OWNER_STALE1;
     else
-      return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential, stale1 or owner");
+      return xf::set_error(XF_EINVAL, "XFSetParam: schedule must be sequential, stale1 or owner "
+                           "(owner_stale1: the owner-compute dataflow, overlapped)");
   }
   else if (n == "pred_path") pred_path = value;
   else if (n == "alpha") alpha = (float)atof(value);
