@@ -298,6 +298,7 @@ def fm_leg(args, batches):
     `ms_first_step_of_a_minibatch` is what a minibatch's FIRST step costs (both tables resolve
     its key list, its records are rebuilt from the tables)."""
     import torch
+    from xflow_amd import capi
     from xflow_amd.single import SingleGpuTrainer
     k, nb = 16, min(4, len(batches))
     cap = int(args.keys_per_gpu / args.load_factor) + 1024
@@ -333,9 +334,54 @@ def fm_leg(args, batches):
         first.append((time.perf_counter() - t0) * 1e3)
         del c
     tr.check()
+    # the whole FMWorker::update including its key build (fm_worker.cc:205-225): raw keys resident
+    # in HBM, xf_batch_compile_dev + the step per minibatch, nothing cached
+    wkb = None
+    try:
+        import ctypes as C
+        L = capi.lib()
+        raw = [(torch.from_numpy(kk.view(np.int64)).cuda(),
+                torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
+                torch.from_numpy(lb).cuda(), len(lb), len(kk)) for rp, kk, lb in batches[:nb]]
+        capi.tune("min_panel_nnz", 1e18)     # (the panel view serves the pre-cells LR forward)
+        prev = [None]
+
+        def one(i):
+            kk, rp, lb, R_, N_ = raw[i % nb]
+            h = capi.vp()
+            capi.check(L.xf_batch_compile_dev(C.byref(h), kk.data_ptr(), rp.data_ptr(),
+                                              lb.data_ptr(), R_, N_, None))
+            if prev[0] is not None:
+                L.xf_batch_free(prev[0])
+            capi.check(L.xf_fm_step(tr.w.h, tr.v.h, h, tr.ws.h, None))
+            prev[0] = h
+        for i in range(2):
+            one(i)
+        torch.cuda.synchronize()
+        wk = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for i in range(6):
+                one(i)
+            torch.cuda.synchronize()
+            wk.append((time.perf_counter() - t0) / 6 * 1e3)
+        if prev[0] is not None:
+            L.xf_batch_free(prev[0])
+        tr.check()
+        wkb = {"ms_per_step": wk[0], "value": batches[0][2].shape[0] / (wk[0] * 1e-3),
+               "unit": "examples/sec", "ms_per_step_repeats": spread(wk),
+               "what": "xf_batch_compile_dev (the sort-based key build: (key, position) pairs "
+                       "through a 64-bit radix sort, key list, CSR index, key-grouped COO, "
+                       "gradient tiles) + xf_fm_step (two key-list Pulls, the minibatch's "
+                       "records rebuilt, forward, gradient + Pushes) per minibatch, raw keys "
+                       "resident in HBM, nothing cached"}
+    except Exception as e:   # (the fm object must not depend on this extra)
+        wkb = {"error": str(e)}
+    finally:
+        capi.tune("min_panel_nnz", 4e6)
     R, NNZ = comp[0].R, int(np.mean([c.NNZ for c in comp]))
     U = int(np.mean([c.U for c in comp]))
-    _, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
+    per_k, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
     pmc = None   # the step's HBM traffic as the PMC passes of an earlier run measured it
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic_fm16_sgd.json")))
@@ -360,6 +406,18 @@ def fm_leg(args, batches):
             "ms_per_step_repeats": spread(per), "steps": steps,
             "ms_first_step_of_a_minibatch": float(np.median(first)),
             "kernels_ms": {kk: v / max(n, 1) for kk, v in ms.items()},
+            "with_key_build": wkb,
+            # the dominant kernel against the HBM peak, SURVEY 8(d)'s gradient + update bytes:
+            # the figure to read (the whole-step figure below prices 4k-byte factor gathers in
+            # the forward that the 32-byte per-key records replace)
+            "gradient_kernel": (lambda by, t: {
+                "kernel": "k_fm_grad_tiled<SGD, update, 16, records>",
+                "algorithmic_bytes_per_launch": by, "avg_launch_ms": t,
+                "achieved": by / (t * 1e-3) / 1e9 if t > 0 else None,
+                "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS if t > 0 else None,
+                "unit": "GB/s", "algorithmic_bytes_source": "SURVEY.md 8(d): U x 4(1+k) gradient "
+                "+ U x (1+k) x 12 update"})(per_k.get("gradient", 0),
+                                            ms.get("gradient", 0.0) / max(n, 1)),
             "step_bytes_survey_8d": survey,
             "step_gbs_survey_8d": survey / (per[0] * 1e-3) / 1e9,
             "frac_of_hbm_peak_survey_8d": survey / (per[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -160,7 +160,7 @@ struct Blob {
 };
 std::mutex g_pool_mu;
 std::vector<Blob> g_pool;
-int g_pool_limit = 8;
+int g_pool_limit = 16;
 }  // namespace
 
 int blob_alloc(void **p, size_t bytes, size_t *got) {
@@ -347,9 +347,9 @@ extern "C" int xf_batch_free(xf_batch *b) {
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);
   if (b->d_uidx_sorted) (void)hipFree(b->d_uidx_sorted);
   if (b->d_ref_coo) (void)hipFree(b->d_ref_coo);
-  for (uint32_t *r : b->d_fm_rows)
-    if (r) (void)hipFree(r);
-  if (b->d_fm_ridx) (void)hipFree(b->d_fm_ridx);
+  for (int i = 0; i < 2; ++i)
+    if (b->d_fm_rows[i]) xf::blob_free(b->d_fm_rows[i], b->fm_rows_bytes[i]);
+  if (b->d_fm_ridx) xf::blob_free(b->d_fm_ridx, b->fm_ridx_bytes);
   delete b;
   return XF_OK;
 }

@@ -37,6 +37,8 @@ struct xf_batch {
   // FM: the unique keys' rows in the w and the v table, valid for one (uid, epoch) of each —
   // the Pulls of a replayed minibatch resolve nothing
   uint32_t *d_fm_rows[2] = {nullptr, nullptr};
+  size_t fm_rows_bytes[2] = {0, 0};  // (pooled allocations, xf::blob_alloc: a fresh minibatch
+  size_t fm_ridx_bytes = 0;          //  per step would otherwise pay three hipMalloc / hipFree)
   uint64_t fm_uid[2] = {0, 0}, fm_epoch[2] = {0, 0};
   // FM with the per-key records kept next to the v table's rows (xf_model.hip): the v row of
   // every nonzero's key [NNZ] (valid with d_fm_rows[1]); what the records of this minibatch's

@@ -219,8 +219,8 @@ __device__ __forceinline__ uint32_t cell_of(const uint32_t *__restrict__ cellptr
 // come from inside the wavefront (measured on the config-2 shape: the LDS atomics cost nothing,
 // the weight gathers ~26 us, the bare index stream ~20 us at 4 entries per lane).  The
 // window's row sums live in LDS as fp64; every entry costs one coalesced index load, one 4-byte
-// gather inside the cell's 16 KiB chunk of the weight array and one LDS atomic.  An entry's
-// cell follows from the block's first cell and the 5 chunk-number bits the entry carries; only
+// gather inside the cell's 8 KiB chunk (kChunk = 2048 weights) of the weight array and one LDS
+// atomic.  An entry's cell follows from the block's first cell and the 5 chunk-number bits the entry carries; only
 // a block that spans 32 or more chunks (a sparse minibatch on a big table) searches cellptr.
 // The partial row sums of the G workgroups of a window are added by k_lr_finalize_cells.
 constexpr int kFwdE = (int)(kBlk / 64);
@@ -350,7 +350,7 @@ k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restric
 }
 
 // ----------------------------------------------------------------------------- gradient
-// One workgroup per work item = (chunk, slice).  The chunk's 4096 key sums live in LDS as
+// One workgroup per work item = (chunk, slice).  The chunk's kChunk (2048) key sums live in LDS as
 // fp64; the item walks its share of the chunk's nwin cells: coalesced entry loads, loss
 // gathers that ascend through the window (a cell is sorted by row), one LDS atomic each.
 // Unsplit chunks (all of them unless a chunk holds > kSliceMax entries) finish in place:

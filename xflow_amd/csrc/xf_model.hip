@@ -1865,7 +1865,8 @@ static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace 
   for (int i = 0; i < 2 && v.U; ++i) {
     const uint64_t uid = xf::table_uid(tabs[i]), ep = xf::table_epoch(tabs[i]);
     const bool fresh = !b->d_fm_rows[i] || b->fm_uid[i] != uid || b->fm_epoch[i] != ep;
-    if (!b->d_fm_rows[i]) XF_HIP(hipMalloc((void **)&b->d_fm_rows[i], (size_t)v.U * 4));
+    if (!b->d_fm_rows[i])
+      XF_TRY(xf::blob_alloc((void **)&b->d_fm_rows[i], (size_t)v.U * 4, &b->fm_rows_bytes[i]));
     if (fresh) {
       if (i == 0) XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, b->d_fm_rows[0], ws->wu, stream));
       else
@@ -1917,7 +1918,8 @@ static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh
   XF_TRY(xf::table_records(vt, sizeof(FmKey), xf::table_uid(w), &recp, &gen));
   const uint64_t uidv = xf::table_uid(vt), epv = xf::table_epoch(vt);
   if (!b->d_fm_ridx || b->fm_ridx_uid != uidv || b->fm_ridx_epoch != epv) {
-    if (!b->d_fm_ridx) XF_HIP(hipMalloc((void **)&b->d_fm_ridx, (size_t)v.NNZ * 4));
+    if (!b->d_fm_ridx)
+      XF_TRY(xf::blob_alloc((void **)&b->d_fm_ridx, (size_t)v.NNZ * 4, &b->fm_ridx_bytes));
     hipLaunchKernelGGL(k_fm_ridx, dim3(blocks_for_groups(v.NNZ, kBlock)), dim3(kBlock), 0,
                        S(stream), v.uidx, b->d_fm_rows[1], (size_t)v.NNZ, b->d_fm_ridx);
     XF_HIP(hipGetLastError());
