@@ -185,9 +185,9 @@ def impl_bytes_cells(R, NNZ, U, opt, info, table_rows):
 
 
 PMC_PROFILE = os.path.join("profiles", "pmc_traffic_latest.json")
-PMC_SOURCE = "committed profile %s (rocprofv3 --pmc passes of an earlier run of this workload: " \
-             "FETCH_SIZE / WRITE_SIZE need their own profiled runs), NOT measured by this run" \
-             % PMC_PROFILE
+PMC_SOURCE = "committed profile %s (two rocprofv3 --pmc passes of an earlier run of this " \
+             "workload — the L2's read / write requests to the fabric by request size, " \
+             "tools/pmc2.sh — need their own profiled runs), NOT measured by this run" % PMC_PROFILE
 
 
 def pmc_traffic(kernel, workload):
@@ -384,7 +384,7 @@ def fm_leg(args, batches):
     per_k, survey = bytes_model("fm", k, R, NNZ, U, "sgd", fused_fm=True)
     pmc = None   # the step's HBM traffic as the PMC passes of an earlier run measured it
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic_fm16_sgd.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic_fm16_sgd.json")))
         by = sum(e["traffic"] for kk, e in prof["kernels"].items()
                  if kk.startswith(("k_fm_forward_scalars", "k_fm_grad_tiled")))
         same = (args.rows, args.nnz_per_row, args.keys_per_gpu) == (50000, 200, 10_000_000) \
@@ -393,10 +393,11 @@ def fm_leg(args, batches):
             pmc = {"bytes_per_step": by, "gbs": by / (per[0] * 1e-3) / 1e9,
                    "frac_of_hbm_peak": by / (per[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "over_survey_8d": by / survey,
-                   "source": "committed profile profiles/r03/pmc_traffic_fm16_sgd.json (rocprofv3 "
-                             "--pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
-                             "leg: forward + gradient & Pushes kernels), NOT measured by this run; "
-                             "the time is this run's"}
+                   "source": "committed profile profiles/r04/pmc_traffic_fm16_sgd.json (two "
+                             "rocprofv3 --pmc passes of an earlier run of this leg, the L2's "
+                             "requests to the fabric by size — Infinity-Cache hits included, so "
+                             "the HBM peak does not bound this figure: forward + gradient & "
+                             "Pushes kernels), NOT measured by this run; the time is this run's"}
     except (OSError, ValueError, KeyError):
         pass
     return {"step_traffic_pmc": pmc,
@@ -634,6 +635,33 @@ def gpu_vs_oracle(args, batches, store, vstore, held=None):
                 d[fld] = {"max_abs_diff": float(diff.max()), "rms": rms,
                           "max_diff_over_abs_plus_rms": float((diff / (np.abs(r) + rms)).max())}
         out[name] = d
+    if not fm:
+        # ... and once more in the product's parity mode (XF_PARITY_REFERENCE_ORDER: the
+        # reference's own fp32 running sums, row and key, in its own orders): the same table as
+        # the oracle's, bit for bit, is the claim — max_abs_diff 0 on every array
+        try:
+            tp = capi.Table(opt, 1, capacity=cap)
+            wp = capi.Workspace()
+            wp.parity("reference_order")
+            for i, (rowptr, keys, labels) in enumerate(batches):
+                b = capi.Batch(rowptr, keys, labels, on_gpu=True)
+                capi.lr_step(tp, b, wp)
+                tp.check()
+                del b
+                if i == 0 and len(batches) > 1:
+                    tp.defrag()
+            g, o = tp.export(), store.export()
+            out["reference_order_mode"] = {
+                "same_keys": bool(np.array_equal(g[0], o[0])),
+                "max_abs_diff": {f: float(np.abs(np.asarray(a, np.float64) -
+                                                 np.asarray(r, np.float64)).max())
+                                 for f, a, r in zip(("w", "n", "z"), g[1:], o[1:])}
+                if len(g[0]) == len(o[0]) else None,
+                "what": "the same minibatches stepped in parity mode (fp32 running sums in the "
+                        "reference's orders, rows and keys): this table against the oracle's"}
+            del tp, wp
+        except Exception as e:
+            out["reference_order_mode"] = {"error": str(e)}
     if held is not None:
         # the logloss half of the metric, GPU and oracle side by side: the held-out rows scored
         # by both after the same minibatches from empty tables (after the comparison above: a
@@ -1214,7 +1242,11 @@ def main():
              "forward": "k_lr_forward_tiled" if lr else "k_fm_forward",
              "gradient": "k_lr_grad_tiled" if lr else "k_fm_grad"}
     if fused:
-        names.update(forward="k_lr_fwd_cells", gradient="k_lr_grad_cells")
+        # one shard, no split chunk, <= 4 row windows: the steady-state kernel; else the general one
+        ci = compiled[0].cells_info() if hasattr(compiled[0], "cells_info") else {}
+        dense = one_shard and ci.get("nsplit_chunks", 1) == 0 and ci.get("nwin", 9) <= 4
+        names.update(forward="k_lr_fwd_cells",
+                     gradient="k_lr_grad_dense" if dense else "k_lr_grad_cells")
     dom_kernel = names.get(dom, dom)
     dom_note = {"forward": " (+ k_lr_finalize_cells)", "gradient": " (gradient+Push)"}.get(
         dom, "") if fused else ""
