@@ -344,13 +344,16 @@ def fm_leg(args, batches):
                 torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
                 torch.from_numpy(lb).cuda(), len(lb), len(kk)) for rp, kk, lb in batches[:nb]]
         capi.tune("min_panel_nnz", 1e18)     # (the panel view serves the pre-cells LR forward)
-        prev = [None]
+        prev, nkeyed = [None], [0]
 
         def one(i):
             kk, rp, lb, R_, N_ = raw[i % nb]
             h = capi.vp()
-            capi.check(L.xf_batch_compile_dev(C.byref(h), kk.data_ptr(), rp.data_ptr(),
-                                              lb.data_ptr(), R_, N_, None))
+            keyed = C.c_int(0)
+            capi.check(L.xf_batch_compile_fm_dev(C.byref(h), tr.w.h, tr.v.h, kk.data_ptr(),
+                                                 rp.data_ptr(), lb.data_ptr(), R_, N_, None,
+                                                 C.byref(keyed)))
+            nkeyed[0] += keyed.value
             if prev[0] is not None:
                 L.xf_batch_free(prev[0])
             capi.check(L.xf_fm_step(tr.w.h, tr.v.h, h, tr.ws.h, None))
@@ -370,11 +373,14 @@ def fm_leg(args, batches):
         tr.check()
         wkb = {"ms_per_step": wk[0], "value": batches[0][2].shape[0] / (wk[0] * 1e-3),
                "unit": "examples/sec", "ms_per_step_repeats": spread(wk),
-               "what": "xf_batch_compile_dev (the sort-based key build: (key, position) pairs "
-                       "through a 64-bit radix sort, key list, CSR index, key-grouped COO, "
-                       "gradient tiles) + xf_fm_step (two key-list Pulls, the minibatch's "
-                       "records rebuilt, forward, gradient + Pushes) per minibatch, raw keys "
-                       "resident in HBM, nothing cached"}
+               "range_partitioned_builds": nkeyed[0], "minibatches": 2 + 3 * 6,
+               "what": "xf_batch_compile_fm_dev + xf_fm_step per minibatch, raw keys resident in "
+                       "HBM, nothing cached: the key build against the tables' settled tiers "
+                       "(xf_keybuild.hip: histogram / scan / scatter of 16-byte records by key "
+                       "range / resolve in LDS, then per super-chunk the key list with its "
+                       "state rows, the occurrence lists and the per-nonzero record index; the "
+                       "sort-based xf_batch_compile_dev when a key is not settled), the "
+                       "minibatch's records rebuilt, forward, gradient + Pushes"}
     except Exception as e:   # (the fm object must not depend on this extra)
         wkb = {"error": str(e)}
     finally:

@@ -110,6 +110,16 @@ int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys, const uint32_t 
                          const int32_t *d_labels, uint32_t R, uint32_t NNZ, void *stream);
 int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t *keys,
                          const int32_t *labels, size_t row_begin, size_t row_end, void *stream);
+/* The FM key build (fm_worker.cc:205-225) against the tables themselves: when every key of the
+ * minibatch sits in the v table's settled tier (xf_table_defrag) and the w table numbers its rows
+ * the same way, the key list comes with its state rows, the key-grouped occurrence lists and
+ * the forward's per-nonzero record index from the range-partitioned build (no sort of (key,
+ * position) pairs); otherwise this IS xf_batch_compile_dev.  *keyed (optional): 1 when the
+ * fast build ran.  Such a minibatch is for xf_fm_step on these two tables in their present row
+ * numbering (k in {4, 8, 16, 32, 64}); after a defrag it must be compiled again. */
+int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v, const uint64_t *d_keys,
+                            const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                            uint32_t NNZ, void *stream, int *keyed);
 /* The key build for a table on THIS GPU, without the sort (LR): every raw key is resolved
  * straight to its state row in `t` (insert on first touch, ftrl.h:56; the table grows when
  * needed) and the nonzeros are grouped into cells (row window x 4096-row chunk of the state)

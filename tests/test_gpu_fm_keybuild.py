@@ -1,0 +1,163 @@
+"""The FM key build against the tables' settled tiers (xf_batch_compile_fm_dev, round 4): the
+range-partitioned build of xf_keybuild.hip with records that carry a nonzero's row and its
+position, the per-super-chunk regroup into the key list / occurrence lists / per-nonzero record
+index — no sort of (key, position) pairs.  A minibatch built that way must step exactly like
+one built by the sort (xf_batch_compile_dev): loss and both tables bit for bit against the
+exact-sum oracle, on uniform and power-law minibatches, ragged and empty rows, several row
+windows and super-chunks, heavy keys; and it must fall back to the sort-based build whenever a
+key is not settled or the two tables number their rows differently."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from xflow_amd import capi
+
+from .test_gpu_parity import same, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    capi.require_gpu()
+
+
+def _tables(k, opt, nkeys, cap=1 << 18):
+    go, oo = (capi.OPT_SGD, O.OPT_SGD) if opt == "sgd" else (capi.OPT_FTRL, O.OPT_FTRL)
+    gi, oi = (capi.INIT_CONST, O.INIT_CONST) if opt == "sgd" else (capi.INIT_HASHNORM,
+                                                                    O.INIT_HASHNORM)
+    tw = capi.Table(go, 1, capacity=cap)
+    tv = capi.Table(go, k, gi, 0.001, seed=7, capacity=cap)
+    sw, sv = O.Store(oo, 1), O.Store(oo, k, oi, 0.001, 7)
+    return tw, tv, sw, sv
+
+
+def _settle(tw, tv, sw, sv, keys):
+    """every key into both tables (a Pull inserts, ftrl.h:56), then the maintenance step"""
+    keys = np.unique(keys)
+    for t in (tw, tv, sw, sv):
+        t.pull(keys)
+    tw.defrag()
+    tv.defrag()
+
+
+@pytest.mark.parametrize("k,opt,R,nnz,nkeys", [
+    (16, "sgd", 3000, 60, 60000),      # eight super-chunks, one row window
+    (64, "ftrl", 1500, 40, 9000),      # k = 64 + FTRL (configs[4]'s model), two super-chunks
+    (4, "ftrl", 40000, 12, 150000),    # three row windows
+])
+def test_keyed_fm_minibatches_step_like_the_oracle(k, opt, R, nnz, nkeys):
+    rng = np.random.RandomState(k + R)
+    tw, tv, sw, sv = _tables(k, opt, nkeys)
+    keytab = capi.hash_decimal_range(0, nkeys)
+    _settle(tw, tv, sw, sv, keytab)
+    ws = capi.Workspace()
+    for step in range(5):
+        raw = synth(rng, R, nnz, nkeys, 1.2 if step % 2 else None, True)
+        b = capi.FmBatch(tw, tv, *raw)
+        assert b.keyed, "every key is settled in both tables: the range-partitioned build"
+        ob = O.Batch(*raw)
+        assert b.U == ob.U
+        if step % 2:
+            assert b.H > 0                       # power-law heads: the heavy-key kernels
+        with O.sum_mode(1):
+            loss_ex, _, _ = ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))
+            O.fm_update(sw, sv, ob)
+        capi.fm_step(tw, tv, b, ws)
+        same(ws.fetch_loss(R), loss_ex)
+        tw.check()
+        tv.check()
+    for t, st in ((tw, sw), (tv, sv)):
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
+
+
+def test_keyed_and_sorted_builds_are_interchangeable_step_by_step():
+    """the same minibatches alternately through the two builds on one pair of tables, a third
+    pair stepping only sort-built ones: the same tables"""
+    k, nkeys, R = 16, 30000, 2500
+    rng = np.random.RandomState(3)
+    keytab = capi.hash_decimal_range(0, nkeys)
+    ta = _tables(k, "ftrl", nkeys)
+    tb = _tables(k, "ftrl", nkeys)
+    for t in (ta, tb):
+        _settle(t[0], t[1], t[2], t[3], keytab)
+    ws = capi.Workspace()
+    for step in range(6):
+        raw = synth(rng, R, 50, nkeys, 1.3 if step == 4 else None, True)
+        if step % 2:
+            ba = capi.FmBatch(ta[0], ta[1], *raw)
+            assert ba.keyed
+        else:
+            ba = capi.Batch(*raw, on_gpu=True)
+        capi.fm_step(ta[0], ta[1], ba, ws)
+        capi.fm_step(tb[0], tb[1], capi.Batch(*raw, on_gpu=True), ws)
+    for x, y in ((ta[0], tb[0]), (ta[1], tb[1])):
+        for a, e in zip(x.export(), y.export()):
+            same(a, e)
+
+
+def test_falls_back_to_the_sort_when_a_key_is_not_settled_or_the_tables_differ():
+    k, nkeys, R = 8, 20000, 1200
+    rng = np.random.RandomState(5)
+    keytab = capi.hash_decimal_range(0, nkeys)
+    tw, tv, sw, sv = _tables(k, "sgd", nkeys)
+    ws = capi.Workspace()
+    raw = synth(rng, R, 30, nkeys, None, True)
+    b = capi.FmBatch(tw, tv, *raw)               # empty tables: nothing settled
+    assert not b.keyed
+    capi.fm_step(tw, tv, b, ws)
+    with O.sum_mode(1):
+        O.fm_update(sw, sv, O.Batch(*raw))
+    tw.defrag()
+    tv.defrag()
+    raw2 = synth(rng, R, 30, nkeys, None, True)  # mostly keys the tier has not seen
+    b2 = capi.FmBatch(tw, tv, *raw2)
+    assert not b2.keyed
+    capi.fm_step(tw, tv, b2, ws)
+    with O.sum_mode(1):
+        O.fm_update(sw, sv, O.Batch(*raw2))
+    for t, st in ((tw, sw), (tv, sv)):
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
+    # ... settled now, but the w table holds one key more than the v table: other numbering
+    tw.pull(np.array([12345], np.uint64))
+    sw.pull(np.array([12345], np.uint64))
+    tw.defrag()
+    tv.defrag()
+    raw3 = (raw[0], raw[1], raw[2])              # keys of the first minibatch: all settled
+    b3 = capi.FmBatch(tw, tv, *raw3)
+    assert not b3.keyed
+    capi.fm_step(tw, tv, b3, ws)
+    with O.sum_mode(1):
+        O.fm_update(sw, sv, O.Batch(*raw3))
+    for t, st in ((tw, sw), (tv, sv)):
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
+
+
+def test_a_keyed_minibatch_is_bound_to_the_row_numbering_it_was_compiled_against():
+    k, nkeys, R = 8, 20000, 1000
+    rng = np.random.RandomState(6)
+    keytab = capi.hash_decimal_range(0, nkeys)
+    tw, tv, sw, sv = _tables(k, "sgd", nkeys)
+    _settle(tw, tv, sw, sv, keytab)
+    ws = capi.Workspace()
+    raw = synth(rng, R, 30, nkeys, None, True)
+    b = capi.FmBatch(tw, tv, *raw)
+    assert b.keyed
+    capi.fm_step(tw, tv, b, ws)
+    with pytest.raises(capi.XFError, match="no CSR index"):
+        capi.fm_predict(tw, tv, b, ws)
+    tv.pull(np.array([777], np.uint64))          # a new key, then a renumbering
+    tw.pull(np.array([777], np.uint64))
+    tw.defrag()
+    tv.defrag()
+    with pytest.raises(capi.XFError, match="compile it again"):
+        capi.fm_step(tw, tv, b, ws)
+    wp = capi.Workspace()
+    wp.parity("reference_order")
+    b2 = capi.FmBatch(tw, tv, *raw)
+    assert b2.keyed
+    with pytest.raises(capi.XFError, match="table-resident records"):
+        capi.fm_step(tw, tv, b2, wp)

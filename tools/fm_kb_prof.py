@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--sorted", action="store_true", help="xf_batch_compile_dev (the sort-based "
+                    "build) instead of xf_batch_compile_fm_dev")
     a = ap.parse_args()
     import torch
     args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=4, zipf=0.0)
@@ -39,13 +41,20 @@ def main():
     raw = [(torch.from_numpy(k.view(np.int64)).cuda(),
             torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
             torch.from_numpy(lb).cuda(), len(lb), len(k)) for rp, k, lb in batches]
-    prev = [None]
+    prev, nk = [None], [0]
 
     def one(i, step=True):
         k, rp, lb, R, N = raw[i % len(raw)]
         h = capi.vp()
-        capi.check(L.xf_batch_compile_dev(C.byref(h), k.data_ptr(), rp.data_ptr(), lb.data_ptr(),
-                                          R, N, None))
+        if a.sorted:
+            capi.check(L.xf_batch_compile_dev(C.byref(h), k.data_ptr(), rp.data_ptr(),
+                                              lb.data_ptr(), R, N, None))
+        else:
+            keyed = C.c_int(0)
+            capi.check(L.xf_batch_compile_fm_dev(C.byref(h), tr.w.h, tr.v.h, k.data_ptr(),
+                                                 rp.data_ptr(), lb.data_ptr(), R, N, None,
+                                                 C.byref(keyed)))
+            nk[0] += keyed.value
         if prev[0] is not None:
             L.xf_batch_free(prev[0])
         if step:
@@ -62,6 +71,7 @@ def main():
         print("%s: %.3f ms per minibatch" % ("compile + step" if step else "compile alone",
                                              (time.perf_counter() - t0) / a.iters * 1e3))
     tr.check()
+    print("range-partitioned builds: %d" % nk[0])
 
 
 if __name__ == "__main__":

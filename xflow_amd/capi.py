@@ -80,6 +80,8 @@ SIGNATURES = {
     "xf_batch_compile_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, C.c_uint32, C.c_uint32, vp]),
     "xf_batch_compile_gpu": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t,
                                        C.c_size_t, vp]),
+    "xf_batch_compile_fm_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, vp, C.c_uint32,
+                                          C.c_uint32, vp, C.POINTER(C.c_int)]),
     "xf_batch_download": (C.c_int, [vp]),
     "xf_batch_compile_local_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, C.c_uint32,
                                              C.c_uint32, C.c_int, vp]),
@@ -389,6 +391,34 @@ class Batch:
         v = DevBatch()
         check(lib().xf_batch_dev_view(self.h, C.byref(v)))
         return v
+
+
+class FmBatch(Batch):
+    """xf_batch_compile_fm_dev: the FM key build against the (w, v) tables' settled tiers
+    (`keyed` says whether the fast build ran; else it is the sort-based one).  The raw arrays go
+    to the device through torch (plumbing)."""
+
+    def __init__(self, wt, vt, rowptr, keys, labels):
+        import torch
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        rp = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        rp32 = (rp - rp[0]).astype(np.uint32)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        R, NNZ = len(rp32) - 1, int(rp32[-1])
+        dk = torch.from_numpy(keys[int(rp[0]):int(rp[0]) + NNZ].view(np.int64).copy()).cuda()
+        dr = torch.from_numpy(rp32.view(np.int32)).cuda()
+        dl = torch.from_numpy(labels[:max(R, 1)] if R else np.zeros(1, np.int32)).cuda()
+        torch.cuda.synchronize()
+        self.h = vp()
+        keyed = C.c_int(0)
+        check(lib().xf_batch_compile_fm_dev(C.byref(self.h), wt.h, vt.h, dk.data_ptr(),
+                                            dr.data_ptr(), dl.data_ptr(), R, NNZ, None,
+                                            C.byref(keyed)))
+        self.keyed = bool(keyed.value)
+        Rr, N, U, H = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().xf_batch_dims(self.h, C.byref(Rr), C.byref(N), C.byref(U), C.byref(H)))
+        self.R, self.NNZ, self.U, self.H = Rr.value, N.value, U.value, H.value
+        self.on_gpu = True
 
 
 class LocalBatch:

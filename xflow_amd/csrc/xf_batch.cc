@@ -342,6 +342,7 @@ extern "C" int xf_batch_free(xf_batch *b) {
     (void)hipDeviceSynchronize();
   }
   if (b->d_blob) xf::blob_free(b->d_blob, b->d_blob_bytes);
+  if (b->d_blob2) xf::blob_free(b->d_blob2, b->d_blob2_bytes);
   if (b->cells) xf::cells_free(b->cells);
   if (b->d_raw) xf::blob_free(b->d_raw, b->d_raw_bytes);
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);

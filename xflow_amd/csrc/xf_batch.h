@@ -22,6 +22,8 @@ struct xf_batch {
   bool on_device_only = false;  // built by xf_batch_compile_dev and not downloaded yet
   void *d_blob = nullptr;  // one device allocation holding all arrays
   size_t d_blob_bytes = 0;
+  void *d_blob2 = nullptr;  // fm_keyed: the lists whose sizes are known last (heavy keys, tiles)
+  size_t d_blob2_bytes = 0;
   xf_dev_batch view{};
   // the cell-sorted form the LR kernels stream (xf_cells.h), compiled against ONE table's row
   // numbering (rebuilt when another table or another epoch of it comes along)
@@ -47,6 +49,11 @@ struct xf_batch {
   uint64_t fm_ridx_uid = 0, fm_ridx_epoch = ~0ull;
   uint64_t fm_rec_gen = 0, fm_rec_writes[2] = {~0ull, ~0ull};
   bool fm_rec_ok = false;
+  // built by xf_batch_compile_fm_dev against the settled tiers of ONE (w, v) pair of tables with
+  // the same row numbering: the key list comes with its state rows and the per-nonzero record
+  // index, there is no CSR index of unique keys (view.uidx == null).  Valid for that numbering
+  // only: after a defrag the minibatch must be compiled again.
+  bool fm_keyed = false;
   // "local" batches (xf_batch_compile_local_*): no key list at all — the raw keys were resolved
   // straight to state rows.  The raw arrays are kept (device) when the cells must be
   // rebuildable after the table renumbers its rows.

@@ -29,6 +29,7 @@
 
 #include "xf_batch.h"
 #include "xf_common.h"
+#include "xf_device.h"
 #include "xf_scratch.h"
 #include "xf_tiling.h"
 
@@ -466,6 +467,230 @@ extern "C" int xf_batch_download(xf_batch *b) {
     XF_HIP(get(b->fpanel_first, v.fwd_panel_first, (size_t)v.P + 1));
   }
   b->on_device_only = false;
+  return XF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The FM key build against the tables themselves (fm_worker.cc:205-225 + the key -> row step
+// of its two Pulls, :228,:231): when every key of the minibatch sits in the v table's settled
+// tier and the w table numbers its rows the same way, the keyed build of xf_keybuild.hip gives
+// the key list with its state rows, the key-grouped occurrence lists and the forward's
+// per-nonzero record index without sorting (key, position) pairs (the 64-bit radix sort and
+// the scattered index passes of xf_batch_compile_dev: 1.7 ms per 10^7 nonzeros).  Otherwise
+// (first minibatches of a run, keys new since the last xf_table_defrag, a minibatch of more
+// than 16 row windows) it IS xf_batch_compile_dev.  *keyed_out (optional) says which.
+namespace xf {
+const TableDev &table_dev(const xf_table *t);
+uint64_t table_uid(const xf_table *t);
+uint64_t table_epoch(const xf_table *t);
+typedef int (*FmKeyedOut)(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow,
+                          uint32_t **segptr, uint32_t **coo);
+int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr, uint32_t R,
+                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, uint32_t *U_out,
+                   uint32_t *ridx, FmKeyedOut place, void *ctx);
+}  // namespace xf
+
+namespace {
+__global__ void k_keys_differ(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                              size_t n, unsigned int *__restrict__ flag) {
+  XF_GRID_STRIDE(i, n) if (a[i] != b[i]) *flag = 1u;
+}
+
+// do the two tables' settled tiers hold the same keys (so that the key of rank r has state row
+// r in both)?  Compared on the device once per pair of table epochs.
+int same_numbering(xf_table *w, xf_table *v, hipStream_t s, bool *same) {
+  struct Memo {
+    uint64_t uw, ew, uv, ev;
+    bool same;
+  };
+  static thread_local Memo memo{0, 0, 0, 0, false};
+  const uint64_t uw = xf::table_uid(w), ew = xf::table_epoch(w);
+  const uint64_t uv = xf::table_uid(v), ev = xf::table_epoch(v);
+  if (memo.uw == uw && memo.ew == ew && memo.uv == uv && memo.ev == ev) {
+    *same = memo.same;
+    return XF_OK;
+  }
+  const xf::TableDev &TW = xf::table_dev(w), &TV = xf::table_dev(v);
+  bool eq = TW.nbase == TV.nbase && TW.nbase > 0 && TW.lo == TV.lo && TW.span == TV.span;
+  if (eq) {
+    xf::Scratch sc;
+    unsigned int *flag = nullptr, h = 0;
+    XF_TRY(sc.get(&flag, 1));
+    XF_HIP(hipMemsetAsync(flag, 0, 4, s));
+    hipLaunchKernelGGL(k_keys_differ, dim3(grid_for(TW.nbase)), dim3(kBlock), 0, s, TW.bkeys,
+                       TV.bkeys, (size_t)TW.nbase, flag);
+    XF_HIP(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+    eq = h == 0;
+  }
+  memo = Memo{uw, ew, uv, ev, eq};
+  *same = eq;
+  return XF_OK;
+}
+}  // namespace
+
+extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
+                                       const uint64_t *d_keys, const uint32_t *d_rowptr,
+                                       const int32_t *d_labels, uint32_t R, uint32_t NNZ,
+                                       void *stream, int *keyed_out) {
+  XF_REQUIRE(out && w && v && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
+             "xf_batch_compile_fm_dev: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (keyed_out) *keyed_out = 0;
+  bool same = false;
+  if (NNZ && R) XF_TRY(same_numbering(w, v, s, &same));
+  if (!same) return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  uint32_t *ridx = nullptr;
+  size_t ridx_bytes = 0;
+  XF_TRY(xf::blob_alloc((void **)&ridx, (size_t)NNZ * 4, &ridx_bytes));
+  struct RidxGuard {
+    uint32_t *p;
+    size_t n;
+    ~RidxGuard() {
+      if (p) xf::blob_free(p, n);
+    }
+  } rguard{ridx, ridx_bytes};
+  // the batch and, once the number of distinct keys is known, its allocation: the build writes
+  // the key list, its rows, the segment offsets and the occurrence lists straight into it
+  xf_batch *b = new xf_batch;
+  struct Guard {
+    xf_batch *b;
+    ~Guard() {
+      if (b) xf_batch_free(b);
+    }
+  } guard{b};
+  struct Place {
+    xf_batch *b;
+    uint32_t R, NNZ;
+    size_t o_ukeys, o_rowptr, o_segptr, o_coo, o_labels;
+    static int at(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow, uint32_t **segptr,
+                  uint32_t **coo) {
+      Place *p = (Place *)ctx;
+      auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+      p->o_ukeys = 0;
+      p->o_rowptr = p->o_ukeys + al((size_t)U * 8);
+      p->o_segptr = p->o_rowptr + al(((size_t)p->R + 1) * 4);
+      p->o_coo = p->o_segptr + al(((size_t)U + 1) * 4);
+      p->o_labels = p->o_coo + al((size_t)p->NNZ * 4);
+      const size_t total = p->o_labels + al((size_t)p->R * 4) + 256;
+      char *d = nullptr;
+      XF_TRY(xf::blob_alloc((void **)&d, total, &p->b->d_blob_bytes));
+      p->b->d_blob = d;
+      for (int i = 0; i < 2; ++i)  // the key list's rows, in both tables (the same numbers)
+        XF_TRY(xf::blob_alloc((void **)&p->b->d_fm_rows[i], std::max<size_t>(U, 1) * 4,
+                              &p->b->fm_rows_bytes[i]));
+      *ukeys = (uint64_t *)(d + p->o_ukeys);
+      *urow = p->b->d_fm_rows[1];
+      *segptr = (uint32_t *)(d + p->o_segptr);
+      *coo = (uint32_t *)(d + p->o_coo);
+      return XF_OK;
+    }
+  } place{b, R, NNZ, 0, 0, 0, 0, 0};
+  Scratch sc;
+  bool ok = false;
+  uint32_t U = 0;
+  XF_TRY(xf::fm_build_keyed(v, d_keys, d_rowptr, R, NNZ, sc, s, &ok, &U, ridx, &Place::at,
+                            &place));
+  if (!ok) {
+    XF_HIP(hipStreamSynchronize(s));
+    return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+  }
+  char *d = (char *)b->d_blob;
+  const uint32_t *segptr = (const uint32_t *)(d + place.o_segptr);
+  XF_HIP(hipMemcpyAsync(b->d_fm_rows[0], b->d_fm_rows[1], (size_t)U * 4, hipMemcpyDeviceToDevice,
+                        s));
+  XF_HIP(hipMemcpyAsync(d + place.o_rowptr, d_rowptr, ((size_t)R + 1) * 4,
+                        hipMemcpyDeviceToDevice, s));
+  XF_HIP(hipMemcpyAsync(d + place.o_labels, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+  // ---- heavy keys and gradient tiles (as in xf_batch_compile_dev)
+  uint32_t *hflag = nullptr, *tflag = nullptr, *hscan = nullptr, *tscan = nullptr;
+  uint32_t *heavy = nullptr, *tile_ptr = nullptr;
+  XF_TRY(sc.get(&hflag, (size_t)U + 1));
+  XF_TRY(sc.get(&tflag, (size_t)U + 1));
+  XF_TRY(sc.get(&hscan, (size_t)U + 1));
+  XF_TRY(sc.get(&tscan, (size_t)U + 1));
+  XF_TRY(sc.get(&heavy, (size_t)U + 1));
+  XF_TRY(sc.get(&tile_ptr, (size_t)U + 2));
+  uint32_t H = 0, ntiles = 0;
+  XF_HIP(hipMemsetAsync(hflag + U, 0, 4, s));
+  XF_HIP(hipMemsetAsync(tflag + U, 0, 4, s));
+  hipLaunchKernelGGL(k_key_flags, dim3(grid_for(U)), dim3(kBlock), 0, s, segptr, U, hflag, tflag);
+  XF_TRY(exclusive_scan_u32(sc, hflag, hscan, (size_t)U + 1, s));
+  XF_TRY(exclusive_scan_u32(sc, tflag, tscan, (size_t)U + 1, s));
+  hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, hflag, hscan,
+                     (size_t)U, heavy);
+  hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, tflag, tscan,
+                     (size_t)U, tile_ptr);
+  XF_HIP(hipMemcpyAsync(&H, hscan + U, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(&ntiles, tscan + U, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  uint32_t *hch = nullptr;
+  uint32_t n_hch = 0;
+  if (H) {
+    uint32_t *hcnt = nullptr;
+    XF_TRY(sc.get(&hcnt, (size_t)H + 1));
+    XF_TRY(sc.get(&hch, (size_t)H + 1));
+    hipLaunchKernelGGL(k_heavy_chunk_counts, dim3(grid_for((size_t)H + 1)), dim3(kBlock), 0, s,
+                       heavy, H, segptr, hcnt);
+    XF_TRY(exclusive_scan_u32(sc, hcnt, hch, (size_t)H + 1, s));
+    XF_HIP(hipMemcpyAsync(&n_hch, hch + H, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipStreamSynchronize(s));
+  }
+  XF_HIP(hipMemcpyAsync(tile_ptr + ntiles, &U, 4, hipMemcpyHostToDevice, s));
+  // ---- the lists whose sizes came last, in a second allocation
+  b->R = R;
+  b->NNZ = NNZ;
+  b->U = U;
+  b->H = H;
+  b->on_device_only = true;
+  b->fm_keyed = true;
+  const size_t n_tile = (size_t)ntiles + 1;
+  const size_t o_heavy = 0;
+  const size_t o_tile = o_heavy + al((size_t)H * 4);
+  const size_t o_hch = o_tile + al(n_tile * 4);
+  const size_t o_hscr = o_hch + al(H ? ((size_t)H + 1) * 4 : 0);
+  const size_t total2 = o_hscr + al((size_t)n_hch * (1 + XF_HEAVY_KMAX) * 8) + 256;
+  char *d2 = nullptr;
+  XF_TRY(xf::blob_alloc((void **)&d2, total2, &b->d_blob2_bytes));
+  b->d_blob2 = d2;
+  auto cp = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    return hipMemcpyAsync(d2 + off, src, bytes, hipMemcpyDeviceToDevice, s);
+  };
+  XF_HIP(cp(o_heavy, heavy, (size_t)H * 4));
+  XF_HIP(cp(o_tile, tile_ptr, n_tile * 4));
+  if (H) XF_HIP(cp(o_hch, hch, ((size_t)H + 1) * 4));
+  b->d_fm_ridx = ridx;
+  b->fm_ridx_bytes = ridx_bytes;
+  rguard.p = nullptr;
+  b->fm_uid[0] = xf::table_uid(w);
+  b->fm_epoch[0] = xf::table_epoch(w);
+  b->fm_uid[1] = b->fm_ridx_uid = xf::table_uid(v);
+  b->fm_epoch[1] = b->fm_ridx_epoch = xf::table_epoch(v);
+  XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+  xf_dev_batch &vw = b->view;
+  vw = xf_dev_batch{};
+  vw.R = R;
+  vw.NNZ = NNZ;
+  vw.U = U;
+  vw.H = H;
+  vw.ukeys = (const uint64_t *)(d + place.o_ukeys);
+  vw.rowptr = (const uint32_t *)(d + place.o_rowptr);
+  vw.uidx = nullptr;
+  vw.segptr = segptr;
+  vw.coo_row = (const uint32_t *)(d + place.o_coo);
+  vw.labels = (const int32_t *)(d + place.o_labels);
+  vw.heavy = H ? (const uint32_t *)(d2 + o_heavy) : nullptr;
+  vw.ntiles = ntiles;
+  vw.n_heavy_chunks = n_hch;
+  vw.heavy_chunk_ptr = H ? (const uint32_t *)(d2 + o_hch) : nullptr;
+  vw.heavy_scratch = H ? (double *)(d2 + o_hscr) : nullptr;
+  vw.tile_ptr = (const uint32_t *)(d2 + o_tile);
+  if (keyed_out) *keyed_out = 1;
+  guard.b = nullptr;
+  *out = b;
   return XF_OK;
 }
 

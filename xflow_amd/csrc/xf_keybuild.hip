@@ -101,6 +101,15 @@ struct __attribute__((packed, aligned(4))) Rec3 {
   uint32_t klo, khi, rp;
 };
 
+// FM: the record carries two payloads — the nonzero's row (packed like Rec3::rp) for the
+// key-grouped occurrence lists of the gradient, and its position in the CSR for the forward's
+// per-nonzero record index
+struct __attribute__((aligned(16))) Rec4 {
+  uint32_t klo, khi, rp, pos;
+};
+constexpr uint32_t kFmRpBits = 19;  // rp of a minibatch of <= 16 row windows; above it, in the
+                                    // staged word, the nonzero's place in its tile (13 bits)
+
 // what the host reads back after the build (one copy)
 struct KbSummary {
   unsigned long long miss;
@@ -134,6 +143,10 @@ struct KbArgs {
   uint32_t *nitems;                // their number
   uint32_t flags;                  // experiments (exp_knob)
   Rec3 *rec;                       // [NNZ] records, grouped by super-chunk
+  Rec4 *rec4;                      // FM build: the records with both payloads
+  uint32_t *fm_vrow;               // FM build: [NNZ] state row of every record (kHole: a miss)
+  uint32_t *fm_ridx;               // FM build: [NNZ] state row of every nonzero's key, CSR order
+  uint32_t *fm_rp;                 // FM build: [NNZ] the records' rows (packed), record order
   uint32_t *entries;               // [NNZ] the cells
   uint64_t *missK;                 // [NNZ] miss list: key,
   uint32_t *missR;                 // [NNZ]            row
@@ -590,7 +603,7 @@ __host__ __device__ inline size_t scatter_lds_bytes(uint32_t nS, uint32_t tile) 
 // TILE: kTile, or a half / a quarter of it when the table has so many super-chunks that their
 // per-tile arrays would not fit the LDS next to a full stage (shorter runs of records, more
 // barriers per nonzero: a big table's price)
-template <bool ROWID, uint32_t TILE>
+template <bool ROWID, uint32_t TILE, bool FM = false>
 __global__ void __launch_bounds__(kKb)
 k_kb_scatter(KbArgs a) {
   extern __shared__ uint64_t smem[];
@@ -804,7 +817,7 @@ k_kb_scatter(KbArgs a) {
       if (i0 + q >= n) continue;
       const uint32_t S = sr[q] >> 13, p = L.lofs[S] + (sr[q] & 8191u);
       L.stK[p] = key[q];
-      L.stR[p] = rp[q];
+      L.stR[p] = FM ? rp[q] | ((i0 + q) << kFmRpBits) : rp[q];
       L.stB[p] = (uint16_t)S;
     }
     if (more) {  // take the prefetch over: the loads were issued a tile's work ago
@@ -823,7 +836,12 @@ k_kb_scatter(KbArgs a) {
       for (uint32_t i = tid; i < n; i += kKb) {
         const uint32_t S = L.stB[i];
         const uint64_t kk = L.stK[i];
-        rec[L.base[S] + (i - L.lofs[S])] = Rec3{(uint32_t)kk, (uint32_t)(kk >> 32), L.stR[i]};
+        if (FM)
+          a.rec4[L.base[S] + (i - L.lofs[S])] =
+              Rec4{(uint32_t)kk, (uint32_t)(kk >> 32), L.stR[i] & ((1u << kFmRpBits) - 1u),
+                   e0 + (L.stR[i] >> kFmRpBits)};
+        else
+          rec[L.base[S] + (i - L.lofs[S])] = Rec3{(uint32_t)kk, (uint32_t)(kk >> 32), L.stR[i]};
       }
     if (dslot < kDbgSlots - 8) KB_T(dslot++);
     lds_barrier();
@@ -1030,9 +1048,213 @@ k_kb_resolve(KbArgs a) {
   KB_T(kDbgSlots - 1);
 }
 
+
+// ----------------------------------------------------------------------------------- FM
+// The key build of FMWorker::update (fm_worker.cc:205-225) against the v table's settled tier.
+// Same partition as above (histogram, scan, scatter by super-chunk) with 16-byte records that
+// carry the nonzero's row AND its position in the CSR; then:
+//   k_kb_resolve_fm  every record's state row (= the key's rank in the tier), in record order,
+//                    and — scattered by position — the forward's per-nonzero record index
+//   k_fm_count       touched keys per super-chunk (an LDS histogram of its records' rows)
+//   k_fm_regroup     per super-chunk: its touched keys in row order (key list, rows, segment
+//                    offsets), its records' rows grouped by key (an LDS counting sort): the
+//                    gradient's key-grouped occurrence lists
+// No sort of (key, position) pairs, no unique-key pass over sorted keys, no probe of the table
+// per nonzero.  The order of a key's occurrences is the records' (not reproducible run to run:
+// LDS cursors): the sums the gradient forms from them are exact in fp64.
+__global__ void __launch_bounds__(kRes)
+k_kb_resolve_fm(KbArgs a) {
+  __shared__ uint64_t lk[kSCKeys];
+  __shared__ uint16_t dir[kDirStride];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (blockIdx.x >= *a.nitems) return;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t sb = a.sstart[S], se = a.sstart[S + 1];
+  const uint32_t rb = sb + part * kPart, re = min(se, rb + kPart);
+  const uint32_t k0 = S * kSCKeys, nk = min(kSCKeys, a.nbase - k0);
+  const uint32_t nb = max(nk / 2, 1u);
+  {
+    const ulonglong2 *__restrict__ src = (const ulonglong2 *)(a.bkeys + k0);  // 16-byte aligned
+    for (uint32_t i = tid; i < (nk + 1) / 2; i += kRes) {  // (bkeys is padded past nbase)
+      const ulonglong2 t = src[i];
+      lk[2 * i] = t.x;
+      lk[2 * i + 1] = t.y;
+    }
+    const uint32_t *__restrict__ gd = (const uint32_t *)(a.sdirs + (size_t)S * kDirStride);
+    uint32_t *ld = (uint32_t *)dir;
+    for (uint32_t i = tid; i < (nb + 2 + 1) / 2; i += kRes) ld[i] = gd[i];
+  }
+  __syncthreads();
+  const uint64_t sm = a.smult[S], kfirst = lk[0];
+  auto lkf = [&](uint32_t i) -> uint64_t { return lk[i]; };
+  constexpr int E = 4;
+  uint32_t nmiss = 0;
+  for (uint32_t i0 = rb; i0 < re; i0 += kRes * E) {
+    uint64_t key[E], x0[E], x1[E];
+    uint32_t ds[E], de[E], pos[E], rpk[E];
+    bool ok[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t i = i0 + q * kRes + tid;
+      ok[q] = i < re;
+      const Rec4 r = ok[q] ? a.rec4[i] : Rec4{0u, 0u, 0u, 0u};
+      pos[q] = r.pos;
+      rpk[q] = r.rp;
+      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+      const uint32_t b = kb_sbucket(key[q], kfirst, sm, nb);
+      ds[q] = dir[b];
+      de[q] = dir[b + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      x0[q] = lk[min(ds[q], nk - 1)];
+      x1[q] = lk[min(ds[q] + 1, nk - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t ub = key[q] < kfirst ? 0u : kb_count(lkf, ds[q], de[q], x0[q], x1[q], key[q]);
+      const uint32_t p = ub ? ub - 1 : 0u;
+      const bool found = ub > 0 && lk[p] == key[q];
+      if (ok[q]) {
+        a.fm_vrow[i0 + q * kRes + tid] = found ? k0 + p : kHole;
+        a.fm_rp[i0 + q * kRes + tid] = rpk[q];  // (4 of the record's 16 bytes for the regroup)
+        // the forward's record index of the nonzero (a scattered 4-byte store: here, where the
+        // look-ups keep the workgroup busy, rather than in the regroup pass)
+        if (found) a.fm_ridx[pos[q]] = k0 + p;
+        nmiss += found ? 0u : 1u;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nmiss += __shfl_xor(nmiss, o);
+  if (lane == 0 && nmiss) atomicAdd(&a.sum->miss, (unsigned long long)nmiss);
+}
+
+struct FmRegroup {
+  const uint32_t *vrow;    // [NNZ] state row of every record
+  const uint32_t *rp;      // [NNZ] row of every record (window << 15 | row in window)
+  const uint32_t *sstart;  // [nS + 1] first record of every super-chunk
+  const uint64_t *bkeys;   // the tier's keys
+  uint32_t nS, W;
+  uint32_t *ucount;        // [nS] touched keys per super-chunk; [nS + 1] after the scan: ubase
+  uint64_t *ukeys;         // [U] the minibatch's keys, ascending (= in row order)
+  uint32_t *urow;          // [U] their state rows
+  uint32_t *segptr;        // [U + 1]
+  uint32_t *coo;           // [NNZ] rows of the occurrences, grouped by key
+};
+
+__global__ void __launch_bounds__(kKb)
+k_fm_count(FmRegroup g) {
+  __shared__ uint32_t cnt[kSCKeys];
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t tid = threadIdx.x, S = blockIdx.x;
+  const uint32_t sb = g.sstart[S], se = g.sstart[S + 1], k0 = S * kSCKeys;
+  for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
+  __syncthreads();
+  for (uint32_t i0 = sb; i0 < se; i0 += kKb * 8) {
+    uint32_t r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t i = i0 + q * kKb + tid;
+      r[q] = i < se ? g.vrow[i] : kHole;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (r[q] != kHole) atomicAdd(&cnt[r[q] - k0], 1u);
+  }
+  __syncthreads();
+  uint32_t n = 0;
+  for (uint32_t k = tid; k < kSCKeys; k += kKb) n += cnt[k] ? 1u : 0u;
+  uint32_t total;
+  (void)block_excl_scan(n, wsum, &total);
+  if (tid == 0) g.ucount[S] = total;
+}
+
+// ucount -> its exclusive scan in place, the total behind it
+__global__ void __launch_bounds__(kKb)
+k_fm_scan(uint32_t *__restrict__ ucount, uint32_t nS) {
+  __shared__ uint32_t sbuf[kScanPiece + kScanPiece / 16];
+  __shared__ uint32_t wsum[kKb / 64];
+  const volatile uint32_t *vin = ucount;
+  const uint32_t total =
+      staged_excl_scan([&](uint32_t c) { return (uint32_t)vin[c]; }, nS, ucount, nullptr, sbuf, wsum);
+  if (threadIdx.x == 0) ucount[nS] = total;
+}
+
+__global__ void __launch_bounds__(kKb)
+k_fm_regroup(FmRegroup g) {
+  __shared__ uint32_t cnt[kSCKeys], off[kSCKeys];
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t tid = threadIdx.x, S = blockIdx.x;
+  const uint32_t sb = g.sstart[S], se = g.sstart[S + 1], k0 = S * kSCKeys;
+  for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
+  __syncthreads();
+  for (uint32_t i0 = sb; i0 < se; i0 += kKb * 8) {
+    uint32_t r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t i = i0 + q * kKb + tid;
+      r[q] = i < se ? g.vrow[i] : kHole;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (r[q] != kHole) atomicAdd(&cnt[r[q] - k0], 1u);
+  }
+  __syncthreads();
+  // a thread owns kSCKeys / kKb consecutive rows: where their occurrences begin, and their
+  // numbers among the touched keys
+  constexpr uint32_t kPer = kSCKeys / kKb;
+  uint32_t occ = 0, used = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; ++q) {
+    const uint32_t c = cnt[tid * kPer + q];
+    occ += c;
+    used += c ? 1u : 0u;
+  }
+  uint32_t t0, t1;
+  uint32_t run = block_excl_scan(occ, wsum, &t0);
+  uint32_t urun = g.ucount[S] + block_excl_scan(used, wsum, &t1);
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; ++q) {
+    const uint32_t k = tid * kPer + q, c = cnt[k];
+    off[k] = run;
+    if (c) {
+      g.urow[urun] = k0 + k;
+      g.ukeys[urun] = g.bkeys[k0 + k];
+      g.segptr[urun] = sb + run;
+      ++urun;
+    }
+    run += c;
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;  // now the rows' cursors
+  __syncthreads();
+  constexpr int E = 8;  // a thread's loads of a round first, then its cursors and stores
+  for (uint32_t i0 = sb; i0 < se; i0 += kKb * E) {
+    uint32_t r[E], rp[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t i = i0 + q * kKb + tid;
+      r[q] = i < se ? g.vrow[i] : kHole;
+      rp[q] = i < se ? g.rp[i] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      if (r[q] == kHole) continue;
+      const uint32_t l = r[q] - k0, slot = sb + off[l] + atomicAdd(&cnt[l], 1u);
+      g.coo[slot] = (rp[q] >> kRinBits) * g.W + (rp[q] & ((1u << kRinBits) - 1u));
+    }
+  }
+}
+
 }  // namespace
 
 namespace xf {
+
+// where the FM build's U-sized arrays go: ukeys [U], urow [U], segptr [U + 1], coo [NNZ]
+typedef int (*FmKeyedOut)(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow,
+                          uint32_t **segptr, uint32_t **coo);
 
 static KbSummary *summary_buf() {
   static thread_local KbSummary *p = nullptr;
@@ -1262,6 +1484,118 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   // general build's own)
   guard.c = nullptr;
   *out = c;
+  return XF_OK;
+}
+
+
+// The FM key build (kernels above).  The arrays whose size is the number of distinct keys are
+// written where `place` says, once that number is known (the caller's allocation: no copies
+// afterwards).  *ok = false: the fast path does not apply (no settled
+// tier, a minibatch of more than 16 row windows, a table too large for the LDS tables, or a key
+// the tier does not hold) — the caller takes the sort-based build.
+int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr, uint32_t R,
+                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, uint32_t *U_out,
+                   uint32_t *ridx /* [NNZ], the caller's */, FmKeyedOut place, void *ctx) {
+  *ok = false;
+  const TableDev T = table_dev(t);
+  const uint64_t cA64 = (T.nbase + kChunk - 1) / kChunk;
+  const uint64_t nS64 = (cA64 + kSC - 1) / kSC;
+  const uint32_t nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+  KbSummary *sum = summary_buf();
+  const bool fits = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
+                    R > 0 && sum != nullptr && cA64 < 0xFFFFu && nwin <= 16 &&
+                    scatter_lds_bytes((uint32_t)nS64, kTile / 2) <= kDynMax &&
+                    hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax &&
+                    ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256;
+  if (!fits) return XF_OK;
+  const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
+  KbArgs a{};
+  a.keys = d_keys;
+  a.rowptr = d_rowptr;
+  a.R = R;
+  a.NNZ = NNZ;
+  a.W = std::max<uint32_t>(1, (R + nwin - 1) / nwin);  // (cells_alloc's window)
+  a.nwin = nwin;
+  a.cA = cA;
+  a.nS = nS;
+  a.tile = scatter_lds_bytes(nS, kTile) <= kDynMax ? kTile : kTile / 2;
+  a.ntile = (NNZ + a.tile - 1) / a.tile;
+  a.nbase = (uint32_t)T.nbase;
+  a.bkeys = T.bkeys;
+  a.lo = T.lo;
+  XF_TRY(kb_index(t, T, cA, nS, &a, s));
+  const size_t ncell = (size_t)nwin * cA;
+  const unsigned max_items = nS + NNZ / kPart + 1;
+  const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
+  if (sub > kMaxSub) return XF_OK;
+  a.span = sub * a.tile;
+  a.nW = (a.ntile + sub - 1) / sub;
+  uint32_t *small = nullptr;
+  const size_t n_zero = 4 + ncell;
+  const size_t n_small = n_zero + ncell + (ncell + 1) + 3 * ((size_t)cA + 1) + (size_t)nS * 2 + 1 +
+                         max_items + 1 + (size_t)a.nW * nS + a.ntile + 1 + ((size_t)nS + 2);
+  XF_TRY(sc.get(&small, n_small));
+  a.sum = (KbSummary *)small;
+  a.hist = small + 4;
+  a.cellcur = a.hist + ncell;
+  a.cellptr = a.cellcur + ncell;
+  a.plan = a.cellptr + ncell + 1;
+  a.scount = a.plan + 3 * ((size_t)cA + 1);
+  a.sstart = a.scount + nS;
+  a.items = a.sstart + nS + 1;
+  a.nitems = a.items + max_items;
+  a.wgcnt = a.nitems + 1;
+  a.tile_r0 = a.wgcnt + (size_t)a.nW * nS;
+  uint32_t *ucount = a.tile_r0 + a.ntile + 1;
+  XF_TRY(sc.get(&a.rec4, NNZ));
+  XF_TRY(sc.get(&a.fm_vrow, NNZ));
+  XF_TRY(sc.get(&a.fm_rp, NNZ));
+  a.fm_ridx = ridx;
+  XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
+  const bool ldsb = hist_lds_bytes(cA, nS, true) <= kDynMax;
+  const size_t hl = hist_lds_bytes(cA, nS, ldsb);
+#define XF_KB_LAUNCH(kern, grid, lds)                                                          \
+  do {                                                                                         \
+    static bool attr_done = false;                                                             \
+    if (!attr_done) {                                                                          \
+      XF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)kDynMax));                                               \
+      attr_done = true;                                                                        \
+    }                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kKb), lds, s, a);                                \
+  } while (0)
+  if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl);
+  else
+    XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
+  hipLaunchKernelGGL(k_kb_scan, dim3(2 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
+  const size_t sl = scatter_lds_bytes(nS, a.tile);
+  if (a.tile == kTile) XF_KB_LAUNCH((k_kb_scatter<false, kTile, true>), a.nW, sl);
+  else
+    XF_KB_LAUNCH((k_kb_scatter<false, kTile / 2, true>), a.nW, sl);
+#undef XF_KB_LAUNCH
+  hipLaunchKernelGGL(k_kb_resolve_fm, dim3(max_items), dim3(kRes), 0, s, a);
+  FmRegroup g{};
+  g.vrow = a.fm_vrow;
+  g.rp = a.fm_rp;
+  g.sstart = a.sstart;
+  g.bkeys = T.bkeys;
+  g.nS = nS;
+  g.W = a.W;
+  g.ucount = ucount;
+  hipLaunchKernelGGL(k_fm_count, dim3(nS), dim3(kKb), 0, s, g);
+  hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(kKb), 0, s, ucount, nS);
+  uint32_t U = 0;
+  XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(&U, ucount + nS, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  if (sum->miss) return XF_OK;  // a key the tier does not hold: the general build
+  XF_TRY(place(ctx, U, &g.ukeys, &g.urow, &g.segptr, &g.coo));
+  hipLaunchKernelGGL(k_fm_regroup, dim3(nS), dim3(kKb), 0, s, g);
+  XF_HIP(hipMemcpyAsync(g.segptr + U, &NNZ, 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipGetLastError());
+  *U_out = U;
+  *ok = true;
   return XF_OK;
 }
 

@@ -1862,6 +1862,18 @@ static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace 
                            void *stream, bool want_w = true, bool *any_fresh = nullptr) {
   const xf_dev_batch &v = b->view;
   xf_table *tabs[2] = {w, vt};
+  if (b->fm_keyed) {
+    // compiled against these tables' settled tiers (xf_batch_compile_fm_dev): the rows came with
+    // the key list, and there is no CSR index to rebuild anything from
+    for (int i = 0; i < 2; ++i)
+      XF_REQUIRE(b->fm_uid[i] == xf::table_uid(tabs[i]) && b->fm_epoch[i] == xf::table_epoch(tabs[i]),
+                 "this FM minibatch was compiled against the tables' row numbering "
+                 "(xf_batch_compile_fm_dev) and %s has renumbered its rows since, or is another "
+                 "table: compile it again", i ? "the v table" : "the w table");
+    if (want_w && v.U)
+      XF_TRY(xf::gather_f32(xf::table_dev(w).w, b->d_fm_rows[0], v.U, ws->wu, S(stream)));
+    return XF_OK;
+  }
   for (int i = 0; i < 2 && v.U; ++i) {
     const uint64_t uid = xf::table_uid(tabs[i]), ep = xf::table_epoch(tabs[i]);
     const bool fresh = !b->d_fm_rows[i] || b->fm_uid[i] != uid || b->fm_epoch[i] != ep;
@@ -1972,6 +1984,9 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
   XF_BEGIN();
   const bool recmode = fm_table_records_enabled() && xf::fm_records_fit(k) && !ws->capture &&
                        ws->parity == XF_PARITY_EXACT_SUMS && v.U && v.R;
+  XF_REQUIRE(!b->fm_keyed || recmode || !v.U,
+             "a minibatch of xf_batch_compile_fm_dev steps on the table-resident records only "
+             "(k in {4, 8, 16, 32, 64}, no capture, no parity mode): use xf_batch_compile_dev");
   bool fresh = false;
   XF_TRY(fm_resolve_rows(w, vt, b, ws, stream, !recmode, &fresh));
   const uint32_t *rows_w = v.U ? b->d_fm_rows[0] : ws->slots;
@@ -2205,6 +2220,8 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
                              float *pctr_out) {
   XF_REQUIRE(w && vt && b && ws && pctr_out, "xf_fm_predict: null argument");
   XF_REQUIRE(!b->local, "xf_fm_predict: needs a minibatch with a key list (xf_batch_compile*)");
+  XF_REQUIRE(!b->fm_keyed, "xf_fm_predict: a minibatch of xf_batch_compile_fm_dev has no CSR index "
+             "of its key list (it is for training steps): use xf_batch_compile_dev");
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, nullptr));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
