@@ -21,6 +21,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+# experiments only (tools/grad_timeline.py: -DXF_GRAD_TIMELINE); part of the source hash, so a
+# library built with extra flags never passes for the plain one
+EXTRA = os.environ.get("XF_EXTRA_FLAGS", "").split()
+FLAGS += EXTRA
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -40,6 +46,8 @@ def source_hash():
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
+    if EXTRA:
+        h.update(" ".join(EXTRA).encode())
     return h.hexdigest()[:32]
 
 

@@ -49,7 +49,10 @@ constexpr uint32_t kTagMask = (1u << (32 - kTagShift)) - 1u;
 static_assert(kChunkBits >= 8 && kChunkBits <= 13, "chunk of 256 .. 8192 index positions");
 constexpr uint32_t kBlk = 1024;                // entries per forward block (blk_cell granule)
 // entries one gradient workgroup takes of a chunk (a chunk with more is cut into slices)
-constexpr uint32_t kSliceMax = 4 * kChunk > 8192 ? 4 * kChunk : 8192;
+#ifndef XF_SLICE_MAX
+#define XF_SLICE_MAX (4 * kChunk > 8192 ? 4 * kChunk : 8192)
+#endif
+constexpr uint32_t kSliceMax = XF_SLICE_MAX;
 constexpr uint32_t kNoDump = 0xFFFFFFFFu;
 
 enum { kCellsTableRows = 0, kCellsUidx = 1 };
@@ -77,14 +80,16 @@ struct xf_cells {
                                     //       == entries when the copy was not built)
   uint32_t *cellptr = nullptr;      // [ncell + 1]
   uint32_t *blk_cell = nullptr;     // [nblk + 1] cell of entry kBlk*b; [nblk] = ncell - 1
-  uint32_t *plan = nullptr;         // [3 * (nchunk + 1)] slices per chunk and their two scans
+  uint32_t *plan = nullptr;         // [4 * (nchunk + 1)] slices per chunk and three scans of them
   uint32_t *item_chunk = nullptr;   // [nitems]   gradient work items: chunk,
   uint32_t *item_slice = nullptr;   // [nitems]   slice | nslices << 16,
   uint32_t *item_dump = nullptr;    // [nitems]   index of the chunk among the split ones
   uint32_t *split_chunk = nullptr;  // [nsplit_chunks] chunks cut into several items
   double *gsum = nullptr;           // [nsplit_chunks * kChunk] their key sums (fp64 atomics)
   uint8_t *gtouched = nullptr;      // [nsplit_chunks * kChunk] 1 = the minibatch holds the key
-  size_t split_bytes = 0;           // gsum + gtouched: cleared before every gradient pass
+  size_t split_bytes = 0;           // gsum + gtouched: zero between gradient passes (the finish
+                                    // kernel leaves them so; a memset only while split_dirty)
+  mutable bool split_dirty = true;
 };
 
 namespace xf {

@@ -114,8 +114,8 @@ constexpr int kPlanBlock = 1024;
 __global__ void __launch_bounds__(kPlanBlock)
 k_plan_items(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
              uint32_t *__restrict__ nsl, uint32_t *__restrict__ off,
-             uint32_t *__restrict__ soff) {
-  __shared__ uint32_t wsum[2][kPlanBlock / 64];
+             uint32_t *__restrict__ soff, uint32_t *__restrict__ poff) {
+  __shared__ uint32_t wsum[3][kPlanBlock / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t per = (nchunk + kPlanBlock - 1) / kPlanBlock;
   const uint32_t c0 = min(tid * per, nchunk), c1 = min(c0 + per, nchunk);
@@ -125,61 +125,92 @@ k_plan_items(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwi
       n += cellptr[(size_t)v * nchunk + c + 1] - cellptr[(size_t)v * nchunk + c];
     return (n + kSliceMax - 1) / kSliceMax;
   };
-  uint32_t a = 0, b = 0;
+  uint32_t a = 0, b = 0, p = 0;
   for (uint32_t c = c0; c < c1; ++c) {
     const uint32_t S = slices(c);
     a += S;
     b += S > 1 ? 1u : 0u;
+    p += S > 1 ? S : 0u;
   }
-  uint32_t ia = a, ib = b;  // inclusive scan over the threads
+  uint32_t ia = a, ib = b, ip = p;  // inclusive scan over the threads
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+    const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o), tp = __shfl_up(ip, o);
     if ((int)lane >= o) {
       ia += ta;
       ib += tb;
+      ip += tp;
     }
   }
   if (lane == 63) {
     wsum[0][wave] = ia;
     wsum[1][wave] = ib;
+    wsum[2][wave] = ip;
   }
   __syncthreads();
-  uint32_t ba = 0, bb = 0;
+  uint32_t ba = 0, bb = 0, bp = 0;
   for (uint32_t w = 0; w < wave; ++w) {
     ba += wsum[0][w];
     bb += wsum[1][w];
+    bp += wsum[2][w];
   }
-  uint32_t ea = ba + ia - a, eb = bb + ib - b;  // exclusive prefix of this thread's range
+  // exclusive prefix of this thread's range
+  uint32_t ea = ba + ia - a, eb = bb + ib - b, ep = bp + ip - p;
   for (uint32_t c = c0; c < c1; ++c) {
     const uint32_t S = slices(c);  // (recomputed: a reload of nsl[] would wait for the stores)
     nsl[c] = S;
     off[c] = ea;
     soff[c] = eb;
+    poff[c] = ep;
     ea += S;
     eb += S > 1 ? 1u : 0u;
+    ep += S > 1 ? S : 0u;
   }
   if (tid == kPlanBlock - 1) {
     nsl[nchunk] = 0;
     off[nchunk] = ba + ia;
     soff[nchunk] = bb + ib;
+    poff[nchunk] = bp + ip;
   }
 }
 
 __global__ void __launch_bounds__(kBlock)
 k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
-             const uint32_t *__restrict__ soff, uint32_t nchunk,
-             uint32_t *__restrict__ item_chunk, uint32_t *__restrict__ item_slice,
-             uint32_t *__restrict__ item_dump, uint32_t *__restrict__ split_chunk) {
-  XF_GRID_STRIDE(c, nchunk) {
-    const uint32_t S = nsl[c];
-    for (uint32_t s = 0; s < S; ++s) {
-      const uint32_t i = off[c] + s;
+             const uint32_t *__restrict__ soff, const uint32_t *__restrict__ poff,
+             uint32_t nchunk, uint32_t *__restrict__ item_chunk,
+             uint32_t *__restrict__ item_slice, uint32_t *__restrict__ item_dump,
+             uint32_t *__restrict__ split_chunk) {
+  // Longest items first: the slices of the split chunks (kSliceMax entries each) take the first
+  // poff[nchunk] places of the list, the unsplit chunks follow in chunk order — a slice that
+  // starts in the last round of workgroups was the tail of the power-law gradient kernel.
+  // (a wavefront per 64 chunks; the slices of a split chunk are written by all its lanes: a
+  // power-law head chunk has a hundred and more, one lane writing them all took 96 us)
+  const uint32_t P = poff[nchunk];
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwave = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t cb = wave0 * 64; cb < nchunk; cb += nwave * 64) {
+    const size_t c = cb + lane;
+    const uint32_t S = c < nchunk ? nsl[c] : 0u;
+    if (S == 1) {
+      const uint32_t i = P + (off[c] - poff[c]);
       item_chunk[i] = (uint32_t)c;
-      item_slice[i] = s | (S << 16);
-      item_dump[i] = S > 1 ? soff[c] : kNoDump;
+      item_slice[i] = 1u << 16;
+      item_dump[i] = kNoDump;
     }
-    if (S > 1) split_chunk[soff[c]] = (uint32_t)c;
+    unsigned long long m = __ballot(S > 1);
+    while (m) {  // wave-uniform
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const uint32_t cs = (uint32_t)cb + (uint32_t)l, Ss = (uint32_t)__shfl((int)S, l);
+      const uint32_t p0 = poff[cs], so = soff[cs];
+      for (uint32_t s = lane; s < Ss; s += 64) {
+        item_chunk[p0 + s] = cs;
+        item_slice[p0 + s] = s | (Ss << 16);
+        item_dump[p0 + s] = so;
+      }
+      if (lane == 0) split_chunk[so] = cs;
+    }
   }
 }
 
@@ -379,7 +410,7 @@ __device__ __forceinline__ void apply_key(const xf::TableDev &T, int opt, size_t
 // as ONE atomic; up to three such keys per call, everything else one atomic per lane.
 // `touched` is a byte per key written with plain stores: every writer stores the same 1.
 __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on, uint32_t k,
-                                         float val) {
+                                         double val) {
   const unsigned lane = threadIdx.x & 63u;
   uint32_t kk = on ? k : (0x80000000u | lane);  // inactive lanes: a key nobody else has
   for (int round = 0; round < 3; ++round) {
@@ -388,7 +419,7 @@ __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on,
     const int leader = __ffsll((long long)cand) - 1;
     const uint32_t k0 = (uint32_t)__shfl((int)kk, leader);
     const bool mine = kk == k0;
-    double sum = mine ? (double)val : 0.0;
+    double sum = mine ? val : 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     if ((int)lane == leader) {
@@ -398,9 +429,52 @@ __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on,
     if (mine) kk = 0x80000000u | lane;
   }
   if (!(kk & 0x80000000u)) {
-    atomicAdd(&acc[kk], (double)val);
+    atomicAdd(&acc[kk], val);
     touched[kk] = 1;
   }
+}
+// ... of a lane's E entries at once.  A power-law head key fills most of the E slots of every
+// lane of its chunk's workgroups, and taken slot by slot it went through E cross-lane
+// reductions per round (~150 instructions per entry slot: they were the power-law gradient
+// kernel).  Here a key found in two neighbouring lanes of slot `round` is summed over ALL the
+// slots of all lanes in registers (fp64 sums of fp32 terms), then over the lanes, and lands as
+// ONE atomic; up to three such keys per call, every other entry one atomic.
+template <int E>
+__device__ __forceinline__ void add_keys_folded(double *acc, uint8_t *touched,
+                                                const uint32_t (&ent)[E], const float (&l)[E]) {
+  const unsigned lane = threadIdx.x & 63u;
+  uint32_t kk[E];  // the key's place in the chunk; bit 31: nothing (left) to add
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    kk[q] = ent[q] != 0xFFFFFFFFu ? (ent[q] & (kChunk - 1)) : 0x80000000u;
+#pragma unroll
+  for (int round = 0; round < 3 && round < E; ++round) {
+    const uint32_t probe = kk[round];
+    const unsigned long long cand =
+        __ballot(probe == (uint32_t)__shfl_xor((int)probe, 1) && !(probe & 0x80000000u));
+    if (!cand) break;  // wave-uniform
+    const int leader = __ffsll((long long)cand) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)probe, leader);
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const bool m = kk[q] == k0;
+      sum += m ? (double)l[q] : 0.0;
+      kk[q] = m ? 0x80000000u : kk[q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((int)lane == leader) {
+      atomicAdd(&acc[k0], sum);
+      touched[k0] = 1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (!(kk[q] & 0x80000000u)) {
+      atomicAdd(&acc[kk[q]], (double)l[q]);
+      touched[kk[q]] = 1;
+    }
 }
 
 #ifndef XF_GRAD_E
@@ -414,6 +488,21 @@ __device__ __forceinline__ void add_keys(double *acc, uint8_t *touched, bool on,
 #endif
 constexpr int kGradE = XF_GRAD_E;  // entries per lane and round
 constexpr uint32_t kGradWin = 32;  // windows whose slice bounds fit the LDS table
+constexpr uint32_t kSparseKeys = 2 * 256;  // touched keys of a chunk that are stepped from a list
+
+// Timeline of the work items (tools/grad_timeline.py; build with -DXF_GRAD_TIMELINE, never by
+// default): wall_clock64 ticks (10 ns) of every workgroup's phases.
+#ifdef XF_GRAD_TIMELINE
+constexpr int kTlSlots = 8;
+__device__ unsigned long long xf_grad_tl[16384 * kTlSlots];
+#define GRAD_T(slot)                                                                  \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 16384)                                       \
+      xf_grad_tl[blockIdx.x * kTlSlots + (slot)] = wall_clock64();                    \
+  } while (0)
+#else
+#define GRAD_T(slot) do { } while (0)
+#endif
 
 template <int OPT, int MODE, bool SRC, bool MULTI = false /* SRC with more than one source */>
 __global__ void __launch_bounds__(kBlock, MULTI ? XF_GRAD_MULTI_WAVES : SRC ? 1 : 6)
@@ -428,7 +517,10 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
+  __shared__ uint32_t nlist;
   const uint32_t tid = threadIdx.x;
+  GRAD_T(0);
+  if (tid == 0) nlist = 0;
   const uint32_t c = item_chunk[blockIdx.x];
   const uint32_t sl = item_slice[blockIdx.x], s = sl & 0xFFFFu, S = sl >> 16;
   for (uint32_t k = tid; k < kChunk; k += kBlock) {
@@ -512,7 +604,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
 #pragma unroll
           for (int i = 0; i < kGradE; ++i)
             if (i >= ib && i <= ie)  // workgroup-uniform
-              add_keys(acc, touched, (ek[i] >> 16) == q, ek[i] & (kChunk - 1), l[i]);
+              add_keys(acc, touched, (ek[i] >> 16) == q, ek[i] & (kChunk - 1), (double)l[i]);
           __syncthreads();
           const uint32_t rq = src_rows[q];
 #pragma unroll
@@ -565,6 +657,10 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
     }
     __syncthreads();
     const uint32_t total = cum[nv];
+    GRAD_T(1);
+#ifdef XF_GRAD_TIMELINE
+    if (tid == 0 && blockIdx.x < 16384) xf_grad_tl[blockIdx.x * kTlSlots + 7] = total;
+#endif
     for (uint32_t p0 = 0; p0 < total; p0 += kBlock * kGradE) {  // workgroup-uniform trip count
       uint32_t ent[kGradE], vq[kGradE];
       float l[kGradE];
@@ -586,12 +682,17 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                    ? loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
                           ((ent[q] >> kChunkBits) & kRowMask)]
                    : 0.0f;
+      if constexpr (SRC)  // (the owner's passes: their registers stay where they were)
 #pragma unroll
-      for (int q = 0; q < kGradE; ++q)
-        add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), l[q]);
+        for (int q = 0; q < kGradE; ++q)
+          add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), (double)l[q]);
+      else
+        add_keys_folded<kGradE>(acc, touched, ent, l);
     }
   }
+  GRAD_T(2);
   __syncthreads();
+  GRAD_T(3);
   if (S > 1) {  // a slice of a split chunk: into the chunk's accumulators in HBM
     const size_t slot = (size_t)q * nsplit + item_dump[blockIdx.x];
     for (uint32_t k = tid; k < kChunk; k += kBlock)
@@ -603,6 +704,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
           touched[k] = 0;
         }
       }
+    GRAD_T(6);
     continue;
   }
   // eight keys per thread at a time in three sweeps — every state row requested, stepped,
@@ -621,7 +723,74 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (g_out) g_out[row0 + k] = g;
       if (MODE == 0) apply_key(T, OPT, row0 + k, g);
     }
-  } else
+  } else {
+  // A chunk of which the minibatch touched few keys (a power-law minibatch touches a tenth of
+  // a chunk's keys: the sweeps below would run every optimizer step with a tenth of the lanes):
+  // the touched keys are listed (in the bytes of `touched`, once every thread has read its own)
+  // and stepped with all lanes busy.  Same sums, same steps.
+  if constexpr (kChunk == kBlock * 8) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (touched[i * kBlock + tid] && row0 + i * kBlock + tid < M) mine |= 1u << i;
+    const uint32_t cnt = (uint32_t)__popc(mine), lane = tid & 63u;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += u;
+    }
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(&nlist, inc);
+    base = (uint32_t)__shfl((int)base, 63);
+    __syncthreads();
+    const uint32_t n = nlist;
+    if (n <= kSparseKeys) {  // workgroup-uniform
+      uint16_t *list = (uint16_t *)touched;
+      uint32_t pos = base + inc - cnt;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (mine >> i & 1u) list[pos++] = (uint16_t)(i * kBlock + tid);
+      __syncthreads();
+      GRAD_T(4);
+      constexpr int kS = (int)(kSparseKeys / kBlock);
+      uint32_t k[kS];
+      float g[kS], sw[kS], sn[kS], sz[kS];
+#pragma unroll
+      for (int i = 0; i < kS; ++i) {
+        const uint32_t j = i * kBlock + tid;
+        k[i] = j < n ? list[j] : 0xFFFFFFFFu;
+        const size_t r = row0 + (j < n ? k[i] : 0u);
+        g[i] = j < n ? xf::div_by_rows((float)acc[k[i]], Rq) : 0.0f;  // lr_worker.cc:117
+        if (MODE == 0) {
+          sw[i] = T.w[r];
+          sn[i] = sz[i] = 0.0f;
+          if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kS; ++i) {
+        if (k[i] == 0xFFFFFFFFu) continue;
+        if (g_out) g_out[row0 + k[i]] = g[i];
+        if (MODE == 0) {
+          if (OPT == XF_OPT_FTRL)
+            xf::ftrl_step(T.alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
+          else
+            sw[i] = xf::sgd_step(T.lr, g[i], sw[i]);
+        }
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < kS; ++i) {
+          if (k[i] == 0xFFFFFFFFu) continue;
+          T.w[row0 + k[i]] = sw[i];
+          if (OPT == XF_OPT_FTRL) xf::store_nz(T, row0 + k[i], sn[i], sz[i]);
+        }
+      }
+      GRAD_T(5);
+      return;
+    }
+  }
   for (uint32_t kb = 0; kb < kChunk; kb += kBlock * 8) {
     bool t[8];
     float g[8], sw[8], sn[8], sz[8];
@@ -661,8 +830,18 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       }
     }
   }
+  GRAD_T(6);
+  }
   }  // sources
 }
+
+#ifdef XF_GRAD_TIMELINE
+}  // namespace
+extern "C" int xf_debug_grad_timeline(unsigned long long *out, size_t n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(xf_grad_tl), n * 8) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
 
 // ---- the gradient + Push of the steady state: ONE source, no split chunk, at most kDenseWin
 // row windows (config 2: three) — the launch that takes most of the LR step.  What the general
@@ -893,18 +1072,24 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
 template <int OPT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_lr_grad_split_finish(xf::TableDev T, const uint32_t *__restrict__ split_chunk,
-                       const double *__restrict__ gsum, const uint8_t *__restrict__ gtouched,
+                       double *__restrict__ gsum, uint8_t *__restrict__ gtouched,
                        uint32_t R, uint32_t M, float *__restrict__ g_out, uint32_t nsrc,
-                       const uint32_t *__restrict__ src_rows, uint32_t nsplit, uint32_t chunk0) {
+                       const uint32_t *__restrict__ src_rows, uint32_t nsplit, uint32_t chunk0,
+                       int clean) {
   const uint32_t slot = blockIdx.x / (kChunk / kBlock);
   const uint32_t k = (blockIdx.x % (kChunk / kBlock)) * kBlock + threadIdx.x;
   const size_t idx = (size_t)(chunk0 + split_chunk[slot]) * kChunk + k;
-  if (idx >= M) return;
+  if (idx >= M) return;  // (no entry names a row the table does not hold: never touched)
   const uint32_t ns = src_rows ? nsrc : 1u;
   for (uint32_t q = 0; q < ns; ++q) {  // the workers' steps in rank order
     const size_t o = ((size_t)q * nsplit + slot) * kChunk + k;
     if (!gtouched[o]) continue;
-    const float g = xf::div_by_rows((float)gsum[o], src_rows ? src_rows[q] : R);
+    const double sum = gsum[o];
+    if (clean) {  // the accumulators go back to zero here: no memset before the next pass
+      gsum[o] = 0.0;
+      gtouched[o] = 0;
+    }
+    const float g = xf::div_by_rows((float)sum, src_rows ? src_rows[q] : R);
     if (g_out) g_out[idx] = g;
     if (MODE == 0) apply_key(T, OPT, idx, g);
   }
@@ -977,7 +1162,7 @@ int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
   const size_t o_cellptr = o_entk + al(key_sorted_copy ? (size_t)NNZ * 4 : 0);
   const size_t o_blk = o_cellptr + al(((size_t)c->ncell + 1) * 4);
   const size_t o_plan = o_blk + al(((size_t)c->nblk + 1) * 4);
-  const size_t total = o_plan + al(3 * ((size_t)c->nchunk + 1) * 4) + 256;
+  const size_t total = o_plan + al(4 * ((size_t)c->nchunk + 1) * 4) + 256;
   int rc = blob_alloc((void **)&c->blob, total, &c->blob_bytes);
   if (rc != XF_OK) {
     delete c;
@@ -1013,12 +1198,12 @@ int cells_key_sorted_copy(xf_cells *c, hipStream_t s) {
 }
 
 // gradient work items, part 1 (on the device, into the cells' own allocation): slices per
-// chunk and their scans; the totals are plan[2*(nchunk+1) - 1] (items) and plan[3*(nchunk+1) - 1]
-// (split chunks)
+// chunk and their scans; the totals are plan[2*(nchunk+1) - 1] (items), plan[3*(nchunk+1) - 1]
+// (split chunks) and plan[4*(nchunk+1) - 1] (their slices)
 int cells_plan_items(xf_cells *c, hipStream_t s) {
   const size_t nc1 = (size_t)c->nchunk + 1;
   hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(kPlanBlock), 0, s, c->cellptr, c->nchunk,
-                     c->nwin, c->plan, c->plan + nc1, c->plan + 2 * nc1);
+                     c->nwin, c->plan, c->plan + nc1, c->plan + 2 * nc1, c->plan + 3 * nc1);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }
@@ -1047,7 +1232,7 @@ int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t 
   const size_t nc1 = (size_t)c->nchunk + 1;
   if (c->nitems)
     hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, c->plan,
-                       c->plan + nc1, c->plan + 2 * nc1, c->nchunk, c->item_chunk,
+                       c->plan + nc1, c->plan + 2 * nc1, c->plan + 3 * nc1, c->nchunk, c->item_chunk,
                        c->item_slice, c->item_dump, c->split_chunk);
   XF_HIP(hipGetLastError());
   return XF_OK;
@@ -1150,9 +1335,10 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
       const size_t cells = (size_t)src->n * c->nsplit_chunks * kChunk;
       XF_HIP(hipMemsetAsync(gsum, 0, cells * 8, s));
       XF_HIP(hipMemsetAsync(gtouched, 0, cells, s));
-    } else {
+    } else if (c->split_dirty) {
       XF_HIP(hipMemsetAsync(c->gsum, 0, c->split_bytes, s));
     }
+    c->split_dirty = true;  // (until the finish kernel that cleans them is in the stream)
   }
   if (src && src->n == 1 && src->rows_host) {
     // ONE source (sum_then_step, or a group of one): the plain instantiation — its optimizer
@@ -1167,7 +1353,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
       hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                          dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
                          c->split_chunk, gsum, gtouched, src->rows_host, c->M, d_g, 1u,
-                         (const uint32_t *)nullptr, c->nsplit_chunks, c->chunk0);
+                         (const uint32_t *)nullptr, c->nsplit_chunks, c->chunk0, 0);
     XF_HIP(hipGetLastError());
     return XF_OK;
   }
@@ -1246,8 +1432,9 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                        dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
                        c->split_chunk, gsum, gtouched, c->R, c->M, d_g, src ? src->n : 1u,
                        src ? src->d_rows : (const uint32_t *)nullptr, c->nsplit_chunks,
-                       c->chunk0);
+                       c->chunk0, src ? 0 : 1);
   XF_HIP(hipGetLastError());
+  if (!src) c->split_dirty = false;
   return XF_OK;
 }
 

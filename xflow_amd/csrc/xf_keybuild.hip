@@ -565,9 +565,15 @@ k_kb_scan(KbArgs a) {
       tb = staged_excl_scan([&](uint32_t c) { return vn[c] > 1 ? 1u : 0u; }, a.cA, soff, nullptr,
                             sbuf, wsum);
     }
+    // the split chunks' slices, scanned: they go first in the item list (k_items_fill)
+    uint32_t *poff = a.plan + 3 * nc1;
+    const uint32_t tp = staged_excl_scan(
+        [&](uint32_t c) { const uint32_t S = vn[c]; return S > 1 ? S : 0u; }, a.cA, poff, nullptr,
+        sbuf, wsum);
     if (tid == 0) {
       off[a.cA] = ta;
       soff[a.cA] = tb;
+      poff[a.cA] = tp;
       a.sum->nitems = ta;
       a.sum->nsplit = tb;
     }
@@ -1532,7 +1538,7 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   a.nW = (a.ntile + sub - 1) / sub;
   uint32_t *small = nullptr;
   const size_t n_zero = 4 + ncell;
-  const size_t n_small = n_zero + ncell + (ncell + 1) + 3 * ((size_t)cA + 1) + (size_t)nS * 2 + 1 +
+  const size_t n_small = n_zero + ncell + (ncell + 1) + 4 * ((size_t)cA + 1) + (size_t)nS * 2 + 1 +
                          max_items + 1 + (size_t)a.nW * nS + a.ntile + 1 + ((size_t)nS + 2);
   XF_TRY(sc.get(&small, n_small));
   a.sum = (KbSummary *)small;
@@ -1540,7 +1546,7 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   a.cellcur = a.hist + ncell;
   a.cellptr = a.cellcur + ncell;
   a.plan = a.cellptr + ncell + 1;
-  a.scount = a.plan + 3 * ((size_t)cA + 1);
+  a.scount = a.plan + 4 * ((size_t)cA + 1);
   a.sstart = a.scount + nS;
   a.items = a.sstart + nS + 1;
   a.nitems = a.items + max_items;
