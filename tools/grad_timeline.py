@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--zipf", type=float, default=1.1)
     ap.add_argument("--batches", type=int, default=16)
     ap.add_argument("--signal-keys", type=int, default=32)
+    ap.add_argument("--knob", type=int, default=0)
     a = ap.parse_args()
     args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=a.batches,
                               zipf=a.zipf, signal_keys=a.signal_keys, keys_per_gpu=10_000_000)
@@ -34,6 +35,7 @@ def main():
         tr.predict(c)
     info = comp[0].cells_info()
     print(info)
+    capi.tune("exp_knob", a.knob)
     for i in range(6):
         tr.step(comp[i % len(comp)])
     tr.step(comp[0])
@@ -66,6 +68,15 @@ def main():
     infl = [(np.sum((us(t[:, 0]) <= x) & (us(end) > x))) for x in edges]
     print("in flight per 2 us:", infl)
     big = total > 4096
+    d = (end - t[:, 0]) / 100.0
+    print("item time percentiles 10/50/90/99/max: %s" % np.percentile(d, [10, 50, 90, 99, 100]).round(1))
+    o = np.argsort(t[:, 0])
+    q = len(o) // 4
+    for i in range(4):
+        m = o[i * q:(i + 1) * q]
+        print("quarter %d of the starts: start %.1f..%.1f  cum %.2f acc %.2f rest %.2f whole %.2f" % (
+            i, us(t[m, 0]).min(), us(t[m, 0]).max(), ((t[m, 1] - t[m, 0]) / 100).mean(),
+            ((t[m, 2] - t[m, 1]) / 100).mean(), ((end[m] - t[m, 3]) / 100).mean(), d[m].mean()))
     print("items with > 4096 entries: %d; their whole time avg %.1f us, start avg %.1f us" % (
         big.sum(), ((end[big] - t[big, 0]) / 100).mean() if big.any() else 0,
         us(t[big, 0]).mean() if big.any() else 0))

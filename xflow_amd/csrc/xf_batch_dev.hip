@@ -89,12 +89,118 @@ __global__ void k_uidx_coo(const uint32_t *__restrict__ spos, const uint32_t *__
   }
 }
 
-__global__ void k_key_flags(const uint32_t *__restrict__ segptr, uint32_t U,
-                            uint32_t *__restrict__ heavy_flag, uint32_t *__restrict__ tile_flag) {
-  XF_GRID_STRIDE(u, U) {
-    heavy_flag[u] = segptr[u + 1] - segptr[u] > XF_HEAVY_SEG ? 1u : 0u;
-    tile_flag[u] = xf::grad_tile_starts_at(segptr, (uint32_t)u) ? 1u : 0u;
+// The heavy keys and the keys at which a gradient tile starts (xf_tiling.h), two ascending
+// lists, without arrays of U flags and their U-element scans: a tile starts every ~192 occurrences and
+// heavy keys are rare, so the lists are counted per block of kFlagBlk keys, the ~U / 4096 block
+// counts scanned by one workgroup, and the lists written block by block (a thread owns 16
+// neighbouring keys).  25 us instead of 115 at 6.3*10^6 keys.
+constexpr uint32_t kFlagPer = 16, kFlagBlk = kBlock * kFlagPer;
+
+// (U: from the device when the host does not know it yet; the launch is sized for a bound)
+__device__ __forceinline__ uint32_t keys_of(uint32_t U, const uint32_t *__restrict__ d_U) {
+  return d_U ? *d_U : U;
+}
+__device__ __forceinline__ void key_flag_bits(const uint32_t *__restrict__ segptr, uint32_t U,
+                                              uint32_t u0, uint32_t &hbits, uint32_t &tbits) {
+  hbits = tbits = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < kFlagPer; ++i) {
+    const uint32_t u = u0 + i;
+    if (u >= U) break;
+    if (segptr[u + 1] - segptr[u] > XF_HEAVY_SEG) hbits |= 1u << i;
+    if (xf::grad_tile_starts_at(segptr, u)) tbits |= 1u << i;
   }
+}
+
+// sums over the workgroup; every thread gets the exclusive prefix of its own value
+__device__ __forceinline__ uint32_t block_prefix(uint32_t x, uint32_t *wsum, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += t;
+  }
+  __syncthreads();  // (wsum may still be read from the previous call)
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return base + inc - x;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_flag_counts(const uint32_t *__restrict__ segptr, uint32_t Ub, const uint32_t *__restrict__ d_U,
+              uint32_t nb,
+              uint32_t *__restrict__ bc /* [2 * nb]: heavy keys, tile starts per block */) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const uint32_t U = keys_of(Ub, d_U);
+  uint32_t hb, tb, th, tt;
+  key_flag_bits(segptr, U, blockIdx.x * kFlagBlk + threadIdx.x * kFlagPer, hb, tb);
+  block_prefix((uint32_t)__popc(hb), wsum, &th);
+  block_prefix((uint32_t)__popc(tb), wsum, &tt);
+  if (threadIdx.x == 0) {
+    bc[blockIdx.x] = th;
+    bc[nb + blockIdx.x] = tt;
+  }
+}
+
+// one workgroup: both rows of bc scanned in place (exclusive); totals[0] = H, totals[1] = ntiles
+__global__ void __launch_bounds__(kBlock)
+k_flag_bases(uint32_t *__restrict__ bc, uint32_t nb, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  for (uint32_t row = 0; row < 2; ++row) {
+    uint32_t *p = bc + (size_t)row * nb;
+    uint32_t carry = 0;
+    for (uint32_t i0 = 0; i0 < nb; i0 += kBlock) {  // workgroup-uniform trip count
+      const uint32_t i = i0 + threadIdx.x;
+      const uint32_t x = i < nb ? p[i] : 0u;
+      uint32_t tot;
+      const uint32_t e = block_prefix(x, wsum, &tot);
+      if (i < nb) p[i] = carry + e;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) totals[row] = carry;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_flag_compact(const uint32_t *__restrict__ segptr, uint32_t Ub,
+               const uint32_t *__restrict__ d_U, uint32_t nb, const uint32_t *__restrict__ bc,
+               uint32_t *__restrict__ heavy, uint32_t *__restrict__ tile_ptr) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const uint32_t U = keys_of(Ub, d_U);
+  const uint32_t u0 = blockIdx.x * kFlagBlk + threadIdx.x * kFlagPer;
+  uint32_t hb, tb, tot;
+  key_flag_bits(segptr, U, u0, hb, tb);
+  uint32_t ph = bc[blockIdx.x] + block_prefix((uint32_t)__popc(hb), wsum, &tot);
+  uint32_t pt = bc[nb + blockIdx.x] + block_prefix((uint32_t)__popc(tb), wsum, &tot);
+  for (; hb; hb &= hb - 1) heavy[ph++] = u0 + (uint32_t)__ffs((int)hb) - 1u;
+  for (; tb; tb &= tb - 1) tile_ptr[pt++] = u0 + (uint32_t)__ffs((int)tb) - 1u;
+}
+
+// heavy [<= U] and tile_ptr [<= U + 1] filled; d_totals[0] = H, d_totals[1] = ntiles (device).
+// d_U != null: the number of keys is on the device, U is a bound on it.
+static int key_lists(xf::Scratch &sc, const uint32_t *segptr, uint32_t U, const uint32_t *d_U,
+                     uint32_t *heavy, uint32_t *tile_ptr, uint32_t **d_totals, hipStream_t s) {
+  const uint32_t nb = (U + kFlagBlk - 1) / kFlagBlk;
+  uint32_t *bc = nullptr;
+  XF_TRY(sc.get(&bc, (size_t)2 * nb + 2));
+  *d_totals = bc + (size_t)2 * nb;
+  if (!U) {
+    XF_HIP(hipMemsetAsync(*d_totals, 0, 8, s));
+    return XF_OK;
+  }
+  hipLaunchKernelGGL(k_flag_counts, dim3(nb), dim3(kBlock), 0, s, segptr, U, d_U, nb, bc);
+  hipLaunchKernelGGL(k_flag_bases, dim3(1), dim3(kBlock), 0, s, bc, nb, *d_totals);
+  hipLaunchKernelGGL(k_flag_compact, dim3(nb), dim3(kBlock), 0, s, segptr, U, d_U, nb, bc, heavy,
+                     tile_ptr);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
 }
 
 // out[scan[i]] = i for flagged i (scan = exclusive scan of flag); out[total] = sentinel
@@ -282,29 +388,13 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
     XF_HIP(hipMemsetAsync(segptr, 0, 4, s));
   }
   // ---- 3. heavy keys and gradient tiles
-  uint32_t *hflag = nullptr, *tflag = nullptr, *hscan = nullptr, *tscan = nullptr;
-  uint32_t *heavy = nullptr, *tile_ptr = nullptr;
-  XF_TRY(sc.get(&hflag, (size_t)U + 1));
-  XF_TRY(sc.get(&tflag, (size_t)U + 1));
-  XF_TRY(sc.get(&hscan, (size_t)U + 1));
-  XF_TRY(sc.get(&tscan, (size_t)U + 1));
+  uint32_t *heavy = nullptr, *tile_ptr = nullptr, *d_tot = nullptr;
   XF_TRY(sc.get(&heavy, (size_t)U + 1));
   XF_TRY(sc.get(&tile_ptr, (size_t)U + 2));
-  uint32_t H = 0, ntiles = 0;
-  if (U) {
-    XF_HIP(hipMemsetAsync(hflag + U, 0, 4, s));
-    XF_HIP(hipMemsetAsync(tflag + U, 0, 4, s));
-    hipLaunchKernelGGL(k_key_flags, dim3(grid_for(U)), dim3(kBlock), 0, s, segptr, U, hflag,
-                       tflag);
-    XF_TRY(exclusive_scan_u32(sc, hflag, hscan, (size_t)U + 1, s));  // hscan[U] = H
-    XF_TRY(exclusive_scan_u32(sc, tflag, tscan, (size_t)U + 1, s));  // tscan[U] = ntiles
-    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, hflag, hscan,
-                       (size_t)U, heavy);
-    hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, tflag, tscan,
-                       (size_t)U, tile_ptr);
-    XF_HIP(hipMemcpyAsync(&H, hscan + U, 4, hipMemcpyDeviceToHost, s));
-    XF_HIP(hipMemcpyAsync(&ntiles, tscan + U, 4, hipMemcpyDeviceToHost, s));
-  }
+  uint32_t tot[2] = {0, 0};
+  uint32_t &H = tot[0], &ntiles = tot[1];  // (on the host after the synchronisation below)
+  XF_TRY(key_lists(sc, segptr, U, nullptr, heavy, tile_ptr, &d_tot, s));
+  XF_HIP(hipMemcpyAsync(tot, d_tot, 8, hipMemcpyDeviceToHost, s));
   // ---- 4. panel-major forward view
   const uint32_t P = xf::panel_count(U, NNZ, xf::panel_slice_bytes(), xf::min_panel_nnz());
   const size_t ncell = (size_t)P * ((size_t)R + 1);
@@ -486,8 +576,9 @@ uint64_t table_epoch(const xf_table *t);
 typedef int (*FmKeyedOut)(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow,
                           uint32_t **segptr, uint32_t **coo);
 int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr, uint32_t R,
-                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, uint32_t *U_out,
-                   uint32_t *ridx, FmKeyedOut place, void *ctx);
+                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, const uint32_t **d_U,
+                   const unsigned long long **d_miss, uint32_t *ridx, FmKeyedOut place,
+                   void *ctx);
 }  // namespace xf
 
 namespace {
@@ -562,12 +653,13 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
   } guard{b};
   struct Place {
     xf_batch *b;
-    uint32_t R, NNZ;
+    uint32_t R, NNZ, Ub;
     size_t o_ukeys, o_rowptr, o_segptr, o_coo, o_labels;
     static int at(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow, uint32_t **segptr,
                   uint32_t **coo) {
       Place *p = (Place *)ctx;
       auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+      p->Ub = U;  // (a bound: the number itself is still on the device)
       p->o_ukeys = 0;
       p->o_rowptr = p->o_ukeys + al((size_t)U * 8);
       p->o_segptr = p->o_rowptr + al(((size_t)p->R + 1) * 4);
@@ -586,46 +678,42 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
       *coo = (uint32_t *)(d + p->o_coo);
       return XF_OK;
     }
-  } place{b, R, NNZ, 0, 0, 0, 0, 0};
+  } place{b, R, NNZ, 0, 0, 0, 0, 0, 0};
   Scratch sc;
   bool ok = false;
-  uint32_t U = 0;
-  XF_TRY(xf::fm_build_keyed(v, d_keys, d_rowptr, R, NNZ, sc, s, &ok, &U, ridx, &Place::at,
-                            &place));
+  const uint32_t *d_U = nullptr;
+  const unsigned long long *d_miss = nullptr;
+  XF_TRY(xf::fm_build_keyed(v, d_keys, d_rowptr, R, NNZ, sc, s, &ok, &d_U, &d_miss, ridx,
+                            &Place::at, &place));
   if (!ok) {
     XF_HIP(hipStreamSynchronize(s));
     return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
   }
   char *d = (char *)b->d_blob;
   const uint32_t *segptr = (const uint32_t *)(d + place.o_segptr);
-  XF_HIP(hipMemcpyAsync(b->d_fm_rows[0], b->d_fm_rows[1], (size_t)U * 4, hipMemcpyDeviceToDevice,
-                        s));
+  XF_HIP(hipMemcpyAsync(b->d_fm_rows[0], b->d_fm_rows[1], (size_t)place.Ub * 4,
+                        hipMemcpyDeviceToDevice, s));
   XF_HIP(hipMemcpyAsync(d + place.o_rowptr, d_rowptr, ((size_t)R + 1) * 4,
                         hipMemcpyDeviceToDevice, s));
   XF_HIP(hipMemcpyAsync(d + place.o_labels, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
-  // ---- heavy keys and gradient tiles (as in xf_batch_compile_dev)
-  uint32_t *hflag = nullptr, *tflag = nullptr, *hscan = nullptr, *tscan = nullptr;
-  uint32_t *heavy = nullptr, *tile_ptr = nullptr;
-  XF_TRY(sc.get(&hflag, (size_t)U + 1));
-  XF_TRY(sc.get(&tflag, (size_t)U + 1));
-  XF_TRY(sc.get(&hscan, (size_t)U + 1));
-  XF_TRY(sc.get(&tscan, (size_t)U + 1));
-  XF_TRY(sc.get(&heavy, (size_t)U + 1));
-  XF_TRY(sc.get(&tile_ptr, (size_t)U + 2));
-  uint32_t H = 0, ntiles = 0;
-  XF_HIP(hipMemsetAsync(hflag + U, 0, 4, s));
-  XF_HIP(hipMemsetAsync(tflag + U, 0, 4, s));
-  hipLaunchKernelGGL(k_key_flags, dim3(grid_for(U)), dim3(kBlock), 0, s, segptr, U, hflag, tflag);
-  XF_TRY(exclusive_scan_u32(sc, hflag, hscan, (size_t)U + 1, s));
-  XF_TRY(exclusive_scan_u32(sc, tflag, tscan, (size_t)U + 1, s));
-  hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, hflag, hscan,
-                     (size_t)U, heavy);
-  hipLaunchKernelGGL(k_compact_index, dim3(grid_for(U)), dim3(kBlock), 0, s, tflag, tscan,
-                     (size_t)U, tile_ptr);
-  XF_HIP(hipMemcpyAsync(&H, hscan + U, 4, hipMemcpyDeviceToHost, s));
-  XF_HIP(hipMemcpyAsync(&ntiles, tscan + U, 4, hipMemcpyDeviceToHost, s));
+  // ---- heavy keys and gradient tiles (as in xf_batch_compile_dev); the number of keys still
+  // on the device: the lists are sized by what NNZ allows (xf_tiling.h)
+  const size_t h_max = (size_t)NNZ / (XF_HEAVY_SEG + 1) + 1;
+  const size_t t_max = (size_t)NNZ / xf::kGradQuantum + 2 * h_max + 2;
+  uint32_t *heavy = nullptr, *tile_ptr = nullptr, *d_tot = nullptr;
+  XF_TRY(sc.get(&heavy, h_max));
+  XF_TRY(sc.get(&tile_ptr, t_max + 1));
+  uint32_t tot[2] = {0, 0}, U = 0;
+  unsigned long long misses = 0;
+  XF_TRY(key_lists(sc, segptr, place.Ub, d_U, heavy, tile_ptr, &d_tot, s));
+  XF_HIP(hipMemcpyAsync(tot, d_tot, 8, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(&U, d_U, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(&misses, d_miss, 8, hipMemcpyDeviceToHost, s));
   XF_HIP(hipGetLastError());
-  XF_HIP(hipStreamSynchronize(s));
+  XF_HIP(hipStreamSynchronize(s));  // the only wait of the build
+  if (misses)  // a key the tiers do not hold: the sort-based build (what was built is dropped)
+    return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+  const uint32_t H = tot[0], ntiles = tot[1];
   uint32_t *hch = nullptr;
   uint32_t n_hch = 0;
   if (H) {

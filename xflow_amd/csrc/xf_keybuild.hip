@@ -1233,6 +1233,7 @@ k_fm_regroup(FmRegroup g) {
     }
     run += c;
   }
+  if (S == g.nS - 1 && tid == kKb - 1) g.segptr[urun] = g.sstart[g.nS];  // segptr[U] = NNZ
   __syncthreads();
   for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;  // now the rows' cursors
   __syncthreads();
@@ -1495,13 +1496,16 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
 
 
 // The FM key build (kernels above).  The arrays whose size is the number of distinct keys are
-// written where `place` says, once that number is known (the caller's allocation: no copies
-// afterwards).  *ok = false: the fast path does not apply (no settled
+// written where `place` says (the caller's allocation, sized for the bound `place` is called
+// with: no copies afterwards, no wait for the number).  Nothing is waited for: *d_U and *d_miss
+// (device, in `sc`) are the number of distinct keys and of keys the tier does not hold — with
+// misses the arrays are to be discarded.  *ok = false: the fast path does not apply (no settled
 // tier, a minibatch of more than 16 row windows, a table too large for the LDS tables, or a key
 // the tier does not hold) — the caller takes the sort-based build.
 int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr, uint32_t R,
-                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, uint32_t *U_out,
-                   uint32_t *ridx /* [NNZ], the caller's */, FmKeyedOut place, void *ctx) {
+                   uint32_t NNZ, Scratch &sc, hipStream_t s, bool *ok, const uint32_t **d_U,
+                   const unsigned long long **d_miss, uint32_t *ridx /* [NNZ], the caller's */,
+                   FmKeyedOut place, void *ctx) {
   *ok = false;
   const TableDev T = table_dev(t);
   const uint64_t cA64 = (T.nbase + kChunk - 1) / kChunk;
@@ -1590,17 +1594,15 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   g.ucount = ucount;
   hipLaunchKernelGGL(k_fm_count, dim3(nS), dim3(kKb), 0, s, g);
   hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(kKb), 0, s, ucount, nS);
-  uint32_t U = 0;
-  XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
-  XF_HIP(hipMemcpyAsync(&U, ucount + nS, 4, hipMemcpyDeviceToHost, s));
-  XF_HIP(hipGetLastError());
-  XF_HIP(hipStreamSynchronize(s));
-  if (sum->miss) return XF_OK;  // a key the tier does not hold: the general build
-  XF_TRY(place(ctx, U, &g.ukeys, &g.urow, &g.segptr, &g.coo));
+  // no wait for the number of distinct keys: the arrays are placed for the most there can be
+  // (every nonzero its own key, every settled key touched), the regroup takes the number from
+  // the device, and the caller reads it — and the misses — when it next synchronises
+  XF_TRY(place(ctx, (uint32_t)std::min<uint64_t>(NNZ, T.nbase), &g.ukeys, &g.urow, &g.segptr,
+               &g.coo));
   hipLaunchKernelGGL(k_fm_regroup, dim3(nS), dim3(kKb), 0, s, g);
-  XF_HIP(hipMemcpyAsync(g.segptr + U, &NNZ, 4, hipMemcpyHostToDevice, s));
   XF_HIP(hipGetLastError());
-  *U_out = U;
+  *d_U = ucount + nS;
+  *d_miss = &a.sum->miss;
   *ok = true;
   return XF_OK;
 }

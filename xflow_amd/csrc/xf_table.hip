@@ -798,6 +798,11 @@ struct xf_table {
   void *rec = nullptr;
   size_t rec_rows = 0, rec_row_bytes = 0;
   uint64_t rec_gen = 0, rec_tag = 0, writes = 0;
+  // "the record of EVERY settled row is current", as of the key the records' owner set it with
+  // (table_records_all_*): a minibatch compiled against the settled tier then needs no pass
+  // over its keys' rows before its first step
+  bool rec_all_ok = false;
+  uint64_t rec_all[5] = {0, 0, 0, 0, 0};
 };
 
 static void refresh_hyper(xf_table *t) {
@@ -1578,6 +1583,16 @@ int table_records(xf_table *t, size_t row_bytes, uint64_t tag, void **rec, uint6
   *rec = t->rec;
   *gen = t->rec_gen;
   return XF_OK;
+}
+void table_records_all_set(xf_table *t, const uint64_t key[5]) {
+  t->rec_all_ok = true;
+  for (int i = 0; i < 5; ++i) t->rec_all[i] = key[i];
+}
+bool table_records_all_is(const xf_table *t, const uint64_t key[5]) {
+  if (!t->rec_all_ok) return false;
+  for (int i = 0; i < 5; ++i)
+    if (t->rec_all[i] != key[i]) return false;
+  return true;
 }
 // weight writes so far by code that does not maintain the records; table_note_write: one more
 uint64_t table_writes(const xf_table *t) { return t->writes; }
