@@ -115,11 +115,16 @@ int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, const uint64_t 
  * the same way, the key list comes with its state rows, the key-grouped occurrence lists and
  * the forward's per-nonzero record index from the range-partitioned build (no sort of (key,
  * position) pairs); otherwise this IS xf_batch_compile_dev.  *keyed (optional): 1 when the
- * fast build ran.  Such a minibatch is for xf_fm_step on these two tables in their present row
- * numbering (k in {4, 8, 16, 32, 64}); after a defrag it must be compiled again. */
+ * fast build ran.  Such a minibatch is for xf_fm_step / xf_fm_predict on these two tables
+ * (k in {4, 8, 16, 32, 64}, no capture, no parity mode); after a defrag its rows are looked up
+ * again and its record index translated at its next use.  xf_batch_compile_fm: the host-array
+ * front end (the reader's block arrays and a row slice, like xf_batch_compile_gpu). */
 int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v, const uint64_t *d_keys,
                             const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
                             uint32_t NNZ, void *stream, int *keyed);
+int xf_batch_compile_fm(xf_batch **out, xf_table *w, xf_table *v, const uint64_t *rowptr,
+                        const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                        size_t row_end, void *stream, int *keyed);
 /* The key build for a table on THIS GPU, without the sort (LR): every raw key is resolved
  * straight to its state row in `t` (insert on first touch, ftrl.h:56; the table grows when
  * needed) and the nonzeros are grouped into cells (row window x 4096-row chunk of the state)
@@ -471,6 +476,9 @@ int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
 int xf_sbatch_free(xf_sbatch *b);
 int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
                    uint64_t *n_owned /* keys of this minibatch (all ranks) this rank owns */);
+/* 1 when the minibatch came from the FM build against the tables' settled tiers
+ * (xf_batch_compile_fm: one shard, every key settled), else 0; < 0: error */
+int xf_sbatch_fm_keyed(const xf_sbatch *b);
 /* COLLECTIVE: one update() of every rank; asynchronous on the trainer's stream */
 int xf_sharded_step(xf_sharded *st, xf_sbatch *b);
 /* COLLECTIVE: forward only over this rank's rows (ranks without rows pass an empty minibatch) */

@@ -136,28 +136,83 @@ def test_falls_back_to_the_sort_when_a_key_is_not_settled_or_the_tables_differ()
             same(a, e)
 
 
-def test_a_keyed_minibatch_is_bound_to_the_row_numbering_it_was_compiled_against():
+def test_a_keyed_minibatch_scores_and_survives_a_renumbering():
+    """xf_fm_predict on a keyed minibatch (the step's forward on the table-resident records) =
+    the sort-built one's; after new keys and a defrag the keyed minibatch's rows are looked up
+    again and its record index translated: it steps like the oracle; in parity mode it is
+    refused (no CSR index of the key list)"""
     k, nkeys, R = 8, 20000, 1000
     rng = np.random.RandomState(6)
     keytab = capi.hash_decimal_range(0, nkeys)
-    tw, tv, sw, sv = _tables(k, "sgd", nkeys)
+    tw, tv, sw, sv = _tables(k, "ftrl", nkeys)
     _settle(tw, tv, sw, sv, keytab)
     ws = capi.Workspace()
-    raw = synth(rng, R, 30, nkeys, None, True)
+    raw = synth(rng, R, 30, nkeys, 1.2, True)
     b = capi.FmBatch(tw, tv, *raw)
     assert b.keyed
+    bs = capi.Batch(*raw, on_gpu=True)
+    ob = O.Batch(*raw)
+    same(capi.fm_predict(tw, tv, b, ws), capi.fm_predict(tw, tv, bs, ws))
     capi.fm_step(tw, tv, b, ws)
-    with pytest.raises(capi.XFError, match="no CSR index"):
-        capi.fm_predict(tw, tv, b, ws)
-    tv.pull(np.array([777], np.uint64))          # a new key, then a renumbering
-    tw.pull(np.array([777], np.uint64))
+    with O.sum_mode(1):
+        O.fm_update(sw, sv, ob)
+    same(capi.fm_predict(tw, tv, b, ws), capi.fm_predict(tw, tv, bs, ws))
+    new = np.array([777, 778, 1 << 60], np.uint64)   # new keys, then a renumbering
+    for t in (tv, tw, sw, sv):
+        t.pull(new)
     tw.defrag()
     tv.defrag()
-    with pytest.raises(capi.XFError, match="compile it again"):
+    for step in range(3):                            # the old minibatch, translated
         capi.fm_step(tw, tv, b, ws)
+        with O.sum_mode(1):
+            loss_ex, _, _ = ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))
+            O.fm_update(sw, sv, ob)
+        same(ws.fetch_loss(R), loss_ex)
+    same(capi.fm_predict(tw, tv, b, ws), capi.fm_predict(tw, tv, bs, ws))
+    raw2 = synth(rng, R, 30, nkeys, None, True)      # and a fresh one in the new numbering
+    b2 = capi.FmBatch(tw, tv, *raw2)
+    assert b2.keyed
+    capi.fm_step(tw, tv, b2, ws)
+    with O.sum_mode(1):
+        O.fm_update(sw, sv, O.Batch(*raw2))
+    for t, st in ((tw, sw), (tv, sv)):
+        t.check()
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
     wp = capi.Workspace()
     wp.parity("reference_order")
-    b2 = capi.FmBatch(tw, tv, *raw)
-    assert b2.keyed
     with pytest.raises(capi.XFError, match="table-resident records"):
         capi.fm_step(tw, tv, b2, wp)
+
+
+def test_the_one_shard_trainer_compiles_fm_minibatches_against_its_settled_tables():
+    """capi.Sharded (what the worker drives) on one GPU, FM: after the defrag its compile is the
+    range-partitioned build (xf_batch_compile_fm) — training steps, scoring and a second defrag
+    in between equal the oracle's"""
+    k, nkeys, R = 16, 40000, 2000
+    rng = np.random.RandomState(11)
+    st = capi.Sharded(None, model="fm", optimizer="ftrl", k=k, capacity=1 << 18, seed=7)
+    sw, sv = O.Store(O.OPT_FTRL, 1), O.Store(O.OPT_FTRL, k, O.INIT_HASHNORM, 0.001, 7)
+    keyed = 0
+    for step in range(7):
+        raw = synth(rng, R, 40, nkeys, 1.2 if step % 3 == 2 else None, True)
+        sb = st.compile(*raw)
+        keyed += int(sb.keyed)
+        st.step(sb)
+        with O.sum_mode(1):
+            O.fm_update(sw, sv, O.Batch(*raw))
+        if step in (1, 4):                       # every key of the key space, then settle
+            allk = capi.hash_decimal_range(0, nkeys)
+            for t in (st.w, st.v, sw, sv):
+                t.pull(allk)
+            st.defrag()
+        if step == 5:
+            ob = O.Batch(*raw)
+            with O.sum_mode(1):
+                loss, pctr, _ = ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))
+            same(st.predict(st.compile(*raw)), pctr)
+    st.check()
+    assert keyed >= 4, "after the defrag every minibatch's keys are settled"
+    for t, so in ((st.w, sw), (st.v, sv)):
+        for a, e in zip(t.export(), so.export()):
+            same(a, e)

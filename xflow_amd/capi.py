@@ -82,6 +82,8 @@ SIGNATURES = {
                                        C.c_size_t, vp]),
     "xf_batch_compile_fm_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, vp, C.c_uint32,
                                           C.c_uint32, vp, C.POINTER(C.c_int)]),
+    "xf_batch_compile_fm": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, vp, C.c_size_t,
+                                      C.c_size_t, vp, C.POINTER(C.c_int)]),
     "xf_batch_download": (C.c_int, [vp]),
     "xf_batch_compile_local_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, C.c_uint32,
                                              C.c_uint32, C.c_int, vp]),
@@ -159,6 +161,7 @@ SIGNATURES = {
                                      C.c_size_t, C.c_int]),
     "xf_sbatch_free": (C.c_int, [vp]),
     "xf_sbatch_dims": (C.c_int, [vp, u32p, u32p, u32p, u64p]),
+    "xf_sbatch_fm_keyed": (C.c_int, [vp]),
     "xf_sharded_step": (C.c_int, [vp, vp]),
     "xf_sharded_predict": (C.c_int, [vp, vp, f32p]),
     "xf_sharded_flush": (C.c_int, [vp]),
@@ -710,6 +713,7 @@ class ShardedBatch:
         R, N, U, own = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(lib().xf_sbatch_dims(h, C.byref(R), C.byref(N), C.byref(U), C.byref(own)))
         self.R, self.NNZ, self.U, self.n_owned = R.value, N.value, U.value, own.value
+        self.keyed = lib().xf_sbatch_fm_keyed(h) == 1
 
     def __del__(self):
         try:

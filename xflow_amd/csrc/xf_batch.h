@@ -22,6 +22,8 @@ struct xf_batch {
   bool on_device_only = false;  // built by xf_batch_compile_dev and not downloaded yet
   void *d_blob = nullptr;  // one device allocation holding all arrays
   size_t d_blob_bytes = 0;
+  uint64_t fm_nbase = 0;     // fm_keyed: rows of the settled tier the batch was compiled against
+  bool fm_same_rows = false; // fm_keyed: key of rank r has row r in BOTH tables (until a renumbering)
   void *d_blob2 = nullptr;  // fm_keyed: the lists whose sizes are known last (heavy keys, tiles)
   size_t d_blob2_bytes = 0;
   xf_dev_batch view{};

@@ -734,6 +734,8 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
   b->H = H;
   b->on_device_only = true;
   b->fm_keyed = true;
+  b->fm_same_rows = true;
+  b->fm_nbase = xf::table_dev(v).nbase;
   const size_t n_tile = (size_t)ntiles + 1;
   const size_t o_heavy = 0;
   const size_t o_tile = o_heavy + al((size_t)H * 4);
@@ -808,6 +810,36 @@ extern "C" int xf_batch_compile_gpu(xf_batch **out, const uint64_t *rowptr, cons
   if (R) XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
   XF_HIP(hipStreamSynchronize(s));
   return xf_batch_compile_dev(out, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ, stream);
+}
+
+// host-array front end of xf_batch_compile_fm_dev (the reader's block arrays and a row slice)
+extern "C" int xf_batch_compile_fm(xf_batch **out, xf_table *w, xf_table *v,
+                                   const uint64_t *rowptr, const uint64_t *keys,
+                                   const int32_t *labels, size_t row_begin, size_t row_end,
+                                   void *stream, int *keyed) {
+  XF_REQUIRE(out && w && v && rowptr && labels && row_end >= row_begin,
+             "xf_batch_compile_fm: bad argument");
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(NNZ == 0 || keys, "xf_batch_compile_fm: null keys");
+  XF_REQUIRE(R < 0xFFFFFFFFull && NNZ < 0xFFFFFFFFull, "xf_batch_compile_fm: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<uint32_t> rp(R + 1);
+  for (size_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+  Scratch sc;
+  uint64_t *d_keys = nullptr;
+  uint32_t *d_rp = nullptr;
+  int32_t *d_lab = nullptr;
+  XF_TRY(sc.get(&d_keys, NNZ));
+  XF_TRY(sc.get(&d_rp, R + 1));
+  XF_TRY(sc.get(&d_lab, R));
+  if (NNZ) XF_HIP(hipMemcpyAsync(d_keys, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_rp, rp.data(), (R + 1) * 4, hipMemcpyHostToDevice, s));
+  if (R) XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return xf_batch_compile_fm_dev(out, w, v, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ,
+                                 stream, keyed);
 }
 
 // every row's unique-key indices in ascending order (parity mode "reference order": ascending

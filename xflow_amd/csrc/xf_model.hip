@@ -29,6 +29,7 @@
 #include "xf_cells.h"
 #include "xf_common.h"
 #include "xf_device.h"
+#include "xf_scratch.h"
 
 namespace xf {
 const TableDev &table_dev(const xf_table *t);
@@ -1860,18 +1861,61 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
 // minibatch finds its keys' rows where it left them and only gathers w
 // want_w = false: the caller reads w where it lives (only a first resolve pulls it anyway);
 // *any_fresh: a table resolved the list anew (first use, or its rows were renumbered)
+__global__ void __launch_bounds__(kBlock)
+k_fm_ridx(const uint32_t *uidx, const uint32_t *__restrict__ rows_v, size_t n, uint32_t *ridx) {
+  // (ridx may be uidx: the translation of a keyed minibatch's index after a renumbering)
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (size_t)gridDim.x * blockDim.x)
+    ridx[j] = rows_v[uidx[j]];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fm_row_map(const uint32_t *__restrict__ old_rows, const uint32_t *__restrict__ new_rows,
+             size_t n, uint32_t *__restrict__ map) {
+  for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < n;
+       u += (size_t)gridDim.x * blockDim.x)
+    map[old_rows[u]] = new_rows[u];
+}
+
 static int fm_resolve_rows(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
                            void *stream, bool want_w = true, bool *any_fresh = nullptr) {
   const xf_dev_batch &v = b->view;
   xf_table *tabs[2] = {w, vt};
   if (b->fm_keyed) {
-    // compiled against these tables' settled tiers (xf_batch_compile_fm_dev): the rows came with
-    // the key list, and there is no CSR index to rebuild anything from
-    for (int i = 0; i < 2; ++i)
-      XF_REQUIRE(b->fm_uid[i] == xf::table_uid(tabs[i]) && b->fm_epoch[i] == xf::table_epoch(tabs[i]),
-                 "this FM minibatch was compiled against the tables' row numbering "
-                 "(xf_batch_compile_fm_dev) and %s has renumbered its rows since, or is another "
-                 "table: compile it again", i ? "the v table" : "the w table");
+    // compiled against these tables' settled tiers (xf_batch_compile_fm*): the rows came with
+    // the key list.  After a renumbering (defrag) the key list's rows are looked up again and
+    // the per-nonzero record index — there is no CSR index of the key list to rebuild it from —
+    // is translated through a map old row -> new row.
+    bool moved = false;
+    for (int i = 0; i < 2; ++i) {
+      XF_REQUIRE(b->fm_uid[i] == xf::table_uid(tabs[i]),
+                 "this FM minibatch was compiled against the row numbering of other tables "
+                 "(xf_batch_compile_fm*): %s is not the one it was compiled for",
+                 i ? "the v table" : "the w table");
+      moved = moved || b->fm_epoch[i] != xf::table_epoch(tabs[i]);
+    }
+    if (moved && v.U) {
+      xf::Scratch sc;
+      uint32_t *old_v = nullptr, *map = nullptr;
+      XF_TRY(sc.get(&old_v, (size_t)v.U));
+      XF_TRY(sc.get(&map, (size_t)b->fm_nbase + 1));
+      XF_HIP(hipMemcpyAsync(old_v, b->d_fm_rows[1], (size_t)v.U * 4, hipMemcpyDeviceToDevice,
+                            S(stream)));
+      XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, b->d_fm_rows[0], ws->wu, stream));
+      XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, b->d_fm_rows[1], stream));
+      hipLaunchKernelGGL(k_fm_row_map, dim3(blocks_for_groups(v.U, kBlock)), dim3(kBlock), 0,
+                         S(stream), old_v, b->d_fm_rows[1], (size_t)v.U, map);
+      hipLaunchKernelGGL(k_fm_ridx, dim3(blocks_for_groups(v.NNZ, kBlock)), dim3(kBlock), 0,
+                         S(stream), b->d_fm_ridx, map, (size_t)v.NNZ, b->d_fm_ridx);
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipStreamSynchronize(S(stream)));  // (the scratch goes back)
+      for (int i = 0; i < 2; ++i) b->fm_epoch[i] = xf::table_epoch(tabs[i]);
+      b->fm_ridx_uid = xf::table_uid(vt);
+      b->fm_ridx_epoch = xf::table_epoch(vt);
+      b->fm_same_rows = false;  // (the two tables number their rows independently)
+      if (any_fresh) *any_fresh = true;
+      return XF_OK;
+    }
     if (want_w && v.U)
       XF_TRY(xf::gather_f32(xf::table_dev(w).w, b->d_fm_rows[0], v.U, ws->wu, S(stream)));
     return XF_OK;
@@ -1915,14 +1959,6 @@ static bool fm_table_records_enabled() {
   return on;
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_fm_ridx(const uint32_t *__restrict__ uidx, const uint32_t *__restrict__ rows_v, size_t n,
-          uint32_t *__restrict__ ridx) {
-  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-       j += (size_t)gridDim.x * blockDim.x)
-    ridx[j] = rows_v[uidx[j]];
-}
-
 // brings the records of b's keys up to date if needed; *rec_out = the v table's records
 static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh, int k,
                               FmKey **rec_out, void *stream) {
@@ -1932,6 +1968,7 @@ static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh
   XF_TRY(xf::table_records(vt, sizeof(FmKey), xf::table_uid(w), &recp, &gen));
   const uint64_t uidv = xf::table_uid(vt), epv = xf::table_epoch(vt);
   if (!b->d_fm_ridx || b->fm_ridx_uid != uidv || b->fm_ridx_epoch != epv) {
+    XF_REQUIRE(!b->fm_keyed, "fm_prepare_records: a keyed minibatch without its record index");
     if (!b->d_fm_ridx)
       XF_TRY(xf::blob_alloc((void **)&b->d_fm_ridx, (size_t)v.NNZ * 4, &b->fm_ridx_bytes));
     hipLaunchKernelGGL(k_fm_ridx, dim3(blocks_for_groups(v.NNZ, kBlock)), dim3(kBlock), 0,
@@ -1948,7 +1985,7 @@ static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh
   // only this step (which rewrites the records of the keys it steps) writes the two tables —
   // instead of a pass over its own keys' rows (0.2 ms) before every fresh minibatch's step.
   const uint64_t allkey[5] = {gen, w0, w1, xf::table_epoch(w), epv};
-  const bool all_rows = b->fm_keyed && xf::table_dev(vt).nbase > 0;
+  const bool all_rows = b->fm_keyed && b->fm_same_rows && xf::table_dev(vt).nbase > 0;
   if (all_rows && xf::table_records_all_is(vt, allkey)) {
     b->fm_rec_ok = true;
     b->fm_rec_gen = gen;
@@ -2237,12 +2274,30 @@ extern "C" int xf_fm_predict(xf_table *w, xf_table *vt, xf_batch *b, xf_workspac
                              float *pctr_out) {
   XF_REQUIRE(w && vt && b && ws && pctr_out, "xf_fm_predict: null argument");
   XF_REQUIRE(!b->local, "xf_fm_predict: needs a minibatch with a key list (xf_batch_compile*)");
-  XF_REQUIRE(!b->fm_keyed, "xf_fm_predict: a minibatch of xf_batch_compile_fm_dev has no CSR index "
-             "of its key list (it is for training steps): use xf_batch_compile_dev");
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, nullptr));
   XF_TRY(ws_reserve(ws, b->U, (size_t)b->U * k, b->R));
   const xf_dev_batch &v = b->view;
+  if (b->fm_keyed) {  // the step's forward (records at the v table's rows), loss left aside
+    XF_REQUIRE(fm_table_records_enabled() && xf::fm_records_fit(k) && !ws->capture &&
+                   ws->parity == XF_PARITY_EXACT_SUMS,
+               "xf_fm_predict: a minibatch of xf_batch_compile_fm* is scored from the "
+               "table-resident records only (k in {4, 8, 16, 32, 64}, no capture, no parity "
+               "mode): use xf_batch_compile_dev");
+    if (v.U && v.R) {
+      bool fresh = false;
+      XF_TRY(fm_resolve_rows(w, vt, b, ws, nullptr, false, &fresh));
+      FmKey *rec = nullptr;
+      XF_TRY(fm_prepare_records(w, vt, b, fresh, k, &rec, nullptr));
+      hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                         dim3(kBlock), 0, S(nullptr), v.rowptr, b->d_fm_ridx, (const FmKey *)rec,
+                         v.labels, v.R, ws->loss, ws->pctr, ws->vsum);
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipMemcpy(pctr_out, ws->pctr, (size_t)b->R * 4, hipMemcpyDeviceToHost));
+    }
+    XF_TRY(xf_table_check(w, nullptr));
+    return xf_table_check(vt, nullptr);
+  }
   XF_TRY(xf_table_pull_dev(w, v.ukeys, v.U, ws->slots, ws->wu, nullptr));
   XF_TRY(xf_table_resolve_dev(vt, v.ukeys, v.U, ws->slots2, nullptr));
   XF_TRY(xf_table_gather_dev(vt, ws->slots2, v.U, ws->vu, nullptr));

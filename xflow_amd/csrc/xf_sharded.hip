@@ -190,6 +190,7 @@ struct xf_sharded {
   xf_sharded_config cfg{};
   xf_table *tw = nullptr, *tv = nullptr;
   xf_workspace *ws = nullptr;  // world 1: the fused step's scratch
+  int parity_mode = XF_PARITY_EXACT_SUMS;  // (what xf_sharded_set_parity last set)
   uint64_t seen_upper = 0;     // world 1: host-side upper bound on the keys in the table
   Dev<double> partial;         // LR forward scratch
   hipStream_t main = nullptr, side = nullptr;
@@ -1089,6 +1090,11 @@ extern "C" int xf_sbatch_free(xf_sbatch *b) {
   return XF_OK;
 }
 
+extern "C" int xf_sbatch_fm_keyed(const xf_sbatch *b) {
+  if (!b) return -1;
+  return b->b && b->b->fm_keyed ? 1 : 0;
+}
+
 extern "C" int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
                               uint64_t *n_owned) {
   XF_REQUIRE(b, "xf_sbatch_dims: null batch");
@@ -1123,6 +1129,11 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     else if (st->cfg.model == 0)
       XF_TRY(xf_batch_compile_local(&b->b, st->tw, rowptr, keys, labels, row_begin, row_end,
                                     keep, s));
+    else if (st->tv && st->parity_mode == XF_PARITY_EXACT_SUMS)
+      // FM: against the tables' settled tiers when every key sits there (no sort; otherwise
+      // this is xf_batch_compile_gpu)
+      XF_TRY(xf_batch_compile_fm(&b->b, st->tw, st->tv, rowptr, keys, labels, row_begin, row_end,
+                                 s, nullptr));
     else
       XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
     XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
@@ -1398,7 +1409,9 @@ extern "C" int xf_sharded_set_parity(xf_sharded *st, int mode) {
   XF_REQUIRE(mode == XF_PARITY_EXACT_SUMS || st->cfg.model == 1 || st->cfg.host_key_build,
              "xf_sharded_set_parity: the reference-order forward needs minibatches with a key "
              "list (host_key_build)");
-  return xf_workspace_parity(st->ws, mode);
+  XF_TRY(xf_workspace_parity(st->ws, mode));
+  st->parity_mode = mode;
+  return XF_OK;
 }
 
 extern "C" int xf_sharded_stream(xf_sharded *st, void **stream) {
