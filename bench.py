@@ -379,8 +379,9 @@ def fm_leg(args, batches):
                        "(xf_keybuild.hip: histogram / scan / scatter of 16-byte records by key "
                        "range / resolve in LDS, then per super-chunk the key list with its "
                        "state rows, the occurrence lists and the per-nonzero record index; the "
-                       "sort-based xf_batch_compile_dev when a key is not settled), the "
-                       "minibatch's records rebuilt, forward, gradient + Pushes"}
+                       "sort-based xf_batch_compile_dev when a key is not settled; one host "
+                       "wait per minibatch), forward over the table-wide records (no pass over "
+                       "the minibatch's rows first), gradient + Pushes"}
     except Exception as e:   # (the fm object must not depend on this extra)
         wkb = {"error": str(e)}
     finally:
