@@ -893,11 +893,7 @@ __global__ void __launch_bounds__(dense_threads(VAR),
 k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin, uint32_t W,
                 const uint32_t *__restrict__ item_chunk, const float *__restrict__ loss,
-                uint32_t R, uint32_t M, uint32_t chunk0, uint32_t nitems, uint32_t stagger) {
-  // (experiment, exp_knob 1000 + n: every other group of 256 workgroups of the first round
-  // starts n x 1.7 us late — do the workgroups of a CU otherwise walk their phases in step?)
-  if (stagger && blockIdx.x < 2048 && ((blockIdx.x >> 8) & 1u))
-    for (uint32_t i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(64);
+                uint32_t R, uint32_t M, uint32_t chunk0, uint32_t nitems) {
   constexpr int NT = dense_team(VAR);                 // threads of a chunk's team
   constexpr int SUB = (VAR & kDenseQuad) && NT * 4 <= 1024 ? 4 : 1;  // chunks per workgroup
   constexpr int kOwn = (int)(kChunk / NT);  // keys per thread = entries per lane and round
@@ -1394,8 +1390,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                                                                             : c->nitems),        \
                        dim3(dense_threads(V)), 0,                                                \
                        s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
-                       d_loss, c->R, c->M, c->chunk0, c->nitems,                                 \
-                       knob >= 1000 && knob < 1064 ? (uint32_t)(knob - 1000) : 0u);              \
+                       d_loss, c->R, c->M, c->chunk0, c->nitems);                                \
     break
           switch (var) {
             XF_DENSE(0);
