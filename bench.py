@@ -209,9 +209,11 @@ def pmc_traffic(kernel, workload):
 
 def with_key_build(args, trainer, batches):
     """The whole LRWorker::update including its key build (lr_worker.cc:146-166) per step — raw
-    CSR keys resident in HBM, xf_batch_compile_local_dev (the range-partitioned key build of
-    xf_keybuild.hip: keys -> state rows where the table's keys of that range sit in LDS, cells
-    as they go) and then the step, nothing cached.  Reported next to `value` at top level."""
+    CSR keys resident in HBM, xf_lr_update_dev = xf_batch_compile_local_dev (the range-partitioned
+    key build of xf_keybuild.hip: keys -> state rows where the table's keys of that range sit in
+    LDS, cells as they go) + xf_lr_step in one call, the build's host wait taken under the
+    forward; nothing cached.  Reported next to `value` at top level; `two_calls_ms_per_step`:
+    the same through the two separate calls."""
     import ctypes as C
     import torch
     from xflow_amd import capi
@@ -223,14 +225,23 @@ def with_key_build(args, trainer, batches):
                     torch.from_numpy(labels).cuda(), len(labels), len(keys)))
 
     prev = [None]
+    fused = [True]
 
     def one(i):
         # one stream, in order: the key build of minibatch i queues behind the step of
         # minibatch i-1 (the host does not wait for a step before it starts on the next
-        # minibatch; the build's own synchronisation — it needs the item counts — is the only
-        # one), and minibatch i-1 is freed once that has returned
+        # minibatch; the build's own wait — it needs the item counts — is the only one: taken
+        # after the forward has been launched in the one-call form, before it in the two-call
+        # form), and minibatch i-1 is freed once that has returned
         k, rp, lb, R, NNZ = raw[i % len(raw)]
         h = capi.vp()
+        if fused[0]:
+            capi.check(L.xf_lr_update_dev(C.byref(h), trainer.w.h, k.data_ptr(), rp.data_ptr(),
+                                          lb.data_ptr(), R, NNZ, 0, trainer.ws.h, None))
+            if prev[0] is not None:
+                L.xf_batch_free(prev[0])
+            prev[0] = h
+            return
         capi.check(L.xf_batch_compile_local_dev(C.byref(h), trainer.w.h, k.data_ptr(),
                                                 rp.data_ptr(), lb.data_ptr(), R, NNZ, 0, None))
         if prev[0] is not None:
@@ -256,12 +267,25 @@ def with_key_build(args, trainer, batches):
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / args.key_build_steps)
     dt = per[0]
+    fused[0] = False                       # the same through the two separate calls
+    for i in range(3):
+        one(i)
+    drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.key_build_steps):
+        one(i)
+    drain()
+    torch.cuda.synchronize()
+    two = (time.perf_counter() - t0) / args.key_build_steps
     return {"value": args.rows / dt, "unit": "examples/sec",
             "ms_per_step": dt * 1e3, "steps": args.key_build_steps,
             "ms_per_step_repeats": spread([x * 1e3 for x in per]),
-            "what": "key build on the GPU (xf_keybuild.hip: histogram / scan / scatter by key "
-                    "range / resolve in LDS against the table's settled tier) + the step, per "
-                    "minibatch, raw keys resident in HBM, nothing cached"}
+            "two_calls_ms_per_step": two * 1e3,
+            "what": "xf_lr_update_dev per minibatch: key build on the GPU (xf_keybuild.hip: "
+                    "histogram / scan / scatter by key range / resolve in LDS against the "
+                    "table's settled tier) + the step, the build's one host wait taken while "
+                    "the forward runs; raw keys resident in HBM, nothing cached"}
 
 
 def with_key_build_sharded(args, trainer, batches, R, world, barrier, allmax):

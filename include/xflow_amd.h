@@ -313,6 +313,14 @@ int xf_workspace_destroy(xf_workspace *ws);
 /* One LRWorker::update (lr_worker.cc:167-176) on a single-shard table, device-resident:
  * pull(resolve+gather) -> loss -> gradient -> push(update).  Asynchronous. */
 int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream);
+/* The whole LRWorker::update (lr_worker.cc:145-177) on a fresh minibatch: xf_batch_compile_local_dev
+ * + xf_lr_step in one call — same kernels, same results; the key build's one host wait (work
+ * items of the gradient pass, keys the table does not hold yet) is taken while the forward
+ * already runs.  *out (optional): the minibatch, for replays (xf_batch_free); with out == NULL
+ * the call waits for the step and frees it. */
+int xf_lr_update_dev(xf_batch **out, xf_table *w, const uint64_t *d_keys, const uint32_t *d_rowptr,
+                     const int32_t *d_labels, uint32_t R, uint32_t NNZ, int retain_keys,
+                     xf_workspace *ws, void *stream);
 /* One FMWorker::update (fm_worker.cc:226-242).  For k in {4, 8, 16, 32, 64} the forward's
  * per-key records (sum_k v, sum_k v^2, w) are kept in an array next to v's state rows and are
  * rewritten by the step's gradient + Push kernel; a minibatch that is stepped again starts with

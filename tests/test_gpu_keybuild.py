@@ -240,3 +240,48 @@ def test_table_growth_is_sized_by_distinct_new_keys():
         assert t.capacity > 1 << 16
         capi.lr_step(t, b2, ws)
         t.check()
+
+
+def test_update_in_one_call_is_the_key_build_and_the_step():
+    """xf_lr_update_dev (the build's host wait taken under the forward) against the two calls
+    and the oracle: settled minibatches, minibatches that bring new keys (holes in the first
+    forward, a second segment, the forward run again), a defrag in between, a replay of the
+    minibatches it returns"""
+    R, nnz, nkeys = 20000, 30, 120000
+    rng = np.random.RandomState(17)
+    ta, tb = (capi.Table(capi.OPT_FTRL, 1, capacity=1 << 19) for _ in range(2))
+    so = O.Store(O.OPT_FTRL, 1)
+    wa, wb = capi.Workspace(), capi.Workspace()
+    kept = []
+    segs = []
+    for step in range(8):
+        # steps 0-1 before any settled tier (the general build: nothing deferred), 2-3 settled
+        # keys only, 4-5 half the keys new, 6-7 settled again after the second defrag
+        lo, hi = (0, nkeys // 2) if step < 4 else (0, nkeys)
+        raw = synth(rng, R, nnz, hi - lo, 1.15 if step % 2 else None, True)
+        ob = O.Batch(*raw)
+        with O.sum_mode(1):
+            loss_ex, _ = ob.lr_loss(so.pull(ob.ukeys))
+            O.lr_update(so, ob)
+        b = capi.LocalBatch.update(ta, wa, *raw)
+        same(wa.fetch_loss(R), loss_ex)
+        capi.lr_step(tb, capi.LocalBatch(tb, *raw), wb)
+        same(wb.fetch_loss(R), loss_ex)
+        segs.append(b.cells_info()["segments"])
+        kept.append((b, ob))
+        if step in (1, 5):                       # every key of the range so far, then settle
+            allk = capi.hash_decimal_range(0, hi)
+            for t in (ta, tb, so):
+                t.pull(allk)
+            ta.defrag()
+            tb.defrag()
+    assert segs[2:] == [1, 1, 2, 2, 1, 1], segs
+    for b, ob in kept[-2:]:                      # replays of what the one call returned
+        with O.sum_mode(1):
+            loss_ex, _ = ob.lr_loss(so.pull(ob.ukeys))
+            O.lr_update(so, ob)
+        capi.lr_step(ta, b, wa)
+        same(wa.fetch_loss(R), loss_ex)
+    ta.check()
+    for a, e in zip(ta.export(), so.export()):
+        same(a, e)

@@ -133,6 +133,8 @@ SIGNATURES = {
     "xf_workspace_create": (C.c_int, [C.POINTER(vp)]),
     "xf_workspace_destroy": (C.c_int, [vp]),
     "xf_lr_step": (C.c_int, [vp, vp, vp, vp]),
+    "xf_lr_update_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int,
+                                   vp, vp]),
     "xf_fm_step": (C.c_int, [vp, vp, vp, vp, vp]),
     "xf_lr_predict": (C.c_int, [vp, vp, vp, f32p]),
     "xf_fm_predict": (C.c_int, [vp, vp, vp, vp, f32p]),
@@ -441,6 +443,32 @@ class LocalBatch:
         R, N = C.c_uint32(), C.c_uint32()
         check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), None, None))
         self.R, self.NNZ, self.U, self.H = R.value, N.value, 0, 0
+
+    @classmethod
+    def update(cls, table, ws, rowptr, keys, labels, retain_keys=True):
+        """xf_lr_update_dev: the key build and the step of a fresh minibatch in one call (the
+        raw arrays go to the GPU through torch first); returns the compiled minibatch"""
+        import torch
+        rp = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        rp32 = (rp - rp[0]).astype(np.uint32)
+        kk = np.ascontiguousarray(keys, dtype=np.uint64)[int(rp[0]):int(rp[-1])]
+        lb = np.ascontiguousarray(labels, dtype=np.int32)
+        d_rp = torch.from_numpy(rp32.view(np.int32)).cuda()
+        d_kk = torch.from_numpy(kk.view(np.int64).copy()).cuda() if len(kk) else None
+        d_lb = torch.from_numpy(lb.copy()).cuda() if len(lb) else None
+        torch.cuda.synchronize()
+        self = cls.__new__(cls)
+        self.h = vp()
+        check(lib().xf_lr_update_dev(C.byref(self.h), table.h,
+                                     d_kk.data_ptr() if d_kk is not None else None,
+                                     d_rp.data_ptr(),
+                                     d_lb.data_ptr() if d_lb is not None else None,
+                                     len(rp32) - 1, len(kk), 1 if retain_keys else 0, ws.h, None))
+        check(lib().xf_stream_sync(None))     # (the torch arrays go away with this frame)
+        R, N = C.c_uint32(), C.c_uint32()
+        check(lib().xf_batch_dims(self.h, C.byref(R), C.byref(N), None, None))
+        self.R, self.NNZ, self.U, self.H = R.value, N.value, 0, 0
+        return self
 
     def cells_info(self):
         return cells_info(self)

@@ -78,6 +78,8 @@ struct xf_cells {
   uint32_t *entries = nullptr;      // [NNZ] cells sorted by row (the gradient's stream)
   uint32_t *entries_k = nullptr;    // [NNZ] the same cells sorted by key (the forward's stream;
                                     //       == entries when the copy was not built)
+  bool entries_k_ready = false;     // (a forward before cells_key_sorted_copy reads `entries`)
+  const uint32_t *fwd_entries() const { return entries_k_ready ? entries_k : entries; }
   uint32_t *cellptr = nullptr;      // [ncell + 1]
   uint32_t *blk_cell = nullptr;     // [nblk + 1] cell of entry kBlk*b; [nblk] = ncell - 1
   uint32_t *plan = nullptr;         // [4 * (nchunk + 1)] slices per chunk and three scans of them
@@ -111,9 +113,21 @@ void cells_free(xf_cells *c);  // the whole chain
 // keys inserted (ftrl.h:56) — on the way.  Nonzeros in CSR order (d_rowptr) or with their row
 // numbers (d_rowid, rows numbered window by window, w_fixed rows per window).  Synchronises
 // `stream`.
+//
+// `defer` (optional): the build's one host wait — for the number of gradient work items and
+// for the keys the settled tier does not hold — is left to cells_build_keyed_finish.  Until
+// then *out serves the FORWARD only (entries, cell offsets: in stream order); keys the tier
+// does not hold are holes in it.  *defer stays null when there is nothing left to wait for
+// (the general build ran).  One deferred build at a time.
+struct KbDeferred;
 int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                       const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
-                      uint32_t NNZ, bool key_sorted_copy, uint32_t w_fixed, hipStream_t stream);
+                      uint32_t NNZ, bool key_sorted_copy, uint32_t w_fixed, hipStream_t stream,
+                      KbDeferred **defer = nullptr);
+// waits for the build's kernels (an event, not the stream: what was launched after them keeps
+// running), then the work items and — *more = true — a second segment of cells over the keys
+// the tier did not hold (inserted now): the forward has to be run again over both.  Frees d.
+int cells_build_keyed_finish(KbDeferred *d, hipStream_t stream, bool *more);
 
 // pieces of cells_build shared with the keyed build
 int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,

@@ -1194,6 +1194,7 @@ int cells_key_sorted_copy(xf_cells *c, hipStream_t s) {
                                             (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
                                             kChunkBits, s));
   XF_HIP(hipStreamSynchronize(s));  // the scratch goes back
+  c->entries_k_ready = true;
   return XF_OK;
 }
 
@@ -1303,7 +1304,7 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
   if (c->R == 0) return XF_OK;
   int acc = 0;
   for (const xf_cells *q = c; q; q = q->next, acc = 1)
-    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->entries_k,
+    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->fwd_entries(),
                        q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
                        d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);
   hipLaunchKernelGGL(k_lr_finalize_cells,
@@ -1530,7 +1531,7 @@ int cells_lr_forward_sums(const xf_cells *c, const float *d_w, double *d_partial
   if (c->R == 0) return XF_OK;
   int acc = 0;
   for (const xf_cells *q = c; q; q = q->next, acc = 1)
-    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->entries_k,
+    hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->fwd_entries(),
                        q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
                        d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);
   const uint32_t n = c->nwin * c->W;
@@ -1592,10 +1593,12 @@ int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s) {
 // identity, the forward reads the table's weights in place and the gradient pass applies the
 // optimizer step where it sums.  retain_keys: keep a device copy of the raw arrays so that the
 // cells can be rebuilt after xf_table_defrag renumbers the rows.
-extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
-                                          const uint32_t *d_rowptr, const int32_t *d_labels,
-                                          uint32_t R, uint32_t NNZ, int retain_keys,
-                                          void *stream) {
+namespace xf {
+// defer != null: the build's host wait is left to cells_build_keyed_finish(*defer) (xf_lr_update_dev:
+// the forward runs under it)
+int batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
+                            const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                            uint32_t NNZ, int retain_keys, void *stream, KbDeferred **defer) {
   XF_REQUIRE(out && t && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
              "xf_batch_compile_local_dev: null argument");
   hipStream_t s = (hipStream_t)stream;
@@ -1625,7 +1628,7 @@ extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uin
     if (NNZ) XF_HIP(hipMemcpyAsync(d + o_keys, d_keys, (size_t)NNZ * 8, hipMemcpyDeviceToDevice, s));
   }
   XF_TRY(xf::cells_build_keyed(&b->cells, t, d_keys, d_rowptr, nullptr, R, NNZ, retain_keys != 0,
-                               0, s));
+                               0, s, defer));
   b->cells->table_uid = xf::table_uid(t);
   b->cells->epoch = xf::table_epoch(t);
   if (retain_keys) {
@@ -1635,6 +1638,15 @@ extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uin
   guard.b = nullptr;
   *out = b;
   return XF_OK;
+}
+}  // namespace xf
+
+extern "C" int xf_batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
+                                          const uint32_t *d_rowptr, const int32_t *d_labels,
+                                          uint32_t R, uint32_t NNZ, int retain_keys,
+                                          void *stream) {
+  return xf::batch_compile_local_dev(out, t, d_keys, d_rowptr, d_labels, R, NNZ, retain_keys,
+                                     stream, nullptr);
 }
 
 // host-array front end (the reader's block arrays and a row slice, like xf_batch_compile)

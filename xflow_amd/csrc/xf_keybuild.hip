@@ -38,7 +38,10 @@
 // HBM-bound integer work, no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
+
 #include <algorithm>
+#include <memory>
 
 #include "xf_batch.h"
 #include "xf_cells.h"
@@ -1337,9 +1340,65 @@ static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, Kb
   return XF_OK;
 }
 
+// what a keyed build holds on to between its kernels and its one host wait
+struct KbDeferred {
+  Scratch sc;  // the records, the miss list, the small arrays
+  KbArgs a{};
+  xf_cells *c = nullptr;
+  xf_table *t = nullptr;
+  KbSummary *sum = nullptr;
+  bool ksc = false, waited = false;
+  uint32_t R = 0, NNZ = 0;
+  uint64_t nbase = 0;
+};
+
+static hipEvent_t kb_event() {
+  static hipEvent_t ev = nullptr;
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+  return ev;
+}
+
+// after the build's kernels and the copy of the summary have finished: the work items, the
+// key-sorted copy, and the second segment for the keys the tier does not hold
+static int keyed_tail(KbDeferred &d, hipStream_t s, bool *more) {
+  xf_cells *c = d.c;
+  const unsigned long long misses = d.sum->miss;
+  if (more) *more = misses != 0;
+  XF_TRY(cells_fill_items(c, d.sum->nitems, d.sum->nsplit, s));
+  XF_TRY(cells_key_sorted_copy(c, s));
+  if (misses) {
+    // segment B: the keys the tier did not hold, through the general path (insert on first
+    // touch), over the rows from the tier's last chunk on
+    XF_REQUIRE(misses <= d.NNZ, "cells_build_keyed: miss list");
+    Scratch sc2;
+    uint32_t *idx = nullptr;
+    XF_TRY(sc2.get(&idx, (size_t)misses));
+    XF_TRY(table_resolve_any(d.t, d.a.missK, (size_t)misses, idx, s, true));
+    const uint64_t M = table_dev(d.t).max_rows + 1;
+    XF_TRY(cells_build(&c->next, idx, nullptr, nullptr, d.R, (uint32_t)misses, (uint32_t)M,
+                       kCellsTableRows, d.ksc, s, d.a.missR, c->W,
+                       (uint32_t)(d.nbase >> kChunkBits)));
+    XF_REQUIRE(c->next->nwin == c->nwin && c->next->G == c->G, "cells_build_keyed: segments");
+    // (the general build synchronises: every kernel that reads the scratch has finished)
+  }
+  return XF_OK;
+}
+
+int cells_build_keyed_finish(KbDeferred *d, hipStream_t s, bool *more) {
+  XF_REQUIRE(d, "cells_build_keyed_finish: null argument");
+  struct Free {
+    KbDeferred *d;
+    ~Free() { delete d; }
+  } guard{d};
+  XF_HIP(hipEventSynchronize(kb_event()));
+  return keyed_tail(*d, s, more);
+}
+
 int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                       const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
-                      uint32_t NNZ, bool ksc, uint32_t w_fixed, hipStream_t s) {
+                      uint32_t NNZ, bool ksc, uint32_t w_fixed, hipStream_t s,
+                      KbDeferred **defer) {
+  if (defer) *defer = nullptr;
   XF_REQUIRE(out && t && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_keys),
              "cells_build_keyed: null argument");
   XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax),
@@ -1357,7 +1416,23 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                     cA64 * nwin < (1ull << 22) &&
                     ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256 &&
                     exp_knob() != 77;
-  if (!fits) return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
+  if (!fits) {
+    // a table or a minibatch beyond the limits in this file's header: said once, loudly — the
+    // general build is 3x slower and its user should know which path the numbers come from
+    if (T.nbase > 0 && NNZ > 0 && exp_knob() != 77) {
+      static bool told = false;
+      if (!told) {
+        told = true;
+        fprintf(stderr,
+                "xflow_amd: the range-partitioned key build does not apply (%llu settled keys, "
+                "%u nonzeros, %u row windows: beyond ~3.4e7 keys / 3.3e7 nonzeros / 4e6 cells per "
+                "GPU, xf_keybuild.hip): minibatches are built by the general path (a probe of the "
+                "table per nonzero + a radix pass)\n",
+                (unsigned long long)T.nbase, NNZ, nwin);
+      }
+    }
+    return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
+  }
   const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
   // segment A: the settled tier's rows [0, nbase)
   xf_cells *c = nullptr;
@@ -1369,9 +1444,16 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     }
   } guard{c};
   XF_REQUIRE(c->nchunk == cA && c->nwin == nwin, "cells_build_keyed: geometry");
-  unsigned long long misses = 0;
-  Scratch sc;  // (outlives the miss path below: the list lives in it)
-  KbArgs a{};
+  std::unique_ptr<KbDeferred> D(new KbDeferred);
+  Scratch &sc = D->sc;  // (outlives the miss path: the list lives in it)
+  KbArgs &a = D->a;
+  D->c = c;
+  D->t = t;
+  D->sum = sum;
+  D->ksc = ksc;
+  D->R = R;
+  D->NNZ = NNZ;
+  D->nbase = T.nbase;
   {
     a.keys = d_keys;
     a.rowptr = d_rowid ? nullptr : d_rowptr;
@@ -1469,26 +1551,16 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
 #undef XF_KB_LAUNCH
     XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
     XF_HIP(hipGetLastError());
-    XF_HIP(hipStreamSynchronize(s));  // the one synchronisation of the steady state
-    misses = sum->miss;
-    XF_TRY(cells_fill_items(c, sum->nitems, sum->nsplit, s));
   }
-  XF_TRY(cells_key_sorted_copy(c, s));
-  if (misses) {
-    // segment B: the keys the tier did not hold, through the general path (insert on first
-    // touch), over the rows from the tier's last chunk on
-    XF_REQUIRE(misses <= NNZ, "cells_build_keyed: miss list");
-    Scratch sc2;
-    uint32_t *idx = nullptr;
-    XF_TRY(sc2.get(&idx, (size_t)misses));
-    XF_TRY(table_resolve_any(t, a.missK, (size_t)misses, idx, s, true));
-    const uint64_t M = table_dev(t).max_rows + 1;
-    XF_TRY(cells_build(&c->next, idx, nullptr, nullptr, R, (uint32_t)misses, (uint32_t)M,
-                       kCellsTableRows, ksc, s, a.missR, c->W, (uint32_t)(T.nbase >> kChunkBits)));
-    XF_REQUIRE(c->next->nwin == c->nwin && c->next->G == c->G, "cells_build_keyed: segments");
+  if (defer && kb_event()) {  // the wait is the caller's (cells_build_keyed_finish)
+    XF_HIP(hipEventRecord(kb_event(), s));
+    guard.c = nullptr;
+    *out = c;
+    *defer = D.release();
+    return XF_OK;
   }
-  // (every kernel that reads the scratch has finished: the synchronisation above, or the
-  // general build's own)
+  XF_HIP(hipStreamSynchronize(s));  // the one synchronisation of the steady state
+  XF_TRY(keyed_tail(*D, s, nullptr));
   guard.c = nullptr;
   *out = c;
   return XF_OK;

@@ -42,6 +42,9 @@ void table_note_write(xf_table *t);
 void table_records_all_set(xf_table *t, const uint64_t key[5]);
 bool table_records_all_is(const xf_table *t, const uint64_t key[5]);
 int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s);
+int batch_compile_local_dev(xf_batch **out, xf_table *t, const uint64_t *d_keys,
+                            const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                            uint32_t NNZ, int retain_keys, void *stream, KbDeferred **defer);
 int cells_lr_grad_update(const xf_cells *c, const xf_table *t, const float *d_loss, float *d_g,
                          hipStream_t s);
 int gather_f32(const float *src, const uint32_t *rows, size_t n, float *dst, hipStream_t s);
@@ -1813,12 +1816,26 @@ extern "C" int xf_workspace_capture(xf_workspace *ws, int enable) {
 // row resolve (and its insert-on-first-touch) happens once per (minibatch, table row
 // numbering), when the batch's cells are built; a step is then two passes over the cells:
 // forward (reads the table's weights in place) and gradient + Push.
-extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream) {
-  XF_REQUIRE(w && b && ws, "xf_lr_step: null argument");
-  XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_step: the w table must have dim 1");
+// `deferred`: the minibatch's key build has not been waited for yet (xf_lr_update_dev): its
+// cells serve the forward as they are, the wait — for the work items of the gradient pass and
+// for the keys the table did not hold — happens on the host while the forward runs on the GPU.
+static int lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream,
+                   xf::KbDeferred *deferred) {
+  struct Settle {  // (an early error return must not leave the build unfinished)
+    xf::KbDeferred *d;
+    void *stream;
+    ~Settle() {
+      if (d) (void)xf::cells_build_keyed_finish(d, S(stream), nullptr);
+    }
+  } settle{deferred, stream};
   XF_TRY(xf::ensure_cells(b, w, S(stream)));  // Pull (:170): keys -> state rows, inserts
   const xf_cells *c = b->cells;
   const bool cap = ws->capture && !b->local && b->d_rows_u;
+  if (settle.d && (cap || ws->parity == XF_PARITY_REFERENCE_ORDER)) {
+    xf::KbDeferred *d = settle.d;
+    settle.d = nullptr;
+    XF_TRY(xf::cells_build_keyed_finish(d, S(stream), nullptr));
+  }
   XF_TRY(ws_reserve(ws, b->U, 0, b->R));
   XF_TRY(ws_reserve_cells(ws, c, cap));
   ws->rec = ws->profiling && ws->step_no++ % xf_workspace::kProfileEvery == 0;
@@ -1832,6 +1849,17 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
     XF_TRY(lr_forward_reforder(w, b, ws->loss, nullptr, S(stream)));
   else
     XF_TRY(xf::cells_lr_forward(c, T.w, labels, ws->partial, ws->loss, nullptr, S(stream)));  // :172
+  if (settle.d) {  // the build's wait, under the forward
+    xf::KbDeferred *d = settle.d;
+    settle.d = nullptr;
+    bool more = false;
+    XF_TRY(xf::cells_build_keyed_finish(d, S(stream), &more));
+    if (more) {  // keys the table did not hold: they are in now, as a second segment of cells
+      XF_TRY(ws_reserve_cells(ws, c, cap));
+      XF_TRY(xf::cells_lr_forward(c, xf::table_dev(w).w, labels, ws->partial, ws->loss, nullptr,
+                                  S(stream)));
+    }
+  }
   XF_END(kEvForward);
   if (cap) XF_TRY(xf::gather_f32(T.w, b->d_rows_u, b->U, ws->wu, S(stream)));
   if (ws->parity == XF_PARITY_REFERENCE_ORDER) {
@@ -1853,6 +1881,38 @@ extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stre
   XF_END(kEvGrad);
   if (cap) XF_TRY(xf::gather_f32(ws->gdense, b->d_rows_u, b->U, ws->g, S(stream)));
   if (ws->rec) ws->sets[ws->cur].pending = true;
+  return XF_OK;
+}
+
+extern "C" int xf_lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream) {
+  XF_REQUIRE(w && b && ws, "xf_lr_step: null argument");
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_step: the w table must have dim 1");
+  return lr_step(w, b, ws, stream, nullptr);
+}
+
+// The whole LRWorker::update (lr_worker.cc:145-177) on a fresh minibatch in one call: the key
+// build against the table (xf_batch_compile_local_dev) and the step (xf_lr_step) — same
+// kernels, same results, but the build's one host wait is taken while the forward, which needs
+// none of what the host waits for, already runs (the wait was ~70 us of idle GPU per
+// minibatch).  *out (optional): the minibatch, for replays; freed here when null.
+extern "C" int xf_lr_update_dev(xf_batch **out, xf_table *w, const uint64_t *d_keys,
+                                const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                                uint32_t NNZ, int retain_keys, xf_workspace *ws, void *stream) {
+  XF_REQUIRE(w && ws, "xf_lr_update_dev: null argument");
+  XF_REQUIRE(xf::table_dim(w) == 1, "xf_lr_update_dev: the w table must have dim 1");
+  if (out) *out = nullptr;
+  xf_batch *b = nullptr;
+  xf::KbDeferred *def = nullptr;
+  XF_TRY(xf::batch_compile_local_dev(&b, w, d_keys, d_rowptr, d_labels, R, NNZ, retain_keys,
+                                     stream, &def));
+  const int rc = lr_step(w, b, ws, stream, def);  // (finishes the build on every path)
+  if (rc != XF_OK || !out) {
+    // (the step's kernels read the minibatch: wait for them before it goes)
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) (void)hipGetLastError();
+    xf_batch_free(b);
+    return rc;
+  }
+  *out = b;
   return XF_OK;
 }
 
