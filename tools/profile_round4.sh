@@ -41,10 +41,11 @@ python bench.py --model fm --k 64 --optimizer ftrl --zipf 1.1 --no-cpu-baseline 
 python bench.py $N8 --force-sharded --general-path --schedule owner --no-cpu-baseline --repeats 3 --batches 8 > $OUT/bench_n8_shard_shape_owner.json 2> $OUT/n8.err; line $OUT/bench_n8_shard_shape_owner.json
 XF_OWNER_TIMING_SOURCES=8 python bench.py $N8 --force-sharded --general-path --schedule owner --no-cpu-baseline --repeats 3 --batches 8 --no-owner-leg > $OUT/bench_n8_shard_shape_owner_8_pretended_sources.json 2> $OUT/n8s.err; line $OUT/bench_n8_shard_shape_owner_8_pretended_sources.json
 python bench.py $N8 --no-cpu-baseline --repeats 3 --batches 8 > $OUT/bench_n8_shard_shape_fused.json 2> $OUT/n8f.err; line $OUT/bench_n8_shard_shape_fused.json
-if [ -z "$QUICK" ]; then
+if [ -z "$QUICK" ] || [ "$QUICK" = "benchonly" ]; then
 python bench.py --force-sharded --general-path --model fm --k 16 --optimizer sgd --schedule owner --batches 4 --no-cpu-baseline --repeats 3 > $OUT/bench_fm16_sgd_owner_exchange_path.json 2> $OUT/fmo.err; line $OUT/bench_fm16_sgd_owner_exchange_path.json
 python bench.py --model fm --k 64 --optimizer ftrl --zipf 1.1 --keys-per-gpu 125000000 --capacity 64000000 --no-cpu-baseline --repeats 3 --batches 8 > $OUT/bench_cfg4_shard_shape_fm64_ftrl_zipf11_125Mkeys.json 2> $OUT/cfg4.err; line $OUT/bench_cfg4_shard_shape_fm64_ftrl_zipf11_125Mkeys.json
 fi
+[ "$QUICK" = "benchonly" ] && exit 0   # (a second box for the timings: the traffic is the box's own)
 # memory-side traffic, request sizes resolved, calibration patterns in the same runs
 B="--steps 6 --warmup 8 --no-cpu-baseline --key-build-steps 0 --repeats 0 --no-fm-leg --batches 8 --pmc-calibrate"
 bash tools/pmc2.sh $OUT lr python $R/bench.py $B 2>&1 | grep -v "^  k_\(build\|fill\|id_wr\|list\|move\|rehash\|take\|count\|cell\|blk\)"

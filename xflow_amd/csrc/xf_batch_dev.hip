@@ -139,6 +139,10 @@ k_flag_counts(const uint32_t *__restrict__ segptr, uint32_t Ub, const uint32_t *
               uint32_t *__restrict__ bc /* [2 * nb]: heavy keys, tile starts per block */) {
   __shared__ uint32_t wsum[kBlock / 64];
   const uint32_t U = keys_of(Ub, d_U);
+  if (blockIdx.x * kFlagBlk >= U) {  // (workgroup-uniform: the launch is sized for the bound)
+    if (threadIdx.x == 0) bc[blockIdx.x] = bc[nb + blockIdx.x] = 0;
+    return;
+  }
   uint32_t hb, tb, th, tt;
   key_flag_bits(segptr, U, blockIdx.x * kFlagBlk + threadIdx.x * kFlagPer, hb, tb);
   block_prefix((uint32_t)__popc(hb), wsum, &th);
@@ -174,6 +178,7 @@ k_flag_compact(const uint32_t *__restrict__ segptr, uint32_t Ub,
                uint32_t *__restrict__ heavy, uint32_t *__restrict__ tile_ptr) {
   __shared__ uint32_t wsum[kBlock / 64];
   const uint32_t U = keys_of(Ub, d_U);
+  if (blockIdx.x * kFlagBlk >= U) return;  // (workgroup-uniform)
   const uint32_t u0 = blockIdx.x * kFlagBlk + threadIdx.x * kFlagPer;
   uint32_t hb, tb, tot;
   key_flag_bits(segptr, U, u0, hb, tb);

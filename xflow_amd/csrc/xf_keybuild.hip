@@ -1099,6 +1099,8 @@ k_kb_resolve_fm(KbArgs a) {
   auto lkf = [&](uint32_t i) -> uint64_t { return lk[i]; };
   constexpr int E = 4;
   uint32_t nmiss = 0;
+  // (all of an item's records in registers up front, as k_kb_resolve has them, was tried: 208 ->
+  // 221 us — the scattered record-index stores are this kernel, not the waits for its loads)
   for (uint32_t i0 = rb; i0 < re; i0 += kRes * E) {
     uint64_t key[E], x0[E], x1[E];
     uint32_t ds[E], de[E], pos[E], rpk[E];
@@ -1146,6 +1148,7 @@ struct FmRegroup {
   const uint32_t *sstart;  // [nS + 1] first record of every super-chunk
   const uint64_t *bkeys;   // the tier's keys
   uint32_t nS, W;
+  uint64_t nbase;          // keys of the tier
   uint32_t *ucount;        // [nS] touched keys per super-chunk; [nS + 1] after the scan: ubase
   uint64_t *ukeys;         // [U] the minibatch's keys, ascending (= in row order)
   uint32_t *urow;          // [U] their state rows
@@ -1197,6 +1200,13 @@ k_fm_regroup(FmRegroup g) {
   __shared__ uint32_t wsum[kKb / 64];
   const uint32_t tid = threadIdx.x, S = blockIdx.x;
   const uint32_t sb = g.sstart[S], se = g.sstart[S + 1], k0 = S * kSCKeys;
+  // a thread owns kSCKeys / kKb consecutive rows; their keys are asked for now — a load per
+  // touched row inside the loop below was a dependent trip to memory each
+  constexpr uint32_t kPer = kSCKeys / kKb;
+  uint64_t mykey[kPer];
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; ++q)
+    mykey[q] = g.bkeys[min((uint64_t)k0 + tid * kPer + q, g.nbase - 1)];
   for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
   __syncthreads();
   for (uint32_t i0 = sb; i0 < se; i0 += kKb * 8) {
@@ -1211,9 +1221,7 @@ k_fm_regroup(FmRegroup g) {
       if (r[q] != kHole) atomicAdd(&cnt[r[q] - k0], 1u);
   }
   __syncthreads();
-  // a thread owns kSCKeys / kKb consecutive rows: where their occurrences begin, and their
-  // numbers among the touched keys
-  constexpr uint32_t kPer = kSCKeys / kKb;
+  // where the rows' occurrences begin, and their numbers among the touched keys
   uint32_t occ = 0, used = 0;
 #pragma unroll
   for (uint32_t q = 0; q < kPer; ++q) {
@@ -1230,7 +1238,7 @@ k_fm_regroup(FmRegroup g) {
     off[k] = run;
     if (c) {
       g.urow[urun] = k0 + k;
-      g.ukeys[urun] = g.bkeys[k0 + k];
+      g.ukeys[urun] = mykey[q];
       g.segptr[urun] = sb + run;
       ++urun;
     }
@@ -1663,6 +1671,7 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   g.bkeys = T.bkeys;
   g.nS = nS;
   g.W = a.W;
+  g.nbase = T.nbase;
   g.ucount = ucount;
   hipLaunchKernelGGL(k_fm_count, dim3(nS), dim3(kKb), 0, s, g);
   hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(kKb), 0, s, ucount, nS);
