@@ -185,6 +185,26 @@ def test_a_keyed_minibatch_scores_and_survives_a_renumbering():
         capi.fm_step(tw, tv, b2, wp)
 
 
+def test_factor_widths_without_table_records_take_the_sort_based_build():
+    """k = 10 (the reference's default): no table-resident records, so no keyed minibatch"""
+    k, nkeys, R = 10, 20000, 1000
+    rng = np.random.RandomState(8)
+    keytab = capi.hash_decimal_range(0, nkeys)
+    tw, tv, sw, sv = _tables(k, "ftrl", nkeys)
+    _settle(tw, tv, sw, sv, keytab)
+    ws = capi.Workspace()
+    for step in range(2):
+        raw = synth(rng, R, 30, nkeys, None, True)
+        b = capi.FmBatch(tw, tv, *raw)
+        assert not b.keyed
+        capi.fm_step(tw, tv, b, ws)
+        with O.sum_mode(1):
+            O.fm_update(sw, sv, O.Batch(*raw))
+    for t, st in ((tw, sw), (tv, sv)):
+        for a, e in zip(t.export(), st.export()):
+            same(a, e)
+
+
 def test_the_one_shard_trainer_compiles_fm_minibatches_against_its_settled_tables():
     """capi.Sharded (what the worker drives) on one GPU, FM: after the defrag its compile is the
     range-partitioned build (xf_batch_compile_fm) — training steps, scoring and a second defrag

@@ -16,6 +16,7 @@
 // The sort is stable on (key, position): radix sort is stable and positions are the values,
 // so inside a key the occurrences stay in row-major order, like the host builder's.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cstring>
@@ -578,6 +579,8 @@ namespace xf {
 const TableDev &table_dev(const xf_table *t);
 uint64_t table_uid(const xf_table *t);
 uint64_t table_epoch(const xf_table *t);
+int table_dim(const xf_table *t);
+bool fm_records_fit(int k);
 typedef int (*FmKeyedOut)(void *ctx, uint32_t U, uint64_t **ukeys, uint32_t **urow,
                           uint32_t **segptr, uint32_t **coo);
 int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr, uint32_t R,
@@ -634,7 +637,10 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
   hipStream_t s = (hipStream_t)stream;
   if (keyed_out) *keyed_out = 0;
   bool same = false;
-  if (NNZ && R) XF_TRY(same_numbering(w, v, s, &same));
+  // (a keyed minibatch steps on the table-resident records only: factor widths they exist for)
+  const char *rec_off = getenv("XF_FM_TABLE_RECORDS");  // ("0": the records are switched off)
+  if (NNZ && R && xf::fm_records_fit(xf::table_dim(v)) && !(rec_off && *rec_off == '0'))
+    XF_TRY(same_numbering(w, v, s, &same));
   if (!same) return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   uint32_t *ridx = nullptr;
