@@ -618,3 +618,42 @@ def test_worker_parameters_are_validated_without_a_gpu():
             assert why in L.xf_last_error().decode()
     finally:
         L.XFDestroy(h)
+
+
+def test_a_library_built_with_experiment_flags_never_passes_for_the_plain_one():
+    """XF_EXTRA_FLAGS (tools/grad_timeline.py: -DXF_GRAD_TIMELINE) is part of the source hash:
+    the binding refuses a library built with other flags than the process asks for"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from xflow_amd import build\n"
+            "print(build.source_hash())\n" % root)
+    env = dict(os.environ, XF_EXTRA_FLAGS="-DXF_GRAD_TIMELINE")
+    a = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    env.pop("XF_EXTRA_FLAGS")
+    b = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout.strip() != b.stdout.strip()
+    assert b.stdout.strip() == capi.lib().xf_source_hash().decode()
+
+
+def test_the_update_entry_points_fail_loudly_without_a_gpu():
+    """xf_lr_update_dev / xf_batch_compile_fm / xf_batch_compile_fm_dev: argument checks first
+    (null tables: XF_EINVAL with the reason), never a silent host path"""
+    n = capi.C.c_int(0)
+    capi.check(capi.lib().xf_device_count(capi.C.byref(n)))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    C, L = capi.C, capi.lib()
+    h = capi.vp()
+    assert L.xf_lr_update_dev(C.byref(h), None, None, None, None, 0, 0, 0, None, None) != 0
+    assert b"null argument" in L.xf_last_error()
+    rp = np.zeros(2, np.uint64)
+    lb = np.zeros(1, np.int32)
+    assert L.xf_batch_compile_fm(C.byref(h), None, None, rp.ctypes.data, None, lb.ctypes.data, 0, 1,
+                                 None, None) != 0
+    assert b"bad argument" in L.xf_last_error()
+    assert L.xf_batch_compile_fm_dev(C.byref(h), None, None, None, None, None, 0, 0, None,
+                                     None) != 0
+    assert L.xf_sbatch_fm_keyed(None) < 0
