@@ -1378,6 +1378,10 @@ static int keyed_tail(KbDeferred &d, hipStream_t s, bool *more) {
     // segment B: the keys the tier did not hold, through the general path (insert on first
     // touch), over the rows from the tier's last chunk on
     XF_REQUIRE(misses <= d.NNZ, "cells_build_keyed: miss list");
+    // the insertions may move the table's arrays: a step of ANOTHER minibatch that a caller
+    // keeps running on a second stream while this one is built (the build itself reads only
+    // the tier's keys, which no step writes) has to be over first
+    XF_HIP(hipDeviceSynchronize());
     Scratch sc2;
     uint32_t *idx = nullptr;
     XF_TRY(sc2.get(&idx, (size_t)misses));
