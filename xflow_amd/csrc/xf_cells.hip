@@ -395,7 +395,7 @@ __device__ __forceinline__ void apply_key(const xf::TableDev &T, int opt, size_t
   if (opt == XF_OPT_FTRL) {
     float w = T.w[row], nn, z;
     xf::load_nz(T, row, nn, z);
-    xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+    xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
     T.w[row] = w;
     xf::store_nz(T, row, nn, z);
   } else {
@@ -616,7 +616,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
             touched[k] = 0;
             const float g = xf::div_by_rows((float)sum, rq);  // lr_worker.cc:117
             if (OPT == XF_OPT_FTRL)
-              xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+              xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
             else
               sw[i] = xf::sgd_step(T.lr, g, sw[i]);
           }
@@ -774,7 +774,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
         if (g_out) g_out[row0 + k[i]] = g[i];
         if (MODE == 0) {
           if (OPT == XF_OPT_FTRL)
-            xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
+            xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
           else
             sw[i] = xf::sgd_step(T.lr, g[i], sw[i]);
         }
@@ -816,7 +816,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (g_out) g_out[row0 + kb + i * kBlock + tid] = g[i];
       if (MODE == 0) {
         if (OPT == XF_OPT_FTRL)
-          xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
+          xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
         else
           sw[i] = xf::sgd_step(T.lr, g[i], sw[i]);
       }
@@ -1016,7 +1016,7 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (kk[i] == 0xFFFFFFFFu) continue;
       const float g = xf::div_by_rows((float)acc[kk[i]], R);  // lr_worker.cc:117
       if (OPT == XF_OPT_FTRL)
-        xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+        xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
       else
         sw[i] = xf::sgd_step(T.lr, g, sw[i]);
     }
@@ -1044,7 +1044,7 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (!t[i] || (VAR & kDiagCopy)) continue;
       const float g = xf::div_by_rows((float)acc[tid + i * NT], R);  // lr_worker.cc:117
       if (OPT == XF_OPT_FTRL)
-        xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
+        xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
       else
         sw[i] = xf::sgd_step(T.lr, g, sw[i]);
     }

@@ -112,24 +112,33 @@ __device__ __forceinline__ float hashnorm(uint64_t seed, uint64_t key, uint32_t 
 
 // One FTRL-proximal coordinate step, ftrl.h:59-74 statement for statement: fp32, the OLD w
 // in the z update, left-to-right evaluation, no fused multiply-add.
-// `inv_alpha` = 1.0 / (double)alpha (TableDev::inv_alpha, set on the host with the
-// hyper-parameters).  The reference divides by alpha twice per step (ftrl.h:63,70); an fp32
-// division is ~11 instructions of a VALU-bound step, and x / alpha == (float)((double)x *
-// inv_alpha) for EVERY fp32 x: the quotient of two floats is never a rounding midpoint and lies
-// at least 2^-49 (relative) away from one, the double product is within 2^-52 of it — checked
-// for all 2^32 values of x at ten values of alpha on the host (zero differences, subnormal and
-// overflowing quotients included) and by the bit-exact parity tests on the GPU.
-__device__ __forceinline__ float div_by_alpha(float x, double inv_alpha) {
-  return (float)((double)x * inv_alpha);
+// x / d for a divisor that does not change from call to call (inv_d = 1.0 / (double)d, from the
+// host or hoisted by the compiler): the double product with the reciprocal, rounded to float.
+// An fp32 division is ~11 instructions of a VALU-bound step, this is three, and it is the SAME
+// float as x / d: the quotient of two floats with a normal result is never a rounding midpoint
+// and lies at least 2^-49 (relative) away from one, the double product is within 2^-52 of it.
+// Where that argument does not reach — a result in or next to the subnormal range, where exact
+// midpoints exist (x = 25000 * 2^-149, d = 50000; the bare product differs at 1308 values of x for
+// that d, all with subnormal quotients) — the division itself is done (a branch no wavefront
+// takes in practice; x == 0 stays on the fast path: +-0 either way).  Checked on the host for
+// all 2^32 values of x at a dozen divisors (tests/test_div_by_alpha_cpu.py), on the GPU by the
+// bit-exact parity tests.
+__device__ __forceinline__ float div_by_const(float x, float d, double inv_d) {
+#pragma clang fp contract(off)
+  const float q = (float)((double)x * inv_d);
+  if (fabsf(q) >= 0x1p-125f || x == 0.0f) return q;
+  return x / d;
 }
 
-__device__ __forceinline__ void ftrl_step(double inv_alpha, float beta, float lambda1,
+// `inv_alpha` = 1.0 / (double)alpha (TableDev::inv_alpha, set on the host with the
+// hyper-parameters): the reference divides by alpha twice per step (ftrl.h:63,70)
+__device__ __forceinline__ void ftrl_step(float alpha, double inv_alpha, float beta, float lambda1,
                                           float lambda2, float g, float &w, float &n,
                                           float &z) {
 #pragma clang fp contract(off)
   const float old_n = n;
   const float nn = old_n + g * g;
-  z = z + (g - div_by_alpha(sqrtf(nn) - sqrtf(old_n), inv_alpha) * w);
+  z = z + (g - div_by_const(sqrtf(nn) - sqrtf(old_n), alpha, inv_alpha) * w);
   n = nn;
   if (fabsf(z) <= lambda1) {
     w = 0.0f;
@@ -137,7 +146,7 @@ __device__ __forceinline__ void ftrl_step(double inv_alpha, float beta, float la
     float tmpr = 0.0f;
     if (z > 0.0f) tmpr = z - lambda1;
     if (z < 0.0f) tmpr = z + lambda1;
-    const float tmpl = -1.0f * (div_by_alpha(beta + sqrtf(nn), inv_alpha) + lambda2);
+    const float tmpl = -1.0f * (div_by_const(beta + sqrtf(nn), alpha, inv_alpha) + lambda2);
     w = tmpr / tmpl;
   }
 }
@@ -156,6 +165,8 @@ __device__ __forceinline__ float sgd_step(float lr, float g, float w) {
 // quotient to float gives the correctly rounded fp32 quotient, which is what x / (float)R
 // is (hipcc keeps fp32 division correctly rounded).  One fp64 division per (key, factor) was a
 // fifth of the FM gradient kernel.
+// (div_by_const with 1.0 / R was measured against this: with its guard it saves two
+// instructions per call, and R = 50000 is a divisor whose subnormal quotients need the guard)
 __device__ __forceinline__ float div_by_rows(float x, uint32_t R) {
 #pragma clang fp contract(off)
   if (R < (1u << 24)) return x / (float)R;

@@ -283,7 +283,7 @@ k_lr_grad_tiled(xf::TableDev T, const uint32_t *__restrict__ tile_ptr, uint32_t 
         g_out[ua + k] = g;
         if (UPDATE) {
           if (OPT == XF_OPT_FTRL) {
-            xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w[q], nn[q], z[q]);
+            xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w[q], nn[q], z[q]);
             T.w[slot[q]] = w[q];
             xf::store_nz(T, slot[q], nn[q], z[q]);
           } else {
@@ -381,7 +381,7 @@ k_lr_heavy_finish(xf::TableDev T, const uint32_t *__restrict__ heavy,
     if (OPT == XF_OPT_FTRL) {
       float w = T.w[slot], nn, z;
       xf::load_nz(T, slot, nn, z);
-      xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+      xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
       T.w[slot] = w;
       xf::store_nz(T, slot, nn, z);
     } else {
@@ -508,7 +508,7 @@ k_update_listed(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t H,
   if (OPT == XF_OPT_FTRL) {
     float w = T.w[slot], nn, z;
       xf::load_nz(T, slot, nn, z);
-    xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[u], w, nn, z);
+    xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[u], w, nn, z);
     T.w[slot] = w;
     xf::store_nz(T, slot, nn, z);
   } else {
@@ -854,10 +854,10 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
           if (UPDATE) {
             float4 w = v[i];
             if (OPT == XF_OPT_FTRL) {
-              xf::ftrl_step(TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.x, w.x, nzA[i].x, nzA[i].y);
-              xf::ftrl_step(TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.y, w.y, nzA[i].z, nzA[i].w);
-              xf::ftrl_step(TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.z, w.z, nzB[i].x, nzB[i].y);
-              xf::ftrl_step(TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.w, w.w, nzB[i].z, nzB[i].w);
+              xf::ftrl_step(TV.alpha, TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.x, w.x, nzA[i].x, nzA[i].y);
+              xf::ftrl_step(TV.alpha, TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.y, w.y, nzA[i].z, nzA[i].w);
+              xf::ftrl_step(TV.alpha, TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.z, w.z, nzB[i].x, nzB[i].y);
+              xf::ftrl_step(TV.alpha, TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g.w, w.w, nzB[i].z, nzB[i].w);
               *reinterpret_cast<float4 *>(TV.nz + to[i]) = nzA[i];
               *reinterpret_cast<float4 *>(TV.nz + to[i] + 2) = nzB[i];
             } else {
@@ -882,7 +882,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
                 const float g1 = div_by_rows((float)(aw * (double)K), R);
                 float w1 = ww[i];
                 if (OPT == XF_OPT_FTRL) {
-                  xf::ftrl_step(TW.inv_alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w1, wn[i], wz[i]);
+                  xf::ftrl_step(TW.alpha, TW.inv_alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w1, wn[i], wz[i]);
                   xf::store_nz(TW, rw[i], wn[i], wz[i]);
                 } else {
                   w1 = xf::sgd_step(TW.lr, g1, w1);
@@ -970,7 +970,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         if (UPDATE) {
           if (OPT == XF_OPT_FTRL) {
             float w = v[i], nn = vn[i], z = vz[i];
-            xf::ftrl_step(TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g, w, nn, z);
+            xf::ftrl_step(TV.alpha, TV.inv_alpha, TV.beta, TV.lambda1, TV.lambda2, g, w, nn, z);
             TV.w[to[i]] = w;
             xf::store_nz(TV, to[i], nn, z);
           } else {
@@ -994,7 +994,7 @@ k_fm_grad_tiled(xf::TableDev TW, xf::TableDev TV, const uint32_t *__restrict__ t
         if (OPT == XF_OPT_FTRL) {
           float w = wu[ua + q], nn, z;
           xf::load_nz(TW, rw, nn, z);
-          xf::ftrl_step(TW.inv_alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
+          xf::ftrl_step(TW.alpha, TW.inv_alpha, TW.beta, TW.lambda1, TW.lambda2, g1, w, nn, z);
           TW.w[rw] = w;
           xf::store_nz(TW, rw, nn, z);
         } else {
@@ -1021,7 +1021,7 @@ k_update_listed_rows(xf::TableDev T, const uint32_t *__restrict__ list, uint32_t
     if (OPT == XF_OPT_FTRL) {
       float w = T.w[o], nn, z;
       xf::load_nz(T, o, nn, z);
-      xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, gg, w, nn, z);
+      xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, gg, w, nn, z);
       T.w[o] = w;
       xf::store_nz(T, o, nn, z);
     } else {

@@ -482,7 +482,7 @@ k_update(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
     if (OPT == XF_OPT_FTRL) {
       float w = T.w[o], nn, z;
       xf::load_nz(T, o, nn, z);
-      xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
+      xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
       T.w[o] = w;
       xf::store_nz(T, o, nn, z);
     } else {
@@ -516,7 +516,7 @@ k_update_merged(xf::TableDev T, const uint64_t *__restrict__ keys_sorted,
       float w = T.w[o], nn, z;
       xf::load_nz(T, o, nn, z);
       for (size_t s = i; s < n && keys_sorted[s] == key; ++s)
-        xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2,
+        xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2,
                       grads[(size_t)order[s] * T.dim + j], w, nn, z);
       T.w[o] = w;
       xf::store_nz(T, o, nn, z);
@@ -561,7 +561,7 @@ k_update_heads(xf::TableDev T, const uint32_t *__restrict__ hrow,
       xf::load_nz(T, o, nn, z);
       size_t s = i;
       do {
-        xf::ftrl_step(T.inv_alpha, T.beta, T.lambda1, T.lambda2,
+        xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2,
                       grads[(size_t)order[s] * T.dim + j], w, nn, z);
         ++s;
       } while (s < n && hrow[s] == kNotHead);
