@@ -82,6 +82,12 @@ def parse_args():
                          "the fused step, to time its stages on one GPU")
     ap.add_argument("--no-fm-leg", action="store_true",
                     help="N=1 LR: skip the FM k=16 + SGD figure (configs[3]) of the JSON line")
+    ap.add_argument("--no-zipf-leg", action="store_true",
+                    help="N=1 LR: skip the power-law (Zipf 1.1) figure of the JSON line")
+    ap.add_argument("--no-table-sweep", action="store_true",
+                    help="N=1 LR: skip the same minibatch shape on tables of 3x10^7 and 10^8 keys")
+    ap.add_argument("--sweep-keys", default="30000000,100000000",
+                    help="table sizes (keys per GPU) of the table sweep")
     ap.add_argument("--no-owner-leg", action="store_true",
                     help="N>1: skip the supplementary run of the owner-compute dataflow")
     ap.add_argument("--repeats", type=int, default=10,
@@ -289,28 +295,47 @@ def with_key_build(args, trainer, batches):
 
 
 def with_key_build_sharded(args, trainer, batches, R, world, barrier, allmax):
-    """N > 1: xf_sharded_compile (COLLECTIVE: the owner-compute compile sends the nonzeros to
-    the key owners, who build their cells) + the step, per minibatch, nothing cached.  The
-    compile takes the reader's HOST arrays (here: pageable numpy memory), so the upload of the
-    raw keys is inside this figure."""
+    """N > 1 (or the N > 1 code path at world 1): xf_sharded_compile_dev (COLLECTIVE: on the
+    owner-compute dataflow a stable partition of the nonzeros by key owner on the device, one
+    all-to-all of them, the owners' range-partitioned key build) + the step, per minibatch,
+    nothing cached, raw keys resident in HBM — what `with_key_build` is at N = 1.
+    `from_host_arrays_ms_per_step`: the same through xf_sharded_compile on the reader's HOST
+    arrays (pageable numpy memory: the upload of the raw keys is inside that figure)."""
+    import torch
     n = max(2, args.key_build_steps // 2)
+    raw = [(torch.from_numpy(k.view(np.int64)).cuda(),
+            torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
+            torch.from_numpy(lb).cuda(), len(lb), len(k)) for rp, k, lb in batches[:4]]
 
-    def one(i):
+    def one_dev(i):
+        k, rp, lb, R_, N_ = raw[i % len(raw)]
+        b = trainer.st.compile_dev(k.data_ptr(), rp.data_ptr(), lb.data_ptr(), R_, N_, keep=False)
+        trainer.step(b)
+        trainer.check()
+        del b
+
+    def one_host(i):
         b = trainer.compile(*batches[i % len(batches)])
         trainer.step(b)
         trainer.check()
         del b
-    for i in range(2):
-        one(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(n):
-        one(i)
-    barrier()
-    dt = allmax(time.perf_counter() - t0) / n
+
+    def timed(one):
+        for i in range(2):
+            one(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            one(i)
+        barrier()
+        return allmax(time.perf_counter() - t0) / n
+    dt = timed(one_dev)
+    dth = timed(one_host)
     return {"value": R * world / dt, "unit": "examples/sec", "ms_per_step": dt * 1e3, "steps": n,
-            "what": "xf_sharded_compile from host arrays (upload of the raw keys included) + "
-                    "the step on the dataflow of `value`, per minibatch, nothing cached"}
+            "from_host_arrays_ms_per_step": dth * 1e3,
+            "what": "xf_sharded_compile_dev (raw keys resident in HBM) + the step on the "
+                    "dataflow of `value`, per minibatch, nothing cached, the host waiting for "
+                    "every step (trainer.check) before it compiles the next minibatch"}
 
 
 def fm_leg(args, batches):
@@ -505,6 +530,182 @@ def fm_leg_sharded(args, batches, group, world, barrier, allmax):
            "fm_mode": "reference (pooled-over-k sums, no 1/2: fm_worker.cc:178-196)"}
     del comp, tr
     return out
+
+
+def _lr_leg_run(tr, comp, steps, warmup=4, repeats=3):
+    """warm-up, then `repeats` blocks of `steps` steps on compiled minibatches; per-kernel HIP
+    event times of the first block"""
+    import torch
+    for i in range(warmup):
+        tr.step(comp[i % len(comp)])
+    tr.check()
+    torch.cuda.synchronize()
+    per, ms, n = [], None, 0
+    for rep in range(repeats):
+        if rep == 0:
+            tr.profile(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(comp[i % len(comp)])
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / steps * 1e3)
+        if rep == 0:
+            ms, n = tr.profile_read()
+            tr.profile(False)
+    tr.check()
+    return per, {k: v / max(n, 1) for k, v in ms.items()}
+
+
+def _update_dev_ms(tr, raw_batches, steps=6, repeats=3):
+    """xf_lr_update_dev (key build + step, raw keys resident in HBM, nothing cached) per
+    minibatch: ms per call"""
+    import ctypes as C
+    import torch
+    from xflow_amd import capi
+    L = capi.lib()
+    raw = [(torch.from_numpy(k.view(np.int64)).cuda(),
+            torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
+            torch.from_numpy(lb).cuda(), len(lb), len(k)) for rp, k, lb in raw_batches]
+    prev = [None]
+
+    def one(i):
+        k, rp, lb, R, NNZ = raw[i % len(raw)]
+        h = capi.vp()
+        capi.check(L.xf_lr_update_dev(C.byref(h), tr.w.h, k.data_ptr(), rp.data_ptr(),
+                                      lb.data_ptr(), R, NNZ, 0, tr.ws.h, None))
+        if prev[0] is not None:
+            L.xf_batch_free(prev[0])
+        prev[0] = h
+    for i in range(2):
+        one(i)
+    capi.stream_sync()
+    torch.cuda.synchronize()
+    per = []
+    for rep in range(repeats):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        capi.stream_sync()
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / steps * 1e3)
+    if prev[0] is not None:
+        L.xf_batch_free(prev[0])
+        prev[0] = None
+    tr.check()
+    return per
+
+
+def _leg_roofline(R, NNZ, U, per_ms, kern):
+    """SURVEY 8(d) bytes of an LR+FTRL step against the times of one leg"""
+    g = kern.get("gradient", 0.0)
+    grad_b, step_b = 32 * U, 12 * NNZ + 8 * R + 32 * U
+    return {"roofline": {"bound": "hbm", "kernel": "gradient + Push",
+                         "algorithmic_bytes_per_launch": grad_b, "avg_launch_ms": g,
+                         "achieved": grad_b / (g * 1e-3) / 1e9 if g > 0 else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": grad_b / (g * 1e-3) / 1e9 / HBM_PEAK_GBS if g > 0 else None,
+                         "traffic": None, "algorithmic_bytes_source": "SURVEY.md 8(d): 32 U"},
+            "step_bytes_survey_8d": step_b,
+            "step_gbs_survey_8d": step_b / (per_ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak_survey_8d": step_b / (per_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def zipf_leg(args, keytab):
+    """SURVEY 8(d) config 2 variant B next to the uniform line: the same table and row shape with
+    fids ~ Zipf(1.1) (head key ~10^6 occurrences per minibatch: split chunks, head-key folds),
+    compiled minibatches replayed from HBM like `value`.  Not `value`."""
+    import argparse as _ap
+    from xflow_amd.single import SingleGpuTrainer
+    a = _ap.Namespace(**vars(args))
+    a.zipf, a.batches, a.signal_keys = 1.1, 8, 0
+    batches = make_batches(a, 0, args.keys_per_gpu, keytab)
+    cap = int(args.keys_per_gpu / args.load_factor) + 1024
+    tr = SingleGpuTrainer(model="lr", optimizer="ftrl", capacity=cap)
+    comp = [tr.compile(*b) for b in batches]
+    for c in comp:
+        tr.predict(c)
+    tr.check()
+    tr.defrag()
+    for c in comp:
+        tr.predict(c)
+    tr.check()
+    per, kern = _lr_leg_run(tr, comp, steps=24)
+    R, NNZ = comp[0].R, comp[0].NNZ
+    U = int(np.mean([len(np.unique(b[1])) for b in batches[:2]]))
+    wkb = _update_dev_ms(tr, batches[:4])
+    out = {"workload": "LR+FTRL, %d keys, %d rows x %d nnz per minibatch, fids ~ Zipf(1.1) "
+                       "(SURVEY 8d config 2 variant B)" % (args.keys_per_gpu, R, args.nnz_per_row),
+           "value": R / (per[0] * 1e-3), "unit": "examples/sec", "ms_per_step": per[0],
+           "ms_per_step_repeats": spread(per), "steps": 24, "kernels_ms": kern,
+           "unique_keys_per_minibatch": U, "cells": comp[0].cells_info(),
+           "with_key_build_ms_per_step": wkb[0], "with_key_build_repeats": spread(wkb)}
+    out.update(_leg_roofline(R, NNZ, U, per[0], kern))
+    del comp, tr
+    return out
+
+
+def table_sweep(args):
+    """The same 5x10^4 x 200 uniform minibatch on tables that do NOT fit the 256 MiB Infinity
+    Cache: every key of the key space is in the table (state 12 B per key: 360 MB at 3x10^7
+    keys, 1.2 GB at 10^8), the minibatch touches a third / a tenth of the rows.  Per size: the
+    step on compiled minibatches (gradient + Push fraction of the HBM peak by SURVEY 8(d)'s
+    bytes, whole-step GB/s) and the whole update() with its key build."""
+    import argparse as _ap
+    import torch
+    from xflow_amd import capi
+    from xflow_amd.single import SingleGpuTrainer
+    out = []
+    for nkeys in [int(x) for x in args.sweep_keys.split(",") if x]:
+        try:
+            t0 = time.perf_counter()
+            keytab = make_key_table(nkeys)
+            a = _ap.Namespace(**vars(args))
+            a.zipf, a.batches, a.signal_keys, a.keys_per_gpu = 0.0, 4, 0, nkeys
+            batches = make_batches(a, 0, nkeys, keytab)
+            tr = SingleGpuTrainer(model="lr", optimizer="ftrl",
+                                  capacity=int(nkeys / args.load_factor) + 1024)
+            # every key of the key space into the table: minibatches that name each key once
+            slab, lab = 10_000_000, None
+            for lo in range(0, nkeys, slab):
+                kk = keytab[lo:lo + slab]
+                rows = max(1, len(kk) // 200)
+                rp = np.minimum(np.arange(rows + 1, dtype=np.uint64) * np.uint64(200),
+                                np.uint64(len(kk)))
+                rp[-1] = len(kk)
+                lab = np.zeros(rows, np.int32)
+                b = capi.LocalBatch(tr.w, rp, kk, lab, retain_keys=False)
+                del b
+            tr.check()
+            tr.defrag()
+            held = len(tr.w)
+            comp = [tr.compile(*b) for b in batches]
+            for c in comp:
+                tr.predict(c)
+            tr.check()
+            torch.cuda.synchronize()
+            setup_s = time.perf_counter() - t0
+            per, kern = _lr_leg_run(tr, comp, steps=16)
+            R, NNZ = comp[0].R, comp[0].NNZ
+            U = int(len(np.unique(batches[0][1])))
+            info = comp[0].cells_info()
+            wkb = _update_dev_ms(tr, batches)
+            e = {"keys_per_gpu": nkeys, "table_keys": held, "state_bytes": held * 12,
+                 "value": R / (per[0] * 1e-3), "unit": "examples/sec", "ms_per_step": per[0],
+                 "ms_per_step_repeats": spread(per), "kernels_ms": kern,
+                 "unique_keys_per_minibatch": U, "cells": info,
+                 "with_key_build_ms_per_step": wkb[0], "with_key_build_repeats": spread(wkb),
+                 "setup_s": setup_s}
+            e.update(_leg_roofline(R, NNZ, U, per[0], kern))
+            out.append(e)
+            del comp, tr, keytab, batches
+            torch.cuda.empty_cache()
+        except Exception as ex:   # the LR line must not depend on this extra
+            out.append({"keys_per_gpu": nkeys, "error": str(ex)})
+    return {"what": "LR+FTRL, 50 000 rows x 200 nnz uniform per minibatch on tables that hold "
+                    "EVERY key of a larger key space (the 10^7-key table of `value` fits the "
+                    "Infinity Cache, these do not); compiled minibatches replayed; "
+                    "with_key_build = xf_lr_update_dev per minibatch, nothing cached",
+            "tables": out}
 
 
 def spread(ms):
@@ -1206,7 +1407,8 @@ def main():
         except Exception as e:
             sum_leg = {"error": str(e)}
     wkb_sharded = None
-    if group is not None and world > 1 and args.model == "lr" and args.key_build_steps > 0:
+    if group is not None and (world > 1 or args.general_path) and args.model == "lr" \
+            and args.key_build_steps > 0 and hasattr(trainer, "st"):
         try:   # (collective: every rank; a failure is symmetric)
             wkb_sharded = with_key_build_sharded(args, trainer, batches, R, world, barrier,
                                                  allmax)
@@ -1363,6 +1565,18 @@ def main():
             out["fm"] = fm_leg(args, batches)
         except Exception as e:   # the LR line must not depend on this extra
             out["fm"] = {"error": str(e)}
+    if world == 1 and not args.force_sharded and args.model == "lr" and not args.zipf:
+        compiled = trainer = hb = None
+        if not args.no_zipf_leg:
+            try:
+                out["zipf"] = zipf_leg(args, keytab)
+            except Exception as e:
+                out["zipf"] = {"error": str(e)}
+        if not args.no_table_sweep:
+            try:
+                out["table_sweep"] = table_sweep(args)
+            except Exception as e:
+                out["table_sweep"] = {"error": str(e)}
     if args.pmc_calibrate:
         for kind in range(10):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))

@@ -481,6 +481,15 @@ int xf_sharded_destroy(xf_sharded *st);
 int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
                        const uint64_t *keys, const int32_t *labels, size_t row_begin,
                        size_t row_end, int keep);
+/* The same from DEVICE-resident arrays: the raw keys in CSR order, 32-bit row offsets (R + 1),
+ * labels.  On the owner-compute dataflow the worker's side is a stable partition by key owner
+ * on the device and ONE host wait (for the per-owner counts, which travel through the group's
+ * all-to-all).  The arrays may be released when the call returns.  COLLECTIVE.  Replaces the
+ * key build + the Pull's routing of lr_worker.cc:146-170 for a minibatch that is already in
+ * HBM (nothing in the reference: its blocks live in host vectors). */
+int xf_sharded_compile_dev(xf_sharded *st, xf_sbatch **out, const uint64_t *d_keys,
+                           const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                           uint32_t NNZ, int keep);
 int xf_sbatch_free(xf_sbatch *b);
 int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, uint32_t *U,
                    uint64_t *n_owned /* keys of this minibatch (all ranks) this rank owns */);

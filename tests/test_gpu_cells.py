@@ -66,7 +66,7 @@ def test_local_batches_match_the_oracle(R, nnz, nkeys, zipf, ragged, cap):
         same(capi.lr_predict(t, bs[1], ws), obs[1].lr_loss(s.pull(obs[1].ukeys))[1])
 
 
-@pytest.mark.parametrize("knob", [300, 301, 302, 304, 305, 306, 428, 432, 556, 684, 557, 299])
+@pytest.mark.parametrize("knob", [300, 301, 302, 304, 428, 432, 299])
 @pytest.mark.parametrize("opt", ["ftrl", "sgd"])
 def test_every_variant_of_the_gradient_kernel_gives_the_oracle_table(knob, opt):
     """k_lr_grad_dense (the steady-state gradient + Push: one fp32 division for sum / R, the

@@ -499,3 +499,140 @@ def test_exchange_code_paths_at_world_one_over_rccl_equal_the_fused_step(tmp_pat
         same(a, e)
     rp, ks, lb = _big_data(0, 99)
     same(got["p"], one.predict(one.compile(rp, ks, lb)))
+
+
+def _pretend_data(step):
+    """rows enough for five row windows, chunks of every kind at once: most hold fewer than 2048
+    entries (k_lr_grad_multi), the power-law head chunks more (the general loop) or more than
+    8192 (slices + the finish kernel)"""
+    rng = np.random.RandomState(500 + step)
+    R, K = 72000, 150000
+    keytab = capi.hash_decimal_range(0, K)
+    lens = rng.randint(0, 4, size=R)
+    n = int(lens.sum())
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    fid = rng.randint(0, K, size=n)
+    hot = rng.rand(n) < 0.25
+    fid[hot] = np.minimum(rng.zipf(1.2, size=int(hot.sum())) - 1, K - 1)
+    return rowptr, keytab[fid], rng.randint(0, 2, size=R).astype(np.int32)
+
+
+def _pretend_rank(port, knob, outdir, q):
+    try:
+        os.environ["XF_SHARDED_GENERAL"] = "1"
+        os.environ["XF_OWNER_TIMING_SOURCES"] = "5"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(0, 1, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
+        st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 19, schedule="owner")
+        capi.tune("exp_knob", knob)
+        alive = []
+        for s in range(4):
+            alive.append(st.compile(*_pretend_data(s % 3)))
+            st.step(alive[-1])
+            if s == 1:
+                st.defrag()      # holes and an arrival segment afterwards
+        st.check()
+        k, w, n, z = st.w.export()
+        np.savez(os.path.join(outdir, "pretend_%d.npz" % knob), k=k, w=w, n=n, z=z)
+        st.close()
+        g.close()
+        q.put(None)
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
+    """An owner's gradient + Pushes for several workers (XF_UPDATE_RANK_ORDERED): k_lr_grad_multi
+    (the chunk's state in LDS, the stepping lane picked among the lanes that hold the key; 512
+    and 256 threads per chunk) against round 4's pass (exp_knob 298: state rows in registers, a
+    sweep per worker) on one GPU whose rows are dealt out to five pretended workers — five
+    optimizer steps per key, chunks below and above one round of registers, split chunks, holes
+    after a defrag: the same table, bit for bit.  (That the steps are the reference's: the
+    world-2 / 3 / 8 tests against the oracle, which run the same kernel.)"""
+    ctx = mp.get_context("spawn")
+    for knob in (298, 0, 297):
+        q = ctx.Queue()
+        p = ctx.Process(target=_pretend_rank, args=(free_port(), knob, str(tmp_path), q))
+        p.start()
+        err = q.get(timeout=240)
+        p.join(timeout=60)
+        assert not err, err
+    ref = np.load(str(tmp_path / "pretend_298.npz"))
+    assert len(ref["k"]) > 100000 and np.any(ref["w"] != 0)
+    for knob in (0, 297):
+        got = np.load(str(tmp_path / ("pretend_%d.npz" % knob)))
+        for f in ("k", "w", "n", "z"):
+            same(got[f], ref[f])
+
+
+def _compile_dev_rank(rank, world, port, dev, outdir, q):
+    try:
+        import torch
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(rank, world, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
+        st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=64, schedule="owner")
+        alive = []
+        for s in range(3):
+            rp, ks, lb = _big_data(rank, s)
+            if dev:
+                d = (torch.from_numpy(ks.view(np.int64).copy()).cuda(),
+                     torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
+                     torch.from_numpy(lb.copy()).cuda())
+                torch.cuda.synchronize()
+                b = st.compile_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(lb),
+                                   len(ks), keep=(s != 1))
+                del d                # (the arrays may go as soon as the call has returned)
+                torch.cuda.empty_cache()
+            else:
+                b = st.compile(rp, ks, lb, keep=(s != 1))
+            alive.append(b)
+            st.step(b)
+        st.check()
+        k, w, n, z = st.w.export()
+        np.savez(os.path.join(outdir, "cd%d_%d.npz" % (dev, rank)), k=k, w=w, n=n, z=z)
+        g.barrier()
+        st.close()
+        g.close()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_compile_from_device_arrays_is_the_compile_from_host_arrays(tmp_path):
+    """xf_sharded_compile_dev (raw keys resident in HBM: the stable partition by key owner on the
+    device, counts through the group's all-to-all, one host wait) against xf_sharded_compile on
+    the same minibatches: world 2, 20 000 / 23 000 rows per worker, uniform and power-law keys —
+    the shards of the table bit for bit, and (the host-array run) bit for bit the oracle's."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    for dev in (0, 1):
+        q = ctx.Queue()
+        port = free_port()
+        ps = [ctx.Process(target=_compile_dev_rank, args=(r, world, port, dev, str(tmp_path), q))
+              for r in range(world)]
+        for p in ps:
+            p.start()
+        res = [q.get(timeout=240) for _ in ps]
+        for p in ps:
+            p.join(timeout=60)
+        errs = [e for _, e in res if e]
+        assert not errs, errs[0]
+    for r in range(world):
+        a, b = (np.load(str(tmp_path / ("cd%d_%d.npz" % (dev, r)))) for dev in (0, 1))
+        for f in ("k", "w", "n", "z"):
+            same(a[f], b[f])
+    with O.sum_mode(1):
+        w = O.Store(O.OPT_FTRL, 1)
+        for s in range(3):
+            obs = [O.Batch(*_big_data(r, s)) for r in range(world)]
+            pulled = [w.pull(ob.ukeys) for ob in obs]
+            grads = [ob.lr_grad(ob.lr_loss(pw)[0]) for ob, pw in zip(obs, pulled)]
+            for ob, g in zip(obs, grads):
+                w.push(ob.ukeys, g)
+    parts = [np.load(str(tmp_path / ("cd1_%d.npz" % r))) for r in range(world)]
+    ks, ws, ns, zs = w.export()
+    k = np.concatenate([p["k"] for p in parts])
+    order = np.argsort(k)
+    same(k[order], ks)
+    for f, ref in (("w", ws), ("n", ns), ("z", zs)):
+        same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)

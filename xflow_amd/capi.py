@@ -161,6 +161,8 @@ SIGNATURES = {
     "xf_sharded_destroy": (C.c_int, [vp]),
     "xf_sharded_compile": (C.c_int, [vp, C.POINTER(vp), u64p, u64p, i32p, C.c_size_t,
                                      C.c_size_t, C.c_int]),
+    "xf_sharded_compile_dev": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, C.c_uint32, C.c_uint32,
+                                         C.c_int]),
     "xf_sbatch_free": (C.c_int, [vp]),
     "xf_sbatch_dims": (C.c_int, [vp, u32p, u32p, u32p, u64p]),
     "xf_sbatch_fm_keyed": (C.c_int, [vp]),
@@ -798,6 +800,14 @@ class Sharded:
         h = vp()
         check(lib().xf_sharded_compile(self.h, C.byref(h), _p(rowptr, u64p), _p(keys, u64p),
                                        _p(labels, i32p), row_begin, row_end, 1 if keep else 0))
+        return ShardedBatch(h, self)
+
+    def compile_dev(self, d_keys, d_rowptr, d_labels, R, NNZ, keep=True):
+        """device pointers (ints): raw keys in CSR order (u64), row offsets (u32, R + 1), labels
+        (i32); the arrays may be released when this returns"""
+        h = vp()
+        check(lib().xf_sharded_compile_dev(self.h, C.byref(h), d_keys, d_rowptr, d_labels, R, NNZ,
+                                           1 if keep else 0))
         return ShardedBatch(h, self)
 
     def step(self, b):

@@ -87,6 +87,8 @@ struct xf_cells {
   uint32_t *item_slice = nullptr;   // [nitems]   slice | nslices << 16,
   uint32_t *item_dump = nullptr;    // [nitems]   index of the chunk among the split ones
   uint32_t *split_chunk = nullptr;  // [nsplit_chunks] chunks cut into several items
+  uint8_t *item_done = nullptr;     // [nitems] scratch of the several-worker gradient pass: 1 = the
+                                    //          item was taken by k_lr_grad_multi (written per pass)
   double *gsum = nullptr;           // [nsplit_chunks * kChunk] their key sums (fp64 atomics)
   uint8_t *gtouched = nullptr;      // [nsplit_chunks * kChunk] 1 = the minibatch holds the key
   size_t split_bytes = 0;           // gsum + gtouched: zero between gradient passes (the finish

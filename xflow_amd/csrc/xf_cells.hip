@@ -513,12 +513,15 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
                 uint32_t R, uint32_t M, float *__restrict__ g_out, double *__restrict__ gsum,
                 uint8_t *__restrict__ gtouched, uint32_t nsrc, const uint32_t *__restrict__ src_win,
                 const uint32_t *__restrict__ src_rows, uint32_t nsplit,
-                const uint32_t *__restrict__ loss_base, uint32_t chunk0) {
+                const uint32_t *__restrict__ loss_base, uint32_t chunk0,
+                const uint8_t *__restrict__ item_done) {
   __shared__ double acc[kChunk];
   __shared__ uint8_t touched[kChunk];
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
   __shared__ uint32_t nlist;
   const uint32_t tid = threadIdx.x;
+  // (several sources: k_lr_grad_multi has run first and says which items it has taken)
+  if (SRC && item_done && item_done[blockIdx.x]) return;
   GRAD_T(0);
   if (tid == 0) nlist = 0;
   const uint32_t c = item_chunk[blockIdx.x];
@@ -842,6 +845,173 @@ extern "C" int xf_debug_grad_timeline(unsigned long long *out, size_t n) {
 }
 namespace {
 #endif
+
+// ---- the gradient + Pushes of an owner of SEVERAL workers (XF_UPDATE_RANK_ORDERED on the
+// owner-compute dataflow): every worker's gradient sum / R_q is its own optimizer step, the steps
+// of a key applied in rank order (lr_worker.cc:116-118 + ftrl.h:54-74 once per Push).
+//
+// Round 4's pass (k_lr_grad_cells<.., SRC, MULTI>) kept a thread's eight state rows in
+// registers and ran, per worker, a sweep over them: 8 workers x 8 rows = 64 optimizer steps per
+// thread, each issued for the whole wavefront although a worker touches a tenth of a chunk's
+// keys — ~5 400 VALU instructions per wavefront and chunk, 108 us of issue time at the N = 8
+// shard shape: the pass was VALU-bound on steps that 90 % of the lanes sat out.
+//
+// Here the chunk's state lives in LDS for the time of the pass (w 8 KiB, {n, z} 16 KiB: loaded
+// and stored once, coalesced, whole lines), so ANY lane can step ANY key, and the lane that
+// steps key k for worker q is one of the lanes that hold an entry (k, q): after a worker's
+// entries have been added to the key sums, every such lane reads back the mark its key carries
+// (the last writer's position) and the one whose position it is takes the step.  A worker's
+// entries are neighbours in the index space, so its ~200 steps per chunk run in three or four
+// wavefronts with nearly every lane busy; the other wavefronts skip the phase.  Same sums (fp64
+// LDS atomics: exact, any order), same steps in the same order per key: the bits of the general
+// loop (tests/test_gpu_sharded.py, world 2 / 3 / 8).
+//
+// Takes the unsplit chunks whose entries fit one round of registers (NT x E = 2048) and that
+// span at most kMultiWin row windows; item_done[item] says which, the general kernel
+// (k_lr_grad_cells<.., SRC>) is launched behind it for the others.
+constexpr uint32_t kMultiWin = 64;
+constexpr uint32_t kMultiSrc = 64;
+constexpr uint32_t kMultiAny = 0x8000u;  // mark: the key has been touched by some worker
+
+template <int OPT, int NT>
+__global__ void __launch_bounds__(NT)
+k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
+                const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
+                const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
+                const float *__restrict__ loss, uint32_t M, uint32_t nsrc,
+                const uint32_t *__restrict__ src_win, const uint32_t *__restrict__ src_rows,
+                const uint32_t *__restrict__ loss_base, uint32_t chunk0, int full_store,
+                uint8_t *__restrict__ item_done) {
+  constexpr int E = (int)(kChunk / NT);  // entries per lane = state rows per thread
+  constexpr bool FTRL = OPT == XF_OPT_FTRL;
+  __shared__ double acc[kChunk];
+  __shared__ float sw[kChunk];
+  __shared__ float2 snz[FTRL ? kChunk : 1];
+  __shared__ uint16_t mark[kChunk];
+  __shared__ uint32_t cum[kMultiWin + 1], sbase[kMultiWin];
+  __shared__ uint32_t spos[kMultiSrc + 1], srow[kMultiSrc];
+  __shared__ uint8_t wsrc[kMultiWin];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = item_chunk[blockIdx.x];
+  const uint32_t S = item_slice[blockIdx.x] >> 16;
+  if (S != 1 || nwin > kMultiWin || nsrc > kMultiSrc) {  // workgroup-uniform
+    if (tid == 0) item_done[blockIdx.x] = 0;
+    return;
+  }
+  // the chunk's state rows: requested now, written to LDS below (rows past M: a table whose
+  // last chunk is not full)
+  const size_t row0 = (size_t)(chunk0 + c) * kChunk;
+  float rw[E];
+  float2 rnz[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const size_t r = row0 + tid + i * NT < M ? row0 + tid + i * NT : row0;
+    rw[i] = T.w[r];
+    rnz[i] = make_float2(0.0f, 0.0f);
+    if (FTRL) rnz[i] = T.nz[r];
+  }
+  if (tid < nwin) {
+    const size_t cell = (size_t)tid * nchunk + c;
+    const uint32_t b = cellptr[cell], e = cellptr[cell + 1];
+    sbase[tid] = b;
+    cum[tid + 1] = e - b;
+    uint32_t q = 0;
+    while (q + 1 < nsrc && tid >= src_win[q + 1]) ++q;
+    wsrc[tid] = (uint8_t)q;
+  }
+  if (tid < nsrc) srow[tid] = src_rows[tid];
+  __syncthreads();
+  if (tid < 64) {  // cum = inclusive scan of the windows' entry counts (one wavefront)
+    uint32_t inc = tid < nwin ? cum[tid + 1] : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if ((int)tid >= o) inc += u;
+    }
+    if (tid < nwin) cum[tid + 1] = inc;
+    if (tid == 0) cum[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t total = cum[nwin];
+  if (total > (uint32_t)(NT * E)) {  // workgroup-uniform: the general kernel's
+    if (tid == 0) item_done[blockIdx.x] = 0;
+    return;
+  }
+  if (tid == 0) item_done[blockIdx.x] = 1;
+  if (tid <= nsrc) spos[tid] = cum[src_win[tid]];  // worker q's entries: positions [spos[q], spos[q+1])
+  // per entry: the key's place in the chunk and its worker in ONE register, the loss in another
+  uint32_t ek[E];
+  float l[E];
+  {
+    uint32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t p = q * NT + tid;
+      ek[q] = 0xFFFFFFFFu;
+      l[q] = 0.0f;
+      if (p < total) {
+        while (p >= cum[v + 1]) ++v;  // p ascends with q: v never goes back
+        const uint32_t e = entries[sbase[v] + (p - cum[v])];
+        if (e != 0xFFFFFFFFu) {  // (a hole: the key went to the arrival segment)
+          l[q] = loss[(size_t)loss_base[v] + ((e >> kChunkBits) & kRowMask)];
+          ek[q] = (e & (kChunk - 1)) | ((uint32_t)wsrc[v] << 16);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t k = tid + i * NT;
+    acc[k] = 0.0;
+    mark[k] = 0;
+    sw[k] = rw[i];
+    if (FTRL) snz[k] = rnz[i];
+  }
+  __syncthreads();
+  for (uint32_t q = 0; q < nsrc; ++q) {
+    const uint32_t pb = spos[q], pe = spos[q + 1];
+    if (pb == pe) continue;  // workgroup-uniform: nothing of this worker in the chunk
+    const int ib = (int)(pb / NT), ie = (int)((pe - 1) / NT);
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+      if (i >= ib && i <= ie && (ek[i] >> 16) == q) {  // (a hole's worker is 0xFFFF)
+        const uint32_t k = ek[i] & (kChunk - 1);
+        atomicAdd(&acc[k], (double)l[i]);
+        mark[k] = (uint16_t)(kMultiAny | (uint32_t)(i * NT + tid));
+      }
+    __syncthreads();
+    const uint32_t rq = srow[q];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+      if (i >= ib && i <= ie && (ek[i] >> 16) == q) {
+        const uint32_t k = ek[i] & (kChunk - 1);
+        if ((mark[k] & (kMultiAny - 1u)) != (uint32_t)(i * NT + tid)) continue;  // not its stepper
+        const double sum = acc[k];
+        acc[k] = 0.0;  // the next worker's phase starts from zero
+        const float g = xf::div_by_rows((float)sum, rq);  // lr_worker.cc:117
+        float w = sw[k];
+        if (FTRL) {
+          float2 s2 = snz[k];
+          xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, s2.x, s2.y);
+          snz[k] = s2;
+        } else {
+          w = xf::sgd_step(T.lr, g, w);
+        }
+        sw[k] = w;
+      }
+    __syncthreads();
+  }
+  // back to the table: every row of the chunk (whole lines; an untouched row gets the bits it
+  // had), or the touched ones only when the minibatch touches the table thinly
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t k = tid + i * NT;
+    if (row0 + k >= M) continue;
+    if (!full_store && !(mark[k] & kMultiAny)) continue;
+    T.w[row0 + k] = sw[k];
+    if (FTRL) T.nz[row0 + k] = snz[k];
+  }
+}
 
 // ---- the gradient + Push of the steady state: ONE source, no split chunk, at most kDenseWin
 // row windows (config 2: three) — the launch that takes most of the LR step.  What the general
@@ -1220,8 +1390,9 @@ int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t 
   const size_t o_sc = o_id + al((size_t)c->nitems * 4);
   const size_t o_gd = o_sc + al((size_t)c->nsplit_chunks * 4);
   const size_t o_td = o_gd + al((size_t)c->nsplit_chunks * kChunk * 8);
-  const size_t total2 = o_td + al((size_t)c->nsplit_chunks * kChunk) + 256;
-  c->split_bytes = o_td + al((size_t)c->nsplit_chunks * kChunk) - o_gd;
+  const size_t o_dn = o_td + al((size_t)c->nsplit_chunks * kChunk);
+  const size_t total2 = o_dn + al((size_t)c->nitems) + 256;
+  c->split_bytes = o_dn - o_gd;
   XF_TRY(blob_alloc((void **)&c->blob2, total2, &c->blob2_bytes));
   char *d = c->blob2;
   c->item_chunk = (uint32_t *)(d + o_ic);
@@ -1230,6 +1401,7 @@ int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t 
   c->split_chunk = (uint32_t *)(d + o_sc);
   c->gsum = (double *)(d + o_gd);
   c->gtouched = (uint8_t *)(d + o_td);
+  c->item_done = (uint8_t *)(d + o_dn);
   const size_t nc1 = (size_t)c->nchunk + 1;
   if (c->nitems)
     hipLaunchKernelGGL(k_items_fill, dim3(grid_for(c->nchunk)), dim3(kBlock), 0, s, c->plan,
@@ -1325,12 +1497,22 @@ struct CellSources {
   uint8_t *gtouched = nullptr;       // [n * nsplit_chunks * kChunk]
 };
 
+// whole-line stores of a chunk's state pay when most 128-byte lines hold a touched row (63 % of
+// the rows at the config-2 shape: 74 -> 70 us); a minibatch that touches the table thinly (a
+// 1e8-key shard: a tenth of the rows) would write ten times what it changes.  Entries per chunk
+// of the items the pass runs over stand in for the touch density (uniform keys: 0.3 entries
+// per row = a quarter of the rows touched, three lines in four hold one).
+static bool dense_touch(const xf_cells *c) {
+  return (double)c->NNZ >= 0.3 * (double)c->nitems * (double)kChunk;
+}
+
 template <int OPT, int MODE>
 static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss, float *d_g,
                        hipStream_t s, const CellSources *src = nullptr) {
   if (c->nitems == 0) return XF_OK;
   double *gsum = src ? src->gsum : c->gsum;
   uint8_t *gtouched = src ? src->gtouched : c->gtouched;
+  const uint8_t *no_skip = nullptr;
   if (c->nsplit_chunks) {
     if (src) {
       const size_t cells = (size_t)src->n * c->nsplit_chunks * kChunk;
@@ -1349,7 +1531,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                        T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, src->rows_host, c->M, d_g, gsum,
                        gtouched, 1u, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       c->nsplit_chunks, src->d_loss_base, c->chunk0);
+                       c->nsplit_chunks, src->d_loss_base, c->chunk0, no_skip);
     if (c->nsplit_chunks)
       hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),
                          dim3(c->nsplit_chunks * (kChunk / kBlock)), dim3(kBlock), 0, s, T,
@@ -1358,19 +1540,45 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     XF_HIP(hipGetLastError());
     return XF_OK;
   }
-  if (src && src->n > 1)  // (its own instantiation: 87 registers instead of 58)
-    hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true, true>), dim3(c->nitems), dim3(kBlock), 0,
-                       s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
-                       c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
-                       src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0);
-  else if (src)
+  if (src && src->n > 1) {
+    // several workers: k_lr_grad_multi takes the unsplit chunks that fit one round of
+    // registers, the general loop the others (the slices of split chunks, chunks with more
+    // entries, more row windows or workers than its LDS tables hold)
+    bool multi = false;
+    if constexpr (MODE == 0) multi = !d_g && c->item_done && exp_knob() != 298;
+    if (multi) {
+      if constexpr (MODE == 0) {
+        const int full = dense_touch(c) ? 1 : 0;
+        if (exp_knob() == 297)
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512>), dim3(c->nitems), dim3(512), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+        else
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 256>), dim3(c->nitems), dim3(256), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+      }
+      hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s,
+                         T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                         c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
+                         src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
+                         c->chunk0, (const uint8_t *)c->item_done);
+    } else {  // (round 4's pass, kept for A/B: exp_knob 298)
+      hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true, true>), dim3(c->nitems), dim3(kBlock),
+                         0, s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
+                         c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
+                         src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
+                         c->chunk0, no_skip);
+    }
+  } else if (src) {
     hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true>), dim3(c->nitems), dim3(kBlock), 0, s, T,
                        c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                        c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                        src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
-                       c->chunk0);
-  else {
+                       c->chunk0, no_skip);
+  } else {
     // one source: the unsplit chunks go to k_lr_grad_dense (gradient + Push, no dense copy of
     // the gradients wanted, few windows), the general kernel keeps the split ones
     bool dense = false;
@@ -1379,7 +1587,9 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
       // and the slices of the split ones share one launch there; two launches one after the other
       // add their tails — Zipf 1.1: 118 us instead of 88)
       if (!d_g && c->nwin <= kDenseWin && c->nsplit_chunks == 0) {
-        int var = XF_GRAD_DENSE_VAR;
+        // whole-line stores (variant kDenseFullStore) where the minibatch touches most lines of
+        // the chunks it runs over, byte-masked stores of the touched rows where it does not
+        int var = dense_touch(c) ? XF_GRAD_DENSE_VAR : (XF_GRAD_DENSE_VAR & ~kDenseFullStore);
         const int knob = exp_knob();
         if (knob >= 300 && knob < 812) var = knob - 300;  // (experiments: tools/cells_knobs.py)
         dense = knob != 299;                               // 299: the general kernel alone
@@ -1398,15 +1608,16 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
             XF_DENSE(1);
             XF_DENSE(2);
             XF_DENSE(4);
+            XF_DENSE(128);
+            XF_DENSE(128 + 4);
+#ifdef XF_EXPERIMENTS  // timing experiments (some with WRONG results): never in a product build
             XF_DENSE(5);
             XF_DENSE(6);
-            XF_DENSE(8);        // timing experiments (wrong results)
+            XF_DENSE(8);
             XF_DENSE(16);
             XF_DENSE(32);
             XF_DENSE(32 + 64);
             XF_DENSE(32 + 8);
-            XF_DENSE(128);
-            XF_DENSE(128 + 4);
             XF_DENSE(256);
             XF_DENSE(256 + 128);
             XF_DENSE(256 + 1);
@@ -1414,8 +1625,10 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
             XF_DENSE(4 + 16);
             XF_DENSE(4 + 32);
             XF_DENSE(4 + 32 + 64);
+#endif
             default:
-              return xf::set_error(XF_EINVAL, "gradient kernel variant %d", var);
+              return xf::set_error(XF_EINVAL, "gradient kernel variant %d (the timing-only "
+                                   "variants need a library built with -DXF_EXPERIMENTS)", var);
           }
 #undef XF_DENSE
         }
@@ -1426,7 +1639,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                          T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                          c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched, 1u,
                          (const uint32_t *)nullptr, (const uint32_t *)nullptr, c->nsplit_chunks,
-                         (const uint32_t *)nullptr, c->chunk0);
+                         (const uint32_t *)nullptr, c->chunk0, no_skip);
   }
   if (c->nsplit_chunks)
     hipLaunchKernelGGL((k_lr_grad_split_finish<OPT, MODE>),

@@ -329,12 +329,15 @@ extern "C" int xf_group_create(xf_group **out, int rank, int world, const char *
       setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
       // A loopback rendezvous address stays on this host, and an explicit numeric address is
       // taken at its word; a NAME is not: it may resolve to a loopback alias on this host
-      // (127.0.1.1 in /etc/hosts) or to another interface than the peers reach, so rank 0
-      // then listens on every interface (the hello's magic word turns strays away).
+      // (127.0.1.1 in /etc/hosts) or to another interface than the peers reach, so an EXPLICIT
+      // rank 0 then listens on every interface (the hello's magic word turns strays away).
+      // Ranks handed out on arrival (rank < 0) always bind the resolved address: on a node that
+      // does not own it the bind fails, and that failure is what elects ONE root across nodes —
+      // a wildcard bind would succeed on every node and give each its own.
       sockaddr_in any = sa;
       const bool numeric = inet_pton(AF_INET, host.c_str(), &any.sin_addr) == 1;
       any.sin_addr = sa.sin_addr;
-      if (!numeric) any.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (!numeric && rank == 0) any.sin_addr.s_addr = htonl(INADDR_ANY);
       if (bind(fd, (sockaddr *)&any, sizeof(any)) == 0 && listen(fd, world + 8) == 0) {
         g->listen_fd = fd;
         root = true;

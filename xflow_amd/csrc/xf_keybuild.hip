@@ -1358,13 +1358,14 @@ struct KbDeferred {
   bool ksc = false, waited = false;
   uint32_t R = 0, NNZ = 0;
   uint64_t nbase = 0;
+  // the build's kernels and the copy of the summary are done: its OWN event (two host threads
+  // with a deferred build each must not wait on one another's record), on the device the build
+  // runs on
+  hipEvent_t ev = nullptr;
+  ~KbDeferred() {
+    if (ev && !device_poisoned()) (void)hipEventDestroy(ev);
+  }
 };
-
-static hipEvent_t kb_event() {
-  static hipEvent_t ev = nullptr;
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-  return ev;
-}
 
 // after the build's kernels and the copy of the summary have finished: the work items, the
 // key-sorted copy, and the second segment for the keys the tier does not hold
@@ -1402,7 +1403,7 @@ int cells_build_keyed_finish(KbDeferred *d, hipStream_t s, bool *more) {
     KbDeferred *d;
     ~Free() { delete d; }
   } guard{d};
-  XF_HIP(hipEventSynchronize(kb_event()));
+  XF_HIP(hipEventSynchronize(d->ev));
   return keyed_tail(*d, s, more);
 }
 
@@ -1564,8 +1565,9 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
     XF_HIP(hipGetLastError());
   }
-  if (defer && kb_event()) {  // the wait is the caller's (cells_build_keyed_finish)
-    XF_HIP(hipEventRecord(kb_event(), s));
+  if (defer && hipEventCreateWithFlags(&D->ev, hipEventDisableTiming) == hipSuccess) {
+    // the wait is the caller's (cells_build_keyed_finish)
+    XF_HIP(hipEventRecord(D->ev, s));
     guard.c = nullptr;
     *out = c;
     *defer = D.release();

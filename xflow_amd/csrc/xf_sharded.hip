@@ -160,11 +160,18 @@ struct xf_sbatch {
   size_t o_n = 0;                            // nonzeros received
   Dev<uint64_t> o_keys;                      // their keys (kept: re-resolved after a defrag)
   Dev<uint32_t> o_rowid;                     // their rows (window-major numbering)
-  Dev<uint32_t> d_win, d_rows;               // o_win, o_rows on the device
-  Dev<uint32_t> d_win1, d_rows1;             // {0, windows}, {all rows}: sum_then_step
-  Dev<uint32_t> d_winT, d_rowsT;             // measuring aid (XF_OWNER_TIMING_SOURCES, world 1)
+  // the small per-minibatch tables: one device allocation, one host copy kept beside it (the
+  // upload reads it asynchronously); the names below point into o_small
+  struct U32View {
+    uint32_t *p = nullptr;
+  };
+  Dev<uint32_t> o_small;
+  std::vector<uint32_t> o_small_host;
+  U32View d_win, d_rows;                     // o_win, o_rows on the device
+  U32View d_win1, d_rows1;                   // {0, windows}, {all rows}: sum_then_step
+  U32View d_winT, d_rowsT;                   // measuring aid (XF_OWNER_TIMING_SOURCES, world 1)
   uint32_t nT = 0;
-  Dev<uint32_t> d_wbase, d_wrows;            // per window: first row in the back-to-back
+  U32View d_wbase, d_wrows;                  // per window: first row in the back-to-back
                                              // layout of the workers' rows; rows it holds
   Dev<int32_t> d_labels;                     // this worker's labels
   xf_cells *ocells = nullptr;                // cells over the shard's state rows
@@ -193,6 +200,11 @@ struct xf_sharded {
   int parity_mode = XF_PARITY_EXACT_SUMS;  // (what xf_sharded_set_parity last set)
   uint64_t seen_upper = 0;     // world 1: host-side upper bound on the keys in the table
   Dev<double> partial;         // LR forward scratch
+  // the owner-compute compile's staging: the worker's nonzeros grouped by owner (sent from
+  // here), their rows, the partition's counts; pinned host memory for what the host reads back
+  Dev<uint64_t> stage_keys, stage_pairs;
+  Dev<uint32_t> stage_rows, stage_rowof, stage_cnt;
+  uint64_t *h_counts = nullptr;
   hipStream_t main = nullptr, side = nullptr;
   hipEvent_t ev_pulled = nullptr, ev_graded = nullptr, ev_applied = nullptr;
   bool have_applied = false, have_graded = false, have_pulled = false;
@@ -431,17 +443,15 @@ int flush_pending(xf_sharded *st) {
 
 
 // ------------------------------------------------------------------ XF_SCHEDULE_OWNER
-// the owner (xf_shard_of) of every nonzero's key, and its row
-__global__ void __launch_bounds__(kBlock)
-k_owner_of(const uint64_t *__restrict__ keys, size_t n, uint32_t world,
-           uint32_t *__restrict__ own) {
-  const uint64_t span = UINT64_MAX / world;
-  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-       j += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t q = keys[j] / span;
-    own[j] = q < world ? (uint32_t)q : world - 1;
-  }
-}
+// The worker's side of the compile: its nonzeros grouped by the OWNER of their key (xf_shard_of:
+// min(key / (UINT64_MAX / world), world - 1), ps-lite's default slicer), row-major order kept
+// within an owner.  Round 4 did it with a rocPRIM radix pass over (owner, position) pairs and a
+// gather of the keys through the permutation; the owner number has at most 8 bits and the list
+// is already in the order wanted inside every owner, so this is a partition: a histogram per
+// workgroup (k_own_hist), the workgroups' write positions from one scan (k_own_scan), and a
+// stable scatter (k_own_scatter) — 8 bytes of key + 4 of row read twice and written once per
+// nonzero, no sort, no permutation array, and the per-owner counts stay on the device until the
+// ONE host wait of the compile (they travel to the peers through the group's all-to-all).
 __global__ void __launch_bounds__(kBlock)
 k_rows_of_nnz(const uint32_t *__restrict__ rowptr, uint32_t R, uint32_t *__restrict__ row_of) {
   const uint32_t lane = threadIdx.x & 63;
@@ -449,36 +459,144 @@ k_rows_of_nnz(const uint32_t *__restrict__ rowptr, uint32_t R, uint32_t *__restr
   for (uint32_t r = blockIdx.x * (kBlock / 64) + threadIdx.x / 64; r < R; r += nw)
     for (uint32_t j = rowptr[r] + lane; j < rowptr[r + 1]; j += 64) row_of[j] = r;
 }
-__global__ void __launch_bounds__(kBlock)
-k_take_by_owner(const uint32_t *__restrict__ perm, const uint64_t *__restrict__ keys,
-                const uint32_t *__restrict__ row_of, size_t n, uint64_t *__restrict__ sk,
-                uint32_t *__restrict__ sr) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t j = perm[i];
-    sk[i] = keys[j];
-    sr[i] = row_of[j];
-  }
+
+constexpr int kOwn = 1024;           // threads of the partition workgroups
+constexpr uint32_t kOwnMax = 256;    // owners (compile_owner requires world <= 255)
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint64_t span, uint32_t world) {
+  const uint64_t q = key / span;
+  return q < world ? (uint32_t)q : world - 1;
 }
-// first[p] = first position of the owner-sorted list that belongs to owner >= p (p = 0..world)
-__global__ void k_owner_first(const uint32_t *__restrict__ own_sorted, uint32_t n, uint32_t world,
-                              uint32_t *__restrict__ first) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > world) return;
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (own_sorted[mid] < p) lo = mid + 1;
-    else
-      hi = mid;
+
+// wgcnt[w * world + o] = nonzeros of workgroup w's share [w * span_nnz, (w + 1) * span_nnz) whose
+// key belongs to owner o.  The lanes of a wavefront that hold the same owner count as one LDS
+// atomic (eight owners: 64 lanes on 8 addresses would serialise).
+__global__ void __launch_bounds__(kOwn)
+k_own_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t world, uint32_t span_nnz,
+           uint32_t *__restrict__ wgcnt) {
+  __shared__ uint32_t h[kOwnMax];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (tid < kOwnMax) h[tid] = 0;
+  __syncthreads();
+  const uint64_t span = UINT64_MAX / world;
+  const uint32_t e0 = blockIdx.x * span_nnz, e1 = min(e0 + span_nnz, n);
+  for (uint32_t j0 = e0; j0 < e1; j0 += kOwn) {
+    const uint32_t j = j0 + tid;
+    const bool ok = j < e1;
+    const uint32_t o = ok ? owner_of(keys[j], span, world) : 0xFFFFFFFFu;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {  // wave-uniform: one round per owner the wavefront holds
+      const int l = __ffsll((long long)todo) - 1;
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)o, l);
+      const unsigned long long m = __ballot(o == cur);
+      if ((int)lane == l) atomicAdd(&h[cur], (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
   }
-  first[p] = lo;
+  __syncthreads();
+  if (tid < world) wgcnt[(size_t)blockIdx.x * world + tid] = h[tid];
+}
+
+// One workgroup.  wgcnt[w * world + o] -> where workgroup w's nonzeros of owner o begin in the
+// owner-grouped list; first[o] = where owner o's begin (first[world] = n); pairs[o] = {nonzeros
+// for owner o, this worker's rows}: what owner o is told (one 16-byte element per peer).
+__global__ void __launch_bounds__(kOwnMax)
+k_own_scan(uint32_t *__restrict__ wgcnt, uint32_t nwg, uint32_t world, uint32_t R,
+           uint32_t *__restrict__ first, uint64_t *__restrict__ pairs) {
+  __shared__ uint32_t tot[kOwnMax + 1];
+  const uint32_t o = threadIdx.x;
+  uint32_t run = 0;
+  if (o < world)
+    for (uint32_t w = 0; w < nwg; ++w) {
+      const uint32_t x = wgcnt[(size_t)w * world + o];
+      wgcnt[(size_t)w * world + o] = run;
+      run += x;
+    }
+  tot[o] = o < world ? run : 0u;
+  __syncthreads();
+  if (o == 0) {
+    uint32_t a = 0;
+    for (uint32_t q = 0; q < world; ++q) {
+      const uint32_t x = tot[q];
+      tot[q] = a;
+      a += x;
+    }
+    tot[world] = a;
+  }
+  __syncthreads();
+  if (o < world) {
+    const uint32_t base = tot[o];
+    for (uint32_t w = 0; w < nwg; ++w) wgcnt[(size_t)w * world + o] += base;
+    pairs[2 * o] = run;
+    pairs[2 * o + 1] = R;
+  }
+  if (o <= world) first[o] = tot[o];
+}
+
+// The stable scatter: workgroup w walks its share in rounds of kOwn consecutive nonzeros.  A
+// nonzero's place = the workgroup's running position for its owner + the nonzeros of that owner
+// in the round's earlier wavefronts + those in the lower lanes of its own (ballots).
+__global__ void __launch_bounds__(kOwn)
+k_own_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ row_of, uint32_t n,
+              uint32_t world, uint32_t span_nnz, const uint32_t *__restrict__ wgbase,
+              uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_rows) {
+  constexpr int NW = kOwn / 64;
+  __shared__ uint32_t run[kOwnMax];
+  __shared__ uint32_t wcnt[NW][kOwnMax];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid < world) run[tid] = wgbase[(size_t)blockIdx.x * world + tid];
+  const uint64_t span = UINT64_MAX / world;
+  const uint32_t e0 = blockIdx.x * span_nnz, e1 = min(e0 + span_nnz, n);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint64_t nkey = 0;
+  uint32_t nrow = 0;
+  if (e0 + tid < e1) {
+    nkey = keys[e0 + tid];
+    nrow = row_of[e0 + tid];
+  }
+  for (uint32_t j0 = e0; j0 < e1; j0 += kOwn) {
+    const uint32_t j = j0 + tid;
+    const bool ok = j < e1;
+    const uint64_t key = nkey;
+    const uint32_t row = nrow;
+    if (j + kOwn < e1) {  // the next round's, on their way while this one is placed
+      nkey = keys[j + kOwn];
+      nrow = row_of[j + kOwn];
+    }
+    const uint32_t o = ok ? owner_of(key, span, world) : 0xFFFFFFFFu;
+    for (uint32_t q = lane; q < world; q += 64) wcnt[wave][q] = 0;  // (this wavefront's row)
+    unsigned long long todo = __ballot(ok);
+    uint32_t rank = 0;
+    while (todo) {  // wave-uniform
+      const int l = __ffsll((long long)todo) - 1;
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)o, l);
+      const unsigned long long m = __ballot(o == cur);
+      if (o == cur) rank = (uint32_t)__popcll(m & lt);
+      if ((int)lane == l) wcnt[wave][cur] = (uint32_t)__popcll(m);
+      todo &= ~m;
+    }
+    __syncthreads();
+    if (ok) {
+      uint32_t pos = run[o] + rank;
+      for (uint32_t w = 0; w < wave; ++w) pos += wcnt[w][o];
+      out_keys[pos] = key;
+      out_rows[pos] = row;
+    }
+    __syncthreads();
+    if (tid < world) {
+      uint32_t a = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += wcnt[w][tid];
+      run[tid] += a;
+    }
+    __syncthreads();
+  }
 }
 
 // received row numbers: worker q's nonzeros sit at [segoff[q], segoff[q+1]); + win[q] * W
 __global__ void __launch_bounds__(kBlock)
 k_rows_to_padded(uint32_t *__restrict__ rowid, size_t n, uint32_t nsrc,
-                 const uint64_t *__restrict__ segoff, const uint32_t *__restrict__ win,
+                 const uint32_t *__restrict__ segoff, const uint32_t *__restrict__ win,
                  uint32_t W) {
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
        j += (size_t)gridDim.x * blockDim.x) {
@@ -558,92 +676,79 @@ k_split_pairs(const float2 *__restrict__ in, uint32_t n, float *__restrict__ a,
   b[i] = q.y;
 }
 
-// (blocking: the small host arrays it is used for are locals of the caller)
-static int upload_u32(Dev<uint32_t> &d, const std::vector<uint32_t> &h, hipStream_t) {
-  XF_TRY(d.reserve(h.size()));
-  if (!h.empty()) XF_HIP(hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  return XF_OK;
-}
-
 // Compile for the owner-compute dataflow: the nonzeros of this worker's rows go to the owners
-// of their keys (once), with the row each belongs to.
-static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
-                         const uint64_t *keys, const int32_t *labels, size_t row_begin,
-                         size_t row_end) {
+// of their keys (once), with the row each belongs to.  Device-resident input (the raw keys in CSR
+// order, 32-bit row offsets, labels); ONE host wait — for the per-owner counts, which the ranks
+// tell each other through the group's all-to-all (16 bytes per peer: nonzeros for that owner,
+// rows of this worker) — and one copy of the small per-minibatch tables.  The input arrays may
+// be released when this returns.
+static int compile_owner_dev(xf_sharded *st, xf_sbatch *b, const uint64_t *d_keys,
+                             const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                             size_t NNZ) {
   const int W = st->world;
   XF_REQUIRE(W <= 255, "xf_sharded_compile: owner-compute dataflow with %d workers", W);
-  hipStream_t s = st->main;
-  const uint32_t R = (uint32_t)(row_end - row_begin);
-  const uint64_t base = rowptr[row_begin];
-  const size_t NNZ = (size_t)(rowptr[row_end] - base);
   XF_REQUIRE(NNZ < 0xFFFFFFFFull, "xf_sharded_compile: %zu nonzeros in one minibatch", NNZ);
+  hipStream_t s = st->main;
   b->oc = true;
   b->R = R;
   b->NNZ = (uint32_t)NNZ;
   b->U = 0;
-  // the nonzeros grouped by the owner of their key, row-major order kept within an owner (one
-  // stable radix pass on the owner number), on the device
-  std::vector<uint64_t> cnt(W, 0);
-  Dev<uint64_t> d_sk;
-  Dev<uint32_t> d_sr;
-  XF_TRY(d_sk.reserve(NNZ));
-  XF_TRY(d_sr.reserve(NNZ));
+  // the nonzeros grouped by the owner of their key, row-major order kept within an owner: a
+  // stable partition into the trainer's staging buffers (stream order protects them: the
+  // exchange of the previous compile has read them before this one's scatter writes)
+  const uint32_t span_nnz = (uint32_t)(((NNZ + 255) / 256 + kOwn - 1) / kOwn * kOwn);
+  const uint32_t nwg = NNZ ? (uint32_t)((NNZ + span_nnz - 1) / span_nnz) : 0u;
+  XF_TRY(st->stage_keys.reserve(NNZ));
+  XF_TRY(st->stage_rows.reserve(NNZ));
+  XF_TRY(st->stage_rowof.reserve(NNZ));
+  XF_TRY(st->stage_cnt.reserve((size_t)nwg * W + (size_t)W + 1));
+  XF_TRY(st->stage_pairs.reserve((size_t)4 * W));
+  if (!st->h_counts)
+    XF_HIP(hipHostMalloc((void **)&st->h_counts, ((size_t)W + 1) * 4 + (size_t)2 * W * 8 + 64));
+  uint32_t *h_first = (uint32_t *)((char *)st->h_counts + (size_t)2 * W * 8);
+  uint64_t *h_pairs = st->h_counts;
+  uint32_t *d_wgcnt = st->stage_cnt.p, *d_first = st->stage_cnt.p + (size_t)nwg * W;
+  uint64_t *d_psend = st->stage_pairs.p, *d_precv = st->stage_pairs.p + (size_t)2 * W;
   if (NNZ) {
-    xf::Scratch sc;
-    uint64_t *d_k = nullptr;
-    uint32_t *d_rp = nullptr, *d_row = nullptr, *d_own = nullptr, *d_own_s = nullptr,
-             *d_iota = nullptr, *d_perm = nullptr, *d_first = nullptr;
-    XF_TRY(sc.get(&d_k, NNZ));
-    XF_TRY(sc.get(&d_rp, (size_t)R + 1));
-    XF_TRY(sc.get(&d_row, NNZ));
-    XF_TRY(sc.get(&d_own, NNZ));
-    XF_TRY(sc.get(&d_own_s, NNZ));
-    XF_TRY(sc.get(&d_iota, NNZ));
-    XF_TRY(sc.get(&d_perm, NNZ));
-    XF_TRY(sc.get(&d_first, (size_t)W + 1));
-    std::vector<uint32_t> rp(R + 1);
-    for (uint32_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
-    XF_HIP(hipMemcpyAsync(d_k, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
-    XF_HIP(hipMemcpyAsync(d_rp, rp.data(), ((size_t)R + 1) * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_rows_of_nnz, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rp, R,
-                       d_row);
-    hipLaunchKernelGGL(k_owner_of, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_k, NNZ, (uint32_t)W,
-                       d_own);
-    hipLaunchKernelGGL(k_iota32, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_iota, NNZ);
-    int bits = 1;
-    while ((1 << bits) < W) ++bits;
-    size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_own, d_own_s, d_iota, d_perm, NNZ, 0, bits, s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, d_own, d_own_s, d_iota, d_perm, NNZ, 0, bits, s));
-    hipLaunchKernelGGL(k_take_by_owner, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, d_perm, d_k, d_row,
-                       NNZ, d_sk.p, d_sr.p);
-    hipLaunchKernelGGL(k_owner_first, dim3((W + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       d_own_s, (uint32_t)NNZ, (uint32_t)W, d_first);
-    XF_HIP(hipGetLastError());
-    std::vector<uint32_t> first(W + 1);
-    XF_HIP(hipMemcpyAsync(first.data(), d_first, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
-    XF_TRY(wait_stream(st, s));  // (also: rp and the scratch may go)
-    for (int p = 0; p < W; ++p) cnt[p] = first[p + 1] - first[p];
+    hipLaunchKernelGGL(k_rows_of_nnz, dim3(grid_for((size_t)R * 64)), dim3(kBlock), 0, s, d_rowptr,
+                       R, st->stage_rowof.p);
+    hipLaunchKernelGGL(k_own_hist, dim3(nwg), dim3(kOwn), 0, s, d_keys, (uint32_t)NNZ, (uint32_t)W,
+                       span_nnz, d_wgcnt);
   }
+  hipLaunchKernelGGL(k_own_scan, dim3(1), dim3(kOwnMax), 0, s, d_wgcnt, nwg, (uint32_t)W, R,
+                     d_first, d_psend);
+  if (NNZ)
+    hipLaunchKernelGGL(k_own_scatter, dim3(nwg), dim3(kOwn), 0, s, d_keys,
+                       (const uint32_t *)st->stage_rowof.p, (uint32_t)NNZ, (uint32_t)W, span_nnz,
+                       (const uint32_t *)d_wgcnt, st->stage_keys.p, st->stage_rows.p);
+  XF_HIP(hipGetLastError());
+  XF_TRY(b->d_labels.reserve(R));
+  if (R)
+    XF_HIP(hipMemcpyAsync(b->d_labels.p, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
   // who sends how much to whom, and how many rows every worker has
-  std::vector<uint64_t> all((size_t)W * W), rows_all(W);
-  XF_TRY(xf_group_allgather_host(st->g, cnt.data(), (size_t)W * 8, all.data()));
-  const uint64_t myR = R;
-  XF_TRY(xf_group_allgather_host(st->g, &myR, 8, rows_all.data()));
-  std::vector<uint64_t> recv(W), segoff(W + 1, 0);
+  const std::vector<uint64_t> ones(W, 1);
+  XF_TRY(a2a(st, d_psend, ones, d_precv, ones, 16, s));
+  XF_HIP(hipMemcpyAsync(h_first, d_first, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(h_pairs, d_precv, (size_t)2 * W * 8, hipMemcpyDeviceToHost, s));
+  XF_TRY(wait_stream(st, s));  // the compile's one wait (the input arrays are not read after it)
+  std::vector<uint64_t> cnt(W), recv(W), rows_all(W);
+  std::vector<uint32_t> segoff(W + 1, 0);
+  uint64_t o_n = 0;
   for (int p = 0; p < W; ++p) {
-    recv[p] = all[(size_t)p * W + st->rank];
-    segoff[p + 1] = segoff[p] + recv[p];
+    cnt[p] = h_first[p + 1] - h_first[p];
+    recv[p] = h_pairs[2 * p];
+    rows_all[p] = h_pairs[2 * p + 1];
+    o_n += recv[p];
+    XF_REQUIRE(o_n < 0xFFFFFFFFull, "xf_sharded_compile: %llu nonzeros for one owner",
+               (unsigned long long)o_n);
+    segoff[p + 1] = (uint32_t)o_n;
   }
-  b->o_n = (size_t)segoff[W];
+  b->o_n = (size_t)o_n;
   b->n_recv = b->o_n;
-  XF_REQUIRE(b->o_n < 0xFFFFFFFFull, "xf_sharded_compile: %zu nonzeros for one owner", b->o_n);
   XF_TRY(b->o_keys.reserve(b->o_n));
   XF_TRY(b->o_rowid.reserve(b->o_n));
-  XF_TRY(a2a(st, d_sk.p, cnt, b->o_keys.p, recv, 8, s));
-  XF_TRY(a2a(st, d_sr.p, cnt, b->o_rowid.p, recv, 4, s));
+  XF_TRY(a2a(st, st->stage_keys.p, cnt, b->o_keys.p, recv, 8, s));
+  XF_TRY(a2a(st, st->stage_rows.p, cnt, b->o_rowid.p, recv, 4, s));
   // windows: every worker's rows fill whole windows of one common size
   uint64_t maxR = 1;
   for (int p = 0; p < W; ++p) maxR = std::max<uint64_t>(maxR, rows_all[p]);
@@ -674,20 +779,27 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
   }
   XF_REQUIRE((uint64_t)b->o_win[W] * b->oW < 0x7FFFFFFFull, "xf_sharded_compile: too many rows");
   b->o_rpad = std::max<uint32_t>(1, b->o_win[W]) * b->oW;
-  XF_TRY(upload_u32(b->d_win, b->o_win, s));
-  XF_TRY(upload_u32(b->d_rows, b->o_rows, s));
-  {  // all workers as ONE source (XF_UPDATE_SUM_THEN_STEP)
-    const std::vector<uint32_t> win1{0u, b->o_win[W]}, rows1{rowoff[W]};
-    b->o_rows_all = rowoff[W];
-    XF_TRY(upload_u32(b->d_win1, win1, s));
-    XF_TRY(upload_u32(b->d_rows1, rows1, s));
-  }
+  b->o_rows_all = rowoff[W];
+  b->o_total = rowoff[W];
+  // the small per-minibatch tables: one host array (kept with the minibatch), one copy
+  std::vector<uint32_t> &H = b->o_small_host;
+  H.clear();
+  auto put = [&](const std::vector<uint32_t> &v) {
+    const size_t at = H.size();
+    H.insert(H.end(), v.begin(), v.end());
+    return at;
+  };
+  const size_t at_win = put(b->o_win), at_rows = put(b->o_rows);
+  // all workers as ONE source (XF_UPDATE_SUM_THEN_STEP)
+  const size_t at_win1 = put({0u, b->o_win[W]}), at_rows1 = put({rowoff[W]});
+  size_t at_winT = 0, at_rowsT = 0;
+  b->nT = 0;
   if (const char *e = getenv("XF_OWNER_TIMING_SOURCES")) {
     // MEASURING AID, one rank only: the gradient + Push pass as an owner of n workers runs it —
     // this rank's windows dealt out to n pretended workers, each its own optimizer step.  The
     // arithmetic is not that of one LRWorker::update any more: for timing the pass on one GPU.
-    const uint32_t n = (uint32_t)atoi(e), nw = b->o_win[W];
-    if (W == 1 && n > 1 && nw >= n) {
+    const uint32_t n = (uint32_t)atoi(e), nwt = b->o_win[W];
+    if (W == 1 && n > 1 && nwt >= n) {
       static bool said = false;
       if (!said) {
         said = true;
@@ -696,15 +808,16 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
                 "the results are NOT those of LRWorker::update\n", n, n, n);
       }
       std::vector<uint32_t> winT(n + 1), rowsT(n);
-      for (uint32_t q = 0; q <= n; ++q) winT[q] = (uint32_t)((uint64_t)nw * q / n);
+      for (uint32_t q = 0; q <= n; ++q) winT[q] = (uint32_t)((uint64_t)nwt * q / n);
       for (uint32_t q = 0; q < n; ++q)
         rowsT[q] = std::min<uint32_t>(rowoff[W], winT[q + 1] * b->oW) -
                    std::min<uint32_t>(rowoff[W], winT[q] * b->oW);
-      XF_TRY(upload_u32(b->d_winT, winT, s));
-      XF_TRY(upload_u32(b->d_rowsT, rowsT, s));
+      at_winT = put(winT);
+      at_rowsT = put(rowsT);
       b->nT = n;
     }
   }
+  size_t at_wbase, at_wrows;
   {
     std::vector<uint32_t> wbase(std::max<uint32_t>(1, b->o_win[W]), 0), wrows(wbase.size(), 0);
     for (int p = 0; p < W; ++p)
@@ -713,24 +826,33 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
         wbase[v] = rowoff[p] + first;
         wrows[v] = std::min<uint32_t>(b->oW, b->o_rows[p] - first);
       }
-    XF_TRY(upload_u32(b->d_wbase, wbase, s));
-    XF_TRY(upload_u32(b->d_wrows, wrows, s));
+    at_wbase = put(wbase);
+    at_wrows = put(wrows);
   }
-  b->o_total = rowoff[W];
+  const size_t at_seg = put(segoff), at_off = put(rowoff);
+  XF_TRY(b->o_small.reserve(H.size()));
+  XF_HIP(hipMemcpyAsync(b->o_small.p, H.data(), H.size() * 4, hipMemcpyHostToDevice, s));
+  uint32_t *D = b->o_small.p;
+  b->d_win.p = D + at_win;
+  b->d_rows.p = D + at_rows;
+  b->d_win1.p = D + at_win1;
+  b->d_rows1.p = D + at_rows1;
+  b->d_winT.p = b->nT ? D + at_winT : nullptr;
+  b->d_rowsT.p = b->nT ? D + at_rowsT : nullptr;
+  b->d_wbase.p = D + at_wbase;
+  b->d_wrows.p = D + at_wrows;
+  const uint32_t *d_seg = D + at_seg, *d_off = D + at_off;
   if (st->cfg.model == 1) {
     // FM: the received nonzeros become one minibatch with a key list (the owner's two tables
     // resolve it), rows numbered worker after worker — they arrive in that order
     if (b->o_n) {
-      Dev<uint64_t> d_seg;
-      Dev<uint32_t> d_off, d_rp;
+      Dev<uint32_t> d_rp;
       Dev<int32_t> d_lab;
-      XF_TRY(d_seg.reserve(W + 1));
       XF_TRY(d_rp.reserve((size_t)b->o_total + 1));
       XF_TRY(d_lab.reserve(b->o_total));
-      XF_HIP(hipMemcpy(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice));
-      XF_TRY(upload_u32(d_off, rowoff, s));
+      const uint32_t one = 1u;
       hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s,
-                         b->o_rowid.p, b->o_n, (uint32_t)W, d_seg.p, d_off.p, 1u);
+                         b->o_rowid.p, b->o_n, (uint32_t)W, d_seg, d_off, one);
       hipLaunchKernelGGL(k_rowptr_of_sorted_rows, dim3(grid_for(b->o_n + 1)), dim3(kBlock), 0, s,
                          b->o_rowid.p, (uint32_t)b->o_n, b->o_total, d_rp.p);
       XF_HIP(hipGetLastError());
@@ -745,20 +867,36 @@ static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
       XF_TRY(xf::table_ensure_room(st->tv, b->U));
     }
   } else if (b->o_n) {
-    Dev<uint64_t> d_seg;
-    XF_TRY(d_seg.reserve(W + 1));
-    XF_HIP(hipMemcpy(d_seg.p, segoff.data(), ((size_t)W + 1) * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_rows_to_padded, dim3(grid_for(b->o_n)), dim3(kBlock), 0, s, b->o_rowid.p,
-                       b->o_n, (uint32_t)W, d_seg.p, b->d_win.p, b->oW);
+                       b->o_n, (uint32_t)W, d_seg, (const uint32_t *)b->d_win.p, b->oW);
     XF_HIP(hipGetLastError());
-    XF_TRY(wait_stream(st, s));  // d_seg goes out of scope
   }
-  XF_TRY(b->d_labels.reserve(R));
-  if (R)
-    XF_HIP(hipMemcpyAsync(b->d_labels.p, labels + row_begin, (size_t)R * 4, hipMemcpyHostToDevice,
-                          s));
-  XF_TRY(wait_stream(st, s));  // the host vectors above
   return XF_OK;
+}
+
+// host-array front end (the reader's block arrays and a row slice): upload, then the above
+static int compile_owner(xf_sharded *st, xf_sbatch *b, const uint64_t *rowptr,
+                         const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                         size_t row_end) {
+  hipStream_t s = st->main;
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  XF_REQUIRE(R < 0xFFFFFFFFull && NNZ < 0xFFFFFFFFull, "xf_sharded_compile: minibatch too large");
+  std::vector<uint32_t> rp(R + 1);
+  for (size_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+  xf::Scratch sc;
+  uint64_t *d_k = nullptr;
+  uint32_t *d_rp = nullptr;
+  int32_t *d_lab = nullptr;
+  XF_TRY(sc.get(&d_k, NNZ));
+  XF_TRY(sc.get(&d_rp, R + 1));
+  XF_TRY(sc.get(&d_lab, R));
+  if (NNZ) XF_HIP(hipMemcpyAsync(d_k, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_rp, rp.data(), (R + 1) * 4, hipMemcpyHostToDevice, s));
+  if (R) XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
+  // (its wait is also the wait for these uploads: `rp` and the scratch may go when it returns)
+  return compile_owner_dev(st, b, d_k, d_rp, d_lab, (uint32_t)R, NNZ);
 }
 
 // the cells of the received nonzeros against the shard's current row numbering (keys resolved —
@@ -1056,6 +1194,7 @@ extern "C" int xf_sharded_destroy(xf_sharded *st) {
   if (!st) return XF_OK;
   if (st->poisoned) return XF_OK;  // stuck work on its streams: everything it owns is leaked
   (void)hipDeviceSynchronize();
+  if (st->h_counts) (void)hipHostFree(st->h_counts);
   if (st->ws) xf_workspace_destroy(st->ws);
   if (st->tw) xf_table_destroy(st->tw);
   if (st->tv) xf_table_destroy(st->tv);
@@ -1105,75 +1244,16 @@ extern "C" int xf_sbatch_dims(const xf_sbatch *b, uint32_t *R, uint32_t *NNZ, ui
   return XF_OK;
 }
 
-// Compile a minibatch: the key build (lr_worker.cc:146-166) and the static part of the
-// exchange.  COLLECTIVE: every rank of the group calls it, in the same order.  Host arrays
-// (the reader's block arrays and a row slice).  keep != 0: the batch will be replayed.
-extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
-                                  const uint64_t *keys, const int32_t *labels, size_t row_begin,
-                                  size_t row_end, int keep) {
-  XF_REQUIRE(st && out && rowptr && labels && row_end >= row_begin,
-             "xf_sharded_compile: bad argument");
-  XF_ALIVE(st);
-  xf_sbatch *b = new xf_sbatch;
-  struct Guard {
-    xf_sbatch *b;
-    ~Guard() {
-      if (b) xf_sbatch_free(b);
-    }
-  } guard{b};
+// the static part of the weight / gradient exchange of a minibatch with a key list (b->b):
+// contiguous owner ranges of the sorted unique keys (ps-lite's slicer), the keys to their
+// owners — once — and the owner's merged walking order
+static int compile_exchange_tail(xf_sharded *st, xf_sbatch *b, int keep) {
   hipStream_t s = st->main;
-  b->owner = st;
-  if (st->fused) {  // one shard: the table is local
-    if (st->cfg.host_key_build)
-      XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
-    else if (st->cfg.model == 0)
-      XF_TRY(xf_batch_compile_local(&b->b, st->tw, rowptr, keys, labels, row_begin, row_end,
-                                    keep, s));
-    else if (st->tv && st->parity_mode == XF_PARITY_EXACT_SUMS)
-      // FM: against the tables' settled tiers when every key sits there (no sort; otherwise
-      // this is xf_batch_compile_gpu)
-      XF_TRY(xf_batch_compile_fm(&b->b, st->tw, st->tv, rowptr, keys, labels, row_begin, row_end,
-                                 s, nullptr));
-    else
-      XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
-    XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
-    // batches with a key list insert at step time (the Pull): make room now.  A host-side
-    // upper bound on the key count keeps the exact (synchronising) check rare.
-    if (b->U) {
-      uint64_t cap = 0;
-      XF_TRY(xf_table_capacity(st->tw, &cap));
-      if ((st->seen_upper + b->U) * 10 > cap * 6) {
-        XF_TRY(xf::table_ensure_room(st->tw, b->U));
-        if (st->tv) XF_TRY(xf::table_ensure_room(st->tv, b->U));
-        uint64_t n = 0;
-        XF_TRY(xf_table_size(st->tw, &n));
-        st->seen_upper = n;
-      }
-      st->seen_upper += b->U;
-    }
-    guard.b = nullptr;
-    *out = b;
-    return XF_OK;
-  }
-  if (owner_dataflow(st->cfg.schedule)) {
-    b->oc_keep = keep != 0;
-    XF_TRY(compile_owner(st, b, rowptr, keys, labels, row_begin, row_end));
-    guard.b = nullptr;
-    *out = b;
-    return XF_OK;
-  }
-  if (st->cfg.host_key_build) {
-    XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
-    XF_TRY(xf_batch_upload(b->b, s));
-  } else {
-    XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
-  }
   XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
   const xf_dev_batch &v = b->b->view;
   if (st->cfg.model == 0)  // the LR kernels stream cells over the batch's unique-key index
     XF_TRY(xf::cells_build(&b->cells, v.uidx, nullptr, v.rowptr, b->R, b->NNZ, b->U,
                            xf::kCellsUidx, keep != 0, s));
-  // contiguous owner ranges of the sorted unique keys (ps-lite's slicer)
   const int W = st->world;
   std::vector<uint32_t> split(W + 1);
   {
@@ -1217,6 +1297,120 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     XF_HIP(rocprim::radix_sort_pairs(tmp, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
                                      b->n_recv, 0, 64, s));
     XF_TRY(wait_stream(st, s));
+  }
+  return XF_OK;
+}
+
+// batches with a key list insert at step time (the Pull): make room now.  A host-side upper
+// bound on the key count keeps the exact (synchronising) check rare.
+static int fused_room(xf_sharded *st, xf_sbatch *b) {
+  XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
+  if (b->U) {
+    uint64_t cap = 0;
+    XF_TRY(xf_table_capacity(st->tw, &cap));
+    if ((st->seen_upper + b->U) * 10 > cap * 6) {
+      XF_TRY(xf::table_ensure_room(st->tw, b->U));
+      if (st->tv) XF_TRY(xf::table_ensure_room(st->tv, b->U));
+      uint64_t n = 0;
+      XF_TRY(xf_table_size(st->tw, &n));
+      st->seen_upper = n;
+    }
+    st->seen_upper += b->U;
+  }
+  return XF_OK;
+}
+
+// Compile a minibatch: the key build (lr_worker.cc:146-166) and the static part of the
+// exchange.  COLLECTIVE: every rank of the group calls it, in the same order.  Host arrays
+// (the reader's block arrays and a row slice).  keep != 0: the batch will be replayed.
+extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_t *rowptr,
+                                  const uint64_t *keys, const int32_t *labels, size_t row_begin,
+                                  size_t row_end, int keep) {
+  XF_REQUIRE(st && out && rowptr && labels && row_end >= row_begin,
+             "xf_sharded_compile: bad argument");
+  XF_ALIVE(st);
+  xf_sbatch *b = new xf_sbatch;
+  struct Guard {
+    xf_sbatch *b;
+    ~Guard() {
+      if (b) xf_sbatch_free(b);
+    }
+  } guard{b};
+  hipStream_t s = st->main;
+  b->owner = st;
+  if (st->fused) {  // one shard: the table is local
+    if (st->cfg.host_key_build)
+      XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
+    else if (st->cfg.model == 0)
+      XF_TRY(xf_batch_compile_local(&b->b, st->tw, rowptr, keys, labels, row_begin, row_end,
+                                    keep, s));
+    else if (st->tv && st->parity_mode == XF_PARITY_EXACT_SUMS)
+      // FM: against the tables' settled tiers when every key sits there (no sort; otherwise
+      // this is xf_batch_compile_gpu)
+      XF_TRY(xf_batch_compile_fm(&b->b, st->tw, st->tv, rowptr, keys, labels, row_begin, row_end,
+                                 s, nullptr));
+    else
+      XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
+    XF_TRY(fused_room(st, b));
+    guard.b = nullptr;
+    *out = b;
+    return XF_OK;
+  }
+  if (owner_dataflow(st->cfg.schedule)) {
+    b->oc_keep = keep != 0;
+    XF_TRY(compile_owner(st, b, rowptr, keys, labels, row_begin, row_end));
+    guard.b = nullptr;
+    *out = b;
+    return XF_OK;
+  }
+  if (st->cfg.host_key_build) {
+    XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
+    XF_TRY(xf_batch_upload(b->b, s));
+  } else {
+    XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
+  }
+  XF_TRY(compile_exchange_tail(st, b, keep));
+  guard.b = nullptr;
+  *out = b;
+  return XF_OK;
+}
+
+// The same from device-resident arrays (raw keys in CSR order, 32-bit row offsets, labels): what
+// a reader that parses straight into HBM, or a caller that keeps its blocks there, hands over.
+// The arrays may be released when this returns.  COLLECTIVE.
+extern "C" int xf_sharded_compile_dev(xf_sharded *st, xf_sbatch **out, const uint64_t *d_keys,
+                                      const uint32_t *d_rowptr, const int32_t *d_labels,
+                                      uint32_t R, uint32_t NNZ, int keep) {
+  XF_REQUIRE(st && out && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
+             "xf_sharded_compile_dev: null argument");
+  XF_ALIVE(st);
+  XF_REQUIRE(!st->cfg.host_key_build, "xf_sharded_compile_dev: the trainer builds its keys on "
+             "the host (host_key_build): hand it host arrays");
+  xf_sbatch *b = new xf_sbatch;
+  struct Guard {
+    xf_sbatch *b;
+    ~Guard() {
+      if (b) xf_sbatch_free(b);
+    }
+  } guard{b};
+  hipStream_t s = st->main;
+  b->owner = st;
+  if (st->fused) {
+    if (st->cfg.model == 0)
+      XF_TRY(xf_batch_compile_local_dev(&b->b, st->tw, d_keys, d_rowptr, d_labels, R, NNZ, keep,
+                                        s));
+    else if (st->tv && st->parity_mode == XF_PARITY_EXACT_SUMS)
+      XF_TRY(xf_batch_compile_fm_dev(&b->b, st->tw, st->tv, d_keys, d_rowptr, d_labels, R, NNZ, s,
+                                     nullptr));
+    else
+      XF_TRY(xf_batch_compile_dev(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s));
+    XF_TRY(fused_room(st, b));
+  } else if (owner_dataflow(st->cfg.schedule)) {
+    b->oc_keep = keep != 0;
+    XF_TRY(compile_owner_dev(st, b, d_keys, d_rowptr, d_labels, R, NNZ));
+  } else {
+    XF_TRY(xf_batch_compile_dev(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s));
+    XF_TRY(compile_exchange_tail(st, b, keep));
   }
   guard.b = nullptr;
   *out = b;
