@@ -437,8 +437,11 @@ int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape);
  * With a group of one rank (or g == NULL) it is the fused single-shard step. */
 #define XF_SCHEDULE_SEQUENTIAL 0 /* Pull, compute, Push of step t before Pull(t+1) */
 #define XF_SCHEDULE_STALE1 1     /* Push(t) overlaps Pull/forward/gradient of t+1 (one step stale) */
-/* LR, and FM with XF_UPDATE_SUM_THEN_STEP (three fp64 row sums per row instead of one; (loss,
- * v_sum) back).  Owner-compute dataflow: a minibatch's NONZEROS go to the key owners once, when it is
+/* LR and FM (FM: three fp64 row sums per row instead of one; (loss, v_sum) back; with
+ * XF_UPDATE_RANK_ORDERED the owner keeps one minibatch per worker and forms every worker's
+ * gradient from the rows that worker's Pull returned, with XF_UPDATE_SUM_THEN_STEP it runs one
+ * fused gradient + Push pass over all workers' rows).
+ * Owner-compute dataflow: a minibatch's NONZEROS go to the key owners once, when it is
  * compiled; a step then runs the table-resident forward and gradient + Push at the owners and
  * exchanges only row-level scalars (fp64 partial row sums to the rows' workers, their losses
  * back) instead of a weight and a gradient per key.  Same results as XF_SCHEDULE_SEQUENTIAL

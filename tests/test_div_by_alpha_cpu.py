@@ -55,13 +55,21 @@ int main(int argc, char **argv) {
 """
 
 
+def _compile(tmp_path, src, name):
+    c = tmp_path / (name + ".c")
+    c.write_text(src)
+    exe = tmp_path / name
+    r = subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", str(c), "-o", str(exe),
+                        "-lm"], capture_output=True, text=True)
+    if r.returncode != 0:     # (no libgomp on this machine, say: nothing to check with)
+        pytest.skip("cannot build the checker: " + r.stderr[-300:])
+    return exe
+
+
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
 def test_double_product_with_the_reciprocal_is_the_fp32_quotient_for_every_float(tmp_path):
-    c = tmp_path / "t.c"
-    c.write_text(SRC)
-    exe = tmp_path / "t"
-    subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", str(c), "-o", str(exe), "-lm"],
-                   check=True)
+    """2 x 10^10 divisions: minutes on a machine with few cores (the time limit is the test's own)"""
+    exe = _compile(tmp_path, SRC, "t")
     divisors = ["0.05", "10", "50000", "16667", "16777215"]
     out = subprocess.run([str(exe)] + divisors, capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, OMP_NUM_THREADS="8"))
@@ -70,3 +78,48 @@ def test_double_product_with_the_reciprocal_is_the_fp32_quotient_for_every_float
     assert len(lines) == len(divisors) and all(": 0 (" in ln for ln in lines), out.stdout
     # the guard is there for a reason: the bare product mis-rounds subnormal quotients of 50000
     assert not lines[2].endswith("(unguarded 0)"), out.stdout
+    # ... and the reference's alpha is a divisor that does not need it: what the table's own
+    # check on the GPU (xf_table.hip: div_exact_for) finds for it, every x, before it lets the
+    # step drop the guard
+    assert lines[0].endswith("(unguarded 0)"), out.stdout
+
+
+RANDOM_SRC = SRC.split("int main")[0] + r"""
+static uint64_t s = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); }
+int main(void) {   /* alpha is the user's to set: random divisors, random and subnormal-range x */
+  unsigned long long bad = 0;
+  for (int di = 0; di < 20000; ++di) {
+    uint32_t ud = rnd() & 0x7FFFFFFFu;
+    float d;
+    memcpy(&d, &ud, 4);
+    if (!isfinite(d) || d == 0.0f) continue;
+    const double inv = 1.0 / (double)d;
+    for (int xi = 0; xi < 2000; ++xi) {
+      uint32_t ux = rnd();
+      if (xi & 1) ux = (ux & 0x80FFFFFFu) | ((rnd() % 40) << 23);   /* tiny x: subnormal quotients */
+      float x;
+      memcpy(&x, &ux, 4);
+      if (!isfinite(x)) continue;
+      volatile float q1 = x / d;
+      float t = q1, q2 = div_by_const(x, d, inv);
+      uint32_t a, b;
+      memcpy(&a, &t, 4);
+      memcpy(&b, &q2, 4);
+      if (isnan(t) && isnan(q2)) continue;
+      bad += a != b;
+    }
+  }
+  printf("%llu\n", bad);
+  return bad != 0;
+}
+"""
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_guarded_product_is_the_quotient_for_random_divisors(tmp_path):
+    """the general claim behind div_by_const (alpha is user-settable): 4 x 10^7 random (x, d)
+    pairs, half of them with x in the range whose quotients are subnormal or next to it"""
+    exe = _compile(tmp_path, RANDOM_SRC, "r")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "0", out.stdout + out.stderr

@@ -311,10 +311,22 @@ def test_fm_on_the_owner_compute_dataflow(tmp_path, world, optimizer, k, data):
             same(parts[r]["loss"], ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))[0])
 
 
-def test_fm_on_the_owner_compute_dataflow_needs_sum_then_step():
+@pytest.mark.parametrize("world,optimizer", [(2, "ftrl"), (3, "sgd"), (3, "ftrl")])
+def test_fm_on_the_owner_compute_dataflow_rank_ordered(tmp_path, world, optimizer):
+    """FM with the reference's update rule (XF_UPDATE_RANK_ORDERED: every worker's Push its own
+    optimizer step, fm_worker.cc:226-242 + server.h:24-29) on the owner-compute dataflow: the
+    owner keeps one minibatch per worker, every worker's gradient comes from what its Pull
+    returned (all Pulls before all Pushes), the Pushes land worker after worker — the tables and
+    a held-out forward of the sequential schedule of the weight / gradient exchange and of the
+    oracle run of that rule, bit for bit (4 steps, a defrag in between)."""
+    _run(world, capi.TRANSPORT_HOST, "fm", optimizer, "owner", tmp_path)
+    _check_against_oracle(world, "fm", optimizer, "sequential", tmp_path)
+
+
+def test_fm_overlapped_owner_schedule_is_refused():
     g = capi.Group(0, 1, "127.0.0.1", free_port(), capi.TRANSPORT_HOST, device=0)
-    with pytest.raises(capi.XFError, match="sum_then_step"):
-        capi.Sharded(g, model="fm", optimizer="ftrl", k=4, schedule="owner")
+    with pytest.raises(capi.XFError, match="owner_stale1 is the LR step"):
+        capi.Sharded(g, model="fm", optimizer="ftrl", k=4, schedule="owner_stale1")
     g.close()
 
 
@@ -550,7 +562,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
     after a defrag: the same table, bit for bit.  (That the steps are the reference's: the
     world-2 / 3 / 8 tests against the oracle, which run the same kernel.)"""
     ctx = mp.get_context("spawn")
-    for knob in (298, 0, 297):
+    for knob in (298, 0, 297, 296):
         q = ctx.Queue()
         p = ctx.Process(target=_pretend_rank, args=(free_port(), knob, str(tmp_path), q))
         p.start()
@@ -559,7 +571,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
         assert not err, err
     ref = np.load(str(tmp_path / "pretend_298.npz"))
     assert len(ref["k"]) > 100000 and np.any(ref["w"] != 0)
-    for knob in (0, 297):
+    for knob in (0, 297, 296):
         got = np.load(str(tmp_path / ("pretend_%d.npz" % knob)))
         for f in ("k", "w", "n", "z"):
             same(got[f], ref[f])

@@ -1549,13 +1549,21 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     if (multi) {
       if constexpr (MODE == 0) {
         const int full = dense_touch(c) ? 1 : 0;
-        if (exp_knob() == 297)
-          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512>), dim3(c->nitems), dim3(512), 0, s, T,
+        // 512 threads per chunk (four entries per lane, 61 registers, 24 wavefronts per CU at
+        // the three workgroups its LDS allows): 164 us at the N = 8 shard shape where 256 threads
+        // (97 registers, 12 wavefronts) take 193 — exp_knob 297 runs the latter
+        if (exp_knob() == 296)  // (experiment: 1024 threads, two workgroups = 32 wavefronts per CU)
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 1024>), dim3(c->nitems), dim3(1024), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+        else if (exp_knob() == 297)
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 256>), dim3(c->nitems), dim3(256), 0, s, T,
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
         else
-          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 256>), dim3(c->nitems), dim3(256), 0, s, T,
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512>), dim3(c->nitems), dim3(512), 0, s, T,
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);

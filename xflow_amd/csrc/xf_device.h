@@ -121,24 +121,33 @@ __device__ __forceinline__ float hashnorm(uint64_t seed, uint64_t key, uint32_t 
 // midpoints exist (x = 25000 * 2^-149, d = 50000; the bare product differs at 1308 values of x for
 // that d, all with subnormal quotients) — the division itself is done (a branch no wavefront
 // takes in practice; x == 0 stays on the fast path: +-0 either way).  Checked on the host for
-// all 2^32 values of x at a dozen divisors (tests/test_div_by_alpha_cpu.py), on the GPU by the
-// bit-exact parity tests.
-__device__ __forceinline__ float div_by_const(float x, float d, double inv_d) {
+// all 2^32 values of x at five divisors and for random (x, d) pairs
+// (tests/test_div_by_alpha_cpu.py), on the GPU by the bit-exact parity tests.
+//
+// `exact` (round 5): the table has checked its alpha on the GPU — every one of the 2^32 values of
+// x, the bare product against the division, when the hyper-parameters were set (xf_table.hip:
+// div_exact_for) — and found no difference: the guard's two compares and its branch go too.
+// TableDev::inv_alpha carries the verdict in its sign (negative: exact).
+__device__ __forceinline__ float div_by_const(float x, float d, double inv_d, bool exact = false) {
 #pragma clang fp contract(off)
   const float q = (float)((double)x * inv_d);
-  if (fabsf(q) >= 0x1p-125f || x == 0.0f) return q;
+  if (exact || fabsf(q) >= 0x1p-125f || x == 0.0f) return q;
   return x / d;
 }
 
-// `inv_alpha` = 1.0 / (double)alpha (TableDev::inv_alpha, set on the host with the
-// hyper-parameters): the reference divides by alpha twice per step (ftrl.h:63,70)
+// `inv_alpha` = +-1.0 / (double)alpha (TableDev::inv_alpha, set on the host with the
+// hyper-parameters; its sign: see div_by_const): the reference divides by alpha twice per step
+// (ftrl.h:63,70)
 __device__ __forceinline__ void ftrl_step(float alpha, double inv_alpha, float beta, float lambda1,
                                           float lambda2, float g, float &w, float &n,
                                           float &z) {
 #pragma clang fp contract(off)
+  const bool exact = __double2hiint(inv_alpha) < 0;  // (scalar: a kernel argument's sign bit)
+  const double ia = __hiloint2double(__double2hiint(inv_alpha) & 0x7FFFFFFF,
+                                     __double2loint(inv_alpha));
   const float old_n = n;
   const float nn = old_n + g * g;
-  z = z + (g - div_by_const(sqrtf(nn) - sqrtf(old_n), alpha, inv_alpha) * w);
+  z = z + (g - div_by_const(sqrtf(nn) - sqrtf(old_n), alpha, ia, exact) * w);
   n = nn;
   if (fabsf(z) <= lambda1) {
     w = 0.0f;
@@ -146,7 +155,7 @@ __device__ __forceinline__ void ftrl_step(float alpha, double inv_alpha, float b
     float tmpr = 0.0f;
     if (z > 0.0f) tmpr = z - lambda1;
     if (z < 0.0f) tmpr = z + lambda1;
-    const float tmpl = -1.0f * (div_by_const(beta + sqrtf(nn), alpha, inv_alpha) + lambda2);
+    const float tmpl = -1.0f * (div_by_const(beta + sqrtf(nn), alpha, ia, exact) + lambda2);
     w = tmpr / tmpl;
   }
 }

@@ -993,6 +993,14 @@ k_kb_resolve(KbArgs a) {
     // window: kSC ballots (wave-uniform masks and counts), lane cl adds cell cl's count to the
     // cell's cursor, every lane takes its base from that lane.  Records of other windows
     // (where the tiles of two windows meet) go through a loop over their cells.
+    if (local && (a.flags & 16)) {
+      // (experiment, exp_knob 116: every lane takes its slot with its own LDS atomic — 64 lanes on
+      // the ~4 cursors of a window's cells serialise in the LDS, but the ~40 VALU instructions of
+      // the ballot rounds below go)
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if (ok[q]) entries[atomicAdd(&lcur[cell[q]], 1u)] = ent[q];
+    } else
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       unsigned long long todo = __ballot(ok[q]);

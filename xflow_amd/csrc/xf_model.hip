@@ -2244,8 +2244,10 @@ k_fm_row_partials(const uint32_t *__restrict__ rowptr, const uint32_t *__restric
 namespace xf {
 // the owner's Pull (key -> row once per row numbering, rows gathered) and its share of the
 // row sums: d_part[3 * b->R]
+// pulled_copies: the rows are gathered into the workspace (what a worker's Pull returns) whatever
+// the record mode — the rank-ordered update rule forms every worker's gradient from them
 int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, double *d_part,
-                      hipStream_t s) {
+                      hipStream_t s, bool pulled_copies) {
   XF_REQUIRE(w && vt && b && ws && d_part && !b->local, "fm_owner_partials: bad argument");
   const int k = xf::table_dim(vt);
   XF_TRY(xf_batch_upload(b, s));
@@ -2257,7 +2259,7 @@ int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, 
     return XF_OK;
   }
   const bool recmode = fm_table_records_enabled() && fm_records_fit(k) && !ws->capture &&
-                       ws->parity == XF_PARITY_EXACT_SUMS;
+                       ws->parity == XF_PARITY_EXACT_SUMS && !pulled_copies;
   bool fresh = false;
   XF_TRY(fm_resolve_rows(w, vt, b, ws, s, !recmode, &fresh));
   ws->owner_rec = nullptr;
@@ -2309,6 +2311,27 @@ int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *w
   if (!v.U || !v.R) return XF_OK;
   return fm_grad_update(w, vt, &v, b->d_fm_rows[0], b->d_fm_rows[1], ws->wu, ws->vu, d_vsum,
                         d_loss, ws->g, ws->gv, false, s, (FmKey *)ws->owner_rec);
+}
+
+// XF_UPDATE_RANK_ORDERED at the owner: `b` holds ONE worker's nonzeros of this owner's keys.
+// The worker's gradient (fm_worker.cc:126-157, its own 1 / R) from the rows its Pull returned
+// (fm_owner_partials(.., pulled_copies) of the same step: ws->vu), kept in the workspace ...
+int fm_owner_grad_pulled(xf_table *vt, xf_batch *b, xf_workspace *ws, const float *d_loss,
+                         const float *d_vsum, hipStream_t s) {
+  XF_REQUIRE(vt && b && ws && d_loss && d_vsum, "fm_owner_grad_pulled: bad argument");
+  const xf_dev_batch &v = b->view;
+  if (!v.U || !v.R) return XF_OK;
+  return xf_fm_grad_dev(&v, xf::table_dim(vt), ws->vu, d_vsum, d_loss, ws->g, ws->gv, s);
+}
+// ... and its two Pushes (fm_worker.cc:241-242 -> ftrl.h:54-74 / sgd.h:52 per key and factor):
+// called worker after worker once ALL workers' gradients exist
+int fm_owner_push_pulled(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                         hipStream_t s) {
+  XF_REQUIRE(w && vt && b && ws, "fm_owner_push_pulled: bad argument");
+  const xf_dev_batch &v = b->view;
+  if (!v.U || !v.R) return XF_OK;
+  XF_TRY(xf_table_update_dev(w, b->d_fm_rows[0], v.U, ws->g, s));
+  return xf_table_update_dev(vt, b->d_fm_rows[1], v.U, ws->gv, s);
 }
 }  // namespace xf
 

@@ -57,7 +57,11 @@ const float *table_weights(const xf_table *t);
 bool fm_records_fit(int k);
 size_t fm_record_bytes(size_t U);
 int fm_owner_partials(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws, double *d_part,
-                      hipStream_t s);
+                      hipStream_t s, bool pulled_copies = false);
+int fm_owner_grad_pulled(xf_table *vt, xf_batch *b, xf_workspace *ws, const float *d_loss,
+                         const float *d_vsum, hipStream_t s);
+int fm_owner_push_pulled(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
+                         hipStream_t s);
 int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *ws,
                          const float *d_loss, const float *d_vsum, hipStream_t s);
 int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
@@ -181,6 +185,12 @@ struct xf_sbatch {
   Dev<float> loss_recv2;                     // owner_stale1: the gradient pass of step t reads one
   int oflip = 0;                             // buffer while the losses of step t+1 arrive in the other
   Dev<uint8_t> gtouched;
+  // FM, XF_UPDATE_RANK_ORDERED: one minibatch (with a key list) and one workspace PER WORKER —
+  // its Pull's copies of the rows and its gradients live there from the forward to the Pushes;
+  // q_rowoff[q] = first of worker q's rows in the back-to-back layout
+  std::vector<xf_batch *> bq;
+  std::vector<xf_workspace *> wsq;
+  std::vector<uint32_t> q_rowoff;
   // FM (sum_then_step): b = the received nonzeros as one minibatch with a key list, rows
   // numbered worker after worker; (loss, v_sum) pairs of the rows
   uint32_t o_total = 0;                      // rows of all workers
@@ -842,7 +852,37 @@ static int compile_owner_dev(xf_sharded *st, xf_sbatch *b, const uint64_t *d_key
   b->d_wbase.p = D + at_wbase;
   b->d_wrows.p = D + at_wrows;
   const uint32_t *d_seg = D + at_seg, *d_off = D + at_off;
-  if (st->cfg.model == 1) {
+  b->q_rowoff = rowoff;
+  if (st->cfg.model == 1 && st->cfg.update_rule == XF_UPDATE_RANK_ORDERED) {
+    // FM, every worker's Push its own optimizer step: the nonzeros of worker q (they arrive
+    // worker after worker, row-major within a worker) become minibatch q, rows numbered as the
+    // worker numbers them
+    b->bq.assign(W, nullptr);
+    b->wsq.assign(W, nullptr);
+    size_t Usum = 0;
+    for (int q = 0; q < W; ++q) {
+      const uint32_t nq = segoff[q + 1] - segoff[q], Rq = b->o_rows[q];
+      if (!nq) continue;
+      Dev<uint32_t> d_rp;
+      Dev<int32_t> d_lab;
+      XF_TRY(d_rp.reserve((size_t)Rq + 1));
+      XF_TRY(d_lab.reserve(Rq));
+      hipLaunchKernelGGL(k_rowptr_of_sorted_rows, dim3(grid_for((size_t)nq + 1)), dim3(kBlock), 0,
+                         s, b->o_rowid.p + segoff[q], nq, Rq, d_rp.p);
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipMemsetAsync(d_lab.p, 0, (size_t)Rq * 4, s));  // (labels stay with the workers)
+      XF_TRY(xf_batch_compile_dev(&b->bq[q], b->o_keys.p + segoff[q], d_rp.p, d_lab.p, Rq, nq, s));
+      XF_TRY(wait_stream(st, s));
+      uint32_t Uq = 0;
+      XF_TRY(xf_batch_dims(b->bq[q], nullptr, nullptr, &Uq, nullptr));
+      Usum += Uq;
+      XF_TRY(xf_workspace_create(&b->wsq[q]));
+    }
+    b->U = (uint32_t)std::min<size_t>(Usum, 0xFFFFFFFFu);
+    // first-touch keys are inserted by the step's Pulls: room for all of them now
+    XF_TRY(xf::table_ensure_room(st->tw, Usum));
+    XF_TRY(xf::table_ensure_room(st->tv, Usum));
+  } else if (st->cfg.model == 1) {
     // FM: the received nonzeros become one minibatch with a key list (the owner's two tables
     // resolve it), rows numbered worker after worker — they arrive in that order
     if (b->o_n) {
@@ -1052,7 +1092,13 @@ static int owner_forward_fm(xf_sharded *st, xf_sbatch *b, float *d_loss, float *
   const int W = st->world;
   XF_TRY(b->rs_send.reserve((size_t)b->o_total * 3));
   XF_TRY(b->rs_recv.reserve((size_t)W * b->R * 3));
-  if (b->b)
+  if (!b->bq.empty()) {  // XF_UPDATE_RANK_ORDERED: every worker's Pull and its share of its rows
+    if (b->o_total) XF_HIP(hipMemsetAsync(b->rs_send.p, 0, (size_t)b->o_total * 24, s));
+    for (size_t q = 0; q < b->bq.size(); ++q)
+      if (b->bq[q])
+        XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->bq[q], b->wsq[q],
+                                     b->rs_send.p + (size_t)3 * b->q_rowoff[q], s, true));
+  } else if (b->b)
     XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->b, st->ws, b->rs_send.p, s));
   else if (b->o_total)
     XF_HIP(hipMemsetAsync(b->rs_send.p, 0, (size_t)b->o_total * 24, s));
@@ -1090,7 +1136,17 @@ static int step_owner_fm(xf_sharded *st, xf_sbatch *b) {
                        b->vsum_recv.p);
   XF_HIP(hipGetLastError());
   XF_MARK(3);
-  if (b->b)
+  if (!b->bq.empty()) {
+    // every worker's gradient from what its Pull returned (all Pulls precede all Pushes), then
+    // the Pushes worker after worker: the state a key's second step starts from is the first's
+    for (size_t q = 0; q < b->bq.size(); ++q)
+      if (b->bq[q])
+        XF_TRY(xf::fm_owner_grad_pulled(st->tv, b->bq[q], b->wsq[q],
+                                        b->loss_recv.p + b->q_rowoff[q],
+                                        b->vsum_recv.p + b->q_rowoff[q], s));
+    for (size_t q = 0; q < b->bq.size(); ++q)
+      if (b->bq[q]) XF_TRY(xf::fm_owner_push_pulled(st->tw, st->tv, b->bq[q], b->wsq[q], s));
+  } else if (b->b)
     XF_TRY(xf::fm_owner_grad_update(st->tw, st->tv, b->b, st->ws, b->loss_recv.p,
                                     b->vsum_recv.p, s));
   XF_MARK(4);
@@ -1133,11 +1189,6 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
                  (cfg->update_rule == XF_UPDATE_SUM_THEN_STEP && owner_dataflow(cfg->schedule)),
              "xf_sharded_create: update_rule %d (sum_then_step needs the owner-compute dataflow: "
              "there the workers' sums meet exactly)", cfg->update_rule);
-  XF_REQUIRE(!owner_dataflow(cfg->schedule) || cfg->model == 0 ||
-                 cfg->update_rule == XF_UPDATE_SUM_THEN_STEP,
-             "xf_sharded_create: FM on the owner-compute dataflow needs update_rule "
-             "sum_then_step (one gradient pass over all workers' rows; the per-worker Pushes of "
-             "the reference order run on the sequential / stale1 dataflows)");
   XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER_STALE1 || cfg->model == 0,
              "xf_sharded_create: owner_stale1 is the LR step (FM: schedule owner)");
   xf_sharded *st = new xf_sharded;
@@ -1225,6 +1276,10 @@ extern "C" int xf_sbatch_free(xf_sbatch *b) {
   if (b->cells) xf::cells_free(b->cells);
   if (b->ocells) xf::cells_free(b->ocells);
   if (b->b) xf_batch_free(b->b);
+  for (xf_batch *q : b->bq)
+    if (q) xf_batch_free(q);
+  for (xf_workspace *q : b->wsq)
+    if (q) xf_workspace_destroy(q);
   delete b;
   return XF_OK;
 }

@@ -32,6 +32,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -805,9 +808,57 @@ struct xf_table {
   uint64_t rec_all[5] = {0, 0, 0, 0, 0};
 };
 
+// Is (float)((double)x * (1.0 / (double)d)) the float x / d for EVERY finite x?  All 2^32 bit
+// patterns on the GPU (~10 ms), once per divisor and process.  The step's two divisions by alpha
+// then go without their subnormal-range guard (xf_device.h: div_by_const); a divisor that fails
+// — 50000 does, at 1308 subnormal quotients — keeps it.  Any failure to run the check keeps it too.
+namespace {
+__global__ void __launch_bounds__(256)
+k_div_exact(float d, double inv_d, unsigned int *__restrict__ bad) {
+#pragma clang fp contract(off)
+  unsigned int mine = 0;
+  for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < (1ull << 32);
+       u += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = __uint_as_float((uint32_t)u);
+    if ((((uint32_t)u >> 23) & 0xFFu) == 0xFFu) continue;  // inf / nan
+    const float q1 = x / d, q2 = (float)((double)x * inv_d);
+    mine |= __float_as_uint(q1) != __float_as_uint(q2) ? 1u : 0u;
+  }
+  if (__any((int)mine) && (threadIdx.x & 63u) == 0) atomicOr(bad, 1u);
+}
+}  // namespace
+
+static bool div_exact_for(float d) {
+  static std::mutex mu;
+  static std::map<uint32_t, bool> known;
+  if (!(d > 0.0f) || !std::isfinite(d)) return false;
+  uint32_t bits;
+  memcpy(&bits, &d, 4);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = known.find(bits);
+  if (it != known.end()) return it->second;
+  bool ok = false;
+  unsigned int *dbad = nullptr, hbad = 1;
+  if (hipMalloc((void **)&dbad, 4) == hipSuccess) {
+    if (hipMemset(dbad, 0, 4) == hipSuccess) {
+      hipLaunchKernelGGL(k_div_exact, dim3(256 * 16), dim3(256), 0, nullptr, d, 1.0 / (double)d,
+                         dbad);
+      if (hipGetLastError() == hipSuccess &&
+          hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost) == hipSuccess)
+        ok = hbad == 0;
+    }
+    (void)hipFree(dbad);
+  }
+  known[bits] = ok;
+  return ok;
+}
+
 static void refresh_hyper(xf_table *t) {
   t->T.alpha = t->cfg.alpha;
   t->T.inv_alpha = 1.0 / (double)t->cfg.alpha;
+  // (FTRL tables only: the check runs on the GPU; its verdict rides in the sign, xf_device.h)
+  if (t->cfg.opt_kind == XF_OPT_FTRL && div_exact_for(t->cfg.alpha))
+    t->T.inv_alpha = -t->T.inv_alpha;
   t->T.beta = t->cfg.beta;
   t->T.lambda1 = t->cfg.lambda1;
   t->T.lambda2 = t->cfg.lambda2;
