@@ -57,12 +57,14 @@ def steps_vs_oracle(t, s, raws, ws, steps, retain=True, defrag_at=None):
     (20000, 3, 50000, None, False),      # short rows: many rows per scatter tile
 ])
 def test_settled_keys_new_keys_and_the_general_build_agree(R, nnz, nkeys, zipf, ragged):
+    """... and the TWO-LEVEL build (exp_knob 78 forces it on these small tables: groups of two
+    super-chunks, k_kb_hist_groups / k_kb_regroup) gives the same cells' results again"""
     rng = np.random.RandomState(R + nnz)
     ws = capi.Workspace()
     raws = [synth(rng, R, nnz, nkeys, zipf, ragged) for _ in range(4)]
     tabs = []
-    for general in (False, True):
-        general_path(general)
+    for knob in (0, 78, 77):
+        capi.tune("exp_knob", knob)
         try:
             t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 20)
             s = O.Store(O.OPT_FTRL, 1)
@@ -74,13 +76,14 @@ def test_settled_keys_new_keys_and_the_general_build_agree(R, nnz, nkeys, zipf, 
             # ... minibatches 1-3 meet a settled tier that holds some of their keys: holes +
             # an arrival segment; after the second defrag everything is settled
             segs = steps_vs_oracle(t, s, raws[1:], ws, 7, defrag_at=3)
-            if not general:
+            if knob != 77:
                 assert segs[0] == 2 and segs[-1] == 1, segs
             tabs.append(t.export())
         finally:
             general_path(False)
-    for a, b in zip(*tabs):
-        same(a, b)
+    for other in tabs[1:]:
+        for a, b in zip(tabs[0], other):
+            same(a, b)
 
 
 def test_one_shot_minibatches_on_a_growing_table():
@@ -285,3 +288,52 @@ def test_update_in_one_call_is_the_key_build_and_the_step():
     ta.check()
     for a, e in zip(ta.export(), so.export()):
         same(a, e)
+
+
+def test_two_level_build_on_a_table_beyond_the_one_level_limit():
+    """3.6e7 settled keys (the one-level partition stops at 3.4e7: the scatter's per-super-chunk
+    arrays no longer fit the LDS): the minibatch takes the two-level build by itself — against
+    the general build (exp_knob 77) on a second table and against the oracle, on the keys the
+    minibatch touches (every other row of the tables is zero), with keys the tier does not hold
+    among them (holes + an arrival segment)."""
+    nkeys = 36_000_000
+    keytab = capi.hash_decimal_range(0, nkeys + 4000)
+    rng = np.random.RandomState(3)
+    R, nnz = 30000, 40
+    rowptr = (np.arange(R + 1) * nnz).astype(np.uint64)
+    fid = rng.randint(0, nkeys, size=R * nnz)
+    fid[::997] = nkeys + rng.randint(0, 4000, size=len(fid[::997]))     # not in the table yet
+    keys = keytab[fid]
+    labels = rng.randint(0, 2, size=R).astype(np.int32)
+    ob = O.Batch(rowptr, keys, labels)
+    s = O.Store(O.OPT_FTRL, 1)
+    with O.sum_mode(1):
+        loss_ex, _ = ob.lr_loss(s.pull(ob.ukeys))
+        O.lr_update(s, ob)
+    want = s.pull(ob.ukeys)
+    ws = capi.Workspace()
+    got = []
+    for knob in (0, 77):
+        t = capi.Table(capi.OPT_FTRL, 1, capacity=2 * nkeys + 65536)
+        for lo in range(0, nkeys, 9_000_000):     # every key once: the table holds them all
+            kk = keytab[lo:min(lo + 9_000_000, nkeys)]
+            rows = len(kk) // 200
+            rp = (np.arange(rows + 1, dtype=np.uint64) * np.uint64(200))
+            rp[-1] = len(kk)
+            capi.LocalBatch(t, rp, kk, np.zeros(rows, np.int32), retain_keys=False)
+        t.defrag()
+        assert len(t) == nkeys
+        capi.tune("exp_knob", knob)
+        try:
+            b = capi.LocalBatch(t, rowptr, keys, labels, retain_keys=False)
+            info = b.cells_info()
+            capi.lr_step(t, b, ws)
+        finally:
+            capi.tune("exp_knob", 0)
+        t.check()
+        assert info["segments"] == 2, info
+        same(ws.fetch_loss(R), loss_ex)
+        got.append(t.pull(ob.ukeys))
+        del b, t
+    same(got[0], want)
+    same(got[1], want)

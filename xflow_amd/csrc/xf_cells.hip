@@ -667,24 +667,31 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (uint32_t p0 = 0; p0 < total; p0 += kBlock * kGradE) {  // workgroup-uniform trip count
       uint32_t ent[kGradE], vq[kGradE];
       float l[kGradE];
-      uint32_t v = 0;
+      // the window of position p: the last v with cum[v] <= p, by a search whose steps are
+      // selects (five LDS reads per entry, the eight entries' searches side by side; a walk
+      // `while (p >= cum[v + 1]) ++v` was a chain of dependent LDS reads — thirty of them per
+      // thread at 32 windows).  Every lane loads (past the end: the last entry, dropped).
 #pragma unroll
       for (int q = 0; q < kGradE; ++q) {
         const uint32_t p = p0 + q * kBlock + tid;
-        ent[q] = 0xFFFFFFFFu;
-        vq[q] = 0;
-        if (p < total) {
-          while (p >= cum[v + 1]) ++v;  // p ascends with q: v never goes back
-          vq[q] = v;
-          ent[q] = entries[sbase[v] + (p - cum[v])];
+        const uint32_t pc = min(p, total - 1);
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t st = kGradWin / 2; st > 0; st >>= 1) {
+          const uint32_t t = v + st;
+          v = (t < nv && cum[t] <= pc) ? t : v;
         }
+        vq[q] = v;
+        const uint32_t e = entries[sbase[v] + (pc - cum[v])];
+        ent[q] = p < total ? e : 0xFFFFFFFFu;
       }
 #pragma unroll
-      for (int q = 0; q < kGradE; ++q)
-        l[q] = ent[q] != 0xFFFFFFFFu
-                   ? loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
-                          ((ent[q] >> kChunkBits) & kRowMask)]
-                   : 0.0f;
+      for (int q = 0; q < kGradE; ++q) {
+        const bool on = ent[q] != 0xFFFFFFFFu;
+        const size_t base = loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W;
+        const float x = loss[on ? base + ((ent[q] >> kChunkBits) & kRowMask) : (size_t)0];
+        l[q] = on ? x : 0.0f;
+      }
       if constexpr (SRC)  // (the owner's passes: their registers stay where they were)
 #pragma unroll
         for (int q = 0; q < kGradE; ++q)
@@ -942,21 +949,35 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   // per entry: the key's place in the chunk and its worker in ONE register, the loss in another
   uint32_t ek[E];
   float l[E];
-  {
-    uint32_t v = 0;
+  if (total) {
+    uint32_t vq[E], en[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {  // (the window of a position: see k_lr_grad_cells)
+      const uint32_t p = q * NT + tid;
+      const uint32_t pc = min(p, total - 1);
+      uint32_t v = 0;
+#pragma unroll
+      for (uint32_t st = kMultiWin / 2; st > 0; st >>= 1) {
+        const uint32_t t = v + st;
+        v = (t < nwin && cum[t] <= pc) ? t : v;
+      }
+      vq[q] = v;
+      const uint32_t e = entries[sbase[v] + (pc - cum[v])];
+      en[q] = p < total ? e : 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-      const uint32_t p = q * NT + tid;
+      const bool on = en[q] != 0xFFFFFFFFu;  // (a hole: the key went to the arrival segment)
+      const float x =
+          loss[on ? (size_t)loss_base[vq[q]] + ((en[q] >> kChunkBits) & kRowMask) : (size_t)0];
+      l[q] = on ? x : 0.0f;
+      ek[q] = on ? (en[q] & (kChunk - 1)) | ((uint32_t)wsrc[vq[q]] << 16) : 0xFFFFFFFFu;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
       ek[q] = 0xFFFFFFFFu;
       l[q] = 0.0f;
-      if (p < total) {
-        while (p >= cum[v + 1]) ++v;  // p ascends with q: v never goes back
-        const uint32_t e = entries[sbase[v] + (p - cum[v])];
-        if (e != 0xFFFFFFFFu) {  // (a hole: the key went to the arrival segment)
-          l[q] = loss[(size_t)loss_base[v] + ((e >> kChunkBits) & kRowMask)];
-          ek[q] = (e & (kChunk - 1)) | ((uint32_t)wsrc[v] << 16);
-        }
-      }
     }
   }
 #pragma unroll
@@ -1119,24 +1140,36 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
     total = 0;
     for (uint32_t k = tid; k < kChunk; k += NT) touched[k] = 1;
   }
+  // Entry p of the chunk's index space sits at entries[p + d], d = the offset of p's window
+  // (wave-uniform numbers).  Selects, not branches, and loads that every lane issues (a lane
+  // past the end re-reads the last entry and drops it): written with `if (p < total)` around
+  // nested ?: the compiler built a tree of divergent branches — ~75 instructions, a dozen
+  // s_cbranch among them, per entry loaded (round 4's "~45 instructions per entry").
+  const uint32_t d0 = cb0, d1 = cb1 - c1, d2 = cb2 - c2, d3 = cb3 - c3;
   for (uint32_t p0 = 0; p0 < total; p0 += NT * kOwn) {  // workgroup-uniform trip count
     uint32_t ent[kOwn], lidx[kOwn];
     float l[kOwn];
 #pragma unroll
     for (int q = 0; q < kOwn; ++q) {
       const uint32_t p = p0 + q * NT + tid;
-      ent[q] = 0xFFFFFFFFu;
-      lidx[q] = 0;
-      if (p < total) {
-        const uint32_t j = p < c1 ? cb0 + p : p < c2 ? cb1 + (p - c1) : p < c3 ? cb2 + (p - c2)
-                                                                               : cb3 + (p - c3);
-        lidx[q] = p < c1 ? 0u : p < c2 ? W : p < c3 ? 2u * W : 3u * W;
-        ent[q] = entries[j];
-      }
+      const uint32_t pc = min(p, total - 1);
+      uint32_t d = d0, li = 0;
+      d = pc >= c1 ? d1 : d;
+      li = pc >= c1 ? W : li;
+      d = pc >= c2 ? d2 : d;
+      li = pc >= c2 ? 2u * W : li;
+      d = pc >= c3 ? d3 : d;
+      li = pc >= c3 ? 3u * W : li;
+      const uint32_t e = entries[pc + d];
+      ent[q] = p < total ? e : 0xFFFFFFFFu;
+      lidx[q] = li;
     }
 #pragma unroll
-    for (int q = 0; q < kOwn; ++q)
-      l[q] = ent[q] != 0xFFFFFFFFu ? loss[lidx[q] + ((ent[q] >> kChunkBits) & kRowMask)] : 0.0f;
+    for (int q = 0; q < kOwn; ++q) {
+      const bool on = ent[q] != 0xFFFFFFFFu;
+      const float x = loss[on ? lidx[q] + ((ent[q] >> kChunkBits) & kRowMask) : 0u];
+      l[q] = on ? x : 0.0f;
+    }
 #pragma unroll
     for (int q = 0; q < kOwn; ++q)
       add_keys(acc, touched, ent[q] != 0xFFFFFFFFu, ent[q] & (kChunk - 1), l[q]);

@@ -24,11 +24,24 @@
 //                 LDS, every record finds its key there (position = state row), takes the next
 //                 slot of its cell and becomes a 4-byte entry
 //
-// Limits (beyond them the general build runs: a probe of the table per nonzero + a radix sort):
-// the scatter's per-super-chunk arrays must fit the LDS next to its stage of records (8192 per
-// tile up to ~1900 super-chunks = 1.5e7 settled keys per GPU — configs[1]: 1e7, configs[2]:
-// 1.25e7 per GPU — 4096 per tile up to ~4200 = 3.4e7 keys); 3.3e7 nonzeros per minibatch;
-// 4e6 cells.
+// Table size.  The scatter's per-super-chunk arrays must fit the LDS next to its stage of
+// records: 8192 nonzeros per tile up to ~1900 super-chunks = 1.5e7 settled keys per GPU
+// (configs[1]: 1e7, configs[2]: 1.25e7 per GPU), 4096 per tile up to ~4200 = 3.4e7 keys.  A
+// larger table (round 5; ftrl.h:84 is an unbounded map) takes the TWO-LEVEL build: the nonzeros
+// are partitioned by GROUP of 2^g super-chunks first (as few groups as the full-tile scatter
+// holds: the same histogram / scan / scatter kernels over coarser ranges), then every group's
+// records — a few thousand, L2-resident — are split by super-chunk and counted by cell by one
+// workgroup (k_kb_regroup), and the resolve runs as before:
+//   k_kb_hist_groups  nonzeros per (workgroup, group)
+//   k_kb_scan         (its per-range part) where every scatter workgroup's records of a group begin
+//   k_kb_scatter      records grouped by group
+//   k_kb_regroup      per group: records per super-chunk and per cell (row window, chunk), the
+//                     records again grouped by super-chunk, the resolve's work items
+//   k_kb_scan         (its cell part) cellptr, the gradient's work items
+//   k_kb_resolve      unchanged
+// up to 65 000 super-chunks (5e8 keys per GPU).  Other limits (beyond them the general build
+// runs: a probe of the table per nonzero + a radix sort): 3.3e7 nonzeros per minibatch; 4e6
+// cells.
 //
 // Keys the settled tier does not hold (new since the last xf_table_defrag, or the reserved key
 // value) leave a hole in their cell (an entry the kernels skip) and go to a miss list; they are
@@ -145,6 +158,13 @@ struct KbArgs {
   uint32_t *items;                 // resolve work items: super-chunk | part << 16
   uint32_t *nitems;                // their number
   uint32_t flags;                  // experiments (exp_knob)
+  uint32_t scan_part;              // k_kb_scan: 0 all of it, 1 the per-range part, 2 the cell part
+  uint32_t npc;                    // k_kb_scan: workgroups that scan the cell counts (pieces)
+  uint32_t *psum;                  // [npc] cell counts per piece (k_kb_psum; npc > 1)
+  // two-level build: groups of 1 << gshift super-chunks
+  uint32_t gshift, nG;
+  const uint32_t *gstart;          // [nG + 1] first record of every group (records by group)
+  const Rec3 *grec;                // [NNZ] records grouped by group (k_kb_regroup reads them)
   Rec3 *rec;                       // [NNZ] records, grouped by super-chunk
   Rec4 *rec4;                      // FM build: the records with both payloads
   uint32_t *fm_vrow;               // FM build: [NNZ] state row of every record (kHole: a miss)
@@ -404,9 +424,11 @@ k_kb_hist(KbArgs a) {
       const uint32_t c = kb_range(bnd, dp[q] & 0xFFFFu, dp[q] >> 16, x0[q], x1[q], key[q]);
       bool in_lds;
       uint32_t v = v0;
-      if (ROWID) {
-        v = a.rowid[j] / a.W;
-        in_lds = v == v0;
+      if (ROWID) {  // (rows ascend within a worker's share: the window rarely changes — no
+                    // division while it does not)
+        const uint32_t r = a.rowid[j], off = r - v0 * a.W;
+        in_lds = off < a.W;
+        if (!in_lds) v = r / a.W;
       } else {
         in_lds = j < wend;  // (a round that straddles the window's end: its tail, rare)
         if (!in_lds) v = window_of_entry(a.rowptr, a.R, a.W, a.nwin, j);
@@ -460,9 +482,9 @@ __device__ __forceinline__ uint32_t sp(uint32_t i) { return i + (i >> 4); }
 template <typename F>
 __device__ __forceinline__ uint32_t staged_excl_scan(F in, uint32_t n, uint32_t *__restrict__ o1,
                                                      uint32_t *__restrict__ o2, uint32_t *sbuf,
-                                                     uint32_t *wsum) {
+                                                     uint32_t *wsum, uint32_t carry0 = 0) {
   const uint32_t tid = threadIdx.x;
-  uint32_t carry = 0;
+  uint32_t carry = carry0;
   for (uint32_t base = 0; base < n; base += kScanPiece) {
     const uint32_t m = min(kScanPiece, n - base);
     for (uint32_t i = tid; i < kScanPiece; i += kKb) sbuf[sp(i)] = i < m ? in(base + i) : 0u;
@@ -490,14 +512,31 @@ __device__ __forceinline__ uint32_t staged_excl_scan(F in, uint32_t n, uint32_t 
   return carry;
 }
 
+// the cell counts of piece p (kScanPiece cells), for the scan's workgroups to start from
+__global__ void __launch_bounds__(kKb)
+k_kb_psum(KbArgs a) {
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t ncell = a.nwin * a.cA, p = blockIdx.x;
+  const uint32_t b = p * kScanPiece, e = min(b + kScanPiece, ncell);
+  uint32_t sum = 0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += kKb) sum += a.hist[i];
+  uint32_t total;
+  (void)block_excl_scan(sum, wsum, &total);
+  if (threadIdx.x == 0) a.psum[p] = total;
+}
+
+// Workgroups [0, npc): the cell counts, a piece of kScanPiece cells each (one workgroup walking
+// 195 000 cells — an owner's 32 row windows — took 77 us).  Workgroup npc: the work items.  The
+// others: the per-range columns.
 __global__ void __launch_bounds__(kKb)
 k_kb_scan(KbArgs a) {
   __shared__ uint32_t sbuf[kScanPiece + kScanPiece / 16];
   __shared__ uint32_t wsum[kKb / 64];
   const uint32_t tid = threadIdx.x;
   const uint32_t *__restrict__ hist = a.hist;
-  if (blockIdx.x > 1) {
-    const uint32_t S = (blockIdx.x - 2) * (kKb / 64) + (tid >> 6), lane = tid & 63u;
+  if (blockIdx.x > a.npc ? a.scan_part == 2 : a.scan_part == 1) return;  // (two-level build)
+  if (blockIdx.x > a.npc) {
+    const uint32_t S = (blockIdx.x - a.npc - 1) * (kKb / 64) + (tid >> 6), lane = tid & 63u;
     if (S >= a.nS) return;
     uint32_t *__restrict__ col = a.wgcnt + S;
     uint32_t carry = 0;
@@ -535,7 +574,7 @@ k_kb_scan(KbArgs a) {
     if (lane == 0) a.scount[S] = carry;
     return;
   }
-  if (blockIdx.x == 1) {  // slices per chunk, first item of every chunk, index among the split
+  if (blockIdx.x == a.npc) {  // slices per chunk, first item of every chunk, index among the split
     const size_t nc1 = (size_t)a.cA + 1;
     uint32_t *nsl = a.plan, *off = a.plan + nc1, *soff = a.plan + 2 * nc1;
     auto slices = [&](uint32_t c) -> uint32_t {
@@ -582,10 +621,182 @@ k_kb_scan(KbArgs a) {
     }
     return;
   }
-  const uint32_t ncell = a.nwin * a.cA;
-  const uint32_t total =
-      staged_excl_scan([&](uint32_t c) { return hist[c]; }, ncell, a.cellptr, a.cellcur, sbuf, wsum);
-  if (tid == 0) a.cellptr[ncell] = total;
+  const uint32_t ncell = a.nwin * a.cA, p = blockIdx.x;
+  const uint32_t b = p * kScanPiece, m = min(kScanPiece, ncell - b);
+  uint32_t base = 0;
+  if (a.npc > 1) {  // the cells before this piece
+    uint32_t x = 0;
+    for (uint32_t q = tid; q < p; q += kKb) x += a.psum[q];
+    (void)block_excl_scan(x, wsum, &base);
+    __syncthreads();  // (wsum is used again below)
+  }
+  const uint32_t total = staged_excl_scan([&](uint32_t c) { return hist[b + c]; }, m,
+                                          a.cellptr + b, a.cellcur + b, sbuf, wsum, base);
+  if (p == a.npc - 1 && tid == 0) a.cellptr[ncell] = total;
+}
+
+// ------------------------------------------------------------- two-level build, level one
+// Nonzeros per (workgroup, group): a.sc holds the GROUP ranges here, a.nS their number.  Same
+// split of the nonzeros over the workgroups as the scatter's; also tile_r0 (CSR input).
+__host__ __device__ inline size_t hist_groups_lds_bytes(uint32_t nG) {
+  return (size_t)nG * 8 + (size_t)nG * 4 + (size_t)nG * 4 + 64;
+}
+
+template <bool ROWID>
+__global__ void __launch_bounds__(kKb)
+k_kb_hist_groups(KbArgs a) {
+  extern __shared__ uint64_t smem[];
+  uint64_t *lb = smem;                        // group boundaries
+  uint32_t *ld2 = (uint32_t *)(smem + a.nS);  // dir[b] | dir[b + 1] << 16
+  uint32_t *ls = ld2 + a.nS;                  // counts
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t e0 = blockIdx.x * a.span, e1 = min(e0 + a.span, a.NNZ);
+  const uint64_t *__restrict__ keys = a.keys;
+  for (uint32_t g = tid; g < a.nS; g += kKb) {
+    lb[g] = a.sc.bnd[g];
+    ld2[g] = (uint32_t)a.sc.dir[g] | ((uint32_t)a.sc.dir[g + 1] << 16);
+    ls[g] = 0;
+  }
+  if (!ROWID) {  // a wavefront per tile of the workgroup: the row of the tile's first nonzero
+    const uint32_t wave = tid >> 6, ntl = (e1 - e0 + a.tile - 1) / a.tile;
+    for (uint32_t k = wave; k < ntl; k += kKb / 64) {
+      const uint32_t r = wave_last_le(a.rowptr, a.R, e0 + k * a.tile);
+      if (lane == 0) a.tile_r0[e0 / a.tile + k] = r;
+    }
+  }
+  __syncthreads();
+  auto bnd = [&](uint32_t g) -> uint64_t { return lb[g]; };
+  constexpr int E = 4;
+  for (uint32_t j0 = e0; j0 < e1; j0 += kKb * E) {
+    uint64_t key[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t j = j0 + q * kKb + tid;
+      key[q] = j < e1 ? keys[j] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t j = j0 + q * kKb + tid;
+      const uint32_t dp = ld2[kb_bucket(key[q], a.lo, a.sc.mult, a.nS)];
+      const uint32_t s0 = dp & 0xFFFFu, s1 = dp >> 16;
+      const uint32_t g = kb_range(bnd, s0, s1, lb[min(s0, a.nS - 1)], lb[min(s0 + 1, a.nS - 1)],
+                                  key[q]);
+      // the lanes of a wavefront that hold the same group count as one atomic
+      unsigned long long todo = __ballot(j < e1);
+      while (todo) {  // wave-uniform
+        const int l = __ffsll((long long)todo) - 1;
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)g, l);
+        const unsigned long long m = __ballot(j < e1 && g == cur);
+        if ((int)lane == l) atomicAdd(&ls[cur], (uint32_t)__popcll(m));
+        todo &= ~m;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t *__restrict__ out = a.wgcnt + (size_t)blockIdx.x * a.nS;
+  for (uint32_t g = tid; g < a.nS; g += kKb) out[g] = ls[g];
+}
+
+// ------------------------------------------------------------- two-level build, level two
+// One workgroup per group g = super-chunks [g << gshift, ...): its records [gstart[g],
+// gstart[g + 1]) of a.grec (a few thousand: read twice, the second time from L2).  Pass 1 counts
+// them per super-chunk and per cell (row window, chunk) — a record's chunk from the group's
+// chunk boundaries in LDS — and leaves scount / sstart of its super-chunks, their resolve work
+// items and its chunks' columns of the cell histogram in memory (a group owns them: no
+// atomics on memory).  Pass 2 writes the records grouped by super-chunk into a.rec.
+constexpr uint32_t kGrpShiftMax = 6;
+__host__ __device__ inline size_t regroup_lds_bytes(uint32_t gshift, uint32_t nwin) {
+  const size_t ncg = (size_t)kSC << gshift;
+  return ncg * 8 + ncg * nwin * 4 + ((size_t)1 << gshift) * 12 + 64;
+}
+
+__global__ void __launch_bounds__(kKb)
+k_kb_regroup(KbArgs a) {
+  extern __shared__ uint64_t smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t g = blockIdx.x, nSg_max = 1u << a.gshift;
+  const uint32_t S0 = g << a.gshift, nSg = min(nSg_max, a.nS - S0);
+  const uint32_t c0 = S0 << kSCShift, ncg = min(nSg << kSCShift, a.cA - c0);
+  uint64_t *cb = smem;                                         // [ncg] chunk boundaries
+  uint32_t *ccnt = (uint32_t *)(smem + ((size_t)kSC << a.gshift));  // [nwin * ncg]
+  uint32_t *scnt = ccnt + (size_t)a.nwin * ((size_t)kSC << a.gshift);  // [nSg] counts
+  uint32_t *soff = scnt + nSg_max;                             // [nSg] first record (relative)
+  uint32_t *scur = soff + nSg_max;                             // [nSg] cursors
+  const uint32_t rb = a.gstart[g], re = a.gstart[g + 1];
+  for (uint32_t c = tid; c < ncg; c += kKb) cb[c] = a.ch.bnd[c0 + c];
+  for (uint32_t i = tid; i < a.nwin * ncg; i += kKb) ccnt[i] = 0;
+  if (tid < nSg_max) scnt[tid] = scur[tid] = 0;
+  __syncthreads();
+  const Rec3 *__restrict__ src = a.grec;
+  // the chunk of a key among the group's: the last c with cb[c] <= key (0 below all of them)
+  auto chunk_of = [&](uint64_t key) -> uint32_t {
+    uint32_t lo = 0, hi = ncg;  // cb[lo] <= key < cb[hi] (cb[0] taken as -inf)
+    while (hi - lo > 1) {
+      const uint32_t m = lo + (hi - lo) / 2;
+      if (cb[m] <= key) lo = m;
+      else
+        hi = m;
+    }
+    return lo;
+  };
+  for (uint32_t i0 = rb; i0 < re; i0 += kKb) {
+    const uint32_t i = i0 + tid;
+    if (i < re) {
+      const Rec3 r = src[i];
+      const uint64_t key = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+      const uint32_t c = chunk_of(key), v = r.rp >> kRinBits;
+      atomicAdd(&ccnt[(size_t)v * ncg + c], 1u);
+      atomicAdd(&scnt[c >> kSCShift], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // (at most 64 super-chunks)
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < nSg; ++j) {
+      soff[j] = run;
+      run += scnt[j];
+    }
+  }
+  __syncthreads();
+  if (tid < nSg) {
+    const uint32_t n = scnt[tid], S = S0 + tid;
+    a.scount[S] = n;
+    a.sstart[S] = rb + soff[tid];
+    const uint32_t parts = (n + kPart - 1) / kPart;
+    if (parts) {
+      const uint32_t at = atomicAdd(a.nitems, parts);
+      for (uint32_t q = 0; q < parts; ++q) a.items[at + q] = S | (q << 16);
+    }
+  }
+  if (g == gridDim.x - 1 && tid == 0) a.sstart[a.nS] = re;
+  for (uint32_t i = tid; i < a.nwin * ncg; i += kKb) {
+    const uint32_t v = i / ncg, c = i - v * ncg;
+    a.hist[(size_t)v * a.cA + c0 + c] = ccnt[i];
+  }
+  Rec3 *__restrict__ dst = a.rec;
+  for (uint32_t i0 = rb; i0 < re; i0 += kKb) {
+    const uint32_t i = i0 + tid;
+    const bool ok = i < re;
+    Rec3 r{0u, 0u, 0u};
+    uint32_t sl = 0xFFFFFFFFu;
+    if (ok) {
+      r = src[i];
+      sl = chunk_of((uint64_t)r.klo | ((uint64_t)r.khi << 32)) >> kSCShift;
+    }
+    unsigned long long todo = __ballot(ok);
+    uint32_t slot = 0;
+    while (todo) {  // wave-uniform: one cursor atomic per super-chunk the wavefront holds
+      const int l = __ffsll((long long)todo) - 1;
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)sl, l);
+      const unsigned long long m = __ballot(ok && sl == cur);
+      uint32_t base = 0;
+      if ((int)lane == l) base = atomicAdd(&scur[cur], (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+      if (ok && sl == cur) slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      todo &= ~m;
+    }
+    if (ok) dst[rb + soff[sl] + slot] = r;
+  }
 }
 
 // -------------------------------------------------------------------------------- scatter
@@ -757,11 +968,18 @@ k_kb_scatter(KbArgs a) {
     const uint32_t i0 = tid * E;  // the thread's first nonzero of the tile
     if (i0 < n) {
       if (ROWID) {
+        // one division per thread and tile: its first nonzero's window; the others are in that
+        // window or (where a window ends inside the thread's run) divide for themselves
+        const uint32_t r0w = a.rowid[e0 + i0] / a.W;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-          const uint32_t r = i0 + q < n ? a.rowid[e0 + i0 + q] : 0u;
-          const uint32_t v = r / a.W;
-          rp[q] = (v << kRinBits) | (r - v * a.W);
+          const uint32_t r = i0 + q < n ? a.rowid[e0 + i0 + q] : r0w * a.W;
+          uint32_t v = r0w, rin = r - r0w * a.W;
+          if (rin >= a.W) {
+            v = r / a.W;
+            rin = r - v * a.W;
+          }
+          rp[q] = (v << kRinBits) | rin;
         }
       } else {
         const uint32_t j0 = e0 + i0;
@@ -993,10 +1211,11 @@ k_kb_resolve(KbArgs a) {
     // window: kSC ballots (wave-uniform masks and counts), lane cl adds cell cl's count to the
     // cell's cursor, every lane takes its base from that lane.  Records of other windows
     // (where the tiles of two windows meet) go through a loop over their cells.
-    if (local && (a.flags & 16)) {
-      // (experiment, exp_knob 116: every lane takes its slot with its own LDS atomic — 64 lanes on
-      // the ~4 cursors of a window's cells serialise in the LDS, but the ~40 VALU instructions of
-      // the ballot rounds below go)
+    if (local && !(a.flags & 16)) {
+      // every lane takes its slot with its own LDS atomic: 64 lanes on the ~4 cursors of a
+      // window's cells serialise in the LDS, but the ~40 VALU instructions per record of the
+      // ballot rounds below go — the kernel is VALU-bound after its load burst: 122 -> 113 us
+      // (exp_knob 116 runs the ballot rounds)
 #pragma unroll
       for (int q = 0; q < E; ++q)
         if (ok[q]) entries[atomicAdd(&lcur[cell[q]], 1u)] = ent[q];
@@ -1309,15 +1528,23 @@ static int general_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
 // the chunk / super-chunk boundaries of the table's settled tier, their directories and the
 // directories over every super-chunk's keys: one device allocation kept with the table,
 // rebuilt when the tier changes (xf_table_defrag)
+// gshift != 0 (two-level build): also the ranges of the groups of 1 << gshift super-chunks (*gr)
 static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, KbArgs *a,
-                    hipStream_t s) {
+                    hipStream_t s, uint32_t gshift = 0, KbRanges *gr = nullptr) {
   uint64_t *ep = nullptr;
   void **slot = table_aux(t, &ep);
   auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const uint32_t nG = gshift ? (nS + (1u << gshift) - 1) >> gshift : 0u;
   const size_t o_cb = 0, o_sb = o_cb + al((size_t)cA * 8), o_sm = o_sb + al((size_t)nS * 8);
   const size_t o_cd = o_sm + al((size_t)nS * 8), o_sd = o_cd + al(((size_t)cA + 1) * 2);
   const size_t o_sdirs = o_sd + al(((size_t)nS + 1) * 2);
-  const size_t total = o_sdirs + al((size_t)nS * kDirStride * 2);
+  const size_t o_gb = o_sdirs + al((size_t)nS * kDirStride * 2);
+  const size_t o_gd = o_gb + al((size_t)nG * 8);
+  const size_t total = o_gd + al(((size_t)nG + 1) * 2);
+  // (the allocation is laid out for one group size: another one — a test forcing the two-level
+  // build on a small table — rebuilds it)
+  static thread_local void *aux_ptr = nullptr;
+  static thread_local uint32_t aux_gshift = 0;
   KbRanges *ch = &a->ch, *sc = &a->sc;
   ch->n = cA;
   sc->n = nS;
@@ -1327,7 +1554,8 @@ static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, Kb
   };
   ch->mult = mult32(cA);
   sc->mult = mult32(nS);
-  const bool fresh = !*slot || *ep != table_epoch(t);
+  const bool fresh = !*slot || *ep != table_epoch(t) ||
+                     (gshift && (aux_ptr != *slot || aux_gshift != gshift));
   if (fresh) {
     if (*slot) {
       XF_HIP(hipDeviceSynchronize());
@@ -1336,8 +1564,15 @@ static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, Kb
     }
     XF_HIP(hipMalloc(slot, total));
     *ep = table_epoch(t);
+    aux_ptr = *slot;
+    aux_gshift = gshift;
   }
   char *d = (char *)*slot;
+  if (gr) {
+    gr->n = nG;
+    gr->bnd = (const uint64_t *)(d + o_gb);
+    gr->dir = (const uint16_t *)(d + o_gd);
+  }
   ch->bnd = (const uint64_t *)(d + o_cb);
   ch->dir = (const uint16_t *)(d + o_cd);
   sc->bnd = (const uint64_t *)(d + o_sb);
@@ -1351,8 +1586,15 @@ static int kb_index(xf_table *t, const TableDev &T, uint32_t cA, uint32_t nS, Kb
                        kChunkBits + kSCShift, sc->mult, (uint64_t *)sc->bnd, (uint16_t *)sc->dir);
     hipLaunchKernelGGL(k_kb_sdir, dim3(nS), dim3(256), 0, s, T.bkeys, (uint32_t)T.nbase,
                        (uint16_t *)a->sdirs, (uint64_t *)a->smult);
+    if (gr) {
+      gr->mult = mult32(nG);
+      hipLaunchKernelGGL(k_kb_index, dim3((nG + 256) / 256), dim3(256), 0, s, T.bkeys, T.lo, nG,
+                         kChunkBits + kSCShift + (int)gshift, gr->mult, (uint64_t *)gr->bnd,
+                         (uint16_t *)gr->dir);
+    }
     XF_HIP(hipGetLastError());
   }
+  if (gr) gr->mult = mult32(nG);
   return XF_OK;
 }
 
@@ -1430,13 +1672,26 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   const uint32_t nwin = w_fixed ? std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed)
                                 : std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
   KbSummary *sum = summary_buf();
-  const bool fits = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
-                    sum != nullptr && cA64 < 0xFFFFu &&
-                    scatter_lds_bytes((uint32_t)nS64, kTile / 2) <= kDynMax &&
-                    hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax &&
-                    cA64 * nwin < (1ull << 22) &&
-                    ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256 &&
-                    exp_knob() != 77;
+  const bool common = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
+                      sum != nullptr && cA64 * nwin < (1ull << 22) &&
+                      ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256 &&
+                      exp_knob() != 77;
+  bool fits = common && cA64 < 0xFFFFu &&
+              scatter_lds_bytes((uint32_t)nS64, kTile / 2) <= kDynMax &&
+              hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax;
+  // the two-level build (this file's header): groups of 1 << gshift super-chunks, as few of
+  // them as the full-tile scatter holds.  exp_knob 78 forces it on a table that does not need
+  // it (tests: two super-chunks per group).
+  uint32_t gshift = 0;
+  if (common && (!fits || exp_knob() == 78) && nS64 >= 2 && nS64 < 0xFFFFu)
+    for (uint32_t g = 1; g <= kGrpShiftMax && !gshift; ++g) {
+      const uint32_t nG = (uint32_t)((nS64 + (1u << g) - 1) >> g);
+      if (scatter_lds_bytes(nG, kTile) <= kDynMax && hist_groups_lds_bytes(nG) <= kDynMax &&
+          regroup_lds_bytes(g, nwin) <= kDynMax)
+        gshift = g;
+    }
+  const bool big = gshift != 0;
+  if (big) fits = true;
   if (!fits) {
     // a table or a minibatch beyond the limits in this file's header: said once, loudly — the
     // general build is 3x slower and its user should know which path the numbers come from
@@ -1446,7 +1701,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
         told = true;
         fprintf(stderr,
                 "xflow_amd: the range-partitioned key build does not apply (%llu settled keys, "
-                "%u nonzeros, %u row windows: beyond ~3.4e7 keys / 3.3e7 nonzeros / 4e6 cells per "
+                "%u nonzeros, %u row windows: beyond 5e8 keys / 3.3e7 nonzeros / 4e6 cells per "
                 "GPU, xf_keybuild.hip): minibatches are built by the general path (a probe of the "
                 "table per nonzero + a radix pass)\n",
                 (unsigned long long)T.nbase, NNZ, nwin);
@@ -1455,6 +1710,8 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     return general_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, s);
   }
   const uint32_t cA = (uint32_t)cA64, nS = (uint32_t)nS64;
+  const uint32_t nG = big ? (nS + (1u << gshift) - 1) >> gshift : 0u;
+  const uint32_t nR = big ? nG : nS;  // the ranges the histogram / scatter partition by
   // segment A: the settled tier's rows [0, nbase)
   xf_cells *c = nullptr;
   XF_TRY(cells_alloc(&c, R, NNZ, (uint32_t)T.nbase, kCellsTableRows, ksc, w_fixed, 0));
@@ -1485,18 +1742,20 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     a.nwin = nwin;
     a.cA = cA;
     a.nS = nS;
-    a.tile = scatter_lds_bytes(nS, kTile) <= kDynMax ? kTile : kTile / 2;
+    a.tile = scatter_lds_bytes(nR, kTile) <= kDynMax ? kTile : kTile / 2;
     a.ntile = (NNZ + a.tile - 1) / a.tile;
     a.nbase = (uint32_t)T.nbase;
     a.bkeys = T.bkeys;
     a.lo = T.lo;
-    XF_TRY(kb_index(t, T, cA, nS, &a, s));
+    KbRanges gr{};
+    XF_TRY(kb_index(t, T, cA, nS, &a, s, gshift, big ? &gr : nullptr));
     a.cellptr = c->cellptr;
     a.entries = c->entries;
     a.plan = c->plan;
     a.blk_cell = c->blk_cell;
     const size_t ncell = (size_t)nwin * cA;
     const unsigned max_items = nS + NNZ / kPart + 1;  // >= sum over S of ceil(n_S / kPart)
+    const unsigned max_gitems = nG + NNZ / kPart + 1;
     // as many histogram / scatter workgroups as the GPU has CUs (one round), whole tiles each
     const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
     XF_REQUIRE(sub <= kMaxSub, "cells_build_keyed: %u nonzeros in one minibatch", NNZ);
@@ -1504,9 +1763,12 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     a.nW = (a.ntile + sub - 1) / sub;
     uint32_t *small = nullptr;
     const size_t n_zero = 4 + ncell;  // the summary and the histogram: cleared together
+    a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
     const size_t n_small = n_zero + ncell + (size_t)nS * 2 + 1 + max_items + 1 +
-                           (size_t)a.nW * nS + a.ntile + 1;
+                           (size_t)a.nW * nR + a.ntile + 1 +
+                           (big ? (size_t)nG * 2 + 1 + max_gitems + 1 : 0) + a.npc;
     XF_TRY(sc.get(&small, n_small));
+    a.psum = small + (n_small - a.npc);
     a.sum = (KbSummary *)small;
     a.hist = small + 4;
     a.cellcur = a.hist + ncell;
@@ -1515,9 +1777,11 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     a.items = a.sstart + nS + 1;
     a.nitems = a.items + max_items;
     a.wgcnt = a.nitems + 1;
-    a.tile_r0 = a.wgcnt + (size_t)a.nW * nS;
+    a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
+    uint32_t *gcount = a.tile_r0 + a.ntile + 1, *gstart = gcount + nG,
+             *gitems = gstart + nG + 1, *gnitems = gitems + max_gitems;
     a.flags = exp_knob() >= 100 && exp_knob() < 200 ? (uint32_t)(exp_knob() - 100) : 0u;
-    if (exp_knob() == 200) {
+    if (exp_knob() == 200 && !big) {
       const size_t need = ((size_t)2 * a.nW + max_items) * kDbgSlots;
       if (need > g_dbg_n) {
         if (g_dbg) (void)hipFree(g_dbg);
@@ -1536,9 +1800,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     XF_TRY(sc.get(&a.missK, NNZ));
     XF_TRY(sc.get(&a.missR, NNZ));
     XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
-    const bool ldsb = hist_lds_bytes(cA, nS, true) <= kDynMax;
-    const size_t hl = hist_lds_bytes(cA, nS, ldsb);
-#define XF_KB_LAUNCH(kern, grid, lds)                                                          \
+#define XF_KB_LAUNCH(kern, grid, lds, args)                                                    \
   do {                                                                                         \
     static bool attr_done = false;                                                             \
     if (!attr_done) {                                                                          \
@@ -1546,27 +1808,72 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                                  (int)kDynMax));                                               \
       attr_done = true;                                                                        \
     }                                                                                          \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kKb), lds, s, a);                                \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kKb), lds, s, args);                             \
   } while (0)
-    if (d_rowid) {
-      if (ldsb) XF_KB_LAUNCH((k_kb_hist<true, true>), a.nW, hl);
-      else
-        XF_KB_LAUNCH((k_kb_hist<true, false>), a.nW, hl);
+    if (!big) {
+      const bool ldsb = hist_lds_bytes(cA, nS, true) <= kDynMax;
+      const size_t hl = hist_lds_bytes(cA, nS, ldsb);
+      if (d_rowid) {
+        if (ldsb) XF_KB_LAUNCH((k_kb_hist<true, true>), a.nW, hl, a);
+        else
+          XF_KB_LAUNCH((k_kb_hist<true, false>), a.nW, hl, a);
+      } else {
+        if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl, a);
+        else
+          XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl, a);
+      }
+      if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
+                         0, s, a);
+      const size_t sl = scatter_lds_bytes(nS, a.tile);
+      if (a.tile == kTile) {
+        if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile>), a.nW, sl, a);
+        else
+          XF_KB_LAUNCH((k_kb_scatter<false, kTile>), a.nW, sl, a);
+      } else {
+        if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile / 2>), a.nW, sl, a);
+        else
+          XF_KB_LAUNCH((k_kb_scatter<false, kTile / 2>), a.nW, sl, a);
+      }
     } else {
-      if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl);
+      // level one over the groups: the same scan and scatter kernels see the groups as their
+      // ranges (ag); level two splits every group's records by super-chunk into a.rec
+      Rec3 *grec = nullptr;
+      XF_TRY(sc.get(&grec, NNZ));
+      XF_HIP(hipMemsetAsync(a.nitems, 0, 4, s));
+      KbArgs ag = a;
+      ag.nS = nG;
+      ag.sc = gr;
+      ag.scount = gcount;
+      ag.sstart = gstart;
+      ag.items = gitems;
+      ag.nitems = gnitems;
+      ag.rec = grec;
+      ag.scan_part = 1;
+      const size_t hl = hist_groups_lds_bytes(nG);
+      if (d_rowid) XF_KB_LAUNCH((k_kb_hist_groups<true>), a.nW, hl, ag);
       else
-        XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
-    }
-    hipLaunchKernelGGL(k_kb_scan, dim3(2 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
-    const size_t sl = scatter_lds_bytes(nS, a.tile);
-    if (a.tile == kTile) {
-      if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile>), a.nW, sl);
-      else
-        XF_KB_LAUNCH((k_kb_scatter<false, kTile>), a.nW, sl);
-    } else {
-      if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile / 2>), a.nW, sl);
-      else
-        XF_KB_LAUNCH((k_kb_scatter<false, kTile / 2>), a.nW, sl);
+        XF_KB_LAUNCH((k_kb_hist_groups<false>), a.nW, hl, ag);
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nG + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
+                         0, s, ag);
+      const size_t sl = scatter_lds_bytes(nG, a.tile);
+      if (a.tile == kTile) {
+        if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile>), a.nW, sl, ag);
+        else
+          XF_KB_LAUNCH((k_kb_scatter<false, kTile>), a.nW, sl, ag);
+      } else {
+        if (d_rowid) XF_KB_LAUNCH((k_kb_scatter<true, kTile / 2>), a.nW, sl, ag);
+        else
+          XF_KB_LAUNCH((k_kb_scatter<false, kTile / 2>), a.nW, sl, ag);
+      }
+      a.gshift = gshift;
+      a.nG = nG;
+      a.gstart = gstart;
+      a.grec = grec;
+      XF_KB_LAUNCH(k_kb_regroup, nG, regroup_lds_bytes(gshift, nwin), a);
+      a.scan_part = 2;
+      if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
     }
     hipLaunchKernelGGL(k_kb_resolve, dim3(max_items), dim3(kRes), 0, s, a);
 #undef XF_KB_LAUNCH
@@ -1636,9 +1943,11 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   a.nW = (a.ntile + sub - 1) / sub;
   uint32_t *small = nullptr;
   const size_t n_zero = 4 + ncell;
+  a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
   const size_t n_small = n_zero + ncell + (ncell + 1) + 4 * ((size_t)cA + 1) + (size_t)nS * 2 + 1 +
-                         max_items + 1 + (size_t)a.nW * nS + a.ntile + 1 + ((size_t)nS + 2);
+                         max_items + 1 + (size_t)a.nW * nS + a.ntile + 1 + ((size_t)nS + 2) + a.npc;
   XF_TRY(sc.get(&small, n_small));
+  a.psum = small + (n_small - a.npc);
   a.sum = (KbSummary *)small;
   a.hist = small + 4;
   a.cellcur = a.hist + ncell;
@@ -1671,7 +1980,9 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl);
   else
     XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
-  hipLaunchKernelGGL(k_kb_scan, dim3(2 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
+  if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
+                     a);
   const size_t sl = scatter_lds_bytes(nS, a.tile);
   if (a.tile == kTile) XF_KB_LAUNCH((k_kb_scatter<false, kTile, true>), a.nW, sl);
   else

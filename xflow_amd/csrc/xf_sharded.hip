@@ -510,37 +510,54 @@ k_own_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t world, uint32
 // One workgroup.  wgcnt[w * world + o] -> where workgroup w's nonzeros of owner o begin in the
 // owner-grouped list; first[o] = where owner o's begin (first[world] = n); pairs[o] = {nonzeros
 // for owner o, this worker's rows}: what owner o is told (one 16-byte element per peer).
+// A wavefront per owner: the column of the (at most 256) workgroups' counts in four loads per
+// lane and a shuffle scan (one lane walking the column was 2 x 256 dependent trips: 41 us).
 __global__ void __launch_bounds__(kOwnMax)
 k_own_scan(uint32_t *__restrict__ wgcnt, uint32_t nwg, uint32_t world, uint32_t R,
            uint32_t *__restrict__ first, uint64_t *__restrict__ pairs) {
   __shared__ uint32_t tot[kOwnMax + 1];
-  const uint32_t o = threadIdx.x;
-  uint32_t run = 0;
-  if (o < world)
-    for (uint32_t w = 0; w < nwg; ++w) {
-      const uint32_t x = wgcnt[(size_t)w * world + o];
-      wgcnt[(size_t)w * world + o] = run;
-      run += x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t NWV = kOwnMax / 64;
+  constexpr int kCol = 4;  // 256 workgroups at most (compile_owner_dev's split)
+  for (uint32_t o = wave; o < world; o += NWV) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int q = 0; q < kCol; ++q) {
+      const uint32_t w = q * 64 + lane;
+      const uint32_t x = w < nwg ? wgcnt[(size_t)w * world + o] : 0u;
+      uint32_t inc = x;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(inc, d);
+        if ((int)lane >= d) inc += y;
+      }
+      if (w < nwg) wgcnt[(size_t)w * world + o] = carry + inc - x;  // (relative to the owner's first)
+      carry += (uint32_t)__shfl((int)inc, 63);
     }
-  tot[o] = o < world ? run : 0u;
+    if (lane == 0) tot[o] = carry;
+  }
   __syncthreads();
-  if (o == 0) {
+  if (tid == 0) {
     uint32_t a = 0;
     for (uint32_t q = 0; q < world; ++q) {
       const uint32_t x = tot[q];
       tot[q] = a;
       a += x;
+      pairs[2 * q] = x;
+      pairs[2 * q + 1] = R;
     }
     tot[world] = a;
   }
   __syncthreads();
-  if (o < world) {
+  for (uint32_t o = wave; o < world; o += NWV) {
     const uint32_t base = tot[o];
-    for (uint32_t w = 0; w < nwg; ++w) wgcnt[(size_t)w * world + o] += base;
-    pairs[2 * o] = run;
-    pairs[2 * o + 1] = R;
+#pragma unroll
+    for (int q = 0; q < kCol; ++q) {
+      const uint32_t w = q * 64 + lane;
+      if (w < nwg) wgcnt[(size_t)w * world + o] += base;
+    }
   }
-  if (o <= world) first[o] = tot[o];
+  if (tid <= world) first[tid] = tot[tid];
 }
 
 // The stable scatter: workgroup w walks its share in rounds of kOwn consecutive nonzeros.  A
