@@ -145,6 +145,31 @@ def oracle_rank_ordered_lr(O, data, optimizer, reserve=0):
     return w
 
 
+def oracle_rank_ordered_fm(O, data, optimizer, k, seed):
+    """the same rule for FM (fm_worker.cc:226-242): per step every worker pulls w and v, forms
+    its loss and both gradients from ITS pull, then the two Pushes of every worker land worker
+    after worker (ftrl.h:54-74, :98-149).  data[s][r]."""
+    ftrl = optimizer == "ftrl"
+    oo = O.OPT_FTRL if ftrl else O.OPT_SGD
+    sw = O.Store(oo, 1)
+    sv = O.Store(oo, k, O.INIT_HASHNORM if ftrl else O.INIT_CONST, 0.001, seed)
+    for mbs in data:
+        obs = [O.Batch(*d) for d in mbs]
+        pulled = [(sw.pull(ob.ukeys), sv.pull(ob.ukeys)) for ob in obs]
+
+        def grad(a):
+            ob, (pw, pv) = a
+            loss, _, vsum = ob.fm_loss(k, pw, pv)
+            return ob.fm_grad(k, pv, vsum, loss)
+        with ThreadPoolExecutor(_threads()) as ex:
+            grads = list(ex.map(grad, zip(obs, pulled)))
+        for ob, (gw, gv) in zip(obs, grads):
+            sw.push(ob.ukeys, gw)
+            sv.push(ob.ukeys, gv)
+        del obs, pulled, grads
+    return sw, sv
+
+
 def oracle_concat_lr(O, data, optimizer, reserve=0):
     """sum_then_step: one LRWorker::update (lr_worker.cc:145-177) per step on the ranks'
     minibatches laid end to end"""

@@ -331,8 +331,8 @@ def test_two_level_build_on_a_table_beyond_the_one_level_limit():
         finally:
             capi.tune("exp_knob", 0)
         t.check()
-        assert info["segments"] == 2, info
-        same(ws.fetch_loss(R), loss_ex)
+        assert info["segments"] == (2 if knob == 0 else 1), (knob, info)   # (the general build
+        same(ws.fetch_loss(R), loss_ex)                                    #  makes one segment)
         got.append(t.pull(ob.ukeys))
         del b, t
     same(got[0], want)

@@ -15,6 +15,10 @@ configs[4]  FM k = 64 + FTRL, fids from Zipf(1.1) over a 10^9 key space, first-t
             the hash-normal initialiser, owner-compute dataflow + sum_then_step, against ONE
             FMWorker::update per step on the concatenation (fm_worker.cc:204-245); the eight
             ranks' rows together are one 10^7-nonzero minibatch per step.
+            The same model with the reference's own update rule (`rank_ordered`: every worker's
+            two Pushes their own optimizer steps, fm_worker.cc:226-242) on the same dataflow at
+            north_star's global minibatch (8 ranks x 6250 rows x 200 = 10^7 nonzeros), against
+            the oracle run of that rule.
 
 The oracle runs in this process while the ranks work (its ~10^8-key store is most of the time:
 a few minutes on the box's 16 usable cores).  Exact-sum mode — what the kernels compute; the
@@ -139,6 +143,29 @@ def test_config4_fm_k64_ftrl_zipf_1e9_keys_8_ranks(tmp_path):
         ew, ev = sw.export(), sv.export()
         # state is allocated on first touch: the tables hold the touched keys and nothing else
         assert len(ew[0]) == len(ev[0]) < WORLD * STEPS * ROWS_FM * NNZ // 4
+        assert H.compare_tables(O, outdir, WORLD, "w", ew) == len(ew[0])
+        assert H.compare_tables(O, outdir, WORLD, "v", ev) == len(ev[0])
+        _check_losses(outdir, held,
+                      lambda ob: ob.fm_loss(k, sw.pull(ob.ukeys), sv.pull(ob.ukeys))[0])
+
+
+def test_config4_fm_k64_ftrl_rank_ordered_8_ranks(tmp_path):
+    """configs[4]'s model under XF_UPDATE_RANK_ORDERED on the owner-compute dataflow: the owner
+    keeps a minibatch per worker, every worker's gradient comes from the rows ITS Pull returned,
+    the Pushes land worker after worker — both tables and the held-out forward bit for bit the
+    oracle run of that rule (all Pulls, then the Pushes in rank order)."""
+    capi.require_gpu()
+    nkeys, k, seed = 1_000_000_000, 64, 7
+    rows = int(os.environ.get("XF_WORLD8_FM_RANKED_ROWS", "6250"))
+    datadir, data, held = _prepare(tmp_path, "fmr", H.zipf_minibatch, nkeys, rows)
+    with O.sum_mode(1):
+        ranked = _in_background(lambda: H.oracle_rank_ordered_fm(O, data, "ftrl", k, seed))
+        outdir, (ps, q) = _run(tmp_path, "fmr", datadir, "fmr", model="fm", k=k, schedule="owner",
+                               update="rank_ordered", capacity=1 << 22, seed=seed)
+        H.join_ranks(ps, q)
+        sw, sv = ranked()
+        ew, ev = sw.export(), sv.export()
+        assert len(ew[0]) == len(ev[0]) > 1000
         assert H.compare_tables(O, outdir, WORLD, "w", ew) == len(ew[0])
         assert H.compare_tables(O, outdir, WORLD, "v", ev) == len(ev[0])
         _check_losses(outdir, held,

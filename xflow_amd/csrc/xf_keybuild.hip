@@ -389,6 +389,29 @@ k_kb_hist(KbArgs a) {
     return LDSB ? ld2[b] : (uint32_t)gd[b] | ((uint32_t)gd[b + 1] << 16);
   };
   auto process = [&](const uint64_t *key, uint32_t j0) {
+    if (ROWID) {
+      // nonzeros with row numbers arrive worker after worker, rows ascending: when a round begins
+      // in another window than the one in LDS, that window's counts are flushed and the new one
+      // moves in (every lane reads the round's first row: a uniform load, no barrier unless the
+      // window changes).  Before, whatever followed the workgroup's first window went to memory
+      // one atomic per nonzero: the workgroups that straddle a window's end — one in eight at 32
+      // windows — were the kernel's tail (85 us where the CSR form takes 36).
+      const uint32_t r = a.rowid[j0], off = r - v0 * a.W;
+      const uint32_t nv = off < a.W ? v0 : r / a.W;
+      if (nv != v0) {  // workgroup-uniform
+        __syncthreads();
+        for (uint32_t c = tid; c < a.cA; c += kKb) {
+          const uint32_t n = lh[c];
+          if (n) {
+            atomicAdd(&a.hist[(size_t)v0 * a.cA + c], n);
+            atomicAdd(&ls[c >> kSCShift], n);
+          }
+          lh[c] = 0;
+        }
+        __syncthreads();
+        v0 = nv;
+      }
+    }
     if (!ROWID && j0 >= wend) {  // (workgroup-uniform) the nonzeros have left the window
       __syncthreads();
       for (uint32_t c = tid; c < a.cA; c += kKb) {
@@ -681,15 +704,10 @@ k_kb_hist_groups(KbArgs a) {
       const uint32_t s0 = dp & 0xFFFFu, s1 = dp >> 16;
       const uint32_t g = kb_range(bnd, s0, s1, lb[min(s0, a.nS - 1)], lb[min(s0 + 1, a.nS - 1)],
                                   key[q]);
-      // the lanes of a wavefront that hold the same group count as one atomic
-      unsigned long long todo = __ballot(j < e1);
-      while (todo) {  // wave-uniform
-        const int l = __ffsll((long long)todo) - 1;
-        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)g, l);
-        const unsigned long long m = __ballot(j < e1 && g == cur);
-        if ((int)lane == l) atomicAdd(&ls[cur], (uint32_t)__popcll(m));
-        todo &= ~m;
-      }
+      // (one LDS atomic per key: a wavefront's 64 keys fall into ~60 of the ~1500 groups — a
+      // round of ballots per distinct group, the owner partition's trick for EIGHT owners, made
+      // this kernel 383 us)
+      if (j < e1) atomicAdd(&ls[g], 1u);
     }
   }
   __syncthreads();
