@@ -290,37 +290,15 @@ __device__ __forceinline__ void fwd_process(const FwdBlock &B, uint32_t b, uint3
                                : cell_of(cellptr, lo, hi, b * kBlk + q * 64 + lane);
     wv[q] = w[(size_t)(cell - c0) * kChunk + (e & (kChunk - 1))];
   }
-  // A block that lies in ONE cell — a thousand and more entries of one chunk in one window: a
-  // head key of a power-law minibatch — holds runs of neighbouring lanes with the SAME row (a row
-  // of 200 tokens names the head key twenty times; the key-sorted cell keeps them together), and
-  // same-address LDS atomics serialise (~2 cycles per lane: +10 us on the Zipf(1.1) forward).
-  // There the lanes of a run add up in registers (a segmented suffix sum over the wavefront,
-  // fp64: exact) and the run's first lane does the one atomic.  Uniform minibatches never take
-  // this path: their cells hold ~700 entries, every block spans several.
-  const bool one_cell = lo == hi;  // wave-uniform
+  // (Power-law minibatches: a block that lies in ONE cell — a head key's — holds runs of
+  // neighbouring lanes with the same row, whose same-address LDS atomics serialise.  Adding a
+  // run up in registers first, a segmented suffix sum over the wavefront, was tried in round 5:
+  // the Zipf(1.1) forward went from 48 to 60 us — twelve ds_bpermute per entry slot load the
+  // LDS pipe more than the serialised atomics they replace.)
 #pragma unroll
   for (int q = 0; q < kFwdE; ++q) {
     const uint32_t e = B.ent[q];
-    bool on = e != 0xFFFFFFFFu;
-    const uint32_t row = (e >> kChunkBits) & kRowMask;
-    double val = on ? (double)wv[q] : 0.0;
-    if (one_cell) {
-      const uint32_t rl = on ? row : 0xFFFF0000u | lane;  // (an idle lane: a row nobody has)
-      const uint32_t prev = (uint32_t)__shfl_up((int)rl, 1);
-      const bool head = lane == 0 || prev != rl;
-      const unsigned long long hm = __ballot(head);
-      if (hm != ~0ull) {  // wave-uniform: some lane continues its neighbour's row
-        const unsigned long long above = hm & ~((2ull << lane) - 1ull);
-        const uint32_t end = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-          const double t = __shfl_down(val, d);
-          if (lane + d < end) val += t;
-        }
-        on = on && head;
-      }
-    }
-    if (on) atomicAdd(&wx[row], val);
+    if (e != 0xFFFFFFFFu) atomicAdd(&wx[(e >> kChunkBits) & kRowMask], (double)wv[q]);
   }
 }
 
