@@ -79,6 +79,44 @@ int xf_reader_next_into(xf_reader *r, xf_block *blk, size_t *rows_out, size_t *n
                         const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,
                         const int32_t **labels);
 
+/* ---- the block as text, for a caller that tokenises it itself (xf_ingest_*) ----
+ * xf_reader_peek_text: the next block's text by the block rule above (*len = 0 at the end of the
+ * file; mapped files without a block cache); nothing moves until xf_reader_skip_text — any
+ * xf_reader_next* call instead parses that block on the host and moves on.
+ * xf_reader_copy_text: the peeked text copied to `dst` by `threads` host threads.
+ * xf_reader_parse_text: a block's text in memory parsed on the host into `blk` (what
+ * xf_reader_next_into yields for that block). */
+int xf_reader_peek_text(xf_reader *r, const char **text, size_t *len);
+int xf_reader_skip_text(xf_reader *r);
+int xf_reader_copy_text(xf_reader *r, char *dst, size_t cap, size_t *len, int threads);
+int xf_reader_parse_text(xf_reader *r, const char *text, size_t len, xf_block *blk,
+                         size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
+                         const uint64_t **keys, const int32_t **fgid, const int32_t **labels);
+
+/* ---------------------------------------------------------------- GPU tokeniser       */
+/* load_minibatch_hash_data_fread's token loop (load_data_from_disk.cc:126-208) and
+ * std::hash<std::string> of every fid (io.h:53) as byte-parallel kernels, for blocks of the
+ * common shape — lines "('0'|'1') '\t' field0:fid:rest (' ' field0:fid:rest)* '\n'" with single
+ * blanks and no control bytes: label = the digit, one key per token = _Hash_bytes(fid), bit for
+ * bit the host parser's arrays.  Any other block (other labels, empty tokens — which the
+ * reference duplicates —, CR LF, NUL, a token without two colons, ...) comes back with *ok = 0 and
+ * is the host parser's (xf_reader_parse_text).  Not in the reference: its io path is host code;
+ * this feeds xf_sharded_compile_dev / xf_lr_update_dev without the keys ever being host arrays. */
+typedef struct xf_ingest xf_ingest;
+int xf_ingest_create(xf_ingest **out, size_t max_text_bytes);
+int xf_ingest_destroy(xf_ingest *g);
+/* the pinned staging buffer the next block's text goes to (xf_reader_copy_text) */
+int xf_ingest_staging(xf_ingest *g, char **buf, size_t *cap);
+/* text == NULL: `len` bytes are in the staging buffer already.  Uploads, tokenises, waits for
+ * the counts.  d_keys [nnz] u64, d_rowptr [rows + 1] u32, d_labels [rows] i32: device arrays
+ * owned by `g`, valid until its next call. */
+int xf_ingest_block(xf_ingest *g, const char *text, size_t len, void *stream,
+                    const uint64_t **d_keys, const uint32_t **d_rowptr, const int32_t **d_labels,
+                    uint32_t *rows, uint32_t *nnz, int *ok);
+
+/* device memory -> host, blocking (the tokeniser's arrays in tests and small tools) */
+int xf_copy_to_host(void *dst, const void *d_src, size_t bytes);
+
 typedef struct xf_table xf_table;
 
 /* ---------------------------------------------------------------- compiled minibatch  */
@@ -544,7 +582,10 @@ int XFDestroy(void **h);
  *        parity(exact|reference_order: the forward's row sums in the reference's own fp32
  *        order — one worker, checking mode)
  *        model_in model_out (model file to load before / save after training)
- *        block_cache(0|1) block_cache_dir (binarized block cache of the text files) */
+ *        block_cache(0|1) block_cache_dir (binarized block cache of the text files)
+ *        ingest(host|gpu: the text of a block tokenised and hashed on the GPU, xf_ingest_*;
+ *        blocks that are not of the common shape go to the host parser; core_num 1, no block
+ *        cache).  XFGetMetric: ... blocks_gpu blocks_host (how the blocks were parsed) */
 int XFSetParam(void *h, const char *name, const char *value);
 /* after XFStartTrain: logloss_ref, logloss_nat, auc, tp, fp, rows_trained, train_seconds,
  * examples_per_sec, keys */

@@ -9,7 +9,7 @@ out=$R/xflow_amd/lib/var_$name
 mkdir -p $out
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$R/include -I$R/xflow_amd/csrc"
 objs=""
-for s in xf_table.hip xf_model.hip xf_calib.hip xf_batch_dev.hip xf_cells.hip xf_keybuild.hip xf_io.cc xf_batch.cc xf_metrics.cc xf_worker.cc xf_group.cc xf_modelfile.cc xf_sharded.hip; do
+for s in xf_table.hip xf_model.hip xf_calib.hip xf_batch_dev.hip xf_cells.hip xf_keybuild.hip xf_io.cc xf_batch.cc xf_metrics.cc xf_worker.cc xf_group.cc xf_modelfile.cc xf_sharded.hip xf_ingest.hip; do
   x=""; case $s in *.hip) x="-x hip";; esac
   /opt/rocm/bin/hipcc $FL "$@" $x -c $R/xflow_amd/csrc/$s -o $out/$s.o &
   objs="$objs $out/$s.o"

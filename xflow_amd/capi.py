@@ -72,6 +72,19 @@ SIGNATURES = {
     "xf_reader_next_into": (C.c_int, [vp, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                       C.POINTER(u64p), C.POINTER(u64p), C.POINTER(i32p),
                                       C.POINTER(i32p)]),
+    "xf_reader_peek_text": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "xf_reader_skip_text": (C.c_int, [vp]),
+    "xf_reader_copy_text": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]),
+    "xf_reader_parse_text": (C.c_int, [vp, vp, C.c_size_t, vp, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_size_t), C.POINTER(u64p), C.POINTER(u64p),
+                                       C.POINTER(i32p), C.POINTER(i32p)]),
+    "xf_copy_to_host": (C.c_int, [vp, vp, C.c_size_t]),
+    "xf_ingest_create": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "xf_ingest_destroy": (C.c_int, [vp]),
+    "xf_ingest_staging": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "xf_ingest_block": (C.c_int, [vp, vp, C.c_size_t, vp, C.POINTER(vp), C.POINTER(vp),
+                                  C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_int)]),
     "xf_reader_next": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                  C.POINTER(u64p), C.POINTER(u64p), C.POINTER(i32p),
                                  C.POINTER(i32p)]),
@@ -313,6 +326,85 @@ def read_blocks(path, cap_bytes, cache_path=None, info=None):
                    np.ctypeslib.as_array(lb, (r,)).copy())
     finally:
         L.xf_reader_close(h)
+
+
+def read_text_blocks(path, cap_bytes):
+    """Yield every block of `path` as TEXT (bytes), by the reader's block rule
+    (xf_reader_peek_text / xf_reader_skip_text)."""
+    L = lib()
+    r = vp()
+    check(L.xf_reader_open(C.byref(r), path.encode(), cap_bytes))
+    try:
+        while True:
+            t, n = vp(), C.c_size_t()
+            check(L.xf_reader_peek_text(r, C.byref(t), C.byref(n)))
+            if n.value == 0:
+                return
+            yield C.string_at(t.value, n.value)
+            check(L.xf_reader_skip_text(r))
+    finally:
+        L.xf_reader_close(r)
+
+
+def parse_text_block(text, cap_bytes=1 << 26):
+    """(rowptr, keys, fgid, labels) of one block's text through the HOST parser
+    (xf_reader_parse_text); raises XFError where the host parser rejects the block."""
+    import tempfile
+    L = lib()
+    r, blk = vp(), vp()
+    with tempfile.NamedTemporaryFile() as f:     # (a reader to borrow the thread team from)
+        f.write(b"0\t0:0:0\n")
+        f.flush()
+        check(L.xf_reader_open(C.byref(r), f.name.encode(), cap_bytes))
+    check(L.xf_block_create(C.byref(blk)))
+    try:
+        rows, nnz = C.c_size_t(), C.c_size_t()
+        rp, ks, fg, lb = u64p(), u64p(), i32p(), i32p()
+        buf = C.create_string_buffer(text, len(text) + 16)
+        check(L.xf_reader_parse_text(r, buf, len(text), blk, C.byref(rows), C.byref(nnz),
+                                     C.byref(rp), C.byref(ks), C.byref(fg), C.byref(lb)))
+        R, N = rows.value, nnz.value
+        return (np.ctypeslib.as_array(rp, (R + 1,)).copy(),
+                np.ctypeslib.as_array(ks, (max(N, 1),))[:N].copy(),
+                np.ctypeslib.as_array(fg, (max(N, 1),))[:N].copy(),
+                np.ctypeslib.as_array(lb, (max(R, 1),))[:R].copy())
+    finally:
+        L.xf_block_destroy(blk)
+        L.xf_reader_close(r)
+
+
+class Ingest:
+    """The GPU tokeniser (xf_ingest_*): text block -> device arrays (keys, rowptr, labels)."""
+
+    def __init__(self, max_text_bytes=1 << 26):
+        self.h = vp()
+        check(lib().xf_ingest_create(C.byref(self.h), max_text_bytes))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().xf_ingest_destroy(self.h)
+            self.h = None
+
+    def block_dev(self, text, stream=None):
+        """(ok, rows, nnz, d_keys, d_rowptr, d_labels): device pointers owned by the object"""
+        dk, dr, dl = vp(), vp(), vp()
+        rows, nnz, ok = C.c_uint32(), C.c_uint32(), C.c_int()
+        buf = C.create_string_buffer(text, len(text) + 1)
+        check(lib().xf_ingest_block(self.h, buf, len(text), stream, C.byref(dk), C.byref(dr),
+                                    C.byref(dl), C.byref(rows), C.byref(nnz), C.byref(ok)))
+        return bool(ok.value), rows.value, nnz.value, dk.value, dr.value, dl.value
+
+    def block(self, text):
+        """(ok, rowptr, keys, labels) as numpy arrays (copied back from the device); the arrays
+        are None when the block is not of the common shape"""
+        ok, R, N, dk, dr, dl = self.block_dev(text)
+        if not ok:
+            return False, None, None, None
+        rp, ks, lb = np.zeros(R + 1, np.uint32), np.zeros(N, np.uint64), np.zeros(R, np.int32)
+        for a, ptr in ((rp, dr), (ks, dk), (lb, dl)):
+            if a.nbytes:
+                check(lib().xf_copy_to_host(a.ctypes.data, ptr, a.nbytes))
+        return True, rp, ks, lb
 
 
 class Batch:

@@ -304,6 +304,7 @@ struct xf_reader {
   // and munmap under 64 threads every time
   std::vector<Piece> pieces;
   Team team;
+  Team copy_team;  // xf_reader_copy_text: on the producer's thread while `team` parses elsewhere
   // block cache (xf_reader_open_cached): either replaying `cfp`, or teeing into `tfp`
   FILE *cfp = nullptr, *tfp = nullptr;
   const char *cmap = nullptr;  // the cache file, mapped
@@ -763,23 +764,12 @@ extern "C" int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
   }
 }
 
-static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
-                       const uint64_t **keys, const int32_t **fgid, const int32_t **labels) {
-  if (r->cfp) {
-    XF_TRY(next_from_cache(r, rows_out, nnz_out));
-    if (rowptr) *rowptr = r->rowptr.data();
-    if (keys) *keys = r->keys.data();
-    if (fgid) *fgid = r->fgid.data();
-    if (labels) *labels = r->labels.data();
-    return XF_OK;
-  }
-  r->rowptr.assign(1, 0);
-  r->keys.clear();
-  r->fgid.clear();
-  r->labels.clear();
-  // The reference fills a cap-byte buffer up to cap-1 bytes (:108-110).  A buffer that
-  // filled completely is cut after its last newline and the rest carried (:112-121,:104-107);
-  // a short read means end of file and everything is parsed.
+// The block rule (load_data_from_disk.cc:104-121): the reference fills a cap-byte buffer up to
+// cap-1 bytes; a buffer that filled completely is cut after its last newline and the rest
+// carried; a short read means end of file and everything is parsed.  *base: the block's first
+// byte (the mapping, or the read buffer after this call's fread), *text bytes of it are parsed,
+// *take bytes consumed.
+static int block_extent(xf_reader *r, const char **base_out, size_t *text_out, size_t *take_out) {
   const char *base;
   if (r->map) {  // the next cap-1 bytes of the mapping == carried tail + fresh read
     base = r->map + r->pos;
@@ -800,8 +790,20 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
     take = cut;
     text = cut - 1;  // the newline is replaced by the terminator (:116)
   }
-  // Parse the text.  Lines are independent, so a large block is cut at newlines into one
-  // piece per thread; the pieces are concatenated in order (bit-identical to a serial pass).
+  *base_out = base;
+  *text_out = text;
+  *take_out = take;
+  return XF_OK;
+}
+
+// [base, base + text) parsed into the reader's arrays.  Lines are independent, so a large
+// block is cut at newlines into one piece per thread; the pieces are concatenated in order
+// (bit-identical to a serial pass).  safe_end: bytes up to there may be READ beyond a token.
+static int parse_text(xf_reader *r, const char *base, size_t text, const char *safe_end) {
+  r->rowptr.assign(1, 0);
+  r->keys.clear();
+  r->fgid.clear();
+  r->labels.clear();
   const char *p0 = base, *end = base + text;
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 1;
@@ -827,9 +829,6 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
     pc.err = nullptr;
     pc.hit_nul = false;
   }
-  // bytes that may be READ beyond a token (the short-fid hash loads 8 at once): the mapping or
-  // the read buffer
-  const char *safe_end = r->map ? r->map + r->map_size : r->buf.data() + r->buf.size();
   r->team.run(nt, [&](unsigned t) {
     parse_piece(cut[t], cut[t + 1], cut[t + 1] == end, safe_end, &pieces[t]);
   });
@@ -868,6 +867,26 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
       r->rowptr[row_off[t] + i + 1] = key_off[t] + pc.rowend[i];
   };
   r->team.run(used, place);
+  return XF_OK;
+}
+
+static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
+                       const uint64_t **keys, const int32_t **fgid, const int32_t **labels) {
+  if (r->cfp) {
+    XF_TRY(next_from_cache(r, rows_out, nnz_out));
+    if (rowptr) *rowptr = r->rowptr.data();
+    if (keys) *keys = r->keys.data();
+    if (fgid) *fgid = r->fgid.data();
+    if (labels) *labels = r->labels.data();
+    return XF_OK;
+  }
+  const char *base = nullptr;
+  size_t text = 0, take = 0;
+  XF_TRY(block_extent(r, &base, &text, &take));
+  // bytes that may be READ beyond a token (the short-fid hash loads 8 at once): the mapping or
+  // the read buffer
+  const char *safe_end = r->map ? r->map + r->map_size : r->buf.data() + r->buf.size();
+  XF_TRY(parse_text(r, base, text, safe_end));
   if (r->map) {
     r->pos += take;
     r->held = 0;
@@ -882,5 +901,75 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
   if (keys) *keys = r->keys.data();
   if (fgid) *fgid = r->fgid.data();
   if (labels) *labels = r->labels.data();
+  return XF_OK;
+}
+
+// ---- the block as TEXT (xf_ingest.hip tokenises it on the GPU) --------------------------------
+// The next block's text by the block rule above, without parsing it: *text points into the
+// mapping, *len bytes (0 at the end of the file).  Mapped files without a block cache only.
+// Nothing moves until xf_reader_skip_text; a xf_reader_next* call instead parses this very block
+// on the host and moves on.
+extern "C" int xf_reader_peek_text(xf_reader *r, const char **text, size_t *len) {
+  XF_REQUIRE(r && text && len, "xf_reader_peek_text: null argument");
+  XF_REQUIRE(r->map && !r->cfp && !r->tfp,
+             "xf_reader_peek_text: a mapped text file without a block cache only");
+  const char *base = nullptr;
+  size_t t = 0, take = 0;
+  XF_TRY(block_extent(r, &base, &t, &take));
+  *text = base;
+  *len = t;
+  return XF_OK;
+}
+
+extern "C" int xf_reader_skip_text(xf_reader *r) {
+  XF_REQUIRE(r && r->map && !r->cfp && !r->tfp, "xf_reader_skip_text: bad reader");
+  const char *base = nullptr;
+  size_t t = 0, take = 0;
+  XF_TRY(block_extent(r, &base, &t, &take));
+  r->pos += take;
+  r->held = 0;
+  return XF_OK;
+}
+
+// the peeked block's text copied to dst (pinned staging memory) by `threads` host threads
+extern "C" int xf_reader_copy_text(xf_reader *r, char *dst, size_t cap, size_t *len,
+                                   int threads) {
+  XF_REQUIRE(r && dst && len, "xf_reader_copy_text: null argument");
+  const char *text = nullptr;
+  XF_TRY(xf_reader_peek_text(r, &text, len));
+  XF_REQUIRE(*len <= cap, "xf_reader_copy_text: a block of %zu bytes, room for %zu", *len, cap);
+  const size_t n = *len;
+  unsigned nt = (unsigned)std::max(1, std::min(threads, 64));
+  if (n / (1 << 20) + 1 < nt) nt = (unsigned)(n / (1 << 20) + 1);
+  r->copy_team.run(nt, [&](unsigned t) {
+    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+    if (hi > lo) memcpy(dst + lo, text + lo, hi - lo);
+  });
+  return XF_OK;
+}
+
+// A block's text in memory (whole lines, as xf_reader_peek_text delimits them) parsed on the
+// host into `blk`: what xf_reader_next_into yields for that block.  For the blocks the GPU
+// tokeniser hands back.
+extern "C" int xf_reader_parse_text(xf_reader *r, const char *text, size_t len, xf_block *blk,
+                                    size_t *rows_out, size_t *nnz_out, const uint64_t **rowptr,
+                                    const uint64_t **keys, const int32_t **fgid,
+                                    const int32_t **labels) {
+  XF_REQUIRE(r && blk && rows_out && (text || len == 0), "xf_reader_parse_text: null argument");
+  try {
+    XF_TRY(parse_text(r, text, len, text + len));
+  } catch (const std::exception &e) {
+    return xf::set_error(XF_EIO, "xf_reader_parse_text: %s", e.what());
+  }
+  *rows_out = r->labels.size();
+  if (nnz_out) *nnz_out = r->keys.size();
+  blk->rowptr.swap(r->rowptr);
+  blk->keys.swap(r->keys);
+  blk->fgid.swap(r->fgid);
+  blk->labels.swap(r->labels);
+  if (rowptr) *rowptr = blk->rowptr.data();
+  if (keys) *keys = blk->keys.data();
+  if (fgid) *fgid = blk->fgid.data();
+  if (labels) *labels = blk->labels.data();
   return XF_OK;
 }

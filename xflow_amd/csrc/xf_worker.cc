@@ -48,6 +48,8 @@ Worker::~Worker() {
   for (std::thread &t : closers_) t.join();
   for (xf_block *b : blocks_)
     if (b) xf_block_destroy(b);
+  for (xf_ingest *g : ingest_)
+    if (g) xf_ingest_destroy(g);
   for (xf_sbatch *b : cache_) xf_sbatch_free(b);
   if (sharded_) xf_sharded_destroy(sharded_);  // owns the tables
   if (group_) xf_group_destroy(group_);
@@ -179,6 +181,7 @@ int Worker::batch_training() {
   }
   const double t0 = now_s();
   rows_trained_ = 0;
+  blocks_gpu = blocks_host = 0;
   for (xf_sbatch *b : cache_) xf_sbatch_free(b);  // a second XFStartTrain starts from the files
   cache_.clear();
   bool cached = false;
@@ -198,6 +201,10 @@ int Worker::batch_training() {
         rows_trained_ += R;
       }
       XF_TRY(xf_sharded_check(sharded_));
+    } else if (ingest_gpu && core_num == 1 && !block_cache) {
+      // the text tokenised and hashed on the GPU (xf_ingest.hip), compiled from device arrays
+      XF_TRY(text_epoch(epoch, keep));
+      cached = keep != 0;
     } else {
       xf_reader *rd = nullptr;
       const bool trace = getenv("XF_TRACE_WORKER") != nullptr;  // per-block timeline on stderr
@@ -356,6 +363,157 @@ int Worker::batch_training() {
   return XF_OK;
 }
 
+// One epoch from the text with the GPU tokeniser (ingest = gpu).  A staging thread copies the
+// next block's text from the mapped file into pinned memory (several host threads: a 64 MiB
+// block is ~2 ms) while the GPU tokenises, compiles and steps the current one; two staging /
+// tokeniser buffers go round between the two threads.  A block the tokeniser hands back (not of
+// the common shape, xf_ingest.hip) is parsed from the staged text by the host parser: the same
+// arrays, the reference's quirks in one place.  Block boundaries are the reader's (a1).
+int Worker::text_epoch(int epoch, int keep) {
+  const bool trace = getenv("XF_TRACE_WORKER") != nullptr;
+  const double te0 = now_s();
+  xf_reader *rd = nullptr;
+  XF_TRY(xf_reader_open(&rd, train_data_path, (size_t)block_size << 20));
+  struct ReaderGuard {
+    xf_reader *r;
+    ~ReaderGuard() {
+      if (r) xf_reader_close(r);
+    }
+  } rguard{rd};
+  for (int i = 0; i < 2; ++i)
+    if (!ingest_[i]) XF_TRY(xf_ingest_create(&ingest_[i], (size_t)block_size << 20));
+  if (!blocks_[0]) XF_TRY(xf_block_create(&blocks_[0]));
+  void *stream = nullptr;
+  XF_TRY(xf_sharded_stream(sharded_, &stream));
+  struct Staged {
+    size_t len = 0;
+    int rc = XF_OK;
+    std::string err;
+  } slot[2];
+  std::mutex mu;
+  std::condition_variable cv;
+  int filled[2] = {0, 0};  // 0 = free for the staging thread, 1 = staged
+  bool stop = false;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int copy_threads = std::max(2, std::min(16, xf::parse_threads()));
+  std::thread stager([&, dev] {
+    (void)hipSetDevice(dev);
+    for (int k = 0;; k ^= 1) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !filled[k]; });
+        if (stop) return;
+      }
+      Staged &p = slot[k];
+      char *buf = nullptr;
+      size_t cap = 0;
+      p.len = 0;
+      p.rc = xf_ingest_staging(ingest_[k], &buf, &cap);
+      if (p.rc == XF_OK) p.rc = xf_reader_copy_text(rd, buf, cap, &p.len, copy_threads);
+      if (p.rc == XF_OK && p.len) p.rc = xf_reader_skip_text(rd);
+      if (p.rc != XF_OK) p.err = xf_last_error();
+      const bool last = p.rc != XF_OK || p.len == 0;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[k] = 1;
+      }
+      cv.notify_all();
+      if (last) return;
+    }
+  });
+  static const uint64_t kNoRows[1] = {0};
+  int rc = XF_OK;
+  bool mine_done = false;
+  for (int k = 0; rc == XF_OK;) {
+    Staged *p = nullptr;
+    const double tw0 = now_s();
+    if (!mine_done) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return filled[k] != 0; });
+      }
+      p = &slot[k];
+      if (p->rc != XF_OK) {
+        rc = xf::set_error(p->rc, "%s", p->err.c_str());
+        break;
+      }
+      if (p->len == 0) mine_done = true;
+    }
+    bool any = false;
+    rc = any_rank(!mine_done, &any);
+    if (rc != XF_OK || !any) break;
+    const double tw1 = now_s();
+    xf_sbatch *b = nullptr;
+    size_t rows = 0;
+    bool on_gpu = false;
+    if (!mine_done) {
+      const uint64_t *dk = nullptr;
+      const uint32_t *drp = nullptr;
+      const int32_t *dl = nullptr;
+      uint32_t R = 0, NNZ = 0;
+      int ok = 0;
+      rc = xf_ingest_block(ingest_[k], nullptr, p->len, stream, &dk, &drp, &dl, &R, &NNZ, &ok);
+      if (rc == XF_OK && ok) {
+        rc = xf_sharded_compile_dev(sharded_, &b, dk, drp, dl, R, NNZ, keep);
+        rows = R;
+        on_gpu = true;
+        ++blocks_gpu;
+      } else if (rc == XF_OK) {  // not of the common shape: the host parser's
+        char *buf = nullptr;
+        size_t nnz = 0;
+        const uint64_t *rowptr = nullptr, *keys = nullptr;
+        const int32_t *fgid = nullptr, *labels = nullptr;
+        rc = xf_ingest_staging(ingest_[k], &buf, nullptr);
+        if (rc == XF_OK)
+          rc = xf_reader_parse_text(rd, buf, p->len, blocks_[0], &rows, &nnz, &rowptr, &keys,
+                                    &fgid, &labels);
+        if (rc == XF_OK)
+          rc = rows ? xf_sharded_compile(sharded_, &b, rowptr, keys, labels, 0, rows, keep)
+                    : xf_sharded_compile(sharded_, &b, kNoRows, nullptr,
+                                         (const int32_t *)kNoRows, 0, 0, keep);
+        ++blocks_host;
+      }
+    } else {  // a rank without rows of its own still takes part in the (collective) step
+      rc = xf_sharded_compile(sharded_, &b, kNoRows, nullptr, (const int32_t *)kNoRows, 0, 0, keep);
+    }
+    const double tc1 = now_s();
+    if (rc == XF_OK) rc = xf_sharded_step(sharded_, b);
+    if (rc == XF_OK) rc = xf_sharded_check(sharded_);
+    if (rc != XF_OK) {
+      if (b) xf_sbatch_free(b);
+      break;
+    }
+    rows_trained_ += (long)rows;
+    if (keep) cache_.push_back(b);
+    else
+      xf_sbatch_free(b);
+    if (world <= 1 && model_ == 0) rc = defrag_if_grown(30);
+    if (trace)
+      fprintf(stderr, "block: %zu rows  waited for the parser %.2f ms  key build %.2f ms  "
+              "step+check %.2f ms  (%s)\n", rows, (tw1 - tw0) * 1e3, (tc1 - tw1) * 1e3,
+              (now_s() - tc1) * 1e3, on_gpu ? "tokenised on the GPU" : "parsed on the host");
+    if (!mine_done) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[k] = 0;
+      }
+      cv.notify_all();
+      k ^= 1;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  stager.join();
+  if (trace)
+    fprintf(stderr, "epoch %d: blocks done after %.2f ms (%ld tokenised on the GPU, %ld parsed on "
+            "the host)\n", epoch, (now_s() - te0) * 1e3, blocks_gpu, blocks_host);
+  return rc;
+}
+
 // predict + calculate_pctr (lr_worker.cc:25-98, fm_worker.cc:25-124).  As in the reference
 // only rank 0 scores its test file (lr_worker.cc:212-215) — against the WHOLE table: the other
 // ranks serve its Pulls (`reader` == false: they step empty minibatches until rank 0 is done).
@@ -510,6 +668,12 @@ int Worker::set_param(const char *name, const char *value) {
   else if (n == "seed") seed = strtoull(value, nullptr, 10);
   else if (n == "cache_batches") cache_batches = atoi(value);
   else if (n == "parse_threads") return xf_tune("parse_threads", atof(value));
+  else if (n == "ingest") {
+    if (!strcmp(value, "gpu")) ingest_gpu = true;
+    else if (!strcmp(value, "host")) ingest_gpu = false;
+    else
+      return xf::set_error(XF_EINVAL, "XFSetParam: ingest must be gpu or host");
+  }
   else if (n == "block_cache") block_cache = atoi(value);
   else if (n == "block_cache_dir") block_cache_dir = value;
   else if (n == "model_in") model_in = value;
@@ -544,6 +708,8 @@ int Worker::get_metric(const char *name, double *value) {
   else if (n == "tp") *value = tp_;
   else if (n == "fp") *value = fp_;
   else if (n == "rows_trained") *value = (double)rows_trained_;
+  else if (n == "blocks_gpu") *value = (double)blocks_gpu;
+  else if (n == "blocks_host") *value = (double)blocks_host;
   else if (n == "train_seconds") *value = train_seconds_;
   else if (n == "examples_per_sec") *value = train_seconds_ > 0 ? rows_trained_ / train_seconds_ : 0;
   else if (n == "keys") {

@@ -57,6 +57,11 @@ class Worker {
   int block_cache = 0;
   std::string block_cache_dir;
   int open_reader(xf_reader **rd, const char *path, size_t cap, bool *writes_cache = nullptr);
+  // ingest = gpu: the text of a block is tokenised and hashed on the GPU (xf_ingest.hip) and
+  // compiled from device arrays; a block that is not of the common shape is parsed on the host
+  // as before.  Needs core_num = 1 and no block cache (both checked where the epoch starts).
+  bool ingest_gpu = false;
+  long blocks_gpu = 0, blocks_host = 0;  // how the blocks of the last training run were parsed
 
  private:
   int create_tables();
@@ -76,6 +81,8 @@ class Worker {
   // the two block buffers that go round between the parser thread and the trainer: pinned host
   // memory, allocated once per worker (pinning and unpinning ~200 MB per epoch cost 30-80 ms)
   xf_block *blocks_[2] = {nullptr, nullptr};
+  xf_ingest *ingest_[2] = {nullptr, nullptr};  // ingest = gpu: two staging / tokeniser buffers
+  int text_epoch(int epoch, int keep);         // one epoch from the text, tokenised on the GPU
   std::vector<std::thread> closers_;  // readers being closed (munmap of the text) off the clock
   long rows_trained_ = 0;
   double train_seconds_ = 0.0;
