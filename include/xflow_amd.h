@@ -107,6 +107,10 @@ int xf_ingest_create(xf_ingest **out, size_t max_text_bytes);
 int xf_ingest_destroy(xf_ingest *g);
 /* the pinned staging buffer the next block's text goes to (xf_reader_copy_text) */
 int xf_ingest_staging(xf_ingest *g, char **buf, size_t *cap);
+/* the staged text on its way to the device, asynchronously on `stream` (a staging thread's own:
+ * the copy of the next block runs while the GPU works on this one); the next
+ * xf_ingest_block(g, NULL, len, ...) waits for that copy instead of making one */
+int xf_ingest_upload(xf_ingest *g, size_t len, void *stream);
 /* text == NULL: `len` bytes are in the staging buffer already.  Uploads, tokenises, waits for
  * the counts.  d_keys [nnz] u64, d_rowptr [rows + 1] u32, d_labels [rows] i32: device arrays
  * owned by `g`, valid until its next call. */

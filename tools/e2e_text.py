@@ -68,6 +68,9 @@ run(1, [])                                   # cold page cache / first HIP start
 text1, w_text = run(1, [])
 text_steady = run.steady
 text4, _ = run(4, [])
+gpu1, w_gpu = run(1, ["ingest=gpu"])         # the text tokenised and hashed on the GPU
+gpu_steady = run.steady
+gpu4, _ = run(4, ["ingest=gpu"])
 run(1, ["block_cache=1"])                    # builds the cache
 cache1, w_cache = run(1, ["block_cache=1"])  # uses it
 cache_steady = run.steady
@@ -77,6 +80,9 @@ res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, 
                "excluded" % (rows, nnz, size_mb, min(rows, CHUNK)),
        "host": {"nproc": os.cpu_count()},
        "first_epoch_from_text": text1, "first_epoch_from_block_cache": cache1,
+       "first_epoch_from_text_gpu_tokeniser": gpu1,
+       "median_block_rate_from_text_gpu_tokeniser": gpu_steady,
+       "average_over_4_epochs_from_text_gpu_tokeniser": gpu4,
        "median_block_rate_from_text": text_steady, "median_block_rate_from_block_cache": cache_steady,
        "note": "first_epoch_* = rows / wall time of the training loop of a fresh process that "
                "runs ONE epoch (its first block still pins the block buffers and sizes the build "
@@ -84,7 +90,12 @@ res = {"what": "xflow_lr on a synthetic libsvm-style file: %d rows x %d tokens, 
                "median_block_rate_* = rows of a block / (wait for the parser + key build incl. "
                "upload + step) for the median block of that epoch",
        "average_over_4_epochs_from_text": text4,
-       "wall_seconds_incl_predict": {"text_1_epoch": w_text, "cache_1_epoch": w_cache},
+       "wall_seconds_incl_predict": {"text_1_epoch": w_text, "cache_1_epoch": w_cache,
+                                     "text_1_epoch_gpu_tokeniser": w_gpu},
+       "git_head": (subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                                   capture_output=True, text=True).stdout.strip() or
+                    (open(os.path.join(ROOT, ".git_head")).read().strip()
+                     if os.path.exists(os.path.join(ROOT, ".git_head")) else None)),
        "measured_by": "tools/e2e_text.py"}
 os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)

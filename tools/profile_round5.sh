@@ -1,0 +1,59 @@
+#!/bin/bash
+# Round-5 evidence in one go (GPU box, repo root): bench lines, rocprofv3 kernel stats, and the
+# size-resolved PMC traffic (tools/pmc2.sh) of the workloads a number is quoted for.
+#   bash tools/profile_round5.sh gpurun_out/r05 [nopmc]
+set -u
+OUT=$1; MODE=${2:-}
+R=$PWD
+mkdir -p $OUT
+HEAD=$(cat .git_head 2>/dev/null || git rev-parse --short HEAD 2>/dev/null || echo unknown)
+line() {  # one line per bench JSON
+  python - "$1" <<'PY'
+import json, sys
+f = sys.argv[1]
+try:
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1], "%.4g ex/s" % d["value"], "%.4f ms" % d["ms_per_step"],
+          d.get("ms_per_step_repeats") and "median %.4f" % d["ms_per_step_repeats"]["median"],
+          {k: round(v * 1e3, 1) for k, v in d["kernels_ms"].items() if v},
+          "wkb", d.get("ms_per_step_with_key_build"), "frac", round(d["roofline"]["frac"], 3),
+          "logloss", d.get("logloss", {}).get("natural"))
+except Exception as e:
+    print(f, "FAILED", e)
+PY
+}
+stats() {  # stats <name> <command...>: rocprofv3 --kernel-trace --stats, the summary kept
+  local name=$1; shift
+  (cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv \
+      -d $R/$OUT/_$name -- "$@" > $R/$OUT/_$name.out 2> $R/$OUT/_$name.err)
+  cp $(find $OUT/_$name -name "*kernel_stats.csv" | head -1) $OUT/${name}_kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/_$name $OUT/_$name.out $OUT/_$name.err
+}
+N8="--rows 400000 --nnz-per-row 25 --keys-per-gpu 12500000 --signal-keys 0"
+N8O="$N8 --force-sharded --general-path --schedule owner --no-cpu-baseline"
+python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; line $OUT/bench_n1.json
+stats step python $R/bench.py --no-cpu-baseline --key-build-steps 0 --repeats 0 --no-fm-leg --no-zipf-leg --no-table-sweep
+stats key_build python $R/tools/kb_knobs.py --knobs 0 --iters 24 --step
+stats n8_key_build python $R/bench.py $N8O --steps 4 --warmup 2 --repeats 0 --batches 2 --no-owner-leg --key-build-steps 16
+stats sweep_1e8 python $R/bench.py --no-cpu-baseline --no-fm-leg --no-zipf-leg --steps 4 --warmup 2 --repeats 0 --batches 2 --key-build-steps 0 --sweep-keys 100000000
+stats fm python $R/tools/fm_leg.py --batches 4
+python bench.py --zipf 1.1 --no-cpu-baseline > $OUT/bench_zipf11.json 2> $OUT/bench_zipf11.err; line $OUT/bench_zipf11.json
+python bench.py $N8O --repeats 3 --batches 8 > $OUT/bench_n8_shard_shape_owner.json 2> $OUT/n8.err; line $OUT/bench_n8_shard_shape_owner.json
+XF_OWNER_TIMING_SOURCES=8 python bench.py $N8O --repeats 3 --batches 8 --no-owner-leg --key-build-steps 0 > $OUT/bench_n8_shard_shape_owner_8_pretended_sources.json 2> $OUT/n8s.err; line $OUT/bench_n8_shard_shape_owner_8_pretended_sources.json
+XF_OWNER_TIMING_SOURCES=8 python bench.py $N8O --repeats 3 --batches 8 --no-owner-leg --key-build-steps 0 --exp-knob 298 > $OUT/bench_n8_shard_shape_owner_8_pretended_sources_round4_pass.json 2> $OUT/n8s4.err; line $OUT/bench_n8_shard_shape_owner_8_pretended_sources_round4_pass.json
+python bench.py $N8 --no-cpu-baseline --repeats 3 --batches 8 --no-fm-leg --no-zipf-leg --no-table-sweep > $OUT/bench_n8_shard_shape_fused.json 2> $OUT/n8f.err; line $OUT/bench_n8_shard_shape_fused.json
+python bench.py --model fm --k 16 --optimizer sgd --no-cpu-baseline --repeats 3 --batches 8 > $OUT/bench_fm16_sgd.json 2> $OUT/bench_fm16_sgd.err; line $OUT/bench_fm16_sgd.json
+python bench.py --model fm --k 64 --optimizer ftrl --zipf 1.1 --no-cpu-baseline --repeats 3 --batches 8 > $OUT/bench_fm64_ftrl_zipf11.json 2> $OUT/bench_fm64_ftrl_zipf11.err; line $OUT/bench_fm64_ftrl_zipf11.json
+[ "$MODE" = "nopmc" ] && exit 0
+# memory-side traffic, request sizes resolved, calibration patterns in the same runs
+B="--steps 6 --warmup 8 --no-cpu-baseline --key-build-steps 0 --repeats 0 --no-fm-leg --no-zipf-leg --batches 8 --pmc-calibrate"
+bash tools/pmc2.sh $OUT lr python $R/bench.py $B --no-table-sweep 2>&1 | grep -v "^  k_\(build\|fill\|id_wr\|list\|move\|rehash\|take\|count\|cell\|blk\)"
+bash tools/pmc2.sh $OUT sweep_1e8 python $R/bench.py $B --batches 2 --sweep-keys 100000000 2>&1 | grep "k_lr\|pmc2"
+bash tools/pmc2.sh $OUT key_build python $R/tools/kb_knobs.py --knobs 0 --iters 8 --step --pmc-calibrate 2>&1 | grep "k_kb\|k_lr\|pmc2"
+XF_OWNER_TIMING_SOURCES=8 bash tools/pmc2.sh $OUT n8_shard_shape_owner_8_sources python $R/bench.py $N8O --no-owner-leg $B --no-table-sweep 2>&1 | grep "k_lr\|k_owner\|k_sum\|pmc2"
+rm -f $OUT/*_rd.json $OUT/*_wr.json
+for f in $OUT/pmc_traffic_*.json; do python - "$f" "$HEAD" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); d["git_head"] = sys.argv[2]; json.dump(d, open(sys.argv[1], "w"), indent=1)
+PY
+done

@@ -82,6 +82,7 @@ SIGNATURES = {
     "xf_ingest_create": (C.c_int, [C.POINTER(vp), C.c_size_t]),
     "xf_ingest_destroy": (C.c_int, [vp]),
     "xf_ingest_staging": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "xf_ingest_upload": (C.c_int, [vp, C.c_size_t, vp]),
     "xf_ingest_block": (C.c_int, [vp, vp, C.c_size_t, vp, C.POINTER(vp), C.POINTER(vp),
                                   C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int)]),

@@ -8,12 +8,14 @@
 //
 // What the GPU takes is the COMMON SHAPE of a block and nothing else — every line
 //     ('0' | '1') '\t' token (' ' token)* '\n'        token = field0 ':' fid ':' rest
-// with single blanks, no empty token, no blank before the line's end, no control bytes, field0
-// of at most 16 bytes, fid of at most 32 — for which the reference's parser yields: label =
-// the digit (atof("1") > 1e-7), one key per token = _Hash_bytes(fid), rows in file order.
-// Anything else (a label like "0.5", an empty token — which the reference turns into a
-// DUPLICATE of the previous token —, CR LF line ends, a NUL byte, a token without two colons
-// ...) raises a flag and the caller parses that block with xf_reader_next on the host: the
+// with single blanks, no empty token, no blank before the line's end, no NUL byte, one tab per
+// line, field0 of at most 16 bytes, fid of at most 32 — for which the reference's parser
+// yields: label = the digit (atof("1") > 1e-7), one key per token = _Hash_bytes(fid), rows in
+// file order.  (Every other byte is an ordinary byte to the reference and to this: the CR of a
+// CR LF file — the reference's own sample data is one — ends up in the last token's third
+// field, which nobody reads.)  Anything else (a label like "0.5", an empty token — which the
+// reference turns into a DUPLICATE of the previous token —, a NUL byte — where the reference
+// stops reading the block —, a token without two colons ...) raises a flag and the caller parses that block with xf_reader_next on the host: the
 // quirks live in one place, and a block is either wholly the GPU's or wholly the host's.
 // Results for accepted blocks are bit for bit the host parser's (tests/test_gpu_ingest.py: the
 // reference's sample files, the golden parses, a fuzz over well- and ill-formed blocks).
@@ -230,8 +232,7 @@ k_tok_emit(const uint8_t *__restrict__ text, uint32_t n, uint32_t span,
       const int i = (int)(i0 + k);
       if ((uint32_t)i >= lim) break;
       const uint32_t ch = T[i], prev = T[i - 1], prev2 = T[i - 2], next = T[i + 1];
-      // no NUL, no control byte but '\t' and '\n' (CR LF files are the host parser's)
-      bad |= (ch < 0x20u && ch != '\t' && ch != '\n') ? 1u : 0u;
+      bad |= ch == 0u ? 1u : 0u;  // (the reference stops at a NUL: the host parser's)
       if (prev == '\n') {  // a line starts: '0' | '1', then the tab (an empty line fails here)
         bad |= (ch != '0' && ch != '1') ? 1u : 0u;
         bad |= next != '\t' ? 1u : 0u;
@@ -279,6 +280,9 @@ k_tok_emit(const uint8_t *__restrict__ text, uint32_t n, uint32_t span,
 }  // namespace
 
 struct xf_ingest {
+  size_t uploaded = 0;          // xf_ingest_upload: bytes of text on their way to d_text (0: none)
+  size_t uploaded_n = 0;        // ... with the closing newline
+  hipEvent_t ev_up = nullptr;   // ... recorded behind that copy
   size_t cap_text = 0;          // bytes of text a block may hold
   uint32_t cap_rows = 0, cap_nnz = 0;
   uint8_t *d_text = nullptr;    // [cap_text rounded up + kTile + kHalo]
@@ -301,6 +305,7 @@ extern "C" int xf_ingest_destroy(xf_ingest *g) {
   if (g->d_wgcnt) (void)hipFree(g->d_wgcnt);
   if (g->d_counts) (void)hipFree(g->d_counts);
   if (g->h_counts) (void)hipHostFree(g->h_counts);
+  if (g->ev_up) (void)hipEventDestroy(g->ev_up);
   delete g;
   return XF_OK;
 }
@@ -331,6 +336,7 @@ extern "C" int xf_ingest_create(xf_ingest **out, size_t max_text_bytes) {
   XF_HIP(hipMalloc((void **)&g->d_wgcnt, kMaxWG * sizeof(uint2)));
   XF_HIP(hipMalloc((void **)&g->d_counts, sizeof(TokCounts)));
   XF_HIP(hipHostMalloc((void **)&g->h_counts, sizeof(TokCounts)));
+  XF_HIP(hipEventCreateWithFlags(&g->ev_up, hipEventDisableTiming));
   guard.g = nullptr;
   *out = g;
   return XF_OK;
@@ -346,8 +352,34 @@ extern "C" int xf_ingest_staging(xf_ingest *g, char **buf, size_t *cap) {
   return XF_OK;
 }
 
-// Tokenise `len` bytes of text: `text` == null: they are in the staging buffer; else they are
-// copied there first.  Uploads, runs the kernels, waits for the counts.  *ok = 0: the block is
+// every line of the text the kernels see ends in '\n' (a block that was cut at a newline comes
+// without it, a file may end without one), and the bytes past the text up to the tile + halo
+// the kernels may read are newlines: returns the length with the closing newline
+static size_t close_and_pad(xf_ingest *g, size_t len) {
+  size_t n = len;
+  if (g->h_text[n - 1] != '\n') g->h_text[n++] = '\n';
+  memset(g->h_text + n, '\n', padded(n) - n);
+  return n;
+}
+
+// The staged text (`len` bytes in the staging buffer) on its way to the device, asynchronously on
+// `stream` — the staging thread's own, so that the copy of block i + 1 runs while the GPU works
+// on block i.  The next xf_ingest_block(g, NULL, len, ...) waits for it on its stream instead of
+// copying; the staging buffer is free again when the copy has finished (xf_ingest_block returns).
+extern "C" int xf_ingest_upload(xf_ingest *g, size_t len, void *stream) {
+  XF_REQUIRE(g && len > 0 && len <= g->cap_text, "xf_ingest_upload: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = close_and_pad(g, len);
+  XF_HIP(hipMemcpyAsync(g->d_text, g->h_text, padded(n), hipMemcpyHostToDevice, s));
+  XF_HIP(hipEventRecord(g->ev_up, s));
+  g->uploaded = len;
+  g->uploaded_n = n;
+  return XF_OK;
+}
+
+// Tokenise `len` bytes of text: `text` == null: they are in the staging buffer (and, after
+// xf_ingest_upload, on their way to the device); else they are copied there first.  Uploads, runs
+// the kernels, waits for the counts.  *ok = 0: the block is
 // not of the common shape (or holds more rows / tokens than the arrays): the device arrays are
 // not to be used — parse the block on the host.  The device arrays stay valid until the next
 // call.
@@ -364,20 +396,23 @@ extern "C" int xf_ingest_block(xf_ingest *g, const char *text, size_t len, void 
   if (d_keys) *d_keys = g->d_keys;
   if (d_rowptr) *d_rowptr = g->d_rowptr;
   if (d_labels) *d_labels = g->d_labels;
+  const size_t up = g->uploaded, up_n = g->uploaded_n;
+  g->uploaded = 0;
   if (len == 0) {
     const uint32_t zero = 0;
     XF_HIP(hipMemcpyAsync(g->d_rowptr, &zero, 4, hipMemcpyHostToDevice, s));
     XF_HIP(hipStreamSynchronize(s));
     return XF_OK;
   }
-  if (text) memcpy(g->h_text, text, len);
-  size_t n = len;
-  // a block that was cut at a newline comes without it, a file may end without one: every
-  // line of the text the kernels see ends in '\n'
-  if (g->h_text[n - 1] != '\n') g->h_text[n++] = '\n';
-  const size_t pad = padded(n);
-  memset(g->h_text + n, '\n', pad - n);
-  XF_HIP(hipMemcpyAsync(g->d_text, g->h_text, pad, hipMemcpyHostToDevice, s));
+  size_t n;
+  if (!text && up == len) {  // xf_ingest_upload has sent it: its copy first, then the kernels
+    XF_HIP(hipStreamWaitEvent(s, g->ev_up, 0));
+    n = up_n;
+  } else {
+    if (text) memcpy(g->h_text, text, len);
+    n = close_and_pad(g, len);
+    XF_HIP(hipMemcpyAsync(g->d_text, g->h_text, padded(n), hipMemcpyHostToDevice, s));
+  }
   const uint32_t ntile = (uint32_t)((n + kTile - 1) / kTile);
   const uint32_t per = (ntile + kMaxWG - 1) / kMaxWG;
   const uint32_t span = per * kTile, nwg = (ntile + per - 1) / per;
