@@ -181,7 +181,7 @@ def test_worker_with_gpu_ingest_trains_the_same_model(tmp_path, model):
     token): with ingest = gpu the clean blocks are tokenised on the GPU, that one is handed back
     to the host parser — tables and metric line of ingest = host, bit for bit"""
     rng = np.random.RandomState(11)
-    clean = gen_block(rng, 9000, max_tok=14, fid_len=(1, 6), f0_len=(1, 2), rest_len=(1, 4))
+    clean = gen_block(rng, 30000, max_tok=14, fid_len=(1, 6), f0_len=(1, 2), rest_len=(1, 4))
     quirky = b"0.00000009\t1:22:0.5  3:4:1\n2e-7\t5:6:7\n"
     lines = clean.split(b"\n")[:-1]
     cut = len(lines) // 2
