@@ -213,6 +213,14 @@ def pmc_traffic(kernel, workload):
     return None
 
 
+def pmc_profile_head():
+    """the commit whose library the committed PMC profile was taken on (None: not recorded)"""
+    try:
+        return json.load(open(os.path.join(ROOT, PMC_PROFILE))).get("git_head")
+    except (OSError, ValueError):
+        return None
+
+
 def with_key_build(args, trainer, batches):
     """The whole LRWorker::update including its key build (lr_worker.cc:146-166) per step — raw
     CSR keys resident in HBM, xf_lr_update_dev = xf_batch_compile_local_dev (the range-partitioned
@@ -441,6 +449,7 @@ def fm_leg(args, batches):
     pmc = None   # the step's HBM traffic as the PMC passes of an earlier run measured it
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic_fm16_sgd.json")))
+        # (round 4's passes: the FM kernels have not changed since)
         by = sum(e["traffic"] for kk, e in prof["kernels"].items()
                  if kk.startswith(("k_fm_forward_scalars", "k_fm_grad_tiled")))
         same = (args.rows, args.nnz_per_row, args.keys_per_gpu) == (50000, 200, 10_000_000) \
@@ -1516,7 +1525,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_kernel + dom_note, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(dom_kernel, workload),
-                     "traffic_source": PMC_SOURCE,
+                     "traffic_source": PMC_SOURCE, "traffic_profile_commit": pmc_profile_head(),
                      "algorithmic_bytes_per_launch": per[dom],
                      "algorithmic_bytes_source": "SURVEY.md 8(d)"
                      if fused or (args.model == "fm" and one_shard and dom == "gradient") else
@@ -1589,8 +1598,9 @@ def main():
             out["logloss"]["learning_check"] = {"error": str(e)}
     try:   # end to end from text / from the binarized block cache: tools/e2e_text.py's last run
         out["end_to_end"] = json.load(open(os.path.join(ROOT, "profiles", "e2e_latest.json")))
-        out["end_to_end"]["source"] = "committed profile profiles/e2e_latest.json (an earlier " \
-                                      "run of tools/e2e_text.py), NOT measured by this run"
+        out["end_to_end"]["source"] = "committed profile profiles/e2e_latest.json (a run of " \
+                                      "tools/e2e_text.py on the library of commit %s), NOT " \
+                                      "measured by this run" % out["end_to_end"].get("git_head")
     except (OSError, ValueError):
         out["end_to_end"] = None
     if dist is not None:
