@@ -1,12 +1,12 @@
 #!/bin/bash
-# gpurun_out/<run> (written by tools/profile_round4.sh on the GPU box) -> profiles/r04 (tracked):
+# gpurun_out/<run> (written by tools/profile_round<N>.sh on the GPU box) -> profiles/r<N> (tracked):
 # the JSON lines and summaries as they are, the raw counter files cut down to the kernels the
 # numbers are quoted for (the step's, the key build's and the calibration kernels).
-#   bash tools/collect_profiles.sh gpurun_out/r04 profiles/r04
+#   bash tools/collect_profiles.sh gpurun_out/r05 profiles/r05
 set -e
 SRC=$1; DST=$2
 mkdir -p $DST
-cp $SRC/bench_*.json $SRC/pmc_traffic_*.json $SRC/*_kernel_stats.csv $SRC/fm_leg.json $DST/ 2>/dev/null || true
+cp $SRC/bench_*.json $SRC/pmc_traffic_*.json $SRC/*_kernel_stats.csv $SRC/fm_leg.json $SRC/e2e.json $DST/ 2>/dev/null || true
 for f in $SRC/pmc_rd_*_counter_collection.csv $SRC/pmc_wr_*_counter_collection.csv; do
   [ -f "$f" ] || continue
   python3 - "$f" "$DST/$(basename $f)" <<'PY'
