@@ -550,7 +550,10 @@ int xf_sharded_defrag(xf_sharded *st); /* local table maintenance (flushes first
 int xf_sharded_check(xf_sharded *st);  /* flush + the tables' sticky errors */
 int xf_sharded_set_schedule(xf_sharded *st, int schedule);
 /* the parity mode of the forward (xf_workspace_parity) for a one-rank trainer whose minibatches
- * carry a key list (host_key_build, or FM) */
+ * carry a key list (host_key_build, or FM).  Set it BEFORE compiling the minibatches it is to
+ * apply to: an FM minibatch compiled in the default mode against the tables' settled tiers
+ * (xf_sbatch_fm_keyed) has no index of its key list, and the reference-order kernels refuse it
+ * (the call says so and names this remedy) */
 int xf_sharded_set_parity(xf_sharded *st, int mode);
 int xf_sharded_tables(xf_sharded *st, xf_table **w, xf_table **v);
 int xf_sharded_stream(xf_sharded *st, void **stream);

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Experiment driver (GPU box): the LR step of the config-2 shape under the exp_knob variants
-of the cells kernels (parts switched off to see what each part costs).  Not a benchmark."""
+of the cells kernels (parts switched off to see what each part costs).  Not a benchmark.
+The timing-only variants (knobs 308 ... 400: they give WRONG tables) exist only in a library built
+with XF_EXTRA_FLAGS=-DXF_EXPERIMENTS (python -m xflow_amd.build, or tools/build_variant.sh); the
+product library refuses them."""
 import argparse
 import json
 import os

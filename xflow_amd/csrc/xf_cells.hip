@@ -884,8 +884,13 @@ namespace {
 constexpr uint32_t kMultiWin = 64;
 constexpr uint32_t kMultiSrc = 64;
 constexpr uint32_t kMultiAny = 0x8000u;  // mark: the key has been touched by some worker
+constexpr uint32_t kMultiCap = 512;      // SLOTS: entries of one worker in a chunk
 
-template <int OPT, int NT>
+// SLOTS: the key sums of a phase live in kMultiCap accumulators indexed by the STEPPING lane's
+// position among the worker's entries instead of 2048 indexed by key (4 KiB of LDS instead of
+// 16: four workgroups per CU instead of three).  A phase is then mark -> barrier -> add to the
+// stepping lane's slot -> barrier -> step -> barrier: one barrier more.
+template <int OPT, int NT, bool SLOTS = false>
 __global__ void __launch_bounds__(NT)
 k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
@@ -896,7 +901,8 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
                 uint8_t *__restrict__ item_done) {
   constexpr int E = (int)(kChunk / NT);  // entries per lane = state rows per thread
   constexpr bool FTRL = OPT == XF_OPT_FTRL;
-  __shared__ double acc[kChunk];
+  __shared__ double acc[SLOTS ? kMultiCap : kChunk];
+  __shared__ uint32_t over;
   __shared__ float sw[kChunk];
   __shared__ float2 snz[FTRL ? kChunk : 1];
   __shared__ uint16_t mark[kChunk];
@@ -932,6 +938,7 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
     wsrc[tid] = (uint8_t)q;
   }
   if (tid < nsrc) srow[tid] = src_rows[tid];
+  if (tid == 0) over = 0;
   __syncthreads();
   if (tid < 64) {  // cum = inclusive scan of the windows' entry counts (one wavefront)
     uint32_t inc = tid < nwin ? cum[tid + 1] : 0u;
@@ -949,8 +956,16 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
     if (tid == 0) item_done[blockIdx.x] = 0;
     return;
   }
-  if (tid == 0) item_done[blockIdx.x] = 1;
   if (tid <= nsrc) spos[tid] = cum[src_win[tid]];  // worker q's entries: positions [spos[q], spos[q+1])
+  if (SLOTS) {  // every worker's entries must fit the slots (else: the general kernel's)
+    if (tid < nsrc && cum[src_win[tid + 1]] - cum[src_win[tid]] > kMultiCap) over = 1;
+    __syncthreads();
+    if (over) {  // workgroup-uniform
+      if (tid == 0) item_done[blockIdx.x] = 0;
+      return;
+    }
+  }
+  if (tid == 0) item_done[blockIdx.x] = 1;
   // per entry: the key's place in the chunk and its worker in ONE register, the loss in another
   uint32_t ek[E];
   float l[E];
@@ -988,11 +1003,13 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const uint32_t k = tid + i * NT;
-    acc[k] = 0.0;
+    if (!SLOTS) acc[k] = 0.0;
     mark[k] = 0;
     sw[k] = rw[i];
     if (FTRL) snz[k] = rnz[i];
   }
+  if (SLOTS)
+    for (uint32_t k = tid; k < kMultiCap; k += NT) acc[k] = 0.0;
   __syncthreads();
   for (uint32_t q = 0; q < nsrc; ++q) {
     const uint32_t pb = spos[q], pe = spos[q + 1];
@@ -1002,18 +1019,28 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (int i = 0; i < E; ++i)
       if (i >= ib && i <= ie && (ek[i] >> 16) == q) {  // (a hole's worker is 0xFFFF)
         const uint32_t k = ek[i] & (kChunk - 1);
-        atomicAdd(&acc[k], (double)l[i]);
+        if (!SLOTS) atomicAdd(&acc[k], (double)l[i]);
         mark[k] = (uint16_t)(kMultiAny | (uint32_t)(i * NT + tid));
       }
     __syncthreads();
+    if (SLOTS) {  // the sums where the stepping lanes will look for them
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+        if (i >= ib && i <= ie && (ek[i] >> 16) == q) {
+          const uint32_t k = ek[i] & (kChunk - 1);
+          atomicAdd(&acc[(mark[k] & (kMultiAny - 1u)) - pb], (double)l[i]);
+        }
+      __syncthreads();
+    }
     const uint32_t rq = srow[q];
 #pragma unroll
     for (int i = 0; i < E; ++i)
       if (i >= ib && i <= ie && (ek[i] >> 16) == q) {
         const uint32_t k = ek[i] & (kChunk - 1);
         if ((mark[k] & (kMultiAny - 1u)) != (uint32_t)(i * NT + tid)) continue;  // not its stepper
-        const double sum = acc[k];
-        acc[k] = 0.0;  // the next worker's phase starts from zero
+        const uint32_t slot = SLOTS ? (uint32_t)(i * NT + tid) - pb : k;
+        const double sum = acc[slot];
+        acc[slot] = 0.0;  // the next worker's phase starts from zero
         const float g = xf::div_by_rows((float)sum, rq);  // lr_worker.cc:117
         float w = sw[k];
         if (FTRL) {
@@ -1590,7 +1617,12 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
         // 512 threads per chunk (four entries per lane, 61 registers, 24 wavefronts per CU at
         // the three workgroups its LDS allows): 164 us at the N = 8 shard shape where 256 threads
         // (97 registers, 12 wavefronts) take 193 — exp_knob 297 runs the latter
-        if (exp_knob() == 296)  // (experiment: 1024 threads, two workgroups = 32 wavefronts per CU)
+        if (exp_knob() == 295)  // (experiment: SLOTS, four workgroups per CU)
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+        else if (exp_knob() == 296)  // (experiment: 1024 threads, two workgroups = 32 wavefronts per CU)
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 1024>), dim3(c->nitems), dim3(1024), 0, s, T,
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,

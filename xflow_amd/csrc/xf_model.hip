@@ -2100,7 +2100,9 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
                        ws->parity == XF_PARITY_EXACT_SUMS && v.U && v.R;
   XF_REQUIRE(!b->fm_keyed || recmode || !v.U,
              "a minibatch of xf_batch_compile_fm_dev steps on the table-resident records only "
-             "(k in {4, 8, 16, 32, 64}, no capture, no parity mode): use xf_batch_compile_dev");
+             "(k in {4, 8, 16, 32, 64}, no capture, no parity mode): it has no index of its key "
+             "list.  Compile it again after the parity / capture mode is set (xf_sharded_compile "
+             "then picks the sort-based build), or with xf_batch_compile_dev");
   bool fresh = false;
   XF_TRY(fm_resolve_rows(w, vt, b, ws, stream, !recmode, &fresh));
   const uint32_t *rows_w = v.U ? b->d_fm_rows[0] : ws->slots;

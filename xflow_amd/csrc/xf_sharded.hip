@@ -1676,6 +1676,9 @@ extern "C" int xf_sharded_set_parity(xf_sharded *st, int mode) {
              "xf_sharded_set_parity: the reference-order forward needs minibatches with a key "
              "list (host_key_build)");
   XF_TRY(xf_workspace_parity(st->ws, mode));
+  // (FM minibatches compiled so far in the default mode may be keyed — no index of their key
+  // list: the reference-order step refuses those; minibatches compiled from here on are built
+  // for the mode set)
   st->parity_mode = mode;
   return XF_OK;
 }
