@@ -120,8 +120,18 @@ k_plan_items(const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwi
   const uint32_t per = (nchunk + kPlanBlock - 1) / kPlanBlock;
   const uint32_t c0 = min(tid * per, nchunk), c1 = min(c0 + per, nchunk);
   auto slices = [&](uint32_t c) -> uint32_t {
-    uint32_t n = 0;
-    for (uint32_t v = 0; v < nwin; ++v)
+    uint32_t n = 0, v = 0;
+    for (; v + 4 <= nwin; v += 4) {  // (four windows' bounds requested at a time)
+      uint32_t b[4], e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        b[k] = cellptr[(size_t)(v + k) * nchunk + c];
+        e[k] = cellptr[(size_t)(v + k) * nchunk + c + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) n += e[k] - b[k];
+    }
+    for (; v < nwin; ++v)
       n += cellptr[(size_t)v * nchunk + c + 1] - cellptr[(size_t)v * nchunk + c];
     return (n + kSliceMax - 1) / kSliceMax;
   };
@@ -673,16 +683,19 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       uint32_t ent[kGradE], vq[kGradE];
       float l[kGradE];
       // the window of position p: the last v with cum[v] <= p, by a search whose steps are
-      // selects (five LDS reads per entry, the eight entries' searches side by side; a walk
-      // `while (p >= cum[v + 1]) ++v` was a chain of dependent LDS reads — thirty of them per
-      // thread at 32 windows).  Every lane loads (past the end: the last entry, dropped).
+      // selects (log2(windows) LDS reads per entry, the eight entries' searches side by side; a
+      // walk `while (p >= cum[v + 1]) ++v` was a chain of dependent LDS reads — thirty of them
+      // per thread at 32 windows).  The first step is the largest power of two below the number
+      // of windows (wave-uniform: three windows search in two steps — five unrolled ones cost
+      // the power-law gradient 8 us).  Every lane loads (past the end: the last entry, dropped).
+      uint32_t st0 = 1;
+      while (st0 * 2 < nv) st0 *= 2;
 #pragma unroll
       for (int q = 0; q < kGradE; ++q) {
         const uint32_t p = p0 + q * kBlock + tid;
         const uint32_t pc = min(p, total - 1);
         uint32_t v = 0;
-#pragma unroll
-        for (uint32_t st = kGradWin / 2; st > 0; st >>= 1) {
+        for (uint32_t st = st0; st > 0; st >>= 1) {  // wave-uniform trip count
           const uint32_t t = v + st;
           v = (t < nv && cum[t] <= pc) ? t : v;
         }
@@ -971,13 +984,14 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   float l[E];
   if (total) {
     uint32_t vq[E], en[E];
+    uint32_t st0 = 1;
+    while (st0 * 2 < nwin) st0 *= 2;
 #pragma unroll
     for (int q = 0; q < E; ++q) {  // (the window of a position: see k_lr_grad_cells)
       const uint32_t p = q * NT + tid;
       const uint32_t pc = min(p, total - 1);
       uint32_t v = 0;
-#pragma unroll
-      for (uint32_t st = kMultiWin / 2; st > 0; st >>= 1) {
+      for (uint32_t st = st0; st > 0; st >>= 1) {  // wave-uniform trip count
         const uint32_t t = v + st;
         v = (t < nwin && cum[t] <= pc) ? t : v;
       }
