@@ -686,8 +686,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       // selects (log2(windows) LDS reads per entry, the eight entries' searches side by side; a
       // walk `while (p >= cum[v + 1]) ++v` was a chain of dependent LDS reads — thirty of them
       // per thread at 32 windows).  The first step is the largest power of two below the number
-      // of windows (wave-uniform: three windows search in two steps — five unrolled ones cost
-      // the power-law gradient 8 us).  Every lane loads (past the end: the last entry, dropped).
+      // of windows (wave-uniform: three windows search in two steps).  The loads themselves stay
+      // under the lane's mask (see k_lr_grad_dense).
       uint32_t st0 = 1;
       while (st0 * 2 < nv) st0 *= 2;
 #pragma unroll
@@ -700,15 +700,17 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
           v = (t < nv && cum[t] <= pc) ? t : v;
         }
         vq[q] = v;
-        const uint32_t e = entries[sbase[v] + (pc - cum[v])];
-        ent[q] = p < total ? e : 0xFFFFFFFFu;
+        uint32_t e = 0xFFFFFFFFu;
+        if (p < total) e = entries[sbase[v] + (pc - cum[v])];
+        ent[q] = e;
       }
 #pragma unroll
       for (int q = 0; q < kGradE; ++q) {
-        const bool on = ent[q] != 0xFFFFFFFFu;
-        const size_t base = loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W;
-        const float x = loss[on ? base + ((ent[q] >> kChunkBits) & kRowMask) : (size_t)0];
-        l[q] = on ? x : 0.0f;
+        float x = 0.0f;
+        if (ent[q] != 0xFFFFFFFFu)
+          x = loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
+                   ((ent[q] >> kChunkBits) & kRowMask)];
+        l[q] = x;
       }
       if constexpr (SRC)  // (the owner's passes: their registers stay where they were)
 #pragma unroll
@@ -996,15 +998,16 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
         v = (t < nwin && cum[t] <= pc) ? t : v;
       }
       vq[q] = v;
-      const uint32_t e = entries[sbase[v] + (pc - cum[v])];
-      en[q] = p < total ? e : 0xFFFFFFFFu;
+      uint32_t e = 0xFFFFFFFFu;
+      if (p < total) e = entries[sbase[v] + (pc - cum[v])];
+      en[q] = e;
     }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const bool on = en[q] != 0xFFFFFFFFu;  // (a hole: the key went to the arrival segment)
-      const float x =
-          loss[on ? (size_t)loss_base[vq[q]] + ((en[q] >> kChunkBits) & kRowMask) : (size_t)0];
-      l[q] = on ? x : 0.0f;
+      float x = 0.0f;
+      if (on) x = loss[(size_t)loss_base[vq[q]] + ((en[q] >> kChunkBits) & kRowMask)];
+      l[q] = x;
       ek[q] = on ? (en[q] & (kChunk - 1)) | ((uint32_t)wsrc[vq[q]] << 16) : 0xFFFFFFFFu;
     }
   } else {
@@ -1187,10 +1190,13 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (uint32_t k = tid; k < kChunk; k += NT) touched[k] = 1;
   }
   // Entry p of the chunk's index space sits at entries[p + d], d = the offset of p's window
-  // (wave-uniform numbers).  Selects, not branches, and loads that every lane issues (a lane
-  // past the end re-reads the last entry and drops it): written with `if (p < total)` around
-  // nested ?: the compiler built a tree of divergent branches — ~75 instructions, a dozen
-  // s_cbranch among them, per entry loaded (round 4's "~45 instructions per entry").
+  // (wave-uniform numbers).  Selects, not branches: written with `if (p < total)` around nested
+  // ?: the compiler built a tree of divergent branches — ~75 instructions, a dozen s_cbranch
+  // among them, per entry loaded (round 4's "~45 instructions per entry").  Only the loads stay
+  // under the lane's mask: a chunk's last round is mostly idle lanes (2087 entries: 39 in the
+  // second round), and with every lane loading — the same address, dropped afterwards — the
+  // kernel took 1.5 us more, the power-law gradient 7 (a lane's load costs its TA cycle whatever
+  // it hits).
   const uint32_t d0 = cb0, d1 = cb1 - c1, d2 = cb2 - c2, d3 = cb3 - c3;
   for (uint32_t p0 = 0; p0 < total; p0 += NT * kOwn) {  // workgroup-uniform trip count
     uint32_t ent[kOwn], lidx[kOwn];
@@ -1206,15 +1212,16 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       li = pc >= c2 ? 2u * W : li;
       d = pc >= c3 ? d3 : d;
       li = pc >= c3 ? 3u * W : li;
-      const uint32_t e = entries[pc + d];
-      ent[q] = p < total ? e : 0xFFFFFFFFu;
+      uint32_t e = 0xFFFFFFFFu;
+      if (p < total) e = entries[pc + d];  // (the load alone under the lane's mask)
+      ent[q] = e;
       lidx[q] = li;
     }
 #pragma unroll
     for (int q = 0; q < kOwn; ++q) {
-      const bool on = ent[q] != 0xFFFFFFFFu;
-      const float x = loss[on ? lidx[q] + ((ent[q] >> kChunkBits) & kRowMask) : 0u];
-      l[q] = on ? x : 0.0f;
+      float x = 0.0f;
+      if (ent[q] != 0xFFFFFFFFu) x = loss[lidx[q] + ((ent[q] >> kChunkBits) & kRowMask)];
+      l[q] = x;
     }
 #pragma unroll
     for (int q = 0; q < kOwn; ++q)
@@ -1628,12 +1635,13 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
     if (multi) {
       if constexpr (MODE == 0) {
         const int full = dense_touch(c) ? 1 : 0;
-        // 512 threads per chunk (four entries per lane, 61 registers, 24 wavefronts per CU at
-        // the three workgroups its LDS allows): 164 us at the N = 8 shard shape where 256 threads
-        // (97 registers, 12 wavefronts) take 193 — exp_knob 297 runs the latter
-        if (exp_knob() == 295)  // (experiment: SLOTS, four workgroups per CU)
-          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s, T,
-                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+        // 512 threads per chunk (four entries per lane, 64 registers), the key sums in the
+        // stepping lanes' slots (SLOTS: 34 KB of LDS, four workgroups = 32 wavefronts per CU):
+        // 140 us at the N = 8 shard shape; the sums indexed by key (46 KB, three workgroups): 155
+        // (exp_knob 295); 256 threads: 164-193 (297); 1024: 183 (296)
+        if (exp_knob() == 295)  // (the key sums indexed by key: three workgroups per CU, 155 us)
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, false>), dim3(c->nitems), dim3(512), 0, s,
+                             T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
         else if (exp_knob() == 296)  // (experiment: 1024 threads, two workgroups = 32 wavefronts per CU)
@@ -1646,9 +1654,9 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
-        else
-          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512>), dim3(c->nitems), dim3(512), 0, s, T,
-                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+        else  // SLOTS: the key sums in the stepping lanes' slots, four workgroups per CU: 140 us
+          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s,
+                             T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
       }
