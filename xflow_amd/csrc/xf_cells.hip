@@ -682,36 +682,28 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (uint32_t p0 = 0; p0 < total; p0 += kBlock * kGradE) {  // workgroup-uniform trip count
       uint32_t ent[kGradE], vq[kGradE];
       float l[kGradE];
-      // the window of position p: the last v with cum[v] <= p, by a search whose steps are
-      // selects (log2(windows) LDS reads per entry, the eight entries' searches side by side; a
-      // walk `while (p >= cum[v + 1]) ++v` was a chain of dependent LDS reads — thirty of them
-      // per thread at 32 windows).  The first step is the largest power of two below the number
-      // of windows (wave-uniform: three windows search in two steps).  The loads themselves stay
-      // under the lane's mask (see k_lr_grad_dense).
-      uint32_t st0 = 1;
-      while (st0 * 2 < nv) st0 *= 2;
+      // (the window of position p by a walk: p ascends with q, v never goes back.  A search of
+      // selects — log2(windows) LDS reads per entry, the eight entries' searches side by side —
+      // was measured in round 5: no different at 32 windows (107 vs 108 us), and the power-law
+      // gradient, three windows, 7 us slower with it.)
+      uint32_t v = 0;
 #pragma unroll
       for (int q = 0; q < kGradE; ++q) {
         const uint32_t p = p0 + q * kBlock + tid;
-        const uint32_t pc = min(p, total - 1);
-        uint32_t v = 0;
-        for (uint32_t st = st0; st > 0; st >>= 1) {  // wave-uniform trip count
-          const uint32_t t = v + st;
-          v = (t < nv && cum[t] <= pc) ? t : v;
+        ent[q] = 0xFFFFFFFFu;
+        vq[q] = 0;
+        if (p < total) {
+          while (p >= cum[v + 1]) ++v;
+          vq[q] = v;
+          ent[q] = entries[sbase[v] + (p - cum[v])];
         }
-        vq[q] = v;
-        uint32_t e = 0xFFFFFFFFu;
-        if (p < total) e = entries[sbase[v] + (pc - cum[v])];
-        ent[q] = e;
       }
 #pragma unroll
-      for (int q = 0; q < kGradE; ++q) {
-        float x = 0.0f;
-        if (ent[q] != 0xFFFFFFFFu)
-          x = loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
-                   ((ent[q] >> kChunkBits) & kRowMask)];
-        l[q] = x;
-      }
+      for (int q = 0; q < kGradE; ++q)
+        l[q] = ent[q] != 0xFFFFFFFFu
+                   ? loss[(loss_base ? (size_t)loss_base[v0 + vq[q]] : (size_t)(v0 + vq[q]) * W) +
+                          ((ent[q] >> kChunkBits) & kRowMask)]
+                   : 0.0f;
       if constexpr (SRC)  // (the owner's passes: their registers stay where they were)
 #pragma unroll
         for (int q = 0; q < kGradE; ++q)
