@@ -124,6 +124,21 @@ int Worker::create_tables() {
   return XF_OK;
 }
 
+// ingest = gpu: the two staging buffers (pinning 2 x block_size of host memory costs tens of ms)
+// and the tokeniser's first launches: start-up work like the two-row update of create_tables
+int Worker::start_ingest() {
+  if (!ingest_gpu) return XF_OK;
+  for (int i = 0; i < 2; ++i)
+    if (!ingest_[i]) XF_TRY(xf_ingest_create(&ingest_[i], (size_t)block_size << 20));
+  static const char two_rows[] = "0\t1:2:0.5 3:4:1\n1\t5:6:0.25\n";
+  void *stream = nullptr;
+  XF_TRY(xf_sharded_stream(sharded_, &stream));
+  uint32_t R = 0, NNZ = 0;
+  int ok = 0;
+  return xf_ingest_block(ingest_[0], two_rows, sizeof(two_rows) - 1, stream, nullptr, nullptr,
+                         nullptr, &R, &NNZ, &ok);
+}
+
 // percent: settle the table when more than that share of its keys has arrived since the last
 // time (5 at the epoch boundaries; inside the first epoch, one worker: 30 — the key build of
 // the blocks still to come finds settled keys where they sit in LDS, arrival keys by a probe
@@ -606,6 +621,7 @@ int Worker::predict(int rank, int block, bool reader) {
 // train (lr_worker.cc:207-217, fm_worker.cc:277-287)
 int Worker::train() {
   XF_TRY(create_tables());
+  XF_TRY(start_ingest());
   std::cout << "my rank is = " << rank << std::endl;
   snprintf(train_data_path, sizeof(train_data_path), "%s-%05d", train_file_path.c_str(), rank);
   if (!model_in.empty()) {  // resume from a model file (XFLoadModel)

@@ -82,6 +82,7 @@ class Worker {
   // memory, allocated once per worker (pinning and unpinning ~200 MB per epoch cost 30-80 ms)
   xf_block *blocks_[2] = {nullptr, nullptr};
   xf_ingest *ingest_[2] = {nullptr, nullptr};  // ingest = gpu: two staging / tokeniser buffers
+  int start_ingest();                          // the buffers + first launches, before the clock
   int text_epoch(int epoch, int keep);         // one epoch from the text, tokenised on the GPU
   std::vector<std::thread> closers_;  // readers being closed (munmap of the text) off the clock
   long rows_trained_ = 0;
