@@ -563,7 +563,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
     world-2 / 3 / 8 tests against the oracle, which run the same kernel.)  exp_knob 78: the
     owner's cells through the two-level key build (nonzeros with row numbers)."""
     ctx = mp.get_context("spawn")
-    for knob in (298, 0, 294, 297, 296, 295, 78):
+    for knob in (298, 0, 297, 296, 295, 78):
         q = ctx.Queue()
         p = ctx.Process(target=_pretend_rank, args=(free_port(), knob, str(tmp_path), q))
         p.start()
@@ -572,7 +572,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
         assert not err, err
     ref = np.load(str(tmp_path / "pretend_298.npz"))
     assert len(ref["k"]) > 100000 and np.any(ref["w"] != 0)
-    for knob in (0, 294, 297, 296, 295, 78):
+    for knob in (0, 297, 296, 295, 78):
         got = np.load(str(tmp_path / ("pretend_%d.npz" % knob)))
         for f in ("k", "w", "n", "z"):
             same(got[f], ref[f])

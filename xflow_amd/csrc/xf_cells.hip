@@ -896,10 +896,11 @@ constexpr uint32_t kMultiCap = 512;      // SLOTS: entries of one worker in a ch
 // SLOTS: the key sums of a phase live in kMultiCap accumulators indexed by the STEPPING lane's
 // position among the worker's entries instead of 2048 indexed by key (4 KiB of LDS instead of
 // 16: four workgroups per CU instead of three).  A phase is then mark -> barrier -> add to the
-// stepping lane's slot -> barrier -> step -> barrier: one barrier more.
-// PP (with SLOTS): two mark arrays that swap roles, so that the NEXT worker's marks are written in
-// the same interval as this worker's steps (other lanes, other array): two barriers per phase.
-template <int OPT, int NT, bool SLOTS = false, bool PP = false>
+// stepping lane's slot -> barrier -> step -> barrier: one barrier more.  (Tried: two mark arrays
+// that swap roles, the next worker's marks written in the interval of this worker's steps — two
+// barriers per phase instead of three: 142 -> 175 us at the N = 8 shard shape, 72 registers
+// instead of 64 and the marks' stores in the way of the steps' LDS traffic.)
+template <int OPT, int NT, bool SLOTS = false>
 __global__ void __launch_bounds__(NT)
 k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
@@ -915,7 +916,6 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   __shared__ float sw[kChunk];
   __shared__ float2 snz[FTRL ? kChunk : 1];
   __shared__ uint16_t mark[kChunk];
-  __shared__ uint16_t mark2[PP ? kChunk : 1];
   __shared__ uint32_t cum[kMultiWin + 1], sbase[kMultiWin];
   __shared__ uint32_t spos[kMultiSrc + 1], srow[kMultiSrc];
   __shared__ uint8_t wsrc[kMultiWin];
@@ -1017,70 +1017,12 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
     const uint32_t k = tid + i * NT;
     if (!SLOTS) acc[k] = 0.0;
     mark[k] = 0;
-    if (PP) mark2[k] = 0;
     sw[k] = rw[i];
     if (FTRL) snz[k] = rnz[i];
   }
   if (SLOTS)
     for (uint32_t k = tid; k < kMultiCap; k += NT) acc[k] = 0.0;
   __syncthreads();
-  if (PP) {
-    static_assert(!PP || SLOTS, "PP needs SLOTS");
-    auto next_worker = [&](uint32_t q) -> uint32_t {  // workgroup-uniform
-      while (q < nsrc && spos[q] == spos[q + 1]) ++q;
-      return q;
-    };
-    auto set_marks = [&](uint32_t q, uint16_t *mk) {
-      const uint32_t pb = spos[q], pe = spos[q + 1];
-      const int ib = (int)(pb / NT), ie = (int)((pe - 1) / NT);
-#pragma unroll
-      for (int i = 0; i < E; ++i)
-        if (i >= ib && i <= ie && (ek[i] >> 16) == q)
-          mk[ek[i] & (kChunk - 1)] = (uint16_t)(kMultiAny | (uint32_t)(i * NT + tid));
-    };
-    uint32_t q = next_worker(0);
-    uint16_t *mk = mark, *mo = mark2;
-    if (q < nsrc) set_marks(q, mk);
-    __syncthreads();
-    while (q < nsrc) {
-      const uint32_t pb = spos[q], pe = spos[q + 1];
-      const int ib = (int)(pb / NT), ie = (int)((pe - 1) / NT);
-#pragma unroll
-      for (int i = 0; i < E; ++i)
-        if (i >= ib && i <= ie && (ek[i] >> 16) == q) {
-          const uint32_t k = ek[i] & (kChunk - 1);
-          atomicAdd(&acc[(mk[k] & (kMultiAny - 1u)) - pb], (double)l[i]);
-        }
-      __syncthreads();
-      const uint32_t qn = next_worker(q + 1);
-      if (qn < nsrc) set_marks(qn, mo);  // (other lanes, the other array)
-      const uint32_t rq = srow[q];
-#pragma unroll
-      for (int i = 0; i < E; ++i)
-        if (i >= ib && i <= ie && (ek[i] >> 16) == q) {
-          const uint32_t k = ek[i] & (kChunk - 1);
-          if ((mk[k] & (kMultiAny - 1u)) != (uint32_t)(i * NT + tid)) continue;  // not its stepper
-          const uint32_t slot = (uint32_t)(i * NT + tid) - pb;
-          const double sum = acc[slot];
-          acc[slot] = 0.0;
-          const float g = xf::div_by_rows((float)sum, rq);  // lr_worker.cc:117
-          float w = sw[k];
-          if (FTRL) {
-            float2 s2 = snz[k];
-            xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, s2.x, s2.y);
-            snz[k] = s2;
-          } else {
-            w = xf::sgd_step(T.lr, g, w);
-          }
-          sw[k] = w;
-        }
-      __syncthreads();
-      q = qn;
-      uint16_t *t = mk;
-      mk = mo;
-      mo = t;
-    }
-  } else
   for (uint32_t q = 0; q < nsrc; ++q) {
     const uint32_t pb = spos[q], pe = spos[q + 1];
     if (pb == pe) continue;  // workgroup-uniform: nothing of this worker in the chunk
@@ -1130,7 +1072,7 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   for (int i = 0; i < E; ++i) {
     const uint32_t k = tid + i * NT;
     if (row0 + k >= M) continue;
-    if (!full_store && !((mark[k] | (PP ? mark2[k] : (uint16_t)0)) & kMultiAny)) continue;
+    if (!full_store && !(mark[k] & kMultiAny)) continue;
     T.w[row0 + k] = sw[k];
     if (FTRL) T.nz[row0 + k] = snz[k];
   }
@@ -1702,11 +1644,6 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
-        else if (exp_knob() == 294)  // (the marks in two arrays that swap roles: two barriers per phase)
-          hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true, true>), dim3(c->nitems), dim3(512), 0,
-                             s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
-                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
-                             src->d_loss_base, c->chunk0, full, c->item_done);
         else if (exp_knob() == 297)
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 256>), dim3(c->nitems), dim3(256), 0, s, T,
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
@@ -1751,13 +1688,17 @@ static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss
         const int knob = exp_knob();
         if (knob >= 300 && knob < 812) var = knob - 300;  // (experiments: tools/cells_knobs.py)
         dense = knob != 299;                               // 299: the general kernel alone
+        // (experiment, exp_knob 281..287: at most knob - 280 workgroups per CU, by a pad of
+        // dynamic LDS the kernel never touches — rounds of workgroups that come out even)
+        size_t lds_pad = 0;
+        if (knob > 280 && knob < 288) lds_pad = (size_t)160 * 1024 / (knob - 280 + 1) + 512 - 18432;
         if (dense) {
 #define XF_DENSE(V)                                                                              \
   case V:                                                                                        \
     hipLaunchKernelGGL((k_lr_grad_dense<OPT, V>),                                                \
                        dim3(((V) & kDenseQuad) && dense_team(V) * 4 <= 1024 ? (c->nitems + 3) / 4 \
                                                                             : c->nitems),        \
-                       dim3(dense_threads(V)), 0,                                                \
+                       dim3(dense_threads(V)), lds_pad,                                          \
                        s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
                        d_loss, c->R, c->M, c->chunk0, c->nitems);                                \
     break
