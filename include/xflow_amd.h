@@ -322,6 +322,15 @@ int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_, float *z_,
                     size_t cap_entries, size_t *n_out);
 int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, const float *w,
                     const float *n_, const float *z_);
+/* *yes = 1: the LR gradient + Push kernels derive a key's old weight from the (n, z) they load
+ * anyway instead of reading it — the w an FTRL step leaves is a function of the n and z it
+ * leaves (ftrl.h:66-73), so the stored w is that function's value, bit for bit, as long as every
+ * row was written by steps under the table's present hyper-parameters (or never: 0, 0, 0).
+ * An FTRL table of dim 1 starts that way; it stops (for good: the kernels read w again) when
+ * xf_table_import brings a row whose w is not the w of its (n, z) — checked row by row on the
+ * GPU, a model file saved under the same hyper-parameters passes — or xf_table_set_hyper
+ * changes alpha / beta / lambda1 / lambda2 with keys in the table.  Same table bits either way. */
+int xf_table_w_derived(xf_table *t, int *yes);
 
 /* ---------------------------------------------------------------- model kernels       */
 /* All pointers are device pointers; asynchronous on `stream`. */

@@ -210,3 +210,80 @@ def test_step_profile_samples_without_stalling_and_leaves_the_result_alone():
         tabs.append(t.export())
     for a, b in zip(*tabs):
         same(a, b)
+
+
+def _ftrl_pair(cap=1 << 18):
+    t, s = capi.Table(capi.OPT_FTRL, 1, capacity=cap), O.Store(O.OPT_FTRL, 1)
+    t.push(np.array([0], np.uint64), np.zeros(1, np.float32))
+    s.push(np.array([0], np.uint64), np.zeros(1, np.float32))
+    return t, s
+
+
+def _steps(t, s, raw, obs, ws, n, keyed=True):
+    for i in range(n):
+        b = capi.LocalBatch(t, *raw[i % len(raw)], retain_keys=False)
+        with O.sum_mode(1):
+            O.lr_update(s, obs[i % len(obs)])
+        capi.lr_step(t, b, ws)
+        del b
+
+
+@pytest.mark.parametrize("knob", [0, 299, 280])
+def test_the_old_weight_is_derived_from_n_and_z_only_while_that_is_the_stored_weight(knob):
+    """The gradient + Push kernels do not read w while every row's w is ftrl_w_of(n, z)
+    (xf_table_w_derived): a fresh table, a table filled from a model this library exported.  A
+    row imported with another w, or a change of the hyper-parameters with keys in the table,
+    ends it — the next step of a key uses the STORED w (ftrl.h:63), as the oracle does.  Dense
+    kernel (0), general kernel (299), and the kernels made to read w throughout (280): the
+    oracle's table bit for bit in every phase."""
+    rng = np.random.RandomState(23)
+    ws = capi.Workspace()
+    raw = [synth(rng, 6000, 40, 30000, 1.2 if i else None, True) for i in range(2)]
+    obs = [O.Batch(*x) for x in raw]
+    capi.tune("exp_knob", knob)
+    try:
+        t, s = _ftrl_pair()
+        assert t.w_derived()
+        _steps(t, s, raw, obs, ws, 3)
+        for a, e in zip(t.export(), s.export()):
+            same(a, e)
+        # a model written by these steps, read into a fresh table: still derived
+        k, w, n, z = t.export()
+        t2, s2 = _ftrl_pair()
+        t2.import_(k, w, n, z)
+        s2.import_(k, w, n, z)
+        assert t2.w_derived()
+        t2.defrag()
+        _steps(t2, s2, raw, obs, ws, 2)
+        for a, e in zip(t2.export(), s2.export()):
+            same(a, e)
+        # a row whose w is not the w of its (n, z): the kernels read w from here on
+        w_odd = w.copy()
+        w_odd[len(w) // 2] = np.float32(0.25)
+        w_odd[1] = np.float32(-0.5)
+        t3, s3 = _ftrl_pair()
+        t3.import_(k, w_odd, n, z)
+        s3.import_(k, w_odd, n, z)
+        assert not t3.w_derived()
+        t3.defrag()
+        _steps(t3, s3, raw, obs, ws, 2)
+        for a, e in zip(t3.export(), s3.export()):
+            same(a, e)
+        # other hyper-parameters with keys in the table: the rows hold the old ones' w
+        t.set_hyper(0.1, 0.5, 1e-4, 5.0)
+        s.set_ftrl(0.1, 0.5, 1e-4, 5.0)
+        assert not t.w_derived()
+        _steps(t, s, raw, obs, ws, 2)
+        for a, e in zip(t.export(), s.export()):
+            same(a, e)
+        # ... set before the first key arrives: nothing to distrust
+        t4 = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 18)
+        s4 = O.Store(O.OPT_FTRL, 1)
+        t4.set_hyper(0.1, 0.5, 1e-4, 5.0)
+        s4.set_ftrl(0.1, 0.5, 1e-4, 5.0)
+        assert t4.w_derived()
+        _steps(t4, s4, raw, obs, ws, 3)
+        for a, e in zip(t4.export(), s4.export()):
+            same(a, e)
+    finally:
+        capi.tune("exp_knob", 0)

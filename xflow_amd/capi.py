@@ -139,6 +139,7 @@ SIGNATURES = {
     "xf_table_export": (C.c_int, [vp, u64p, f32p, f32p, f32p, C.c_size_t,
                                   C.POINTER(C.c_size_t)]),
     "xf_table_import": (C.c_int, [vp, u64p, C.c_size_t, f32p, f32p, f32p]),
+    "xf_table_w_derived": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "xf_lr_forward_dev": (C.c_int, [C.POINTER(DevBatch), vp, vp, vp, vp]),
     "xf_lr_grad_dev": (C.c_int, [C.POINTER(DevBatch), vp, vp, vp]),
     "xf_fm_forward_dev": (C.c_int, [C.POINTER(DevBatch), C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -661,6 +662,15 @@ class Table:
                 for a in (w, n, z)]
         check(lib().xf_table_import(self.h, _p(keys, u64p), len(keys),
                                     *[None if a is None else _p(a, f32p) for a in arrs]))
+
+    def set_hyper(self, alpha, beta, l1, l2, lr=0.001):
+        check(lib().xf_table_set_hyper(self.h, alpha, beta, l1, l2, lr))
+
+    def w_derived(self):
+        """the gradient + Push kernels derive the old weight from (n, z) (xf_table_w_derived)"""
+        yes = C.c_int(0)
+        check(lib().xf_table_w_derived(self.h, C.byref(yes)))
+        return bool(yes.value)
 
     # device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr())
     def resolve_dev(self, d_keys, n, d_slots, stream=None):

@@ -408,8 +408,10 @@ k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restric
 // in HBM (fp64 atomics) and k_lr_grad_split_finish does the rest.
 __device__ __forceinline__ void apply_key(const xf::TableDev &T, int opt, size_t row, float g) {
   if (opt == XF_OPT_FTRL) {
-    float w = T.w[row], nn, z;
+    float w, nn, z;
     xf::load_nz(T, row, nn, z);
+    w = T.w_of_nz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, nn, z)
+                  : T.w[row];
     xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
     T.w[row] = w;
     xf::store_nz(T, row, nn, z);
@@ -535,6 +537,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
   __shared__ uint32_t cum[kGradWin + 1], sbase[kGradWin];
   __shared__ uint32_t nlist;
   const uint32_t tid = threadIdx.x;
+  // the old weight of a step derived from the row's (n, z) instead of read (TableDev::w_of_nz)
+  const bool wnz = OPT == XF_OPT_FTRL && MODE == 0 && T.w_of_nz;
   // (several sources: k_lr_grad_multi has run first and says which items it has taken)
   if (SRC && item_done && item_done[blockIdx.x]) return;
   GRAD_T(0);
@@ -785,7 +789,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
         const size_t r = row0 + (j < n ? k[i] : 0u);
         g[i] = j < n ? xf::div_by_rows((float)acc[k[i]], Rq) : 0.0f;  // lr_worker.cc:117
         if (MODE == 0) {
-          sw[i] = T.w[r];
+          sw[i] = 0.0f;
+          if (!wnz) sw[i] = T.w[r];
           sn[i] = sz[i] = 0.0f;
           if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
         }
@@ -795,6 +800,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
         if (k[i] == 0xFFFFFFFFu) continue;
         if (g_out) g_out[row0 + k[i]] = g[i];
         if (MODE == 0) {
+          if (wnz) sw[i] = xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, sn[i], sz[i]);
           if (OPT == XF_OPT_FTRL)
             xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
           else
@@ -827,7 +833,8 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       }
       if (MODE == 0) {  // (an idle slot loads the chunk's first row: no load under a branch)
         const size_t r = t[i] ? row0 + k : row0;
-        sw[i] = T.w[r];
+        sw[i] = 0.0f;
+        if (!wnz) sw[i] = T.w[r];
         sn[i] = sz[i] = 0.0f;
         if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
       }
@@ -837,6 +844,7 @@ k_lr_grad_cells(xf::TableDev T, const uint32_t *__restrict__ entries,
       if (!t[i]) continue;
       if (g_out) g_out[row0 + kb + i * kBlock + tid] = g[i];
       if (MODE == 0) {
+        if (wnz) sw[i] = xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, sn[i], sz[i]);
         if (OPT == XF_OPT_FTRL)
           xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g[i], sw[i], sn[i], sz[i]);
         else
@@ -920,6 +928,7 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   __shared__ uint32_t spos[kMultiSrc + 1], srow[kMultiSrc];
   __shared__ uint8_t wsrc[kMultiWin];
   const uint32_t tid = threadIdx.x;
+  const bool wnz = FTRL && T.w_of_nz;  // the rows' w derived from their (n, z), not read
   const uint32_t c = item_chunk[blockIdx.x];
   const uint32_t S = item_slice[blockIdx.x] >> 16;
   if (S != 1 || nwin > kMultiWin || nsrc > kMultiSrc) {  // workgroup-uniform
@@ -934,7 +943,8 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const size_t r = row0 + tid + i * NT < M ? row0 + tid + i * NT : row0;
-    rw[i] = T.w[r];
+    rw[i] = 0.0f;
+    if (!wnz) rw[i] = T.w[r];
     rnz[i] = make_float2(0.0f, 0.0f);
     if (FTRL) rnz[i] = T.nz[r];
   }
@@ -1017,7 +1027,8 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
     const uint32_t k = tid + i * NT;
     if (!SLOTS) acc[k] = 0.0;
     mark[k] = 0;
-    sw[k] = rw[i];
+    sw[k] = wnz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, rnz[i].x, rnz[i].y)
+                : rw[i];
     if (FTRL) snz[k] = rnz[i];
   }
   if (SLOTS)
@@ -1152,12 +1163,16 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
   const uint32_t c = item_chunk[live ? item : blockIdx.x * SUB];  // (no chunk is split)
   const size_t row0 = (size_t)(chunk0 + c) * kChunk;
   if (!live) M = 0;  // no row of a spare team is in range: nothing accumulated, nothing stored
+  // the old weight of a step derived from the row's (n, z) instead of read (TableDev::w_of_nz):
+  // 40 of the launch's 284 MB at the config-2 shape
+  const bool wnz = OPT == XF_OPT_FTRL && T.w_of_nz;
   float sw[kOwn], sn[kOwn], sz[kOwn];
   if constexpr (PREFETCH) {
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
       const size_t r = row0 + tid + i * NT < M ? row0 + tid + i * NT : row0;
-      sw[i] = T.w[r];
+      sw[i] = 0.0f;
+      if (!wnz) sw[i] = T.w[r];
       sn[i] = sz[i] = 0.0f;
       if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
     }
@@ -1258,7 +1273,8 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       // (an idle slot loads the chunk's first row: a load under a branch would have to be
       // waited for where the branch ends, one slot after the other)
       const size_t r = row0 + (kk[i] != 0xFFFFFFFFu ? kk[i] : 0u);
-      sw[i] = T.w[r];
+      sw[i] = 0.0f;
+      if (!wnz) sw[i] = T.w[r];
       sn[i] = sz[i] = 0.0f;
       if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
     }
@@ -1266,6 +1282,7 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (int i = 0; i < kSlots; ++i) {
       if (kk[i] == 0xFFFFFFFFu) continue;
       const float g = xf::div_by_rows((float)acc[kk[i]], R);  // lr_worker.cc:117
+      if (wnz) sw[i] = xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, sn[i], sz[i]);
       if (OPT == XF_OPT_FTRL)
         xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, sw[i], sn[i], sz[i]);
       else
@@ -1285,13 +1302,16 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
       t[i] = touched[k] != 0 && row0 + k < M;
       if constexpr (!PREFETCH) {  // (unconditional, see above; row0 itself is below M)
         const size_t r = (t[i] || ((VAR & kDenseFullStore) && row0 + k < M)) ? row0 + k : row0;
-        sw[i] = T.w[r];
+        sw[i] = 0.0f;
+        if (!wnz) sw[i] = T.w[r];
         sn[i] = sz[i] = 0.0f;
         if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
+      // (every row: kDenseFullStore stores the untouched ones too — the bits they had)
+      if (wnz) sw[i] = xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, sn[i], sz[i]);
       if (!t[i] || (VAR & kDiagCopy)) continue;
       const float g = xf::div_by_rows((float)acc[tid + i * NT], R);  // lr_worker.cc:117
       if (OPT == XF_OPT_FTRL)
@@ -1588,9 +1608,11 @@ static bool dense_touch(const xf_cells *c) {
 }
 
 template <int OPT, int MODE>
-static int launch_grad(const xf_cells *c, const TableDev &T, const float *d_loss, float *d_g,
+static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_loss, float *d_g,
                        hipStream_t s, const CellSources *src = nullptr) {
   if (c->nitems == 0) return XF_OK;
+  TableDev T = T_;
+  if (exp_knob() == 280) T.w_of_nz = false;  // (A/B: the kernels read w, as before round 5)
   double *gsum = src ? src->gsum : c->gsum;
   uint8_t *gtouched = src ? src->gtouched : c->gtouched;
   const uint8_t *no_skip = nullptr;

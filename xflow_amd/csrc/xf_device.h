@@ -59,6 +59,11 @@ struct TableDev {
   float alpha, beta, lambda1, lambda2, lr;
   double inv_alpha;  // 1.0 / (double)alpha (ftrl_step)
   bool last_shard, single;
+  // FTRL, dim 1: every row's w is ftrl_w_of(n, z) under the table's hyper-parameters — true of a
+  // table whose rows were all written by ftrl_step (or never: w = n = z = 0); the table keeps
+  // track (xf_table.hip: w_tainted).  The gradient + Push kernels then do not READ w: they
+  // derive the old weight from the (n, z) they load anyway — 4 of a step's 28 bytes.
+  bool w_of_nz;
 };
 
 __device__ __forceinline__ void load_nz(const TableDev &T, size_t o, float &n, float &z) {
@@ -138,6 +143,23 @@ __device__ __forceinline__ float div_by_const(float x, float d, double inv_d, bo
 // `inv_alpha` = +-1.0 / (double)alpha (TableDev::inv_alpha, set on the host with the
 // hyper-parameters; its sign: see div_by_const): the reference divides by alpha twice per step
 // (ftrl.h:63,70)
+// the weight a step leaves next to (n, z): ftrl.h:66-73 (ftrl_step's last statement).  It is a
+// function of the stored n and z alone, so a row that a step wrote holds w == ftrl_w_of(n, z),
+// bit for bit — what TableDev::w_of_nz is about.
+__device__ __forceinline__ float ftrl_w_of(float alpha, double inv_alpha, float beta, float lambda1,
+                                           float lambda2, float n, float z) {
+#pragma clang fp contract(off)
+  const bool exact = __double2hiint(inv_alpha) < 0;  // (scalar: a kernel argument's sign bit)
+  const double ia = __hiloint2double(__double2hiint(inv_alpha) & 0x7FFFFFFF,
+                                     __double2loint(inv_alpha));
+  if (fabsf(z) <= lambda1) return 0.0f;
+  float tmpr = 0.0f;
+  if (z > 0.0f) tmpr = z - lambda1;
+  if (z < 0.0f) tmpr = z + lambda1;
+  const float tmpl = -1.0f * (div_by_const(beta + sqrtf(n), alpha, ia, exact) + lambda2);
+  return tmpr / tmpl;
+}
+
 __device__ __forceinline__ void ftrl_step(float alpha, double inv_alpha, float beta, float lambda1,
                                           float lambda2, float g, float &w, float &n,
                                           float &z) {
@@ -149,15 +171,7 @@ __device__ __forceinline__ void ftrl_step(float alpha, double inv_alpha, float b
   const float nn = old_n + g * g;
   z = z + (g - div_by_const(sqrtf(nn) - sqrtf(old_n), alpha, ia, exact) * w);
   n = nn;
-  if (fabsf(z) <= lambda1) {
-    w = 0.0f;
-  } else {
-    float tmpr = 0.0f;
-    if (z > 0.0f) tmpr = z - lambda1;
-    if (z < 0.0f) tmpr = z + lambda1;
-    const float tmpl = -1.0f * (div_by_const(beta + sqrtf(nn), alpha, ia, exact) + lambda2);
-    w = tmpr / tmpl;
-  }
+  w = ftrl_w_of(alpha, inv_alpha, beta, lambda1, lambda2, nn, z);
 }
 
 // sgd.h:52,96

@@ -806,6 +806,9 @@ struct xf_table {
   // over its keys' rows before its first step
   bool rec_all_ok = false;
   uint64_t rec_all[5] = {0, 0, 0, 0, 0};
+  // a row's w may differ from ftrl_w_of(n, z): rows were imported with a w that is not (checked
+  // on the GPU, row by row), or the hyper-parameters changed with rows in the table.  Sticky.
+  bool w_tainted = false;
 };
 
 // Is (float)((double)x * (1.0 / (double)d)) the float x / d for EVERY finite x?  All 2^32 bit
@@ -863,6 +866,9 @@ static void refresh_hyper(xf_table *t) {
   t->T.lambda1 = t->cfg.lambda1;
   t->T.lambda2 = t->cfg.lambda2;
   t->T.lr = t->cfg.lr;
+  // (TableDev::w_of_nz; a fresh row is w = n = z = 0 = ftrl_w_of(0, 0) when lambda1 >= 0)
+  t->T.w_of_nz = t->cfg.opt_kind == XF_OPT_FTRL && t->cfg.dim == 1 &&
+                 t->cfg.init_kind == XF_INIT_ZERO && t->cfg.lambda1 >= 0.0f && !t->w_tainted;
 }
 
 static int ensure_scratch(xf_table *t, size_t n) {
@@ -1005,6 +1011,15 @@ extern "C" int xf_table_destroy(xf_table *t) {
 extern "C" int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2,
                                   float lr) {
   XF_REQUIRE(t, "xf_table_set_hyper: null table");
+  // the rows in the table hold the w of the OLD hyper-parameters, and the next step of a key uses
+  // that w (ftrl.h:63): from here on the kernels read it
+  if (t->cfg.opt_kind == XF_OPT_FTRL &&
+      (memcmp(&alpha, &t->cfg.alpha, 4) || memcmp(&beta, &t->cfg.beta, 4) ||
+       memcmp(&l1, &t->cfg.lambda1, 4) || memcmp(&l2, &t->cfg.lambda2, 4))) {
+    uint64_t nk = 0;
+    XF_TRY(xf_table_size(t, &nk));
+    if (nk) t->w_tainted = true;
+  }
   t->cfg.alpha = alpha;
   t->cfg.beta = beta;
   t->cfg.lambda1 = l1;
@@ -1394,6 +1409,19 @@ extern "C" int xf_table_export(xf_table *t, uint64_t *keys, float *w, float *n_,
   return XF_OK;
 }
 
+// rows whose w is not ftrl_w_of(n, z), bit for bit
+__global__ void __launch_bounds__(kBlock)
+k_check_w_of_nz(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
+                unsigned long long *__restrict__ bad) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = rows[i];
+    const float2 s = T.nz[r];
+    const float w = xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, s.x, s.y);
+    if (__float_as_uint(w) != __float_as_uint(T.w[r])) atomicAdd(bad, 1ull);
+  }
+}
+
 extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, const float *w,
                                const float *n_, const float *z_) {
   XF_REQUIRE(t && (n == 0 || keys), "xf_table_import: null argument");
@@ -1414,7 +1442,32 @@ extern "C" int xf_table_import(xf_table *t, const uint64_t *keys, size_t n, cons
                          a - 1, t->T.dim, t->s_rows, n, t->s_vals);
     XF_HIP(hipGetLastError());
   }
+  if (t->T.w_of_nz) {  // do the imported rows hold the w their (n, z) give?  (a model file this
+                       // library wrote under the same hyper-parameters does)
+    unsigned long long *d_bad = nullptr, bad = 0;
+    XF_HIP(hipMalloc((void **)&d_bad, 8));
+    XF_HIP(hipMemset(d_bad, 0, 8));
+    hipLaunchKernelGGL(k_check_w_of_nz, dim3(grid_for(n)), dim3(kBlock), 0, 0, t->T, t->s_rows, n,
+                       d_bad);
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    XF_HIP(e1);
+    XF_HIP(e2);
+    if (bad) {
+      t->w_tainted = true;
+      refresh_hyper(t);
+    }
+  }
   return xf_table_check(t, nullptr);
+}
+
+// does the gradient + Push of this table derive a key's old weight from its (n, z)
+// (TableDev::w_of_nz) instead of reading it?  (tests, tools)
+extern "C" int xf_table_w_derived(xf_table *t, int *yes) {
+  XF_REQUIRE(t && yes, "xf_table_w_derived: null argument");
+  *yes = t->T.w_of_nz ? 1 : 0;
+  return XF_OK;
 }
 
 // keys[i] (or keys[list[i]]) for i < n into out
