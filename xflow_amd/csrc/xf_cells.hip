@@ -1714,6 +1714,14 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         // dynamic LDS the kernel never touches — rounds of workgroups that come out even)
         size_t lds_pad = 0;
         if (knob > 280 && knob < 288) lds_pad = (size_t)160 * 1024 / (knob - 280 + 1) + 512 - 18432;
+        // The old weights derived from (n, z) instead of read (TableDev::w_of_nz) only where the
+        // minibatch touches the chunks thinly: there the kernel waits for lines of state (10^8
+        // keys, a tenth of them touched: a third of its read traffic goes).  At the config-2
+        // density every line of w is needed anyway and the ~45 instructions of the derivation per
+        // row are not hidden (this kernel's phases add up): 74.6 -> 77.7 us with it,
+        // so there the kernel reads w.  (exp_knob 279: derived at any density.)
+        TableDev Td = T;
+        if (dense_touch(c) && knob != 279) Td.w_of_nz = false;
         if (dense) {
 #define XF_DENSE(V)                                                                              \
   case V:                                                                                        \
@@ -1721,7 +1729,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
                        dim3(((V) & kDenseQuad) && dense_team(V) * 4 <= 1024 ? (c->nitems + 3) / 4 \
                                                                             : c->nitems),        \
                        dim3(dense_threads(V)), lds_pad,                                          \
-                       s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
+                       s, Td, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
                        d_loss, c->R, c->M, c->chunk0, c->nitems);                                \
     break
           switch (var) {
