@@ -1714,14 +1714,17 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         // dynamic LDS the kernel never touches — rounds of workgroups that come out even)
         size_t lds_pad = 0;
         if (knob > 280 && knob < 288) lds_pad = (size_t)160 * 1024 / (knob - 280 + 1) + 512 - 18432;
-        // The old weights derived from (n, z) instead of read (TableDev::w_of_nz) only where the
-        // minibatch touches the chunks thinly: there the kernel waits for lines of state (10^8
-        // keys, a tenth of them touched: a third of its read traffic goes).  At the config-2
-        // density every line of w is needed anyway and the ~45 instructions of the derivation per
-        // row are not hidden (this kernel's phases add up): 74.6 -> 77.7 us with it,
-        // so there the kernel reads w.  (exp_knob 279: derived at any density.)
+        // The old weights derived from (n, z) instead of read (TableDev::w_of_nz) where the
+        // kernel waits for lines of state: a table whose state does not fit the 256 MiB Infinity
+        // Cache (2 / 3 / 10 x 10^7 keys: 125.6 -> 120.4, 159.8 -> 148.4, 377.7 -> 310.6 us), or a
+        // minibatch that touches the chunks thinly.  A small table touched densely (config 2:
+        // 120 MB of state, every line of w needed anyway) has the lines on hand and the ~45
+        // instructions of the derivation per row are not hidden (this kernel's phases add up,
+        // DESIGN 3): 74.6 -> 77.7 us with it, so there the kernel reads w.  (exp_knob 279:
+        // derived whatever the table.)
         TableDev Td = T;
-        if (dense_touch(c) && knob != 279) Td.w_of_nz = false;
+        if (dense_touch(c) && (size_t)c->M * 12 <= ((size_t)180 << 20) && knob != 279)
+          Td.w_of_nz = false;
         if (dense) {
 #define XF_DENSE(V)                                                                              \
   case V:                                                                                        \

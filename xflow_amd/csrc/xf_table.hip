@@ -483,8 +483,12 @@ k_update(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
     const size_t o = (size_t)rows[i] * T.dim + j;
     const float g = grads[e];
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[o], nn, z;
+      float w, nn, z;
       xf::load_nz(T, o, nn, z);
+      // (the old weight: derived from the row's n and z where the table vouches for it — one
+      // sector less per key, TableDev::w_of_nz)
+      w = T.w_of_nz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, nn, z)
+                    : T.w[o];
       xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, nn, z);
       T.w[o] = w;
       xf::store_nz(T, o, nn, z);
@@ -516,8 +520,12 @@ k_update_merged(xf::TableDev T, const uint64_t *__restrict__ keys_sorted,
     if (i > 0 && keys_sorted[i - 1] == key) continue;  // not the first entry of its key
     const size_t o = (size_t)rows[order[i]] * T.dim + j;
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[o], nn, z;
+      float w, nn, z;
       xf::load_nz(T, o, nn, z);
+      // (the old weight: derived from the row's n and z where the table vouches for it — one
+      // sector less per key, TableDev::w_of_nz)
+      w = T.w_of_nz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, nn, z)
+                    : T.w[o];
       for (size_t s = i; s < n && keys_sorted[s] == key; ++s)
         xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2,
                       grads[(size_t)order[s] * T.dim + j], w, nn, z);
@@ -560,8 +568,12 @@ k_update_heads(xf::TableDev T, const uint32_t *__restrict__ hrow,
     if (row == kNotHead) continue;  // a later push of a key whose first entry does the walk
     const size_t o = (size_t)row * T.dim + j;
     if (OPT == XF_OPT_FTRL) {
-      float w = T.w[o], nn, z;
+      float w, nn, z;
       xf::load_nz(T, o, nn, z);
+      // (the old weight: derived from the row's n and z where the table vouches for it — one
+      // sector less per key, TableDev::w_of_nz)
+      w = T.w_of_nz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, nn, z)
+                    : T.w[o];
       size_t s = i;
       do {
         xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2,
