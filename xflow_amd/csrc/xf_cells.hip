@@ -1089,6 +1089,251 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
   }
 }
 
+// ---- the same pass with the workers' phases merged (round 5, second version).  The kernel above
+// takes a worker at a time — mark, add, step, three barriers each — and a phase costs ~5 us of a
+// workgroup's life whatever it holds (measured: 101 us + 5 us per worker at the N = 8 shard
+// shape): a chain of LDS round trips and one optimizer step's ~140 dependent instructions, with
+// half the wavefronts waiting at the barrier.  But only the steps of ONE key have an order; here:
+//   * every entry ORs its worker into the key's mask (LDS atomic);
+//   * one scan over the chunk's keys numbers the (key, worker) pairs — a key's pairs are
+//     neighbours, in rank order — and lists the touched keys and the keys of several workers;
+//   * every entry adds its loss to its pair's sum (fp64 LDS atomic: exact, any order);
+//   * all touched keys take their FIRST worker's step at once, a lane per key off the list
+//     (full wavefronts: a step is ~140 instructions, idle lanes were what made round 4's pass
+//     VALU-bound); then the keys of several workers — a quarter of the touched ones at N = 8 —
+//     take their remaining steps, a lane per key, in rank order, no barrier in between.
+// Nine barriers per chunk instead of 3 x workers + 3; the same sums, the same steps in the same
+// order per key: the bits of the general loop (tests/test_gpu_sharded.py).  MB = width of a
+// key's mask: 8 (packed four to a word, 52 KB of LDS: three workgroups per CU) or 32.
+template <int OPT, int MB>
+__global__ void __launch_bounds__(512)
+k_lr_grad_ranked(xf::TableDev T, const uint32_t *__restrict__ entries,
+                 const uint32_t *__restrict__ cellptr, uint32_t nchunk, uint32_t nwin,
+                 const uint32_t *__restrict__ item_chunk, const uint32_t *__restrict__ item_slice,
+                 const float *__restrict__ loss, uint32_t M, uint32_t nsrc,
+                 const uint32_t *__restrict__ src_win, const uint32_t *__restrict__ src_rows,
+                 const uint32_t *__restrict__ loss_base, uint32_t chunk0, int full_store,
+                 uint8_t *__restrict__ item_done) {
+  constexpr int NT = 512;
+  constexpr int E = (int)(kChunk / NT);  // entries per lane = state rows per thread = keys it scans
+  constexpr bool FTRL = OPT == XF_OPT_FTRL;
+  static_assert(MB == 8 || MB == 32, "mask width");
+  static_assert(E == 4, "the scan below gives a thread four neighbouring keys");
+  __shared__ double acc[kChunk];                       // the pairs' sums
+  __shared__ float sw[kChunk];
+  __shared__ float2 snz[FTRL ? kChunk : 1];
+  __shared__ uint32_t wm[MB == 8 ? kChunk / 4 : kChunk];  // per key: the workers that touch it
+  __shared__ uint16_t base[kChunk];                    // per key: its first pair
+  __shared__ uint16_t lists[kChunk];  // touched keys from the bottom, keys of several workers from the top
+  __shared__ uint32_t cum[kMultiWin + 1], sbase[kMultiWin];
+  __shared__ uint32_t srow[kMultiSrc];
+  __shared__ uint8_t wsrc[kMultiWin];
+  __shared__ unsigned long long wtot[NT / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool wnz = FTRL && T.w_of_nz;  // the rows' w derived from their (n, z), not read
+  const uint32_t c = item_chunk[blockIdx.x];
+  const uint32_t S = item_slice[blockIdx.x] >> 16;
+  if (S != 1 || nwin > kMultiWin || nsrc > (uint32_t)MB) {  // workgroup-uniform
+    if (tid == 0) item_done[blockIdx.x] = 0;
+    return;
+  }
+  auto mask_of = [&](uint32_t k) -> uint32_t {
+    return MB == 8 ? (wm[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu : wm[k];
+  };
+  const size_t row0 = (size_t)(chunk0 + c) * kChunk;
+  float rw[E];
+  float2 rnz[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const size_t r = row0 + tid + i * NT < M ? row0 + tid + i * NT : row0;
+    rw[i] = 0.0f;
+    if (!wnz) rw[i] = T.w[r];
+    rnz[i] = make_float2(0.0f, 0.0f);
+    if (FTRL) rnz[i] = T.nz[r];
+  }
+  if (tid < nwin) {
+    const size_t cell = (size_t)tid * nchunk + c;
+    const uint32_t b = cellptr[cell], e = cellptr[cell + 1];
+    sbase[tid] = b;
+    cum[tid + 1] = e - b;
+    uint32_t q = 0;
+    while (q + 1 < nsrc && tid >= src_win[q + 1]) ++q;
+    wsrc[tid] = (uint8_t)q;
+  }
+  if (tid < nsrc) srow[tid] = src_rows[tid];
+  __syncthreads();
+  if (tid < 64) {  // cum = inclusive scan of the windows' entry counts (one wavefront)
+    uint32_t inc = tid < nwin ? cum[tid + 1] : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if ((int)tid >= o) inc += u;
+    }
+    if (tid < nwin) cum[tid + 1] = inc;
+    if (tid == 0) cum[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t total = cum[nwin];
+  if (total > (uint32_t)(NT * E)) {  // workgroup-uniform: the general kernel's
+    if (tid == 0) item_done[blockIdx.x] = 0;
+    return;
+  }
+  if (tid == 0) item_done[blockIdx.x] = 1;
+  // per entry: the key's place in the chunk and its worker in ONE register, the loss in another
+  uint32_t ek[E];
+  float l[E];
+  if (total) {
+    uint32_t vq[E], en[E];
+    uint32_t st0 = 1;
+    while (st0 * 2 < nwin) st0 *= 2;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {  // (the window of a position: see k_lr_grad_multi)
+      const uint32_t p = q * NT + tid;
+      const uint32_t pc = min(p, total - 1);
+      uint32_t v = 0;
+      for (uint32_t st = st0; st > 0; st >>= 1) {  // wave-uniform trip count
+        const uint32_t t = v + st;
+        v = (t < nwin && cum[t] <= pc) ? t : v;
+      }
+      vq[q] = v;
+      uint32_t e = 0xFFFFFFFFu;
+      if (p < total) e = entries[sbase[v] + (pc - cum[v])];
+      en[q] = e;
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const bool on = en[q] != 0xFFFFFFFFu;  // (a hole: the key went to the arrival segment)
+      float x = 0.0f;
+      if (on) x = loss[(size_t)loss_base[vq[q]] + ((en[q] >> kChunkBits) & kRowMask)];
+      l[q] = x;
+      ek[q] = on ? (en[q] & (kChunk - 1)) | ((uint32_t)wsrc[vq[q]] << 16) : 0xFFFFFFFFu;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      ek[q] = 0xFFFFFFFFu;
+      l[q] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t k = tid + i * NT;
+    acc[k] = 0.0;
+    if (MB == 32) wm[k] = 0;
+    sw[k] = wnz ? xf::ftrl_w_of(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, rnz[i].x, rnz[i].y)
+                : rw[i];
+    if (FTRL) snz[k] = rnz[i];
+  }
+  if (MB == 8) wm[tid] = 0;  // (kChunk / 4 == NT words)
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+    if (ek[i] != 0xFFFFFFFFu) {
+      const uint32_t k = ek[i] & (kChunk - 1), q = ek[i] >> 16;
+      if (MB == 8) atomicOr(&wm[k >> 2], (1u << q) << ((k & 3u) * 8u));
+      else
+        atomicOr(&wm[k], 1u << q);
+    }
+  __syncthreads();
+  // the scan: thread t takes keys 4t .. 4t + 3; pairs | touched keys << 16 | keys of several
+  // workers << 32 in one 64-bit number (each count is at most 2048)
+  uint32_t km[E];
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    km[j] = mask_of(tid * E + j);
+    const uint32_t pc = (uint32_t)__popc(km[j]);
+    mine += (unsigned long long)pc | ((unsigned long long)(pc > 0) << 16) |
+            ((unsigned long long)(pc > 1) << 32);
+  }
+  unsigned long long inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += u;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  unsigned long long before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const unsigned long long x = wtot[w];
+    if (w < (int)wave) before += x;
+    all += x;
+  }
+  {
+    unsigned long long run = before + inc - mine;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const uint32_t k = tid * E + j, pc = (uint32_t)__popc(km[j]);
+      base[k] = (uint16_t)(run & 0xFFFFu);
+      if (pc > 0) lists[(run >> 16) & 0xFFFFu] = (uint16_t)k;
+      if (pc > 1) lists[kChunk - 1u - (uint32_t)((run >> 32) & 0xFFFFu)] = (uint16_t)k;
+      run += (unsigned long long)pc | ((unsigned long long)(pc > 0) << 16) |
+             ((unsigned long long)(pc > 1) << 32);
+    }
+  }
+  const uint32_t ntouched = (uint32_t)((all >> 16) & 0xFFFFu), nmulti = (uint32_t)((all >> 32) & 0xFFFFu);
+  __syncthreads();
+  // the pairs' sums
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+    if (ek[i] != 0xFFFFFFFFu) {
+      const uint32_t k = ek[i] & (kChunk - 1), q = ek[i] >> 16;
+      const uint32_t m = mask_of(k);
+      atomicAdd(&acc[(uint32_t)base[k] + (uint32_t)__popc(m & ((1u << q) - 1u))], (double)l[i]);
+    }
+  __syncthreads();
+  auto step_key = [&](uint32_t k, uint32_t q, uint32_t pair, float &w, float2 &s2) {
+    const float g = xf::div_by_rows((float)acc[pair], srow[q]);  // lr_worker.cc:117
+    if (FTRL) xf::ftrl_step(T.alpha, T.inv_alpha, T.beta, T.lambda1, T.lambda2, g, w, s2.x, s2.y);
+    else
+      w = xf::sgd_step(T.lr, g, w);
+  };
+  // every touched key: its first worker's step
+  for (uint32_t idx = tid; idx < ntouched; idx += NT) {
+    const uint32_t k = lists[idx];
+    const uint32_t m = mask_of(k);
+    float w = sw[k];
+    float2 s2 = make_float2(0.0f, 0.0f);
+    if (FTRL) s2 = snz[k];
+    step_key(k, (uint32_t)__ffs((int)m) - 1u, base[k], w, s2);
+    sw[k] = w;
+    if (FTRL) snz[k] = s2;
+  }
+  if (nmulti) {  // workgroup-uniform
+    __syncthreads();
+    // the keys of several workers: the other workers' steps, in rank order, a lane per key
+    for (uint32_t idx = tid; idx < nmulti; idx += NT) {
+      const uint32_t k = lists[kChunk - 1u - idx];
+      uint32_t m = mask_of(k);
+      m &= m - 1u;  // (the first worker has stepped)
+      float w = sw[k];
+      float2 s2 = make_float2(0.0f, 0.0f);
+      if (FTRL) s2 = snz[k];
+      uint32_t pair = (uint32_t)base[k] + 1u;
+      while (m) {
+        step_key(k, (uint32_t)__ffs((int)m) - 1u, pair, w, s2);
+        m &= m - 1u;
+        ++pair;
+      }
+      sw[k] = w;
+      if (FTRL) snz[k] = s2;
+    }
+  }
+  __syncthreads();
+  // back to the table: every row of the chunk (whole lines; an untouched row gets the bits it
+  // had), or the touched ones only when the minibatch touches the table thinly
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t k = tid + i * NT;
+    if (row0 + k >= M) continue;
+    if (!full_store && !mask_of(k)) continue;
+    T.w[row0 + k] = sw[k];
+    if (FTRL) T.nz[row0 + k] = snz[k];
+  }
+}
+
 // ---- the gradient + Push of the steady state: ONE source, no split chunk, at most kDenseWin
 // row windows (config 2: three) — the launch that takes most of the LR step.  What the general
 // kernel above spends there (ISA count, 58 registers): ~140 VALU instructions per optimizer step
@@ -1671,9 +1916,21 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
-        else  // SLOTS: the key sums in the stepping lanes' slots, four workgroups per CU: 140 us
+        else if (exp_knob() == 293 || src->n > 32)  // SLOTS: the key sums in the stepping lanes'
+                                                     // slots, a phase per worker: 140 us
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s,
                              T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+        else if (src->n <= 8 && exp_knob() != 292)  // the workers' phases merged (k_lr_grad_ranked;
+                                                     // 292: its 32-bit masks whatever the number)
+          hipLaunchKernelGGL((k_lr_grad_ranked<OPT, 8>), dim3(c->nitems), dim3(512), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
+                             c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
+                             src->d_loss_base, c->chunk0, full, c->item_done);
+        else
+          hipLaunchKernelGGL((k_lr_grad_ranked<OPT, 32>), dim3(c->nitems), dim3(512), 0, s, T,
+                             c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
       }
