@@ -555,7 +555,7 @@ def _pretend_rank(port, knob, outdir, q):
 
 def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
     """An owner's gradient + Pushes for several workers (XF_UPDATE_RANK_ORDERED): k_lr_grad_multi
-    and k_lr_grad_ranked (the chunk's state in LDS; the workers' phases merged — default, and 292
+    and k_lr_grad_ranked (the chunk's state in LDS; the workers' phases merged — 291, and 292
     with 32-bit masks — or a phase per worker with the stepping lane picked among the lanes that
     hold the key: 293, and 512 / 256 / 1024 threads per chunk) against round 4's pass (exp_knob 298: state rows in registers, a
     sweep per worker) on one GPU whose rows are dealt out to five pretended workers — five
@@ -564,7 +564,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
     world-2 / 3 / 8 tests against the oracle, which run the same kernel.)  exp_knob 78: the
     owner's cells through the two-level key build (nonzeros with row numbers)."""
     ctx = mp.get_context("spawn")
-    for knob in (298, 0, 293, 292, 297, 296, 295, 78):
+    for knob in (298, 0, 293, 291, 292, 297, 296, 295, 78):
         q = ctx.Queue()
         p = ctx.Process(target=_pretend_rank, args=(free_port(), knob, str(tmp_path), q))
         p.start()
@@ -573,7 +573,7 @@ def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
         assert not err, err
     ref = np.load(str(tmp_path / "pretend_298.npz"))
     assert len(ref["k"]) > 100000 and np.any(ref["w"] != 0)
-    for knob in (0, 293, 292, 297, 296, 295, 78):
+    for knob in (0, 293, 291, 292, 297, 296, 295, 78):
         got = np.load(str(tmp_path / ("pretend_%d.npz" % knob)))
         for f in ("k", "w", "n", "z"):
             same(got[f], ref[f])

@@ -1105,6 +1105,11 @@ k_lr_grad_multi(xf::TableDev T, const uint32_t *__restrict__ entries,
 // Nine barriers per chunk instead of 3 x workers + 3; the same sums, the same steps in the same
 // order per key: the bits of the general loop (tests/test_gpu_sharded.py).  MB = width of a
 // key's mask: 8 (packed four to a word, 52 KB of LDS: three workgroups per CU) or 32.
+// Measured (tools/r5/call18.sh, N = 8 shard shape, 2 / 4 / 8 / 16 pretended workers): 134 / 141 /
+// 143 / 186 us against the kernel above's 185 (over its slots: the general kernel) / 123 / 141 /
+// 184 — the scan, the second pass over the entries and a third workgroup less per CU cost what
+// eight phases cost; it is the pass for two or three workers, whose entries per chunk do not fit
+// the other kernel's slots (launch_grad decides).
 template <int OPT, int MB>
 __global__ void __launch_bounds__(512)
 k_lr_grad_ranked(xf::TableDev T, const uint32_t *__restrict__ entries,
@@ -1916,8 +1921,14 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
-        else if (exp_knob() == 293 || src->n > 32)  // SLOTS: the key sums in the stepping lanes'
-                                                     // slots, a phase per worker: 140 us
+        // a phase per worker (k_lr_grad_multi, SLOTS: the key sums in the stepping lanes' slots,
+        // 140 us at the N = 8 shard shape) where a worker's entries in a chunk fit its slots; the
+        // merged phases (k_lr_grad_ranked: ~140 us whatever the number of workers — 134 / 141 /
+        // 143 us for 2 / 4 / 8 of them against 185 (the general kernel: over the slots) / 123 /
+        // 141) where they do not: two or three workers.  (exp_knob 293 / 291: one or the other.)
+        else if (exp_knob() == 293 || src->n > 32 ||
+                 (exp_knob() != 291 && exp_knob() != 292 &&
+                  (double)c->NNZ / c->nitems / src->n <= 0.9 * kMultiCap))
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s,
                              T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
