@@ -160,7 +160,7 @@ struct Blob {
 };
 std::mutex g_pool_mu;
 std::vector<Blob> g_pool;
-int g_pool_limit = 16;
+int g_pool_limit = 64;
 }  // namespace
 
 int blob_alloc(void **p, size_t bytes, size_t *got) {

@@ -110,20 +110,27 @@ __global__ void k_iota32(uint32_t *p, size_t n) {
 
 template <typename T>
 struct Dev {
+  // (from the pool of device allocations the minibatches' arrays come from, xf::blob_alloc: a
+  // fresh minibatch per step — the first epoch — would otherwise pay a dozen hipMalloc and as
+  // many hipFree, each of which waits for the device)
   T *p = nullptr;
-  size_t n = 0;
+  size_t n = 0, bytes = 0;
   Dev() = default;
   Dev(const Dev &) = delete;
   Dev &operator=(const Dev &) = delete;
   ~Dev() {
-    if (p && !xf::device_poisoned()) (void)hipFree(p);  // (poisoned: leaked, see wait_stream)
+    if (p && !xf::device_poisoned()) xf::blob_free(p, bytes);  // (poisoned: leaked, see wait_stream)
   }
   int reserve(size_t want) {
     if (want <= n && p) return XF_OK;
-    if (p) XF_HIP(hipFree(p));
+    if (p) {  // growing: work in flight may still read the old array (hipFree used to wait)
+      XF_HIP(hipDeviceSynchronize());
+      xf::blob_free(p, bytes);
+    }
     p = nullptr;
     n = 0;
-    XF_HIP(hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T)));
+    bytes = 0;
+    XF_TRY(xf::blob_alloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T), &bytes));
     n = want;
     return XF_OK;
   }
