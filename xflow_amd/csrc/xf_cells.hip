@@ -1978,10 +1978,9 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         const int knob = exp_knob();
         if (knob >= 300 && knob < 812) var = knob - 300;  // (experiments: tools/cells_knobs.py)
         dense = knob != 299;                               // 299: the general kernel alone
-        // (experiment, exp_knob 281..287: at most knob - 280 workgroups per CU, by a pad of
-        // dynamic LDS the kernel never touches — rounds of workgroups that come out even)
-        size_t lds_pad = 0;
-        if (knob > 280 && knob < 288) lds_pad = (size_t)160 * 1024 / (knob - 280 + 1) + 512 - 18432;
+        // (Measured and dropped: fewer workgroups per CU — 4 .. 7 instead of 8, by a pad of dynamic
+        // LDS — so that the rounds of workgroups come out even (4883 chunks are 2.38 rounds of
+        // 2048): 74.5-76.6 us at every occupancy against 74.6-75.4, tools/r5/call13.sh.)
         // The old weights derived from (n, z) instead of read (TableDev::w_of_nz) where the
         // kernel waits for lines of state: a table whose state does not fit the 256 MiB Infinity
         // Cache (2 / 3 / 10 x 10^7 keys: 125.6 -> 120.4, 159.8 -> 148.4, 377.7 -> 310.6 us), or a
@@ -1999,7 +1998,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
     hipLaunchKernelGGL((k_lr_grad_dense<OPT, V>),                                                \
                        dim3(((V) & kDenseQuad) && dense_team(V) * 4 <= 1024 ? (c->nitems + 3) / 4 \
                                                                             : c->nitems),        \
-                       dim3(dense_threads(V)), lds_pad,                                          \
+                       dim3(dense_threads(V)), 0,                                                \
                        s, Td, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,    \
                        d_loss, c->R, c->M, c->chunk0, c->nitems);                                \
     break
