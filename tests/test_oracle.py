@@ -223,3 +223,34 @@ def test_parser_quirks_golden(golden_dir, cap):
     assert np.array_equal(np.concatenate([b[3] for b in blocks]), g["labels"])
     rp = np.concatenate([[0]] + [np.diff(b[0]) for b in blocks]).cumsum()
     assert np.array_equal(rp.astype(np.uint64), g["rowptr"])
+
+
+def test_the_weight_a_step_leaves_is_a_function_of_the_n_and_z_it_leaves():
+    """What TableDev::w_of_nz (xf_device.h: ftrl_w_of) rests on, shown on the oracle's
+    statement-for-statement FTRL step (ftrl.h:59-74): the w of a row that a step wrote is
+    determined by the row's n and z alone — a further step with g = 0 changes neither n (n + 0)
+    nor z (z + (0 - 0 / alpha * w)) and recomputes w from them, so it must hand back the same
+    bits.  Random trajectories (gradients of every size, sign changes, zeros, the |z| <= lambda1
+    branch), three sets of hyper-parameters; and the untouched row (0, 0, 0) is such a row."""
+    L = O.lib()
+    rng = np.random.RandomState(7)
+    f32 = lambda x: np.array([x], dtype=np.float32)
+    for alpha, beta, l1, l2 in [(0.05, 1.0, 5e-5, 10.0), (0.1, 0.5, 1e-4, 5.0), (1.0, 0.0, 0.0, 0.0)]:
+        for traj in range(300):
+            w, n, z = f32(0), f32(0), f32(0)
+            scale = 10.0 ** rng.uniform(-8, 3)
+            for step in range(rng.randint(1, 12)):
+                g = np.float32(rng.standard_normal() * scale) if rng.rand() > 0.1 else np.float32(0)
+                L.xo_ftrl_step(alpha, beta, l1, l2, float(g), O._ptr(w, O._f32p), O._ptr(n, O._f32p),
+                               O._ptr(z, O._f32p))
+                w2, n2, z2 = w.copy(), n.copy(), z.copy()
+                L.xo_ftrl_step(alpha, beta, l1, l2, 0.0, O._ptr(w2, O._f32p), O._ptr(n2, O._f32p),
+                               O._ptr(z2, O._f32p))
+                if not (np.isfinite(w[0]) and np.isfinite(z[0]) and np.isfinite(n[0])):
+                    break
+                assert n2.view(np.uint32)[0] == n.view(np.uint32)[0]
+                assert z2.view(np.uint32)[0] == z.view(np.uint32)[0]
+                assert w2.view(np.uint32)[0] == w.view(np.uint32)[0], (alpha, traj, step, w, w2)
+        w, n, z = f32(0), f32(0), f32(0)
+        L.xo_ftrl_step(alpha, beta, l1, l2, 0.0, O._ptr(w, O._f32p), O._ptr(n, O._f32p), O._ptr(z, O._f32p))
+        assert w.view(np.uint32)[0] == 0 and n[0] == 0 and z[0] == 0
