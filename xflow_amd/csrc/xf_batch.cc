@@ -336,15 +336,14 @@ void cells_free(xf_cells *c);
 
 extern "C" int xf_batch_free(xf_batch *b) {
   if (!b) return XF_OK;
-  if (b->d_blob || b->cells || b->fm_cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0] ||
-      b->d_uidx_sorted || b->d_ref_coo) {
+  if (b->d_blob || b->cells || b->d_raw || b->d_rows_u || b->d_fm_rows[0] || b->d_uidx_sorted ||
+      b->d_ref_coo) {
     // kernels still running on the batch must finish first (hipFree used to imply that)
     (void)hipDeviceSynchronize();
   }
   if (b->d_blob) xf::blob_free(b->d_blob, b->d_blob_bytes);
   if (b->d_blob2) xf::blob_free(b->d_blob2, b->d_blob2_bytes);
   if (b->cells) xf::cells_free(b->cells);
-  if (b->fm_cells) xf::cells_free(b->fm_cells);
   if (b->d_raw) xf::blob_free(b->d_raw, b->d_raw_bytes);
   if (b->d_rows_u) (void)hipFree(b->d_rows_u);
   if (b->d_uidx_sorted) (void)hipFree(b->d_uidx_sorted);

@@ -51,11 +51,6 @@ struct xf_batch {
   uint64_t fm_ridx_uid = 0, fm_ridx_epoch = ~0ull;
   uint64_t fm_rec_gen = 0, fm_rec_writes[2] = {~0ull, ~0ull};
   bool fm_rec_ok = false;
-  // ... and, from the minibatch's second step on, the cells of the forward over those rows
-  // (xf_cells.h: cells_fm_forward), valid for one numbering of the v table's rows
-  xf_cells *fm_cells = nullptr;
-  uint64_t fm_cells_uid = 0, fm_cells_epoch = ~0ull;
-  uint32_t fm_rec_steps = 0;  // steps taken on the records so far
   // built by xf_batch_compile_fm_dev against the settled tiers of ONE (w, v) pair of tables with
   // the same row numbering: the key list comes with its state rows and the per-nonzero record
   // index, there is no CSR index of unique keys (view.uidx == null).  Valid for that numbering

@@ -104,12 +104,10 @@ namespace xf {
 // d_rowid != null: the nonzeros come in any order with their row number (d_rowptr unused, no
 // map); the rows are then numbered window by window by the caller: w_fixed rows per window.
 // chunk0 != 0: a segment over the chunks from chunk0 on (every position is >= chunk0 * kChunk).
-// win_max != 0: at most that many rows per window (the FM forward keeps three fp64 accumulators
-// per row in LDS: kWinMax / 3).
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
                 bool key_sorted_copy, hipStream_t stream, const uint32_t *d_rowid = nullptr,
-                uint32_t w_fixed = 0, uint32_t chunk0 = 0, uint32_t win_max = 0);
+                uint32_t w_fixed = 0, uint32_t chunk0 = 0);
 void cells_free(xf_cells *c);  // the whole chain
 
 // The key build of LRWorker::update (lr_worker.cc:146-166) against table `t` on this GPU,
@@ -135,7 +133,7 @@ int cells_build_keyed_finish(KbDeferred *d, hipStream_t stream, bool *more);
 
 // pieces of cells_build shared with the keyed build
 int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0, uint32_t win_max = 0);
+                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0);
 int cells_plan_items(xf_cells *c, hipStream_t stream);            // after cellptr is final
 int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t stream);
 int cells_key_sorted_copy(xf_cells *c, hipStream_t stream);
@@ -143,16 +141,6 @@ uint32_t cells_split_chunks(const xf_cells *c);  // over the chain
 
 // scratch of the forward: G * nwin * W partial row sums (fp64)
 size_t cells_partial_doubles(const xf_cells *c);
-
-// The FM forward of the reference's pooled form (fm_worker.cc:159-202) over cells whose index
-// space is the v table's state rows: per nonzero one 32-byte record {double sum_k v, double
-// sum_k v^2, float w, pad} at the key's row (xf_model.hip keeps them), three fp64 row sums per
-// example, loss = sigmoid(wx + v_sum^2 - v_pow_sum) - label, v_sum for the gradient.  The cells
-// must have been built with win_max <= kFmWinMax; d_partial: 3 * cells_partial_doubles(c).
-constexpr uint32_t kFmWinMax = kWinMax / 3;
-int cells_fm_forward(const xf_cells *c, const void *d_records, const int32_t *d_labels,
-                     double *d_partial, float *d_loss, float *d_pctr, float *d_vsum,
-                     hipStream_t stream);
 
 // forward: loss[r] = sigmoid(sum_j w[idx_j]) - label[r]   (lr_worker.cc:121-143)
 int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,

@@ -395,133 +395,6 @@ k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restric
   if (loss) loss[r] = pr - (float)labels[r];
 }
 
-// ---- the FM forward over cells (round 5): the same stream of entries, a 32-byte record per
-// nonzero instead of a weight — gathered inside the cell's chunk of the v table's rows, 64 KiB,
-// through the L2 of the XCD the chunk's groups run on, where the row-major forward
-// (k_fm_forward_scalars, xf_model.hip) takes a sector at random out of the table's 320 MB per
-// nonzero — and three fp64 accumulators per row (windows of kFmWinMax rows).  The sums are exact
-// in fp64 (addends that are sums of k fp32 factors), so the order the atomics land in does not
-// show; fm_worker.cc:166-201 for what is summed.
-struct __attribute__((aligned(32))) FmRec {
-  double a, b;  // sum_k v, sum_k v^2
-  float w;
-  float pad[3];
-};
-
-__device__ __forceinline__ void fm_fwd_process(const FwdBlock &B, uint32_t b, uint32_t c0,
-                                               uint32_t nchunk, uint32_t lane,
-                                               const uint32_t *__restrict__ cellptr,
-                                               const FmRec *__restrict__ rec, double *wx,
-                                               uint32_t W) {
-  const uint32_t lo = B.lo < c0 ? c0 : B.lo;
-  const uint32_t hi = B.hi >= c0 + nchunk ? c0 + nchunk - 1 : B.hi;
-  const bool near = hi - lo <= kTagMask;  // wave-uniform
-  constexpr int H = kFwdE / 2;  // (two halves: 16 records of 32 bytes in registers are too many)
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    double2 ab[H];
-    float wv[H];
-#pragma unroll
-    for (int q = 0; q < H; ++q) {
-      const uint32_t e = B.ent[h * H + q];
-      ab[q] = make_double2(0.0, 0.0);
-      wv[q] = 0.0f;
-      if (e == 0xFFFFFFFFu) continue;
-      const uint32_t cell = near ? lo + (((e >> kTagShift) - (lo - c0)) & kTagMask)
-                                 : cell_of(cellptr, lo, hi, b * kBlk + (h * H + q) * 64 + lane);
-      const FmRec *r = rec + ((size_t)(cell - c0) * kChunk + (e & (kChunk - 1)));
-      ab[q] = *(const double2 *)r;
-      wv[q] = r->w;
-    }
-#pragma unroll
-    for (int q = 0; q < H; ++q) {
-      const uint32_t e = B.ent[h * H + q];
-      if (e == 0xFFFFFFFFu) continue;
-      const uint32_t rin = (e >> kChunkBits) & kRowMask;
-      atomicAdd(&wx[rin], (double)wv[q]);
-      atomicAdd(&wx[W + rin], ab[q].x);
-      atomicAdd(&wx[2 * W + rin], ab[q].y);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(kFwdBlock)
-k_fm_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ cellptr,
-               const uint32_t *__restrict__ blk_cell, uint32_t nchunk, uint32_t W, uint32_t G,
-               const FmRec *__restrict__ rec, double *__restrict__ partial) {
-  __shared__ double wx[kWinMax];  // [3][W], W <= kFmWinMax
-  __shared__ uint32_t next_blk;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t nwin = gridDim.x / G;  // (placement: see k_lr_fwd_cells)
-  const uint32_t slot = blockIdx.x >> 3, v = slot % nwin, g = (slot / nwin) * 8 + (blockIdx.x & 7u);
-  double *out = partial + ((size_t)v * G + g) * 3 * W;
-  for (uint32_t r = tid; r < 3 * W; r += kFwdBlock) wx[r] = 0.0;
-  const uint32_t c0 = v * nchunk;
-  const uint32_t wb = cellptr[c0], we = cellptr[c0 + nchunk];
-  const uint64_t n = we - wb;
-  uint32_t pb = g == 0 ? wb : (uint32_t)((wb + n * g / G) & ~(uint64_t)(kBlk - 1));
-  uint32_t pe = g == G - 1 ? we : (uint32_t)((wb + n * (g + 1) / G) & ~(uint64_t)(kBlk - 1));
-  if (pb < wb) pb = wb;
-  if (pe < pb) pe = pb;
-  const uint32_t b_first = pb / kBlk, b_end = pb < pe ? (pe - 1) / kBlk + 1 : b_first;
-  if (tid == 0) next_blk = b_first;
-  __syncthreads();
-  auto grab = [&]() -> uint32_t {  // the wavefront's next block
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(&next_blk, 1u);
-    return (uint32_t)__shfl((int)b, 0);
-  };
-  FwdBlock A, B;
-  uint32_t ba = grab(), bb = 0;
-  if (ba < b_end) fwd_load(A, entries, blk_cell, ba, pb, pe, lane);
-  while (ba < b_end) {
-    bb = grab();
-    if (bb < b_end) fwd_load(B, entries, blk_cell, bb, pb, pe, lane);
-    fm_fwd_process(A, ba, c0, nchunk, lane, cellptr, rec, wx, W);
-    if (bb >= b_end) break;
-    ba = grab();
-    if (ba < b_end) fwd_load(A, entries, blk_cell, ba, pb, pe, lane);
-    fm_fwd_process(B, bb, c0, nchunk, lane, cellptr, rec, wx, W);
-  }
-  __syncthreads();
-  for (uint32_t r = tid; r < 3 * W; r += kFwdBlock) out[r] = wx[r];
-}
-
-// row r: the G workgroups' partial sums of its three accumulators, then fm_worker.cc:193-201.
-// Four lanes per row (lane q: the workgroups g = q mod 4), combined in a fixed association.
-__global__ void __launch_bounds__(kBlock)
-k_fm_finalize_cells(const double *__restrict__ partial, const int32_t *__restrict__ labels,
-                    uint32_t R, uint32_t W, uint32_t G, float *__restrict__ loss,
-                    float *__restrict__ pctr, float *__restrict__ vsum) {
-#pragma clang fp contract(off)
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r = t >> 2, q = t & 3u;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  if (r < R) {
-    const uint32_t v = r / W, rin = r - v * W;
-    const double *p = partial + (size_t)v * G * 3 * W + rin;
-    for (uint32_t g = q; g < G; g += 4) {
-      const double *pg = p + (size_t)g * 3 * W;
-      s0 += pg[0];
-      s1 += pg[W];
-      s2 += pg[2 * (size_t)W];
-    }
-  }
-  s0 += __shfl_xor(s0, 1);
-  s0 += __shfl_xor(s0, 2);
-  s1 += __shfl_xor(s1, 1);
-  s1 += __shfl_xor(s1, 2);
-  s2 += __shfl_xor(s2, 1);
-  s2 += __shfl_xor(s2, 2);
-  if (r >= R || q != 0) return;
-  const float vsf = (float)s1, vpf = (float)s2;
-  const float vy = vsf * vsf - vpf;                     // :194-195
-  const float pr = xf::sigmoid_ref((float)s0 + vy);     // :199
-  if (pctr) pctr[r] = pr;
-  if (loss) loss[r] = pr - (float)labels[r];
-  if (vsum) vsum[r] = vsf;
-}
-
 // ----------------------------------------------------------------------------- gradient
 // One workgroup per work item = (chunk, slice).  The chunk's kChunk (2048) key sums live in LDS as
 // fp64; the item walks its share of the chunk's nwin cells: coalesced entry loads, loss
@@ -1775,11 +1648,9 @@ uint32_t cells_split_chunks(const xf_cells *c) {
 // geometry + the allocation whose size the shape decides: entries (two copies when the
 // key-sorted one is wanted), cellptr, blk_cell, the item plan
 int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
-                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0, uint32_t win_max) {
+                bool key_sorted_copy, uint32_t w_fixed, uint32_t chunk0) {
   XF_REQUIRE(out, "cells_alloc: null argument");
   XF_REQUIRE(w_fixed <= kWinMax, "cells_alloc: %u rows per window", w_fixed);
-  XF_REQUIRE(win_max <= kWinMax, "cells_alloc: at most %u rows per window", win_max);
-  if (!win_max) win_max = kWinMax;
   xf_cells *c = new xf_cells;
   c->R = R;
   c->NNZ = NNZ;
@@ -1790,7 +1661,7 @@ int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
     c->W = w_fixed;
     c->nwin = std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed);
   } else {
-    c->nwin = std::max<uint32_t>(1, (R + win_max - 1) / win_max);
+    c->nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
     c->W = std::max<uint32_t>(1, (R + c->nwin - 1) / c->nwin);
   }
   const uint64_t nchunk_all = std::max<uint64_t>(1, ((uint64_t)M + kChunk - 1) / kChunk);
@@ -1894,13 +1765,13 @@ int cells_fill_items(xf_cells *c, uint32_t nitems, uint32_t nsplit, hipStream_t 
 int cells_build(xf_cells **out, const uint32_t *d_src, const uint32_t *d_map,
                 const uint32_t *d_rowptr, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
                 bool key_sorted_copy, hipStream_t s, const uint32_t *d_rowid, uint32_t w_fixed,
-                uint32_t chunk0, uint32_t win_max) {
+                uint32_t chunk0) {
   XF_REQUIRE(out && (d_rowptr || d_rowid || NNZ == 0) && (NNZ == 0 || d_src),
              "cells_build: null argument");
   XF_REQUIRE(!d_rowid || (w_fixed >= 1 && w_fixed <= kWinMax && !d_map),
              "cells_build: row ids need a window size");
   xf_cells *c = nullptr;
-  XF_TRY(cells_alloc(&c, R, NNZ, M, mode, key_sorted_copy, w_fixed, chunk0, win_max));
+  XF_TRY(cells_alloc(&c, R, NNZ, M, mode, key_sorted_copy, w_fixed, chunk0));
   struct Guard {
     xf_cells *c;
     ~Guard() {
@@ -1962,24 +1833,6 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
   hipLaunchKernelGGL(k_lr_finalize_cells,
                      dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                      d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
-  XF_HIP(hipGetLastError());
-  return XF_OK;
-}
-
-int cells_fm_forward(const xf_cells *c, const void *d_records, const int32_t *d_labels,
-                     double *d_partial, float *d_loss, float *d_pctr, float *d_vsum,
-                     hipStream_t s) {
-  XF_REQUIRE(c && d_records && d_partial && (d_loss || d_pctr), "cells_fm_forward: null argument");
-  XF_REQUIRE(!c->next && c->chunk0 == 0 && c->W <= kFmWinMax,
-             "cells_fm_forward: one segment of cells with windows of at most %u rows", kFmWinMax);
-  static_assert(sizeof(FmRec) == 32, "the FM forward's record is 32 bytes");
-  if (c->R == 0) return XF_OK;
-  hipLaunchKernelGGL(k_fm_fwd_cells, dim3(c->nwin * c->G), dim3(kFwdBlock), 0, s, c->fwd_entries(),
-                     c->cellptr, c->blk_cell, c->nchunk, c->W, c->G, (const FmRec *)d_records,
-                     d_partial);
-  hipLaunchKernelGGL(k_fm_finalize_cells,
-                     dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                     d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr, d_vsum);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }

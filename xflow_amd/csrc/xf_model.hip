@@ -1751,8 +1751,6 @@ extern "C" int xf_workspace_profile_read(xf_workspace *ws, double *ms_sum, long 
   } while (0)
 
 // ---------------------------------------------------------------------------- fused steps
-static int ws_reserve_partial(xf_workspace *ws, size_t need);
-
 static int ws_reserve_cells(xf_workspace *ws, const xf_cells *c, bool dense_g) {
   const size_t need = xf::cells_partial_doubles(c);
   if (need > ws->capPartial) {
@@ -1775,17 +1773,6 @@ static int ws_reserve_cells(xf_workspace *ws, const xf_cells *c, bool dense_g) {
     ws->capGdense = gd;
   }
   return XF_OK;
-}
-
-static int ws_reserve_partial(xf_workspace *ws, size_t need) {
-  return need > ws->capPartial ? [&] {
-    if (ws->partial) XF_HIP(hipFree(ws->partial));
-    ws->partial = nullptr;
-    ws->capPartial = 0;
-    XF_HIP(hipMalloc((void **)&ws->partial, (need + need / 8 + 1024) * 8));
-    ws->capPartial = need + need / 8 + 1024;
-    return (int)XF_OK;
-  }() : (int)XF_OK;
 }
 
 extern "C" int xf_workspace_parity(xf_workspace *ws, int mode) {
@@ -2032,45 +2019,6 @@ static bool fm_table_records_enabled() {
   return on;
 }
 
-// The forward of a REPLAYED minibatch over cells (xf_cells.h: cells_fm_forward): a minibatch that
-// is stepped a second time — the reference trains 60 epochs over the same blocks, a worker with
-// cache_batches keeps them compiled — gets the cells of its nonzeros over the v table's rows
-// (one radix pass, ~0.4 ms, once per numbering of the rows), and from then on its forward
-// gathers the records chunk by chunk through one XCD's L2 instead of at random over the table:
-// k_fm_forward_scalars 201 us -> k_fm_fwd_cells + k_fm_finalize_cells (config 4).  A minibatch
-// that is stepped once never pays for them.  XF_FM_CELLS=0 turns them off (a measuring aid).
-static bool fm_cells_enabled() {
-  static const bool on = [] {
-    const char *e = getenv("XF_FM_CELLS");
-    return !(e && *e == '0');
-  }();
-  return on;
-}
-
-static int fm_forward_cells(xf_table *vt, xf_batch *b, xf_workspace *ws, void *stream,
-                            const xf_cells **out) {
-  *out = nullptr;
-  if (!fm_cells_enabled() || !b->d_fm_ridx || !b->R || !b->NNZ) return XF_OK;
-  const uint64_t uid = xf::table_uid(vt), ep = xf::table_epoch(vt);
-  if (b->fm_cells && (b->fm_cells_uid != uid || b->fm_cells_epoch != ep)) {
-    xf::cells_free(b->fm_cells);  // the rows were renumbered (stream order covers its last reader)
-    b->fm_cells = nullptr;
-  }
-  if (!b->fm_cells) {
-    if (b->fm_rec_steps++ == 0) return XF_OK;  // (the first step: perhaps the only one)
-    const uint64_t rows = xf::table_dev(vt).max_rows;
-    if (rows >= 0xFFFFFFF0ull) return XF_OK;
-    XF_TRY(xf::cells_build(&b->fm_cells, b->d_fm_ridx, nullptr, b->view.rowptr, b->R, b->NNZ,
-                           (uint32_t)rows, xf::kCellsTableRows, false, S(stream), nullptr, 0, 0,
-                           xf::kFmWinMax));
-    b->fm_cells_uid = uid;
-    b->fm_cells_epoch = ep;
-  }
-  XF_TRY(ws_reserve_partial(ws, 3 * xf::cells_partial_doubles(b->fm_cells)));
-  *out = b->fm_cells;
-  return XF_OK;
-}
-
 // brings the records of b's keys up to date if needed; *rec_out = the v table's records
 static int fm_prepare_records(xf_table *w, xf_table *vt, xf_batch *b, bool fresh, int k,
                               FmKey **rec_out, void *stream) {
@@ -2164,15 +2112,9 @@ extern "C" int xf_fm_step(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *
     FmKey *rec = nullptr;
     XF_TRY(fm_prepare_records(w, vt, b, fresh, k, &rec, stream));
     XF_END(kEvResolve);
-    const xf_cells *fc = nullptr;
-    XF_TRY(fm_forward_cells(vt, b, ws, stream, &fc));
-    if (fc)
-      XF_TRY(xf::cells_fm_forward(fc, rec, v.labels, ws->partial, ws->loss, nullptr, ws->vsum,
-                                  S(stream)));  // :237
-    else
-      hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
-                         dim3(kBlock), 0, S(stream), v.rowptr, b->d_fm_ridx, (const FmKey *)rec,
-                         v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
+    hipLaunchKernelGGL(k_fm_forward_scalars, dim3(blocks_for_groups(v.R, kBlock / 64)),
+                       dim3(kBlock), 0, S(stream), v.rowptr, b->d_fm_ridx, (const FmKey *)rec,
+                       v.labels, v.R, ws->loss, (float *)nullptr, ws->vsum);  // :237
     XF_HIP(hipGetLastError());
     XF_END(kEvForward);
     XF_TRY(fm_grad_update(w, vt, &v, rows_w, rows_v, ws->wu, ws->vu, ws->vsum, ws->loss, ws->g,
