@@ -43,9 +43,12 @@ def test_cli_roles_without_a_process_return_at_once(sample_prefixes):
         assert out.returncode == 0 and "no %s process" % role in out.stdout
 
 
-@pytest.mark.parametrize("schedule", ["sequential", "owner"])
+@pytest.mark.parametrize("schedule", ["sequential", "owner", "owner ingest=gpu",
+                                      "sequential ingest=gpu"])
 def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, tmp_path, schedule):
-    """scripts/local.sh 2 2 xflow_lr ...: worker r trains on small_train-0000r (identical files,
+    """(ingest=gpu: the workers' text tokenised on the GPU, xf_ingest.hip, and compiled from
+    device arrays — the same tables and metric line.)
+    scripts/local.sh 2 2 xflow_lr ...: worker r trains on small_train-0000r (identical files,
     SURVEY 2 row 18), both shards of the table take both workers' pushes in rank order, rank 0
     scores the test file against the whole table.  Checkpoint (one file per shard) and metric
     line against the oracle on that schedule."""
@@ -53,8 +56,8 @@ def test_local_sh_two_workers_equal_the_rank_ordered_schedule(sample_prefixes, t
     ckpt = str(tmp_path / "model")
     env = dict(os.environ, DMLC_PS_ROOT_PORT=str(free_port()))
     out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "local.sh"), "2", "2", CLI, tr, te,
-                          "0", "3", "transport=host", "capacity=256", "schedule=" + schedule,
-                          "model_out=" + ckpt,
+                          "0", "3", "transport=host", "capacity=256",
+                          *("schedule=" + schedule).split(), "model_out=" + ckpt,
                           "pred_path=" + str(tmp_path / "pred.txt")],
                          capture_output=True, text=True, timeout=240, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout + out.stderr
