@@ -362,36 +362,33 @@ k_lr_fwd_cells(const uint32_t *__restrict__ entries, const uint32_t *__restrict_
   for (uint32_t r = tid; r < W; r += kFwdBlock) out[r] = wx[r];
 }
 
-// loss[r] = sigmoid(sum of the window workgroups' partial sums of row r) - label.  LPR lanes per
-// row, lane q adding the workgroups g = q mod LPR, then a butterfly over the row's lanes: a
-// fixed association, the same bits every run (and fp64 sums of fp32 addends are exact in any).
-// LPR = 4 with four loads in flight per lane, or — G >= 16 — 16 lanes with all of a lane's loads
-// in flight at once: the kernel is a chain of loads, 2 x 10^5 lanes do not fill the memory
-// system (config 2, G = 64: 9.4 us for 25.6 MB with four lanes per row).
-template <int LPR>
+// loss[r] = sigmoid(sum of the window workgroups' partial sums of row r) - label.  Four lanes
+// per row, lane q adding the workgroups g = q mod 4; combined as (s0 + s1) + (s2 + s3): a
+// fixed association, the same bits every run.
 __global__ void __launch_bounds__(kBlock)
 k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restrict__ labels,
                     uint32_t R, uint32_t W, uint32_t G, float *__restrict__ loss,
                     float *__restrict__ pctr) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r = t / LPR, q = t % LPR;
+  const uint32_t r = t >> 2, q = t & 3u;
   double a = 0.0;
   if (r < R) {
     const uint32_t v = r / W, rin = r - v * W;
     const double *p = partial + (size_t)v * G * W + rin;
+    // four loads in flight per lane (fp64 sums of fp32 addends: exact in any association)
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     uint32_t g = q;
-    for (; g + 3 * LPR < G; g += 4 * LPR) {
+    for (; g + 12 < G; g += 16) {
       a += p[(size_t)g * W];
-      a1 += p[(size_t)(g + LPR) * W];
-      a2 += p[(size_t)(g + 2 * LPR) * W];
-      a3 += p[(size_t)(g + 3 * LPR) * W];
+      a1 += p[(size_t)(g + 4) * W];
+      a2 += p[(size_t)(g + 8) * W];
+      a3 += p[(size_t)(g + 12) * W];
     }
-    for (; g < G; g += LPR) a += p[(size_t)g * W];
+    for (; g < G; g += 4) a += p[(size_t)g * W];
     a += a1 + (a2 + a3);
   }
-#pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) a += __shfl_xor(a, o);
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
   if (r >= R || q != 0) return;
   const float pr = xf::sigmoid_ref((float)a);  // lr_worker.cc:141, base.h:54-63
   if (pctr) pctr[r] = pr;
@@ -1833,14 +1830,9 @@ int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_label
     hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->fwd_entries(),
                        q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
                        d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);
-  if (c->G >= 16 && exp_knob() != 289)
-    hipLaunchKernelGGL(k_lr_finalize_cells<16>,
-                       dim3((unsigned)(((size_t)c->R * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       s, d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
-  else
-    hipLaunchKernelGGL(k_lr_finalize_cells<4>,
-                       dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       s, d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
+  hipLaunchKernelGGL(k_lr_finalize_cells,
+                     dim3((unsigned)(((size_t)c->R * 4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                     d_partial, d_labels, c->R, c->W, c->G, d_loss, d_pctr);
   XF_HIP(hipGetLastError());
   return XF_OK;
 }
