@@ -90,10 +90,21 @@ def parse_args():
                     help="table sizes (keys per GPU) of the table sweep")
     ap.add_argument("--no-owner-leg", action="store_true",
                     help="N>1: skip the supplementary run of the owner-compute dataflow")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5,
+                    help="N=1 LR: the timed loop run again for this long (0 = skip)")
+    ap.add_argument("--no-fresh-table", action="store_true",
+                    help="N=1 LR: skip the first-epoch legs (empty tables of 10^7 and 10^8 keys)")
+    ap.add_argument("--fresh-keys", default="10000000,100000000")
+    ap.add_argument("--no-n8-shape", action="store_true",
+                    help="N=1 LR: skip the staged N = 8 owner shape")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="N=1 LR: skip the xflow_lr runs on a text file")
     ap.add_argument("--repeats", type=int, default=10,
                     help="blocks of K steps timed again after the official one (median / min / "
                          "max of ms_per_step are reported next to it)")
-    ap.add_argument("--exp-knob", type=int, default=0)
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="xf_tune switches (xf_common.h: key_build, old_weight, lr_gradient, "
+                         "owner_pass); repeatable")
     ap.add_argument("--seed", type=int, default=20260926)
     return ap.parse_args()
 
@@ -717,6 +728,357 @@ def table_sweep(args):
             "tables": out}
 
 
+def gpu_clocks():
+    """sclk / mclk / power as rocm-smi reports them (None when it cannot be read: an ordinary
+    user on the box may not)"""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower"],
+                             capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return None
+    res = {}
+    for key, pat in (("sclk_mhz", r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz"),
+                     ("mclk_mhz", r"mclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz"),
+                     ("power_w", r"Power \(W\):\s*([0-9.]+)")):
+        m = re.search(pat, out, re.I)
+        if m:
+            res[key] = float(m.group(1))
+    return res or None
+
+
+def sustained_leg(args, trainer, compiled, short_ms):
+    """The step for a few seconds instead of a few milliseconds: the same compiled minibatches,
+    back to back, until at least `--sustained-seconds` have passed (>= 2e4 steps at the config-2
+    shape) — what the clocks, the power limit and the caches settle at.  Not `value`."""
+    import torch
+    n = max(1000, int(args.sustained_seconds / max(short_ms * 1e-3, 1e-6)))
+    c0 = gpu_clocks()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    blocks = []
+    while done < n:
+        tb = time.perf_counter()
+        for i in range(2000):
+            trainer.step(compiled[(done + i) % len(compiled)])
+        done += 2000
+        if len(blocks) < 64:
+            capi_sync()
+            blocks.append((time.perf_counter() - tb) / 2000 * 1e3)
+    if hasattr(trainer, "flush"):
+        trainer.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = gpu_clocks()
+    trainer.check()
+    ms = dt / done * 1e3
+    return {"steps": done, "seconds": dt, "ms_per_step": ms,
+            "value": compiled[0].R / (ms * 1e-3), "unit": "examples/sec",
+            "ratio_to_the_k_step_block": ms / short_ms if short_ms > 0 else None,
+            "ms_per_step_by_block_of_2000": spread(blocks) if blocks else None,
+            "clocks_before": c0, "clocks_after": c1,
+            "what": "the timed loop of `value` run for seconds: %d steps over the same %d "
+                    "compiled minibatches, one host wait per 2000 steps" % (done, len(compiled))}
+
+
+def capi_sync():
+    import torch
+    from xflow_amd import capi
+    capi.stream_sync()
+    torch.cuda.synchronize()
+
+
+def fresh_table_leg(args, nkeys, nbatches=40):
+    """What a run's FIRST epoch costs on the GPU (lr_worker.cc:183-188 starts from an empty
+    store, ftrl.h:56 inserts on the first Pull): an EMPTY table, `nbatches` distinct minibatches
+    of the bench shape over a key space of `nkeys`, xf_lr_update_dev (key build + step) per
+    minibatch, the worker's table maintenance between them (Worker::defrag_if_grown(30): settle the
+    table when its keys have grown by 30 % since the last time).  Raw keys resident in HBM (drawn
+    there: uniform fids through the same std::hash table).  examples/sec over all of them, and
+    per minibatch what it cost and how many of its nonzeros were first touches."""
+    import ctypes as C
+    import torch
+    from xflow_amd import capi
+    from xflow_amd.single import SingleGpuTrainer
+    L = capi.lib()
+    R, nnz = args.rows, args.nnz_per_row
+    t_set = time.perf_counter()
+    keytab = torch.from_numpy(make_key_table(nkeys).view(np.int64)).cuda()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed + 77)
+    rp = torch.arange(0, (R + 1) * nnz, nnz, dtype=torch.int32, device="cuda")
+    raw = []
+    for _ in range(nbatches):
+        fid = torch.randint(0, nkeys, (R * nnz,), generator=g, device="cuda")
+        raw.append((keytab[fid], torch.randint(0, 2, (R,), generator=g, device="cuda",
+                                                  dtype=torch.int32)))
+    del keytab
+    tr = SingleGpuTrainer(model="lr", optimizer="ftrl",
+                          capacity=int(nkeys / args.load_factor) + 1024)
+    # (code loading, scratch sizing: a two-row update on a private table, as the worker does)
+    warm = SingleGpuTrainer(model="lr", optimizer="ftrl", capacity=1 << 16)
+    h = capi.vp()
+    capi.check(L.xf_lr_update_dev(C.byref(h), warm.w.h, raw[0][0].data_ptr(), rp.data_ptr(),
+                                  raw[0][1].data_ptr(), 2, 2 * nnz, 0, warm.ws.h, None))
+    capi_sync()
+    L.xf_batch_free(h)
+    del warm
+    setup_s = time.perf_counter() - t_set
+    per, keys_after, defrags = [], [], []
+    at_defrag, prev = 0, None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i, (k, lb) in enumerate(raw):
+        tb = time.perf_counter()
+        h = capi.vp()
+        capi.check(L.xf_lr_update_dev(C.byref(h), tr.w.h, k.data_ptr(), rp.data_ptr(),
+                                      lb.data_ptr(), R, R * nnz, 0, tr.ws.h, None))
+        if prev is not None:
+            L.xf_batch_free(prev)
+        prev = h
+        n = len(tr.w)                      # (xf_table_size: waits for the step, as the worker's
+        if n > at_defrag + at_defrag // 100 * 30 + 4096:   # defrag_if_grown does)
+            L.xf_batch_free(prev)
+            prev = None
+            td = time.perf_counter()
+            tr.defrag()
+            defrags.append({"after_minibatch": i, "keys": n,
+                            "ms": (time.perf_counter() - td) * 1e3})
+            at_defrag = n
+        keys_after.append(n)
+        per.append((time.perf_counter() - tb) * 1e3)
+    capi_sync()
+    dt = time.perf_counter() - t0
+    if prev is not None:
+        L.xf_batch_free(prev)
+    tr.check()
+    new = [keys_after[0]] + [b - a for a, b in zip(keys_after, keys_after[1:])]
+    no_defrag = [m for i, m in enumerate(per) if all(d["after_minibatch"] != i for d in defrags)]
+    return {"keys_per_gpu": nkeys, "minibatches": nbatches, "rows_per_minibatch": R,
+            "value": R * nbatches / dt, "unit": "examples/sec", "seconds": dt,
+            "ms_per_minibatch": dt / nbatches * 1e3,
+            "ms_first_minibatch": per[0], "ms_by_minibatch": [round(x, 3) for x in per],
+            "new_keys_by_minibatch": new, "table_keys_at_the_end": keys_after[-1],
+            "defrags": defrags,
+            "ms_per_minibatch_without_the_defrags":
+                float(np.mean(no_defrag)) if no_defrag else None,
+            "ms_last_5_minibatches": float(np.mean(per[-5:])), "setup_s": setup_s,
+            "what": "an EMPTY table, xf_lr_update_dev (key build with insert on first touch + "
+                    "step) per minibatch, the host waiting for each (xf_table_size) and settling "
+                    "the table when its keys have grown by 30 % (the worker's policy); "
+                    "ms_by_minibatch includes that wait and the defrag where one ran"}
+
+
+def n8_shape_leg(args, n1_ms, nsrc=8):
+    """What ONE owner of an N = 8 run executes per step, staged on this one GPU (no node measures
+    the scaling curve: this is the evidence the > 6x target gets): a 1.25e7-key shard, the rows
+    of all 8 workers that hold its keys — 4e5 rows x 25 nonzeros (10^7 nonzeros per GPU: weak
+    scaling, SURVEY 8(d) config 3's large variant) and 5e4 rows x 25 (1.25e6 per GPU: its small
+    variant) — through the owner-compute exchange path (a group of one: the exchanges are device
+    copies), under both update rules: sum_then_step (one source) and rank_ordered with the rows
+    dealt out to 8 pretended workers (XF_OWNER_TIMING_SOURCES: eight optimizer steps per key, what
+    the rule costs an owner of 8).  `projected_speedup_free_exchange` = 8 x the N = 1 step / this
+    step: an upper bound, the exchanges of 12 B x rows x 7 per rank are not in it."""
+    import argparse as _ap
+    import torch
+    from xflow_amd import capi
+    kpg = 12_500_000
+    keytab = make_key_table(kpg)
+    group = make_group(0, 1, 0, "auto")
+    out = {"keys_per_gpu": kpg, "transport": "rccl" if group.transport == capi.TRANSPORT_RCCL
+           else "host", "n1_ms_per_step": n1_ms}
+    saved = {k: os.environ.get(k) for k in ("XF_SHARDED_GENERAL", "XF_OWNER_TIMING_SOURCES")}
+    os.environ["XF_SHARDED_GENERAL"] = "1"
+    try:
+        for shape, rows in (("weak_1e7_nnz_per_gpu", 400_000), ("strong_1p25e6_nnz_per_gpu", 50_000)):
+            a = _ap.Namespace(**vars(args))
+            a.rows, a.nnz_per_row, a.keys_per_gpu, a.batches, a.zipf = rows, 25, kpg, 8, 0.0
+            a.model, a.optimizer = "lr", "ftrl"
+            batches = make_batches(a, 0, kpg, keytab)
+            U = int(np.mean([len(np.unique(b[1])) for b in batches[:2]]))
+            NNZ = rows * 25
+            leg = {"rows": rows, "nnz_per_row": 25, "unique_keys_per_minibatch": U}
+            for rule, env in (("sum_then_step", None), ("rank_ordered", str(nsrc))):
+                if env:
+                    os.environ["XF_OWNER_TIMING_SOURCES"] = env
+                else:
+                    os.environ.pop("XF_OWNER_TIMING_SOURCES", None)
+                tr = NativeSharded(group, a, "owner", int(kpg / args.load_factor) + 1024,
+                                   update=rule)
+                comp = [tr.compile(*b) for b in batches]
+                for c in comp:
+                    tr.predict(c)
+                tr.check()
+                tr.defrag()
+                for c in comp:
+                    tr.predict(c)
+                for i in range(args.warmup):
+                    tr.step(comp[i % len(comp)])
+                tr.check()
+                torch.cuda.synchronize()
+                per = []
+                for rep in range(3):
+                    if rep == 0:
+                        tr.profile(True)
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        tr.step(comp[i % len(comp)])
+                    tr.flush()
+                    torch.cuda.synchronize()
+                    per.append((time.perf_counter() - t0) / args.steps * 1e3)
+                    if rep == 0:
+                        ms, n = tr.profile_read()
+                        tr.profile(False)
+                tr.check()
+                kern = {k: v / max(n, 1) for k, v in ms.items()}
+                g = kern.get("gradient", 0.0)
+                e = {"ms_per_step": per[0], "ms_per_step_repeats": spread(per),
+                     "value_one_gpu": rows / (per[0] * 1e-3),
+                     "kernels_ms": {"forward_at_owners": kern.get("forward"),
+                                    "row_sums_and_sigmoid": kern.get("a2a_weights"),
+                                    "losses_to_owners": kern.get("a2a_grads"),
+                                    "gradient_and_pushes": g},
+                     "roofline": {"bound": "hbm", "kernel": "gradient + Push(es) at the owner",
+                                  "algorithmic_bytes_per_launch": 32 * U,
+                                  "avg_launch_ms": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "achieved": 32 * U / (g * 1e-3) / 1e9 if g > 0 else None,
+                                  "frac": 32 * U / (g * 1e-3) / 1e9 / HBM_PEAK_GBS if g > 0 else None},
+                     "step_gbs_survey_8d": (12 * NNZ + 8 * rows + 32 * U) / (per[0] * 1e-3) / 1e9}
+                if shape.startswith("weak"):
+                    e["projected_speedup_free_exchange"] = 8.0 * n1_ms / per[0]
+                    if rule == "sum_then_step" and args.key_build_steps > 0:
+                        try:
+                            wk = with_key_build_sharded(args, tr, batches, rows, 1,
+                                                        capi_sync, lambda x: x)
+                            e["with_key_build"] = {k: wk[k] for k in
+                                                   ("ms_per_step", "from_host_arrays_ms_per_step")}
+                        except Exception as ex:
+                            e["with_key_build"] = {"error": str(ex)}
+                leg[rule] = e
+                del comp, tr
+            out[shape] = leg
+            del batches
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        try:
+            group.close()
+        except Exception:
+            pass
+    return out
+
+
+def end_to_end_leg(rows=240_000):
+    """The worker end to end on a libsvm-style text file, measured by THIS run: `xflow_lr` (fresh
+    processes) on `rows` rows x 200 tokens over a 1e7 key space in 64 MiB blocks — first epoch from
+    the text with the host parser and with the GPU tokeniser (examples/sec of the training loop:
+    read + parse / tokenise + key build with first-touch inserts + steps; predict excluded).  A
+    small file so that the bench stays short: tools/e2e_text.py runs the same on 3 GB
+    (profiles/)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="xf_e2e_")
+    try:
+        rng = np.random.RandomState(0)
+        nnz, K, chunk = 200, 10_000_000, 6000
+        t0 = time.perf_counter()
+        for name, n in (("train-00000", rows), ("test-00000", chunk)):
+            fid = rng.randint(0, K, size=(chunk, nnz))
+            lab = rng.randint(0, 2, size=chunk)
+            text = "".join("%d\t" % lab[r] + " ".join("%d:%d:1" % (j & 31, v)
+                                                      for j, v in enumerate(fid[r])) + "\n"
+                           for r in range(chunk))
+            with open(os.path.join(d, name), "w") as f:
+                left = n
+                while left > 0:
+                    f.write(text if left >= chunk else "".join(text.splitlines(True)[:left]))
+                    left -= chunk
+        size_mb = os.path.getsize(os.path.join(d, "train-00000")) / 1e6
+        gen_s = time.perf_counter() - t0
+        exe = os.path.join(ROOT, "xflow_amd", "lib", "xflow_lr")
+
+        def run(extra):
+            o = subprocess.run([exe, os.path.join(d, "train"), os.path.join(d, "test"), "0", "1",
+                                "block_size_mb=64", "capacity=30000000",
+                                "pred_path=" + os.path.join(d, "pred.txt")] + extra,
+                               capture_output=True, text=True, timeout=120)
+            m = re.search(r"examples/sec \(train loop\): ([0-9.e+]+)", o.stdout)
+            return float(m.group(1)) if m else None
+        run([])                              # (page cache, first HIP start: not recorded)
+        text1 = run([])
+        gpu1 = run(["ingest=gpu"])
+        return {"rows": rows, "text_mb": size_mb, "generate_s": gen_s,
+                "first_epoch_from_text": text1, "first_epoch_from_text_gpu_tokeniser": gpu1,
+                "unit": "examples/sec", "source": "measured by this run (bench.py: end_to_end_leg)",
+                "what": "xflow_lr, one epoch, a fresh process each: %d rows x %d tokens (%.0f MB of "
+                        "text, a %d-row chunk written out repeatedly), 64 MiB blocks, LR + FTRL, "
+                        "every key a first touch or a replay of the chunk's" % (rows, nnz, size_mb,
+                                                                                chunk)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def summary_of(out):
+    """The run's headline figures as short scalars, LAST in the JSON line (a reader that keeps
+    the tail of a long line keeps this) — every one of them is also in its own object above."""
+    def get(d, *path):
+        for k in path:
+            if isinstance(d, dict):
+                d = d.get(k)
+            elif isinstance(d, list) and isinstance(k, int) and k < len(d):
+                d = d[k]
+            else:
+                return None
+        return d
+
+    def r3(x):
+        return round(x, 4) if isinstance(x, (int, float)) else x
+    s = {"ms_per_step": out.get("ms_per_step"),
+         "roofline_frac": get(out, "roofline", "frac"),
+         "with_key_build_ms": out.get("ms_per_step_with_key_build"),
+         "sustained_ms_per_step": get(out, "sustained", "ms_per_step"),
+         "sustained_ratio": get(out, "sustained", "ratio_to_the_k_step_block"),
+         "zipf_ms_per_step": get(out, "zipf", "ms_per_step"),
+         "zipf_gradient_frac": get(out, "zipf", "roofline", "frac"),
+         "fm_ms_per_step": get(out, "fm", "ms_per_step"),
+         "fm_with_key_build_ms": get(out, "fm", "with_key_build", "ms_per_step"),
+         "e2e_text_examples_per_s": get(out, "end_to_end", "first_epoch_from_text"),
+         "e2e_gpu_tokeniser_examples_per_s":
+             get(out, "end_to_end", "first_epoch_from_text_gpu_tokeniser"),
+         "logloss_before": get(out, "logloss", "before_training", "natural"),
+         "logloss_after": get(out, "logloss", "natural")}
+    for i, t in enumerate(get(out, "table_sweep", "tables") or []):
+        tag = "sweep_%.0e" % t.get("keys_per_gpu", 0)
+        s[tag + "_ms_per_step"] = t.get("ms_per_step")
+        s[tag + "_gradient_frac"] = get(t, "roofline", "frac")
+        s[tag + "_with_key_build_ms"] = t.get("with_key_build_ms_per_step")
+    for t in out.get("fresh_table") or []:
+        tag = "fresh_%.0e" % t.get("keys_per_gpu", 0)
+        s[tag + "_examples_per_s"] = t.get("value")
+        s[tag + "_first_minibatch_ms"] = t.get("ms_first_minibatch")
+        s[tag + "_ms_per_minibatch"] = t.get("ms_per_minibatch")
+    for shape in ("weak_1e7_nnz_per_gpu", "strong_1p25e6_nnz_per_gpu"):
+        tag = "n8_" + shape.split("_")[0]
+        for rule in ("sum_then_step", "rank_ordered"):
+            s["%s_%s_ms" % (tag, rule)] = get(out, "n8_shape", shape, rule, "ms_per_step")
+        s[tag + "_with_key_build_ms"] = get(out, "n8_shape", shape, "sum_then_step",
+                                           "with_key_build", "ms_per_step")
+    s["n8_projected_speedup_sum_then_step"] = get(out, "n8_shape", "weak_1e7_nnz_per_gpu",
+                                                  "sum_then_step",
+                                                  "projected_speedup_free_exchange")
+    s["n8_projected_speedup_rank_ordered"] = get(out, "n8_shape", "weak_1e7_nnz_per_gpu",
+                                                 "rank_ordered",
+                                                 "projected_speedup_free_exchange")
+    return {k: r3(v) for k, v in s.items() if v is not None}
+
+
 def spread(ms):
     ms = sorted(ms)
     return {"median": ms[len(ms) // 2], "min": ms[0], "max": ms[-1], "n": len(ms)}
@@ -1134,8 +1496,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
         exchange = "torch.distributed all_to_all_single (RCCL), Python driver"
-    if args.exp_knob:
-        capi.tune("exp_knob", args.exp_knob)
+    for kv in args.tune:
+        name, _, val = kv.partition("=")
+        capi.tune(name, float(val))
     if args.panel_slice_kb > 0:
         capi.tune("panel_slice_bytes", args.panel_slice_kb * 1024)
     elif args.panel_slice_kb < 0:
@@ -1272,6 +1635,12 @@ def main():
         barrier()
         rep_ms.append(allmax(time.perf_counter() - t1) / args.steps * 1e3)
     trainer.check()
+    sustained = None
+    if world == 1 and not sharded and args.model == "lr" and args.sustained_seconds > 0:
+        try:
+            sustained = sustained_leg(args, trainer, compiled, dt / args.steps * 1e3)
+        except Exception as e:   # the throughput line must not depend on this extra
+            sustained = {"error": str(e)}
     unoverlapped_ms = None
     kernel_timing = "HIP events on the step's stream inside the timed region (every 4th step " \
                     "records, into a ring of event sets: the host never waits for a step it " \
@@ -1304,7 +1673,8 @@ def main():
             trainer.check()
     dt = allmax(dt)
     # ... and after the last step (warm-up + the K timed steps + the repeats)
-    steps_trained = args.warmup + args.steps * (1 + args.repeats)
+    steps_trained = args.warmup + args.steps * (1 + args.repeats) + \
+        (sustained.get("steps", 0) if sustained else 0)
     try:
         if hb is None:
             raise RuntimeError("no held-out minibatch (see stderr)")
@@ -1565,6 +1935,9 @@ def main():
     if out.get("with_key_build") and "value" in out["with_key_build"]:
         out["value_with_key_build"] = out["with_key_build"]["value"]
         out["ms_per_step_with_key_build"] = out["with_key_build"]["ms_per_step"]
+        # (also inside the objects a reader of the line's head keeps)
+        out["roofline"]["with_key_build_ms"] = out["with_key_build"]["ms_per_step"]
+        out["config"]["with_key_build_ms"] = out["with_key_build"]["ms_per_step"]
     if fm_sharded is not None:
         out["fm"] = fm_sharded
     if world == 1 and not args.force_sharded and args.model == "lr" and not args.no_fm_leg:
@@ -1586,6 +1959,23 @@ def main():
                 out["table_sweep"] = table_sweep(args)
             except Exception as e:
                 out["table_sweep"] = {"error": str(e)}
+    if sustained is not None:
+        out["sustained"] = sustained
+    if world == 1 and not args.force_sharded and args.model == "lr" and not args.zipf:
+        if not args.no_fresh_table:
+            out["fresh_table"] = []
+            for nk in [int(x) for x in args.fresh_keys.split(",") if x]:
+                try:
+                    out["fresh_table"].append(fresh_table_leg(args, nk))
+                except Exception as e:
+                    out["fresh_table"].append({"keys_per_gpu": nk, "error": str(e)})
+                torch.cuda.empty_cache()
+        if not args.no_n8_shape:
+            try:
+                out["n8_shape"] = n8_shape_leg(args, ms_per_step)
+            except Exception as e:
+                out["n8_shape"] = {"error": str(e)}
+            torch.cuda.empty_cache()
     if args.pmc_calibrate:
         for kind in range(10):
             capi.check(capi.lib().xf_calib_stream(kind, 1 << 30, 3))
@@ -1596,13 +1986,33 @@ def main():
             out["logloss"]["learning_check"] = learning_check(args.seed + 5)
         except Exception as e:   # the throughput line must not depend on this extra
             out["logloss"]["learning_check"] = {"error": str(e)}
-    try:   # end to end from text / from the binarized block cache: tools/e2e_text.py's last run
-        out["end_to_end"] = json.load(open(os.path.join(ROOT, "profiles", "e2e_latest.json")))
-        out["end_to_end"]["source"] = "committed profile profiles/e2e_latest.json (a run of " \
-                                      "tools/e2e_text.py on the library of commit %s), NOT " \
-                                      "measured by this run" % out["end_to_end"].get("git_head")
+    out["end_to_end"] = None
+    if world == 1 and not args.force_sharded and args.model == "lr" and not args.no_end_to_end:
+        try:   # the worker on a text file, fresh processes: measured here, on a small file
+            out["end_to_end"] = end_to_end_leg()
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)}
+    try:   # ... and tools/e2e_text.py's last run on a 3 GB file, for reference
+        big = json.load(open(os.path.join(ROOT, "profiles", "e2e_latest.json")))
+        ref = {k: big.get(k) for k in ("first_epoch_from_text", "first_epoch_from_block_cache",
+                                       "first_epoch_from_text_gpu_tokeniser",
+                                       "average_over_4_epochs_from_text_gpu_tokeniser", "git_head")}
+        ref["source"] = "committed profile profiles/e2e_latest.json (tools/e2e_text.py, 1.2e6 " \
+                        "rows), NOT measured by this run"
+        if isinstance(out["end_to_end"], dict):
+            out["end_to_end"]["reference_3gb_file"] = ref
     except (OSError, ValueError):
-        out["end_to_end"] = None
+        pass
+    out["summary"] = summary_of(out)
+    for k in ("sustained_ms_per_step", "sustained_ratio", "n8_weak_sum_then_step_ms",
+              "n8_weak_rank_ordered_ms", "n8_strong_sum_then_step_ms",
+              "n8_strong_rank_ordered_ms", "n8_weak_with_key_build_ms", "fresh_1e+07_examples_per_s",
+              "fresh_1e+07_first_minibatch_ms", "fresh_1e+08_examples_per_s",
+              "sweep_1e+08_ms_per_step", "sweep_1e+08_gradient_frac",
+              "sweep_1e+08_with_key_build_ms", "zipf_ms_per_step", "zipf_gradient_frac",
+              "e2e_gpu_tokeniser_examples_per_s"):
+        if k in out["summary"]:   # (short scalars where a reader of the line's head keeps them)
+            out["roofline"][k] = out["summary"][k]
     if dist is not None:
         dist.destroy_process_group()
     if group is not None:

@@ -66,21 +66,23 @@ def test_local_batches_match_the_oracle(R, nnz, nkeys, zipf, ragged, cap):
         same(capi.lr_predict(t, bs[1], ws), obs[1].lr_loss(s.pull(obs[1].ukeys))[1])
 
 
-@pytest.mark.parametrize("knob", [300, 301, 302, 304, 428, 432, 299])
+@pytest.mark.parametrize("path", [("lr_gradient", 2), ("lr_gradient", 3), ("lr_gradient", 1),
+                                  ("old_weight", 2)])
 @pytest.mark.parametrize("opt", ["ftrl", "sgd"])
-def test_every_variant_of_the_gradient_kernel_gives_the_oracle_table(knob, opt):
-    """k_lr_grad_dense (the steady-state gradient + Push: one fp32 division for sum / R, the
-    touched keys compacted per wavefront / the state rows prefetched / 512 threads per chunk)
-    in every instantiation, and the general kernel alone (299): three windows, split and unsplit
-    chunks side by side (power law), holes and an arrival segment after the defrag — the table
-    bit for bit the exact-sum oracle's after every variant."""
+def test_every_variant_of_the_gradient_kernel_gives_the_oracle_table(path, opt):
+    """k_lr_grad_dense (the steady-state gradient + Push: one fp32 division for sum / R) with
+    byte-masked and with whole-line stores (lr_gradient = 2 / 3: the shape picks one), the general
+    kernel alone (lr_gradient = 1), and the old weights derived wherever the table vouches for them
+    (old_weight = 2): three windows, split and unsplit chunks side by side (power law), holes and
+    an arrival segment after the defrag — the table bit for bit the exact-sum oracle's each time.
+    (The measured-and-dropped variants of the kernel live behind -DXF_EXPERIMENTS.)"""
     rng = np.random.RandomState(11)
     oo, go = (O.OPT_FTRL, capi.OPT_FTRL) if opt == "ftrl" else (O.OPT_SGD, capi.OPT_SGD)
     t, s = capi.Table(go, 1, capacity=1 << 19), O.Store(oo, 1)
     ws = capi.Workspace()
     raw = [synth(rng, 40000, 30, 120000, 1.2 if i % 2 else None, True) for i in range(3)]
     obs = [O.Batch(*x) for x in raw]
-    capi.tune("exp_knob", knob)
+    capi.tune(*path)
     try:
         for i in range(4):
             b = capi.LocalBatch(t, *raw[i % 3], retain_keys=False)
@@ -94,7 +96,7 @@ def test_every_variant_of_the_gradient_kernel_gives_the_oracle_table(knob, opt):
             if i == 1:
                 t.defrag()
     finally:
-        capi.tune("exp_knob", 0)
+        capi.tune(path[0], 0)
     for a, e in zip(t.export(), s.export()):
         same(a, e)
 
@@ -228,19 +230,20 @@ def _steps(t, s, raw, obs, ws, n, keyed=True):
         del b
 
 
-@pytest.mark.parametrize("knob", [0, 299, 280])
-def test_the_old_weight_is_derived_from_n_and_z_only_while_that_is_the_stored_weight(knob):
+@pytest.mark.parametrize("path", [("lr_gradient", 0), ("lr_gradient", 1), ("old_weight", 1)])
+def test_the_old_weight_is_derived_from_n_and_z_only_while_that_is_the_stored_weight(path):
     """The gradient + Push kernels do not read w while every row's w is ftrl_w_of(n, z)
     (xf_table_w_derived): a fresh table, a table filled from a model this library exported.  A
     row imported with another w, or a change of the hyper-parameters with keys in the table,
     ends it — the next step of a key uses the STORED w (ftrl.h:63), as the oracle does.  Dense
-    kernel (0), general kernel (299), and the kernels made to read w throughout (280): the
+    kernel, general kernel (lr_gradient = 1), and the kernels made to read w throughout
+    (old_weight = 1): the
     oracle's table bit for bit in every phase."""
     rng = np.random.RandomState(23)
     ws = capi.Workspace()
     raw = [synth(rng, 6000, 40, 30000, 1.2 if i else None, True) for i in range(2)]
     obs = [O.Batch(*x) for x in raw]
-    capi.tune("exp_knob", knob)
+    capi.tune(*path)
     try:
         t, s = _ftrl_pair()
         assert t.w_derived()
@@ -286,4 +289,4 @@ def test_the_old_weight_is_derived_from_n_and_z_only_while_that_is_the_stored_we
         for a, e in zip(t4.export(), s4.export()):
             same(a, e)
     finally:
-        capi.tune("exp_knob", 0)
+        capi.tune(path[0], 0)

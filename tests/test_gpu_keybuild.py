@@ -2,7 +2,7 @@
 keys -> cells against a table with a settled tier, keys found where the tier's keys sit in LDS,
 first-touch keys as holes + a second segment of cells over the arrival rows.  Every case is
 checked three ways: against the oracle's exact-sum mode (bit for bit), against the general
-build of the same minibatches (table probe per nonzero + radix sort: tune exp_knob = 77), and
+build of the same minibatches (table probe per nonzero + radix sort: tune key_build = 1), and
 through the shape the build reports (segments)."""
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ def gpu():
 
 
 def general_path(on):
-    capi.tune("exp_knob", 77 if on else 0)
+    capi.tune("key_build", 1 if on else 0)
 
 
 def steps_vs_oracle(t, s, raws, ws, steps, retain=True, defrag_at=None):
@@ -57,14 +57,14 @@ def steps_vs_oracle(t, s, raws, ws, steps, retain=True, defrag_at=None):
     (20000, 3, 50000, None, False),      # short rows: many rows per scatter tile
 ])
 def test_settled_keys_new_keys_and_the_general_build_agree(R, nnz, nkeys, zipf, ragged):
-    """... and the TWO-LEVEL build (exp_knob 78 forces it on these small tables: groups of two
+    """... and the TWO-LEVEL build (key_build = 2 takes it on these small tables: groups of two
     super-chunks, k_kb_hist_groups / k_kb_regroup) gives the same cells' results again"""
     rng = np.random.RandomState(R + nnz)
     ws = capi.Workspace()
     raws = [synth(rng, R, nnz, nkeys, zipf, ragged) for _ in range(4)]
     tabs = []
-    for knob in (0, 78, 77):
-        capi.tune("exp_knob", knob)
+    for knob in (0, 2, 1):
+        capi.tune("key_build", knob)
         try:
             t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 20)
             s = O.Store(O.OPT_FTRL, 1)
@@ -76,7 +76,7 @@ def test_settled_keys_new_keys_and_the_general_build_agree(R, nnz, nkeys, zipf, 
             # ... minibatches 1-3 meet a settled tier that holds some of their keys: holes +
             # an arrival segment; after the second defrag everything is settled
             segs = steps_vs_oracle(t, s, raws[1:], ws, 7, defrag_at=3)
-            if knob != 77:
+            if knob != 1:
                 assert segs[0] == 2 and segs[-1] == 1, segs
             tabs.append(t.export())
         finally:
@@ -293,7 +293,7 @@ def test_update_in_one_call_is_the_key_build_and_the_step():
 def test_two_level_build_on_a_table_beyond_the_one_level_limit():
     """3.6e7 settled keys (the one-level partition stops at 3.4e7: the scatter's per-super-chunk
     arrays no longer fit the LDS): the minibatch takes the two-level build by itself — against
-    the general build (exp_knob 77) on a second table and against the oracle, on the keys the
+    the sort-based build (key_build = 1) on a second table and against the oracle, on the keys the
     minibatch touches (every other row of the tables is zero), with keys the tier does not hold
     among them (holes + an arrival segment)."""
     nkeys = 36_000_000
@@ -313,7 +313,7 @@ def test_two_level_build_on_a_table_beyond_the_one_level_limit():
     want = s.pull(ob.ukeys)
     ws = capi.Workspace()
     got = []
-    for knob in (0, 77):
+    for knob in (0, 1):
         t = capi.Table(capi.OPT_FTRL, 1, capacity=2 * nkeys + 65536)
         for lo in range(0, nkeys, 9_000_000):     # every key once: the table holds them all
             kk = keytab[lo:min(lo + 9_000_000, nkeys)]
@@ -323,13 +323,13 @@ def test_two_level_build_on_a_table_beyond_the_one_level_limit():
             capi.LocalBatch(t, rp, kk, np.zeros(rows, np.int32), retain_keys=False)
         t.defrag()
         assert len(t) == nkeys
-        capi.tune("exp_knob", knob)
+        capi.tune("key_build", knob)
         try:
             b = capi.LocalBatch(t, rowptr, keys, labels, retain_keys=False)
             info = b.cells_info()
             capi.lr_step(t, b, ws)
         finally:
-            capi.tune("exp_knob", 0)
+            capi.tune("key_build", 0)
         t.check()
         assert info["segments"] == (2 if knob == 0 else 1), (knob, info)   # (the general build
         same(ws.fetch_loss(R), loss_ex)                                    #  makes one segment)

@@ -529,14 +529,14 @@ def _pretend_data(step):
     return rowptr, keytab[fid], rng.randint(0, 2, size=R).astype(np.int32)
 
 
-def _pretend_rank(port, knob, outdir, q):
+def _pretend_rank(port, path, outdir, q):
     try:
         os.environ["XF_SHARDED_GENERAL"] = "1"
         os.environ["XF_OWNER_TIMING_SOURCES"] = "5"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         g = capi.Group(0, 1, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
         st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 19, schedule="owner")
-        capi.tune("exp_knob", knob)
+        capi.tune(*path)
         alive = []
         for s in range(4):
             alive.append(st.compile(*_pretend_data(s % 3)))
@@ -545,7 +545,7 @@ def _pretend_rank(port, knob, outdir, q):
                 st.defrag()      # holes and an arrival segment afterwards
         st.check()
         k, w, n, z = st.w.export()
-        np.savez(os.path.join(outdir, "pretend_%d.npz" % knob), k=k, w=w, n=n, z=z)
+        np.savez(os.path.join(outdir, "pretend_%s_%d.npz" % path), k=k, w=w, n=n, z=z)
         st.close()
         g.close()
         q.put(None)
@@ -555,26 +555,28 @@ def _pretend_rank(port, knob, outdir, q):
 
 def test_the_several_workers_pass_takes_the_steps_of_the_general_loop(tmp_path):
     """An owner's gradient + Pushes for several workers (XF_UPDATE_RANK_ORDERED): k_lr_grad_multi
-    and k_lr_grad_ranked (the chunk's state in LDS; the workers' phases merged — 291, and 292
-    with 32-bit masks — or a phase per worker with the stepping lane picked among the lanes that
-    hold the key: 293, and 512 / 256 / 1024 threads per chunk) against round 4's pass (exp_knob 298: state rows in registers, a
-    sweep per worker) on one GPU whose rows are dealt out to five pretended workers — five
-    optimizer steps per key, chunks below and above one round of registers, split chunks, holes
-    after a defrag: the same table, bit for bit.  (That the steps are the reference's: the
-    world-2 / 3 / 8 tests against the oracle, which run the same kernel.)  exp_knob 78: the
-    owner's cells through the two-level key build (nonzeros with row numbers)."""
+    and k_lr_grad_ranked (the chunk's state in LDS; the workers' phases merged — owner_pass = 2,
+    and 3 with 32-bit masks — or a phase per worker with the stepping lane picked among the lanes
+    that hold the key: 4; 0: the shape picks) against the general loop (owner_pass = 1: state rows
+    in registers, a sweep per worker) on one GPU whose rows are dealt out to five pretended
+    workers — five optimizer steps per key, chunks below and above one round of registers, split
+    chunks, holes after a defrag: the same table, bit for bit.  (That the steps are the
+    reference's: the world-2 / 3 / 8 tests against the oracle, which run the same kernel.)
+    key_build = 2: the owner's cells through the two-level key build (nonzeros with row
+    numbers)."""
     ctx = mp.get_context("spawn")
-    for knob in (298, 0, 293, 291, 292, 297, 296, 295, 78):
+    paths = [("owner_pass", v) for v in (1, 0, 4, 2, 3)] + [("key_build", 2)]
+    for path in paths:
         q = ctx.Queue()
-        p = ctx.Process(target=_pretend_rank, args=(free_port(), knob, str(tmp_path), q))
+        p = ctx.Process(target=_pretend_rank, args=(free_port(), path, str(tmp_path), q))
         p.start()
         err = q.get(timeout=240)
         p.join(timeout=60)
         assert not err, err
-    ref = np.load(str(tmp_path / "pretend_298.npz"))
+    ref = np.load(str(tmp_path / "pretend_owner_pass_1.npz"))
     assert len(ref["k"]) > 100000 and np.any(ref["w"] != 0)
-    for knob in (0, 293, 291, 292, 297, 296, 295, 78):
-        got = np.load(str(tmp_path / ("pretend_%d.npz" % knob)))
+    for path in paths[1:]:
+        got = np.load(str(tmp_path / ("pretend_%s_%d.npz" % path)))
         for f in ("k", "w", "n", "z"):
             same(got[f], ref[f])
 

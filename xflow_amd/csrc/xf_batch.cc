@@ -220,9 +220,14 @@ void blob_pool_limit(int blobs) {
 }  // namespace xf
 
 namespace xf {
+static int g_path[kPathCount] = {0, 0, 0, 0};
+int path_switch(int which) { return g_path[which]; }
+void set_path_switch(int which, int v) { g_path[which] = v; }
+#ifdef XF_EXPERIMENTS
 static int g_exp_knob = 0;
 int exp_knob() { return g_exp_knob; }
 void set_exp_knob(int v) { g_exp_knob = v; }
+#endif
 static std::atomic<bool> g_device_poisoned{false};
 bool device_poisoned() { return g_device_poisoned.load(std::memory_order_relaxed); }
 void scratch_poison() { g_device_poisoned.store(true); }
@@ -233,10 +238,20 @@ extern "C" int xf_tune(const char *name, double value) {
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
   else if (!strcmp(name, "parse_threads")) xf::set_parse_threads((int)value);
+  else if (!strcmp(name, "key_build") && value >= 0 && value <= 2)
+    xf::set_path_switch(xf::kPathKeyBuild, (int)value);
+  else if (!strcmp(name, "old_weight") && value >= 0 && value <= 2)
+    xf::set_path_switch(xf::kPathOldWeight, (int)value);
+  else if (!strcmp(name, "lr_gradient") && value >= 0 && value <= 3)
+    xf::set_path_switch(xf::kPathLrGradient, (int)value);
+  else if (!strcmp(name, "owner_pass") && value >= 0 && value <= 4)
+    xf::set_path_switch(xf::kPathOwnerPass, (int)value);
+#ifdef XF_EXPERIMENTS
   else if (!strcmp(name, "exp_knob")) xf::set_exp_knob((int)value);
+#endif
   else if (!strcmp(name, "batch_pool_blobs")) xf::blob_pool_limit((int)value);
   else
-    return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s'", name);
+    return xf::set_error(XF_EINVAL, "xf_tune: unknown knob '%s' (or a value it does not take)", name);
   return XF_OK;
 }
 

@@ -224,6 +224,93 @@ k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
   }
 }
 
+// The forward's copy of the cells: inside every cell the entries ordered by their position in
+// the chunk (the entry's low bits), so that neighbouring lanes gather neighbouring weights.  A
+// counting sort in LDS over the chunk's kChunk positions — a wavefront per cell (config 2: ~680
+// entries per cell, an owner's 32-window minibatch: ~50), the whole workgroup on a cell of more
+// than kSortWave entries, and a cell beyond kSortMax (a power-law head key's: one position holds
+// most of it) is copied as it is.  Not stable — the order of a position's entries is whatever
+// the LDS cursors make of it: the forward's fp64 row sums do not depend on it (exact).
+// Replaces rocprim::segmented_radix_sort_keys (2 x 112 us per 1e7 entries, round 2).
+constexpr uint32_t kSortWave = 4096, kSortMax = 1u << 17;
+constexpr int kSortCells = 4;  // cells (wavefronts) per workgroup
+__device__ __forceinline__ uint32_t sortp(uint32_t i) { return i + (i >> 5); }  // (bank padding)
+__device__ __forceinline__ void lds_wave_sync() {
+  // LDS accesses of ONE wavefront are served in order; this keeps the compiler from moving them
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT>  // threads that share `bins`: 64 (a wavefront, no barriers) or kBlock
+__device__ __forceinline__ void cell_sort_pos(uint32_t *bins, const uint32_t *__restrict__ in,
+                                              uint32_t *__restrict__ out, uint32_t n, uint32_t t) {
+  auto sync = [&]() {
+    if (NT == 64) lds_wave_sync();
+    else
+      __syncthreads();
+  };
+  constexpr uint32_t kPer = kChunk / NT;  // consecutive bins a thread scans
+  for (uint32_t i = t; i < kChunk + kChunk / 32; i += NT) bins[i] = 0;
+  sync();
+  for (uint32_t i = t; i < n; i += NT) atomicAdd(&bins[sortp(in[i] & (kChunk - 1))], 1u);
+  sync();
+  uint32_t sum = 0;
+#pragma unroll 8
+  for (uint32_t k = 0; k < kPer; ++k) sum += bins[sortp(t * kPer + k)];
+  // exclusive scan of the threads' sums: over the wavefront, then (NT > 64) over the wavefronts
+  const uint32_t lane = t & 63u;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += y;
+  }
+  uint32_t run = inc - sum;
+  if (NT > 64) {
+    uint32_t *wsum = bins + kChunk + kChunk / 32;  // [NT / 64] behind the bins
+    if (lane == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    for (uint32_t w = 0; w < (t >> 6); ++w) run += wsum[w];
+  }
+#pragma unroll 8
+  for (uint32_t k = 0; k < kPer; ++k) {
+    const uint32_t x = bins[sortp(t * kPer + k)];
+    bins[sortp(t * kPer + k)] = run;
+    run += x;
+  }
+  sync();
+  for (uint32_t i = t; i < n; i += NT) {
+    const uint32_t e = in[i];
+    out[atomicAdd(&bins[sortp(e & (kChunk - 1))], 1u)] = e;
+  }
+  sync();
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_cells_sort_pos(const uint32_t *__restrict__ entries, uint32_t *__restrict__ out,
+                 const uint32_t *__restrict__ cellptr, uint32_t ncell) {
+  static_assert(kBlock == 64 * kSortCells, "a wavefront per cell");
+  __shared__ uint32_t bins[kSortCells][kChunk + kChunk / 32 + 8];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t c0 = blockIdx.x * kSortCells;
+  {
+    const uint32_t c = c0 + wave;
+    if (c < ncell) {  // wave-uniform
+      const uint32_t b = cellptr[c], n = cellptr[c + 1] - b;
+      if (n && n <= kSortWave) cell_sort_pos<64>(bins[wave], entries + b, out + b, n, lane);
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < (uint32_t)kSortCells && c0 + k < ncell; ++k) {  // workgroup-uniform
+    const uint32_t b = cellptr[c0 + k], n = cellptr[c0 + k + 1] - b;
+    if (n <= kSortWave) continue;
+    if (n > kSortMax)
+      for (uint32_t i = tid; i < n; i += kBlock) out[b + i] = entries[b + i];
+    else
+      cell_sort_pos<kBlock>(bins[0], entries + b, out + b, n, tid);
+  }
+}
+
 // the same for nonzeros that come with their row number instead of in CSR order (the owner side
 // of the owner-compute step: nonzeros of several workers' minibatches, rows numbered window by
 // window across the workers)
@@ -1700,23 +1787,15 @@ int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
   return XF_OK;
 }
 
-// the forward's copy: every cell sorted by its entries' low bits (the position within the
-// chunk), stable, so that neighbouring lanes gather neighbouring weights (forward kernel
-// 58 -> 42 us on the config-2 shape; the segmented sort takes 100 us, so a minibatch that is
-// stepped once goes without and the forward reads the row-sorted cells)
+// the forward's copy: every cell ordered by its entries' low bits (the position within the
+// chunk), so that neighbouring lanes gather neighbouring weights (forward kernel 58 -> 42 us on
+// the config-2 shape): k_cells_sort_pos.  A minibatch that is stepped once goes without and the
+// forward reads the row-sorted cells.  In stream order, nothing is waited for.
 int cells_key_sorted_copy(xf_cells *c, hipStream_t s) {
   if (!c->NNZ || c->entries_k == c->entries) return XF_OK;
-  Scratch sc;
-  size_t tb = 0;
-  XF_HIP(rocprim::segmented_radix_sort_keys(nullptr, tb, c->entries, c->entries_k,
-                                            (size_t)c->NNZ, (unsigned)c->ncell, c->cellptr,
-                                            c->cellptr + 1, 0, kChunkBits, s));
-  void *tmp = nullptr;
-  XF_TRY(sc.get((char **)&tmp, tb));
-  XF_HIP(rocprim::segmented_radix_sort_keys(tmp, tb, c->entries, c->entries_k, (size_t)c->NNZ,
-                                            (unsigned)c->ncell, c->cellptr, c->cellptr + 1, 0,
-                                            kChunkBits, s));
-  XF_HIP(hipStreamSynchronize(s));  // the scratch goes back
+  hipLaunchKernelGGL(k_cells_sort_pos, dim3((c->ncell + kSortCells - 1) / kSortCells), dim3(kBlock),
+                     0, s, c->entries, c->entries_k, c->cellptr, c->ncell);
+  XF_HIP(hipGetLastError());
   c->entries_k_ready = true;
   return XF_OK;
 }
@@ -1864,7 +1943,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
                        hipStream_t s, const CellSources *src = nullptr) {
   if (c->nitems == 0) return XF_OK;
   TableDev T = T_;
-  if (exp_knob() == 280) T.w_of_nz = false;  // (A/B: the kernels read w, as before round 5)
+  if (path_switch(kPathOldWeight) == 1) T.w_of_nz = false;  // (old_weight = read, xf_common.h)
   double *gsum = src ? src->gsum : c->gsum;
   uint8_t *gtouched = src ? src->gtouched : c->gtouched;
   const uint8_t *no_skip = nullptr;
@@ -1900,14 +1979,16 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
     // registers, the general loop the others (the slices of split chunks, chunks with more
     // entries, more row windows or workers than its LDS tables hold)
     bool multi = false;
-    if constexpr (MODE == 0) multi = !d_g && c->item_done && exp_knob() != 298;
+    const int pass = path_switch(kPathOwnerPass);  // (xf_common.h: 0 by shape)
+    if constexpr (MODE == 0) multi = !d_g && c->item_done && pass != 1;
     if (multi) {
       if constexpr (MODE == 0) {
         const int full = dense_touch(c) ? 1 : 0;
         // 512 threads per chunk (four entries per lane, 64 registers), the key sums in the
         // stepping lanes' slots (SLOTS: 34 KB of LDS, four workgroups = 32 wavefronts per CU):
-        // 140 us at the N = 8 shard shape; the sums indexed by key (46 KB, three workgroups): 155
-        // (exp_knob 295); 256 threads: 164-193 (297); 1024: 183 (296)
+        // 140 us at the N = 8 shard shape; the sums indexed by key (46 KB, three workgroups): 155;
+        // 256 threads: 164-193; 1024: 183 (the variants: -DXF_EXPERIMENTS)
+#ifdef XF_EXPERIMENTS
         if (exp_knob() == 295)  // (the key sums indexed by key: three workgroups per CU, 155 us)
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, false>), dim3(c->nitems), dim3(512), 0, s,
                              T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
@@ -1927,16 +2008,17 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         // 140 us at the N = 8 shard shape) where a worker's entries in a chunk fit its slots; the
         // merged phases (k_lr_grad_ranked: ~140 us whatever the number of workers — 134 / 141 /
         // 143 us for 2 / 4 / 8 of them against 185 (the general kernel: over the slots) / 123 /
-        // 141) where they do not: two or three workers.  (exp_knob 293 / 291: one or the other.)
-        else if (exp_knob() == 293 || src->n > 32 ||
-                 (exp_knob() != 291 && exp_knob() != 292 &&
-                  (double)c->NNZ / c->nitems / src->n <= 0.9 * kMultiCap))
+        // 141) where they do not: two or three workers.  (owner_pass = 4 / 2: one or the other.)
+        else
+#endif
+        if (pass == 4 || src->n > 32 ||
+            (pass != 2 && pass != 3 && (double)c->NNZ / c->nitems / src->n <= 0.9 * kMultiCap))
           hipLaunchKernelGGL((k_lr_grad_multi<OPT, 512, true>), dim3(c->nitems), dim3(512), 0, s,
                              T, c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
                              src->d_loss_base, c->chunk0, full, c->item_done);
-        else if (src->n <= 8 && exp_knob() != 292)  // the workers' phases merged (k_lr_grad_ranked;
-                                                     // 292: its 32-bit masks whatever the number)
+        else if (src->n <= 8 && pass != 3)  // the workers' phases merged (k_lr_grad_ranked;
+                                            // owner_pass = 3: its 32-bit masks whatever the number)
           hipLaunchKernelGGL((k_lr_grad_ranked<OPT, 8>), dim3(c->nitems), dim3(512), 0, s, T,
                              c->entries, c->cellptr, c->nchunk, c->nwin, c->item_chunk,
                              c->item_slice, d_loss, c->M, src->n, src->d_win, src->d_rows,
@@ -1952,7 +2034,7 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
                          c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
                          src->n, src->d_win, src->d_rows, c->nsplit_chunks, src->d_loss_base,
                          c->chunk0, (const uint8_t *)c->item_done);
-    } else {  // (round 4's pass, kept for A/B: exp_knob 298)
+    } else {  // (the general loop, a sweep per worker: gradients wanted, or owner_pass = 1)
       hipLaunchKernelGGL((k_lr_grad_cells<OPT, MODE, true, true>), dim3(c->nitems), dim3(kBlock),
                          0, s, T, c->entries, c->cellptr, c->nchunk, c->nwin, c->W, c->item_chunk,
                          c->item_slice, c->item_dump, d_loss, c->R, c->M, d_g, gsum, gtouched,
@@ -1977,9 +2059,14 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         // whole-line stores (variant kDenseFullStore) where the minibatch touches most lines of
         // the chunks it runs over, byte-masked stores of the touched rows where it does not
         int var = dense_touch(c) ? XF_GRAD_DENSE_VAR : (XF_GRAD_DENSE_VAR & ~kDenseFullStore);
+#ifdef XF_EXPERIMENTS
         const int knob = exp_knob();
-        if (knob >= 300 && knob < 812) var = knob - 300;  // (experiments: tools/cells_knobs.py)
-        dense = knob != 299;                               // 299: the general kernel alone
+        if (knob >= 300 && knob < 812) var = knob - 300;  // (tools/cells_knobs.py)
+#endif
+        const int lg = path_switch(kPathLrGradient);  // (xf_common.h)
+        if (lg == 2) var = 0;
+        if (lg == 3) var = kDenseFullStore;
+        dense = lg != 1;
         // (Measured and dropped: fewer workgroups per CU — 4 .. 7 instead of 8, by a pad of dynamic
         // LDS — so that the rounds of workgroups come out even (4883 chunks are 2.38 rounds of
         // 2048): 74.5-76.6 us at every occupancy against 74.6-75.4, tools/r5/call13.sh.)
@@ -1989,10 +2076,11 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         // minibatch that touches the chunks thinly.  A small table touched densely (config 2:
         // 120 MB of state, every line of w needed anyway) has the lines on hand and the ~45
         // instructions of the derivation per row are not hidden (this kernel's phases add up,
-        // DESIGN 3): 74.6 -> 77.7 us with it, so there the kernel reads w.  (exp_knob 279:
+        // DESIGN 3): 74.6 -> 77.7 us with it, so there the kernel reads w.  (old_weight = derive:
         // derived whatever the table.)
         TableDev Td = T;
-        if (dense_touch(c) && (size_t)c->M * 12 <= ((size_t)180 << 20) && knob != 279)
+        if (dense_touch(c) && (size_t)c->M * 12 <= ((size_t)180 << 20) &&
+            path_switch(kPathOldWeight) != 2)
           Td.w_of_nz = false;
         if (dense) {
 #define XF_DENSE(V)                                                                              \
@@ -2006,12 +2094,13 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
     break
           switch (var) {
             XF_DENSE(0);
+            XF_DENSE(128);
+#ifdef XF_EXPERIMENTS  // the measured-and-not-adopted variants and the timing
+                       // experiments (some with WRONG results): never in a product build
             XF_DENSE(1);
             XF_DENSE(2);
             XF_DENSE(4);
-            XF_DENSE(128);
             XF_DENSE(128 + 4);
-#ifdef XF_EXPERIMENTS  // timing experiments (some with WRONG results): never in a product build
             XF_DENSE(5);
             XF_DENSE(6);
             XF_DENSE(8);

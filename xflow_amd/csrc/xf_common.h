@@ -20,8 +20,26 @@ void set_parse_threads(int n);
 // Scratch and the trainer's Dev<> buffers leak their memory from then on.
 bool device_poisoned();
 void scratch_poison();
+// Named switches between code paths that are ALL product code — which one runs is normally
+// decided by the shape; tests pin one to run each against the oracle (xf_tune, by name):
+//   key_build    0 by shape; 1 the sort-based build (a probe of the table per nonzero + a radix
+//                pass on the cell number: the limits' fallback and the tests' independent second
+//                implementation); 2 the two-level partition also where one level would do
+//   old_weight   0 by shape (xf_cells_grad.hip); 1 the gradient + Push kernels READ a step's old w;
+//                2 they derive it from (n, z) wherever the table vouches for it
+//   lr_gradient  0 by shape; 1 the general kernel also where the dense one applies; 2 / 3 the
+//                dense kernel with byte-masked / whole-line stores whatever the touch density
+//   owner_pass   an owner's gradient + Pushes for several workers: 0 by shape; 1 the general
+//                loop (a sweep per worker); 2 the workers' phases merged (k_lr_grad_ranked);
+//                3 the same with 32-bit worker masks; 4 a phase per worker (k_lr_grad_multi)
+enum PathSwitch { kPathKeyBuild = 0, kPathOldWeight, kPathLrGradient, kPathOwnerPass, kPathCount };
+int path_switch(int which);
+void set_path_switch(int which, int v);
+inline int key_build_mode() { return path_switch(kPathKeyBuild); }
+#ifdef XF_EXPERIMENTS  // timing experiments (tools/): never in a product build
 int exp_knob();
 void set_exp_knob(int v);
+#endif
 
 #define XF_HIP(expr)                                                                  \
   do {                                                                                \

@@ -67,6 +67,7 @@ void **table_aux(xf_table *t, uint64_t **epoch);
 uint64_t table_epoch(const xf_table *t);
 int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
                       hipStream_t s, bool allow_grow);
+int table_grow_for(xf_table *t, const uint64_t *d_keys, size_t n, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -176,6 +177,12 @@ struct KbArgs {
   KbSummary *sum;                  // device copy
   unsigned long long *dbg;         // phase timestamps (tools/kb_timeline.py), or null
 };
+// timing-only switches of the kernels (parts skipped, WRONG results): constants in a product build
+#ifdef XF_EXPERIMENTS
+#define KB_FLAG(bit) (a.flags & (bit))
+#else
+#define KB_FLAG(bit) false
+#endif
 #define KB_T(slot)                                                                   \
   do {                                                                               \
     if (a.dbg && threadIdx.x == 0) dbg_base[(slot)] = wall_clock64();                \
@@ -456,7 +463,7 @@ k_kb_hist(KbArgs a) {
         in_lds = j < wend;  // (a round that straddles the window's end: its tail, rare)
         if (!in_lds) v = window_of_entry(a.rowptr, a.R, a.W, a.nwin, j);
       }
-      if (a.flags & 64) continue;
+      if (KB_FLAG(64)) continue;
       if (in_lds) {
         atomicAdd(&lh[c], 1u);
       } else {
@@ -475,7 +482,7 @@ k_kb_hist(KbArgs a) {
   KB_T(2);
   __syncthreads();
   KB_T(3);
-  if (!(a.flags & 1))
+  if (!KB_FLAG(1))
     for (uint32_t c = tid; c < a.cA; c += kKb) {
       const uint32_t n = lh[c];
       if (n) {
@@ -1086,7 +1093,7 @@ k_kb_scatter(KbArgs a) {
     if (dslot < kDbgSlots - 8) KB_T(dslot++);
     lds_barrier();
     if (dslot < kDbgSlots - 8) KB_T(dslot++);
-    if (!(a.flags & 2))
+    if (!KB_FLAG(2))
       for (uint32_t i = tid; i < n; i += kKb) {
         const uint32_t S = L.stB[i];
         const uint64_t kk = L.stK[i];
@@ -1216,7 +1223,7 @@ k_kb_resolve(KbArgs a) {
     for (int q = 0; q < E; ++q) {
       // ub = number of the super-chunk's keys <= key
       uint32_t ub = key[q] < kfirst ? 0u : kb_count(lkf, ds[q], de[q], x0[q], x1[q], key[q]);
-      if (a.flags & 8) ub = 1;
+      if (KB_FLAG(8)) ub = 1;
       const uint32_t p = ub ? ub - 1 : 0u;  // the largest position with lk <= key
       const bool found = ok[q] && ub > 0 && lk[p] == key[q];
       const uint32_t cl = p >> kChunkBits, c = (S << kSCShift) + cl;
@@ -1224,10 +1231,10 @@ k_kb_resolve(KbArgs a) {
       cell[q] = local ? (v << kSCShift) + cl : v * a.cA + c;
       ent[q] = found ? ((c & xf::kTagMask) << kTagShift) | (rin << kChunkBits) | (p & (kChunk - 1))
                      : kHole;
-      miss[q] = ok[q] && !found && !(a.flags & 8);
+      miss[q] = ok[q] && !found && !KB_FLAG(8);
     }
     if (dslot < kDbgSlots - 4) KB_T(dslot++);
-    if (a.flags & 4) {
+    if (KB_FLAG(4)) {
 #pragma unroll
       for (int q = 0; q < E; ++q)
         if (ok[q]) entries[i0 + q * kRes + tid] = ent[q];
@@ -1238,7 +1245,7 @@ k_kb_resolve(KbArgs a) {
     // window: kSC ballots (wave-uniform masks and counts), lane cl adds cell cl's count to the
     // cell's cursor, every lane takes its base from that lane.  Records of other windows
     // (where the tiles of two windows meet) go through a loop over their cells.
-    if (local && !(a.flags & 16)) {
+    if (local && !KB_FLAG(16)) {
       // every lane takes its slot with its own LDS atomic: 64 lanes on the ~4 cursors of a
       // window's cells serialise in the LDS, but the ~40 VALU instructions per record of the
       // ballot rounds below go — the kernel is VALU-bound after its load burst: 122 -> 113 us
@@ -1311,6 +1318,271 @@ k_kb_resolve(KbArgs a) {
   KB_T(kDbgSlots - 1);
 }
 
+
+// --------------------------------------------------------------------- first touch (round 6)
+// Keys the settled tier does not hold — every key of a run's first minibatches (ftrl.h:56 inserts
+// on the first Pull, lr_worker.cc:183-188 starts from an empty store).  Until round 5 they went
+// through a probe of the 24-bytes-per-key arrival index per nonzero (a 128-byte line from HBM
+// each: 457 us per 1e7) and two rocPRIM radix passes on the cell number.  Now the same partition
+// idea as above, with UNIFORM key ranges (the arrival index is order-preserving: a key range is a
+// range of index positions):
+//   k_ar_ranges                       range r = bucket r of kb_bucket (boundaries + directory,
+//                                     so that the partition kernels above serve unchanged)
+//   k_kb_hist_groups / _scan / _scatter   (key, row) records grouped by key range
+//   k_ar_insert   one workgroup per range (parts of a heavy one): its records probe the arrival
+//                 index — the range's positions, L2-resident while the workgroup runs — with an
+//                 insert on miss; ONE atomic on the table's row counter per batch of 8192 records,
+//                 the new keys' rows consecutive; every record's state row is written out and
+//                 counted into its cell (row window, chunk of arrival rows)
+//   k_kb_scan     (cell part) cellptr, the gradient's work items
+//   k_ar_place    every record takes the next slot of its cell and becomes an entry
+// No sort, no probe that leaves the L2, no library call.
+struct ArArgs {
+  xf::TableDev T;
+  const Rec3 *rec;         // [n] records grouped by key range
+  const uint32_t *sstart;  // [nR + 1]
+  const uint32_t *items;   // range | part << 16
+  const uint32_t *nitems;
+  uint32_t n, nwin, nchunk, chunk0;
+  uint32_t *rec_row;       // [n] state row of every record
+  uint32_t *hist;          // [nwin * nchunk]
+  uint32_t *cellcur;       // [nwin * nchunk] next free slot of every cell (after the scan)
+  const uint32_t *cellptr; // [nwin * nchunk + 1]
+  uint32_t *entries;       // [n]
+  uint32_t *blk_cell;      // [n / kBlk + 1]
+};
+
+__global__ void __launch_bounds__(256)
+k_ar_ranges(uint64_t lo, uint32_t n, uint32_t mult, uint64_t *__restrict__ bnd,
+            uint16_t *__restrict__ dir) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  dir[r] = (uint16_t)r;  // ranges that begin in buckets < r
+  // the smallest h = (key - lo) >> 32 with mulhi32(h, mult) >= r
+  if (r < n) bnd[r] = lo + ((r == 0 ? 0ull : (((uint64_t)r << 32) + mult - 1) / mult) << 32);
+}
+
+// add 1 to counter[cell] (count = true) or take a slot from it (count = false) for every lane
+// with `on`: the lanes of the wavefront that hold the same cell share one atomic (a range's new
+// keys get consecutive rows: a wavefront's records fall into a few cells); after kArRounds
+// distinct cells the lanes left over go one by one
+constexpr int kArRounds = 6;
+__device__ __forceinline__ uint32_t ar_cell_slot(uint32_t *__restrict__ counter, bool on,
+                                                 uint32_t cell) {
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long todo = __ballot(on);
+  uint32_t slot = 0;
+  bool placed = !on;
+  for (int round = 0; todo && round < kArRounds; ++round) {  // wave-uniform
+    const int l = __ffsll((long long)todo) - 1;
+    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell, l);
+    const bool me = !placed && cell == lc;
+    const unsigned long long m = __ballot(me);
+    uint32_t base = 0;
+    if ((int)lane == l) base = atomicAdd(&counter[lc], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+    if (me) {
+      slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      placed = true;
+    }
+    todo &= ~m;
+  }
+  if (!placed) slot = atomicAdd(&counter[cell], 1u);
+  return slot;
+}
+
+constexpr int kAr = 1024;                      // threads of an insert workgroup
+constexpr int kArE = 8;                        // records per thread and batch
+constexpr uint32_t kArBatch = kAr * kArE;      // records whose rows are handed out together
+constexpr int kArWin = 4;                      // index positions read per probe round
+
+__global__ void __launch_bounds__(kAr)
+k_ar_insert(ArArgs a) {
+  __shared__ uint32_t s_new, s_cur;
+  __shared__ unsigned long long s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (blockIdx.x >= *a.nitems) return;
+  const xf::TableDev &T = a.T;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t sb = a.sstart[S], se = a.sstart[S + 1];
+  const uint32_t rb = sb + part * kPart, re = min(se, rb + kPart);
+  for (uint32_t b0 = rb; b0 < re; b0 += kArBatch) {  // workgroup-uniform
+    if (tid == 0) {
+      s_new = 0;
+      s_cur = 0;
+    }
+    __syncthreads();
+    uint64_t key[kArE];
+    uint32_t rp[kArE], pos[kArE], row[kArE];
+    bool ok[kArE], ins[kArE], bad[kArE];
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      const uint32_t i = b0 + q * kAr + tid;
+      ok[q] = i < re;
+      const Rec3 r = ok[q] ? a.rec[i] : Rec3{0u, 0u, 0u};
+      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+      rp[q] = r.rp;
+    }
+    // (a) every record finds its key's position in the arrival index, or claims an empty one
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      ins[q] = bad[q] = false;
+      pos[q] = (uint32_t)T.cap;
+      row[q] = (uint32_t)T.max_rows;  // the write-off row
+      if (!ok[q]) continue;
+      if (key[q] == xf::kEmptyKey) {  // the reserved value lives at the spare position
+        ins[q] = atomicExch(&T.stat->spare_used, 1u) == 0u;
+        if (ins[q]) T.keys[T.cap] = key[q];
+      } else if (!xf::owns(T, key[q])) {
+        atomicOr(&T.stat->err, xf::kErrForeignKey);
+        bad[q] = true;
+      } else {
+        bool done = false;
+        uint64_t p = xf::home_of(T, key[q]);
+        for (uint64_t probes = 0; probes < T.cap && !done; probes += kArWin) {
+          uint64_t idx[kArWin], cur[kArWin];
+#pragma unroll
+          for (int t = 0; t < kArWin; ++t) {
+            idx[t] = p + t;
+            if (idx[t] >= T.cap) idx[t] -= T.cap;
+          }
+#pragma unroll
+          for (int t = 0; t < kArWin; ++t) cur[t] = T.keys[idx[t]];
+#pragma unroll
+          for (int t = 0; t < kArWin; ++t) {
+            if (done) break;
+            uint64_t c = cur[t];
+            if (c == xf::kEmptyKey) {
+              // (the atomic is served at the coherent point: a stale EMPTY read — another
+              // workgroup inserted meanwhile — is corrected by the returned value)
+              c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key[q]);
+              if (c == xf::kEmptyKey) {
+                ins[q] = true;
+                c = key[q];
+              }
+            }
+            if (c == key[q]) {
+              pos[q] = (uint32_t)idx[t];
+              done = true;
+            }
+          }
+          p = idx[kArWin - 1] + 1;
+          if (p >= T.cap) p -= T.cap;
+        }
+        if (!done) {
+          atomicOr(&T.stat->err, xf::kErrFull);
+          bad[q] = true;
+        }
+      }
+      mine += ins[q] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0 && mine) atomicAdd(&s_new, mine);
+    __syncthreads();
+    if (tid == 0) s_base = s_new ? atomicAdd(&T.stat->count, (unsigned long long)s_new) : 0ull;
+    __syncthreads();
+    // (b) consecutive rows for the batch's new keys; published at once — a record of another
+    // workgroup that met the key in this launch waits for the row below, and nobody waits before
+    // publishing
+    const unsigned long long base = s_base;
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      const unsigned long long m = __ballot(ins[q]);
+      if (!m) continue;  // wave-uniform
+      const int l = __ffsll((long long)m) - 1;
+      uint32_t at = 0;
+      if ((int)lane == l) at = atomicAdd(&s_cur, (uint32_t)__popcll(m));
+      at = (uint32_t)__builtin_amdgcn_readlane((int)at, l);
+      if (ins[q]) {
+        const unsigned long long r = base + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (r < T.max_rows) {
+          row[q] = (uint32_t)r;
+          if (T.init_kind != XF_INIT_ZERO) {  // (the memory is pre-zeroed for XF_INIT_ZERO)
+            float *dst = T.w + (size_t)row[q] * T.dim;
+            for (int j = 0; j < T.dim; ++j)
+              dst[j] = T.init_kind == XF_INIT_CONST ? T.init_const
+                                                    : xf::hashnorm(T.seed, key[q], (uint32_t)j);
+          }
+        } else {
+          atomicOr(&T.stat->err, xf::kErrFull);
+        }
+        __hip_atomic_store(&T.rows[pos[q]], row[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // (c) the rows of the keys that were there (or were inserted by somebody else just now)
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      if (!ok[q]) continue;
+      if (!ins[q] && !bad[q]) {
+        uint32_t r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; r == xf::kNoRow && spin < (1 << 22); ++spin) {
+          __builtin_amdgcn_s_sleep(1);
+          r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (r == xf::kNoRow) {
+          atomicOr(&T.stat->err, xf::kErrDupKey);
+          r = (uint32_t)T.max_rows;
+        }
+        row[q] = r;
+      }
+      a.rec_row[b0 + q * kAr + tid] = row[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      const uint32_t cell =
+          (rp[q] >> kRinBits) * a.nchunk + ((row[q] >> kChunkBits) - a.chunk0);
+      (void)ar_cell_slot(a.hist, ok[q], cell);
+    }
+    __syncthreads();  // (s_new / s_cur are reset by the next batch)
+  }
+}
+
+// every record becomes the entry of its cell; the workgroups beyond the records compute blk_cell
+__global__ void __launch_bounds__(kRes)
+k_ar_place(ArArgs a) {
+  constexpr int E = 4;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nwg = (a.n + kRes * E - 1) / (kRes * E);
+  if (blockIdx.x >= nwg) {  // blk_cell[b] = the largest cell with cellptr[cell] <= kBlk * b
+    const uint32_t ncell = a.nwin * a.nchunk, nblk = (a.n + kBlk - 1) / kBlk;
+    const uint32_t spare = gridDim.x - nwg;
+    for (uint32_t b = (blockIdx.x - nwg) * kRes + tid; b <= nblk; b += spare * kRes) {
+      uint32_t lo = 0, hi = ncell;  // cellptr[0] = 0
+      if (b == nblk) lo = ncell - 1;
+      else
+        while (hi - lo > 1) {
+          const uint32_t m = lo + (hi - lo) / 2;
+          if (a.cellptr[m] <= b * kBlk) lo = m;
+          else
+            hi = m;
+        }
+      a.blk_cell[b] = lo;
+    }
+    return;
+  }
+  Rec3 rec[E];
+  uint32_t row[E];
+  bool ok[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t i = blockIdx.x * kRes * E + q * kRes + tid;
+    ok[q] = i < a.n;
+    rec[q] = ok[q] ? a.rec[i] : Rec3{0u, 0u, 0u};
+    row[q] = ok[q] ? a.rec_row[i] : a.chunk0 << kChunkBits;
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t v = rec[q].rp >> kRinBits, rin = rec[q].rp & ((1u << kRinBits) - 1u);
+    const uint32_t c = (row[q] >> kChunkBits) - a.chunk0;
+    const uint32_t slot = ar_cell_slot(a.cellcur, ok[q], v * a.nchunk + c);
+    if (ok[q])
+      a.entries[slot] =
+          ((c & xf::kTagMask) << kTagShift) | (rin << kChunkBits) | (row[q] & (kChunk - 1));
+  }
+}
 
 // ----------------------------------------------------------------------------------- FM
 // The key build of FMWorker::update (fm_worker.cc:205-225) against the v table's settled tier.
@@ -1537,12 +1809,24 @@ static KbSummary *summary_buf() {
 // phase timestamps of the last keyed build (exp_knob 200 turns them on): [hist workgroups |
 // scatter workgroups | resolve workgroups] x kDbgSlots, wall_clock64 ticks (10 ns)
 static unsigned long long *g_dbg = nullptr;
-static size_t g_dbg_n = 0, g_dbg_used = 0;
+[[maybe_unused]] static size_t g_dbg_n = 0;
+static size_t g_dbg_used = 0;
 static uint32_t g_dbg_shape[3] = {0, 0, 0};
 
+static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
+                         const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R, uint32_t n,
+                         bool ksc, uint32_t w_fixed, uint32_t chunk0, hipStream_t s, bool *done);
+
+// no settled tier (a table's first minibatches), or beyond the keyed build's limits
 static int general_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                          const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R,
                          uint32_t NNZ, bool ksc, uint32_t w_fixed, hipStream_t s) {
+  if (table_dev(t).nbase == 0) {  // every key goes through the arrival index: the first-touch build
+    bool done = false;
+    XF_TRY(arrival_build(out, t, d_keys, d_rowptr, d_rowid, R, NNZ, ksc, w_fixed, 0, s, &done));
+    if (done) return XF_OK;
+  }
+  // the sort-based build: a probe of the table per nonzero + a radix pass on the cell number
   Scratch sc;
   uint32_t *idx = nullptr;
   XF_TRY(sc.get(&idx, NNZ));
@@ -1550,6 +1834,148 @@ static int general_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   const uint64_t M = table_dev(t).max_rows + 1;
   return cells_build(out, idx, nullptr, d_rowptr, R, NNZ, (uint32_t)M, kCellsTableRows, ksc, s,
                      NNZ ? d_rowid : nullptr, w_fixed);
+}
+
+#define XF_KB_LAUNCH_N(kern, grid, threads, lds, args)                                         \
+  do {                                                                                         \
+    static bool attr_done = false;                                                             \
+    if (!attr_done) {                                                                          \
+      XF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)kDynMax));                                               \
+      attr_done = true;                                                                        \
+    }                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, args);                         \
+  } while (0)
+
+// The first-touch build (kernels: "first touch" above): the n nonzeros d_keys[] — CSR order with
+// d_rowptr, or any order with their row numbers d_rowid (rows numbered window by window, w_fixed
+// per window) — NONE of whose keys the settled tier holds are looked up in the arrival index
+// (insert on miss, ftrl.h:56), and *out are their cells over the chunks from chunk0 on.  The
+// table may grow first.  Synchronises the stream.  *done = false: beyond this build's limits,
+// nothing was done (the caller takes the sort-based build).
+constexpr uint32_t kArMaxRanges = 1500;
+static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
+                         const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R, uint32_t n,
+                         bool ksc, uint32_t w_fixed, uint32_t chunk0, hipStream_t s, bool *done) {
+  *done = false;
+  KbSummary *sum = summary_buf();
+  if (n == 0 || n >= (1u << 30) || !sum ||
+      ((uint64_t)n + kTile - 1) / kTile > (uint64_t)kMaxSub * 256 || key_build_mode() == 1)
+    return XF_OK;
+  {
+    const TableDev &T0 = table_dev(t);
+    const uint32_t nwin0 = w_fixed ? std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed)
+                                   : std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+    // (the cell histogram: a table that grows below has more chunks — bounded by twice the rows
+    // this minibatch can add)
+    const uint64_t rows_bound = std::max<uint64_t>(T0.max_rows + 1, 2 * ((uint64_t)n + T0.max_rows));
+    if ((rows_bound / kChunk + 1) * nwin0 >= (1ull << 22)) return XF_OK;
+  }
+  XF_TRY(table_grow_for(t, d_keys, n, s));
+  const TableDev T = table_dev(t);
+  xf_cells *c = nullptr;
+  XF_TRY(cells_alloc(&c, R, n, (uint32_t)(T.max_rows + 1), kCellsTableRows, ksc, w_fixed, chunk0));
+  struct Guard {
+    xf_cells *c;
+    ~Guard() {
+      if (c) cells_free(c);
+    }
+  } guard{c};
+  const size_t ncell = (size_t)c->nwin * c->nchunk;
+  Scratch sc;
+  const uint32_t nR = std::min<uint32_t>(kArMaxRanges, std::max<uint32_t>(1, (n + kArBatch - 1) / kArBatch));
+  KbArgs a{};
+  a.keys = d_keys;
+  a.rowptr = d_rowid ? nullptr : d_rowptr;
+  a.rowid = d_rowid;
+  a.R = R;
+  a.NNZ = n;
+  a.W = c->W;
+  a.nwin = c->nwin;
+  a.cA = c->nchunk;
+  a.nS = nR;
+  a.tile = kTile;
+  a.ntile = (n + a.tile - 1) / a.tile;
+  a.lo = T.lo;
+  const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
+  a.span = sub * a.tile;
+  a.nW = (a.ntile + sub - 1) / sub;
+  a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
+  const unsigned max_items = nR + n / kPart + 1;
+  uint32_t *small = nullptr;
+  const size_t n_zero = 4 + ncell;  // the summary and the cell histogram: cleared together
+  const size_t n_small = n_zero + ncell + (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR +
+                         a.ntile + 1 + a.npc;
+  XF_TRY(sc.get(&small, n_small));
+  a.sum = (KbSummary *)small;
+  a.hist = small + 4;
+  a.cellcur = a.hist + ncell;
+  a.scount = a.cellcur + ncell;
+  a.sstart = a.scount + nR;
+  a.items = a.sstart + nR + 1;
+  a.nitems = a.items + max_items;
+  a.wgcnt = a.nitems + 1;
+  a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
+  a.psum = a.tile_r0 + a.ntile + 1;
+  a.cellptr = c->cellptr;
+  a.entries = c->entries;
+  a.plan = c->plan;
+  a.blk_cell = c->blk_cell;
+  uint64_t *bnd = nullptr;
+  uint16_t *dir = nullptr;
+  uint32_t *rec_row = nullptr;
+  XF_TRY(sc.get(&bnd, nR));
+  XF_TRY(sc.get(&dir, nR + 1));
+  XF_TRY(sc.get(&a.rec, n));
+  XF_TRY(sc.get(&rec_row, n));
+  a.sc.bnd = bnd;
+  a.sc.dir = dir;
+  a.sc.n = nR;
+  a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((T.span >> 32) + 1), 0xFFFFFFFFull);
+  XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
+  hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, T.lo, nR, a.sc.mult, bnd,
+                     dir);
+  a.scan_part = 1;
+  if (d_rowid) XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
+  else
+    XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
+                     a);
+  if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, scatter_lds_bytes(nR, kTile), a);
+  else
+    XF_KB_LAUNCH_N((k_kb_scatter<false, kTile>), a.nW, kKb, scatter_lds_bytes(nR, kTile), a);
+  ArArgs r{};
+  r.T = T;
+  r.rec = a.rec;
+  r.sstart = a.sstart;
+  r.items = a.items;
+  r.nitems = a.nitems;
+  r.n = n;
+  r.nwin = c->nwin;
+  r.nchunk = c->nchunk;
+  r.chunk0 = chunk0;
+  r.rec_row = rec_row;
+  r.hist = a.hist;
+  r.cellcur = a.cellcur;
+  r.cellptr = c->cellptr;
+  r.entries = c->entries;
+  r.blk_cell = c->blk_cell;
+  hipLaunchKernelGGL(k_ar_insert, dim3(max_items), dim3(kAr), 0, s, r);
+  a.scan_part = 2;
+  if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
+  const uint32_t nwg = (n + kRes * 4 - 1) / (kRes * 4);
+  hipLaunchKernelGGL(k_ar_place, dim3(nwg + std::min<uint32_t>(64, nwg / 8 + 1)), dim3(kRes), 0, s, r);
+  XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  XF_TRY(cells_fill_items(c, sum->nitems, sum->nsplit, s));
+  XF_TRY(cells_key_sorted_copy(c, s));
+  XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+  guard.c = nullptr;
+  *out = c;
+  *done = true;
+  return XF_OK;
 }
 
 // the chunk / super-chunk boundaries of the table's settled tier, their directories and the
@@ -1660,14 +2086,19 @@ static int keyed_tail(KbDeferred &d, hipStream_t s, bool *more) {
     // keeps running on a second stream while this one is built (the build itself reads only
     // the tier's keys, which no step writes) has to be over first
     XF_HIP(hipDeviceSynchronize());
-    Scratch sc2;
-    uint32_t *idx = nullptr;
-    XF_TRY(sc2.get(&idx, (size_t)misses));
-    XF_TRY(table_resolve_any(d.t, d.a.missK, (size_t)misses, idx, s, true));
-    const uint64_t M = table_dev(d.t).max_rows + 1;
-    XF_TRY(cells_build(&c->next, idx, nullptr, nullptr, d.R, (uint32_t)misses, (uint32_t)M,
-                       kCellsTableRows, d.ksc, s, d.a.missR, c->W,
-                       (uint32_t)(d.nbase >> kChunkBits)));
+    bool done = false;
+    XF_TRY(arrival_build(&c->next, d.t, d.a.missK, nullptr, d.a.missR, d.R, (uint32_t)misses, d.ksc,
+                         c->W, (uint32_t)(d.nbase >> kChunkBits), s, &done));
+    if (!done) {  // (beyond the first-touch build's limits: the sort-based build)
+      Scratch sc2;
+      uint32_t *idx = nullptr;
+      XF_TRY(sc2.get(&idx, (size_t)misses));
+      XF_TRY(table_resolve_any(d.t, d.a.missK, (size_t)misses, idx, s, true));
+      const uint64_t M = table_dev(d.t).max_rows + 1;
+      XF_TRY(cells_build(&c->next, idx, nullptr, nullptr, d.R, (uint32_t)misses, (uint32_t)M,
+                         kCellsTableRows, d.ksc, s, d.a.missR, c->W,
+                         (uint32_t)(d.nbase >> kChunkBits)));
+    }
     XF_REQUIRE(c->next->nwin == c->nwin && c->next->G == c->G, "cells_build_keyed: segments");
     // (the general build synchronises: every kernel that reads the scratch has finished)
   }
@@ -1702,15 +2133,15 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   const bool common = T.nbase > 0 && T.nbase < 0xFFFF0000ull && NNZ > 0 && NNZ < (1u << 30) &&
                       sum != nullptr && cA64 * nwin < (1ull << 22) &&
                       ((uint64_t)NNZ + kTile / 2 - 1) / (kTile / 2) <= (uint64_t)kMaxSub * 256 &&
-                      exp_knob() != 77;
+                      key_build_mode() != 1;
   bool fits = common && cA64 < 0xFFFFu &&
               scatter_lds_bytes((uint32_t)nS64, kTile / 2) <= kDynMax &&
               hist_lds_bytes((uint32_t)cA64, (uint32_t)nS64, false) <= kDynMax;
   // the two-level build (this file's header): groups of 1 << gshift super-chunks, as few of
-  // them as the full-tile scatter holds.  exp_knob 78 forces it on a table that does not need
-  // it (tests: two super-chunks per group).
+  // them as the full-tile scatter holds.  key_build = 2 (xf_tune) takes it on a table that does
+  // not need it (tests: two super-chunks per group).
   uint32_t gshift = 0;
-  if (common && (!fits || exp_knob() == 78) && nS64 >= 2 && nS64 < 0xFFFFu)
+  if (common && (!fits || key_build_mode() == 2) && nS64 >= 2 && nS64 < 0xFFFFu)
     for (uint32_t g = 1; g <= kGrpShiftMax && !gshift; ++g) {
       const uint32_t nG = (uint32_t)((nS64 + (1u << g) - 1) >> g);
       if (scatter_lds_bytes(nG, kTile) <= kDynMax && hist_groups_lds_bytes(nG) <= kDynMax &&
@@ -1722,7 +2153,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   if (!fits) {
     // a table or a minibatch beyond the limits in this file's header: said once, loudly — the
     // general build is 3x slower and its user should know which path the numbers come from
-    if (T.nbase > 0 && NNZ > 0 && exp_knob() != 77) {
+    if (T.nbase > 0 && NNZ > 0 && key_build_mode() != 1) {
       static bool told = false;
       if (!told) {
         told = true;
@@ -1807,6 +2238,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
     uint32_t *gcount = a.tile_r0 + a.ntile + 1, *gstart = gcount + nG,
              *gitems = gstart + nG + 1, *gnitems = gitems + max_gitems;
+#ifdef XF_EXPERIMENTS  // (tools/kb_knobs.py, tools/kb_timeline.py)
     a.flags = exp_knob() >= 100 && exp_knob() < 200 ? (uint32_t)(exp_knob() - 100) : 0u;
     if (exp_knob() == 200 && !big) {
       const size_t need = ((size_t)2 * a.nW + max_items) * kDbgSlots;
@@ -1823,6 +2255,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
       g_dbg_shape[1] = a.nW;
       g_dbg_shape[2] = max_items;
     }
+#endif
     XF_TRY(sc.get(&a.rec, NNZ));
     XF_TRY(sc.get(&a.missK, NNZ));
     XF_TRY(sc.get(&a.missR, NNZ));

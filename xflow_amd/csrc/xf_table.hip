@@ -777,6 +777,271 @@ k_build_cdir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
   }
 }
 
+// ---- defrag without a library sort (round 6) ---------------------------------------------
+// The arrival index is ORDER-PRESERVING: a key sits at or after its home = floor((key - lo) *
+// cap / span), inside the same CLUSTER (a maximal run of occupied positions) as its home.  So
+// every key of a cluster is smaller than every key of the next one, and the index read front to
+// back is sorted up to the order inside the clusters (a handful of keys each at load 0.6).
+//   k_df_count  per block of kDfBlock positions: the keys of the clusters that START in it (a
+//               cluster that began in the block before is that block's, to its end)
+//   k_df_scan   where every block's keys go
+//   k_df_sort   a block's keys compacted into LDS, sorted there (bitonic, padded to a power of
+//               two) and written out with their rows
+//   k_df_merge  the sorted new keys merged with the settled tier's (merge path: one diagonal
+//               search per workgroup, the rest in LDS)
+// instead of a 64-bit radix sort of every key the table holds (8 passes over 12 bytes per key).
+// The one cluster that may wrap around the end of the index holds keys of both ends: an entry
+// whose home lies AFTER its position has wrapped (it belongs to the end), the others to block 0.
+// A block that would own more than kDfMax keys (keys that are not hashes: one home for all)
+// sets a flag and the radix sort runs instead.
+constexpr uint32_t kDfBlock = 4096;  // index positions per block
+constexpr uint32_t kDfMax = 8192;    // keys a block may own
+constexpr int kDfThreads = 1024;
+
+struct DfBlock {
+  uint32_t lead;  // positions at the block's start that belong to the cluster before it
+  uint32_t ext;   // positions past the block's end that its last cluster runs on for
+};
+
+// lead / ext of block b (every thread of the workgroup gets them); occ[]: LDS scratch of
+// kDfThreads / 64 words
+__device__ __forceinline__ DfBlock df_extent(const xf::TableDev &T, uint32_t b, uint32_t *sh) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t p0 = (uint64_t)b * kDfBlock, p1 = min(p0 + kDfBlock, T.cap);
+  const uint32_t len = (uint32_t)(p1 - p0);
+  if (tid == 0) {
+    sh[0] = len;  // first empty position of the block (relative)
+    sh[1] = 0;
+  }
+  __syncthreads();
+  uint32_t first_empty = len;
+  for (uint32_t i = tid; i < len; i += kDfThreads)
+    if (T.keys[p0 + i] == xf::kEmptyKey) first_empty = min(first_empty, i);
+  if (first_empty < len) atomicMin(&sh[0], first_empty);
+  __syncthreads();
+  first_empty = sh[0];
+  const bool pred_occ = T.keys[p0 ? p0 - 1 : T.cap - 1] != xf::kEmptyKey;
+  DfBlock r;
+  r.lead = pred_occ ? first_empty : 0u;
+  r.ext = 0;
+  // the block's last position is occupied and belongs to a cluster the block owns (or, block 0:
+  // to the wrapped cluster, whose far end then is the last block's): how far does it run on?
+  if (r.lead < len && T.keys[p1 - 1] != xf::kEmptyKey) {
+    if (tid < 64) {  // one wavefront, 64 positions at a time
+      uint32_t ext = 0;
+      for (;;) {  // wave-uniform
+        uint64_t q = p1 + ext + tid;
+        if (q >= T.cap) q -= T.cap;
+        const unsigned long long m = __ballot(T.keys[q] == xf::kEmptyKey);
+        if (m) {
+          ext += (uint32_t)__ffsll((long long)m) - 1;
+          break;
+        }
+        ext += 64;
+        if (ext > 4 * kDfMax) break;  // (too long: the caller's count trips the flag)
+      }
+      if (tid == 0) sh[1] = ext;
+    }
+  }
+  __syncthreads();
+  r.ext = sh[1];
+  return r;
+}
+
+// is the entry at position p (key k) one of the block's?  In the block's own range: everything
+// past `lead` — and, block 0 only, the entries of the leading run that have NOT wrapped; in the
+// extension: everything, except that past the end of the index only the wrapped entries count
+__device__ __forceinline__ bool df_owned(const xf::TableDev &T, uint32_t b, const DfBlock &e,
+                                         uint32_t rel /* position - p0 */, uint64_t key,
+                                         uint64_t *pos_out) {
+  const uint64_t p0 = (uint64_t)b * kDfBlock;
+  uint64_t p = p0 + rel;
+  const bool past_end = p >= T.cap;
+  if (past_end) p -= T.cap;
+  *pos_out = p;
+  if (key == xf::kEmptyKey) return false;
+  if (past_end) return xf::home_of(T, key) > p;                      // wrapped: the end's
+  if (b == 0 && rel < e.lead) return xf::home_of(T, key) <= p;       // not wrapped: block 0's
+  return rel >= e.lead;
+}
+
+__global__ void __launch_bounds__(kDfThreads)
+k_df_count(xf::TableDev T, uint32_t nblk, uint32_t *__restrict__ cnt, unsigned int *__restrict__ flag) {
+  __shared__ uint32_t sh[2];
+  __shared__ uint32_t total;
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint64_t p0 = (uint64_t)b * kDfBlock, p1 = min(p0 + kDfBlock, T.cap);
+  const DfBlock e = df_extent(T, b, sh);
+  if (tid == 0) total = 0;
+  __syncthreads();
+  const uint32_t span = (uint32_t)(p1 - p0) + min(e.ext, 4 * kDfMax);
+  uint32_t mine = 0;
+  for (uint32_t i = tid; i < span; i += kDfThreads) {
+    uint64_t p = p0 + i;
+    if (p >= T.cap) p -= T.cap;
+    uint64_t pp;
+    mine += df_owned(T, b, e, i, T.keys[p], &pp) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((tid & 63u) == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (tid == 0) {
+    cnt[b] = total;
+    if (total > kDfMax || e.ext > 4 * kDfMax) atomicOr(flag, 1u);
+  }
+}
+
+// cnt[0 .. n) -> its exclusive scan in place, the total in cnt[n]
+__global__ void __launch_bounds__(kDfThreads)
+k_df_scan(uint32_t *__restrict__ cnt, uint32_t n) {
+  __shared__ uint32_t wsum[kDfThreads / 64];
+  __shared__ uint32_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += kDfThreads) {
+    const uint32_t i = base + tid;
+    const uint32_t x = i < n ? cnt[i] : 0u;
+    uint32_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = carry_s;
+    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+    if (i < n) cnt[i] = pre + inc - x;
+    __syncthreads();
+    if (tid == kDfThreads - 1) carry_s = pre + inc;
+    __syncthreads();
+  }
+  if (tid == 0) cnt[n] = carry_s;
+}
+
+__global__ void __launch_bounds__(kDfThreads)
+k_df_sort(xf::TableDev T, const uint32_t *__restrict__ base, uint64_t *__restrict__ out_keys,
+          uint32_t *__restrict__ out_rows) {
+  __shared__ uint64_t lk[kDfMax];
+  __shared__ uint32_t lr[kDfMax];
+  __shared__ uint32_t sh[2];
+  __shared__ uint32_t nown;
+  const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t at = base[b], n = base[b + 1] - at;
+  if (n == 0 || n > kDfMax) return;  // (workgroup-uniform; > kDfMax: the flag is set)
+  const uint64_t p0 = (uint64_t)b * kDfBlock, p1 = min(p0 + kDfBlock, T.cap);
+  const DfBlock e = df_extent(T, b, sh);
+  if (tid == 0) nown = 0;
+  __syncthreads();
+  const uint32_t span = (uint32_t)(p1 - p0) + e.ext;
+  for (uint32_t i0 = 0; i0 < span; i0 += kDfThreads) {  // workgroup-uniform
+    const uint32_t i = i0 + tid;
+    uint64_t key = xf::kEmptyKey, p = 0;
+    bool own = false;
+    if (i < span) {
+      uint64_t q = p0 + i;
+      if (q >= T.cap) q -= T.cap;
+      key = T.keys[q];
+      own = df_owned(T, b, e, i, key, &p);
+    }
+    const unsigned long long m = __ballot(own);
+    uint32_t slot = 0;
+    if (m) {
+      const int l = __ffsll((long long)m) - 1;
+      if ((int)lane == l) slot = atomicAdd(&nown, (uint32_t)__popcll(m));
+      slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, l) +
+             (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    if (own && slot < kDfMax) {
+      lk[slot] = key;
+      lr[slot] = T.rows[p];
+    }
+  }
+  __syncthreads();
+  uint32_t n2 = 64;
+  while (n2 < n) n2 <<= 1;
+  for (uint32_t i = n + tid; i < n2; i += kDfThreads) {
+    lk[i] = xf::kEmptyKey;  // (sorts behind every stored key)
+    lr[i] = xf::kNoRow;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= n2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = tid; t < n2 / 2; t += kDfThreads) {
+        const uint32_t i = 2 * t - (t & (j - 1));  // the lower index of the pair (i, i + j)
+        const bool up = (i & k) == 0;
+        const uint64_t a = lk[i], c = lk[i + j];
+        if ((a > c) == up) {
+          lk[i] = c;
+          lk[i + j] = a;
+          const uint32_t ra = lr[i];
+          lr[i] = lr[i + j];
+          lr[i + j] = ra;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < n; i += kDfThreads) {
+    out_keys[at + i] = lk[i];
+    out_rows[at + i] = lr[i];
+  }
+}
+
+// merge A = the settled tier (keys ascending, row = rank) with B = the sorted new keys
+constexpr uint32_t kMgTile = 4096;
+constexpr int kMgThreads = 512;
+__device__ __forceinline__ uint64_t merge_split(const uint64_t *__restrict__ A, uint64_t nA,
+                                                const uint64_t *__restrict__ B, uint64_t nB,
+                                                uint64_t d) {
+  uint64_t lo = d > nB ? d - nB : 0, hi = d < nA ? d : nA;  // elements of A among the first d
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (A[mid] < B[d - 1 - mid]) lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+__global__ void __launch_bounds__(kMgThreads)
+k_df_merge(const uint64_t *__restrict__ A, uint64_t nA, const uint64_t *__restrict__ B,
+           const uint32_t *__restrict__ Brow, uint64_t nB, uint64_t *__restrict__ out_keys,
+           uint32_t *__restrict__ out_rows) {
+  __shared__ uint64_t la[kMgTile], lb[kMgTile];
+  __shared__ uint64_t cut[2];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n = nA + nB, d0 = (uint64_t)blockIdx.x * kMgTile, d1 = min(d0 + kMgTile, n);
+  if (tid < 2) cut[tid] = merge_split(A, nA, B, nB, tid ? d1 : d0);
+  __syncthreads();
+  const uint64_t i0 = cut[0], i1 = cut[1], j0 = d0 - i0, j1 = d1 - i1;
+  const uint32_t na = (uint32_t)(i1 - i0), nb = (uint32_t)(j1 - j0);
+  for (uint32_t k = tid; k < na; k += kMgThreads) la[k] = A[i0 + k];
+  for (uint32_t k = tid; k < nb; k += kMgThreads) lb[k] = B[j0 + k];
+  __syncthreads();
+  auto lower = [](const uint64_t *x, uint32_t m, uint64_t key) -> uint32_t {  // x[i] < key
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (x[mid] < key) lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  for (uint32_t k = tid; k < na; k += kMgThreads) {
+    const uint64_t o = d0 + k + lower(lb, nb, la[k]);
+    out_keys[o] = la[k];
+    out_rows[o] = (uint32_t)(i0 + k);
+  }
+  for (uint32_t k = tid; k < nb; k += kMgThreads) {
+    const uint64_t o = d0 + k + lower(la, na, lb[k]);
+    out_keys[o] = lb[k];
+    out_rows[o] = Brow[j0 + k];
+  }
+}
+
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -1136,24 +1401,60 @@ extern "C" int xf_table_defrag(xf_table *t) {
   XF_HIP(k_sorted.alloc(n + xf::kBaseWin));
   XF_HIP(r_sorted.alloc(n));
   XF_HIP(d_cnt.alloc(1));
-  XF_HIP(hipMemset(d_cnt, 0, 8));
-  if (T.nbase)
-    hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all.p,
-                       r_all.p);
-  hipLaunchKernelGGL(k_list_index, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T,
-                     k_all.p + T.nbase, r_all.p + T.nbase, d_cnt.p, n_idx);
-  XF_HIP(hipGetLastError());
-  unsigned long long listed = 0;
-  XF_HIP(hipMemcpy(&listed, d_cnt, 8, hipMemcpyDeviceToHost));
-  if (listed != n_idx)
-    return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
-                         listed, n_idx);
-  size_t tb = 0;
-  XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n, 0, 64,
-                                   (hipStream_t)0));
-  XF_HIP(tmp.alloc(tb));
-  XF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n,
-                                   0, 64, (hipStream_t)0));
+  // the index's keys in key order without a sort (kernels: "defrag without a library sort"):
+  // into k_all / r_all, then merged with the settled tier's into k_sorted / r_sorted
+  bool sorted_ok = false;
+  const uint64_t nblk64 = (T.cap + kDfBlock - 1) / kDfBlock;
+  if (nblk64 < (1u << 24) && n_idx < 0xFFFFFFFFull && xf::key_build_mode() != 1) {
+    const uint32_t nblk = (uint32_t)nblk64;
+    DevBuf<uint32_t> bcnt;
+    DevBuf<unsigned int> dflag;
+    XF_HIP(bcnt.alloc((size_t)nblk + 1));
+    XF_HIP(dflag.alloc(1));
+    XF_HIP(hipMemset(dflag, 0, 4));
+    hipLaunchKernelGGL(k_df_count, dim3(nblk), dim3(kDfThreads), 0, 0, T, nblk, bcnt.p, dflag.p);
+    hipLaunchKernelGGL(k_df_scan, dim3(1), dim3(kDfThreads), 0, 0, bcnt.p, nblk);
+    XF_HIP(hipGetLastError());
+    unsigned int hflag = 1;
+    uint32_t listed32 = 0;
+    XF_HIP(hipMemcpy(&hflag, dflag, 4, hipMemcpyDeviceToHost));
+    XF_HIP(hipMemcpy(&listed32, bcnt.p + nblk, 4, hipMemcpyDeviceToHost));
+    if (!hflag) {
+      if (listed32 != n_idx)
+        return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %u keys, %zu expected",
+                             listed32, n_idx);
+      uint64_t *bk = T.nbase ? k_all.p : k_sorted.p;  // (no settled tier: nothing to merge with)
+      uint32_t *br = T.nbase ? r_all.p : r_sorted.p;
+      hipLaunchKernelGGL(k_df_sort, dim3(nblk), dim3(kDfThreads), 0, 0, T, bcnt.p, bk, br);
+      if (T.nbase)
+        hipLaunchKernelGGL(k_df_merge, dim3((unsigned)((n + kMgTile - 1) / kMgTile)),
+                           dim3(kMgThreads), 0, 0, T.bkeys, (uint64_t)T.nbase, k_all.p, r_all.p,
+                           (uint64_t)n_idx, k_sorted.p, r_sorted.p);
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipDeviceSynchronize());  // (bcnt / dflag go)
+      sorted_ok = true;
+    }
+  }
+  if (!sorted_ok) {  // keys that are not hashes (one home for thousands of them): a radix sort
+    XF_HIP(hipMemset(d_cnt, 0, 8));
+    if (T.nbase)
+      hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all.p,
+                         r_all.p);
+    hipLaunchKernelGGL(k_list_index, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T,
+                       k_all.p + T.nbase, r_all.p + T.nbase, d_cnt.p, n_idx);
+    XF_HIP(hipGetLastError());
+    unsigned long long listed = 0;
+    XF_HIP(hipMemcpy(&listed, d_cnt, 8, hipMemcpyDeviceToHost));
+    if (listed != n_idx)
+      return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
+                           listed, n_idx);
+    size_t tb = 0;
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n, 0,
+                                     64, (hipStream_t)0));
+    XF_HIP(tmp.alloc(tb));
+    XF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p,
+                                     n, 0, 64, (hipStream_t)0));
+  }
   hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted.p + n,
                      (size_t)xf::kBaseWin, xf::kEmptyKey);
   // state in rank order; the spare key's row, if any, follows the settled tier
@@ -1596,6 +1897,26 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
                      (const uint32_t *)nullptr);
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
+  return XF_OK;
+}
+
+// Room for the keys of d_keys[0 .. n) that may be new (duplicates allowed, any order): the table is
+// grown (xf_table_reserve) when they would push the load past 0.6 — on the strength of a count
+// of the DISTINCT keys when the number of nonzeros alone would say so.  The arrival build calls
+// this before it inserts (xf_keybuild.hip).  Synchronises the stream; may move the table's arrays.
+int table_grow_for(xf_table *t, const uint64_t *d_keys, size_t n, hipStream_t s) {
+  XF_HIP(hipStreamSynchronize(s));
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  const uint64_t cap = t->T.cap;
+  if ((st.count + n) * 10 <= cap * 6) return XF_OK;
+  size_t distinct = n;
+  XF_TRY(count_distinct(d_keys, nullptr, n, s, &distinct));
+  if ((st.count + distinct) * 10 > cap * 6) {
+    uint64_t want = cap * 2;
+    while ((st.count + distinct) * 10 > want * 6) want *= 2;
+    XF_TRY(xf_table_reserve(t, want));
+  }
   return XF_OK;
 }
 
