@@ -790,7 +790,7 @@ def capi_sync():
     torch.cuda.synchronize()
 
 
-def fresh_table_leg(args, nkeys, nbatches=40):
+def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
     """What a run's FIRST epoch costs on the GPU (lr_worker.cc:183-188 starts from an empty
     store, ftrl.h:56 inserts on the first Pull): an EMPTY table, `nbatches` distinct minibatches
     of the bench shape over a key space of `nkeys`, xf_lr_update_dev (key build + step) per
@@ -839,7 +839,7 @@ def fresh_table_leg(args, nkeys, nbatches=40):
             L.xf_batch_free(prev)
         prev = h
         n = len(tr.w)                      # (xf_table_size: waits for the step, as the worker's
-        if n > at_defrag + at_defrag // 100 * 30 + 4096:   # defrag_if_grown does)
+        if n > at_defrag + at_defrag // 100 * percent + 4096:   # defrag_if_grown does)
             L.xf_batch_free(prev)
             prev = None
             td = time.perf_counter()
@@ -886,7 +886,7 @@ def n8_shape_leg(args, n1_ms, nsrc=8):
     from xflow_amd import capi
     kpg = 12_500_000
     keytab = make_key_table(kpg)
-    group = make_group(0, 1, 0, "auto")
+    group = make_group(0, 1, 0, "host")   # (a group of one: the exchanges are device copies)
     out = {"keys_per_gpu": kpg, "transport": "rccl" if group.transport == capi.TRANSPORT_RCCL
            else "host", "n1_ms_per_step": n1_ms}
     saved = {k: os.environ.get(k) for k in ("XF_SHARDED_GENERAL", "XF_OWNER_TIMING_SOURCES")}
@@ -2025,6 +2025,8 @@ def main():
     if sharded:
         import ctypes
         ctypes.CDLL(None).fflush(None)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)   # (C stdio of the libraries: nothing may follow the line)
     print(json.dumps(out), flush=True)
 
 

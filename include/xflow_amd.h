@@ -65,6 +65,10 @@ int xf_reader_open(xf_reader **out, const char *path, size_t cap_bytes);
 int xf_reader_open_cached(xf_reader **out, const char *path, size_t cap_bytes,
                           const char *cache_path, int *from_cache);
 int xf_reader_close(xf_reader *r);
+/* *yes = 1: the text is a memory mapping (a non-empty regular file) — what xf_reader_peek_text /
+ * _copy_text / _skip_text (the GPU tokeniser's feed) work on; 0: an empty file, a pipe: only
+ * xf_reader_next* serve it. */
+int xf_reader_mapped(xf_reader *r, int *yes);
 /* rows_out = 0 at end of file.  Arrays are owned by the reader, valid until next call. */
 int xf_reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out,
                    const uint64_t **rowptr, const uint64_t **keys, const int32_t **fgid,

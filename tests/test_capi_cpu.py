@@ -657,3 +657,31 @@ def test_the_update_entry_points_fail_loudly_without_a_gpu():
     assert L.xf_batch_compile_fm_dev(C.byref(h), None, None, None, None, None, 0, 0, None,
                                      None) != 0
     assert L.xf_sbatch_fm_keyed(None) < 0
+
+
+def test_tune_takes_the_named_switches_and_no_experiment_knob():
+    """xf_tune: the code paths a test may pin have names (xf_common.h); the experiments' numeric
+    knob exists only in a library built with -DXF_EXPERIMENTS, and values out of range are refused."""
+    for name, hi in (("key_build", 2), ("old_weight", 2), ("lr_gradient", 3), ("owner_pass", 4)):
+        for v in range(hi + 1):
+            capi.tune(name, v)
+        with pytest.raises(capi.XFError):
+            capi.tune(name, hi + 1)
+        capi.tune(name, 0)
+    with pytest.raises(capi.XFError):
+        capi.tune("exp_knob", 77)
+    with pytest.raises(capi.XFError):
+        capi.tune("no_such_switch", 1)
+
+
+def test_ftrl_tables_refuse_an_alpha_that_is_not_positive():
+    """the step divides by alpha twice (ftrl.h:63,70) and the table keeps a verdict in the sign of
+    1 / alpha: zero, negative and non-finite alphas are refused when the table is created"""
+    import ctypes as C
+    for bad in (0.0, -0.05, float("inf"), float("nan")):
+        c = capi.TableConfig()
+        capi.lib().xf_table_config_default(C.byref(c))
+        c.alpha = bad
+        h = capi.vp()
+        rc = capi.lib().xf_table_create(C.byref(h), C.byref(c))
+        assert rc != 0 and b"alpha" in capi.lib().xf_last_error()

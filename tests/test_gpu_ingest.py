@@ -199,3 +199,20 @@ def test_worker_with_gpu_ingest_trains_the_same_model(tmp_path, model):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert open(str(tmp_path / "p_host")).read() == open(str(tmp_path / "p_gpu")).read()
+
+
+def test_worker_with_gpu_ingest_and_an_empty_training_file(tmp_path):
+    """ingest = gpu with a training shard the reader cannot map (an empty file): the epoch falls
+    back to the host reader, which yields zero rows — the same run as ingest = host (the init push's
+    key 0 and whatever the predict pass pulls), no error."""
+    rng = np.random.RandomState(5)
+    (tmp_path / "train-00000").write_bytes(b"")
+    (tmp_path / "test-00000").write_bytes(gen_block(rng, 300, max_tok=10, fid_len=(1, 5)))
+    data = {"train": str(tmp_path / "train"), "test": str(tmp_path / "test")}
+    host, htabs = _worker_run(tmp_path, "host", 0, data)
+    gpu, gtabs = _worker_run(tmp_path, "gpu", 0, data)
+    assert host["rows_trained"] == 0 and gpu["rows_trained"] == 0 and gpu["blocks_gpu"] == 0
+    for m in ("logloss_ref", "auc", "keys"):
+        assert host[m] == gpu[m], (m, host[m], gpu[m])
+    for x, y in zip(htabs[0], gtabs[0]):
+        assert np.array_equal(x, y)

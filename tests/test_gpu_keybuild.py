@@ -337,3 +337,37 @@ def test_two_level_build_on_a_table_beyond_the_one_level_limit():
         del b, t
     same(got[0], want)
     same(got[1], want)
+
+
+@pytest.mark.parametrize("cap", [256, 1024, 5000])
+def test_defrag_without_a_sort_a_cluster_that_wraps_around_the_end_of_the_index(cap):
+    """xf_table_defrag reads the order-preserving arrival index front to back (k_df_count / _sort /
+    _merge): keys at the very top of the key space pile up at the index's last position and run on
+    into its first ones, where the smallest keys live — one cluster with keys of both ends.  Twice
+    (the second defrag merges with a settled tier), against the radix-sort defrag (key_build = 1)
+    and the oracle's store."""
+    rng = np.random.RandomState(cap)
+    top = (np.uint64(2**64 - 2) - np.arange(40, dtype=np.uint64))
+    low = np.arange(1, 41, dtype=np.uint64)
+    mid = capi.hash_decimal_range(0, cap // 4)
+    waves = [np.unique(np.concatenate([top[:20], low[:20], mid[: len(mid) // 2]])),
+             np.unique(np.concatenate([top, low, mid, capi.hash_decimal_range(10**6, cap // 16)]))]
+    grads = [rng.randn(len(k)).astype(np.float32) for k in waves]
+    exports = []
+    for mode in (0, 1):
+        capi.tune("key_build", mode)
+        try:
+            t = capi.Table(capi.OPT_FTRL, 1, capacity=cap)
+            s = O.Store(O.OPT_FTRL, 1)
+            for keys, g in zip(waves, grads):
+                t.push(keys, g)
+                s.push(keys, g)
+                t.defrag()
+                for a, e in zip(t.export(), s.export()):
+                    same(a, e)
+                same(t.pull(keys), s.pull(keys))
+            exports.append(t.export())
+        finally:
+            capi.tune("key_build", 0)
+    for a, b in zip(*exports):
+        same(a, b)

@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libxflow_amd.so")
 CLI = os.path.join(LIBDIR, "xflow_lr")
 
-LIB_SOURCES = ["xf_table.hip", "xf_model.hip", "xf_calib.hip", "xf_batch_dev.hip", "xf_cells.hip", "xf_keybuild.hip", "xf_io.cc", "xf_batch.cc", "xf_metrics.cc",
+LIB_SOURCES = ["xf_table.hip", "xf_model.hip", "xf_calib.hip", "xf_batch_dev.hip", "xf_cells_build.hip", "xf_cells_fwd.hip", "xf_cells_grad.hip", "xf_cells_grad_dense.hip", "xf_keybuild.hip", "xf_io.cc", "xf_batch.cc", "xf_metrics.cc",
                "xf_worker.cc", "xf_group.cc", "xf_modelfile.cc", "xf_sharded.hip", "xf_ingest.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-unused-value",

@@ -67,6 +67,7 @@ SIGNATURES = {
     "xf_reader_open_cached": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_char_p,
                                         C.POINTER(C.c_int)]),
     "xf_reader_close": (C.c_int, [vp]),
+    "xf_reader_mapped": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "xf_block_create": (C.c_int, [C.POINTER(vp)]),
     "xf_block_destroy": (C.c_int, [vp]),
     "xf_reader_next_into": (C.c_int, [vp, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),

@@ -242,7 +242,7 @@ extern "C" int xf_tune(const char *name, double value) {
     xf::set_path_switch(xf::kPathKeyBuild, (int)value);
   else if (!strcmp(name, "old_weight") && value >= 0 && value <= 2)
     xf::set_path_switch(xf::kPathOldWeight, (int)value);
-  else if (!strcmp(name, "lr_gradient") && value >= 0 && value <= 3)
+  else if (!strcmp(name, "lr_gradient") && value >= 0 && value <= 6)
     xf::set_path_switch(xf::kPathLrGradient, (int)value);
   else if (!strcmp(name, "owner_pass") && value >= 0 && value <= 4)
     xf::set_path_switch(xf::kPathOwnerPass, (int)value);

@@ -179,9 +179,14 @@ k_tok_emit(const uint8_t *__restrict__ text, uint32_t n, uint32_t span,
   // [16 bytes: the two bytes before the tile at their end | the tile | the halo]
   __shared__ __attribute__((aligned(16))) uint8_t lt[16 + kTile + kHalo];
   __shared__ uint32_t wsum[kTok / 64];
-  __shared__ uint32_t run_nl, run_sp;
+  __shared__ uint32_t run_nl, run_sp, s_full;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (out->bad) return;  // (more rows or tokens than the output arrays hold)
+  // more rows or tokens than the output arrays hold (k_tok_scan's verdict): nothing to emit.  One
+  // thread reads the word — other workgroups of this launch OR their shape verdicts into it, and
+  // wavefronts that read it at different times must not part ways ahead of the barriers below
+  if (tid == 0) s_full = out->bad;
+  __syncthreads();
+  if (s_full) return;
   const uint32_t b0 = blockIdx.x * span, b1 = min(b0 + span, n);
   if (tid == 0) {
     const uint2 base = wgbase[blockIdx.x];

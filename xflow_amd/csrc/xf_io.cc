@@ -905,6 +905,12 @@ static int reader_next(xf_reader *r, size_t *rows_out, size_t *nnz_out, const ui
 }
 
 // ---- the block as TEXT (xf_ingest.hip tokenises it on the GPU) --------------------------------
+extern "C" int xf_reader_mapped(xf_reader *r, int *yes) {
+  XF_REQUIRE(r && yes, "xf_reader_mapped: null argument");
+  *yes = r->map && !r->cfp && !r->tfp ? 1 : 0;
+  return XF_OK;
+}
+
 // The next block's text by the block rule above, without parsing it: *text points into the
 // mapping, *len bytes (0 at the end of the file).  Mapped files without a block cache only.
 // Nothing moves until xf_reader_skip_text; a xf_reader_next* call instead parses this very block

@@ -1249,6 +1249,10 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
              (unsigned long long)cfg->capacity);
   XF_REQUIRE(cfg->nshards >= 1 && cfg->shard < cfg->nshards, "xf_table_create: shard %u/%u",
              cfg->shard, cfg->nshards);
+  // (the step divides by alpha twice, ftrl.h:63,70 — and TableDev::inv_alpha carries a verdict in
+  // its sign: a negative or zero alpha is refused rather than silently re-signed)
+  XF_REQUIRE(cfg->opt_kind != XF_OPT_FTRL || (cfg->alpha > 0.0f && std::isfinite(cfg->alpha)),
+             "xf_table_create: FTRL needs a finite alpha > 0 (got %g)", (double)cfg->alpha);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return xf::set_error(XF_ENOGPU, "xf_table_create: no HIP device (the table lives in HBM)");
@@ -1288,6 +1292,8 @@ extern "C" int xf_table_destroy(xf_table *t) {
 extern "C" int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2,
                                   float lr) {
   XF_REQUIRE(t, "xf_table_set_hyper: null table");
+  XF_REQUIRE(t->cfg.opt_kind != XF_OPT_FTRL || (alpha > 0.0f && std::isfinite(alpha)),
+             "xf_table_set_hyper: FTRL needs a finite alpha > 0 (got %g)", (double)alpha);
   // the rows in the table hold the w of the OLD hyper-parameters, and the next step of a key uses
   // that w (ftrl.h:63): from here on the kernels read it
   if (t->cfg.opt_kind == XF_OPT_FTRL &&

@@ -127,9 +127,15 @@ int Worker::create_tables() {
 // ingest = gpu: the two staging buffers (pinning 2 x block_size of host memory costs tens of ms)
 // and the tokeniser's first launches: start-up work like the two-row update of create_tables
 int Worker::start_ingest() {
-  if (!ingest_gpu) return XF_OK;
+  if (!gpu_ingest_applies()) return XF_OK;  // (nothing is pinned for a path that will not run)
   for (int i = 0; i < 2; ++i)
-    if (!ingest_[i]) XF_TRY(xf_ingest_create(&ingest_[i], (size_t)block_size << 20));
+    if (!ingest_[i] && xf_ingest_create(&ingest_[i], (size_t)block_size << 20) != XF_OK) {
+      // (a block size the tokeniser does not take, or no memory to pin: the host parser's run)
+      fprintf(stderr, "xflow_amd: ingest=gpu is not available (%s): the host parser reads the text\n",
+              xf_last_error());
+      ingest_gpu = false;
+      return XF_OK;
+    }
   static const char two_rows[] = "0\t1:2:0.5 3:4:1\n1\t5:6:0.25\n";
   void *stream = nullptr;
   XF_TRY(xf_sharded_stream(sharded_, &stream));
@@ -216,11 +222,17 @@ int Worker::batch_training() {
         rows_trained_ += R;
       }
       XF_TRY(xf_sharded_check(sharded_));
-    } else if (ingest_gpu && core_num == 1 && !block_cache) {
-      // the text tokenised and hashed on the GPU (xf_ingest.hip), compiled from device arrays
-      XF_TRY(text_epoch(epoch, keep));
-      cached = keep != 0;
     } else {
+      // ingest = gpu: the text tokenised and hashed on the GPU (xf_ingest.hip), compiled from
+      // device arrays — unless this rank's shard file cannot be mapped (empty, not a regular
+      // file): the host reader below yields zero rows for such a file and the rank still joins
+      // every collective with empty minibatches
+      bool took = false;
+      if (gpu_ingest_applies()) XF_TRY(text_epoch(epoch, keep, &took));
+      if (took) {
+        cached = keep != 0;
+        goto epoch_done;
+      }
       xf_reader *rd = nullptr;
       const bool trace = getenv("XF_TRACE_WORKER") != nullptr;  // per-block timeline on stderr
       const double te0 = now_s();
@@ -363,6 +375,7 @@ int Worker::batch_training() {
       if (rc != XF_OK) return rc;
       cached = keep != 0;
     }
+  epoch_done:
     // table maintenance at the epoch boundary: when this epoch inserted a noticeable share of
     // the keys, renumber the state rows in key order for the epochs that replay them.  The
     // flush is collective (every rank, every epoch); the defrag itself is local to the shard.
@@ -384,7 +397,12 @@ int Worker::batch_training() {
 // tokeniser buffers go round between the two threads.  A block the tokeniser hands back (not of
 // the common shape, xf_ingest.hip) is parsed from the staged text by the host parser: the same
 // arrays, the reference's quirks in one place.  Block boundaries are the reader's (a1).
-int Worker::text_epoch(int epoch, int keep) {
+// the conditions of the GPU tokeniser's epoch that do not depend on the file
+bool Worker::gpu_ingest_applies() const { return ingest_gpu && core_num == 1 && !block_cache; }
+
+// *took = false: this rank's shard file is not a mapped regular file — nothing was done
+int Worker::text_epoch(int epoch, int keep, bool *took) {
+  *took = false;
   const bool trace = getenv("XF_TRACE_WORKER") != nullptr;
   const double te0 = now_s();
   xf_reader *rd = nullptr;
@@ -395,6 +413,12 @@ int Worker::text_epoch(int epoch, int keep) {
       if (r) xf_reader_close(r);
     }
   } rguard{rd};
+  {
+    int mapped = 0;
+    XF_TRY(xf_reader_mapped(rd, &mapped));
+    if (!mapped) return XF_OK;  // (xf_reader_peek_text / copy_text work on a mapping)
+  }
+  *took = true;
   for (int i = 0; i < 2; ++i)
     if (!ingest_[i]) XF_TRY(xf_ingest_create(&ingest_[i], (size_t)block_size << 20));
   if (!blocks_[0]) XF_TRY(xf_block_create(&blocks_[0]));

@@ -83,7 +83,8 @@ class Worker {
   xf_block *blocks_[2] = {nullptr, nullptr};
   xf_ingest *ingest_[2] = {nullptr, nullptr};  // ingest = gpu: two staging / tokeniser buffers
   int start_ingest();                          // the buffers + first launches, before the clock
-  int text_epoch(int epoch, int keep);         // one epoch from the text, tokenised on the GPU
+  bool gpu_ingest_applies() const;
+  int text_epoch(int epoch, int keep, bool *took);  // one epoch from the text, tokenised on the GPU
   std::vector<std::thread> closers_;  // readers being closed (munmap of the text) off the clock
   long rows_trained_ = 0;
   double train_seconds_ = 0.0;
