@@ -14,6 +14,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from xflow_amd import capi  # noqa: E402
+
+
+def exp_knob(v):
+    """the experiments' numeric knob: only a library built with XF_EXTRA_FLAGS=-DXF_EXPERIMENTS
+    has it (xf_common.h); 0 = the product's choice needs none"""
+    try:
+        capi.tune("exp_knob", v)
+    except capi.XFError:
+        if v:
+            raise SystemExit("this experiment needs a library built with "
+                             "XF_EXTRA_FLAGS=-DXF_EXPERIMENTS python -m xflow_amd.build --force")
+
 from xflow_amd.single import SingleGpuTrainer  # noqa: E402
 
 
@@ -38,7 +50,7 @@ def main():
         tr.predict(c)
     print(json.dumps(comp[0].cells_info()))
     for knob in [int(x) for x in a.knobs.split(",")]:
-        capi.tune("exp_knob", knob)
+        exp_knob(knob)
         for i in range(4):
             tr.step(comp[i % len(comp)])
         tr.check()
@@ -49,7 +61,7 @@ def main():
         tr.profile(False)
         print("knob %3d  forward %.1f us  gradient %.1f us" % (
             knob, ms["forward"] / n * 1e3, ms["gradient"] / n * 1e3), flush=True)
-    capi.tune("exp_knob", 0)
+    exp_knob(0)
 
 
 if __name__ == "__main__":

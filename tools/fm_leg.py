@@ -20,9 +20,11 @@ def main():
     capi.require_gpu()
     keytab = bench.make_key_table(args.keys_per_gpu)
     batches = bench.make_batches(args, 0, args.keys_per_gpu, keytab)
-    # FM_KNOBS=0,301,...: the leg once per exp_knob value (experiments)
-    for knob in [int(x) for x in os.environ.get("FM_KNOBS", str(args.exp_knob)).split(",")]:
-        capi.tune("exp_knob", knob)
+    # FM_KNOBS=0,301,...: the leg once per exp_knob value (experiments: a library built with
+    # XF_EXTRA_FLAGS=-DXF_EXPERIMENTS; 0 = the product's kernels, any library)
+    for knob in [int(x) for x in os.environ.get("FM_KNOBS", "0").split(",")]:
+        if knob:
+            capi.tune("exp_knob", knob)
         out = bench.fm_leg(args, batches)
         out["exp_knob"] = knob
         print(json.dumps(out), flush=True)

@@ -12,6 +12,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from xflow_amd import capi  # noqa: E402
+
+
+def exp_knob(v):
+    """the experiments' numeric knob: only a library built with XF_EXTRA_FLAGS=-DXF_EXPERIMENTS
+    has it (xf_common.h); 0 = the product's choice needs none"""
+    try:
+        capi.tune("exp_knob", v)
+    except capi.XFError:
+        if v:
+            raise SystemExit("this experiment needs a library built with "
+                             "XF_EXTRA_FLAGS=-DXF_EXPERIMENTS python -m xflow_amd.build --force")
+
 from xflow_amd.single import SingleGpuTrainer  # noqa: E402
 
 
@@ -35,7 +47,7 @@ def main():
         tr.predict(c)
     info = comp[0].cells_info()
     print(info)
-    capi.tune("exp_knob", a.knob)
+    exp_knob(a.knob)
     for i in range(6):
         tr.step(comp[i % len(comp)])
     tr.step(comp[0])

@@ -16,6 +16,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from xflow_amd import capi  # noqa: E402
+
+
+def exp_knob(v):
+    """the experiments' numeric knob: only a library built with XF_EXTRA_FLAGS=-DXF_EXPERIMENTS
+    has it (xf_common.h); 0 = the product's choice needs none"""
+    try:
+        capi.tune("exp_knob", v)
+    except capi.XFError:
+        if v:
+            raise SystemExit("this experiment needs a library built with "
+                             "XF_EXTRA_FLAGS=-DXF_EXPERIMENTS python -m xflow_amd.build --force")
+
 from xflow_amd.single import SingleGpuTrainer  # noqa: E402
 
 
@@ -60,7 +72,7 @@ def main():
         return h
 
     for knob in [int(x) for x in a.knobs.split(",")]:
-        capi.tune("exp_knob", knob)
+        exp_knob(knob)
         for i in range(3):
             L.xf_batch_free(one(i))
         torch.cuda.synchronize()
@@ -77,7 +89,7 @@ def main():
         print(json.dumps({"knob": knob, "median_us": round(ts[len(ts) // 2] * 1e6, 1),
                           "min_us": round(ts[0] * 1e6, 1), "segments": info[5],
                           "nitems": info[4]}), flush=True)
-    capi.tune("exp_knob", 0)
+    exp_knob(0)
     tr.check()
     if a.pmc_calibrate:
         for kind in range(10):

@@ -14,6 +14,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from xflow_amd import capi  # noqa: E402
+
+
+def exp_knob(v):
+    """the experiments' numeric knob: only a library built with XF_EXTRA_FLAGS=-DXF_EXPERIMENTS
+    has it (xf_common.h); 0 = the product's choice needs none"""
+    try:
+        capi.tune("exp_knob", v)
+    except capi.XFError:
+        if v:
+            raise SystemExit("this experiment needs a library built with "
+                             "XF_EXTRA_FLAGS=-DXF_EXPERIMENTS python -m xflow_amd.build --force")
+
 from xflow_amd.single import SingleGpuTrainer  # noqa: E402
 
 
@@ -49,9 +61,9 @@ def main():
 
     for _ in range(3):
         one()
-    capi.tune("exp_knob", 200)
+    exp_knob(200)
     one()
-    capi.tune("exp_knob", 0)
+    exp_knob(0)
     cap = 1 << 22
     buf = (C.c_ulonglong * cap)()
     shape = (C.c_uint32 * 3)()

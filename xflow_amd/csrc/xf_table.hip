@@ -785,17 +785,17 @@ k_build_cdir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
 //   k_df_count  per block of kDfBlock positions: the keys of the clusters that START in it (a
 //               cluster that began in the block before is that block's, to its end)
 //   k_df_scan   where every block's keys go
-//   k_df_sort   a block's keys compacted into LDS, sorted there (bitonic, padded to a power of
-//               two) and written out with their rows
+//   k_df_list   a block's keys written out in position order with their rows and the cluster
+//               starts; k_df_fix: every cluster sorted in place by one thread
 //   k_df_merge  the sorted new keys merged with the settled tier's (merge path: one diagonal
 //               search per workgroup, the rest in LDS)
 // instead of a 64-bit radix sort of every key the table holds (8 passes over 12 bytes per key).
 // The one cluster that may wrap around the end of the index holds keys of both ends: an entry
 // whose home lies AFTER its position has wrapped (it belongs to the end), the others to block 0.
-// A block that would own more than kDfMax keys (keys that are not hashes: one home for all)
-// sets a flag and the radix sort runs instead.
+// A cluster of more than kDfCluster keys (keys that are not hashes: one home for all) sets a
+// flag and the radix sort runs instead.
 constexpr uint32_t kDfBlock = 4096;  // index positions per block
-constexpr uint32_t kDfMax = 8192;    // keys a block may own
+constexpr uint32_t kDfMax = 8192;    // (4 x this: how far a block follows its last cluster)
 constexpr int kDfThreads = 1024;
 
 struct DfBlock {
@@ -888,7 +888,7 @@ k_df_count(xf::TableDev T, uint32_t nblk, uint32_t *__restrict__ cnt, unsigned i
   __syncthreads();
   if (tid == 0) {
     cnt[b] = total;
-    if (total > kDfMax || e.ext > 4 * kDfMax) atomicOr(flag, 1u);
+    if (e.ext > 4 * kDfMax) atomicOr(flag, 1u);  // (a cluster of tens of thousands of keys)
   }
 }
 
@@ -921,72 +921,78 @@ k_df_scan(uint32_t *__restrict__ cnt, uint32_t n) {
   if (tid == 0) cnt[n] = carry_s;
 }
 
+// a block's keys in POSITION order (ordered compaction: ballots + a scan over the wavefronts),
+// with their rows, and for every key whether it begins a cluster — the block's first key does
 __global__ void __launch_bounds__(kDfThreads)
-k_df_sort(xf::TableDev T, const uint32_t *__restrict__ base, uint64_t *__restrict__ out_keys,
-          uint32_t *__restrict__ out_rows) {
-  __shared__ uint64_t lk[kDfMax];
-  __shared__ uint32_t lr[kDfMax];
+k_df_list(xf::TableDev T, const uint32_t *__restrict__ base, uint64_t *__restrict__ out_keys,
+          uint32_t *__restrict__ out_rows, uint8_t *__restrict__ start) {
   __shared__ uint32_t sh[2];
-  __shared__ uint32_t nown;
-  const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  __shared__ uint32_t wsum[kDfThreads / 64];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t at = base[b], n = base[b + 1] - at;
-  if (n == 0 || n > kDfMax) return;  // (workgroup-uniform; > kDfMax: the flag is set)
+  if (n == 0) return;  // (workgroup-uniform)
   const uint64_t p0 = (uint64_t)b * kDfBlock, p1 = min(p0 + kDfBlock, T.cap);
   const DfBlock e = df_extent(T, b, sh);
-  if (tid == 0) nown = 0;
-  __syncthreads();
   const uint32_t span = (uint32_t)(p1 - p0) + e.ext;
+  uint32_t run = 0;  // keys written so far (the same number in every thread)
   for (uint32_t i0 = 0; i0 < span; i0 += kDfThreads) {  // workgroup-uniform
     const uint32_t i = i0 + tid;
     uint64_t key = xf::kEmptyKey, p = 0;
-    bool own = false;
+    bool own = false, pred_empty = false;
     if (i < span) {
       uint64_t q = p0 + i;
       if (q >= T.cap) q -= T.cap;
       key = T.keys[q];
       own = df_owned(T, b, e, i, key, &p);
+      if (own) pred_empty = T.keys[q ? q - 1 : T.cap - 1] == xf::kEmptyKey;
     }
     const unsigned long long m = __ballot(own);
-    uint32_t slot = 0;
-    if (m) {
-      const int l = __ffsll((long long)m) - 1;
-      if ((int)lane == l) slot = atomicAdd(&nown, (uint32_t)__popcll(m));
-      slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, l) +
-             (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kDfThreads / 64; ++w) {
+      if (w < wave) before += wsum[w];
+      total += wsum[w];
     }
-    if (own && slot < kDfMax) {
-      lk[slot] = key;
-      lr[slot] = T.rows[p];
+    if (own) {
+      const uint32_t slot = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      out_keys[at + slot] = key;
+      out_rows[at + slot] = T.rows[p];
+      start[at + slot] = (slot == 0 || pred_empty) ? 1 : 0;
     }
+    run += total;
+    __syncthreads();  // (wsum is rewritten by the next pass)
   }
-  __syncthreads();
-  uint32_t n2 = 64;
-  while (n2 < n) n2 <<= 1;
-  for (uint32_t i = n + tid; i < n2; i += kDfThreads) {
-    lk[i] = xf::kEmptyKey;  // (sorts behind every stored key)
-    lr[i] = xf::kNoRow;
+}
+
+// every cluster sorted by the thread of its first key (an insertion sort in memory: a cluster is
+// a handful of keys at load 0.6, and already in order where no key was displaced); a cluster of
+// more than kDfCluster keys sets the flag (keys that are not hashes) and the radix sort runs
+constexpr uint32_t kDfCluster = 1024;
+__global__ void __launch_bounds__(256)
+k_df_fix(uint64_t *__restrict__ keys, uint32_t *__restrict__ rows,
+         const uint8_t *__restrict__ start, size_t n, unsigned int *__restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !start[i]) return;
+  size_t j = i + 1;
+  while (j < n && !start[j] && j - i <= kDfCluster) ++j;
+  if (j - i > kDfCluster) {
+    atomicOr(flag, 1u);
+    return;
   }
-  __syncthreads();
-  for (uint32_t k = 2; k <= n2; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = tid; t < n2 / 2; t += kDfThreads) {
-        const uint32_t i = 2 * t - (t & (j - 1));  // the lower index of the pair (i, i + j)
-        const bool up = (i & k) == 0;
-        const uint64_t a = lk[i], c = lk[i + j];
-        if ((a > c) == up) {
-          lk[i] = c;
-          lk[i + j] = a;
-          const uint32_t ra = lr[i];
-          lr[i] = lr[i + j];
-          lr[i + j] = ra;
-        }
-      }
-      __syncthreads();
+  for (size_t a = i + 1; a < j; ++a) {
+    const uint64_t k = keys[a];
+    const uint32_t r = rows[a];
+    size_t c = a;
+    while (c > i && keys[c - 1] > k) {
+      keys[c] = keys[c - 1];
+      rows[c] = rows[c - 1];
+      --c;
     }
-  }
-  for (uint32_t i = tid; i < n; i += kDfThreads) {
-    out_keys[at + i] = lk[i];
-    out_rows[at + i] = lr[i];
+    if (c != a) {
+      keys[c] = k;
+      rows[c] = r;
+    }
   }
 }
 
@@ -1086,6 +1092,10 @@ struct xf_table {
   // a row's w may differ from ftrl_w_of(n, z): rows were imported with a w that is not (checked
   // on the GPU, row by row), or the hyper-parameters changed with rows in the table.  Sticky.
   bool w_tainted = false;
+  // xf_table_defrag's second state buffer (as large as the first; the two swap roles)
+  float *w_alt = nullptr;
+  float2 *nz_alt = nullptr;
+  size_t alt_elems = 0;
 };
 
 // Is (float)((double)x * (1.0 / (double)d)) the float x / d for EVERY finite x?  All 2^32 bit
@@ -1282,7 +1292,7 @@ extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
   void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
                 (void *)t->T.bdir, (void *)t->T.cdir, t->s_keys, t->s_rows, t->s_vals, t->miss,
-                t->miss_n, t->aux, t->rec};
+                t->miss_n, t->aux, t->rec, t->w_alt, t->nz_alt};
   for (void *p : ps)
     if (p) hipFree(p);
   delete t;
@@ -1371,6 +1381,11 @@ extern "C" int xf_table_reserve(xf_table *t, uint64_t new_capacity) {
   XF_HIP(hipFree(t->T.keys));
   XF_HIP(hipFree(t->T.rows));
   XF_TRY(alloc_state(N, rows_for(new_capacity), t->cfg.opt_kind == XF_OPT_FTRL, st.count));
+  if (t->w_alt) (void)hipFree(t->w_alt);  // (the second state buffer is of the old size)
+  if (t->nz_alt) (void)hipFree(t->nz_alt);
+  t->w_alt = nullptr;
+  t->nz_alt = nullptr;
+  t->alt_elems = 0;
   t->T = N;
   t->cfg.capacity = new_capacity;
   return XF_OK;
@@ -1396,58 +1411,68 @@ extern "C" int xf_table_defrag(xf_table *t) {
   const size_t n_idx = n - (size_t)T.nbase;
   if (n_idx == 0) return XF_OK;                // nothing arrived since the last defrag
   const size_t elems = ((size_t)T.max_rows + 1) * (size_t)T.dim;
-  DevBuf<uint64_t> k_all, k_sorted;
-  DevBuf<uint32_t> r_all, r_sorted, dir, cdir;
-  DevBuf<unsigned long long> d_cnt;
-  DevBuf<float> w2;
-  DevBuf<float2> nz2;
-  DevBuf<char> tmp;
-  XF_HIP(k_all.alloc(n));
-  XF_HIP(r_all.alloc(n));
+  // Temporaries from the builders' arena (no hipMalloc / hipFree per call: a free waits for the
+  // device and a GB-sized one takes milliseconds); what outlives the call — the new tier's keys
+  // and directories — is allocated, and the state moves into the table's SECOND state buffer
+  // (kept between calls: the two swap roles).  Rows at or beyond the table's key count are zero
+  // in both: a buffer only ever held rows below the count of its time, and the count only grows.
+  xf::Scratch sc;
+  uint64_t *k_all = nullptr;
+  uint32_t *r_all = nullptr, *r_sorted = nullptr, *bcnt = nullptr;
+  uint8_t *cstart = nullptr;
+  unsigned int *dflag = nullptr;
+  DevBuf<uint64_t> k_sorted;
+  DevBuf<uint32_t> dir, cdir;
+  XF_TRY(sc.get(&k_all, n));
+  XF_TRY(sc.get(&r_all, n));
+  XF_TRY(sc.get(&r_sorted, n));
   XF_HIP(k_sorted.alloc(n + xf::kBaseWin));
-  XF_HIP(r_sorted.alloc(n));
-  XF_HIP(d_cnt.alloc(1));
   // the index's keys in key order without a sort (kernels: "defrag without a library sort"):
   // into k_all / r_all, then merged with the settled tier's into k_sorted / r_sorted
   bool sorted_ok = false;
   const uint64_t nblk64 = (T.cap + kDfBlock - 1) / kDfBlock;
   if (nblk64 < (1u << 24) && n_idx < 0xFFFFFFFFull && xf::key_build_mode() != 1) {
     const uint32_t nblk = (uint32_t)nblk64;
-    DevBuf<uint32_t> bcnt;
-    DevBuf<unsigned int> dflag;
-    XF_HIP(bcnt.alloc((size_t)nblk + 1));
-    XF_HIP(dflag.alloc(1));
-    XF_HIP(hipMemset(dflag, 0, 4));
-    hipLaunchKernelGGL(k_df_count, dim3(nblk), dim3(kDfThreads), 0, 0, T, nblk, bcnt.p, dflag.p);
-    hipLaunchKernelGGL(k_df_scan, dim3(1), dim3(kDfThreads), 0, 0, bcnt.p, nblk);
+    XF_TRY(sc.get(&bcnt, (size_t)nblk + 1));
+    XF_TRY(sc.get(&cstart, n_idx));
+    XF_TRY(sc.get(&dflag, 1));
+    XF_HIP(hipMemsetAsync(dflag, 0, 4, 0));
+    hipLaunchKernelGGL(k_df_count, dim3(nblk), dim3(kDfThreads), 0, 0, T, nblk, bcnt, dflag);
+    hipLaunchKernelGGL(k_df_scan, dim3(1), dim3(kDfThreads), 0, 0, bcnt, nblk);
     XF_HIP(hipGetLastError());
     unsigned int hflag = 1;
     uint32_t listed32 = 0;
     XF_HIP(hipMemcpy(&hflag, dflag, 4, hipMemcpyDeviceToHost));
-    XF_HIP(hipMemcpy(&listed32, bcnt.p + nblk, 4, hipMemcpyDeviceToHost));
+    XF_HIP(hipMemcpy(&listed32, bcnt + nblk, 4, hipMemcpyDeviceToHost));
     if (!hflag) {
       if (listed32 != n_idx)
         return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %u keys, %zu expected",
                              listed32, n_idx);
-      uint64_t *bk = T.nbase ? k_all.p : k_sorted.p;  // (no settled tier: nothing to merge with)
-      uint32_t *br = T.nbase ? r_all.p : r_sorted.p;
-      hipLaunchKernelGGL(k_df_sort, dim3(nblk), dim3(kDfThreads), 0, 0, T, bcnt.p, bk, br);
-      if (T.nbase)
-        hipLaunchKernelGGL(k_df_merge, dim3((unsigned)((n + kMgTile - 1) / kMgTile)),
-                           dim3(kMgThreads), 0, 0, T.bkeys, (uint64_t)T.nbase, k_all.p, r_all.p,
-                           (uint64_t)n_idx, k_sorted.p, r_sorted.p);
+      uint64_t *bk = T.nbase ? k_all : k_sorted.p;  // (no settled tier: nothing to merge with)
+      uint32_t *br = T.nbase ? r_all : r_sorted;
+      hipLaunchKernelGGL(k_df_list, dim3(nblk), dim3(kDfThreads), 0, 0, T, bcnt, bk, br, cstart);
+      hipLaunchKernelGGL(k_df_fix, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, bk, br,
+                         cstart, n_idx, dflag);
       XF_HIP(hipGetLastError());
-      XF_HIP(hipDeviceSynchronize());  // (bcnt / dflag go)
-      sorted_ok = true;
+      XF_HIP(hipMemcpy(&hflag, dflag, 4, hipMemcpyDeviceToHost));
+      if (!hflag) {
+        if (T.nbase)
+          hipLaunchKernelGGL(k_df_merge, dim3((unsigned)((n + kMgTile - 1) / kMgTile)),
+                             dim3(kMgThreads), 0, 0, T.bkeys, (uint64_t)T.nbase, k_all, r_all,
+                             (uint64_t)n_idx, k_sorted.p, r_sorted);
+        XF_HIP(hipGetLastError());
+        sorted_ok = true;
+      }
     }
   }
   if (!sorted_ok) {  // keys that are not hashes (one home for thousands of them): a radix sort
-    XF_HIP(hipMemset(d_cnt, 0, 8));
+    unsigned long long *d_cnt = nullptr;
+    XF_TRY(sc.get(&d_cnt, 1));
+    XF_HIP(hipMemsetAsync(d_cnt, 0, 8, 0));
     if (T.nbase)
-      hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all.p,
-                         r_all.p);
+      hipLaunchKernelGGL(k_list_base, dim3(grid_for(T.nbase)), dim3(kBlock), 0, 0, T, k_all, r_all);
     hipLaunchKernelGGL(k_list_index, dim3(grid_for(T.cap)), dim3(kBlock), 0, 0, T,
-                       k_all.p + T.nbase, r_all.p + T.nbase, d_cnt.p, n_idx);
+                       k_all + T.nbase, r_all + T.nbase, d_cnt, n_idx);
     XF_HIP(hipGetLastError());
     unsigned long long listed = 0;
     XF_HIP(hipMemcpy(&listed, d_cnt, 8, hipMemcpyDeviceToHost));
@@ -1455,26 +1480,37 @@ extern "C" int xf_table_defrag(xf_table *t) {
       return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
                            listed, n_idx);
     size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p, n, 0,
-                                     64, (hipStream_t)0));
-    XF_HIP(tmp.alloc(tb));
-    XF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, k_all.p, k_sorted.p, r_all.p, r_sorted.p,
-                                     n, 0, 64, (hipStream_t)0));
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all, k_sorted.p, r_all, r_sorted, n, 0, 64,
+                                     (hipStream_t)0));
+    char *tmp = nullptr;
+    XF_TRY(sc.get(&tmp, tb));
+    XF_HIP(rocprim::radix_sort_pairs((void *)tmp, tb, k_all, k_sorted.p, r_all, r_sorted, n, 0, 64,
+                                     (hipStream_t)0));
   }
   hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted.p + n,
                      (size_t)xf::kBaseWin, xf::kEmptyKey);
-  // state in rank order; the spare key's row, if any, follows the settled tier
-  XF_HIP(w2.alloc(elems));
-  XF_HIP(hipMemset(w2, 0, elems * sizeof(float)));
-  if (T.nz) {
-    XF_HIP(nz2.alloc(elems));
-    XF_HIP(hipMemset(nz2, 0, elems * sizeof(float2)));
+  // state in rank order, into the second buffer; the spare key's row, if any, follows the tier
+  if (!t->w_alt || t->alt_elems != elems) {
+    if (t->w_alt) XF_HIP(hipFree(t->w_alt));
+    if (t->nz_alt) XF_HIP(hipFree(t->nz_alt));
+    t->w_alt = nullptr;
+    t->nz_alt = nullptr;
+    t->alt_elems = 0;
+    XF_HIP(hipMalloc((void **)&t->w_alt, elems * sizeof(float)));
+    XF_HIP(hipMemset(t->w_alt, 0, elems * sizeof(float)));
+    if (T.nz) {
+      XF_HIP(hipMalloc((void **)&t->nz_alt, elems * sizeof(float2)));
+      XF_HIP(hipMemset(t->nz_alt, 0, elems * sizeof(float2)));
+    }
+    t->alt_elems = elems;
   }
+  float *w2 = t->w_alt;
+  float2 *nz2 = T.nz ? t->nz_alt : nullptr;
   hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * T.dim)), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
-                     r_sorted.p, n, (size_t)0, w2.p, nz2.p);
+                     r_sorted, n, (size_t)0, w2, nz2);
   if (spare)
     hipLaunchKernelGGL(k_move_rows, dim3(1), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
-                       T.rows + T.cap, (size_t)1, n, w2.p, nz2.p);
+                       T.rows + T.cap, (size_t)1, n, w2, nz2);
   // the directory: one key per bucket on average
   xf::TableDev N = T;
   N.nbase = n;
@@ -1501,13 +1537,13 @@ extern "C" int xf_table_defrag(xf_table *t) {
                        (uint32_t)n);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  (void)hipFree(T.w);
-  if (T.nz) (void)hipFree(T.nz);
   if (T.bkeys) (void)hipFree((void *)T.bkeys);
   if (T.bdir) (void)hipFree((void *)T.bdir);
   if (T.cdir) (void)hipFree((void *)T.cdir);
-  N.w = w2.take();
-  N.nz = T.nz ? nz2.take() : nullptr;
+  t->w_alt = T.w;  // (the old state: rows below the old count hold data, all below n)
+  t->nz_alt = T.nz;
+  N.w = w2;
+  N.nz = nz2;
   N.bkeys = k_sorted.take();
   N.bdir = dir.take();
   N.cdir = cdir.take();
