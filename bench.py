@@ -795,7 +795,8 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
     store, ftrl.h:56 inserts on the first Pull): an EMPTY table, `nbatches` distinct minibatches
     of the bench shape over a key space of `nkeys`, xf_lr_update_dev (key build + step) per
     minibatch, the worker's table maintenance between them (Worker::defrag_if_grown(30): settle the
-    table when its keys have grown by 30 % since the last time).  Raw keys resident in HBM (drawn
+    table when its keys have grown by 30 % since the last time, or when the inflow has stopped —
+    under 0.1 % new keys in a minibatch — with more than 0.5 % of the keys unsettled).  Raw keys resident in HBM (drawn
     there: uniform fids through the same std::hash table).  examples/sec over all of them, and
     per minibatch what it cost and how many of its nonzeros were first touches."""
     import ctypes as C
@@ -839,7 +840,10 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
             L.xf_batch_free(prev)
         prev = h
         n = len(tr.w)                      # (xf_table_size: waits for the step, as the worker's
-        if n > at_defrag + at_defrag // 100 * percent + 4096:   # defrag_if_grown does)
+        arrived, fresh = n - at_defrag, n - (keys_after[-1] if keys_after else 0)
+        # defrag_if_grown does): grown by `percent`, or the inflow has stopped with keys unsettled
+        if n > at_defrag + at_defrag // 100 * percent + 4096 or \
+                (arrived * 200 > n and fresh * 1000 < n and arrived > 4096):
             L.xf_batch_free(prev)
             prev = None
             td = time.perf_counter()
@@ -892,14 +896,21 @@ def n8_shape_leg(args, n1_ms, nsrc=8):
     saved = {k: os.environ.get(k) for k in ("XF_SHARDED_GENERAL", "XF_OWNER_TIMING_SOURCES")}
     os.environ["XF_SHARDED_GENERAL"] = "1"
     try:
-        for shape, rows in (("weak_1e7_nnz_per_gpu", 400_000), ("strong_1p25e6_nnz_per_gpu", 50_000)):
+        # (uniform fids: the shape the round-5 figures were taken on; `weak_with_signal_field`:
+        # the bench stream's low-cardinality field too — 32 hot keys per GPU with R / 32
+        # occurrences each, whose chunks are split into slices and, under rank_ordered, take the
+        # general loop)
+        for shape, rows, sig in (("weak_1e7_nnz_per_gpu", 400_000, 0),
+                                 ("weak_with_signal_field", 400_000, args.signal_keys),
+                                 ("strong_1p25e6_nnz_per_gpu", 50_000, 0)):
             a = _ap.Namespace(**vars(args))
             a.rows, a.nnz_per_row, a.keys_per_gpu, a.batches, a.zipf = rows, 25, kpg, 8, 0.0
-            a.model, a.optimizer = "lr", "ftrl"
+            a.model, a.optimizer, a.signal_keys = "lr", "ftrl", sig
             batches = make_batches(a, 0, kpg, keytab)
             U = int(np.mean([len(np.unique(b[1])) for b in batches[:2]]))
             NNZ = rows * 25
-            leg = {"rows": rows, "nnz_per_row": 25, "unique_keys_per_minibatch": U}
+            leg = {"rows": rows, "nnz_per_row": 25, "unique_keys_per_minibatch": U,
+                   "signal_keys": sig}
             for rule, env in (("sum_then_step", None), ("rank_ordered", str(nsrc))):
                 if env:
                     os.environ["XF_OWNER_TIMING_SOURCES"] = env
@@ -948,7 +959,7 @@ def n8_shape_leg(args, n1_ms, nsrc=8):
                      "step_gbs_survey_8d": (12 * NNZ + 8 * rows + 32 * U) / (per[0] * 1e-3) / 1e9}
                 if shape.startswith("weak"):
                     e["projected_speedup_free_exchange"] = 8.0 * n1_ms / per[0]
-                    if rule == "sum_then_step" and args.key_build_steps > 0:
+                    if rule == "sum_then_step" and args.key_build_steps > 0 and sig == 0:
                         try:
                             wk = with_key_build_sharded(args, tr, batches, rows, 1,
                                                         capi_sync, lambda x: x)
@@ -1064,8 +1075,8 @@ def summary_of(out):
         s[tag + "_examples_per_s"] = t.get("value")
         s[tag + "_first_minibatch_ms"] = t.get("ms_first_minibatch")
         s[tag + "_ms_per_minibatch"] = t.get("ms_per_minibatch")
-    for shape in ("weak_1e7_nnz_per_gpu", "strong_1p25e6_nnz_per_gpu"):
-        tag = "n8_" + shape.split("_")[0]
+    for shape in ("weak_1e7_nnz_per_gpu", "weak_with_signal_field", "strong_1p25e6_nnz_per_gpu"):
+        tag = "n8_" + ("weak_signal" if "signal" in shape else shape.split("_")[0])
         for rule in ("sum_then_step", "rank_ordered"):
             s["%s_%s_ms" % (tag, rule)] = get(out, "n8_shape", shape, rule, "ms_per_step")
         s[tag + "_with_key_build_ms"] = get(out, "n8_shape", shape, "sum_then_step",

@@ -99,6 +99,34 @@ def _run(world, transport, model, optimizer, schedule, outdir, save=False, steps
     assert not errs, errs[0]
 
 
+def _fm_replay_rank(port, outdir, q):
+    try:
+        os.environ["XF_SHARDED_GENERAL"] = "1"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(0, 1, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
+        for name, fresh in (("replayed", False), ("fresh", True)):
+            st = capi.Sharded(g, model="fm", optimizer="ftrl", k=4, capacity=1 << 12,
+                              schedule="owner_stale1", seed=7)
+            kept = [st.compile(*_data(0, s)) for s in range(2)]
+            alive = []
+            for s in range(6):      # 0 0 1 1 0 0: every step but the first meets its own Pushes
+                b = st.compile(*_data(0, (s // 2) % 2)) if fresh else kept[(s // 2) % 2]
+                alive.append(b)
+                st.step(b)
+            st.check()
+            out = {}
+            for nm, t in (("w", st.w), ("v", st.v)):
+                k, w, n, z = t.export()
+                out.update({nm + "_k": k, nm + "_w": w, nm + "_n": n, nm + "_z": z})
+            np.savez(os.path.join(outdir, name + ".npz"), **out)
+            del alive, kept
+            st.close()
+        g.close()
+        q.put(None)
+    except Exception:
+        q.put(traceback.format_exc())
+
+
 def _check_against_oracle(world, model, optimizer, schedule, outdir, steps=4):
     with O.sum_mode(1):
         w, v, losses = _simulate(world, model, optimizer, steps, schedule)
@@ -323,10 +351,38 @@ def test_fm_on_the_owner_compute_dataflow_rank_ordered(tmp_path, world, optimize
     _check_against_oracle(world, "fm", optimizer, "sequential", tmp_path)
 
 
-def test_fm_overlapped_owner_schedule_is_refused():
+@pytest.mark.parametrize("world,optimizer", [(2, "ftrl"), (3, "sgd"), (3, "ftrl")])
+def test_fm_on_the_overlapped_owner_schedule(tmp_path, world, optimizer):
+    """XF_SCHEDULE_OWNER_STALE1 for FM (fm_worker.cc:226-242 with every worker's two Pushes one
+    step late): the Pushes of step t on the second HIP stream under the row-sum / (loss, v_sum)
+    exchanges of step t+1, every worker's gradient from the rows ITS Pull returned — the numbers
+    of the stale1 schedule of the weight / gradient exchange and of the oracle run of that rule,
+    both tables and a held-out forward, bit for bit."""
+    _run(world, capi.TRANSPORT_HOST, "fm", optimizer, "owner_stale1", tmp_path)
+    _check_against_oracle(world, "fm", optimizer, "stale1", tmp_path)
+
+
+def test_fm_overlapped_owner_schedule_replays_a_minibatch(tmp_path):
+    """the same compiled minibatch stepped again while its Pushes are outstanding (two workspace
+    sets that swap roles), against one rank per step of fresh compiles"""
+    import multiprocessing as mp2
+    ctx = mp2.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_fm_replay_rank, args=(free_port(), str(tmp_path), q))
+    p.start()
+    err = q.get(timeout=240)
+    p.join(timeout=60)
+    assert not err, err
+    a, b = np.load(str(tmp_path / "replayed.npz")), np.load(str(tmp_path / "fresh.npz"))
+    for f in a.files:
+        same(a[f], b[f])
+
+
+def test_fm_overlapped_owner_schedule_needs_the_rank_ordered_rule():
     g = capi.Group(0, 1, "127.0.0.1", free_port(), capi.TRANSPORT_HOST, device=0)
-    with pytest.raises(capi.XFError, match="owner_stale1 is the LR step"):
-        capi.Sharded(g, model="fm", optimizer="ftrl", k=4, schedule="owner_stale1")
+    with pytest.raises(capi.XFError, match="needs update_rule rank_ordered"):
+        capi.Sharded(g, model="fm", optimizer="ftrl", k=4, schedule="owner_stale1",
+                     update="sum_then_step")
     g.close()
 
 

@@ -197,6 +197,9 @@ struct xf_sbatch {
   // q_rowoff[q] = first of worker q's rows in the back-to-back layout
   std::vector<xf_batch *> bq;
   std::vector<xf_workspace *> wsq;
+  // owner_stale1, FM: the workspaces of the step whose Pushes are still outstanding — its pulled
+  // rows and gradients — while the next step of the SAME minibatch pulls into the other set
+  std::vector<xf_workspace *> wsq2;
   std::vector<uint32_t> q_rowoff;
   // FM (sum_then_step): b = the received nonzeros as one minibatch with a key list, rows
   // numbered worker after worker; (loss, v_sum) pairs of the rows
@@ -1043,7 +1046,15 @@ static int owner_apply_pending(xf_sharded *st) {
   if (!pb) return XF_OK;
   if (st->have_graded) XF_HIP(hipStreamWaitEvent(st->side, st->ev_graded, 0));
   if (st->have_pulled) XF_HIP(hipStreamWaitEvent(st->side, st->ev_pulled, 0));
-  XF_TRY(owner_grad(st, pb, (st->pending_flip ? pb->loss_recv2 : pb->loss_recv).p, st->side));
+  if (st->cfg.model == 1) {
+    // FM (XF_UPDATE_RANK_ORDERED): the workers' two Pushes, worker after worker, of the gradients
+    // the step left in its workspaces (fm_worker.cc:241-242)
+    std::vector<xf_workspace *> &W = st->pending_flip ? pb->wsq2 : pb->wsq;
+    for (size_t q = 0; q < pb->bq.size(); ++q)
+      if (pb->bq[q]) XF_TRY(xf::fm_owner_push_pulled(st->tw, st->tv, pb->bq[q], W[q], st->side));
+  } else {
+    XF_TRY(owner_grad(st, pb, (st->pending_flip ? pb->loss_recv2 : pb->loss_recv).p, st->side));
+  }
   XF_HIP(hipEventRecord(st->ev_applied, st->side));
   st->have_applied = true;
   st->pending = nullptr;
@@ -1115,20 +1126,24 @@ static int step_owner(xf_sharded *st, xf_sbatch *b) {
 // sums to the rows' workers, (loss, v_sum) back, one gradient + optimizer step per key over all
 // the rows of the step
 static int owner_forward_fm(xf_sharded *st, xf_sbatch *b, float *d_loss, float *d_pctr,
-                            float2 *d_lv, hipStream_t s) {
+                            float2 *d_lv, hipStream_t s,
+                            std::vector<xf_workspace *> *wsq_use = nullptr,
+                            hipEvent_t table_read = nullptr) {
   const int W = st->world;
+  std::vector<xf_workspace *> &WS = wsq_use ? *wsq_use : b->wsq;
   XF_TRY(b->rs_send.reserve((size_t)b->o_total * 3));
   XF_TRY(b->rs_recv.reserve((size_t)W * b->R * 3));
   if (!b->bq.empty()) {  // XF_UPDATE_RANK_ORDERED: every worker's Pull and its share of its rows
     if (b->o_total) XF_HIP(hipMemsetAsync(b->rs_send.p, 0, (size_t)b->o_total * 24, s));
     for (size_t q = 0; q < b->bq.size(); ++q)
       if (b->bq[q])
-        XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->bq[q], b->wsq[q],
+        XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->bq[q], WS[q],
                                      b->rs_send.p + (size_t)3 * b->q_rowoff[q], s, true));
   } else if (b->b)
     XF_TRY(xf::fm_owner_partials(st->tw, st->tv, b->b, st->ws, b->rs_send.p, s));
   else if (b->o_total)
     XF_HIP(hipMemsetAsync(b->rs_send.p, 0, (size_t)b->o_total * 24, s));
+  if (table_read) XF_HIP(hipEventRecord(table_read, s));  // (the tables are not read after this)
   XF_MARK(1);
   const std::vector<uint64_t> mine(W, b->R);
   XF_TRY(a2a(st, b->rs_send.p, b->o_rows64, b->rs_recv.p, mine, 24, s));
@@ -1147,7 +1162,32 @@ static int step_owner_fm(xf_sharded *st, xf_sbatch *b) {
   XF_MARK(0);
   XF_TRY(b->oloss.reserve(b->R));
   XF_TRY(b->lv.reserve((size_t)b->R * 2));
-  XF_TRY(owner_forward_fm(st, b, b->oloss.p, nullptr, (float2 *)b->lv.p, s));
+  // owner_stale1 (XF_UPDATE_RANK_ORDERED): the two Pushes of every worker of step t-1 run on the
+  // side stream under this step's exchanges — after this step's Pulls have read the tables
+  // (ev_pulled) and step t-1's gradients exist (ev_graded); this step's Pulls wait for the
+  // Pushes of step t-2 (ev_applied).  Rows exactly one step stale, reader and writer of the
+  // tables never concurrent: the stale1 schedule of the weight / gradient exchange.
+  const bool stale = st->cfg.schedule == XF_SCHEDULE_OWNER_STALE1;
+  const int flip = stale ? b->oflip : 0;
+  std::vector<xf_workspace *> *WS = &b->wsq;
+  if (stale) {
+    XF_REQUIRE(!b->bq.empty() || (!b->b && b->o_total == 0),
+               "xf_sharded_step: owner_stale1 for FM takes minibatches compiled under "
+               "update_rule rank_ordered");
+    b->oflip ^= 1;
+    if (flip) {
+      if (b->wsq2.size() != b->wsq.size()) b->wsq2.assign(b->wsq.size(), nullptr);
+      for (size_t q = 0; q < b->wsq.size(); ++q)
+        if (b->wsq[q] && !b->wsq2[q]) XF_TRY(xf_workspace_create(&b->wsq2[q]));
+      WS = &b->wsq2;
+    }
+    if (st->have_applied) XF_HIP(hipStreamWaitEvent(s, st->ev_applied, 0));
+    XF_TRY(owner_forward_fm(st, b, b->oloss.p, nullptr, (float2 *)b->lv.p, s, WS, st->ev_pulled));
+    st->have_pulled = true;
+    XF_TRY(owner_apply_pending(st));
+  } else {
+    XF_TRY(owner_forward_fm(st, b, b->oloss.p, nullptr, (float2 *)b->lv.p, s));
+  }
   XF_TRY(b->lv_rep.reserve((size_t)W * b->R * 2));
   XF_TRY(b->lv_recv.reserve((size_t)b->o_total * 2));
   XF_TRY(b->loss_recv.reserve(b->o_total));
@@ -1168,9 +1208,20 @@ static int step_owner_fm(xf_sharded *st, xf_sbatch *b) {
     // the Pushes worker after worker: the state a key's second step starts from is the first's
     for (size_t q = 0; q < b->bq.size(); ++q)
       if (b->bq[q])
-        XF_TRY(xf::fm_owner_grad_pulled(st->tv, b->bq[q], b->wsq[q],
+        XF_TRY(xf::fm_owner_grad_pulled(st->tv, b->bq[q], (*WS)[q],
                                         b->loss_recv.p + b->q_rowoff[q],
                                         b->vsum_recv.p + b->q_rowoff[q], s));
+    if (stale) {  // the Pushes wait for the next step's Pulls (or a flush)
+      XF_HIP(hipEventRecord(st->ev_graded, s));
+      st->have_graded = true;
+      st->pending = b;
+      st->pending_flip = flip;
+      XF_MARK(4);
+      XF_MARK(5);
+      XF_MARK(6);
+      if (st->rec) st->sets[st->cur].pending = true;
+      return XF_OK;
+    }
     for (size_t q = 0; q < b->bq.size(); ++q)
       if (b->bq[q]) XF_TRY(xf::fm_owner_push_pulled(st->tw, st->tv, b->bq[q], b->wsq[q], s));
   } else if (b->b)
@@ -1216,8 +1267,12 @@ extern "C" int xf_sharded_create(xf_sharded **out, xf_group *g, const xf_sharded
                  (cfg->update_rule == XF_UPDATE_SUM_THEN_STEP && owner_dataflow(cfg->schedule)),
              "xf_sharded_create: update_rule %d (sum_then_step needs the owner-compute dataflow: "
              "there the workers' sums meet exactly)", cfg->update_rule);
-  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER_STALE1 || cfg->model == 0,
-             "xf_sharded_create: owner_stale1 is the LR step (FM: schedule owner)");
+  // (FM's fused gradient + Push reads the factors where they live, at Push time: only the rule
+  // that forms every worker's gradient from what its Pull returned can run one step late)
+  XF_REQUIRE(cfg->schedule != XF_SCHEDULE_OWNER_STALE1 || cfg->model == 0 ||
+                 cfg->update_rule == XF_UPDATE_RANK_ORDERED,
+             "xf_sharded_create: owner_stale1 for FM needs update_rule rank_ordered (sum_then_step: "
+             "schedule owner)");
   xf_sharded *st = new xf_sharded;
   st->g = g;
   st->cfg = *cfg;
@@ -1306,6 +1361,8 @@ extern "C" int xf_sbatch_free(xf_sbatch *b) {
   for (xf_batch *q : b->bq)
     if (q) xf_batch_free(q);
   for (xf_workspace *q : b->wsq)
+    if (q) xf_workspace_destroy(q);
+  for (xf_workspace *q : b->wsq2)
     if (q) xf_workspace_destroy(q);
   delete b;
   return XF_OK;
@@ -1672,8 +1729,9 @@ extern "C" int xf_sharded_set_schedule(xf_sharded *st, int schedule) {
   XF_REQUIRE(owner_dataflow(st->cfg.schedule) == owner_dataflow(schedule),
              "xf_sharded_set_schedule: minibatches compiled for the owner-compute dataflow "
              "cannot be stepped on the weight / gradient exchange, nor the other way round");
-  XF_REQUIRE(st->cfg.model == 0 || schedule != XF_SCHEDULE_OWNER_STALE1,
-             "xf_sharded_set_schedule: owner_stale1 is the LR step");
+  XF_REQUIRE(st->cfg.model == 0 || schedule != XF_SCHEDULE_OWNER_STALE1 ||
+                 st->cfg.update_rule == XF_UPDATE_RANK_ORDERED,
+             "xf_sharded_set_schedule: owner_stale1 for FM needs update_rule rank_ordered");
   XF_TRY(xf_sharded_flush(st));
   st->cfg.schedule = schedule;
   return XF_OK;

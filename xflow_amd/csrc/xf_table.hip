@@ -794,7 +794,7 @@ k_build_cdir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
 // whose home lies AFTER its position has wrapped (it belongs to the end), the others to block 0.
 // A cluster of more than kDfCluster keys (keys that are not hashes: one home for all) sets a
 // flag and the radix sort runs instead.
-constexpr uint32_t kDfBlock = 4096;  // index positions per block
+constexpr uint32_t kDfBlock = 16384;  // index positions per block (a workgroup: 16 per thread)
 constexpr uint32_t kDfMax = 8192;    // (4 x this: how far a block follows its last cluster)
 constexpr int kDfThreads = 1024;
 
