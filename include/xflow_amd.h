@@ -211,8 +211,19 @@ int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_pt
  * "min_panel_nnz" (default 4e6: smaller batches keep the plain CSR forward),
  * "parse_threads" (default 64: threads of the block text parser),
  * "batch_pool_blobs" (default 8: device allocations of freed minibatches kept for reuse by
- * the next compile/upload; 0 returns every one to the driver) */
+ * the next compile/upload; 0 returns every one to the driver).
+ * Named switches between code paths that are all product code and normally chosen by the shape
+ * (tests pin one to run each against the oracle; 0 = by shape): "key_build" (1 the sort-based
+ * build, 2 the two-level partition), "old_weight" (1 read, 2 derive from (n, z)), "lr_gradient"
+ * (1 the general kernel, 2 / 3 the dense kernel with byte-masked / whole-line stores),
+ * "owner_pass" (1 the general loop, 2 / 3 the merged phases, 4 a phase per worker) —
+ * xflow_amd/csrc/xf_common.h.  An unknown name, or a value a switch does not take, is XF_EINVAL
+ * (a library built with -DXF_EXPERIMENTS also has the experiments' numeric "exp_knob"). */
 int xf_tune(const char *name, double value);
+/* Size the calling thread's scratch arena of the device-side builders ahead of its first build
+ * (a minibatch of NNZ nonzeros needs about 40 B x NNZ + 64 MiB when it meets new keys): a run's
+ * first minibatches otherwise grow it build by build.  No-op when it is that large already. */
+int xf_scratch_reserve(size_t bytes);
 /* copy to the current device (async on stream); idempotent */
 int xf_batch_upload(xf_batch *b, void *stream);
 
@@ -284,7 +295,9 @@ int xf_table_capacity(xf_table *t, uint64_t *slots);
 /* grow to new_capacity slots (rehash on device); earlier slot arrays become invalid */
 int xf_table_reserve(xf_table *t, uint64_t new_capacity);
 /* renumber the state rows in key order (locality of the Pull gather and the Push pass once
- * the key set has settled); row numbers change — call it between steps */
+ * the key set has settled); row numbers change — call it between steps.  The table keeps a
+ * second state buffer of the same size from its first call on (the two swap roles: no
+ * allocation, no clearing per call). */
 int xf_table_defrag(xf_table *t);
 int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1, float l2, float lr);
 
@@ -480,7 +493,8 @@ int xf_group_selftest(xf_group *g, size_t bytes);
 const char *xf_source_hash(void);
 
 /* Diagnostic (tools/kb_timeline.py): wall_clock64 stamps of the phases of the last keyed build
- * made with xf_tune("exp_knob", 200): [histogram | scatter | resolve] workgroups x slots;
+ * made with xf_tune("exp_knob", 200) (a library built with -DXF_EXPERIMENTS; empty otherwise):
+ * [histogram | scatter | resolve] workgroups x slots;
  * returns the slots per workgroup, shape[3] = workgroups per kernel. */
 int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape);
 
@@ -508,7 +522,10 @@ int xf_kb_debug_read(unsigned long long *out, size_t cap, uint32_t *shape);
  * while the row sums and losses of step t+1 travel, and forward(t+2) waits for them — weights
  * exactly one step stale, deterministic (events order the table's reader and writer), inside
  * ps-lite's asynchronous semantics; the results of XF_SCHEDULE_STALE1.  Same compiled
- * minibatches as XF_SCHEDULE_OWNER (xf_sharded_set_schedule switches between the two). */
+ * minibatches as XF_SCHEDULE_OWNER (xf_sharded_set_schedule switches between the two).
+ * FM: under XF_UPDATE_RANK_ORDERED (every worker's gradient from the rows ITS Pull returned,
+ * fm_worker.cc:226-242) the workers' two Pushes are what runs one step late; the fused pass of
+ * XF_UPDATE_SUM_THEN_STEP reads the factors where they live at Push time and is refused here. */
 #define XF_SCHEDULE_OWNER_STALE1 3
 typedef struct {
   int32_t model;     /* 0 LR, 1 FM */

@@ -56,6 +56,12 @@ bash tools/pmc2.sh $OUT sweep_1e8 python $R/bench.py $B --batches 2 --sweep-keys
 bash tools/pmc2.sh $OUT key_build python $R/tools/kb_knobs.py --knobs 0 --iters 8 --step --pmc-calibrate 2>&1 | grep "k_kb\|k_lr\|pmc2"
 XF_OWNER_TIMING_SOURCES=8 bash tools/pmc2.sh $OUT n8_shard_shape_owner_8_sources python $R/bench.py $N8O --signal-keys 0 --no-owner-leg $B --no-table-sweep 2>&1 | grep "k_lr\|k_owner\|k_sum\|pmc2"
 bash tools/pmc2.sh $OUT n8_shard_shape_owner_sum_then_step python $R/bench.py $N8O --signal-keys 0 --no-owner-leg $B --no-table-sweep 2>&1 | grep "k_lr\|k_owner\|k_sum\|pmc2"
+# the vector-memory path of the N = 8 owner shape's kernels (TA busy, L1 -> L2 requests and their
+# latency, address translation): why the forward at 32 windows and the several-workers pass sit
+# where they do
+XF_OWNER_TIMING_SOURCES=8 bash tools/pmc_mem_passes.sh $OUT/_mem_n8 $N8O --signal-keys 0 --no-owner-leg --repeats 0 --batches 4 > $OUT/pmc_mem_n8_owner_8_sources.txt 2>&1
+bash tools/pmc_mem_passes.sh $OUT/_mem_n1 $QUIET --repeats 0 --batches 8 --no-fm-leg --no-zipf-leg --no-table-sweep > $OUT/pmc_mem_lr.txt 2>&1
+rm -rf $OUT/_mem_n8 $OUT/_mem_n1
 rm -f $OUT/*_rd.json $OUT/*_wr.json
 for f in $OUT/pmc_traffic_*.json; do python - "$f" "$HEAD" <<'PY'
 import json, sys

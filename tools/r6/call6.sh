@@ -4,6 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r6
 export TMPDIR=/tmp
+python -m xflow_amd.build > /tmp/build.log 2>&1 || tail -5 /tmp/build.log   # (no-op when the library matches the sources)
 timeout 2000 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_keybuild.py tests/test_gpu_cli.py \
   tests/test_gpu_ingest.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -12 > gpurun_out/r6/call6_tests.log
 cat gpurun_out/r6/call6_tests.log

@@ -10,6 +10,7 @@
 // The result depends only on the input rows, so a compiled batch can be cached across
 // epochs (the reference re-parses and re-sorts every epoch, lr_worker.cc:184).
 #include "xf_batch.h"
+#include "xf_scratch.h"
 #include "xf_tiling.h"
 
 #include <atomic>
@@ -233,6 +234,22 @@ bool device_poisoned() { return g_device_poisoned.load(std::memory_order_relaxed
 void scratch_poison() { g_device_poisoned.store(true); }
 }  // namespace xf
 
+// the calling thread's builder arena (xf_scratch.h) sized ahead of its first build: a run's first
+// minibatches otherwise grow it build by build — a hipFree and a hipMalloc of ~0.5 GB, ~0.8 ms,
+// each time a nested builder asked for more than the last one had (the gaps in the timeline of a
+// table's first minibatches, profiles/r06/)
+extern "C" int xf_scratch_reserve(size_t bytes) {
+  xf::Arena &a = xf::arena();
+  XF_REQUIRE(a.used == 0, "xf_scratch_reserve: a build is in progress on this thread");
+  if (bytes <= a.cap) return XF_OK;
+  if (a.base) XF_HIP(hipFree(a.base));
+  a.base = nullptr;
+  a.cap = 0;
+  XF_HIP(hipMalloc((void **)&a.base, bytes));
+  a.cap = bytes;
+  return XF_OK;
+}
+
 extern "C" int xf_tune(const char *name, double value) {
   XF_REQUIRE(name, "xf_tune: null name");
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
@@ -242,7 +259,7 @@ extern "C" int xf_tune(const char *name, double value) {
     xf::set_path_switch(xf::kPathKeyBuild, (int)value);
   else if (!strcmp(name, "old_weight") && value >= 0 && value <= 2)
     xf::set_path_switch(xf::kPathOldWeight, (int)value);
-  else if (!strcmp(name, "lr_gradient") && value >= 0 && value <= 6)
+  else if (!strcmp(name, "lr_gradient") && value >= 0 && value <= 3)
     xf::set_path_switch(xf::kPathLrGradient, (int)value);
   else if (!strcmp(name, "owner_pass") && value >= 0 && value <= 4)
     xf::set_path_switch(xf::kPathOwnerPass, (int)value);

@@ -143,8 +143,11 @@ uint32_t cells_split_chunks(const xf_cells *c);  // over the chain
 size_t cells_partial_doubles(const xf_cells *c);
 
 // forward: loss[r] = sigmoid(sum_j w[idx_j]) - label[r]   (lr_worker.cc:121-143)
+// resume_from: a later segment of c's chain — d_partial still holds the partial row sums a call
+// over the segments before it left there: only the rest is run (and the rows finalized again)
 int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,
-                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t stream);
+                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t stream,
+                     const xf_cells *resume_from = nullptr);
 
 // owner-compute step (xf_sharded.hip): forward up to the fp64 row sums, and the gradient with
 // the Pushes of several workers applied in rank order (see xf_cells.hip)

@@ -171,11 +171,17 @@ k_lr_finalize_cells(const double *__restrict__ partial, const int32_t *__restric
 namespace xf {
 
 int cells_lr_forward(const xf_cells *c, const float *d_w, const int32_t *d_labels,
-                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t s) {
+                     double *d_partial, float *d_loss, float *d_pctr, hipStream_t s,
+                     const xf_cells *resume_from) {
   XF_REQUIRE(c && d_w && d_partial && (d_loss || d_pctr), "cells_lr_forward: null argument");
   if (c->R == 0) return XF_OK;
   int acc = 0;
-  for (const xf_cells *q = c; q; q = q->next, acc = 1)
+  const xf_cells *first = c;
+  if (resume_from) {  // d_partial holds the sums of the segments before it (an earlier call)
+    first = resume_from;
+    acc = 1;
+  }
+  for (const xf_cells *q = first; q; q = q->next, acc = 1)
     hipLaunchKernelGGL(k_lr_fwd_cells, dim3(q->nwin * q->G), dim3(kFwdBlock), 0, s, q->fwd_entries(),
                        q->cellptr, q->blk_cell, q->nchunk, q->W, q->G,
                        d_w + (size_t)q->chunk0 * kChunk, d_partial, acc);

@@ -1027,8 +1027,6 @@ static int launch_grad(const xf_cells *c, const TableDev &T_, const float *d_los
         const int lg = path_switch(kPathLrGradient);  // (xf_common.h)
         if (lg == 2) var = 0;
         if (lg == 3) var = kDenseFullStore;
-        if (lg >= 4) var = lg == 4 ? kDensePrefetch : lg == 5 ? kDenseWide
-                                                              : kDensePrefetch | kDenseWide;
         dense = lg != 1;
         // (Measured and dropped: fewer workgroups per CU — 4 .. 7 instead of 8, by a pad of dynamic
         // LDS — so that the rounds of workgroups come out even (4883 chunks are 2.38 rounds of

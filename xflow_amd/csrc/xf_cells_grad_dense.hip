@@ -275,12 +275,13 @@ int cells_launch_grad_dense(int opt, int var, const xf_cells *c, const TableDev 
   switch (var) {
     XF_DENSE(0);
     XF_DENSE(128);
+#ifdef XF_EXPERIMENTS  // the measured-and-not-adopted variants (round 6: prefetch, 512
+                       // threads and both on a 1e8-key table, tools/r6/sweep_variants.py) and the
+                       // timing experiments (some with WRONG results): never in a product build
+    XF_DENSE(1);
     XF_DENSE(2);
     XF_DENSE(4);
     XF_DENSE(6);
-#ifdef XF_EXPERIMENTS  // the measured-and-not-adopted variants and the timing
-                       // experiments (some with WRONG results): never in a product build
-    XF_DENSE(1);
     XF_DENSE(128 + 4);
     XF_DENSE(5);
     XF_DENSE(6);

@@ -1351,7 +1351,7 @@ k_kb_resolve(KbArgs a) {
 //   k_kb_hist_groups / _scan / _scatter   (key, row) records grouped by key range
 //   k_ar_insert   one workgroup per range (parts of a heavy one): its records probe the arrival
 //                 index — the range's positions, L2-resident while the workgroup runs — with an
-//                 insert on miss; ONE atomic on the table's row counter per batch of 8192 records,
+//                 insert on miss; ONE atomic on the table's row counter per batch of 4096 records,
 //                 the new keys' rows consecutive; every record's state row is written out and
 //                 counted into its cell (row window, chunk of arrival rows)
 //   k_kb_scan     (cell part) cellptr, the gradient's work items
@@ -1411,7 +1411,8 @@ __device__ __forceinline__ uint32_t ar_cell_slot(uint32_t *__restrict__ counter,
   return slot;
 }
 
-constexpr int kAr = 1024;                      // threads of an insert workgroup
+constexpr int kAr = 512;                       // threads of an insert workgroup (a thread's eight
+                                               // windows in flight: ~150 registers)
 constexpr int kArE = 8;                        // records per thread and batch
 constexpr uint32_t kArBatch = kAr * kArE;      // records whose rows are handed out together
 constexpr int kArWin = 4;                      // index positions read per probe round
@@ -1444,39 +1445,103 @@ k_ar_insert(ArArgs a) {
       key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
       rp[q] = r.rp;
     }
-    // (a) every record finds its key's position in the arrival index, or claims an empty one
+    // (a) every record finds its key's position in the arrival index, or claims an empty one.
+    // The thread's eight first probe windows are requested together, then its eight claims
+    // (independent atomics): one record after the other — a window's trip, its claim's trip,
+    // eight times over — this phase was 0.7 ms per 1e7 records.  A record whose first window
+    // holds neither its key nor an empty position (or whose claim another key won) walks on alone.
     uint32_t mine = 0;
+    uint64_t home[kArE], cur[kArE][kArWin];
+    uint32_t slot[kArE];  // position to claim (kArWin: none), or the window's hit
+    bool more[kArE];      // the walk goes on from home + start[q]
+    uint32_t start[kArE];
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
-      ins[q] = bad[q] = false;
+      ins[q] = bad[q] = more[q] = false;
       pos[q] = (uint32_t)T.cap;
       row[q] = (uint32_t)T.max_rows;  // the write-off row
-      if (!ok[q]) continue;
-      if (key[q] == xf::kEmptyKey) {  // the reserved value lives at the spare position
-        ins[q] = atomicExch(&T.stat->spare_used, 1u) == 0u;
-        if (ins[q]) T.keys[T.cap] = key[q];
-      } else if (!xf::owns(T, key[q])) {
-        atomicOr(&T.stat->err, xf::kErrForeignKey);
-        bad[q] = true;
+      slot[q] = kArWin;
+      start[q] = 0;
+      home[q] = 0;
+      const bool plain = ok[q] && key[q] != xf::kEmptyKey && xf::owns(T, key[q]);
+      if (ok[q] && !plain) {
+        if (key[q] == xf::kEmptyKey) {  // the reserved value lives at the spare position
+          ins[q] = atomicExch(&T.stat->spare_used, 1u) == 0u;
+          if (ins[q]) T.keys[T.cap] = key[q];
+        } else {
+          atomicOr(&T.stat->err, xf::kErrForeignKey);
+          bad[q] = true;
+        }
+      }
+      if (plain) home[q] = xf::home_of(T, key[q]);
+      more[q] = plain;
+#pragma unroll
+      for (int t = 0; t < kArWin; ++t) {
+        uint64_t i = home[q] + t;
+        if (i >= T.cap) i -= T.cap;
+        cur[q][t] = plain ? T.keys[i] : 0ull;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      if (!more[q]) continue;
+#pragma unroll
+      for (int t = kArWin - 1; t >= 0; --t)  // (the first hit or empty position of the window)
+        if (cur[q][t] == key[q] || cur[q][t] == xf::kEmptyKey) slot[q] = (uint32_t)t;
+    }
+    uint64_t won[kArE];
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      won[q] = 0;
+      if (!more[q] || slot[q] == kArWin) continue;
+      uint64_t i = home[q] + slot[q];
+      if (i >= T.cap) i -= T.cap;
+      if (cur[q][slot[q]] == key[q]) {
+        pos[q] = (uint32_t)i;
+        more[q] = false;
       } else {
+        // (the atomic is served at the coherent point: a stale EMPTY read — another workgroup
+        // inserted meanwhile — is corrected by the returned value)
+        won[q] = atomicCAS((unsigned long long *)&T.keys[i], xf::kEmptyKey, key[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      if (!more[q]) continue;
+      if (slot[q] == kArWin) {
+        start[q] = kArWin;  // a window of other keys: walk on behind it
+        continue;
+      }
+      uint64_t i = home[q] + slot[q];
+      if (i >= T.cap) i -= T.cap;
+      if (won[q] == xf::kEmptyKey || won[q] == key[q]) {
+        ins[q] = won[q] == xf::kEmptyKey;
+        pos[q] = (uint32_t)i;
+        more[q] = false;
+      } else {
+        start[q] = slot[q] + 1;  // another key took the position: walk on behind it
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      if (more[q]) {  // (rare at load <= 0.6: the walk of round 5's k_resolve)
         bool done = false;
-        uint64_t p = xf::home_of(T, key[q]);
-        for (uint64_t probes = 0; probes < T.cap && !done; probes += kArWin) {
-          uint64_t idx[kArWin], cur[kArWin];
+        uint64_t p = home[q] + start[q];
+        if (p >= T.cap) p -= T.cap;
+        for (uint64_t probes = start[q]; probes < T.cap && !done; probes += kArWin) {
+          uint64_t idx[kArWin], c4[kArWin];
 #pragma unroll
           for (int t = 0; t < kArWin; ++t) {
             idx[t] = p + t;
             if (idx[t] >= T.cap) idx[t] -= T.cap;
           }
 #pragma unroll
-          for (int t = 0; t < kArWin; ++t) cur[t] = T.keys[idx[t]];
+          for (int t = 0; t < kArWin; ++t) c4[t] = T.keys[idx[t]];
 #pragma unroll
           for (int t = 0; t < kArWin; ++t) {
             if (done) break;
-            uint64_t c = cur[t];
+            uint64_t c = c4[t];
             if (c == xf::kEmptyKey) {
-              // (the atomic is served at the coherent point: a stale EMPTY read — another
-              // workgroup inserted meanwhile — is corrected by the returned value)
               c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key[q]);
               if (c == xf::kEmptyKey) {
                 ins[q] = true;
@@ -1534,10 +1599,14 @@ k_ar_insert(ArArgs a) {
     }
     // (c) the rows of the keys that were there (or were inserted by somebody else just now)
 #pragma unroll
+    for (int q = 0; q < kArE; ++q)  // (all of the thread's rows requested before the first wait)
+      if (ok[q] && !ins[q] && !bad[q])
+        row[q] = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
     for (int q = 0; q < kArE; ++q) {
       if (!ok[q]) continue;
       if (!ins[q] && !bad[q]) {
-        uint32_t r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t r = row[q];
         for (int spin = 0; r == xf::kNoRow && spin < (1 << 22); ++spin) {
           __builtin_amdgcn_s_sleep(1);
           r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1854,10 +1854,12 @@ static int lr_step(xf_table *w, xf_batch *b, xf_workspace *ws, void *stream,
     settle.d = nullptr;
     bool more = false;
     XF_TRY(xf::cells_build_keyed_finish(d, S(stream), &more));
-    if (more) {  // keys the table did not hold: they are in now, as a second segment of cells
+    if (more) {  // keys the table did not hold: they are in now, as a second segment of cells —
+                 // its row sums on top of the first segment's (still in ws->partial)
+      const size_t had = ws->capPartial;
       XF_TRY(ws_reserve_cells(ws, c, cap));
       XF_TRY(xf::cells_lr_forward(c, xf::table_dev(w).w, labels, ws->partial, ws->loss, nullptr,
-                                  S(stream)));
+                                  S(stream), ws->capPartial == had ? c->next : nullptr));
     }
   }
   XF_END(kEvForward);

