@@ -892,7 +892,10 @@ def n8_shape_leg(args, n1_ms, nsrc=8):
     from xflow_amd import capi
     kpg = 12_500_000
     keytab = make_key_table(kpg)
-    group = make_group(0, 1, 0, "host")   # (a group of one: the exchanges are device copies)
+    # (a group of one over RCCL: a rank's own slice of an exchange is a plain device copy — the
+    # host transport would stage it through the sockets; RCCL prints its banner through C stdio,
+    # flushed before the JSON line)
+    group = make_group(0, 1, 0, "auto")
     out = {"keys_per_gpu": kpg, "transport": "rccl" if group.transport == capi.TRANSPORT_RCCL
            else "host", "n1_ms_per_step": n1_ms}
     saved = {k: os.environ.get(k) for k in ("XF_SHARDED_GENERAL", "XF_OWNER_TIMING_SOURCES")}

@@ -34,7 +34,7 @@ stats() {  # stats <name> <command...>: rocprofv3 --kernel-trace --stats, the su
 }
 QUIET="--no-cpu-baseline --no-fresh-table --no-n8-shape --no-end-to-end --sustained-seconds 0"
 N8="--rows 400000 --nnz-per-row 25 --keys-per-gpu 12500000"
-N8O="$N8 --force-sharded --general-path --schedule owner --transport host --no-cpu-baseline"
+N8O="$N8 --force-sharded --general-path --schedule owner --no-cpu-baseline"
 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err; line $OUT/bench_n1.json
 stats step python $R/bench.py $QUIET --key-build-steps 0 --repeats 0 --no-fm-leg --no-zipf-leg --no-table-sweep
 stats key_build python $R/tools/kb_knobs.py --knobs 0 --iters 24 --step

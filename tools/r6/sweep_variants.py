@@ -4,7 +4,8 @@ the named variants of the gradient + Push kernel (xf_tune lr_gradient / old_weig
 DESIGN 3 quotes — lr_gradient 4 / 5 / 6 = the dense kernel with its state rows prefetched, with 512
 threads per chunk, with both — was made at commit 615221c's successor, where those variants were
 product instantiations for the length of the experiment; they live behind -DXF_EXPERIMENTS now:
-exp_knob 302 / 304 / 306.)
+exp_knob 302 / 304 / 306; likewise the touched keys compacted per wavefront with the idle
+slots issuing no loads, exp_knob 301: 310.7 against 309.4 us at 1e8 keys, call 9.)
     python tools/r6/sweep_variants.py [nkeys] [name=value ...]"""
 import argparse
 import json
@@ -23,7 +24,7 @@ from xflow_amd.single import SingleGpuTrainer  # noqa: E402
 
 nkeys = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 variants = [a for a in sys.argv[2:]] or ["lr_gradient=0", "lr_gradient=2", "lr_gradient=3",
-                                         "old_weight=1"]
+                                         "lr_gradient=1"]
 args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=4, zipf=0.0,
                           signal_keys=0, keys_per_gpu=nkeys)
 keytab = bench.make_key_table(nkeys)

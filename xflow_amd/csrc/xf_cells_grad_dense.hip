@@ -186,13 +186,18 @@ k_lr_grad_dense(xf::TableDev T, const uint32_t *__restrict__ entries,
     for (int i = 0; i < kSlots; ++i) {
       const uint32_t p = lane + 64u * i;
       kk[i] = p < cnt ? (uint32_t)wl[p] : 0xFFFFFFFFu;
-      // (an idle slot loads the chunk's first row: a load under a branch would have to be
-      // waited for where the branch ends, one slot after the other)
-      const size_t r = row0 + (kk[i] != 0xFFFFFFFFu ? kk[i] : 0u);
       sw[i] = 0.0f;
-      if (!wnz) sw[i] = T.w[r];
       sn[i] = sz[i] = 0.0f;
-      if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
+      // (a slot NO lane of the wavefront fills — cnt is the wavefront's, the test a scalar one —
+      // issues nothing: a load costs its lanes' TA cycles whatever it hits, and at a tenth of
+      // the rows touched seven of the eight slots are idle.  Inside a slot in use an idle lane
+      // loads the chunk's first row: a load under a divergent branch would have to be waited for
+      // where the branch ends, one slot after the other)
+      if (64u * (uint32_t)i < cnt) {
+        const size_t r = row0 + (kk[i] != 0xFFFFFFFFu ? kk[i] : 0u);
+        if (!wnz) sw[i] = T.w[r];
+        if (OPT == XF_OPT_FTRL) xf::load_nz(T, r, sn[i], sz[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
@@ -284,7 +289,6 @@ int cells_launch_grad_dense(int opt, int var, const xf_cells *c, const TableDev 
     XF_DENSE(6);
     XF_DENSE(128 + 4);
     XF_DENSE(5);
-    XF_DENSE(6);
     XF_DENSE(8);
     XF_DENSE(16);
     XF_DENSE(32);

@@ -52,6 +52,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <memory>
@@ -1364,6 +1365,8 @@ struct ArArgs {
   const uint32_t *items;   // range | part << 16
   const uint32_t *nitems;
   uint32_t n, nwin, nchunk, chunk0;
+  const uint64_t *bnd;     // [nR] first key of every range
+  uint32_t nR;
   uint32_t *rec_row;       // [n] state row of every record
   uint32_t *hist;          // [nwin * nchunk]
   uint32_t *cellcur;       // [nwin * nchunk] next free slot of every cell (after the scan)
@@ -1382,32 +1385,61 @@ k_ar_ranges(uint64_t lo, uint32_t n, uint32_t mult, uint64_t *__restrict__ bnd,
   if (r < n) bnd[r] = lo + ((r == 0 ? 0ull : (((uint64_t)r << 32) + mult - 1) / mult) << 32);
 }
 
-// add 1 to counter[cell] (count = true) or take a slot from it (count = false) for every lane
-// with `on`: the lanes of the wavefront that hold the same cell share one atomic (a range's new
-// keys get consecutive rows: a wavefront's records fall into a few cells); after kArRounds
-// distinct cells the lanes left over go one by one
+// A wavefront's records fall into a few cells (a range's new keys get consecutive rows): the
+// lanes that hold the same cell share one atomic on the cell's counter; after kArRounds distinct
+// cells the lanes left over go one by one.
 constexpr int kArRounds = 6;
-__device__ __forceinline__ uint32_t ar_cell_slot(uint32_t *__restrict__ counter, bool on,
-                                                 uint32_t cell) {
+// ... counting: nobody reads what the atomics return, so they are issued one behind the other
+// (with the returns read — one trip to the L2 per round, eight slots of six rounds per thread —
+// this was most of k_ar_insert's 0.7-0.9 ms per 1e7 records)
+__device__ __forceinline__ void ar_cell_count(uint32_t *__restrict__ counter, bool on,
+                                              uint32_t cell) {
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long todo = __ballot(on);
-  uint32_t slot = 0;
   bool placed = !on;
   for (int round = 0; todo && round < kArRounds; ++round) {  // wave-uniform
     const int l = __ffsll((long long)todo) - 1;
     const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell, l);
     const bool me = !placed && cell == lc;
     const unsigned long long m = __ballot(me);
-    uint32_t base = 0;
-    if ((int)lane == l) base = atomicAdd(&counter[lc], (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, l);
+    if ((int)lane == l) atomicAdd(&counter[lc], (uint32_t)__popcll(m));
+    placed = placed || me;
+    todo &= ~m;
+  }
+  if (!placed) atomicAdd(&counter[cell], 1u);
+}
+// ... taking slots: the rounds' atomics do not depend on one another (only the ballots do, and
+// those are register work), so all of them are in flight before the first return is read
+__device__ __forceinline__ uint32_t ar_cell_slot(uint32_t *__restrict__ counter, bool on,
+                                                 uint32_t cell) {
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long todo = __ballot(on);
+  uint32_t ret[kArRounds], rank = 0;
+  int lead[kArRounds], mine = -1;
+#pragma unroll
+  for (int round = 0; round < kArRounds; ++round) {
+    ret[round] = 0;
+    lead[round] = 0;
+    if (!todo) continue;  // wave-uniform
+    const int l = __ffsll((long long)todo) - 1;
+    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell, l);
+    const bool me = on && mine < 0 && cell == lc;
+    const unsigned long long m = __ballot(me);
+    if ((int)lane == l) ret[round] = atomicAdd(&counter[lc], (uint32_t)__popcll(m));
+    lead[round] = l;
     if (me) {
-      slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      placed = true;
+      mine = round;
+      rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
     todo &= ~m;
   }
-  if (!placed) slot = atomicAdd(&counter[cell], 1u);
+  uint32_t slot = 0;
+  if (on && mine < 0) slot = atomicAdd(&counter[cell], 1u);
+#pragma unroll
+  for (int round = 0; round < kArRounds; ++round) {
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)ret[round], lead[round]);
+    if (mine == round) slot = base + rank;
+  }
   return slot;
 }
 
@@ -1417,6 +1449,19 @@ constexpr int kArE = 8;                        // records per thread and batch
 constexpr uint32_t kArBatch = kAr * kArE;      // records whose rows are handed out together
 constexpr int kArWin = 4;                      // index positions read per probe round
 
+// LOCAL (the first launch): a range whose records are ONE work item has its slice of the index —
+// positions [home(bnd[S]), home(bnd[S + 1])) — to itself: nobody else claims a position there, so
+// its claims and its row publications are WORKGROUP-scope operations (no waiting protocol: a
+// barrier orders the batch's publications and reads).  Where the kernel's 0.95 ms per 1e7 first
+// touches go, measured with its parts switched off (tools/r6/call12.sh): the records in and the
+// rows out 54 us, the probe windows 246 (4e7 divergent 8-byte loads), the 6.3e6 claims ~480
+// (a compare-and-swap per new key, whatever its scope), the cell counts 170.  A record
+// whose probe leaves the slice (a cluster across the slice's end, a home on the boundary) and
+// every record of a range cut into several items are DEFERRED: marked in rec_row and taken by the
+// second launch (LOCAL = false: agent scope, the waiting protocol), after the first has finished.
+constexpr uint32_t kArDeferred = 0xFFFFFFFEu;
+
+template <bool LOCAL>
 __global__ void __launch_bounds__(kAr)
 k_ar_insert(ArArgs a) {
   __shared__ uint32_t s_new, s_cur;
@@ -1428,41 +1473,66 @@ k_ar_insert(ArArgs a) {
   const uint32_t S = item & 0xFFFFu, part = item >> 16;
   const uint32_t sb = a.sstart[S], se = a.sstart[S + 1];
   const uint32_t rb = sb + part * kPart, re = min(se, rb + kPart);
+  uint64_t h0 = 0, h1 = T.cap;  // the positions this workgroup may claim
+  if (LOCAL) {
+    if (se - sb > kPart) {  // a range of several items: all of it to the second launch
+      for (uint32_t i = rb + tid; i < re; i += kAr) a.rec_row[i] = kArDeferred;
+      return;
+    }
+    h0 = xf::home_of(T, a.bnd[S]);
+    h1 = S + 1 < a.nR ? xf::home_of(T, a.bnd[S + 1]) : T.cap;
+  }
+  constexpr int kScope = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+  auto claim = [&](uint64_t i, uint64_t key) -> uint64_t {  // the key the position holds now
+    unsigned long long expect = xf::kEmptyKey;
+    __hip_atomic_compare_exchange_strong((unsigned long long *)&T.keys[i], &expect,
+                                         (unsigned long long)key, __ATOMIC_RELAXED,
+                                         __ATOMIC_RELAXED, kScope);
+    return expect;  // (kEmptyKey: the claim succeeded)
+  };
   for (uint32_t b0 = rb; b0 < re; b0 += kArBatch) {  // workgroup-uniform
+    uint64_t key[kArE];
+    uint32_t rp[kArE], pos[kArE], row[kArE];
+    bool ok[kArE], ins[kArE], bad[kArE];
+    int any = 0;
+#pragma unroll
+    for (int q = 0; q < kArE; ++q) {
+      const uint32_t i = b0 + q * kAr + tid;
+      ok[q] = i < re && (LOCAL || a.rec_row[i] == kArDeferred);
+      any |= ok[q] ? 1 : 0;
+    }
     if (tid == 0) {
       s_new = 0;
       s_cur = 0;
     }
-    __syncthreads();
-    uint64_t key[kArE];
-    uint32_t rp[kArE], pos[kArE], row[kArE];
-    bool ok[kArE], ins[kArE], bad[kArE];
+    if (!__syncthreads_or(any)) continue;  // (the second launch: nothing deferred in this batch)
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
       const uint32_t i = b0 + q * kAr + tid;
-      ok[q] = i < re;
       const Rec3 r = ok[q] ? a.rec[i] : Rec3{0u, 0u, 0u};
       key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
       rp[q] = r.rp;
     }
     // (a) every record finds its key's position in the arrival index, or claims an empty one.
     // The thread's eight first probe windows are requested together, then its eight claims
-    // (independent atomics): one record after the other — a window's trip, its claim's trip,
-    // eight times over — this phase was 0.7 ms per 1e7 records.  A record whose first window
-    // holds neither its key nor an empty position (or whose claim another key won) walks on alone.
+    // (independent atomics).  A record whose first window holds neither its key nor an empty
+    // position (or whose claim another key won) walks on alone.
     uint32_t mine = 0;
     uint64_t home[kArE], cur[kArE][kArWin];
     uint32_t slot[kArE];  // position to claim (kArWin: none), or the window's hit
+    uint32_t lim[kArE];   // LOCAL: positions from the home on that lie inside the slice
     bool more[kArE];      // the walk goes on from home + start[q]
+    bool defer[kArE];
     uint32_t start[kArE];
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
-      ins[q] = bad[q] = more[q] = false;
+      ins[q] = bad[q] = more[q] = defer[q] = false;
       pos[q] = (uint32_t)T.cap;
       row[q] = (uint32_t)T.max_rows;  // the write-off row
       slot[q] = kArWin;
       start[q] = 0;
       home[q] = 0;
+      lim[q] = 0xFFFFFFFFu;
       const bool plain = ok[q] && key[q] != xf::kEmptyKey && xf::owns(T, key[q]);
       if (ok[q] && !plain) {
         if (key[q] == xf::kEmptyKey) {  // the reserved value lives at the spare position
@@ -1475,19 +1545,32 @@ k_ar_insert(ArArgs a) {
       }
       if (plain) home[q] = xf::home_of(T, key[q]);
       more[q] = plain;
+      if (LOCAL && plain)
+        lim[q] = home[q] >= h0 && home[q] < h1 ? (uint32_t)std::min<uint64_t>(h1 - home[q], 0xFFFFFFFFull)
+                                               : 0u;
 #pragma unroll
       for (int t = 0; t < kArWin; ++t) {
         uint64_t i = home[q] + t;
         if (i >= T.cap) i -= T.cap;
-        cur[q][t] = plain ? T.keys[i] : 0ull;
+        cur[q][t] = plain && (uint32_t)t < lim[q] ? T.keys[i] : 0ull;
       }
     }
+    bool hit[kArE];  // the window holds the key at slot[q] (no run-time index into cur[][]: an
+                     // array indexed so lives in scratch memory)
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
+      hit[q] = false;
       if (!more[q]) continue;
 #pragma unroll
       for (int t = kArWin - 1; t >= 0; --t)  // (the first hit or empty position of the window)
-        if (cur[q][t] == key[q] || cur[q][t] == xf::kEmptyKey) slot[q] = (uint32_t)t;
+        if ((uint32_t)t < lim[q] && (cur[q][t] == key[q] || cur[q][t] == xf::kEmptyKey)) {
+          slot[q] = (uint32_t)t;
+          hit[q] = cur[q][t] == key[q];
+        }
+      if (slot[q] == kArWin && lim[q] <= (uint32_t)kArWin) {  // the slice ends inside the window
+        defer[q] = true;
+        more[q] = false;
+      }
     }
     uint64_t won[kArE];
 #pragma unroll
@@ -1496,13 +1579,12 @@ k_ar_insert(ArArgs a) {
       if (!more[q] || slot[q] == kArWin) continue;
       uint64_t i = home[q] + slot[q];
       if (i >= T.cap) i -= T.cap;
-      if (cur[q][slot[q]] == key[q]) {
+      if (hit[q]) {
         pos[q] = (uint32_t)i;
         more[q] = false;
       } else {
-        // (the atomic is served at the coherent point: a stale EMPTY read — another workgroup
-        // inserted meanwhile — is corrected by the returned value)
-        won[q] = atomicCAS((unsigned long long *)&T.keys[i], xf::kEmptyKey, key[q]);
+        // (a stale EMPTY read — somebody inserted meanwhile — is corrected by the returned value)
+        won[q] = claim(i, key[q]);
       }
     }
 #pragma unroll
@@ -1524,42 +1606,38 @@ k_ar_insert(ArArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
-      if (more[q]) {  // (rare at load <= 0.6: the walk of round 5's k_resolve)
+      if (more[q]) {  // (rare at load <= 0.6: one position after the other)
         bool done = false;
         uint64_t p = home[q] + start[q];
         if (p >= T.cap) p -= T.cap;
-        for (uint64_t probes = start[q]; probes < T.cap && !done; probes += kArWin) {
-          uint64_t idx[kArWin], c4[kArWin];
-#pragma unroll
-          for (int t = 0; t < kArWin; ++t) {
-            idx[t] = p + t;
-            if (idx[t] >= T.cap) idx[t] -= T.cap;
+        for (uint64_t probes = start[q]; probes < T.cap && !done; ++probes) {
+          if (LOCAL && probes >= lim[q]) {  // the walk leaves the slice: the second launch's
+            defer[q] = true;
+            done = true;
+            break;
           }
-#pragma unroll
-          for (int t = 0; t < kArWin; ++t) c4[t] = T.keys[idx[t]];
-#pragma unroll
-          for (int t = 0; t < kArWin; ++t) {
-            if (done) break;
-            uint64_t c = c4[t];
+          uint64_t c = T.keys[p];
+          if (c == xf::kEmptyKey) {
+            c = claim(p, key[q]);
             if (c == xf::kEmptyKey) {
-              c = atomicCAS((unsigned long long *)&T.keys[idx[t]], xf::kEmptyKey, key[q]);
-              if (c == xf::kEmptyKey) {
-                ins[q] = true;
-                c = key[q];
-              }
-            }
-            if (c == key[q]) {
-              pos[q] = (uint32_t)idx[t];
-              done = true;
+              ins[q] = true;
+              c = key[q];
             }
           }
-          p = idx[kArWin - 1] + 1;
-          if (p >= T.cap) p -= T.cap;
+          if (c == key[q]) {
+            pos[q] = (uint32_t)p;
+            done = true;
+          }
+          if (++p >= T.cap) p -= T.cap;
         }
         if (!done) {
           atomicOr(&T.stat->err, xf::kErrFull);
           bad[q] = true;
         }
+      }
+      if (defer[q]) {
+        a.rec_row[b0 + q * kAr + tid] = kArDeferred;
+        ok[q] = false;
       }
       mine += ins[q] ? 1u : 0u;
     }
@@ -1569,9 +1647,9 @@ k_ar_insert(ArArgs a) {
     __syncthreads();
     if (tid == 0) s_base = s_new ? atomicAdd(&T.stat->count, (unsigned long long)s_new) : 0ull;
     __syncthreads();
-    // (b) consecutive rows for the batch's new keys; published at once — a record of another
-    // workgroup that met the key in this launch waits for the row below, and nobody waits before
-    // publishing
+    // (b) consecutive rows for the batch's new keys, published at once.  Second launch: a record
+    // of another workgroup that met the key in this launch waits for the row below, and nobody
+    // waits before publishing.  First launch: only this workgroup reads them, after the barrier.
     const unsigned long long base = s_base;
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
@@ -1594,22 +1672,23 @@ k_ar_insert(ArArgs a) {
         } else {
           atomicOr(&T.stat->err, xf::kErrFull);
         }
-        __hip_atomic_store(&T.rows[pos[q]], row[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&T.rows[pos[q]], row[q], __ATOMIC_RELAXED, kScope);
       }
     }
+    if (LOCAL) __syncthreads();  // (the rows of this batch's new keys: stored, visible to the CU)
     // (c) the rows of the keys that were there (or were inserted by somebody else just now)
 #pragma unroll
     for (int q = 0; q < kArE; ++q)  // (all of the thread's rows requested before the first wait)
       if (ok[q] && !ins[q] && !bad[q])
-        row[q] = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        row[q] = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, kScope);
 #pragma unroll
     for (int q = 0; q < kArE; ++q) {
       if (!ok[q]) continue;
       if (!ins[q] && !bad[q]) {
         uint32_t r = row[q];
-        for (int spin = 0; r == xf::kNoRow && spin < (1 << 22); ++spin) {
+        for (int spin = 0; !LOCAL && r == xf::kNoRow && spin < (1 << 22); ++spin) {
           __builtin_amdgcn_s_sleep(1);
-          r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          r = __hip_atomic_load(&T.rows[pos[q]], __ATOMIC_RELAXED, kScope);
         }
         if (r == xf::kNoRow) {
           atomicOr(&T.stat->err, xf::kErrDupKey);
@@ -1623,7 +1702,7 @@ k_ar_insert(ArArgs a) {
     for (int q = 0; q < kArE; ++q) {
       const uint32_t cell =
           (rp[q] >> kRinBits) * a.nchunk + ((row[q] >> kChunkBits) - a.chunk0);
-      (void)ar_cell_slot(a.hist, ok[q], cell);
+      ar_cell_count(a.hist, ok[q], cell);
     }
     __syncthreads();  // (s_new / s_cur are reset by the next batch)
   }
@@ -1942,14 +2021,14 @@ static int general_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
 // (insert on miss, ftrl.h:56), and *out are their cells over the chunks from chunk0 on.  The
 // table may grow first.  Synchronises the stream.  *done = false: beyond this build's limits,
 // nothing was done (the caller takes the sort-based build).
-constexpr uint32_t kArMaxRanges = 1500;
+constexpr uint32_t kArMaxRanges = 4000;  // (beyond ~1900 the scatter takes half tiles: its LDS)
 static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
                          const uint32_t *d_rowptr, const uint32_t *d_rowid, uint32_t R, uint32_t n,
                          bool ksc, uint32_t w_fixed, uint32_t chunk0, hipStream_t s, bool *done) {
   *done = false;
   KbSummary *sum = summary_buf();
   if (n == 0 || n >= (1u << 30) || !sum ||
-      ((uint64_t)n + kTile - 1) / kTile > (uint64_t)kMaxSub * 256 || key_build_mode() == 1)
+      ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256 || key_build_mode() == 1)
     return XF_OK;
   {
     const TableDev &T0 = table_dev(t);
@@ -1983,7 +2062,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   a.nwin = c->nwin;
   a.cA = c->nchunk;
   a.nS = nR;
-  a.tile = kTile;
+  a.tile = scatter_lds_bytes(nR, kTile) <= kDynMax ? kTile : kTile / 2;
   a.ntile = (n + a.tile - 1) / a.tile;
   a.lo = T.lo;
   const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
@@ -2030,9 +2109,16 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
                      a);
-  if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, scatter_lds_bytes(nR, kTile), a);
-  else
-    XF_KB_LAUNCH_N((k_kb_scatter<false, kTile>), a.nW, kKb, scatter_lds_bytes(nR, kTile), a);
+  const size_t sl = scatter_lds_bytes(nR, a.tile);
+  if (a.tile == kTile) {
+    if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
+    else
+      XF_KB_LAUNCH_N((k_kb_scatter<false, kTile>), a.nW, kKb, sl, a);
+  } else {
+    if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile / 2>), a.nW, kKb, sl, a);
+    else
+      XF_KB_LAUNCH_N((k_kb_scatter<false, kTile / 2>), a.nW, kKb, sl, a);
+  }
   ArArgs r{};
   r.T = T;
   r.rec = a.rec;
@@ -2049,7 +2135,10 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   r.cellptr = c->cellptr;
   r.entries = c->entries;
   r.blk_cell = c->blk_cell;
-  hipLaunchKernelGGL(k_ar_insert, dim3(max_items), dim3(kAr), 0, s, r);
+  r.bnd = bnd;
+  r.nR = nR;
+  hipLaunchKernelGGL(k_ar_insert<true>, dim3(max_items), dim3(kAr), 0, s, r);
+  hipLaunchKernelGGL(k_ar_insert<false>, dim3(max_items), dim3(kAr), 0, s, r);
   a.scan_part = 2;
   if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
