@@ -68,3 +68,5 @@ import json, sys
 d = json.load(open(sys.argv[1])); d["git_head"] = sys.argv[2]; json.dump(d, open(sys.argv[1], "w"), indent=1)
 PY
 done
+# end to end through xflow_lr on a 3 GB file (text, GPU tokeniser, block cache)
+python tools/e2e_text.py 1200000 $OUT/e2e.json > $OUT/e2e.log 2>&1; tail -1 $OUT/e2e.log | cut -c1-600

@@ -178,10 +178,10 @@ k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
 // counting sort in LDS over the chunk's kChunk positions — a wavefront per cell (config 2: ~680
 // entries per cell, an owner's 32-window minibatch: ~50), the whole workgroup on a cell of more
 // than kSortWave entries, and a cell beyond kSortMax (a power-law head key's: one position holds
-// most of it) is copied as it is.  Not stable — the order of a position's entries is whatever
+// most of it) is copied, by as many workgroups as it has kBlk blocks.  Not stable — the order of a position's entries is whatever
 // the LDS cursors make of it: the forward's fp64 row sums do not depend on it (exact).
 // Replaces rocprim::segmented_radix_sort_keys (2 x 112 us per 1e7 entries, round 2).
-constexpr uint32_t kSortWave = 4096, kSortMax = 1u << 17;
+constexpr uint32_t kSortWave = 4096, kSortMax = 1u << 15;
 constexpr int kSortCells = 4;  // cells (wavefronts) per workgroup
 __device__ __forceinline__ uint32_t sortp(uint32_t i) { return i + (i >> 5); }  // (bank padding)
 __device__ __forceinline__ void lds_wave_sync() {
@@ -252,10 +252,33 @@ __device__ __forceinline__ void cell_sort_pos(uint32_t *bins, const uint32_t *__
 
 __global__ void __launch_bounds__(kBlock)
 k_cells_sort_pos(const uint32_t *__restrict__ entries, uint32_t *__restrict__ out,
-                 const uint32_t *__restrict__ cellptr, uint32_t ncell) {
+                 const uint32_t *__restrict__ cellptr, const uint32_t *__restrict__ blk_cell,
+                 uint32_t ncell, uint32_t nsort) {
   static_assert(kBlock == 64 * kSortCells, "a wavefront per cell");
   __shared__ uint32_t bins[kSortCells][kChunk + kChunk / 32 + 8];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  if (blockIdx.x >= nsort) {
+    // The cells beyond kSortMax, kBlk entries per workgroup (a cell of a million entries — Zipf
+    // 1.1 has four — was one workgroup's copy loop: 740 us).  Such a cell cannot lie inside one
+    // kBlk block: the block meets it as the cell of its first entry or as the cell of the next
+    // block's first entry.  Copied with its row order taken apart the way the sort does it:
+    // output j = input (j % 64) * m + j / 64 over the first 64 * m entries (neighbouring lanes
+    // of the forward: inputs m apart).
+    const uint32_t blk = blockIdx.x - nsort;
+    const uint32_t j0 = blk * kBlk, c1 = blk_cell[blk], c2 = blk_cell[blk + 1];
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t c = k ? c2 : c1;
+      if (k && c2 == c1) break;
+      const uint32_t b = cellptr[c], e = cellptr[c + 1], n = e - b;
+      if (n <= kSortMax) continue;
+      const uint32_t m = n / 64, jb = max(b, j0), je = min(e, j0 + kBlk);
+      for (uint32_t j = jb + tid; j < je; j += kBlock) {
+        const uint32_t rel = j - b;
+        out[j] = entries[b + (rel < 64 * m ? (rel & 63u) * m + (rel >> 6) : rel)];
+      }
+    }
+    return;
+  }
   const uint32_t c0 = blockIdx.x * kSortCells;
   {
     const uint32_t c = c0 + wave;
@@ -267,15 +290,7 @@ k_cells_sort_pos(const uint32_t *__restrict__ entries, uint32_t *__restrict__ ou
   __syncthreads();
   for (uint32_t k = 0; k < (uint32_t)kSortCells && c0 + k < ncell; ++k) {  // workgroup-uniform
     const uint32_t b = cellptr[c0 + k], n = cellptr[c0 + k + 1] - b;
-    if (n <= kSortWave) continue;
-    if (n > kSortMax) {
-      // copied, its row order taken apart the same way: output j = input (j % 64) * m + j / 64
-      // over the first 64 * m entries (neighbouring lanes of the forward: inputs m apart)
-      const uint32_t m = n / 64;
-      for (uint32_t j = tid; j < n; j += kBlock)
-        out[b + j] = entries[b + (j < 64 * m ? (j & 63u) * m + (j >> 6) : j)];
-    } else
-      cell_sort_pos<kBlock>(bins[0], entries + b, out + b, n, tid);
+    if (n > kSortWave && n <= kSortMax) cell_sort_pos<kBlock>(bins[0], entries + b, out + b, n, tid);
   }
 }
 
@@ -374,8 +389,9 @@ int cells_alloc(xf_cells **out, uint32_t R, uint32_t NNZ, uint32_t M, int mode,
 // forward reads the row-sorted cells.  In stream order, nothing is waited for.
 int cells_key_sorted_copy(xf_cells *c, hipStream_t s) {
   if (!c->NNZ || c->entries_k == c->entries) return XF_OK;
-  hipLaunchKernelGGL(k_cells_sort_pos, dim3((c->ncell + kSortCells - 1) / kSortCells), dim3(kBlock),
-                     0, s, c->entries, c->entries_k, c->cellptr, c->ncell);
+  const uint32_t nsort = (c->ncell + kSortCells - 1) / kSortCells;
+  hipLaunchKernelGGL(k_cells_sort_pos, dim3(nsort + c->nblk), dim3(kBlock), 0, s, c->entries,
+                     c->entries_k, c->cellptr, c->blk_cell, c->ncell, nsort);
   XF_HIP(hipGetLastError());
   c->entries_k_ready = true;
   return XF_OK;

@@ -69,6 +69,7 @@ uint64_t table_epoch(const xf_table *t);
 int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d_rows,
                       hipStream_t s, bool allow_grow);
 int table_grow_for(xf_table *t, const uint64_t *d_keys, size_t n, hipStream_t s);
+int table_count(xf_table *t, hipStream_t s, uint64_t *count);
 }  // namespace xf
 
 namespace {
@@ -1708,6 +1709,67 @@ k_ar_insert(ArArgs a) {
   }
 }
 
+// How many NEW keys would these records bring?  (The table grows before the inserts when they
+// would push its load past 0.6: ftrl.h:84 is an unbounded map.)  Per work item: every record's
+// key is looked for in the arrival index, read-only; the absent ones go into a set in LDS, whose
+// size is the item's count — duplicates of a new key inside an item count once, a key of a range
+// cut into several items once per item, a set that has filled up counts what it cannot hold:
+// an upper bound that is the number itself for hashed keys.  Replaces a 64-bit radix sort of
+// every key of the minibatch (count_distinct, xf_table.hip: still there for the sort-based build).
+constexpr uint32_t kAbsSlots = 8192;
+__global__ void __launch_bounds__(kAr)
+k_ar_absent(ArArgs a, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long lset[kAbsSlots];
+  __shared__ uint32_t s_cnt;
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= *a.nitems) return;
+  const xf::TableDev &T = a.T;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t sb = a.sstart[S], se = a.sstart[S + 1];
+  const uint32_t rb = sb + part * kPart, re = min(se, rb + kPart);
+  for (uint32_t i = tid; i < kAbsSlots; i += kAr) lset[i] = xf::kEmptyKey;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t i = rb + tid; i < re; i += kAr) {
+    const Rec3 r = a.rec[i];
+    const uint64_t key = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    if (key == xf::kEmptyKey || !xf::owns(T, key)) continue;  // (the spare position / an error)
+    bool absent = false;
+    uint64_t p = xf::home_of(T, key);
+    for (uint64_t probes = 0; probes < T.cap; ++probes) {
+      const uint64_t c = T.keys[p];
+      if (c == key) break;
+      if (c == xf::kEmptyKey) {
+        absent = true;
+        break;
+      }
+      if (++p >= T.cap) p -= T.cap;
+    }
+    if (!absent) continue;
+    uint32_t h = (uint32_t)xf::mix64(key) & (kAbsSlots - 1);
+    bool counted = false;
+    for (int t = 0; t < 32 && !counted; ++t) {
+      const unsigned long long old = atomicCAS(&lset[h], (unsigned long long)xf::kEmptyKey,
+                                               (unsigned long long)key);
+      if (old == xf::kEmptyKey) {
+        ++mine;
+        counted = true;
+      } else if (old == key) {
+        counted = true;
+      }
+      h = (h + 1) & (kAbsSlots - 1);
+    }
+    if (!counted) ++mine;  // (the set is full around here: counted without being remembered)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((tid & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (tid == 0 && s_cnt) atomicAdd(out, (unsigned long long)s_cnt);
+}
+
 // every record becomes the entry of its cell; the workgroups beyond the records compute blk_cell
 __global__ void __launch_bounds__(kRes)
 k_ar_place(ArArgs a) {
@@ -2039,17 +2101,12 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     const uint64_t rows_bound = std::max<uint64_t>(T0.max_rows + 1, 2 * ((uint64_t)n + T0.max_rows));
     if ((rows_bound / kChunk + 1) * nwin0 >= (1ull << 22)) return XF_OK;
   }
-  XF_TRY(table_grow_for(t, d_keys, n, s));
-  const TableDev T = table_dev(t);
-  xf_cells *c = nullptr;
-  XF_TRY(cells_alloc(&c, R, n, (uint32_t)(T.max_rows + 1), kCellsTableRows, ksc, w_fixed, chunk0));
-  struct Guard {
-    xf_cells *c;
-    ~Guard() {
-      if (c) cells_free(c);
-    }
-  } guard{c};
-  const size_t ncell = (size_t)c->nwin * c->nchunk;
+  // the partition first: it needs nothing of the table but its key range — and the growth check
+  // below counts over the partitioned records
+  const TableDev T0 = table_dev(t);
+  const uint32_t nwin = w_fixed ? std::max<uint32_t>(1, (R + w_fixed - 1) / w_fixed)
+                                : std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+  const uint32_t W = w_fixed ? w_fixed : std::max<uint32_t>(1, (R + nwin - 1) / nwin);
   Scratch sc;
   const uint32_t nR = std::min<uint32_t>(kArMaxRanges, std::max<uint32_t>(1, (n + kArBatch - 1) / kArBatch));
   KbArgs a{};
@@ -2058,37 +2115,27 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   a.rowid = d_rowid;
   a.R = R;
   a.NNZ = n;
-  a.W = c->W;
-  a.nwin = c->nwin;
-  a.cA = c->nchunk;
+  a.W = W;
+  a.nwin = nwin;
   a.nS = nR;
   a.tile = scatter_lds_bytes(nR, kTile) <= kDynMax ? kTile : kTile / 2;
   a.ntile = (n + a.tile - 1) / a.tile;
-  a.lo = T.lo;
+  a.lo = T0.lo;
   const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
   a.span = sub * a.tile;
   a.nW = (a.ntile + sub - 1) / sub;
-  a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
+  a.npc = 0;  // (the scan's per-range part alone)
   const unsigned max_items = nR + n / kPart + 1;
-  uint32_t *small = nullptr;
-  const size_t n_zero = 4 + ncell;  // the summary and the cell histogram: cleared together
-  const size_t n_small = n_zero + ncell + (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR +
-                         a.ntile + 1 + a.npc;
-  XF_TRY(sc.get(&small, n_small));
-  a.sum = (KbSummary *)small;
-  a.hist = small + 4;
-  a.cellcur = a.hist + ncell;
-  a.scount = a.cellcur + ncell;
+  uint32_t *part1 = nullptr;
+  const size_t n_part1 = (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 2;
+  XF_TRY(sc.get(&part1, n_part1));
+  a.scount = part1;
   a.sstart = a.scount + nR;
   a.items = a.sstart + nR + 1;
   a.nitems = a.items + max_items;
   a.wgcnt = a.nitems + 1;
   a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
-  a.psum = a.tile_r0 + a.ntile + 1;
-  a.cellptr = c->cellptr;
-  a.entries = c->entries;
-  a.plan = c->plan;
-  a.blk_cell = c->blk_cell;
+  unsigned long long *d_absent = (unsigned long long *)(((uintptr_t)(a.tile_r0 + a.ntile + 1) + 7) & ~(uintptr_t)7);
   uint64_t *bnd = nullptr;
   uint16_t *dir = nullptr;
   uint32_t *rec_row = nullptr;
@@ -2099,16 +2146,14 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   a.sc.bnd = bnd;
   a.sc.dir = dir;
   a.sc.n = nR;
-  a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((T.span >> 32) + 1), 0xFFFFFFFFull);
-  XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
-  hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, T.lo, nR, a.sc.mult, bnd,
+  a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((T0.span >> 32) + 1), 0xFFFFFFFFull);
+  hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, T0.lo, nR, a.sc.mult, bnd,
                      dir);
   a.scan_part = 1;
   if (d_rowid) XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
   else
     XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
-  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
-                     a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(1 + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
   const size_t sl = scatter_lds_bytes(nR, a.tile);
   if (a.tile == kTile) {
     if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
@@ -2119,24 +2164,70 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     else
       XF_KB_LAUNCH_N((k_kb_scatter<false, kTile / 2>), a.nW, kKb, sl, a);
   }
+  XF_HIP(hipGetLastError());
   ArArgs r{};
-  r.T = T;
   r.rec = a.rec;
   r.sstart = a.sstart;
   r.items = a.items;
   r.nitems = a.nitems;
   r.n = n;
-  r.nwin = c->nwin;
-  r.nchunk = c->nchunk;
+  r.nwin = nwin;
   r.chunk0 = chunk0;
   r.rec_row = rec_row;
+  r.bnd = bnd;
+  r.nR = nR;
+  // room for the keys that may be new (the table's count: a wait for the stream, which the
+  // partition's kernels share)
+  {
+    uint64_t count = 0;
+    XF_TRY(table_count(t, s, &count));
+    if ((count + n) * 10 > T0.cap * 6) {  // the records alone would say "grow": count the new keys
+      XF_HIP(hipMemsetAsync(d_absent, 0, 8, s));
+      r.T = T0;
+      hipLaunchKernelGGL(k_ar_absent, dim3(max_items), dim3(kAr), 0, s, r, d_absent);
+      unsigned long long absent = 0;
+      XF_HIP(hipMemcpyAsync(&absent, d_absent, 8, hipMemcpyDeviceToHost, s));
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipStreamSynchronize(s));
+      if ((count + absent) * 10 > T0.cap * 6) {
+        uint64_t want = T0.cap * 2;
+        while ((count + absent) * 10 > want * 6) want *= 2;
+        XF_TRY(xf_table_reserve(t, want));
+      }
+    }
+  }
+  const TableDev T = table_dev(t);
+  xf_cells *c = nullptr;
+  XF_TRY(cells_alloc(&c, R, n, (uint32_t)(T.max_rows + 1), kCellsTableRows, ksc, w_fixed, chunk0));
+  struct Guard {
+    xf_cells *c;
+    ~Guard() {
+      if (c) cells_free(c);
+    }
+  } guard{c};
+  XF_REQUIRE(c->W == W && c->nwin == nwin, "arrival_build: geometry");
+  const size_t ncell = (size_t)c->nwin * c->nchunk;
+  a.cA = c->nchunk;
+  a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
+  uint32_t *small = nullptr;
+  const size_t n_zero = 4 + ncell;  // the summary and the cell histogram: cleared together
+  XF_TRY(sc.get(&small, n_zero + ncell + a.npc));
+  a.sum = (KbSummary *)small;
+  a.hist = small + 4;
+  a.cellcur = a.hist + ncell;
+  a.psum = a.cellcur + ncell;
+  a.cellptr = c->cellptr;
+  a.entries = c->entries;
+  a.plan = c->plan;
+  a.blk_cell = c->blk_cell;
+  XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
+  r.T = T;
+  r.nchunk = c->nchunk;
   r.hist = a.hist;
   r.cellcur = a.cellcur;
   r.cellptr = c->cellptr;
   r.entries = c->entries;
   r.blk_cell = c->blk_cell;
-  r.bnd = bnd;
-  r.nR = nR;
   hipLaunchKernelGGL(k_ar_insert<true>, dim3(max_items), dim3(kAr), 0, s, r);
   hipLaunchKernelGGL(k_ar_insert<false>, dim3(max_items), dim3(kAr), 0, s, r);
   a.scan_part = 2;

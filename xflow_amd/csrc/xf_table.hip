@@ -1962,6 +1962,15 @@ int table_grow_for(xf_table *t, const uint64_t *d_keys, size_t n, hipStream_t s)
   return XF_OK;
 }
 
+// the keys the table holds (waits for the stream: inserts on it have finished)
+int table_count(xf_table *t, hipStream_t s, uint64_t *count) {
+  XF_HIP(hipStreamSynchronize(s));
+  xf::TableStat st;
+  XF_TRY(read_stat(t, &st));
+  *count = st.count;
+  return XF_OK;
+}
+
 // grow the table (xf_table_reserve) when `incoming` more keys would push the load past 0.6.
 // Synchronises the device.
 int table_ensure_room(xf_table *t, size_t incoming) {
