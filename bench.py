@@ -828,6 +828,8 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
     capi_sync()
     L.xf_batch_free(h)
     del warm
+    # the worker's init push (lr_worker.cc:180-182: key 0, a zero gradient) before the clock starts
+    tr.w.push(np.zeros(1, np.uint64), np.zeros(1, np.float32))
     setup_s = time.perf_counter() - t_set
     per, keys_after, defrags = [], [], []
     at_defrag, prev = 0, None
@@ -842,6 +844,7 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
             L.xf_batch_free(prev)
         prev = h
         n = len(tr.w)                      # (xf_table_size: waits for the step, as the worker's
+        at_defrag = tr.w.settled           # (the first minibatch's build settles an empty table)
         arrived, fresh = n - at_defrag, n - (keys_after[-1] if keys_after else 0)
         # defrag_if_grown does): grown by `percent`, or the inflow has stopped with keys unsettled
         if n > at_defrag + at_defrag // 100 * percent + 4096 or \
@@ -852,7 +855,6 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
             tr.defrag()
             defrags.append({"after_minibatch": i, "keys": n,
                             "ms": (time.perf_counter() - td) * 1e3})
-            at_defrag = n
         keys_after.append(n)
         per.append((time.perf_counter() - tb) * 1e3)
     capi_sync()
@@ -871,8 +873,8 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
             "ms_per_minibatch_without_the_defrags":
                 float(np.mean(no_defrag)) if no_defrag else None,
             "ms_last_5_minibatches": float(np.mean(per[-5:])), "setup_s": setup_s,
-            "what": "an EMPTY table, xf_lr_update_dev (key build with insert on first touch + "
-                    "step) per minibatch, the host waiting for each (xf_table_size) and settling "
+            "what": "a table that holds key 0 (the worker's init push), xf_lr_update_dev (key "
+                    "build with insert on first touch + step) per minibatch, the host waiting for each (xf_table_size) and settling "
                     "the table when its keys have grown by 30 % (the worker's policy); "
                     "ms_by_minibatch includes that wait and the defrag where one ran"}
 

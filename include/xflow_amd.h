@@ -214,7 +214,7 @@ int xf_batch_tiles(const xf_batch *b, uint32_t *ntiles, const uint32_t **tile_pt
  * the next compile/upload; 0 returns every one to the driver).
  * Named switches between code paths that are all product code and normally chosen by the shape
  * (tests pin one to run each against the oracle; 0 = by shape): "key_build" (1 the sort-based
- * build, 2 the two-level partition), "old_weight" (1 read, 2 derive from (n, z)), "lr_gradient"
+ * build, 2 the two-level partition, 3 an empty table's keys through the arrival index too), "old_weight" (1 read, 2 derive from (n, z)), "lr_gradient"
  * (1 the general kernel, 2 / 3 the dense kernel with byte-masked / whole-line stores),
  * "owner_pass" (1 the general loop, 2 / 3 the merged phases, 4 a phase per worker) —
  * xflow_amd/csrc/xf_common.h.  An unknown name, or a value a switch does not take, is XF_EINVAL
@@ -292,6 +292,9 @@ int xf_table_create(xf_table **out, const xf_table_config *cfg); /* on current d
 int xf_table_destroy(xf_table *t);
 int xf_table_size(xf_table *t, uint64_t *nkeys); /* synchronises */
 int xf_table_capacity(xf_table *t, uint64_t *slots);
+/* keys of the settled tier (sorted, key r owns state row r): what the last xf_table_defrag —
+ * or the first-touch build of an empty table's first minibatch — left there; 0 before */
+int xf_table_settled(xf_table *t, uint64_t *nkeys);
 /* grow to new_capacity slots (rehash on device); earlier slot arrays become invalid */
 int xf_table_reserve(xf_table *t, uint64_t new_capacity);
 /* renumber the state rows in key order (locality of the Pull gather and the Push pass once

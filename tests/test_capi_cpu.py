@@ -662,7 +662,7 @@ def test_the_update_entry_points_fail_loudly_without_a_gpu():
 def test_tune_takes_the_named_switches_and_no_experiment_knob():
     """xf_tune: the code paths a test may pin have names (xf_common.h); the experiments' numeric
     knob exists only in a library built with -DXF_EXPERIMENTS, and values out of range are refused."""
-    for name, hi in (("key_build", 2), ("old_weight", 2), ("lr_gradient", 3), ("owner_pass", 4)):
+    for name, hi in (("key_build", 3), ("old_weight", 2), ("lr_gradient", 3), ("owner_pass", 4)):
         for v in range(hi + 1):
             capi.tune(name, v)
         with pytest.raises(capi.XFError):

@@ -148,7 +148,8 @@ def test_local_batch_without_keys_refuses_a_renumbered_table():
     t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 14)
     ws = capi.Workspace()
     raw = synth(rng, 200, 10, 3000, None, False)
-    b = capi.LocalBatch(t, *raw, retain_keys=False)
+    t.pull(capi.hash_decimal_range(10**6, 5000))     # (a table with keys: the build of an EMPTY
+    b = capi.LocalBatch(t, *raw, retain_keys=False)  # table's first minibatch settles it at once)
     capi.lr_step(t, b, ws)
     t.defrag()
     with pytest.raises(capi.XFError, match="did not keep its keys"):

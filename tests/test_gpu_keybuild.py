@@ -371,3 +371,147 @@ def test_defrag_without_a_sort_a_cluster_that_wraps_around_the_end_of_the_index(
             capi.tune("key_build", 0)
     for a, b in zip(*exports):
         same(a, b)
+
+
+def _first_minibatches(kind, rng):
+    R, nnz = 6000, 30
+    rowptr = (np.arange(R + 1) * nnz).astype(np.uint64)
+    n = R * nnz
+    if kind == "hashed":
+        return [synth(rng, R, nnz, 60000) for _ in range(3)]
+    if kind == "ragged_zipf":
+        return [synth(rng, R, nnz, 40000, 1.2, True) for _ in range(3)]
+    out = []
+    for step in range(3):
+        if kind == "integers":          # every key in the first key range
+            keys = rng.randint(0, 50000, size=n).astype(np.uint64)
+        elif kind == "reserved":        # hashes, among them the reserved key value
+            keys = synth(rng, R, nnz, 60000)[1].copy()
+            keys[::211] = np.uint64(2**64 - 1)
+        elif kind == "clustered":       # 256 keys next to each of 300 hashes: one home each
+            base = synth(rng, R, nnz, 300)[1]
+            keys = base + rng.randint(0, 256, size=n).astype(np.uint64)
+        elif kind == "one_key":
+            keys = np.full(n, capi.hash_decimal_range(7, 1)[0], np.uint64)
+        else:
+            raise AssertionError(kind)
+        out.append((rowptr, keys, rng.randint(0, 2, size=R).astype(np.int32)))
+    return out
+
+
+@pytest.mark.parametrize("kind,settles", [
+    ("hashed", True), ("ragged_zipf", True), ("one_key", True),
+    ("integers", False), ("reserved", False), ("clustered", False),
+])
+def test_the_first_minibatch_settles_an_empty_table(kind, settles):
+    """xf_keybuild.hip "an empty table": the keys of the first minibatch become the settled tier
+    at once (sorted in LDS, range by range) — bit for bit the oracle, and the table that took the
+    same keys through the arrival index (key_build = 3) and a defrag.  Keys the LDS sort does not
+    take (a run of integers: one key range holds them all, more than its set has room for; the
+    reserved key value; hundreds of keys with one home) go the old way, and nothing is settled.
+    One key in every nonzero, a power-law head: a range's set holds DISTINCT keys."""
+    rng = np.random.RandomState(len(kind))
+    raws = _first_minibatches(kind, rng)
+    ws = capi.Workspace()
+    tabs = []
+    for mode in (0, 3):
+        capi.tune("key_build", mode)
+        try:
+            t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 12)     # (grows under the first build)
+            s = O.Store(O.OPT_FTRL, 1)
+            b0 = capi.LocalBatch(t, *raws[0])
+            nu = len(np.unique(raws[0][1]))
+            assert len(t) == nu
+            assert t.settled == (nu if settles and mode == 0 else 0), (t.settled, nu)
+            assert b0.cells_info()["segments"] == 1
+            if mode == 3:
+                t.defrag()          # (the cells of b0 are built again: its keys are retained)
+            ob0 = O.Batch(*raws[0])
+            for _ in range(2):
+                with O.sum_mode(1):
+                    loss_ex, _ = ob0.lr_loss(s.pull(ob0.ukeys))
+                    O.lr_update(s, ob0)
+                capi.lr_step(t, b0, ws)
+                same(ws.fetch_loss(b0.R), loss_ex)
+            # the next minibatches: settled keys, holes, an arrival segment
+            steps_vs_oracle(t, s, raws[1:], ws, 4, defrag_at=1)
+            tabs.append(t.export())
+        finally:
+            capi.tune("key_build", 0)
+    for a, b in zip(tabs[0], tabs[1]):
+        same(a, b)
+
+
+def test_an_empty_sgd_table_with_constant_initial_weights_settles_too():
+    """the settled rows' initial weights are the init kind's (k_first_rows), as a first Pull
+    would have left them (sgd.h / ftrl.h: the store's default)"""
+    rng = np.random.RandomState(77)
+    raws = [synth(rng, 5000, 20, 30000) for _ in range(2)]
+    outs = []
+    for mode in (0, 3):
+        capi.tune("key_build", mode)
+        try:
+            t = capi.Table(capi.OPT_SGD, 1, init=capi.INIT_CONST, init_const=0.25, capacity=1 << 17)
+            ws = capi.Workspace()
+            b = capi.LocalBatch(t, *raws[0])
+            assert t.settled == (len(np.unique(raws[0][1])) if mode == 0 else 0)
+            w0 = t.pull(np.unique(raws[0][1]))
+            assert np.all(w0 == np.float32(0.25))
+            capi.lr_step(t, b, ws)
+            b1 = capi.LocalBatch(t, *raws[1])
+            capi.lr_step(t, b1, ws)
+            t.check()
+            outs.append((ws.fetch_loss(b1.R), t.export()))
+        finally:
+            capi.tune("key_build", 0)
+    same(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        same(a, b)
+
+
+@pytest.mark.parametrize("opt", [capi.OPT_FTRL, capi.OPT_SGD])
+def test_keys_the_host_api_pushed_first_do_not_keep_the_first_minibatch_from_settling(opt):
+    """lr_worker.cc:180-182 pushes key 0 before the first minibatch: the table is not empty, but
+    what it holds is what the host API put there (the table knows: its key count is theirs) — the
+    first build takes those keys out of the arrival index, settles the table with the minibatch's
+    keys and puts them back with their state: a key of the minibatch into its settled row, the
+    others behind the tier.  Bit for bit the oracle, whichever way the keys went in."""
+    rng = np.random.RandomState(23)
+    raws = [synth(rng, 5000, 20, 40000) for _ in range(3)]
+    in_batch = np.unique(raws[0][1])[[5, 700]]
+    elsewhere = capi.hash_decimal_range(10**7, 3)
+    tabs = []
+    for mode in (0, 3):
+        capi.tune("key_build", mode)
+        try:
+            t = capi.Table(opt, 1, capacity=1 << 18)
+            s = O.Store(opt, 1)
+            ws = capi.Workspace()
+            for keys, g in ((np.array([0], np.uint64), np.zeros(1, np.float32)),
+                            (np.sort(np.concatenate([in_batch, elsewhere])),
+                             np.linspace(-0.5, 0.75, 5).astype(np.float32))):
+                t.push(keys, g)
+                s.push(keys, g)
+            assert len(t) == 6 and t.settled == 0
+            b0 = capi.LocalBatch(t, *raws[0])
+            nu = len(np.unique(raws[0][1]))
+            assert len(t) == nu + 4                      # key 0 and the three from elsewhere
+            assert t.settled == (nu if mode == 0 else 0)
+            steps_vs_oracle(t, s, raws, ws, 5, defrag_at=2)
+            tabs.append(t.export())
+        finally:
+            capi.tune("key_build", 0)
+    for a, b in zip(tabs[0], tabs[1]):
+        same(a, b)
+
+
+def test_a_table_others_hold_rows_of_is_not_renumbered_by_its_first_minibatch():
+    """more keys than the table remembers (4096), or keys that did not come through the host
+    API: the first minibatch goes through the arrival index"""
+    rng = np.random.RandomState(29)
+    raw = synth(rng, 3000, 20, 20000)
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 17)
+    t.pull(capi.hash_decimal_range(10**6, 5000))
+    b = capi.LocalBatch(t, *raw)
+    assert t.settled == 0 and b.cells_info()["segments"] == 1
+    t.check()

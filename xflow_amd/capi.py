@@ -124,6 +124,7 @@ SIGNATURES = {
     "xf_table_create": (C.c_int, [C.POINTER(vp), C.POINTER(TableConfig)]),
     "xf_table_destroy": (C.c_int, [vp]),
     "xf_table_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "xf_table_settled": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_capacity": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_reserve": (C.c_int, [vp, C.c_uint64]),
     "xf_table_defrag": (C.c_int, [vp]),
@@ -618,6 +619,12 @@ class Table:
     def __len__(self):
         n = C.c_uint64(0)
         check(lib().xf_table_size(self.h, C.byref(n)))
+        return n.value
+
+    @property
+    def settled(self):
+        n = C.c_uint64(0)
+        check(lib().xf_table_settled(self.h, C.byref(n)))
         return n.value
 
     @property

@@ -255,7 +255,7 @@ extern "C" int xf_tune(const char *name, double value) {
   if (!strcmp(name, "panel_slice_bytes")) g_panel_slice_bytes = value;
   else if (!strcmp(name, "min_panel_nnz")) g_min_panel_nnz = value;
   else if (!strcmp(name, "parse_threads")) xf::set_parse_threads((int)value);
-  else if (!strcmp(name, "key_build") && value >= 0 && value <= 2)
+  else if (!strcmp(name, "key_build") && value >= 0 && value <= 3)
     xf::set_path_switch(xf::kPathKeyBuild, (int)value);
   else if (!strcmp(name, "old_weight") && value >= 0 && value <= 2)
     xf::set_path_switch(xf::kPathOldWeight, (int)value);

@@ -536,7 +536,7 @@ int ensure_cells(xf_batch *b, xf_table *t, hipStream_t s) {
                        kCellsTableRows, true, s));
   }
   c->table_uid = uid;
-  c->epoch = ep;
+  c->epoch = table_epoch(t);  // (after the build: a table's first build may renumber early rows)
   b->cells = c;
   return XF_OK;
 }

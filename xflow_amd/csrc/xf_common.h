@@ -24,7 +24,8 @@ void scratch_poison();
 // decided by the shape; tests pin one to run each against the oracle (xf_tune, by name):
 //   key_build    0 by shape; 1 the sort-based build (a probe of the table per nonzero + a radix
 //                pass on the cell number: the limits' fallback and the tests' independent second
-//                implementation); 2 the two-level partition also where one level would do
+//                implementation); 2 the two-level partition also where one level would do; 3 the keys
+//                of a table's first minibatch through the arrival index (not settled at once)
 //   old_weight   0 by shape (xf_cells_grad.hip); 1 the gradient + Push kernels READ a step's old w;
 //                2 they derive it from (n, z) wherever the table vouches for it
 //   lr_gradient  0 by shape; 1 the general kernel also where the dense one applies; 2 / 3 the

@@ -56,6 +56,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <vector>
 
 #include "xf_batch.h"
 #include "xf_cells.h"
@@ -70,6 +71,14 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
                       hipStream_t s, bool allow_grow);
 int table_grow_for(xf_table *t, const uint64_t *d_keys, size_t n, hipStream_t s);
 int table_count(xf_table *t, hipStream_t s, uint64_t *count);
+int table_first_tier(xf_table *t, size_t d, uint64_t **keys);
+int table_settle_first(xf_table *t, size_t d, hipStream_t s);
+bool table_early_keys(xf_table *t, uint64_t count, std::vector<uint64_t> *out);
+void table_note_rows_out(xf_table *t);
+int table_take_early(xf_table *t, const uint64_t *d_keys, size_t n, float *tw, float2 *tnz,
+                     unsigned long long *d_pos, hipStream_t s);
+int table_put_early(xf_table *t, const uint64_t *d_keys, size_t n, const float *tw,
+                    const float2 *tnz, uint32_t *d_rows, hipStream_t s);
 }  // namespace xf
 
 namespace {
@@ -1770,27 +1779,31 @@ k_ar_absent(ArArgs a, unsigned long long *__restrict__ out) {
   if (tid == 0 && s_cnt) atomicAdd(out, (unsigned long long)s_cnt);
 }
 
+// blk_cell[b] = the largest cell with cellptr[cell] <= kBlk * b, by `spare` workgroups
+__device__ __forceinline__ void ar_blk_cell(const ArArgs &a, uint32_t wg, uint32_t spare) {
+  const uint32_t ncell = a.nwin * a.nchunk, nblk = (a.n + kBlk - 1) / kBlk;
+  for (uint32_t b = wg * blockDim.x + threadIdx.x; b <= nblk; b += spare * blockDim.x) {
+    uint32_t lo = 0, hi = ncell;  // cellptr[0] = 0
+    if (b == nblk) lo = ncell - 1;
+    else
+      while (hi - lo > 1) {
+        const uint32_t m = lo + (hi - lo) / 2;
+        if (a.cellptr[m] <= b * kBlk) lo = m;
+        else
+          hi = m;
+      }
+    a.blk_cell[b] = lo;
+  }
+}
+
 // every record becomes the entry of its cell; the workgroups beyond the records compute blk_cell
 __global__ void __launch_bounds__(kRes)
 k_ar_place(ArArgs a) {
   constexpr int E = 4;
   const uint32_t tid = threadIdx.x;
   const uint32_t nwg = (a.n + kRes * E - 1) / (kRes * E);
-  if (blockIdx.x >= nwg) {  // blk_cell[b] = the largest cell with cellptr[cell] <= kBlk * b
-    const uint32_t ncell = a.nwin * a.nchunk, nblk = (a.n + kBlk - 1) / kBlk;
-    const uint32_t spare = gridDim.x - nwg;
-    for (uint32_t b = (blockIdx.x - nwg) * kRes + tid; b <= nblk; b += spare * kRes) {
-      uint32_t lo = 0, hi = ncell;  // cellptr[0] = 0
-      if (b == nblk) lo = ncell - 1;
-      else
-        while (hi - lo > 1) {
-          const uint32_t m = lo + (hi - lo) / 2;
-          if (a.cellptr[m] <= b * kBlk) lo = m;
-          else
-            hi = m;
-        }
-      a.blk_cell[b] = lo;
-    }
+  if (blockIdx.x >= nwg) {
+    ar_blk_cell(a, blockIdx.x - nwg, gridDim.x - nwg);
     return;
   }
   Rec3 rec[E];
@@ -1811,6 +1824,310 @@ k_ar_place(ArArgs a) {
     if (ok[q])
       a.entries[slot] =
           ((c & xf::kTagMask) << kTagShift) | (rin << kChunkBits) | (row[q] & (kChunk - 1));
+  }
+}
+
+// ------------------------------------------------------------- an empty table (round 6)
+// The first minibatch of a run meets a table that holds nothing (lr_worker.cc:183-188 starts
+// from an empty store): every key is new, and what the arrival index would be asked to do — a
+// claim per key, then xf_table_defrag to read the index back in key order — is a sort of the
+// minibatch's keys.  The uniform key ranges above ARE the first level of that sort; the second
+// runs in LDS, a workgroup per range:
+//   k_eb_rank    the range's distinct keys, ascending, and every record's rank among them: an
+//                order-preserving key set in LDS (below).  More distinct keys than the set holds,
+//                clusters of hundreds (keys that are no hashes), a reserved or a foreign key: the
+//                flag goes up and the build takes the arrival index after all.
+//   k_eb_scan    ranks of the ranges' first keys (a scan over <= 4000 counts)
+//   k_eb_count   the keys into the table's settled tier (rank = state row, fresh: zeroed memory,
+//                or k_first_rows), every record's state row, its cell counted — in LDS: a range's
+//                rows are consecutive, its records fall into nwin x (<= 6) cells
+//   table_settle_first (xf_table.hip)   the tier's two directories
+//   k_kb_scan    (cell part), then
+//   k_eb_place   the entries: a range's records take their slots from LDS cursors, one atomic on
+//                the cell's cursor per (range, cell) instead of one per wavefront and cell
+// No claim, no probe, no defrag after the minibatch: the table is settled when the build returns.
+// 10^7 nonzeros, 6.3e6 keys: DESIGN.md §3 "First touch".
+constexpr int kEb = 512;                   // threads of k_eb_count / k_eb_place
+constexpr int kEbR = 1024;                 // threads of k_eb_rank
+constexpr uint32_t kEbSlots = 8192;        // positions of a range's key set in LDS ...
+constexpr uint32_t kEbPad = 1024;          // ... and behind them, for the last homes' clusters
+constexpr uint32_t kEbAll = kEbSlots + kEbPad;
+constexpr uint32_t kEbPerT = kEbAll / kEbR;      // positions per thread: 9, groups of 3
+constexpr uint32_t kEbCluster = 512;       // keys of one cluster its thread sorts
+constexpr uint32_t kEbCells = 2048;        // cells a range's records may fall into (LDS counters)
+static_assert(kEbPerT * kEbR == kEbAll && kEbPerT % 3 == 0, "k_eb_rank: a thread's groups");
+struct EbArgs {
+  xf::TableDev T;
+  const Rec3 *rec;         // [n] records grouped by key range
+  const uint32_t *sstart;  // [nR + 1]
+  const uint64_t *bnd;     // [nR]
+  uint32_t nR, n;
+  uint32_t *rec_row;       // [n] k_eb_rank: rank of the record's key in its range; k_eb_count: row
+  uint64_t *ukeys;         // [n] the ranges' distinct keys, range S's from sstart[S] on
+  uint32_t *dbase;         // [nR + 1] distinct keys per range, then (k_eb_scan) their scan
+  unsigned int *out;       // [0] flag: not this way; [1] distinct keys in all
+  uint64_t *bkeys;         // the settled tier to be
+  uint32_t nwin, nchunk;
+  uint32_t *hist, *cellcur, *entries;
+};
+// two workgroups per CU: 2 x (72 KB of keys + 6 KB of counts) of the 160 KB
+constexpr size_t kEbLds = (size_t)kEbAll * 8 + (size_t)(kEbAll / 3) * 2;
+
+// The range's DISTINCT keys as an order-preserving set in LDS (the arrival index's own scheme: a
+// key sits at or behind its home = its share of the range's width, inside the home's cluster; no
+// wrap-around: kEbPad positions behind the last home), so the records of a heavy key cost a read
+// each and a range may hold any number of them.  The clusters (one or two keys at this load,
+// dozens now and then) are then sorted where they lie, by the thread that holds their first
+// position — every key still sits at or behind its home (the positions from the cluster's start
+// to a key's home hold keys with smaller homes: smaller keys) — and a key's rank is the number of
+// occupied positions before it: a count per group of three positions.  Every record finds its
+// key again and takes the rank.
+__global__ void __launch_bounds__(kEbR)
+k_eb_rank(EbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char eb_lds[];
+  unsigned long long *tab = (unsigned long long *)eb_lds;  // [kEbAll]
+  uint16_t *gp = (uint16_t *)(tab + kEbAll);               // [kEbAll / 3] keys before the group
+  __shared__ uint32_t wsum[kEbR / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
+  if (m == 0) {  // workgroup-uniform
+    if (tid == 0) a.dbase[S] = 0;
+    return;
+  }
+  // home of a key: (key - first key of the range) >> sh, the range's width cut into at most
+  // kEbSlots equal pieces (the last range ends where the key space does)
+  const uint64_t k0 = a.bnd[S];
+  const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] : 0ull) - k0 - 1ull;  // width - 1, mod 2^64
+  const int bits = 64 - __clzll((long long)(width1 | 1ull));
+  const int sh = bits > 13 ? bits - 13 : 0;
+  static_assert(kEbSlots == 1u << 13, "the shift above");
+  for (uint32_t i = tid; i < kEbAll; i += kEbR) tab[i] = xf::kEmptyKey;
+  __syncthreads();
+  bool bad = false;
+  constexpr int E = 4;  // records in flight per thread
+  for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
+    uint64_t key[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t i = i0 + q * kEbR + tid;
+      const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      if (i0 + q * kEbR + tid >= m) continue;
+      if (key[q] == xf::kEmptyKey || !xf::owns(a.T, key[q]) || key[q] < k0) {
+        bad = true;  // the reserved value, a foreign key: the arrival index knows what to do
+        continue;
+      }
+      uint32_t h = (uint32_t)min((key[q] - k0) >> sh, (uint64_t)(kEbSlots - 1));
+      for (;;) {
+        unsigned long long c = tab[h];
+        if (c == xf::kEmptyKey)
+          c = atomicCAS(&tab[h], (unsigned long long)xf::kEmptyKey, (unsigned long long)key[q]);
+        if (c == xf::kEmptyKey || c == key[q]) break;
+        if (++h >= kEbAll) {  // more keys than the set holds
+          bad = true;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the clusters in key order
+  const uint32_t p0 = tid * kEbPerT;
+  for (uint32_t k = 0; k < kEbPerT; ++k) {
+    const uint32_t p = p0 + k;
+    if (tab[p] == xf::kEmptyKey || (p > 0 && tab[p - 1] != xf::kEmptyKey)) continue;
+    uint32_t e = p + 1;
+    while (e < kEbAll && tab[e] != xf::kEmptyKey && e - p <= kEbCluster) ++e;
+    if (e - p > kEbCluster) {  // keys that are no hashes
+      bad = true;
+      continue;
+    }
+    for (uint32_t i = p + 1; i < e; ++i) {
+      const unsigned long long x = tab[i];
+      uint32_t j = i;
+      while (j > p && tab[j - 1] > x) {
+        tab[j] = tab[j - 1];
+        --j;
+      }
+      tab[j] = x;
+    }
+  }
+  if (__syncthreads_or(bad ? 1 : 0)) {  // not this way: the caller takes the arrival index
+    if (tid == 0) {
+      a.dbase[S] = 0;
+      atomicOr(&a.out[0], 1u);
+    }
+    return;
+  }
+  // ranks: occupied positions before every group of three
+  unsigned long long mine[kEbPerT];
+  uint32_t occ = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kEbPerT; ++k) {
+    mine[k] = tab[p0 + k];
+    occ += mine[k] != xf::kEmptyKey ? 1u : 0u;
+  }
+  uint32_t inc = occ;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += y;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = inc - occ, d = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < (uint32_t)kEbR / 64; ++w) {
+    const uint32_t x = wsum[w];
+    if (w < wave) before += x;
+    d += x;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kEbPerT; ++k) {
+    if (k % 3 == 0) gp[(p0 + k) / 3] = (uint16_t)before;
+    if (mine[k] != xf::kEmptyKey) {
+      a.ukeys[sb + before] = mine[k];
+      ++before;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
+    uint64_t key[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t i = i0 + q * kEbR + tid;
+      const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0u, 0u, 0u};
+      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t i = i0 + q * kEbR + tid;
+      if (i >= m) continue;
+      uint32_t h = (uint32_t)min((key[q] - k0) >> sh, (uint64_t)(kEbSlots - 1));
+      while (tab[h] != key[q]) ++h;  // (the key is there, at or behind its home)
+      const uint32_t g = h / 3, g0 = g * 3;
+      uint32_t rank = gp[g];
+      if (h > g0) rank += tab[g0] != xf::kEmptyKey ? 1u : 0u;
+      if (h > g0 + 1) rank += tab[g0 + 1] != xf::kEmptyKey ? 1u : 0u;
+      a.rec_row[sb + i] = rank;
+    }
+  }
+  if (tid == 0) a.dbase[S] = d;
+}
+
+__global__ void __launch_bounds__(1024)
+k_eb_scan(EbArgs a) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t kPerT = 4;  // 4096 >= kArMaxRanges
+  uint32_t v[kPerT], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kPerT; ++k) {
+    const uint32_t r = tid * kPerT + k;
+    v[k] = r < a.nR ? a.dbase[r] : 0u;
+    sum += v[k];
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(inc, o);
+    if ((int)lane >= o) inc += y;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t run = inc - sum;
+  for (uint32_t w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerT; ++k) {
+    const uint32_t r = tid * kPerT + k;
+    if (r < a.nR) a.dbase[r] = run;
+    run += v[k];
+    if (r + 1 == a.nR) {
+      a.dbase[a.nR] = run;
+      a.out[1] = run;
+    }
+  }
+}
+
+// the cells a range's records fall into: (row window) x (the chunks its consecutive rows span)
+struct EbLocal {
+  uint32_t base, d, c_lo, nloc;
+};
+__device__ __forceinline__ EbLocal eb_local(const EbArgs &a, uint32_t S) {
+  EbLocal L;
+  L.base = a.dbase[S];
+  L.d = a.dbase[S + 1] - L.base;
+  L.c_lo = L.base >> kChunkBits;
+  L.nloc = L.d ? ((L.base + L.d - 1) >> kChunkBits) - L.c_lo + 1 : 1u;
+  return L;
+}
+
+// PLACE = false: k_eb_count; true: k_eb_place (the workgroups beyond the ranges: blk_cell)
+template <bool PLACE>
+__global__ void __launch_bounds__(kEb)
+k_eb_cells(EbArgs a, ArArgs r) {
+  __shared__ uint32_t lcnt[kEbCells], lcur[kEbCells];
+  const uint32_t tid = threadIdx.x;
+  if (PLACE && blockIdx.x >= a.nR) {
+    ar_blk_cell(r, blockIdx.x - a.nR, gridDim.x - a.nR);
+    return;
+  }
+  const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
+  if (m == 0) return;
+  const EbLocal L = eb_local(a, S);
+  const uint32_t nl = a.nwin * L.nloc;  // <= kEbCells (the host saw to it)
+  for (uint32_t i = tid; i < nl; i += kEb) lcnt[i] = 0;
+  if (!PLACE)
+    for (uint32_t j = tid; j < L.d; j += kEb) a.bkeys[L.base + j] = a.ukeys[sb + j];
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < m; i0 += kEb * 4) {
+    uint32_t rp[4], row[4], lc[4], at[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t i = i0 + q * kEb + tid;
+      ok[q] = i < m;
+      rp[q] = ok[q] ? a.rec[sb + i].rp : 0u;
+      row[q] = ok[q] ? a.rec_row[sb + i] + (PLACE ? 0u : L.base) : L.base;
+      lc[q] = (rp[q] >> kRinBits) * L.nloc + ((row[q] >> kChunkBits) - L.c_lo);
+      if (ok[q]) at[q] = atomicAdd(&lcnt[lc[q]], 1u);
+      if (!PLACE && ok[q]) a.rec_row[sb + i] = row[q];
+    }
+    if (PLACE) {
+      // this round's records take their slots: the cells' cursors move once per round and cell
+      __syncthreads();
+      for (uint32_t c = tid; c < nl; c += kEb) {
+        const uint32_t k = lcnt[c];
+        if (k) {
+          const uint32_t v = c / L.nloc, ch = L.c_lo + (c - v * L.nloc);
+          lcur[c] = atomicAdd(&a.cellcur[v * a.nchunk + ch], k);
+          lcnt[c] = 0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+          const uint32_t ch = row[q] >> kChunkBits;
+          a.entries[lcur[lc[q]] + at[q]] = ((ch & xf::kTagMask) << kTagShift) |
+                                           ((rp[q] & ((1u << kRinBits) - 1u)) << kChunkBits) |
+                                           (row[q] & (kChunk - 1));
+        }
+      __syncthreads();
+    }
+  }
+  if (!PLACE) {
+    __syncthreads();
+    for (uint32_t c = tid; c < nl; c += kEb) {
+      const uint32_t k = lcnt[c];
+      if (k) {
+        const uint32_t v = c / L.nloc, ch = L.c_lo + (c - v * L.nloc);
+        atomicAdd(&a.hist[v * a.nchunk + ch], k);
+      }
+    }
   }
 }
 
@@ -2177,11 +2494,69 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   r.bnd = bnd;
   r.nR = nR;
   // room for the keys that may be new (the table's count: a wait for the stream, which the
-  // partition's kernels share)
+  // partition's kernels share) — and, of a table that holds nothing, the whole tier at once
+  // (kernels: "an empty table")
+  EbArgs e{};
+  bool eb = false;
+  uint64_t eb_keys = 0;
+  // (the keys the host API put there before the first minibatch, lr_worker.cc:180-182: taken out
+  // of the arrival index, put back when the tier stands — found in it, or inserted behind it)
+  std::vector<uint64_t> early;
+  uint64_t *d_early = nullptr;
+  float *early_w = nullptr;
+  float2 *early_nz = nullptr;
+  uint32_t *early_rows = nullptr;
+  unsigned long long *early_pos = nullptr;
   {
     uint64_t count = 0;
     XF_TRY(table_count(t, s, &count));
-    if ((count + n) * 10 > T0.cap * 6) {  // the records alone would say "grow": count the new keys
+    eb = T0.nbase == 0 && chunk0 == 0 && key_build_mode() != 3 && (uint64_t)nwin * 6 <= kEbCells &&
+         (count == 0 || table_early_keys(t, count, &early));
+    if (eb) {
+      e.T = T0;
+      e.rec = a.rec;
+      e.sstart = a.sstart;
+      e.bnd = bnd;
+      e.nR = nR;
+      e.n = n;
+      e.rec_row = rec_row;
+      XF_TRY(sc.get(&e.ukeys, n));
+      XF_TRY(sc.get(&e.dbase, nR + 2));
+      XF_TRY(sc.get(&e.out, 2));
+      XF_HIP(hipMemsetAsync(e.out, 0, 8, s));
+      XF_KB_LAUNCH_N(k_eb_rank, nR, kEbR, kEbLds, e);
+      hipLaunchKernelGGL(k_eb_scan, dim3(1), dim3(1024), 0, s, e);
+      unsigned int *hout = (unsigned int *)&sum->miss;  // (pinned: flag, distinct keys)
+      XF_HIP(hipMemcpyAsync(hout, e.out, 8, hipMemcpyDeviceToHost, s));
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipStreamSynchronize(s));
+      const uint64_t distinct = hout[1];
+      eb = hout[0] == 0 && distinct > 0;
+      eb_keys = distinct;
+      if (eb) {
+        const uint64_t all = distinct + early.size();
+        if (all * 10 > T0.cap * 6) {  // (the arrival index's load rule, for the rows' sake)
+          uint64_t want = T0.cap * 2;
+          while (all * 10 > want * 6) want *= 2;
+          XF_TRY(xf_table_reserve(t, want));
+        }
+        XF_REQUIRE(all <= table_dev(t).max_rows, "first-touch build: %llu keys, %llu rows",
+                   (unsigned long long)all, (unsigned long long)table_dev(t).max_rows);
+        XF_TRY(table_first_tier(t, (size_t)distinct, &e.bkeys));
+        if (!early.empty()) {
+          const size_t ne = early.size(), dim = (size_t)table_dev(t).dim;
+          unsigned long long *d_pos = nullptr;
+          XF_TRY(sc.get(&d_early, ne));
+          XF_TRY(sc.get(&d_pos, ne));
+          XF_TRY(sc.get(&early_w, ne * dim));
+          XF_TRY(sc.get(&early_nz, ne * dim));
+          XF_TRY(sc.get(&early_rows, ne));
+          XF_HIP(hipMemcpyAsync(d_early, early.data(), ne * 8, hipMemcpyHostToDevice, s));
+          early_pos = d_pos;
+        }
+      }
+    }
+    if (!eb && (count + n) * 10 > T0.cap * 6) {  // the records alone would say "grow": count the new keys
       XF_HIP(hipMemsetAsync(d_absent, 0, 8, s));
       r.T = T0;
       hipLaunchKernelGGL(k_ar_absent, dim3(max_items), dim3(kAr), 0, s, r, d_absent);
@@ -2228,13 +2603,35 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   r.cellptr = c->cellptr;
   r.entries = c->entries;
   r.blk_cell = c->blk_cell;
-  hipLaunchKernelGGL(k_ar_insert<true>, dim3(max_items), dim3(kAr), 0, s, r);
-  hipLaunchKernelGGL(k_ar_insert<false>, dim3(max_items), dim3(kAr), 0, s, r);
+  if (eb) {
+    e.T = T;
+    e.nwin = nwin;
+    e.nchunk = c->nchunk;
+    e.hist = a.hist;
+    e.cellcur = a.cellcur;
+    e.entries = c->entries;
+    if (!early.empty())  // (from here on nothing fails before they are back)
+      XF_TRY(table_take_early(t, d_early, early.size(), early_w, early_nz, early_pos, s));
+    hipLaunchKernelGGL(k_eb_cells<false>, dim3(nR), dim3(kEb), 0, s, e, r);
+    XF_HIP(hipGetLastError());
+    XF_TRY(table_settle_first(t, (size_t)eb_keys, s));
+    if (!early.empty())
+      XF_TRY(table_put_early(t, d_early, early.size(), early_w, early_nz, early_rows, s));
+  } else {
+    hipLaunchKernelGGL(k_ar_insert<true>, dim3(max_items), dim3(kAr), 0, s, r);
+    hipLaunchKernelGGL(k_ar_insert<false>, dim3(max_items), dim3(kAr), 0, s, r);
+  }
   a.scan_part = 2;
   if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
-  const uint32_t nwg = (n + kRes * 4 - 1) / (kRes * 4);
-  hipLaunchKernelGGL(k_ar_place, dim3(nwg + std::min<uint32_t>(64, nwg / 8 + 1)), dim3(kRes), 0, s, r);
+  if (eb) {
+    hipLaunchKernelGGL(k_eb_cells<true>, dim3(nR + std::min<uint32_t>(64, nR / 8 + 1)), dim3(kEb), 0,
+                       s, e, r);
+  } else {
+    const uint32_t nwg = (n + kRes * 4 - 1) / (kRes * 4);
+    hipLaunchKernelGGL(k_ar_place, dim3(nwg + std::min<uint32_t>(64, nwg / 8 + 1)), dim3(kRes), 0, s,
+                       r);
+  }
   XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
@@ -2242,6 +2639,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   XF_TRY(cells_key_sorted_copy(c, s));
   XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
   guard.c = nullptr;
+  table_note_rows_out(t);  // (the cells hold row numbers)
   *out = c;
   *done = true;
   return XF_OK;

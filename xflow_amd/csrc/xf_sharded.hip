@@ -984,9 +984,8 @@ static int ensure_ocells(xf_sharded *st, xf_sbatch *b) {
                                b->o_n ? b->o_rowid.p : nullptr, b->o_rpad, (uint32_t)b->o_n,
                                b->oc_keep, b->oW, s));
   b->ocells->table_uid = uid;
-  b->ocells->epoch = ep;
+  b->ocells->epoch = b->oc_epoch = xf::table_epoch(st->tw);  // (after the build, which may move it)
   b->oc_uid = uid;
-  b->oc_epoch = ep;
   const size_t sp = (size_t)std::max<uint32_t>((uint32_t)st->world, b->nT) *
                     xf::cells_split_chunks(b->ocells) * xf::kChunk;
   XF_TRY(b->gsum.reserve(sp));

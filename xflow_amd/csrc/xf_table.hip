@@ -744,36 +744,26 @@ k_move_rows(const float *__restrict__ w, const float2 *__restrict__ nz, int dim,
   }
 }
 
-// bucket directory over the sorted keys: dir[b] = number of keys whose bucket is < b.
-// Work item r closes the buckets between key r-1's and key r's (r == n closes the tail).
+// The two directories over the sorted keys, in one pass (round 6: they were a kernel each, 40 +
+// 37 us per 6e6 keys): dir[b] = number of keys whose bucket is < b — work item r closes the
+// buckets between key r-1's and key r's (r == n closes the tail) — and the coarse directory
+// likewise, cdir[b] = first rank whose coarse bucket is >= b.
 __global__ void __launch_bounds__(kBlock)
-k_build_dir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
-            uint32_t *__restrict__ dir) {
+k_build_dirs(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
+             uint32_t *__restrict__ dir, uint32_t *__restrict__ cdir) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  auto coarse = [&](uint64_t key) -> uint64_t {
+    const uint64_t h = __umul64hi(key - T.lo, T.cmult);
+    return h < T.ncdir ? h : T.ncdir - 1;
+  };
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
-    const uint64_t first = r == 0 ? 0 : xf::bucket_of(T, skeys[r - 1]) + 1;
-    const uint64_t last = r == n ? T.ndir : xf::bucket_of(T, skeys[r]);
+    const uint64_t kp = r ? skeys[r - 1] : 0ull, kr = r < n ? skeys[r] : 0ull;
+    const uint64_t first = r == 0 ? 0 : xf::bucket_of(T, kp) + 1;
+    const uint64_t last = r == n ? T.ndir : xf::bucket_of(T, kr);
     for (uint64_t b = first; b <= last; ++b) dir[b] = (uint32_t)r;
-  }
-}
-
-// the coarse directory: cdir[b] = first rank whose coarse bucket is >= b (a lower bound per
-// bucket: 6e5 searches of 24 steps)
-__global__ void __launch_bounds__(kBlock)
-k_build_cdir(xf::TableDev T, const uint64_t *__restrict__ skeys, size_t n,
-             uint32_t *__restrict__ cdir) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b <= T.ncdir; b += stride) {
-    size_t lo = 0, hi = n;  // first r with bucket(skeys[r]) >= b
-    while (lo < hi) {
-      const size_t mid = lo + (hi - lo) / 2;
-      uint64_t bk = __umul64hi(skeys[mid] - T.lo, T.cmult);
-      if (bk >= T.ncdir) bk = T.ncdir - 1;
-      if (bk < b) lo = mid + 1;
-      else
-        hi = mid;
-    }
-    cdir[b] = (uint32_t)lo;
+    const uint64_t cfirst = r == 0 ? 0 : coarse(kp) + 1;
+    const uint64_t clast = r == n ? T.ncdir : coarse(kr);
+    for (uint64_t b = cfirst; b <= clast; ++b) cdir[b] = (uint32_t)r;  // first rank with bucket >= b
   }
 }
 
@@ -1048,6 +1038,76 @@ k_df_merge(const uint64_t *__restrict__ A, uint64_t nA, const uint64_t *__restri
   }
 }
 
+// table_take_early / table_put_early: the few keys the host API put into the arrival index,
+// taken out (state rows into a buffer, the rows zero again, the positions empty) and put back
+// where the resolve finds or puts them
+__global__ void __launch_bounds__(kBlock)
+k_early_find(xf::TableDev T, const uint64_t *__restrict__ keys, size_t n,
+             unsigned long long *__restrict__ pos, float *__restrict__ tw,
+             float2 *__restrict__ tnz) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t key = keys[j];
+  uint64_t p = xf::home_of(T, key);
+  bool found = false;
+  for (uint64_t probes = 0; probes < T.cap; ++probes) {
+    const uint64_t c = T.keys[p];
+    if (c == key) {
+      found = true;
+      break;
+    }
+    if (c == xf::kEmptyKey) break;
+    if (++p >= T.cap) p -= T.cap;
+  }
+  if (!found) {
+    atomicOr(&T.stat->err, xf::kErrDupKey);
+    pos[j] = ~0ull;
+    return;
+  }
+  pos[j] = p;
+  const size_t row = T.rows[p];
+  for (int d = 0; d < T.dim; ++d) {
+    tw[j * T.dim + d] = T.w[row * T.dim + d];
+    if (T.nz) tnz[j * T.dim + d] = T.nz[row * T.dim + d];
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+k_early_clear(xf::TableDev T, const unsigned long long *__restrict__ pos, size_t n) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || pos[j] == ~0ull) return;
+  const size_t row = T.rows[pos[j]];
+  for (int d = 0; d < T.dim; ++d) {
+    T.w[row * T.dim + d] = 0.0f;
+    if (T.nz) T.nz[row * T.dim + d] = make_float2(0.0f, 0.0f);
+  }
+  T.keys[pos[j]] = xf::kEmptyKey;
+  T.rows[pos[j]] = xf::kNoRow;
+}
+__global__ void __launch_bounds__(kBlock)
+k_early_put(xf::TableDev T, const uint32_t *__restrict__ rows, size_t n,
+            const float *__restrict__ tw, const float2 *__restrict__ tnz) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t row = rows[j];
+  for (int d = 0; d < T.dim; ++d) {
+    T.w[row * T.dim + d] = tw[j * T.dim + d];
+    if (T.nz) T.nz[row * T.dim + d] = tnz[j * T.dim + d];
+  }
+}
+
+// table_settle_first: the initial weights of the first d rows (row r belongs to keys[r]) for the
+// init kinds that are not "zero" (zeroed memory), and the table's key count
+__global__ void __launch_bounds__(kBlock)
+k_first_rows(xf::TableDev T, const uint64_t *__restrict__ keys, size_t d) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, n = d * (size_t)T.dim;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t row = i / (size_t)T.dim;
+    const uint32_t j = (uint32_t)(i - row * (size_t)T.dim);
+    T.w[i] = T.init_kind == XF_INIT_CONST ? T.init_const : xf::hashnorm(T.seed, keys[row], j);
+  }
+}
+__global__ void k_set_count(xf::TableStat *st, unsigned long long d) { st->count = d; }
+
 __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -1096,7 +1156,68 @@ struct xf_table {
   float *w_alt = nullptr;
   float2 *nz_alt = nullptr;
   size_t alt_elems = 0;
+  // The keys the HOST API (xf_table_pull / xf_table_push) has put into a table without a settled
+  // tier, while they are few (lr_worker.cc:180-182 pushes key 0 before the first minibatch).
+  // When they are ALL the table holds — the key count says so — and no row number has left the
+  // table (rows_out), the build of the first minibatch may still settle the table at once:
+  // table_early_keys, xf_keybuild.hip "an empty table".
+  std::vector<uint64_t> early;
+  bool early_over = false, rows_out = false;
+  // the settled tier's keys and its two directories are ONE allocation (T.bkeys / bdir / cdir
+  // point into it); tier_next: the one a build has asked for and not yet handed back
+  void *tier = nullptr, *tier_next = nullptr;
 };
+// the tier of n keys: where its parts lie in one allocation
+struct TierLayout {
+  uint64_t ndir, ncdir;
+  size_t o_dir, o_cdir, bytes;
+};
+static TierLayout tier_layout(size_t n) {
+  TierLayout L;
+  L.ndir = n + 1;
+  L.ncdir = std::max<uint64_t>(1, n / xf::kCoarse);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  L.o_dir = al((n + xf::kBaseWin) * sizeof(uint64_t));
+  L.o_cdir = L.o_dir + al((L.ndir + 1) * sizeof(uint32_t));
+  L.bytes = L.o_cdir + al((L.ncdir + 1) * sizeof(uint32_t));
+  return L;
+}
+static int tier_alloc(xf_table *t, size_t n, uint64_t **keys) {
+  if (t->tier_next) (void)hipFree(t->tier_next);
+  t->tier_next = nullptr;
+  XF_HIP(hipMalloc(&t->tier_next, tier_layout(n).bytes));
+  *keys = (uint64_t *)t->tier_next;
+  return XF_OK;
+}
+// tier_next (n keys in place) becomes the table's tier: directories built on `s`, N's tier fields
+// set; the old tier is the caller's to free (after the device has finished with it)
+static void tier_install(xf_table *t, xf::TableDev &N, size_t n, hipStream_t s) {
+  const TierLayout L = tier_layout(n);
+  char *base = (char *)t->tier_next;
+  uint64_t *keys = (uint64_t *)base;
+  N.nbase = n;
+  N.ndir = L.ndir;
+  N.dmult = (uint64_t)((((unsigned __int128)N.ndir) << 64) / N.span);
+  N.ncdir = L.ncdir;
+  N.cmult = (uint64_t)((((unsigned __int128)N.ncdir) << 64) / N.span);
+  N.bkeys = keys;
+  N.bdir = (uint32_t *)(base + L.o_dir);
+  N.cdir = (uint32_t *)(base + L.o_cdir);
+  hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, s, keys + n, (size_t)xf::kBaseWin,
+                     xf::kEmptyKey);
+  hipLaunchKernelGGL(k_build_dirs, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, N, keys, n,
+                     (uint32_t *)(base + L.o_dir), (uint32_t *)(base + L.o_cdir));
+}
+constexpr size_t kEarlyMax = 4096;
+static void note_early(xf_table *t, const uint64_t *keys, size_t n) {
+  if (t->T.nbase != 0 || t->early_over) return;
+  if (t->early.size() + n > kEarlyMax) {
+    t->early_over = true;
+    t->early.clear();
+    return;
+  }
+  t->early.insert(t->early.end(), keys, keys + n);
+}
 
 // Is (float)((double)x * (1.0 / (double)d)) the float x / d for EVERY finite x?  All 2^32 bit
 // patterns on the GPU (~10 ms), once per divisor and process.  The step's two divisions by alpha
@@ -1290,8 +1411,7 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
-  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, (void *)t->T.bkeys,
-                (void *)t->T.bdir, (void *)t->T.cdir, t->s_keys, t->s_rows, t->s_vals, t->miss,
+  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, t->tier, t->tier_next, t->s_keys, t->s_rows, t->s_vals, t->miss,
                 t->miss_n, t->aux, t->rec, t->w_alt, t->nz_alt};
   for (void *p : ps)
     if (p) hipFree(p);
@@ -1324,6 +1444,12 @@ extern "C" int xf_table_set_hyper(xf_table *t, float alpha, float beta, float l1
 
 static int read_stat(xf_table *t, xf::TableStat *st) {
   XF_HIP(hipMemcpy(st, t->T.stat, sizeof(*st), hipMemcpyDeviceToHost));
+  return XF_OK;
+}
+
+extern "C" int xf_table_settled(xf_table *t, uint64_t *nkeys) {
+  XF_REQUIRE(t && nkeys, "xf_table_settled: null argument");
+  *nkeys = t->T.nbase;
   return XF_OK;
 }
 
@@ -1421,12 +1547,11 @@ extern "C" int xf_table_defrag(xf_table *t) {
   uint32_t *r_all = nullptr, *r_sorted = nullptr, *bcnt = nullptr;
   uint8_t *cstart = nullptr;
   unsigned int *dflag = nullptr;
-  DevBuf<uint64_t> k_sorted;
-  DevBuf<uint32_t> dir, cdir;
+  uint64_t *k_sorted = nullptr;  // (the new tier's allocation: keys, then the directories)
   XF_TRY(sc.get(&k_all, n));
   XF_TRY(sc.get(&r_all, n));
   XF_TRY(sc.get(&r_sorted, n));
-  XF_HIP(k_sorted.alloc(n + xf::kBaseWin));
+  XF_TRY(tier_alloc(t, n, &k_sorted));
   // the index's keys in key order without a sort (kernels: "defrag without a library sort"):
   // into k_all / r_all, then merged with the settled tier's into k_sorted / r_sorted
   bool sorted_ok = false;
@@ -1448,7 +1573,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
       if (listed32 != n_idx)
         return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %u keys, %zu expected",
                              listed32, n_idx);
-      uint64_t *bk = T.nbase ? k_all : k_sorted.p;  // (no settled tier: nothing to merge with)
+      uint64_t *bk = T.nbase ? k_all : k_sorted;  // (no settled tier: nothing to merge with)
       uint32_t *br = T.nbase ? r_all : r_sorted;
       hipLaunchKernelGGL(k_df_list, dim3(nblk), dim3(kDfThreads), 0, 0, T, bcnt, bk, br, cstart);
       hipLaunchKernelGGL(k_df_fix, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, bk, br,
@@ -1459,7 +1584,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
         if (T.nbase)
           hipLaunchKernelGGL(k_df_merge, dim3((unsigned)((n + kMgTile - 1) / kMgTile)),
                              dim3(kMgThreads), 0, 0, T.bkeys, (uint64_t)T.nbase, k_all, r_all,
-                             (uint64_t)n_idx, k_sorted.p, r_sorted);
+                             (uint64_t)n_idx, k_sorted, r_sorted);
         XF_HIP(hipGetLastError());
         sorted_ok = true;
       }
@@ -1480,15 +1605,13 @@ extern "C" int xf_table_defrag(xf_table *t) {
       return xf::set_error(XF_EINVAL, "xf_table_defrag: index holds %llu keys, %zu expected",
                            listed, n_idx);
     size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all, k_sorted.p, r_all, r_sorted, n, 0, 64,
+    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
                                      (hipStream_t)0));
     char *tmp = nullptr;
     XF_TRY(sc.get(&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs((void *)tmp, tb, k_all, k_sorted.p, r_all, r_sorted, n, 0, 64,
+    XF_HIP(rocprim::radix_sort_pairs((void *)tmp, tb, k_all, k_sorted, r_all, r_sorted, n, 0, 64,
                                      (hipStream_t)0));
   }
-  hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(kBlock), 0, 0, k_sorted.p + n,
-                     (size_t)xf::kBaseWin, xf::kEmptyKey);
   // state in rank order, into the second buffer; the spare key's row, if any, follows the tier
   if (!t->w_alt || t->alt_elems != elems) {
     if (t->w_alt) XF_HIP(hipFree(t->w_alt));
@@ -1511,19 +1634,9 @@ extern "C" int xf_table_defrag(xf_table *t) {
   if (spare)
     hipLaunchKernelGGL(k_move_rows, dim3(1), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
                        T.rows + T.cap, (size_t)1, n, w2, nz2);
-  // the directory: one key per bucket on average
+  // the directories: one key per bucket on average, and the coarse one
   xf::TableDev N = T;
-  N.nbase = n;
-  N.ndir = n + 1;
-  N.dmult = (uint64_t)((((unsigned __int128)N.ndir) << 64) / T.span);
-  XF_HIP(dir.alloc(N.ndir + 1));
-  hipLaunchKernelGGL(k_build_dir, dim3(grid_for(n + 1)), dim3(kBlock), 0, 0, N, k_sorted.p, n,
-                     dir.p);
-  N.ncdir = std::max<uint64_t>(1, n / xf::kCoarse);
-  N.cmult = (uint64_t)((((unsigned __int128)N.ncdir) << 64) / T.span);
-  XF_HIP(cdir.alloc(N.ncdir + 1));
-  hipLaunchKernelGGL(k_build_cdir, dim3(grid_for(N.ncdir + 1)), dim3(kBlock), 0, 0, N,
-                     k_sorted.p, n, cdir.p);
+  tier_install(t, N, n, 0);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
   // everything is built: from here on nothing fails half-way.  Empty the index (the spare
@@ -1537,16 +1650,13 @@ extern "C" int xf_table_defrag(xf_table *t) {
                        (uint32_t)n);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  if (T.bkeys) (void)hipFree((void *)T.bkeys);
-  if (T.bdir) (void)hipFree((void *)T.bdir);
-  if (T.cdir) (void)hipFree((void *)T.cdir);
+  if (t->tier) (void)hipFree(t->tier);
+  t->tier = t->tier_next;
+  t->tier_next = nullptr;
   t->w_alt = T.w;  // (the old state: rows below the old count hold data, all below n)
   t->nz_alt = T.nz;
   N.w = w2;
   N.nz = nz2;
-  N.bkeys = k_sorted.take();
-  N.bdir = dir.take();
-  N.cdir = cdir.take();
   T = N;
   ++t->epoch;  // every row number handed out before this call is stale
   return XF_OK;
@@ -1600,6 +1710,7 @@ extern "C" int xf_table_resolve_dev(xf_table *t, const uint64_t *d_keys, size_t 
                                     uint32_t *d_rows, void *stream) {
   XF_REQUIRE(t && (n == 0 || (d_keys && d_rows)), "xf_table_resolve_dev: null argument");
   if (n == 0) return XF_OK;
+  t->rows_out = true;
   return launch_resolve<false>(t, d_keys, n, d_rows, nullptr, S(stream));
 }
 
@@ -1613,6 +1724,7 @@ extern "C" int xf_table_pull_dev(xf_table *t, const uint64_t *d_keys, size_t n,
   XF_REQUIRE(t->T.init_kind == XF_INIT_ZERO,
              "xf_table_pull_dev: only zero-initialised tables (use resolve + gather)");
   if (n == 0) return XF_OK;
+  t->rows_out = true;
   return launch_resolve<true>(t, d_keys, n, d_rows, d_vals, S(stream));
 }
 
@@ -1658,6 +1770,7 @@ extern "C" int xf_table_pull_ordered_dev(xf_table *t, const uint64_t *d_keys_sor
   XF_REQUIRE(!d_vals || (t->T.dim == 1 && t->T.init_kind == XF_INIT_ZERO),
              "xf_table_pull_ordered_dev: values only for dim-1 zero-initialised tables");
   if (n == 0) return XF_OK;
+  t->rows_out = true;
   if (d_vals) return launch_resolve<true>(t, d_keys_sorted, n, d_rows, d_vals, S(stream), d_order);
   return launch_resolve<false>(t, d_keys_sorted, n, d_rows, nullptr, S(stream), d_order);
 }
@@ -1687,10 +1800,12 @@ extern "C" int xf_table_pull(xf_table *t, const uint64_t *keys, size_t n, float 
   if (n == 0) return XF_OK;
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
+  XF_TRY(launch_resolve<false>(t, t->s_keys, n, t->s_rows, nullptr, nullptr));  // (rows stay inside)
   XF_TRY(xf_table_gather_dev(t, t->s_rows, n, t->s_vals, nullptr));
   XF_HIP(hipMemcpy(vals, t->s_vals, n * t->T.dim * sizeof(float), hipMemcpyDeviceToHost));
-  return xf_table_check(t, nullptr);
+  XF_TRY(xf_table_check(t, nullptr));
+  note_early(t, keys, n);
+  return XF_OK;
 }
 
 extern "C" int xf_table_push(xf_table *t, const uint64_t *keys, size_t n, const float *grads) {
@@ -1699,9 +1814,11 @@ extern "C" int xf_table_push(xf_table *t, const uint64_t *keys, size_t n, const 
   XF_TRY(ensure_scratch(t, n));
   XF_HIP(hipMemcpy(t->s_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
   XF_HIP(hipMemcpy(t->s_vals, grads, n * t->T.dim * sizeof(float), hipMemcpyHostToDevice));
-  XF_TRY(xf_table_resolve_dev(t, t->s_keys, n, t->s_rows, nullptr));
+  XF_TRY(launch_resolve<false>(t, t->s_keys, n, t->s_rows, nullptr, nullptr));  // (rows stay inside)
   XF_TRY(xf_table_update_dev(t, t->s_rows, n, t->s_vals, nullptr));
-  return xf_table_check(t, nullptr);
+  XF_TRY(xf_table_check(t, nullptr));
+  note_early(t, keys, n);
+  return XF_OK;
 }
 
 // ---- state dump / load ----------------------------------------------------------------
@@ -1881,6 +1998,7 @@ int table_resolve_any(xf_table *t, const uint64_t *d_keys, size_t n, uint32_t *d
   XF_REQUIRE(t && (n == 0 || (d_keys && d_rows)), "table_resolve_any: null argument");
   XF_REQUIRE(n < 0xFFFFFFFFull, "table_resolve_any: %zu keys in one call", n);
   if (n == 0) return XF_OK;
+  t->rows_out = true;
   size_t maybe_new = n;
   const bool tiered = t->T.nbase != 0;
   if (tiered) {
@@ -1968,6 +2086,72 @@ int table_count(xf_table *t, hipStream_t s, uint64_t *count) {
   xf::TableStat st;
   XF_TRY(read_stat(t, &st));
   *count = st.count;
+  return XF_OK;
+}
+
+// A table that holds NOTHING takes a list of distinct keys, ascending, as its settled tier: key r
+// owns state row r, fresh (what the first Pull of every key would have made of it, ftrl.h:56).
+// What xf_table_defrag builds from the arrival index, without the index and without a state move
+// — for the first minibatch of a run (xf_keybuild.hip: "an empty table").  The keys go where
+// table_first_tier says (the tier's allocation: keys and directories in one); no row number
+// existed before, so none goes stale: the epoch stays.  In stream order, nothing is waited for.
+int table_first_tier(xf_table *t, size_t d, uint64_t **keys) { return tier_alloc(t, d, keys); }
+int table_settle_first(xf_table *t, size_t d, hipStream_t s) {
+  xf::TableDev &T = t->T;
+  XF_REQUIRE(T.nbase == 0 && t->tier_next && d > 0 && d <= T.max_rows && d < 0xFFFFFFF0ull,
+             "table_settle_first: %zu keys into a table of %llu rows, %llu settled", d,
+             (unsigned long long)T.max_rows, (unsigned long long)T.nbase);
+  xf::TableDev N = T;
+  tier_install(t, N, d, s);
+  if (T.init_kind != XF_INIT_ZERO)
+    hipLaunchKernelGGL(k_first_rows, dim3(grid_for(d * (size_t)T.dim)), dim3(kBlock), 0, s, N,
+                       N.bkeys, d);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, T.stat, (unsigned long long)d);
+  XF_HIP(hipGetLastError());
+  if (t->tier) (void)hipFree(t->tier);  // (a table without a settled tier has none)
+  t->tier = t->tier_next;
+  t->tier_next = nullptr;
+  T = N;
+  ++t->writes;  // (rows that records derived from the state know nothing of)
+  t->rec_all_ok = false;
+  return XF_OK;
+}
+
+// The keys of a table without a settled tier when the host API put every one of them there and
+// nobody outside holds a row number of it: sorted, distinct.  `count`: the table's key count
+// (the caller has just read it); false: not known, or not so.
+bool table_early_keys(xf_table *t, uint64_t count, std::vector<uint64_t> *out) {
+  out->clear();
+  if (t->T.nbase != 0 || t->early_over || t->rows_out || t->early.empty()) return false;
+  std::vector<uint64_t> k = t->early;
+  std::sort(k.begin(), k.end());
+  k.erase(std::unique(k.begin(), k.end()), k.end());
+  if (k.size() != count || k.back() == xf::kEmptyKey) return false;
+  *out = std::move(k);
+  return true;
+}
+void table_note_rows_out(xf_table *t) { t->rows_out = true; }
+// ... taken out of the arrival index: their state into tw / tnz ([n * dim], key order of d_keys),
+// their rows zeroed, their positions emptied, the key count 0.  d_pos: n words of scratch.
+int table_take_early(xf_table *t, const uint64_t *d_keys, size_t n, float *tw, float2 *tnz,
+                     unsigned long long *d_pos, hipStream_t s) {
+  const xf::TableDev &T = t->T;
+  hipLaunchKernelGGL(k_early_find, dim3(grid_for(n)), dim3(kBlock), 0, s, T, d_keys, n, d_pos, tw,
+                     tnz);
+  hipLaunchKernelGGL(k_early_clear, dim3(grid_for(n)), dim3(kBlock), 0, s, T, d_pos, n);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, T.stat, 0ull);
+  XF_HIP(hipGetLastError());
+  return XF_OK;
+}
+// ... and put back after table_settle_first: found in the tier or inserted behind it, the state
+// written to the row the key has now.  Their rows have changed: the epoch moves.
+int table_put_early(xf_table *t, const uint64_t *d_keys, size_t n, const float *tw,
+                    const float2 *tnz, uint32_t *d_rows, hipStream_t s) {
+  XF_TRY(launch_resolve<false>(t, d_keys, n, d_rows, nullptr, s));
+  hipLaunchKernelGGL(k_early_put, dim3(grid_for(n)), dim3(kBlock), 0, s, t->T, d_rows, n, tw, tnz);
+  XF_HIP(hipGetLastError());
+  ++t->epoch;
+  t->early.clear();
   return XF_OK;
 }
 

@@ -150,21 +150,22 @@ int Worker::start_ingest() {
 // the blocks still to come finds settled keys where they sit in LDS, arrival keys by a probe
 // per nonzero, and a defrag is a sort of the table's keys)
 int Worker::defrag_if_grown(int percent) {
-  uint64_t n = 0;
+  uint64_t n = 0, settled = 0;
   XF_TRY(xf_table_size(table_w_, &n));
-  const uint64_t arrived = n - std::min(n, keys_at_defrag_), fresh = n - std::min(n, keys_seen_);
+  // (the settled tier as the table reports it: the first minibatch's build may have settled the
+  // table already)
+  XF_TRY(xf_table_settled(table_w_, &settled));
+  settled = std::min(n, settled);
+  const uint64_t arrived = n - settled, fresh = n - std::min(n, keys_seen_);
   keys_seen_ = n;
   // grown by `percent` since the table was last settled — or (inside an epoch) the inflow has
   // stopped: the last minibatch brought less than 0.1 % new keys while more than 0.5 % of the
   // table's keys still sit in the arrival index, where every minibatch that meets them pays the
   // first-touch path for them (measured, DESIGN 3: a defrag of 1e7 keys 1.1 ms, the path ~0.15 ms
   // per minibatch at 14 % unsettled keys)
-  const bool grown = n > keys_at_defrag_ + keys_at_defrag_ / 100 * percent + (percent > 5 ? 4096 : 0);
+  const bool grown = n > settled + settled / 100 * percent + (percent > 5 ? 4096 : 0);
   const bool settled_down = percent > 5 && arrived * 200 > n && fresh * 1000 < n && arrived > 4096;
-  if (grown || settled_down) {
-    XF_TRY(xf_sharded_defrag(sharded_));
-    keys_at_defrag_ = n;
-  }
+  if (grown || settled_down) XF_TRY(xf_sharded_defrag(sharded_));
   return XF_OK;
 }
 

@@ -67,8 +67,7 @@ class Worker {
   int create_tables();
   int defrag_if_grown(int percent);
   int any_rank(bool mine, bool *any);
-  uint64_t keys_at_defrag_ = 0;
-  uint64_t keys_seen_ = 0;  // ... and at the last look (defrag_if_grown: the inflow per minibatch)
+  uint64_t keys_seen_ = 0;  // the table's keys at the last look (defrag_if_grown: the inflow per minibatch)
   bool rank_given_ = false;
 
   int model_;
