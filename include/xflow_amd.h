@@ -224,6 +224,12 @@ int xf_tune(const char *name, double value);
  * (a minibatch of NNZ nonzeros needs about 40 B x NNZ + 64 MiB when it meets new keys): a run's
  * first minibatches otherwise grow it build by build.  No-op when it is that large already. */
 int xf_scratch_reserve(size_t bytes);
+/* Set a device allocation of `bytes` aside in the pool of freed minibatches ("batch_pool_blobs")
+ * for the first compile that asks for that much or less (and at least an eighth of it): a run's
+ * first minibatch otherwise waits for the driver to map its cells (4-8 B x NNZ; 0.25 ms for
+ * 40 MB, measured in its first xf_lr_update_dev).  No-op when such an allocation is waiting
+ * already, or without pooling. */
+int xf_batch_pool_reserve(size_t bytes);
 /* copy to the current device (async on stream); idempotent */
 int xf_batch_upload(xf_batch *b, void *stream);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
                                  C.POINTER(u64p), C.POINTER(u64p), C.POINTER(i32p),
                                  C.POINTER(i32p)]),
     "xf_scratch_reserve": (C.c_int, [C.c_size_t]),
+    "xf_batch_pool_reserve": (C.c_int, [C.c_size_t]),
     "xf_batch_compile": (C.c_int, [C.POINTER(vp), u64p, u64p, i32p, C.c_size_t, C.c_size_t]),
     "xf_batch_free": (C.c_int, [vp]),
     "xf_batch_compile_dev": (C.c_int, [C.POINTER(vp), vp, vp, vp, C.c_uint32, C.c_uint32, vp]),

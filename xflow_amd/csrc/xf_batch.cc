@@ -158,6 +158,7 @@ struct Blob {
   void *p;
   size_t bytes;
   int dev;
+  bool reserved;  // xf_batch_pool_reserve: serves ONE request of an eighth of its size up to its size
 };
 std::mutex g_pool_mu;
 std::vector<Blob> g_pool;
@@ -175,6 +176,12 @@ int blob_alloc(void **p, size_t bytes, size_t *got) {
       if (c.dev != dev || c.bytes < bytes || c.bytes > bytes + bytes / 4 + (1u << 20)) continue;
       if (best == g_pool.size() || c.bytes < g_pool[best].bytes) best = i;
     }
+    if (best == g_pool.size())  // a blob set aside for a run's first minibatch
+      for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].reserved && g_pool[i].dev == dev && g_pool[i].bytes >= bytes &&
+            bytes >= g_pool[i].bytes / 8 &&  // (not for a minibatch's small arrays)
+            (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes))
+          best = i;
     if (best != g_pool.size()) {
       *p = g_pool[best].p;
       *got = g_pool[best].bytes;
@@ -198,7 +205,7 @@ void blob_free(void *p, size_t bytes) {
         evict = g_pool.front().p;
         g_pool.erase(g_pool.begin());
       }
-      g_pool.push_back({p, bytes, dev});
+      g_pool.push_back({p, bytes, dev, false});
       p = nullptr;
     }
   }
@@ -233,6 +240,25 @@ static std::atomic<bool> g_device_poisoned{false};
 bool device_poisoned() { return g_device_poisoned.load(std::memory_order_relaxed); }
 void scratch_poison() { g_device_poisoned.store(true); }
 }  // namespace xf
+
+// a device allocation set aside in the pool for a run's first cells (include/xflow_amd.h): the
+// driver maps tens of MB in ~0.25 ms when asked under the first build (profiles/r06/)
+extern "C" int xf_batch_pool_reserve(size_t bytes) {
+  XF_REQUIRE(bytes > 0, "xf_batch_pool_reserve: no bytes");
+  int dev = 0;
+  XF_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(xf::g_pool_mu);
+    if (xf::g_pool_limit <= 0) return XF_OK;  // (no pooling: every blob goes back to the driver)
+    for (const xf::Blob &b : xf::g_pool)
+      if (b.reserved && b.dev == dev && b.bytes >= bytes) return XF_OK;
+  }
+  void *p = nullptr;
+  XF_HIP(hipMalloc(&p, bytes));
+  std::lock_guard<std::mutex> lk(xf::g_pool_mu);
+  xf::g_pool.push_back({p, bytes, dev, true});
+  return XF_OK;
+}
 
 // the calling thread's builder arena (xf_scratch.h) sized ahead of its first build: a run's first
 // minibatches otherwise grow it build by build — a hipFree and a hipMalloc of ~0.5 GB, ~0.8 ms,

@@ -74,6 +74,7 @@ int table_count(xf_table *t, hipStream_t s, uint64_t *count);
 int table_first_tier(xf_table *t, size_t d, uint64_t **keys);
 int table_settle_first(xf_table *t, size_t d, hipStream_t s);
 bool table_early_keys(xf_table *t, uint64_t count, std::vector<uint64_t> *out);
+bool table_maybe_first(const xf_table *t);
 void table_note_rows_out(xf_table *t);
 int table_take_early(xf_table *t, const uint64_t *d_keys, size_t n, float *tw, float2 *tnz,
                      unsigned long long *d_pos, hipStream_t s);
@@ -1853,7 +1854,7 @@ constexpr uint32_t kEbSlots = 8192;        // positions of a range's key set in 
 constexpr uint32_t kEbPad = 1024;          // ... and behind them, for the last homes' clusters
 constexpr uint32_t kEbAll = kEbSlots + kEbPad;
 constexpr uint32_t kEbPerT = kEbAll / kEbR;      // positions per thread: 9, groups of 3
-constexpr uint32_t kEbCluster = 512;       // keys of one cluster its thread sorts
+constexpr uint32_t kEbCluster = 512;       // keys of one cluster a walk goes back over
 constexpr uint32_t kEbCells = 2048;        // cells a range's records may fall into (LDS counters)
 static_assert(kEbPerT * kEbR == kEbAll && kEbPerT % 3 == 0, "k_eb_rank: a thread's groups");
 struct EbArgs {
@@ -1877,8 +1878,7 @@ constexpr size_t kEbLds = (size_t)kEbAll * 8 + (size_t)(kEbAll / 3) * 2;
 // key sits at or behind its home = its share of the range's width, inside the home's cluster; no
 // wrap-around: kEbPad positions behind the last home), so the records of a heavy key cost a read
 // each and a range may hold any number of them.  The clusters (one or two keys at this load,
-// dozens now and then) are then sorted where they lie, by the thread that holds their first
-// position — every key still sits at or behind its home (the positions from the cluster's start
+// dozens now and then) are then sorted where they lie — every key still sits at or behind its home (the positions from the cluster's start
 // to a key's home hold keys with smaller homes: smaller keys) — and a key's rank is the number of
 // occupied positions before it: a count per group of three positions.  Every record finds its
 // key again and takes the rank.
@@ -1887,7 +1887,7 @@ k_eb_rank(EbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char eb_lds[];
   unsigned long long *tab = (unsigned long long *)eb_lds;  // [kEbAll]
   uint16_t *gp = (uint16_t *)(tab + kEbAll);               // [kEbAll / 3] keys before the group
-  __shared__ uint32_t wsum[kEbR / 64];
+  __shared__ uint32_t wsum[kEbR / 64], s_nlong;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
   if (m == 0) {  // workgroup-uniform
@@ -1904,9 +1904,12 @@ k_eb_rank(EbArgs a) {
   for (uint32_t i = tid; i < kEbAll; i += kEbR) tab[i] = xf::kEmptyKey;
   __syncthreads();
   bool bad = false;
-  constexpr int E = 4;  // records in flight per thread
+  // records in flight per thread; a range of up to kEbR * E records (the usual one: ranges are
+  // cut for 4096) keeps its keys in registers for the second pass
+  constexpr int E = 5;
+  const bool once = m <= (uint32_t)kEbR * E;  // workgroup-uniform
+  uint64_t key[E];
   for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
-    uint64_t key[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t i = i0 + q * kEbR + tid;
@@ -1934,26 +1937,86 @@ k_eb_rank(EbArgs a) {
     }
   }
   __syncthreads();
-  // the clusters in key order
+  // The clusters in key order.  A thread looks at its positions for clusters' first positions:
+  // a cluster of up to four keys it sorts in registers (five reads in flight, a few
+  // compare-and-swaps, the writes); a longer one goes on a list (in gp[], not yet in use) that
+  // the wavefronts take in turns: a lane per key, the key's place = the smaller keys of the
+  // cluster, counted from registers.  (One thread per cluster with an insertion sort in LDS was
+  // the kernel's time: 20 of a workgroup's 31 us were its longest cluster — tools/r6/call22.sh.)
+  if (tid == 0) s_nlong = 0;
+  __syncthreads();
   const uint32_t p0 = tid * kEbPerT;
-  for (uint32_t k = 0; k < kEbPerT; ++k) {
-    const uint32_t p = p0 + k;
-    if (tab[p] == xf::kEmptyKey || (p > 0 && tab[p - 1] != xf::kEmptyKey)) continue;
-    uint32_t e = p + 1;
-    while (e < kEbAll && tab[e] != xf::kEmptyKey && e - p <= kEbCluster) ++e;
-    if (e - p > kEbCluster) {  // keys that are no hashes
-      bad = true;
+  {
+    unsigned long long c[kEbPerT + 1];
+    c[0] = p0 ? tab[p0 - 1] : xf::kEmptyKey;
+#pragma unroll
+    for (uint32_t k = 0; k < kEbPerT; ++k) c[k + 1] = tab[p0 + k];
+#pragma unroll
+    for (uint32_t k = 0; k < kEbPerT; ++k) {
+      if (c[k + 1] == xf::kEmptyKey || c[k] != xf::kEmptyKey) continue;
+      const uint32_t p = p0 + k;  // a cluster begins here
+      auto at = [&](uint32_t i) { return i < kEbAll ? tab[i] : (unsigned long long)xf::kEmptyKey; };
+      unsigned long long x0 = c[k + 1], x1 = at(p + 1), x2 = at(p + 2), x3 = at(p + 3);
+      const unsigned long long x4 = at(p + 4);
+      if (x1 == xf::kEmptyKey) continue;
+      const uint32_t len = x2 == xf::kEmptyKey ? 2u : x3 == xf::kEmptyKey ? 3u : x4 == xf::kEmptyKey ? 4u : 5u;
+      if (len == 5) {
+        gp[atomicAdd(&s_nlong, 1u)] = (uint16_t)p;
+        continue;
+      }
+      auto cs2 = [](unsigned long long &u, unsigned long long &v) {
+        if (u > v) {
+          const unsigned long long t = u;
+          u = v;
+          v = t;
+        }
+      };
+      if (len < 4) x3 = xf::kEmptyKey;  // (the largest value: stays last)
+      if (len < 3) x2 = xf::kEmptyKey;
+      cs2(x0, x1);
+      cs2(x2, x3);
+      cs2(x0, x2);
+      cs2(x1, x3);
+      cs2(x1, x2);
+      tab[p] = x0;
+      tab[p + 1] = x1;
+      if (len > 2) tab[p + 2] = x2;
+      if (len > 3) tab[p + 3] = x3;
+    }
+  }
+  __syncthreads();
+  for (uint32_t idx = wave; idx < s_nlong; idx += kEbR / 64) {  // wave-uniform
+    const uint32_t cs = gp[idx];
+    const uint32_t pl = cs + lane;
+    const unsigned long long k = pl < kEbAll ? tab[pl] : xf::kEmptyKey;
+    const unsigned long long occm = __ballot(k != xf::kEmptyKey);
+    if (~occm == 0ull) {  // 64 keys and more in one cluster: one lane, in place
+      if (lane == 0) {
+        uint32_t e = cs + 64;
+        while (e < kEbAll && tab[e] != xf::kEmptyKey && e - cs <= kEbCluster) ++e;
+        if (e - cs > kEbCluster) bad = true;  // keys that are no hashes
+        else
+          for (uint32_t i = cs + 1; i < e; ++i) {
+            const unsigned long long x = tab[i];
+            uint32_t j = i;
+            while (j > cs && tab[j - 1] > x) {
+              tab[j] = tab[j - 1];
+              --j;
+            }
+            tab[j] = x;
+          }
+      }
       continue;
     }
-    for (uint32_t i = p + 1; i < e; ++i) {
-      const unsigned long long x = tab[i];
-      uint32_t j = i;
-      while (j > p && tab[j - 1] > x) {
-        tab[j] = tab[j - 1];
-        --j;
-      }
-      tab[j] = x;
+    const uint32_t len = (uint32_t)__ffsll((long long)~occm) - 1;  // the first empty position
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < len; ++j) {
+      const unsigned long long kj =
+          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, (int)j) |
+          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), (int)j) << 32);
+      rank += kj < k ? 1u : 0u;
     }
+    if (lane < len) tab[cs + rank] = k;
   }
   if (__syncthreads_or(bad ? 1 : 0)) {  // not this way: the caller takes the arrival index
     if (tid == 0) {
@@ -1995,12 +2058,13 @@ k_eb_rank(EbArgs a) {
   }
   __syncthreads();
   for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
-    uint64_t key[E];
+    if (!once) {
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const uint32_t i = i0 + q * kEbR + tid;
-      const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0u, 0u, 0u};
-      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+      for (int q = 0; q < E; ++q) {
+        const uint32_t i = i0 + q * kEbR + tid;
+        const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0u, 0u, 0u};
+        key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+      }
     }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -2507,29 +2571,33 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   float2 *early_nz = nullptr;
   uint32_t *early_rows = nullptr;
   unsigned long long *early_pos = nullptr;
+  // (launched before the table's count is known — one wait for both; a table that cannot be a
+  // first-minibatch table, the host knows without asking)
+  const bool maybe = T0.nbase == 0 && chunk0 == 0 && key_build_mode() != 3 &&
+                     (uint64_t)nwin * 6 <= kEbCells && table_maybe_first(t);
+  unsigned int *hout = (unsigned int *)&sum->miss;  // (pinned: flag, distinct keys)
+  if (maybe) {
+    e.T = T0;
+    e.rec = a.rec;
+    e.sstart = a.sstart;
+    e.bnd = bnd;
+    e.nR = nR;
+    e.n = n;
+    e.rec_row = rec_row;
+    XF_TRY(sc.get(&e.ukeys, n));
+    XF_TRY(sc.get(&e.dbase, nR + 2));
+    XF_TRY(sc.get(&e.out, 2));
+    XF_HIP(hipMemsetAsync(e.out, 0, 8, s));
+    XF_KB_LAUNCH_N(k_eb_rank, nR, kEbR, kEbLds, e);
+    hipLaunchKernelGGL(k_eb_scan, dim3(1), dim3(1024), 0, s, e);
+    XF_HIP(hipMemcpyAsync(hout, e.out, 8, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipGetLastError());
+  }
   {
     uint64_t count = 0;
     XF_TRY(table_count(t, s, &count));
-    eb = T0.nbase == 0 && chunk0 == 0 && key_build_mode() != 3 && (uint64_t)nwin * 6 <= kEbCells &&
-         (count == 0 || table_early_keys(t, count, &early));
+    eb = maybe && (count == 0 || table_early_keys(t, count, &early));
     if (eb) {
-      e.T = T0;
-      e.rec = a.rec;
-      e.sstart = a.sstart;
-      e.bnd = bnd;
-      e.nR = nR;
-      e.n = n;
-      e.rec_row = rec_row;
-      XF_TRY(sc.get(&e.ukeys, n));
-      XF_TRY(sc.get(&e.dbase, nR + 2));
-      XF_TRY(sc.get(&e.out, 2));
-      XF_HIP(hipMemsetAsync(e.out, 0, 8, s));
-      XF_KB_LAUNCH_N(k_eb_rank, nR, kEbR, kEbLds, e);
-      hipLaunchKernelGGL(k_eb_scan, dim3(1), dim3(1024), 0, s, e);
-      unsigned int *hout = (unsigned int *)&sum->miss;  // (pinned: flag, distinct keys)
-      XF_HIP(hipMemcpyAsync(hout, e.out, 8, hipMemcpyDeviceToHost, s));
-      XF_HIP(hipGetLastError());
-      XF_HIP(hipStreamSynchronize(s));
       const uint64_t distinct = hout[1];
       eb = hout[0] == 0 && distinct > 0;
       eb_keys = distinct;

@@ -2131,6 +2131,11 @@ bool table_early_keys(xf_table *t, uint64_t count, std::vector<uint64_t> *out) {
   return true;
 }
 void table_note_rows_out(xf_table *t) { t->rows_out = true; }
+// could this table's keys be none, or only what the host API put there?  (the host's knowledge:
+// the count is on the device)
+bool table_maybe_first(const xf_table *t) {
+  return t->T.nbase == 0 && !t->early_over && !t->rows_out;
+}
 // ... taken out of the arrival index: their state into tw / tnz ([n * dim], key order of d_keys),
 // their rows zeroed, their positions emptied, the key count 0.  d_pos: n words of scratch.
 int table_take_early(xf_table *t, const uint64_t *d_keys, size_t n, float *tw, float2 *tnz,

@@ -213,6 +213,9 @@ int Worker::batch_training() {
   // the builders' scratch arena for a block's worth of nonzeros (a token is at least four bytes of
   // text), sized before the clock starts instead of growing over the first blocks
   XF_TRY(xf_scratch_reserve(((size_t)block_size << 20) / 4 * 40 + ((size_t)64 << 20)));
+  // ... and the first block's cells (4 bytes per nonzero, 8 when the minibatches are kept for
+  // replay, + the cell offsets): set aside now, not mapped by the driver under the first build
+  XF_TRY(xf_batch_pool_reserve(((size_t)block_size << 20) / 4 * 8 + ((size_t)16 << 20)));
   const double t0 = now_s();
   rows_trained_ = 0;
   blocks_gpu = blocks_host = 0;
