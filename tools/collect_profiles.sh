@@ -11,7 +11,7 @@ for f in $SRC/pmc_rd_*_counter_collection.csv $SRC/pmc_wr_*_counter_collection.c
   [ -f "$f" ] || continue
   python3 - "$f" "$DST/$(basename $f)" <<'PY'
 import csv, sys
-keep = ("k_lr_", "k_fm_", "k_kb_", "k_calib", "k_owner", "k_sum_partials")
+keep = ("k_lr_", "k_fm_", "k_kb_", "k_eb_", "k_ar_", "k_calib", "k_owner", "k_sum_partials")
 rows = list(csv.reader(open(sys.argv[1])))
 hdr, body = rows[0], rows[1:]
 ki = hdr.index("Kernel_Name")
