@@ -1171,6 +1171,13 @@ k_kb_resolve(KbArgs a) {
   const uint32_t k0 = S * kSCKeys, nk = min(kSCKeys, a.nbase - k0);
   const uint32_t nb = max(nk / 2, 1u);
   const bool local = se - sb <= kPart && a.nwin * kSC <= kLocalCells;  // workgroup-uniform
+  // a super-chunk of several items (a power-law head's): the items share its cells' cursors in
+  // memory — a round's records are counted per cell in LDS and the workgroup takes their places
+  // with ONE atomic per cell (one per wavefront and cell, all on the few cursors of the head
+  // key's cells, made this kernel 323 us on the Zipf(1.1) stream: 115 on the uniform one)
+  const uint32_t nlc = a.nwin * kSC;
+  const bool shared = !local && nlc <= kLocalCells / 2;
+  uint32_t *const lbase = lcur + kLocalCells / 2;
   uint32_t *__restrict__ entries = a.entries;
   constexpr int E = 4, kRounds = (int)(kBatch / (kRes * E));
   // A batch of kBatch records goes into registers at once (16 per thread): the rounds below end
@@ -1200,6 +1207,8 @@ k_kb_resolve(KbArgs a) {
         const uint32_t c = (S << kSCShift) + (i & (kSC - 1));
         lcur[i] = c < a.cA ? a.cellptr[(size_t)(i >> kSCShift) * a.cA + c] : 0u;
       }
+    if (shared)
+      for (uint32_t i = tid; i < nlc; i += kRes) lcur[i] = 0;
     if (tid == 0) s_mcnt = 0;
   }
   const uint64_t sm = a.smult[S];
@@ -1218,7 +1227,7 @@ k_kb_resolve(KbArgs a) {
     if (i0 >= re) break;  // workgroup-uniform
     if (dslot < kDbgSlots - 4) KB_T(dslot++);
     uint64_t key[E], x0[E], x1[E];
-    uint32_t rp[E], cell[E], ent[E], ds[E], de[E];
+    uint32_t rp[E], cell[E], ent[E], ds[E], de[E], at[E] = {0u, 0u, 0u, 0u};
     bool ok[E], miss[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -1243,7 +1252,7 @@ k_kb_resolve(KbArgs a) {
       const bool found = ok[q] && ub > 0 && lk[p] == key[q];
       const uint32_t cl = p >> kChunkBits, c = (S << kSCShift) + cl;
       const uint32_t v = rp[q] >> kRinBits, rin = rp[q] & ((1u << kRinBits) - 1u);
-      cell[q] = local ? (v << kSCShift) + cl : v * a.cA + c;
+      cell[q] = local || shared ? (v << kSCShift) + cl : v * a.cA + c;
       ent[q] = found ? ((c & xf::kTagMask) << kTagShift) | (rin << kChunkBits) | (p & (kChunk - 1))
                      : kHole;
       miss[q] = ok[q] && !found && !KB_FLAG(8);
@@ -1268,6 +1277,10 @@ k_kb_resolve(KbArgs a) {
 #pragma unroll
       for (int q = 0; q < E; ++q)
         if (ok[q]) entries[atomicAdd(&lcur[cell[q]], 1u)] = ent[q];
+    } else if (shared) {
+#pragma unroll
+      for (int q = 0; q < E; ++q)  // (rank in the round; the slots after the barriers below)
+        if (ok[q]) at[q] = atomicAdd(&lcur[cell[q]], 1u);
     } else
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -1337,7 +1350,20 @@ k_kb_resolve(KbArgs a) {
       s_mbase = n ? atomicAdd(&a.sum->miss, (unsigned long long)n) : 0ull;
       s_mcnt = 0;  // (the next round's: nobody adds before the barrier below)
     }
+    if (shared)
+      for (uint32_t c = tid; c < nlc; c += kRes) {
+        const uint32_t n = lcur[c];
+        if (n) {
+          lbase[c] = atomicAdd(
+              &a.cellcur[(size_t)(c >> kSCShift) * a.cA + (S << kSCShift) + (c & (kSC - 1))], n);
+          lcur[c] = 0;
+        }
+      }
     lds_barrier();
+    if (shared)
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if (ok[q]) entries[lbase[cell[q]] + at[q]] = ent[q];
     const unsigned long long mbase = s_mbase;
 #pragma unroll
     for (int q = 0; q < E; ++q)
