@@ -1888,7 +1888,7 @@ struct EbArgs {
   const Rec3 *rec;         // [n] records grouped by key range
   const uint32_t *sstart;  // [nR + 1]
   const uint64_t *bnd;     // [nR]
-  uint32_t nR, n;
+  uint32_t nR, n, max_items;
   uint32_t *rec_row;       // [n] k_eb_rank: rank of the record's key in its range; k_eb_count: row
   uint64_t *ukeys;         // [n] the ranges' distinct keys, range S's from sstart[S] on
   uint32_t *dbase;         // [nR + 1] distinct keys per range, then (k_eb_scan) their scan
@@ -2161,17 +2161,22 @@ __global__ void __launch_bounds__(kEb)
 k_eb_cells(EbArgs a, ArArgs r) {
   __shared__ uint32_t lcnt[kEbCells], lcur[kEbCells];
   const uint32_t tid = threadIdx.x;
-  if (PLACE && blockIdx.x >= a.nR) {
-    ar_blk_cell(r, blockIdx.x - a.nR, gridDim.x - a.nR);
+  if (PLACE && blockIdx.x >= a.max_items) {
+    ar_blk_cell(r, blockIdx.x - a.max_items, gridDim.x - a.max_items);
     return;
   }
-  const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
-  if (m == 0) return;
+  if (blockIdx.x >= *r.nitems) return;
+  // a work item of the partition: a range, or kPart records of a heavy one (a power-law head's
+  // 10^6 records are thirty workgroups' work, not one's)
+  const uint32_t item = r.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t s0 = a.sstart[S], s1 = a.sstart[S + 1];
+  const uint32_t sb = s0 + part * kPart, m = min(s1, sb + kPart) - sb;
   const EbLocal L = eb_local(a, S);
   const uint32_t nl = a.nwin * L.nloc;  // <= kEbCells (the host saw to it)
   for (uint32_t i = tid; i < nl; i += kEb) lcnt[i] = 0;
-  if (!PLACE)
-    for (uint32_t j = tid; j < L.d; j += kEb) a.bkeys[L.base + j] = a.ukeys[sb + j];
+  if (!PLACE && part == 0)
+    for (uint32_t j = tid; j < L.d; j += kEb) a.bkeys[L.base + j] = a.ukeys[s0 + j];
   __syncthreads();
   for (uint32_t i0 = 0; i0 < m; i0 += kEb * 4) {
     uint32_t rp[4], row[4], lc[4], at[4];
@@ -2609,6 +2614,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     e.bnd = bnd;
     e.nR = nR;
     e.n = n;
+    e.max_items = max_items;
     e.rec_row = rec_row;
     XF_TRY(sc.get(&e.ukeys, n));
     XF_TRY(sc.get(&e.dbase, nR + 2));
@@ -2706,7 +2712,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     e.entries = c->entries;
     if (!early.empty())  // (from here on nothing fails before they are back)
       XF_TRY(table_take_early(t, d_early, early.size(), early_w, early_nz, early_pos, s));
-    hipLaunchKernelGGL(k_eb_cells<false>, dim3(nR), dim3(kEb), 0, s, e, r);
+    hipLaunchKernelGGL(k_eb_cells<false>, dim3(max_items), dim3(kEb), 0, s, e, r);
     XF_HIP(hipGetLastError());
     XF_TRY(table_settle_first(t, (size_t)eb_keys, s));
     if (!early.empty())
@@ -2719,8 +2725,8 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
   if (eb) {
-    hipLaunchKernelGGL(k_eb_cells<true>, dim3(nR + std::min<uint32_t>(64, nR / 8 + 1)), dim3(kEb), 0,
-                       s, e, r);
+    hipLaunchKernelGGL(k_eb_cells<true>, dim3(max_items + std::min<uint32_t>(64, nR / 8 + 1)),
+                       dim3(kEb), 0, s, e, r);
   } else {
     const uint32_t nwg = (n + kRes * 4 - 1) / (kRes * 4);
     hipLaunchKernelGGL(k_ar_place, dim3(nwg + std::min<uint32_t>(64, nwg / 8 + 1)), dim3(kRes), 0, s,
