@@ -555,9 +555,22 @@ __device__ __forceinline__ uint32_t staged_excl_scan(F in, uint32_t n, uint32_t 
 }
 
 // the cell counts of piece p (kScanPiece cells), for the scan's workgroups to start from
+// ... and, by the workgroups beyond the pieces, the gradient's slices per chunk (the item plan's
+// input): kKb chunks per workgroup.  (In the scan's plan workgroup — a load per window, its wait,
+// an add, 48 times over for the 48 829 chunks of a 10^8-key table — they were 100 of that
+// kernel's 157 us.)
 __global__ void __launch_bounds__(kKb)
 k_kb_psum(KbArgs a) {
   __shared__ uint32_t wsum[kKb / 64];
+  if (blockIdx.x >= a.npc) {
+    const uint32_t c = (blockIdx.x - a.npc) * kKb + threadIdx.x;
+    if (c > a.cA) return;
+    uint32_t n = 0;
+    if (c < a.cA)
+      for (uint32_t v = 0; v < a.nwin; ++v) n += a.hist[(size_t)v * a.cA + c];
+    a.plan[c] = (n + xf::kSliceMax - 1) / xf::kSliceMax;  // (plan[cA] = 0)
+    return;
+  }
   const uint32_t ncell = a.nwin * a.cA, p = blockIdx.x;
   const uint32_t b = p * kScanPiece, e = min(b + kScanPiece, ncell);
   uint32_t sum = 0;
@@ -633,8 +646,10 @@ k_kb_scan(KbArgs a) {
       for (; v < a.nwin; ++v) n += hist[(size_t)v * a.cA + c];
       return (n + xf::kSliceMax - 1) / xf::kSliceMax;
     };
-    for (uint32_t c = tid; c < a.cA; c += kKb) nsl[c] = slices(c);
-    if (tid == 0) nsl[a.cA] = 0;
+    if (a.npc <= 1) {  // (else k_kb_psum has them)
+      for (uint32_t c = tid; c < a.cA; c += kKb) nsl[c] = slices(c);
+      if (tid == 0) nsl[a.cA] = 0;
+    }
     __syncthreads();  // (its fence: the slices are in L2 before this workgroup reads them back)
     const volatile uint32_t *vn = nsl;
     // both scans in one pass: the slices' prefix in a word's low 20 bits, the split chunks'
@@ -2722,7 +2737,8 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     hipLaunchKernelGGL(k_ar_insert<false>, dim3(max_items), dim3(kAr), 0, s, r);
   }
   a.scan_part = 2;
-  if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+  if (a.npc > 1)
+    hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
   if (eb) {
     hipLaunchKernelGGL(k_eb_cells<true>, dim3(max_items + std::min<uint32_t>(64, nR / 8 + 1)),
@@ -3049,7 +3065,8 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
         else
           XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl, a);
       }
-      if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+      if (a.npc > 1)
+    hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
       hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
                          0, s, a);
       const size_t sl = scatter_lds_bytes(nS, a.tile);
@@ -3099,7 +3116,8 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
       a.grec = grec;
       XF_KB_LAUNCH(k_kb_regroup, nG, regroup_lds_bytes(gshift, nwin), a);
       a.scan_part = 2;
-      if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+      if (a.npc > 1)
+    hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
       hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
     }
     hipLaunchKernelGGL(k_kb_resolve, dim3(max_items), dim3(kRes), 0, s, a);
@@ -3207,7 +3225,8 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   if (ldsb) XF_KB_LAUNCH((k_kb_hist<false, true>), a.nW, hl);
   else
     XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
-  if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc), dim3(kKb), 0, s, a);
+  if (a.npc > 1)
+    hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
   hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
                      a);
   const size_t sl = scatter_lds_bytes(nS, a.tile);
