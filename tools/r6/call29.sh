@@ -10,4 +10,4 @@ Q="--no-cpu-baseline --no-fresh-table --no-n8-shape --no-end-to-end --sustained-
 grep "k_kb_scan\|k_kb_psum\|k_kb_resolve" $(find /tmp/_s -name "*kernel_stats.csv" | head -1) | cut -c1-150
 python bench.py $Q --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('line', d['ms_per_step'], d.get('ms_per_step_with_key_build'), [(t['keys_per_gpu'], round(t['ms_per_step'],4), t.get('ms_per_step_with_key_build')) for t in d.get('table_sweep',[])])"
+d=json.loads(sys.stdin.read()); print('line', d['ms_per_step'], d.get('ms_per_step_with_key_build'), d.get('summary'))"

@@ -519,6 +519,7 @@ k_kb_hist(KbArgs a) {
 // loads in, a thread scans 16 neighbouring elements (17-word stride: no bank conflicts),
 // coalesced stores out.
 constexpr uint32_t kScanPiece = 16 * kKb;
+constexpr uint32_t kPlanWgs = 3;  // k_kb_scan: workgroups of the item plan (a scan each)
 __device__ __forceinline__ uint32_t sp(uint32_t i) { return i + (i >> 4); }
 
 template <typename F>
@@ -589,9 +590,9 @@ k_kb_scan(KbArgs a) {
   __shared__ uint32_t wsum[kKb / 64];
   const uint32_t tid = threadIdx.x;
   const uint32_t *__restrict__ hist = a.hist;
-  if (blockIdx.x > a.npc ? a.scan_part == 2 : a.scan_part == 1) return;  // (two-level build)
-  if (blockIdx.x > a.npc) {
-    const uint32_t S = (blockIdx.x - a.npc - 1) * (kKb / 64) + (tid >> 6), lane = tid & 63u;
+  if (blockIdx.x >= a.npc + kPlanWgs ? a.scan_part == 2 : a.scan_part == 1) return;  // (two-level build)
+  if (blockIdx.x >= a.npc + kPlanWgs) {
+    const uint32_t S = (blockIdx.x - a.npc - kPlanWgs) * (kKb / 64) + (tid >> 6), lane = tid & 63u;
     if (S >= a.nS) return;
     uint32_t *__restrict__ col = a.wgcnt + S;
     uint32_t carry = 0;
@@ -629,7 +630,10 @@ k_kb_scan(KbArgs a) {
     if (lane == 0) a.scount[S] = carry;
     return;
   }
-  if (blockIdx.x == a.npc) {  // slices per chunk, first item of every chunk, index among the split
+  if (blockIdx.x >= a.npc) {  // slices per chunk, first item of every chunk, index among the split
+    // (three workgroups, a scan each — unless one packed scan does for two of them: a 10^8-key
+    // table's 48 829 chunks, three scans one behind the other, were 84 us)
+    const uint32_t which = blockIdx.x - a.npc;
     const size_t nc1 = (size_t)a.cA + 1;
     uint32_t *nsl = a.plan, *off = a.plan + nc1, *soff = a.plan + 2 * nc1;
     auto slices = [&](uint32_t c) -> uint32_t {
@@ -656,6 +660,16 @@ k_kb_scan(KbArgs a) {
     // in its high 12, whenever both fit (else one pass each)
     uint32_t ta, tb;
     const bool packed = a.cA < (1u << 12) && a.NNZ / xf::kSliceMax + a.cA < (1u << 20);
+    if (packed && which == 1) return;  // (workgroup 0 scans both)
+    uint32_t *poff = a.plan + 3 * nc1;
+    if (which == 2) {
+      // the split chunks' slices, scanned: they go first in the item list (k_items_fill)
+      const uint32_t tp = staged_excl_scan(
+          [&](uint32_t c) { const uint32_t S = vn[c]; return S > 1 ? S : 0u; }, a.cA, poff, nullptr,
+          sbuf, wsum);
+      if (tid == 0) poff[a.cA] = tp;
+      return;
+    }
     if (packed) {
       const uint32_t t = staged_excl_scan(
           [&](uint32_t c) { const uint32_t S = vn[c]; return S | ((S > 1 ? 1u : 0u) << 20); },
@@ -667,21 +681,26 @@ k_kb_scan(KbArgs a) {
       }
       ta = t & 0xFFFFFu;
       tb = t >> 20;
-    } else {
+    } else if (which == 0) {
       ta = staged_excl_scan([&](uint32_t c) { return (uint32_t)vn[c]; }, a.cA, off, nullptr, sbuf,
                             wsum);
+      if (tid == 0) {
+        off[a.cA] = ta;
+        a.sum->nitems = ta;
+      }
+      return;
+    } else {
       tb = staged_excl_scan([&](uint32_t c) { return vn[c] > 1 ? 1u : 0u; }, a.cA, soff, nullptr,
                             sbuf, wsum);
+      if (tid == 0) {
+        soff[a.cA] = tb;
+        a.sum->nsplit = tb;
+      }
+      return;
     }
-    // the split chunks' slices, scanned: they go first in the item list (k_items_fill)
-    uint32_t *poff = a.plan + 3 * nc1;
-    const uint32_t tp = staged_excl_scan(
-        [&](uint32_t c) { const uint32_t S = vn[c]; return S > 1 ? S : 0u; }, a.cA, poff, nullptr,
-        sbuf, wsum);
-    if (tid == 0) {
+    if (tid == 0) {  // (the packed scan's two totals)
       off[a.cA] = ta;
       soff[a.cA] = tb;
-      poff[a.cA] = tp;
       a.sum->nitems = ta;
       a.sum->nsplit = tb;
     }
@@ -2580,7 +2599,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   if (d_rowid) XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
   else
     XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
-  hipLaunchKernelGGL(k_kb_scan, dim3(1 + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(kPlanWgs + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
   const size_t sl = scatter_lds_bytes(nR, a.tile);
   if (a.tile == kTile) {
     if (d_rowid) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
@@ -2739,7 +2758,7 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
   a.scan_part = 2;
   if (a.npc > 1)
     hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
-  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs), dim3(kKb), 0, s, a);
   if (eb) {
     hipLaunchKernelGGL(k_eb_cells<true>, dim3(max_items + std::min<uint32_t>(64, nR / 8 + 1)),
                        dim3(kEb), 0, s, e, r);
@@ -3067,7 +3086,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
       }
       if (a.npc > 1)
     hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
-      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
                          0, s, a);
       const size_t sl = scatter_lds_bytes(nS, a.tile);
       if (a.tile == kTile) {
@@ -3098,7 +3117,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
       if (d_rowid) XF_KB_LAUNCH((k_kb_hist_groups<true>), a.nW, hl, ag);
       else
         XF_KB_LAUNCH((k_kb_hist_groups<false>), a.nW, hl, ag);
-      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nG + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs + (nG + kKb / 64 - 1) / (kKb / 64)), dim3(kKb),
                          0, s, ag);
       const size_t sl = scatter_lds_bytes(nG, a.tile);
       if (a.tile == kTile) {
@@ -3118,7 +3137,7 @@ int cells_build_keyed(xf_cells **out, xf_table *t, const uint64_t *d_keys,
       a.scan_part = 2;
       if (a.npc > 1)
     hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
-      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1), dim3(kKb), 0, s, a);
+      hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs), dim3(kKb), 0, s, a);
     }
     hipLaunchKernelGGL(k_kb_resolve, dim3(max_items), dim3(kRes), 0, s, a);
 #undef XF_KB_LAUNCH
@@ -3227,7 +3246,7 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
     XF_KB_LAUNCH((k_kb_hist<false, false>), a.nW, hl);
   if (a.npc > 1)
     hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
-  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + 1 + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs + (nS + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s,
                      a);
   const size_t sl = scatter_lds_bytes(nS, a.tile);
   if (a.tile == kTile) XF_KB_LAUNCH((k_kb_scatter<false, kTile, true>), a.nW, sl);
