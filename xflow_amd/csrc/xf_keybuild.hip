@@ -1916,6 +1916,7 @@ constexpr uint32_t kEbAll = kEbSlots + kEbPad;
 constexpr uint32_t kEbPerT = kEbAll / kEbR;      // positions per thread: 9, groups of 3
 constexpr uint32_t kEbCluster = 512;       // keys of one cluster a walk goes back over
 constexpr uint32_t kEbCells = 2048;        // cells a range's records may fall into (LDS counters)
+constexpr uint32_t kEbHeavy = 1u << 21;    // records of ONE range k_eb_rank streams (1.8 ms per 10^6)
 static_assert(kEbPerT * kEbR == kEbAll && kEbPerT % 3 == 0, "k_eb_rank: a thread's groups");
 struct EbArgs {
   xf::TableDev T;
@@ -1950,8 +1951,11 @@ k_eb_rank(EbArgs a) {
   __shared__ uint32_t wsum[kEbR / 64], s_nlong;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
-  if (m == 0) {  // workgroup-uniform
-    if (tid == 0) a.dbase[S] = 0;
+  if (m == 0 || m > kEbHeavy) {  // workgroup-uniform
+    if (tid == 0) {
+      a.dbase[S] = 0;
+      if (m) atomicOr(&a.out[0], 1u);  // (one workgroup streams a range: not millions of records)
+    }
     return;
   }
   // home of a key: (key - first key of the range) >> sh, the range's width cut into at most
@@ -2356,36 +2360,113 @@ struct FmRegroup {
   uint32_t *urow;          // [U] their state rows
   uint32_t *segptr;        // [U + 1]
   uint32_t *coo;           // [NNZ] rows of the occurrences, grouped by key
+  // work items (the partition's: a super-chunk, or kPart records of a heavy one — a power-law
+  // head key's 10^6 records in ONE workgroup made k_fm_count 1.5 ms and k_fm_regroup 3.1 ms on
+  // the Zipf(1.1) stream: 0.013 and 0.13 on the uniform one)
+  const uint32_t *items, *nitems;
+  uint32_t *pcnt;          // [items][kSCKeys] a heavy super-chunk's records per key and part
+  uint32_t *gbits;         // [nS][kSCKeys / 32] ... its touched keys (zeroed)
+  uint32_t *done;          // [nS] ... its parts that have counted (zeroed)
 };
+
+// Every lane with `on` adds one to cnt[l] and learns the count before it (WANT) — the lanes that
+// share the first lane's key with ONE atomic: a wavefront of a head key's records is one LDS
+// operation instead of 64 on one address.
+template <bool WANT>
+__device__ __forceinline__ uint32_t fm_lds_add(uint32_t *cnt, uint32_t l, bool on) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long m_on = __ballot(on);
+  if (!m_on) return 0;  // wave-uniform
+  const int leader = __ffsll((long long)m_on) - 1;
+  const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)l, leader);
+  const bool same = on && l == l0;
+  const unsigned long long ms = __ballot(same);
+  uint32_t base = 0;
+  if ((int)lane == leader) {
+    if (WANT) base = atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
+    else
+      atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
+  }
+  if (WANT) base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  if (same) return base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+  if (on) {
+    if (WANT) return atomicAdd(&cnt[l], 1u);
+    atomicAdd(&cnt[l], 1u);
+  }
+  return 0;
+}
+
+struct FmItem {
+  uint32_t S, part, parts, sb, se, rb, re;
+};
+__device__ __forceinline__ FmItem fm_item(const FmRegroup &g, uint32_t item) {
+  FmItem it;
+  it.S = item & 0xFFFFu;
+  it.part = item >> 16;
+  it.sb = g.sstart[it.S];
+  it.se = g.sstart[it.S + 1];
+  it.parts = (it.se - it.sb + kPart - 1) / kPart;
+  it.rb = it.sb + it.part * kPart;
+  it.re = min(it.se, it.rb + kPart);
+  return it;
+}
 
 __global__ void __launch_bounds__(kKb)
 k_fm_count(FmRegroup g) {
   __shared__ uint32_t cnt[kSCKeys];
   __shared__ uint32_t wsum[kKb / 64];
-  const uint32_t tid = threadIdx.x, S = blockIdx.x;
-  const uint32_t sb = g.sstart[S], se = g.sstart[S + 1], k0 = S * kSCKeys;
+  __shared__ uint32_t s_last;
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= *g.nitems) return;
+  const FmItem it = fm_item(g, g.items[blockIdx.x]);
+  const uint32_t k0 = it.S * kSCKeys;
   for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
   __syncthreads();
-  for (uint32_t i0 = sb; i0 < se; i0 += kKb * 8) {
+  for (uint32_t i0 = it.rb; i0 < it.re; i0 += kKb * 8) {
     uint32_t r[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const uint32_t i = i0 + q * kKb + tid;
-      r[q] = i < se ? g.vrow[i] : kHole;
+      r[q] = i < it.re ? g.vrow[i] : kHole;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (r[q] != kHole) atomicAdd(&cnt[r[q] - k0], 1u);
+    for (int q = 0; q < 8; ++q) (void)fm_lds_add<false>(cnt, r[q] - k0, r[q] != kHole);
   }
   __syncthreads();
+  if (it.parts > 1) {  // workgroup-uniform: the counts out, the touched keys into the super-chunk's bits
+    uint32_t *__restrict__ pc = g.pcnt + (size_t)blockIdx.x * kSCKeys;
+    for (uint32_t k = tid; k < kSCKeys; k += kKb) {
+      const uint32_t c = cnt[k];
+      pc[k] = c;
+      const unsigned long long mb = __ballot(c != 0);  // (k = 64 * wave + lane: two words)
+      if ((tid & 63u) == 0 && mb) {
+        const uint32_t w = it.S * (kSCKeys / 32) + (k >> 5);
+        if ((uint32_t)mb) atomicOr(&g.gbits[w], (uint32_t)mb);
+        if ((uint32_t)(mb >> 32)) atomicOr(&g.gbits[w + 1], (uint32_t)(mb >> 32));
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&g.done[it.S], 1u) == it.parts - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    uint32_t n = 0;  // the last part to count: every part's bits are there
+    for (uint32_t w = tid; w < kSCKeys / 32; w += kKb)
+      n += (uint32_t)__popc(__hip_atomic_load(&g.gbits[it.S * (kSCKeys / 32) + w], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT));
+    uint32_t total;
+    (void)block_excl_scan(n, wsum, &total);
+    if (tid == 0) g.ucount[it.S] = total;
+    return;
+  }
   uint32_t n = 0;
   for (uint32_t k = tid; k < kSCKeys; k += kKb) n += cnt[k] ? 1u : 0u;
   uint32_t total;
   (void)block_excl_scan(n, wsum, &total);
-  if (tid == 0) g.ucount[S] = total;
+  if (tid == 0) g.ucount[it.S] = total;
 }
 
-// ucount -> its exclusive scan in place, the total behind it
 __global__ void __launch_bounds__(kKb)
 k_fm_scan(uint32_t *__restrict__ ucount, uint32_t nS) {
   __shared__ uint32_t sbuf[kScanPiece + kScanPiece / 16];
@@ -2400,27 +2481,48 @@ __global__ void __launch_bounds__(kKb)
 k_fm_regroup(FmRegroup g) {
   __shared__ uint32_t cnt[kSCKeys], off[kSCKeys];
   __shared__ uint32_t wsum[kKb / 64];
-  const uint32_t tid = threadIdx.x, S = blockIdx.x;
-  const uint32_t sb = g.sstart[S], se = g.sstart[S + 1], k0 = S * kSCKeys;
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= *g.nitems) return;
+  const FmItem it = fm_item(g, g.items[blockIdx.x]);
+  const uint32_t S = it.S, sb = it.sb, k0 = S * kSCKeys;
+  const bool heavy = it.parts > 1;  // workgroup-uniform
   // a thread owns kSCKeys / kKb consecutive rows; their keys are asked for now — a load per
   // touched row inside the loop below was a dependent trip to memory each
   constexpr uint32_t kPer = kSCKeys / kKb;
   uint64_t mykey[kPer];
+  uint32_t before[kPer];  // a heavy super-chunk: the key's records in the parts before this one
 #pragma unroll
-  for (uint32_t q = 0; q < kPer; ++q)
+  for (uint32_t q = 0; q < kPer; ++q) {
     mykey[q] = g.bkeys[min((uint64_t)k0 + tid * kPer + q, g.nbase - 1)];
-  for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
-  __syncthreads();
-  for (uint32_t i0 = sb; i0 < se; i0 += kKb * 8) {
-    uint32_t r[8];
+    before[q] = 0;
+  }
+  if (heavy) {
+    // every part's counts per key (k_fm_count): the key's total, and what lies before this part
+    const uint32_t *__restrict__ pc = g.pcnt + (size_t)(blockIdx.x - it.part) * kSCKeys;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint32_t i = i0 + q * kKb + tid;
-      r[q] = i < se ? g.vrow[i] : kHole;
+    for (uint32_t q = 0; q < kPer; ++q) {
+      const uint32_t k = tid * kPer + q;
+      uint32_t tot = 0;
+      for (uint32_t p = 0; p < it.parts; ++p) {
+        const uint32_t c = pc[(size_t)p * kSCKeys + k];
+        tot += c;
+        if (p < it.part) before[q] += c;
+      }
+      cnt[k] = tot;
     }
+  } else {
+    for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t i0 = it.rb; i0 < it.re; i0 += kKb * 8) {
+      uint32_t r[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (r[q] != kHole) atomicAdd(&cnt[r[q] - k0], 1u);
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t i = i0 + q * kKb + tid;
+        r[q] = i < it.re ? g.vrow[i] : kHole;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) (void)fm_lds_add<false>(cnt, r[q] - k0, r[q] != kHole);
+    }
   }
   __syncthreads();
   // where the rows' occurrences begin, and their numbers among the touched keys
@@ -2438,32 +2540,36 @@ k_fm_regroup(FmRegroup g) {
   for (uint32_t q = 0; q < kPer; ++q) {
     const uint32_t k = tid * kPer + q, c = cnt[k];
     off[k] = run;
-    if (c) {
+    if (c && it.part == 0) {
       g.urow[urun] = k0 + k;
       g.ukeys[urun] = mykey[q];
       g.segptr[urun] = sb + run;
-      ++urun;
     }
+    urun += c ? 1u : 0u;
     run += c;
   }
-  if (S == g.nS - 1 && tid == kKb - 1) g.segptr[urun] = g.sstart[g.nS];  // segptr[U] = NNZ
+  if (S == g.nS - 1 && it.part == 0 && tid == kKb - 1) g.segptr[urun] = g.sstart[g.nS];  // segptr[U] = NNZ
   __syncthreads();
-  for (uint32_t k = tid; k < kSCKeys; k += kKb) cnt[k] = 0;  // now the rows' cursors
+  // now the rows' cursors (a heavy super-chunk: behind the parts before this one)
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; ++q) cnt[tid * kPer + q] = before[q];
   __syncthreads();
   constexpr int E = 8;  // a thread's loads of a round first, then its cursors and stores
-  for (uint32_t i0 = sb; i0 < se; i0 += kKb * E) {
+  for (uint32_t i0 = it.rb; i0 < it.re; i0 += kKb * E) {
     uint32_t r[E], rp[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t i = i0 + q * kKb + tid;
-      r[q] = i < se ? g.vrow[i] : kHole;
-      rp[q] = i < se ? g.rp[i] : 0u;
+      r[q] = i < it.re ? g.vrow[i] : kHole;
+      rp[q] = i < it.re ? g.rp[i] : 0u;
     }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-      if (r[q] == kHole) continue;
-      const uint32_t l = r[q] - k0, slot = sb + off[l] + atomicAdd(&cnt[l], 1u);
-      g.coo[slot] = (rp[q] >> kRinBits) * g.W + (rp[q] & ((1u << kRinBits) - 1u));
+      const bool on = r[q] != kHole;
+      const uint32_t l = on ? r[q] - k0 : 0u;
+      const uint32_t at = fm_lds_add<true>(cnt, l, on);
+      if (on)
+        g.coo[sb + off[l] + at] = (rp[q] >> kRinBits) * g.W + (rp[q] & ((1u << kRinBits) - 1u));
     }
   }
 }
@@ -3263,14 +3369,20 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   g.W = a.W;
   g.nbase = T.nbase;
   g.ucount = ucount;
-  hipLaunchKernelGGL(k_fm_count, dim3(nS), dim3(kKb), 0, s, g);
+  g.items = a.items;
+  g.nitems = a.nitems;
+  XF_TRY(sc.get(&g.pcnt, (size_t)max_items * kSCKeys));
+  XF_TRY(sc.get(&g.gbits, (size_t)nS * (kSCKeys / 32) + nS));
+  g.done = g.gbits + (size_t)nS * (kSCKeys / 32);
+  XF_HIP(hipMemsetAsync(g.gbits, 0, ((size_t)nS * (kSCKeys / 32) + nS) * 4, s));
+  hipLaunchKernelGGL(k_fm_count, dim3(max_items), dim3(kKb), 0, s, g);
   hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(kKb), 0, s, ucount, nS);
   // no wait for the number of distinct keys: the arrays are placed for the most there can be
   // (every nonzero its own key, every settled key touched), the regroup takes the number from
   // the device, and the caller reads it — and the misses — when it next synchronises
   XF_TRY(place(ctx, (uint32_t)std::min<uint64_t>(NNZ, T.nbase), &g.ukeys, &g.urow, &g.segptr,
                &g.coo));
-  hipLaunchKernelGGL(k_fm_regroup, dim3(nS), dim3(kKb), 0, s, g);
+  hipLaunchKernelGGL(k_fm_regroup, dim3(max_items), dim3(kKb), 0, s, g);
   XF_HIP(hipGetLastError());
   *d_U = ucount + nS;
   *d_miss = &a.sum->miss;
