@@ -45,9 +45,17 @@
 //
 // Keys the settled tier does not hold (new since the last xf_table_defrag, or the reserved key
 // value) leave a hole in their cell (an entry the kernels skip) and go to a miss list; they are
-// inserted by the general path (table_resolve_any) and form a second SEGMENT of the batch's
-// cells (xf_cells::next) over the arrival rows.  In the steady state (every key settled) the
+// inserted by the first-touch build (round 6, "first touch" below: the same partition over
+// UNIFORM key ranges, the arrival index probed where a range's positions sit in L2) and form a
+// second SEGMENT of the batch's cells (xf_cells::next) over the arrival rows.  A table that
+// holds nothing yet — a run's first minibatch — is settled by its build at once ("an empty
+// table" below: the key ranges sorted in LDS).  In the steady state (every key settled) the
 // list is empty and the build is four streaming passes and ONE host synchronisation.
+// Power-law streams: whatever works on a range's or a super-chunk's records takes them in work
+// items of kPart records (k_kb_resolve, k_ar_insert, k_eb_cells, k_fm_count / k_fm_regroup), and
+// takes the places of a head key's records with one atomic per workgroup and round, not one per
+// wavefront (same-address atomics serialise: ~10 ns each on memory); k_eb_rank alone streams a
+// range in one workgroup (1.8 ms per 10^6 records of one key).
 // HBM-bound integer work, no MFMA.
 #include <hip/hip_runtime.h>
 
