@@ -515,3 +515,25 @@ def test_a_table_others_hold_rows_of_is_not_renumbered_by_its_first_minibatch():
     b = capi.LocalBatch(t, *raw)
     assert t.settled == 0 and b.cells_info()["segments"] == 1
     t.check()
+
+
+@pytest.mark.parametrize("shard,nshards", [(0, 4), (2, 4), (3, 4), (7, 8)])
+def test_a_shard_of_the_key_space_settles_on_its_first_minibatch_too(shard, nshards):
+    """the uniform key ranges and a range's homes are cut from the SHARD's key span (ps-lite's
+    uniform ranges): the first and a middle shard, and the last one, whose span takes
+    the division's remainder"""
+    rng = np.random.RandomState(40 + shard)
+    allk = capi.hash_decimal_range(0, 100000)
+    mine = allk[np.array([capi.lib().xf_shard_of(int(k), nshards) for k in allk]) == shard]
+    assert len(mine) > 5000
+    R, nnz = 4000, 25
+    rowptr = (np.arange(R + 1) * nnz).astype(np.uint64)
+    raws = [(rowptr, mine[rng.randint(0, len(mine), size=R * nnz)],
+             rng.randint(0, 2, size=R).astype(np.int32)) for _ in range(3)]
+    t = capi.Table(capi.OPT_FTRL, 1, capacity=1 << 16, shard=shard, nshards=nshards)
+    s = O.Store(O.OPT_FTRL, 1)
+    ws = capi.Workspace()
+    b0 = capi.LocalBatch(t, *raws[0])
+    assert t.settled == len(np.unique(raws[0][1])) == len(t)
+    del b0
+    steps_vs_oracle(t, s, raws, ws, 4, defrag_at=2)

@@ -1967,9 +1967,10 @@ k_eb_rank(EbArgs a) {
     return;
   }
   // home of a key: (key - first key of the range) >> sh, the range's width cut into at most
-  // kEbSlots equal pieces (the last range ends where the key space does)
+  // kEbSlots equal pieces (the last range ends where the shard's key span does; the keys of the
+  // last shard beyond it — the division's remainder — share the last home)
   const uint64_t k0 = a.bnd[S];
-  const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] : 0ull) - k0 - 1ull;  // width - 1, mod 2^64
+  const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] : a.T.lo + a.T.span) - k0 - 1ull;  // width - 1
   const int bits = 64 - __clzll((long long)(width1 | 1ull));
   const int sh = bits > 13 ? bits - 13 : 0;
   static_assert(kEbSlots == 1u << 13, "the shift above");
