@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 6, call 32: the whole GPU suite on the round's last library
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+python -m xflow_amd.build > /tmp/build.log 2>&1 || tail -5 /tmp/build.log
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
