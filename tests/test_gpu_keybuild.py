@@ -537,3 +537,21 @@ def test_a_shard_of_the_key_space_settles_on_its_first_minibatch_too(shard, nsha
     assert t.settled == len(np.unique(raws[0][1])) == len(t)
     del b0
     steps_vs_oracle(t, s, raws, ws, 4, defrag_at=2)
+
+
+def test_a_table_of_rows_of_16_hashed_initial_values_settles_with_them():
+    """k_first_rows: the rows of a table settled by its first minibatch carry the init kind's
+    values of THEIR keys (FM's v table: hashnorm(seed, key, j), fm_worker.cc's store default) —
+    what a Pull through the arrival index puts there; checked against the oracle's store"""
+    rng = np.random.RandomState(31)
+    raw = synth(rng, 3000, 20, 20000)
+    t = capi.Table(capi.OPT_FTRL, 16, capi.INIT_HASHNORM, seed=1234, capacity=1 << 16)
+    s = O.Store(O.OPT_FTRL, 16, O.INIT_HASHNORM, 0.0, 1234)
+    b = capi.LocalBatch(t, *raw, retain_keys=False)     # (the cells are not stepped: dim 16)
+    uk = np.unique(raw[1])
+    assert t.settled == len(uk) == len(t)
+    assert np.array_equal(t.pull(uk), s.pull(uk))
+    fresh = capi.hash_decimal_range(10**6, 100)          # later arrivals: behind the tier
+    assert np.array_equal(t.pull(fresh), s.pull(fresh))
+    t.check()
+    del b
