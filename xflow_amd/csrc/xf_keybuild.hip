@@ -1922,7 +1922,9 @@ constexpr uint32_t kEbSlots = 8192;        // positions of a range's key set in 
 constexpr uint32_t kEbPad = 1024;          // ... and behind them, for the last homes' clusters
 constexpr uint32_t kEbAll = kEbSlots + kEbPad;
 constexpr uint32_t kEbPerT = kEbAll / kEbR;      // positions per thread: 9, groups of 3
-constexpr uint32_t kEbCluster = 512;       // keys of one cluster a walk goes back over
+constexpr uint32_t kEbCluster = 192;       // keys of one cluster one lane still sorts (half-full sets:
+                                           // the longest of 2e7 positions' clusters ~90; a set
+                                           // fuller than that is keys that are no hashes)
 constexpr uint32_t kEbCells = 2048;        // cells a range's records may fall into (LDS counters)
 constexpr uint32_t kEbHeavy = 1u << 21;    // records of ONE range k_eb_rank streams (1.8 ms per 10^6)
 static_assert(kEbPerT * kEbR == kEbAll && kEbPerT % 3 == 0, "k_eb_rank: a thread's groups");
