@@ -1167,6 +1167,33 @@ k_kb_scatter(KbArgs a) {
 }
 
 // -------------------------------------------------------------------------------- resolve
+// Every lane with `on` adds one to cnt[l] and learns the count before it (WANT) — the lanes that
+// share the first lane's key with ONE atomic: a wavefront of a head key's records is one LDS
+// operation instead of 64 on one address.
+template <bool WANT>
+__device__ __forceinline__ uint32_t lds_add_shared(uint32_t *cnt, uint32_t l, bool on) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long m_on = __ballot(on);
+  if (!m_on) return 0;  // wave-uniform
+  const int leader = __ffsll((long long)m_on) - 1;
+  const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)l, leader);
+  const bool same = on && l == l0;
+  const unsigned long long ms = __ballot(same);
+  uint32_t base = 0;
+  if ((int)lane == leader) {
+    if (WANT) base = atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
+    else
+      atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
+  }
+  if (WANT) base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  if (same) return base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+  if (on) {
+    if (WANT) return atomicAdd(&cnt[l], 1u);
+    atomicAdd(&cnt[l], 1u);
+  }
+  return 0;
+}
+
 // Work item = up to kPart records of one super-chunk, whose keys sit in LDS with the
 // directory over them (k_kb_sdir).  A record finds its key with the directory pair and the
 // bucket's first two keys (a plain binary search would put the 64 lanes' probes of its first
@@ -1322,7 +1349,7 @@ k_kb_resolve(KbArgs a) {
     } else if (shared) {
 #pragma unroll
       for (int q = 0; q < E; ++q)  // (rank in the round; the slots after the barriers below)
-        if (ok[q]) at[q] = atomicAdd(&lcur[cell[q]], 1u);
+        at[q] = lds_add_shared<true>(lcur, cell[q], ok[q]);  // (a head key's records: one cell)
     } else
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -2380,33 +2407,6 @@ struct FmRegroup {
   uint32_t *done;          // [nS] ... its parts that have counted (zeroed)
 };
 
-// Every lane with `on` adds one to cnt[l] and learns the count before it (WANT) — the lanes that
-// share the first lane's key with ONE atomic: a wavefront of a head key's records is one LDS
-// operation instead of 64 on one address.
-template <bool WANT>
-__device__ __forceinline__ uint32_t fm_lds_add(uint32_t *cnt, uint32_t l, bool on) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long m_on = __ballot(on);
-  if (!m_on) return 0;  // wave-uniform
-  const int leader = __ffsll((long long)m_on) - 1;
-  const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)l, leader);
-  const bool same = on && l == l0;
-  const unsigned long long ms = __ballot(same);
-  uint32_t base = 0;
-  if ((int)lane == leader) {
-    if (WANT) base = atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
-    else
-      atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
-  }
-  if (WANT) base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-  if (same) return base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
-  if (on) {
-    if (WANT) return atomicAdd(&cnt[l], 1u);
-    atomicAdd(&cnt[l], 1u);
-  }
-  return 0;
-}
-
 struct FmItem {
   uint32_t S, part, parts, sb, se, rb, re;
 };
@@ -2441,7 +2441,7 @@ k_fm_count(FmRegroup g) {
       r[q] = i < it.re ? g.vrow[i] : kHole;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) (void)fm_lds_add<false>(cnt, r[q] - k0, r[q] != kHole);
+    for (int q = 0; q < 8; ++q) (void)lds_add_shared<false>(cnt, r[q] - k0, r[q] != kHole);
   }
   __syncthreads();
   if (it.parts > 1) {  // workgroup-uniform: the counts out, the touched keys into the super-chunk's bits
@@ -2532,7 +2532,7 @@ k_fm_regroup(FmRegroup g) {
         r[q] = i < it.re ? g.vrow[i] : kHole;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) (void)fm_lds_add<false>(cnt, r[q] - k0, r[q] != kHole);
+      for (int q = 0; q < 8; ++q) (void)lds_add_shared<false>(cnt, r[q] - k0, r[q] != kHole);
     }
   }
   __syncthreads();
@@ -2578,7 +2578,7 @@ k_fm_regroup(FmRegroup g) {
     for (int q = 0; q < E; ++q) {
       const bool on = r[q] != kHole;
       const uint32_t l = on ? r[q] - k0 : 0u;
-      const uint32_t at = fm_lds_add<true>(cnt, l, on);
+      const uint32_t at = lds_add_shared<true>(cnt, l, on);
       if (on)
         g.coo[sb + off[l] + at] = (rp[q] >> kRinBits) * g.W + (rp[q] & ((1u << kRinBits) - 1u));
     }
