@@ -52,10 +52,9 @@
 // table" below: the key ranges sorted in LDS).  In the steady state (every key settled) the
 // list is empty and the build is four streaming passes and ONE host synchronisation.
 // Power-law streams: whatever works on a range's or a super-chunk's records takes them in work
-// items of kPart records (k_kb_resolve, k_ar_insert, k_eb_cells, k_fm_count / k_fm_regroup), and
-// takes the places of a head key's records with one atomic per workgroup and round, not one per
-// wavefront (same-address atomics serialise: ~10 ns each on memory); k_eb_rank alone streams a
-// range in one workgroup (1.8 ms per 10^6 records of one key).
+// items of kPart records (k_kb_resolve, k_ar_insert, k_eb_rank / k_eb_cells, k_fm_count /
+// k_fm_regroup), and takes the places of a head key's records with one atomic per workgroup and
+// round, not one per wavefront (same-address atomics serialise: ~10 ns each on memory).
 // HBM-bound integer work, no MFMA.
 #include <hip/hip_runtime.h>
 
@@ -1953,7 +1952,6 @@ constexpr uint32_t kEbCluster = 192;       // keys of one cluster one lane still
                                            // the longest of 2e7 positions' clusters ~90; a set
                                            // fuller than that is keys that are no hashes)
 constexpr uint32_t kEbCells = 2048;        // cells a range's records may fall into (LDS counters)
-constexpr uint32_t kEbHeavy = 1u << 21;    // records of ONE range k_eb_rank streams (1.8 ms per 10^6)
 static_assert(kEbPerT * kEbR == kEbAll && kEbPerT % 3 == 0, "k_eb_rank: a thread's groups");
 struct EbArgs {
   xf::TableDev T;
@@ -1968,6 +1966,10 @@ struct EbArgs {
   uint64_t *bkeys;         // the settled tier to be
   uint32_t nwin, nchunk;
   uint32_t *hist, *cellcur, *entries;
+  const uint32_t *items, *nitems;  // the partition's work items (a range | its part << 16)
+  uint64_t *pkeys;         // [n] a heavy range's parts' distinct keys, part q's from its first record on
+  uint32_t *pmap;          // [n] ... their ranks among the range's keys (k_eb_rank<true>)
+  uint32_t *pd;            // [max_items] ... how many a part has
 };
 // two workgroups per CU: 2 x (72 KB of keys + 6 KB of counts) of the 160 KB
 constexpr size_t kEbLds = (size_t)kEbAll * 8 + (size_t)(kEbAll / 3) * 2;
@@ -1980,6 +1982,13 @@ constexpr size_t kEbLds = (size_t)kEbAll * 8 + (size_t)(kEbAll / 3) * 2;
 // to a key's home hold keys with smaller homes: smaller keys) — and a key's rank is the number of
 // occupied positions before it: a count per group of three positions.  Every record finds its
 // key again and takes the rank.
+// MERGE = false: a work item of the partition — a range, or kPart records of a heavy one (a
+// power-law head key's 10^6 records streamed by ONE workgroup were 1.8 ms): a part ranks its
+// records among ITS distinct keys, which go to pkeys.  MERGE = true (a second launch; the first
+// part's workgroup of every heavy range): the set again, over the parts' distinct keys — the
+// range's keys in order, and for every part's key its rank among them (pmap), through which
+// k_eb_count reads the parts' records' rows.
+template <bool MERGE>
 __global__ void __launch_bounds__(kEbR)
 k_eb_rank(EbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char eb_lds[];
@@ -1987,14 +1996,14 @@ k_eb_rank(EbArgs a) {
   uint16_t *gp = (uint16_t *)(tab + kEbAll);               // [kEbAll / 3] keys before the group
   __shared__ uint32_t wsum[kEbR / 64], s_nlong;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t S = blockIdx.x, sb = a.sstart[S], m = a.sstart[S + 1] - sb;
-  if (m == 0 || m > kEbHeavy) {  // workgroup-uniform
-    if (tid == 0) {
-      a.dbase[S] = 0;
-      if (m) atomicOr(&a.out[0], 1u);  // (one workgroup streams a range: not millions of records)
-    }
-    return;
-  }
+  if (blockIdx.x >= *a.nitems) return;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t s0 = a.sstart[S], s1 = a.sstart[S + 1];
+  const uint32_t parts = (s1 - s0 + kPart - 1) / kPart;
+  const bool heavy = parts > 1;  // workgroup-uniform
+  if (MERGE && (!heavy || part != 0 || a.out[0] != 0)) return;  // (out[0]: the build goes the other way)
+  const uint32_t sb = s0 + part * kPart, m = min(s1, sb + kPart) - sb;  // (this item's records)
   // home of a key: (key - first key of the range) >> sh, the range's width cut into at most
   // kEbSlots equal pieces (the last range ends where the shard's key span does; the keys of the
   // last shard beyond it — the division's remainder — share the last home)
@@ -2006,36 +2015,53 @@ k_eb_rank(EbArgs a) {
   for (uint32_t i = tid; i < kEbAll; i += kEbR) tab[i] = xf::kEmptyKey;
   __syncthreads();
   bool bad = false;
-  // records in flight per thread; a range of up to kEbR * E records (the usual one: ranges are
+  auto insert = [&](uint64_t key) {
+    if (key == xf::kEmptyKey || !xf::owns(a.T, key) || key < k0) {
+      bad = true;  // the reserved value, a foreign key: the arrival index knows what to do
+      return;
+    }
+    uint32_t h = (uint32_t)min((key - k0) >> sh, (uint64_t)(kEbSlots - 1));
+    for (;;) {
+      unsigned long long c = tab[h];
+      if (c == xf::kEmptyKey)
+        c = atomicCAS(&tab[h], (unsigned long long)xf::kEmptyKey, (unsigned long long)key);
+      if (c == xf::kEmptyKey || c == key) break;
+      if (++h >= kEbAll) {  // more keys than the set holds
+        bad = true;
+        break;
+      }
+    }
+  };
+  auto rank_of = [&](uint64_t key) -> uint32_t {
+    uint32_t h = (uint32_t)min((key - k0) >> sh, (uint64_t)(kEbSlots - 1));
+    while (tab[h] != key) ++h;  // (the key is there, at or behind its home)
+    const uint32_t g = h / 3, g0 = g * 3;
+    uint32_t rank = gp[g];
+    if (h > g0) rank += tab[g0] != xf::kEmptyKey ? 1u : 0u;
+    if (h > g0 + 1) rank += tab[g0 + 1] != xf::kEmptyKey ? 1u : 0u;
+    return rank;
+  };
+  // records in flight per thread; an item of up to kEbR * E records (the usual one: ranges are
   // cut for 4096) keeps its keys in registers for the second pass
   constexpr int E = 5;
   const bool once = m <= (uint32_t)kEbR * E;  // workgroup-uniform
   uint64_t key[E];
-  for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const uint32_t i = i0 + q * kEbR + tid;
-      const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-      key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+  if (MERGE) {
+    for (uint32_t q = 0; q < parts; ++q) {
+      const uint32_t pb = s0 + q * kPart, pn = a.pd[blockIdx.x + q];
+      for (uint32_t j = tid; j < pn; j += kEbR) insert(a.pkeys[pb + j]);
     }
+  } else {
+    for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-      if (i0 + q * kEbR + tid >= m) continue;
-      if (key[q] == xf::kEmptyKey || !xf::owns(a.T, key[q]) || key[q] < k0) {
-        bad = true;  // the reserved value, a foreign key: the arrival index knows what to do
-        continue;
+      for (int q = 0; q < E; ++q) {
+        const uint32_t i = i0 + q * kEbR + tid;
+        const Rec3 r = i < m ? a.rec[sb + i] : Rec3{0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+        key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
       }
-      uint32_t h = (uint32_t)min((key[q] - k0) >> sh, (uint64_t)(kEbSlots - 1));
-      for (;;) {
-        unsigned long long c = tab[h];
-        if (c == xf::kEmptyKey)
-          c = atomicCAS(&tab[h], (unsigned long long)xf::kEmptyKey, (unsigned long long)key[q]);
-        if (c == xf::kEmptyKey || c == key[q]) break;
-        if (++h >= kEbAll) {  // more keys than the set holds
-          bad = true;
-          break;
-        }
-      }
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if (i0 + q * kEbR + tid < m) insert(key[q]);
     }
   }
   __syncthreads();
@@ -2121,13 +2147,11 @@ k_eb_rank(EbArgs a) {
     if (lane < len) tab[cs + rank] = k;
   }
   if (__syncthreads_or(bad ? 1 : 0)) {  // not this way: the caller takes the arrival index
-    if (tid == 0) {
-      a.dbase[S] = 0;
-      atomicOr(&a.out[0], 1u);
-    }
+    if (tid == 0) atomicOr(&a.out[0], 1u);
     return;
   }
-  // ranks: occupied positions before every group of three
+  // ranks: occupied positions before every group of three; the distinct keys go out in order
+  uint64_t *__restrict__ dst = MERGE || !heavy ? a.ukeys + s0 : a.pkeys + sb;
   unsigned long long mine[kEbPerT];
   uint32_t occ = 0;
 #pragma unroll
@@ -2154,11 +2178,19 @@ k_eb_rank(EbArgs a) {
   for (uint32_t k = 0; k < kEbPerT; ++k) {
     if (k % 3 == 0) gp[(p0 + k) / 3] = (uint16_t)before;
     if (mine[k] != xf::kEmptyKey) {
-      a.ukeys[sb + before] = mine[k];
+      dst[before] = mine[k];
       ++before;
     }
   }
   __syncthreads();
+  if (MERGE) {
+    for (uint32_t q = 0; q < parts; ++q) {
+      const uint32_t pb = s0 + q * kPart, pn = a.pd[blockIdx.x + q];
+      for (uint32_t j = tid; j < pn; j += kEbR) a.pmap[pb + j] = rank_of(a.pkeys[pb + j]);
+    }
+    if (tid == 0) a.dbase[S] = d;
+    return;
+  }
   for (uint32_t i0 = 0; i0 < m; i0 += kEbR * E) {
     if (!once) {
 #pragma unroll
@@ -2171,17 +2203,14 @@ k_eb_rank(EbArgs a) {
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t i = i0 + q * kEbR + tid;
-      if (i >= m) continue;
-      uint32_t h = (uint32_t)min((key[q] - k0) >> sh, (uint64_t)(kEbSlots - 1));
-      while (tab[h] != key[q]) ++h;  // (the key is there, at or behind its home)
-      const uint32_t g = h / 3, g0 = g * 3;
-      uint32_t rank = gp[g];
-      if (h > g0) rank += tab[g0] != xf::kEmptyKey ? 1u : 0u;
-      if (h > g0 + 1) rank += tab[g0 + 1] != xf::kEmptyKey ? 1u : 0u;
-      a.rec_row[sb + i] = rank;
+      if (i < m) a.rec_row[sb + i] = rank_of(key[q]);
     }
   }
-  if (tid == 0) a.dbase[S] = d;
+  if (tid == 0) {
+    if (heavy) a.pd[blockIdx.x] = d;
+    else
+      a.dbase[S] = d;
+  }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -2262,7 +2291,11 @@ k_eb_cells(EbArgs a, ArArgs r) {
       const uint32_t i = i0 + q * kEb + tid;
       ok[q] = i < m;
       rp[q] = ok[q] ? a.rec[sb + i].rp : 0u;
-      row[q] = ok[q] ? a.rec_row[sb + i] + (PLACE ? 0u : L.base) : L.base;
+      row[q] = L.base;
+      if (ok[q]) {
+        const uint32_t rr = a.rec_row[sb + i];  // PLACE: the row; else the key's rank in its part / range
+        row[q] = PLACE ? rr : (s1 - s0 > kPart ? a.pmap[sb + rr] : rr) + L.base;
+      }
       lc[q] = (rp[q] >> kRinBits) * L.nloc + ((row[q] >> kChunkBits) - L.c_lo);
       if (ok[q]) at[q] = atomicAdd(&lcnt[lc[q]], 1u);
       if (!PLACE && ok[q]) a.rec_row[sb + i] = row[q];
@@ -2767,11 +2800,18 @@ static int arrival_build(xf_cells **out, xf_table *t, const uint64_t *d_keys,
     e.n = n;
     e.max_items = max_items;
     e.rec_row = rec_row;
+    e.items = a.items;
+    e.nitems = a.nitems;
     XF_TRY(sc.get(&e.ukeys, n));
-    XF_TRY(sc.get(&e.dbase, nR + 2));
-    XF_TRY(sc.get(&e.out, 2));
-    XF_HIP(hipMemsetAsync(e.out, 0, 8, s));
-    XF_KB_LAUNCH_N(k_eb_rank, nR, kEbR, kEbLds, e);
+    XF_TRY(sc.get(&e.pkeys, n));
+    XF_TRY(sc.get(&e.pmap, n));
+    XF_TRY(sc.get(&e.dbase, (size_t)nR + 2 + 2 + max_items));
+    e.out = e.dbase + nR + 2;
+    e.pd = e.out + 2;
+    // (an empty range has no item to write its count; a part that gives up leaves its count 0)
+    XF_HIP(hipMemsetAsync(e.dbase, 0, ((size_t)nR + 4 + max_items) * 4, s));
+    XF_KB_LAUNCH_N(k_eb_rank<false>, max_items, kEbR, kEbLds, e);
+    XF_KB_LAUNCH_N(k_eb_rank<true>, max_items, kEbR, kEbLds, e);  // (heavy ranges' first parts)
     hipLaunchKernelGGL(k_eb_scan, dim3(1), dim3(1024), 0, s, e);
     XF_HIP(hipMemcpyAsync(hout, e.out, 8, hipMemcpyDeviceToHost, s));
     XF_HIP(hipGetLastError());
