@@ -820,7 +820,9 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
                           capacity=int(nkeys / args.load_factor) + 1024)
     # (code loading, scratch sizing: a two-row update on a private table and the builders' arena
     # sized for a minibatch, as the worker does before its clock starts)
-    capi.check(L.xf_scratch_reserve(R * nnz * 40 + (64 << 20)))
+    # (... or for the table's defrags, 17 B of temporaries per key: this run knows its key space;
+    # an arena that regrows by a GB between two defrags is a hipFree + hipMalloc of that size)
+    capi.check(L.xf_scratch_reserve(max(R * nnz * 40, nkeys * 18) + (64 << 20)))
     warm = SingleGpuTrainer(model="lr", optimizer="ftrl", capacity=1 << 16)
     h = capi.vp()
     capi.check(L.xf_lr_update_dev(C.byref(h), warm.w.h, raw[0][0].data_ptr(), rp.data_ptr(),
