@@ -4,6 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 python -m xflow_amd.build > /tmp/build.log 2>&1 || tail -5 /tmp/build.log
+timeout 1500 python -m pytest tests/test_gpu_cells.py tests/test_gpu_sharded.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
 N8="--rows 400000 --nnz-per-row 25 --keys-per-gpu 12500000 --force-sharded --general-path --schedule owner --no-cpu-baseline"
 (cd /tmp && timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/_n -- python $GRAFT_REPO_ROOT/bench.py $N8 --signal-keys 0 --steps 4 --warmup 2 --repeats 0 --batches 2 --no-owner-leg --key-build-steps 16 > /tmp/_n.out 2>&1)
 F=$(find /tmp/_n -name "*kernel_stats.csv" | head -1)

@@ -182,6 +182,7 @@ k_items_fill(const uint32_t *__restrict__ nsl, const uint32_t *__restrict__ off,
 // the LDS cursors make of it: the forward's fp64 row sums do not depend on it (exact).
 // Replaces rocprim::segmented_radix_sort_keys (2 x 112 us per 1e7 entries, round 2).
 constexpr uint32_t kSortWave = 4096, kSortMax = 1u << 15;
+constexpr uint32_t kSortLine = 128;  // entries of a cell ordered by line only (64 bins)
 constexpr int kSortCells = 4;  // cells (wavefronts) per workgroup
 __device__ __forceinline__ uint32_t sortp(uint32_t i) { return i + (i >> 5); }  // (bank padding)
 __device__ __forceinline__ void lds_wave_sync() {
@@ -284,7 +285,33 @@ k_cells_sort_pos(const uint32_t *__restrict__ entries, uint32_t *__restrict__ ou
     const uint32_t c = c0 + wave;
     if (c < ncell) {  // wave-uniform
       const uint32_t b = cellptr[c], n = cellptr[c + 1] - b;
-      if (n && n <= kSortWave) cell_sort_pos<64>(bins[wave], entries + b, out + b, n, lane);
+      if (n && n <= kSortLine) {
+        // A small cell (an owner's 32-window minibatch: ~50 entries): ordered by the 128-byte
+        // LINE of its position — what the forward's gathers coalesce by — with 64 bins, one per
+        // lane: the 2112 bins of the sort by position, cleared and scanned per cell, were most of
+        // this kernel at that shape (137 us per 10^7 entries).
+        uint32_t *lb = bins[wave];
+        lb[lane] = 0;
+        lds_wave_sync();
+        for (uint32_t i = lane; i < n; i += 64) atomicAdd(&lb[(entries[b + i] >> 5) & 63u], 1u);
+        lds_wave_sync();
+        const uint32_t x = lb[lane];
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t y = __shfl_up(inc, o);
+          if ((int)lane >= o) inc += y;
+        }
+        lb[lane] = inc - x;
+        lds_wave_sync();
+        for (uint32_t i = lane; i < n; i += 64) {
+          const uint32_t e = entries[b + i];
+          out[b + atomicAdd(&lb[(e >> 5) & 63u], 1u)] = e;
+        }
+        lds_wave_sync();
+      } else if (n && n <= kSortWave) {
+        cell_sort_pos<64>(bins[wave], entries + b, out + b, n, lane);
+      }
     }
   }
   __syncthreads();
