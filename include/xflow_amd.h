@@ -501,6 +501,15 @@ int xf_group_selftest(xf_group *g, size_t bytes);
  * Python binding refuses a library whose hash differs from the sources next to it. */
 const char *xf_source_hash(void);
 
+/* The sort at the top of the reference's key build (lr_worker.cc:146-166: all_keys[(fid, sid)],
+ * std::sort by fid) as a device routine: d_sorted_keys = d_keys[0..n) ascending, d_sorted_pos =
+ * their positions, ascending inside a key (what a stable sort gives).  [lo, lo + span] = where
+ * the keys lie (0, UINT64_MAX: anywhere); n < 2^30.  Hashed keys: a partition by uniform key
+ * range + a range sorted in LDS (*by_hand = 1); a power-law head's range, keys that are no
+ * hashes: the library's radix sort (*by_hand = 0).  Waits for the stream. */
+int xf_sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
+                    uint64_t *d_sorted_keys, uint32_t *d_sorted_pos, void *stream, int *by_hand);
+
 /* Diagnostic (tools/kb_timeline.py): wall_clock64 stamps of the phases of the last keyed build
  * made with xf_tune("exp_knob", 200) (a library built with -DXF_EXPERIMENTS; empty otherwise):
  * [histogram | scatter | resolve] workgroups x slots;

@@ -555,3 +555,80 @@ def test_a_table_of_rows_of_16_hashed_initial_values_settles_with_them():
     assert np.array_equal(t.pull(fresh), s.pull(fresh))
     t.check()
     del b
+
+
+# ------------------------------------------------------------ (key, position) in key order
+def _check_sorted(keys, lo=0, span=2**64 - 1, by_hand=None):
+    sk, sp, h = capi.sort_key_pos(keys, lo, span)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(sp, order.astype(np.uint32))
+    assert np.array_equal(sk, keys[order])
+    if by_hand is not None:
+        assert h == by_hand
+    return h
+
+
+@pytest.mark.parametrize("n", [1, 5, 3000, 8192, 70001, 2_000_000])
+def test_sort_key_pos_hashed_keys(n):
+    """xf_sort_key_pos (lr_worker.cc:146-166's std::sort of (fid, sid) as a device routine): hashed
+    keys with repeats go through the hand-written sort — uniform key ranges, a range in LDS —
+    and come out as numpy's stable argsort orders them."""
+    rng = np.random.RandomState(n % 1000)
+    pool = rng.randint(0, 2**63, size=max(1, n // 2)).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    keys = pool[rng.randint(0, len(pool), size=n)]
+    _check_sorted(keys, by_hand=True)
+    # the library's sort (the tests' second implementation) agrees
+    capi.tune("key_build", 1)
+    try:
+        _check_sorted(keys, by_hand=False)
+    finally:
+        capi.tune("key_build", 0)
+
+
+def test_sort_key_pos_hot_keys_pieces_of_every_length():
+    """keys with 2 ... 6000 occurrences in one minibatch: a range's pieces ranked by comparison,
+    sorted by a wavefront, sorted by the workgroup"""
+    rng = np.random.RandomState(7)
+    n = 1_500_000
+    keys = rng.randint(0, 2**63, size=n).astype(np.uint64) * np.uint64(2)
+    at = rng.permutation(n)
+    o = 0
+    for c in [2, 3, 31, 32, 33, 40, 64, 65, 100, 511, 512, 513, 700, 1024, 1560, 2047, 2048, 4000]:
+        keys[at[o:o + c]] = np.uint64(rng.randint(0, 2**63)) * np.uint64(2) + np.uint64(1)
+        o += c
+    # two keys that differ in their lowest bits only (one piece, two keys, hundreds of records)
+    k = np.uint64(rng.randint(0, 2**62)) * np.uint64(4)
+    keys[at[o:o + 300]] = k
+    keys[at[o + 300:o + 700]] = k + np.uint64(1)
+    _check_sorted(keys, by_hand=True)
+
+
+def test_sort_key_pos_key_range_of_a_shard_and_the_extremes():
+    """an owner's keys (shard 5 of 8) with the shard's range given, keys outside the given range,
+    the reserved key value and key 0"""
+    rng = np.random.RandomState(9)
+    span = (2**64 - 1) // 8
+    lo = 5 * span
+    n = 400_000
+    keys = (np.uint64(lo) + rng.randint(0, span >> 1, size=n).astype(np.uint64) * np.uint64(2))
+    keys[rng.randint(0, n, size=2000)] = keys[0]
+    _check_sorted(keys, lo, span, by_hand=True)
+    keys[:7] = np.array([0, 1, 2**64 - 1, 2**64 - 2, lo - 1, lo + span + 1, 2**63], dtype=np.uint64)
+    keys[100:107] = keys[:7]
+    _check_sorted(keys, lo, span, by_hand=True)
+    _check_sorted(keys, by_hand=False)  # (no range given: seven eighths of the ranges empty, the
+                                        # others beyond a range's LDS)
+
+
+def test_sort_key_pos_beyond_its_limits_goes_to_the_library():
+    """a power-law head (one key with a tenth of the nonzeros), keys that are no hashes: still
+    sorted — by the library's radix sort"""
+    rng = np.random.RandomState(11)
+    n = 300_000
+    keys = rng.randint(0, 2**63, size=n).astype(np.uint64) * np.uint64(2)
+    keys[rng.randint(0, n, size=n // 10)] = np.uint64(12345678901234567)
+    assert _check_sorted(keys) is False
+    small = rng.randint(0, 5000, size=n).astype(np.uint64)
+    assert _check_sorted(small) is False
+    _check_sorted(small[:6000], by_hand=True)   # (few enough for one range's LDS)
+    _check_sorted(np.zeros(0, np.uint64))

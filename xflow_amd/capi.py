@@ -175,6 +175,8 @@ SIGNATURES = {
                                         vp]),
     "xf_group_selftest": (C.c_int, [vp, C.c_size_t]),
     "xf_kb_debug_read": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_size_t, u32p]),
+    "xf_sort_key_pos": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp,
+                                  C.POINTER(C.c_int)]),
     "xf_sharded_config_default": (None, [C.POINTER(ShardedConfig)]),
     "xf_sharded_create": (C.c_int, [C.POINTER(vp), vp, C.POINTER(ShardedConfig)]),
     "xf_sharded_destroy": (C.c_int, [vp]),
@@ -294,6 +296,32 @@ def hash_decimal_range(start, n):
     out = np.empty(n, dtype=np.uint64)
     check(lib().xf_hash_decimal_range(start, n, _p(out, u64p)))
     return out
+
+
+def sort_key_pos(keys, lo=0, span=2**64 - 1, repeat=0):
+    """xf_sort_key_pos on a host array (through torch: plumbing): (sorted keys, their positions,
+    by_hand[, ms per call over `repeat` calls])"""
+    import torch
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = len(keys)
+    dk = torch.from_numpy(keys.view(np.int64).copy()).cuda() if n else torch.zeros(1, dtype=torch.int64).cuda()
+    sk = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+    sp = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    h = C.c_int(0)
+    args = (dk.data_ptr(), n, lo, span, sk.data_ptr(), sp.data_ptr(), None, C.byref(h))
+    check(lib().xf_sort_key_pos(*args))
+    ms = None
+    if repeat:
+        import time
+        check(lib().xf_stream_sync(None))
+        t0 = time.perf_counter()
+        for _ in range(repeat):
+            check(lib().xf_sort_key_pos(*args))
+        check(lib().xf_stream_sync(None))
+        ms = (time.perf_counter() - t0) * 1e3 / repeat
+    out = (sk.cpu().numpy().view(np.uint64)[:n], sp.cpu().numpy().view(np.uint32)[:n], bool(h.value))
+    return out + (ms,) if repeat else out
 
 
 def hash_decimal_ids(ids):

@@ -2,6 +2,8 @@
 #ifndef XF_BATCH_H_
 #define XF_BATCH_H_
 
+#include <hip/hip_runtime_api.h>
+
 #include <vector>
 
 #include "xf_common.h"
@@ -74,6 +76,14 @@ namespace xf {
 int blob_alloc(void **p, size_t bytes, size_t *got);
 void blob_free(void *p, size_t bytes);
 void blob_pool_limit(int blobs);  // 0 = no pooling (every free goes back to the driver)
+// (key, position) of d_keys[0..n) in key order, positions ascending inside a key (xf_keybuild.hip:
+// uniform key ranges over [lo, lo + span], a range sorted in LDS).  *done = false: not sorted —
+// beyond its limits — and the caller sorts some other way.  Waits for the stream.
+int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
+                 uint32_t *spos, hipStream_t s, bool *done);
+// ... by that sort, or beyond its limits by the library's radix sort (xf_batch_dev.hip)
+int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
+                     uint32_t *spos, hipStream_t s, bool *by_hand);
 }  // namespace xf
 
 #endif  // XF_BATCH_H_

@@ -7,14 +7,15 @@
 // the host builder's (tests/test_gpu_parity.py::test_device_key_build_equals_host).
 //
 // Pipeline, all on one stream:
-//   1. (key, position) pairs sorted by key           rocPRIM device radix sort (library sort,
-//                                                    as hipBLASLt would be for a plain GEMM)
+//   1. (key, position) pairs sorted by key           xf::sort_key_pos (round 6: uniform key ranges,
+//                                                    a range sorted in LDS); rocPRIM's radix sort
+//                                                    beyond its limits
 //   2. segment heads -> unique index (scan), ukeys / segptr / uidx / coo_row
 //   3. heavy-key list and gradient tiles             flag + scan + scatter (xf_tiling.h rules)
 //   4. panel-major forward view: cell counts (atomics), scan, stable in-row placement with
 //      wave ballots; forward tiles by the same flag + scan + scatter
-// The sort is stable on (key, position): radix sort is stable and positions are the values,
-// so inside a key the occurrences stay in row-major order, like the host builder's.
+// The order is (key, position) — what a stable sort of the keys gives: inside a key the
+// occurrences stay in row-major order, like the host builder's.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -338,6 +339,42 @@ int inclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
 
 }  // namespace
 
+// (key, position) of d_keys[0..n) in key order, positions ascending inside a key.  Round 6: the
+// partition by uniform key range + a range sorted in LDS (xf::sort_key_pos, xf_keybuild.hip);
+// the library's radix sort beyond that sort's limits — a power-law head's range, keys that are
+// no hashes, xf_tune key_build = 1 (the tests' second implementation).
+namespace xf {
+int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
+                     uint32_t *spos, hipStream_t s, bool *by_hand) {
+  bool sorted = false;
+  if (n) XF_TRY(sort_key_pos(d_keys, n, lo, span, sk, spos, s, &sorted));
+  if (by_hand) *by_hand = sorted;
+  if (sorted || !n) return XF_OK;
+  Scratch sc;
+  uint32_t *pos = nullptr;
+  XF_TRY(sc.get(&pos, n));
+  hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, s, pos, (size_t)n);
+  size_t tb = 0;
+  XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, sk, pos, spos, (size_t)n, 0, 64, s));
+  void *tmp = nullptr;
+  XF_TRY(sc.get((char **)&tmp, tb));
+  XF_HIP(rocprim::radix_sort_pairs(tmp, tb, d_keys, sk, pos, spos, (size_t)n, 0, 64, s));
+  XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+  return XF_OK;
+}
+}  // namespace xf
+
+extern "C" int xf_sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
+                               uint64_t *d_sorted_keys, uint32_t *d_sorted_pos, void *stream,
+                               int *by_hand) {
+  XF_REQUIRE(n == 0 || (d_keys && d_sorted_keys && d_sorted_pos), "xf_sort_key_pos: null argument");
+  bool h = false;
+  XF_TRY(xf::sort_key_pos_any(d_keys, n, lo, span, d_sorted_keys, d_sorted_pos,
+                              (hipStream_t)stream, &h));
+  if (by_hand) *by_hand = h ? 1 : 0;
+  return XF_OK;
+}
+
 // Device key build.  d_keys[NNZ], d_rowptr[R+1] (row-relative, d_rowptr[0] == 0),
 // d_labels[R] are device pointers; the compiled batch stays on the device
 // (xf_batch_download brings the arrays to the host for inspection).
@@ -364,12 +401,7 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   XF_TRY(sc.get(&uid1, NNZ));
   uint32_t U = 0;
   if (NNZ) {
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, pos, (size_t)NNZ);
-    size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, sk, pos, spos, (size_t)NNZ, 0, 64, s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, d_keys, sk, pos, spos, (size_t)NNZ, 0, 64, s));
+    XF_TRY(xf::sort_key_pos_any(d_keys, NNZ, 0, ~0ull, sk, spos, s, nullptr));
     // ---- 2. unique index
     hipLaunchKernelGGL(k_heads, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, sk, (size_t)NNZ, head);
     XF_TRY(inclusive_scan_u32(sc, head, uid1, NNZ, s));

@@ -2618,6 +2618,193 @@ k_fm_regroup(FmRegroup g) {
   }
 }
 
+
+// ------------------------------------------------- (key, position) in key order (round 6)
+// The sort at the top of the reference's key build (lr_worker.cc:146-166: all_keys[(fid, sid)],
+// std::sort by fid) where no table stands behind the keys — the worker side of the weight /
+// gradient exchange, the FM fallback, an owner's merged walking order: until round 6 a 64-bit
+// rocPRIM radix sort of (key, position).  The uniform key ranges above are its first level here
+// as well (k_kb_hist_groups / _scan / _scatter with the position as the record's payload); the
+// second runs in LDS, a workgroup per range:
+//   k_sp_sort   the range's records (a few thousand) counted into 8192 equal pieces of the
+//               range's width, staged piece by piece (a counting sort in LDS); a piece holds one
+//               record, sometimes two or three — ranked by comparison, a lane per record — and
+//               now and then the thousand records of one hot key: those are sorted where they lie
+//               by a bitonic network over (key, position) (a wavefront for up to 512 records,
+//               the workgroup beyond); every record leaves for its place in the range's window
+//               of the output.
+// The partition does not keep the positions' order (a tile's records of a range are ranked by an
+// LDS atomic), the comparisons are on (key, position): the result is THE sorted order, as a
+// stable sort's.  A range of more than kSpCap records (a power-law head, keys that are no
+// hashes): the flag goes up and the caller sorts with the library.
+constexpr int kSp = 1024;
+constexpr uint32_t kSpCap = 8192;      // records of a range
+constexpr uint32_t kSpPieces = 8192;   // equal pieces of a range's width
+constexpr uint32_t kSpBrute = 32;      // records of a piece ranked by comparison
+constexpr uint32_t kSpWave = 512;      // ... sorted by one wavefront
+constexpr uint32_t kSpList = 256;      // longer pieces per range and kind (8192 / 33 < 256)
+constexpr size_t kSpLds = (size_t)kSpCap * 12 + ((size_t)kSpPieces + 1 + 2 * kSpList) * 4;
+static_assert(kSpLds <= kDynMax && kSp == kKb, "k_sp_sort: LDS, block_excl_scan's workgroup");
+struct SpArgs {
+  const Rec3 *rec;         // [n] records grouped by key range, rp = the nonzero's position
+  const uint32_t *sstart;  // [nR + 1]
+  const uint64_t *bnd;     // [nR]
+  uint32_t nR;
+  uint64_t last;           // the largest key of the span
+  uint64_t *sk;            // [n] out: keys, ascending
+  uint32_t *spos;          // [n] out: their positions (ascending inside a key)
+  unsigned int *flag;      // != 0: not this way
+};
+
+__global__ void k_sp_iota(uint32_t *__restrict__ p, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    p[i] = i;
+}
+
+// K[0..c), P[0..c) in (key, position) order: the bitonic network whose every comparator puts the
+// smaller element at the lower index (a stage's first step mirrors the upper half), so c need
+// not be a power of two — the elements beyond c are +infinity and never move.  nt threads, t
+// this one's number; sync() between the steps.
+template <typename Sync>
+__device__ __forceinline__ void sp_bitonic(unsigned long long *K, uint32_t *P, uint32_t c,
+                                           uint32_t t, uint32_t nt, Sync sync) {
+  uint32_t n2 = 2;
+  while (n2 < c) n2 <<= 1;
+  auto cx = [&](uint32_t l, uint32_t r) {
+    if (r >= c) return;
+    const unsigned long long kl = K[l], kr = K[r];
+    const uint32_t pl = P[l], pr = P[r];
+    if (kl > kr || (kl == kr && pl > pr)) {
+      K[l] = kr;
+      K[r] = kl;
+      P[l] = pr;
+      P[r] = pl;
+    }
+  };
+  for (uint32_t k = 2; k <= n2; k <<= 1) {
+    const uint32_t h = k >> 1;
+    for (uint32_t i = t; i < n2 / 2; i += nt) {
+      const uint32_t b0 = (i / h) * k, off = i & (h - 1);
+      cx(b0 + off, b0 + k - 1 - off);
+    }
+    sync();
+    for (uint32_t j = h >> 1; j >= 1; j >>= 1) {
+      for (uint32_t i = t; i < n2 / 2; i += nt) {
+        const uint32_t l = (i / j) * 2 * j + (i & (j - 1));
+        cx(l, l + j);
+      }
+      sync();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kSp)
+k_sp_sort(SpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+  unsigned long long *stK = (unsigned long long *)sp_lds;  // [kSpCap] the staged records' keys
+  uint32_t *stP = (uint32_t *)(stK + kSpCap);              // [kSpCap] ... positions
+  uint32_t *st = stP + kSpCap;                             // [kSpPieces + 1] counts, then starts
+  uint32_t *lw = st + kSpPieces + 1;                       // pieces a wavefront sorts
+  uint32_t *lg = lw + kSpList;                             // pieces the workgroup sorts
+  __shared__ uint32_t wsum[kSp / 64], s_nw, s_ng;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t S = blockIdx.x;
+  const uint32_t s0 = a.sstart[S], m = a.sstart[S + 1] - s0;
+  if (m == 0) return;
+  if (m > kSpCap) {  // (workgroup-uniform)
+    if (tid == 0) atomicOr(a.flag, 1u);
+    return;
+  }
+  const uint64_t k0 = a.bnd[S];
+  const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] - 1ull : a.last) - k0;  // width - 1
+  const int bits = 64 - __clzll((long long)(width1 | 1ull));
+  const int sh = bits > 13 ? bits - 13 : 0;
+  static_assert(kSpPieces == 1u << 13, "the shift above");
+  // (a key below the range's first — one that lies below the span, in range 0 — goes with the
+  // first piece, one beyond the span with the last: the comparisons below are on whole keys)
+  auto piece = [&](uint64_t key) -> uint32_t {
+    return key < k0 ? 0u : (uint32_t)min((key - k0) >> sh, (uint64_t)(kSpPieces - 1));
+  };
+  for (uint32_t i = tid; i <= kSpPieces; i += kSp) st[i] = 0;
+  if (tid == 0) s_nw = s_ng = 0;
+  __syncthreads();
+  constexpr int E = (int)(kSpCap / kSp);
+  uint64_t key[E];
+  uint32_t pos[E], pc[E], at[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t i = q * kSp + tid;
+    const Rec3 r = i < m ? a.rec[s0 + i] : Rec3{0u, 0u, 0u};
+    key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    pos[q] = r.rp;
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    pc[q] = piece(key[q]);
+    at[q] = q * kSp + tid < m ? atomicAdd(&st[pc[q]], 1u) : 0u;
+  }
+  __syncthreads();
+  {  // st = exclusive scan of the counts; the long pieces on their lists
+    constexpr uint32_t per = kSpPieces / kSp;
+    uint32_t c[per], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) {
+      c[k] = st[tid * per + k];
+      sum += c[k];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, wsum, &total);
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) {
+      st[tid * per + k] = run;
+      run += c[k];
+      if (c[k] > kSpBrute) {
+        if (c[k] <= kSpWave) lw[atomicAdd(&s_nw, 1u)] = tid * per + k;
+        else
+          lg[atomicAdd(&s_ng, 1u)] = tid * per + k;
+      }
+    }
+    if (tid == 0) st[kSpPieces] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (q * kSp + tid < m) {
+      const uint32_t p = st[pc[q]] + at[q];
+      stK[p] = key[q];
+      stP[p] = pos[q];
+    }
+  __syncthreads();
+  for (uint32_t idx = wave; idx < s_nw; idx += kSp / 64) {  // wave-uniform
+    const uint32_t b = st[lw[idx]], c = st[lw[idx] + 1] - b;
+    sp_bitonic(stK + b, stP + b, c, lane, 64u,
+               [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); });
+  }
+  __syncthreads();
+  for (uint32_t idx = 0; idx < s_ng; ++idx) {  // workgroup-uniform
+    const uint32_t b = st[lg[idx]], c = st[lg[idx] + 1] - b;
+    sp_bitonic(stK + b, stP + b, c, tid, (uint32_t)kSp, [] { lds_barrier(); });
+  }
+  // every record to its place: where it is staged, or — a short piece — at its rank in the piece
+  for (uint32_t p = tid; p < m; p += kSp) {
+    const unsigned long long kk = stK[p];
+    const uint32_t pp = stP[p], pcs = piece(kk);
+    const uint32_t b = st[pcs], c = st[pcs + 1] - b;
+    uint32_t out = p;
+    if (c > 1 && c <= kSpBrute) {
+      uint32_t rank = 0;
+      for (uint32_t q = 0; q < c; ++q) {
+        const unsigned long long kq = stK[b + q];
+        const uint32_t pq = stP[b + q];
+        rank += (kq < kk || (kq == kk && pq < pp)) ? 1u : 0u;
+      }
+      out = b + rank;
+    }
+    a.sk[s0 + out] = kk;
+    a.spos[s0 + out] = pp;
+  }
+}
+
 }  // namespace
 
 namespace xf {
@@ -3438,6 +3625,88 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
   *d_U = ucount + nS;
   *d_miss = &a.sum->miss;
   *ok = true;
+  return XF_OK;
+}
+
+
+// (key, position) of d_keys[0..n) in key order, positions ascending inside a key — what a stable
+// sort of the keys with their indices gives (kernels: "(key, position) in key order" above).
+// [lo, lo + span]: where the keys lie (a shard's key range; 0 and UINT64_MAX for any key) — keys
+// outside it are sorted as well, only slower.  *done = false: not sorted (a range of more than
+// kSpCap records, more nonzeros than the partition takes): the caller sorts some other way.
+// Waits for the stream once (the flag).
+int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
+                 uint32_t *spos, hipStream_t s, bool *done) {
+  *done = false;
+  KbSummary *sum = summary_buf();
+  if (n == 0 || n >= (1u << 30) || !sum || key_build_mode() == 1 ||
+      ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256)
+    return XF_OK;
+  // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap)
+  const uint32_t nR = std::min<uint32_t>(kArMaxRanges, (n + 2999) / 3000);
+  if ((uint64_t)n > (uint64_t)nR * 6000) return XF_OK;
+  Scratch sc;
+  KbArgs a{};
+  uint32_t *iota = nullptr;
+  XF_TRY(sc.get(&iota, n));
+  a.keys = d_keys;
+  a.rowid = iota;  // the record's payload: (window << kRinBits | row in window) of "row" i is i
+  a.W = 1u << kRinBits;
+  a.R = n;
+  a.NNZ = n;
+  a.nwin = (n + a.W - 1) / a.W;
+  a.nS = nR;
+  a.tile = scatter_lds_bytes(nR, kTile) <= kDynMax ? kTile : kTile / 2;
+  a.ntile = (n + a.tile - 1) / a.tile;
+  a.lo = lo;
+  const uint32_t sub = std::max<uint32_t>(1, (a.ntile + 255) / 256);
+  a.span = sub * a.tile;
+  a.nW = (a.ntile + sub - 1) / sub;
+  a.npc = 0;  // (the scan's per-range part alone)
+  const unsigned max_items = nR + n / kPart + 1;
+  uint32_t *part1 = nullptr;
+  XF_TRY(sc.get(&part1, (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 2));
+  a.scount = part1;
+  a.sstart = a.scount + nR;
+  a.items = a.sstart + nR + 1;
+  a.nitems = a.items + max_items;
+  a.wgcnt = a.nitems + 1;
+  a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
+  unsigned int *d_flag = (unsigned int *)(a.tile_r0 + a.ntile + 1);
+  uint64_t *bnd = nullptr;
+  uint16_t *dir = nullptr;
+  XF_TRY(sc.get(&bnd, nR));
+  XF_TRY(sc.get(&dir, nR + 1));
+  XF_TRY(sc.get(&a.rec, n));
+  a.sc.bnd = bnd;
+  a.sc.dir = dir;
+  a.sc.n = nR;
+  a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((span >> 32) + 1), 0xFFFFFFFFull);
+  XF_HIP(hipMemsetAsync(d_flag, 0, 4, s));
+  hipLaunchKernelGGL(k_sp_iota, dim3(std::min<uint32_t>(2048, (n + 255) / 256)), dim3(256), 0, s, iota, n);
+  hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
+  a.scan_part = 1;
+  XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(kPlanWgs + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
+  const size_t sl = scatter_lds_bytes(nR, a.tile);
+  if (a.tile == kTile) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
+  else
+    XF_KB_LAUNCH_N((k_kb_scatter<true, kTile / 2>), a.nW, kKb, sl, a);
+  SpArgs p{};
+  p.rec = a.rec;
+  p.sstart = a.sstart;
+  p.bnd = bnd;
+  p.nR = nR;
+  p.last = lo + span < lo ? ~0ull : lo + span;
+  p.sk = sk;
+  p.spos = spos;
+  p.flag = d_flag;
+  XF_KB_LAUNCH_N(k_sp_sort, nR, kSp, kSpLds, p);
+  unsigned int *h_flag = (unsigned int *)&sum->miss;  // (pinned)
+  XF_HIP(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  *done = *h_flag == 0;
   return XF_OK;
 }
 

@@ -27,7 +27,6 @@
 // (xf_lr_step / xf_fm_step) on a locally compiled minibatch.
 #include <hip/hip_runtime.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <stdlib.h>
 #include <string.h>
@@ -66,6 +65,7 @@ int fm_owner_grad_update(xf_table *w, xf_table *vt, xf_batch *b, xf_workspace *w
                          const float *d_loss, const float *d_vsum, hipStream_t s);
 int fm_forward_records(const xf_dev_batch *b, int k, const float *d_wu, const float *d_vu,
                        void *d_ks, float *d_loss, float *d_pctr, float *d_vsum, hipStream_t s);
+const TableDev &table_dev(const xf_table *t);
 int table_head_rows(const uint64_t *d_keys_sorted, const uint32_t *d_order,
                     const uint32_t *d_rows, size_t n, uint32_t *d_hrow, hipStream_t s);
 int table_update_heads(xf_table *t, const uint32_t *d_hrow, const uint32_t *d_order, size_t n,
@@ -100,12 +100,6 @@ __global__ void k_owner_split(const uint64_t *__restrict__ ukeys, uint32_t U, ui
       hi = mid;
   }
   split[p] = lo;
-}
-
-__global__ void k_iota32(uint32_t *p, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    p[i] = (uint32_t)i;
 }
 
 template <typename T>
@@ -1423,17 +1417,11 @@ static int compile_exchange_tail(xf_sharded *st, xf_sbatch *b, int keep) {
   XF_TRY(b->rkeys_sorted.reserve(b->n_recv));
   XF_TRY(b->rorder.reserve(b->n_recv));
   if (b->n_recv) {
-    xf::Scratch sc;
-    uint32_t *iota = nullptr;
-    XF_TRY(sc.get(&iota, b->n_recv));
-    hipLaunchKernelGGL(k_iota32, dim3(grid_for(b->n_recv)), dim3(kBlock), 0, s, iota, b->n_recv);
-    size_t tb = 0;
-    XF_HIP(rocprim::radix_sort_pairs(nullptr, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
-                                     b->n_recv, 0, 64, s));
-    void *tmp = nullptr;
-    XF_TRY(sc.get((char **)&tmp, tb));
-    XF_HIP(rocprim::radix_sort_pairs(tmp, tb, b->rkeys.p, b->rkeys_sorted.p, iota, b->rorder.p,
-                                     b->n_recv, 0, 64, s));
+    // (round 6: this shard's key range cut into uniform ranges, a range sorted in LDS —
+    // xf::sort_key_pos; the library's radix sort beyond its limits)
+    const xf::TableDev &T = xf::table_dev(st->tw);
+    XF_TRY(xf::sort_key_pos_any(b->rkeys.p, (uint32_t)b->n_recv, T.lo, T.span, b->rkeys_sorted.p,
+                                b->rorder.p, s, nullptr));
     XF_TRY(wait_stream(st, s));
   }
   return XF_OK;
