@@ -616,19 +616,30 @@ def test_sort_key_pos_key_range_of_a_shard_and_the_extremes():
     keys[:7] = np.array([0, 1, 2**64 - 1, 2**64 - 2, lo - 1, lo + span + 1, 2**63], dtype=np.uint64)
     keys[100:107] = keys[:7]
     _check_sorted(keys, lo, span, by_hand=True)
-    _check_sorted(keys, by_hand=False)  # (no range given: seven eighths of the ranges empty, the
-                                        # others beyond a range's LDS)
+    _check_sorted(keys, by_hand=True)   # (no range given: seven eighths of the ranges empty, the
+                                        # others beyond a range's LDS: merged)
 
 
-def test_sort_key_pos_beyond_its_limits_goes_to_the_library():
-    """a power-law head (one key with a tenth of the nonzeros), keys that are no hashes: still
-    sorted — by the library's radix sort"""
+def test_sort_key_pos_heavy_ranges_are_a_merge_sort():
+    """a power-law head (one key with a tenth, a third of the nonzeros; Zipf 1.1), keys that are
+    no hashes (every key in one range), all keys equal: the ranges beyond a range's LDS are
+    sorted part by part and merged — no library sort"""
     rng = np.random.RandomState(11)
     n = 300_000
     keys = rng.randint(0, 2**63, size=n).astype(np.uint64) * np.uint64(2)
     keys[rng.randint(0, n, size=n // 10)] = np.uint64(12345678901234567)
-    assert _check_sorted(keys) is False
+    _check_sorted(keys, by_hand=True)
     small = rng.randint(0, 5000, size=n).astype(np.uint64)
-    assert _check_sorted(small) is False
+    _check_sorted(small, by_hand=True)
     _check_sorted(small[:6000], by_hand=True)   # (few enough for one range's LDS)
+    _check_sorted(small[:8193], by_hand=True)   # (two parts, the second of one record)
+    _check_sorted(np.zeros(20_000, np.uint64) + np.uint64(77), by_hand=True)
     _check_sorted(np.zeros(0, np.uint64))
+    n = 3_000_000
+    table = rng.randint(0, 2**63, size=1_000_000).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    zipf = table[np.minimum(rng.zipf(1.1, size=n), len(table)) - 1]
+    _check_sorted(zipf, by_hand=True)
+    zipf[rng.randint(0, n, size=n // 3)] = table[5]
+    _check_sorted(zipf, by_hand=True)
+    # the shard's range given and not met (all keys in the first of 1000 ranges)
+    _check_sorted(zipf >> np.uint64(12), 0, 2**64 - 1, by_hand=True)

@@ -2635,8 +2635,11 @@ k_fm_regroup(FmRegroup g) {
 //               of the output.
 // The partition does not keep the positions' order (a tile's records of a range are ranked by an
 // LDS atomic), the comparisons are on (key, position): the result is THE sorted order, as a
-// stable sort's.  A range of more than kSpCap records (a power-law head, keys that are no
-// hashes): the flag goes up and the caller sorts with the library.
+// stable sort's.  A range of more than kSpCap records (a power-law head — real click logs have
+// them —, keys that are no hashes) is a merge sort: it goes on a list the host reads with the
+// build's one wait; its parts of kSpCap records are sorted in LDS the same way (k_sp_parts) and
+// merged pair by pair, a pass per doubling (k_sp_merge: an output tile's two inputs found by a
+// search along its diagonal, merged in LDS, eight outputs per thread).
 constexpr int kSp = 1024;
 constexpr uint32_t kSpCap = 8192;      // records of a range
 constexpr uint32_t kSpPieces = 8192;   // equal pieces of a range's width
@@ -2653,7 +2656,15 @@ struct SpArgs {
   uint64_t last;           // the largest key of the span
   uint64_t *sk;            // [n] out: keys, ascending
   uint32_t *spos;          // [n] out: their positions (ascending inside a key)
-  unsigned int *flag;      // != 0: not this way
+  unsigned int *heavy;     // [0] ranges of more than kSpCap records, [1] their parts of kSpCap
+                           // records in all, [2] the longest one's records
+  uint2 *hv;               // [nR] those ranges: (range, its first part's number among all parts)
+  // the merge passes (k_sp_merge): runs of kSpCap << pass records, from (mk, mp) to (ok, op)
+  const uint64_t *mk;
+  const uint32_t *mp;
+  uint64_t *ok;
+  uint32_t *op;
+  uint32_t pass;
 };
 
 __global__ void k_sp_iota(uint32_t *__restrict__ p, uint32_t n) {
@@ -2698,8 +2709,10 @@ __device__ __forceinline__ void sp_bitonic(unsigned long long *K, uint32_t *P, u
   }
 }
 
-__global__ void __launch_bounds__(kSp)
-k_sp_sort(SpArgs a) {
+// records rec[0..m) of range S (all of them, or a part of a heavy range's) to out_k / out_p[0..m)
+__device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const Rec3 *__restrict__ rec,
+                                              uint32_t m, uint64_t *__restrict__ out_k,
+                                              uint32_t *__restrict__ out_p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
   unsigned long long *stK = (unsigned long long *)sp_lds;  // [kSpCap] the staged records' keys
   uint32_t *stP = (uint32_t *)(stK + kSpCap);              // [kSpCap] ... positions
@@ -2708,13 +2721,6 @@ k_sp_sort(SpArgs a) {
   uint32_t *lg = lw + kSpList;                             // pieces the workgroup sorts
   __shared__ uint32_t wsum[kSp / 64], s_nw, s_ng;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t S = blockIdx.x;
-  const uint32_t s0 = a.sstart[S], m = a.sstart[S + 1] - s0;
-  if (m == 0) return;
-  if (m > kSpCap) {  // (workgroup-uniform)
-    if (tid == 0) atomicOr(a.flag, 1u);
-    return;
-  }
   const uint64_t k0 = a.bnd[S];
   const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] - 1ull : a.last) - k0;  // width - 1
   const int bits = 64 - __clzll((long long)(width1 | 1ull));
@@ -2734,7 +2740,7 @@ k_sp_sort(SpArgs a) {
 #pragma unroll
   for (int q = 0; q < E; ++q) {
     const uint32_t i = q * kSp + tid;
-    const Rec3 r = i < m ? a.rec[s0 + i] : Rec3{0u, 0u, 0u};
+    const Rec3 r = i < m ? rec[i] : Rec3{0u, 0u, 0u};
     key[q] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
     pos[q] = r.rp;
   }
@@ -2800,8 +2806,137 @@ k_sp_sort(SpArgs a) {
       }
       out = b + rank;
     }
-    a.sk[s0 + out] = kk;
-    a.spos[s0 + out] = pp;
+    out_k[out] = kk;
+    out_p[out] = pp;
+  }
+}
+
+__global__ void __launch_bounds__(kSp)
+k_sp_sort(SpArgs a) {
+  const uint32_t S = blockIdx.x;
+  const uint32_t s0 = a.sstart[S], m = a.sstart[S + 1] - s0;
+  if (m == 0) return;
+  if (m > kSpCap) {  // (workgroup-uniform) a merge sort's: on the list
+    if (threadIdx.x == 0) {
+      const uint32_t parts = (m + kSpCap - 1) / kSpCap;
+      a.hv[atomicAdd(&a.heavy[0], 1u)] = make_uint2(S, atomicAdd(&a.heavy[1], parts));
+      atomicMax(&a.heavy[2], m);
+    }
+    return;
+  }
+  sp_sort_block(a, S, a.rec + s0, m, a.sk + s0, a.spos + s0);
+}
+
+// part b of the heavy ranges' parts: its range, the range's first record and length, the part's
+// number in the range
+struct SpPart {
+  uint32_t S, s0, m, t;
+};
+__device__ __forceinline__ SpPart sp_part_of(const SpArgs &a, uint32_t b) {
+  __shared__ SpPart sp;
+  for (uint32_t e = threadIdx.x; e < a.heavy[0]; e += blockDim.x) {
+    const uint2 h = a.hv[e];
+    const uint32_t s0 = a.sstart[h.x], m = a.sstart[h.x + 1] - s0;
+    if (b >= h.y && b < h.y + (m + kSpCap - 1) / kSpCap) sp = SpPart{h.x, s0, m, b - h.y};
+  }
+  __syncthreads();
+  return sp;
+}
+
+// a heavy range's parts of kSpCap records, each in (key, position) order where it lies
+__global__ void __launch_bounds__(kSp)
+k_sp_parts(SpArgs a) {
+  const SpPart p = sp_part_of(a, blockIdx.x);
+  const uint32_t o = p.t * kSpCap, m = min(kSpCap, p.m - o);
+  sp_sort_block(a, p.S, a.rec + p.s0 + o, m, a.sk + p.s0 + o, a.spos + p.s0 + o);
+}
+
+// One pass of the heavy ranges' merge sort: runs of L = kSpCap << pass records of (mk, mp) merged
+// pair by pair into (ok, op); a range whose runs are one by now takes no part (the host's last
+// launch, pass = ~0, copies the ranges that ended in the other buffer).  A workgroup per output
+// tile of kSpTile records: the tile's share of the two runs from a search along its first and
+// its last diagonal (a wavefront each, 64 probes a round; no two elements compare equal: the
+// positions differ), both shares into LDS, a thread's eight outputs from a search of its own there.
+constexpr int kSpM = 512;
+constexpr uint32_t kSpTile = 4096;
+static_assert(kSpCap % kSpTile == 0 && kSpTile % kSpM == 0, "k_sp_merge: tiles of a part");
+__global__ void __launch_bounds__(kSpM)
+k_sp_merge(SpArgs a) {
+  __shared__ unsigned long long LK[kSpTile];
+  __shared__ uint32_t LP[kSpTile];
+  __shared__ uint32_t s_ai[2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  constexpr uint32_t kPer = kSpCap / kSpTile;
+  const SpPart p = sp_part_of(a, blockIdx.x / kPer);
+  const uint32_t t0 = (p.t * kPer + blockIdx.x % kPer) * kSpTile;
+  if (t0 >= p.m) return;
+  const uint32_t tn = min(kSpTile, p.m - t0);
+  const uint32_t parts = (p.m + kSpCap - 1) / kSpCap;  // >= 2
+  const uint32_t passes = 32u - (uint32_t)__clz((int)(parts - 1));
+  const uint64_t *__restrict__ mk = a.mk + p.s0;
+  const uint32_t *__restrict__ mp = a.mp + p.s0;
+  uint64_t *__restrict__ ok = a.ok + p.s0;
+  uint32_t *__restrict__ op = a.op + p.s0;
+  if (a.pass == 0xFFFFFFFFu) {
+    if (passes & 1u)
+      for (uint32_t i = tid; i < tn; i += kSpM) {
+        ok[t0 + i] = mk[t0 + i];
+        op[t0 + i] = mp[t0 + i];
+      }
+    return;
+  }
+  if (a.pass >= passes) return;
+  const uint32_t L = kSpCap << a.pass;
+  const uint32_t gb = (t0 / (2 * L)) * 2 * L;  // the pair's first record
+  const uint32_t la = min(L, p.m - gb), lb = min(L, p.m - gb - la);
+  const uint64_t *__restrict__ Ak = mk + gb, *__restrict__ Bk = mk + gb + la;
+  const uint32_t *__restrict__ Ap = mp + gb, *__restrict__ Bp = mp + gb + la;
+  auto less = [](uint64_t k1, uint32_t p1, uint64_t k2, uint32_t p2) {
+    return k1 < k2 || (k1 == k2 && p1 < p2);
+  };
+  const uint32_t o0 = t0 - gb;
+  if (tid < 128) {  // elements of A among the pair's first o outputs: wavefront 0 for o0, 1 for o0 + tn
+    const uint32_t o = tid < 64 ? o0 : o0 + tn;
+    uint32_t lo = o > lb ? o - lb : 0u, hi = min(o, la);
+    while (lo < hi) {  // wave-uniform
+      const uint32_t step = (hi - lo + 63u) / 64u, mid = lo + lane * step;
+      const bool pr = mid < hi && less(Ak[mid], Ap[mid], Bk[o - 1 - mid], Bp[o - 1 - mid]);
+      const uint32_t cnt = (uint32_t)__popcll(__ballot(pr));  // (true for the first cnt lanes)
+      if (cnt == 0) hi = lo;
+      else {
+        hi = min(hi, lo + cnt * step);
+        lo = lo + (cnt - 1) * step + 1;
+      }
+    }
+    if (lane == 0) s_ai[tid >> 6] = lo;
+  }
+  __syncthreads();
+  const uint32_t a0 = s_ai[0], na = s_ai[1] - a0, b0 = o0 - a0, nb = tn - na;
+  for (uint32_t i = tid; i < tn; i += kSpM) {
+    LK[i] = i < na ? Ak[a0 + i] : Bk[b0 + i - na];
+    LP[i] = i < na ? Ap[a0 + i] : Bp[b0 + i - na];
+  }
+  __syncthreads();
+  constexpr uint32_t E = kSpTile / kSpM;
+  const uint32_t d = min(tid * E, tn), de = min(d + E, tn);
+  uint32_t x;  // elements of the tile's A share among its first d outputs
+  {
+    uint32_t lo = d > nb ? d - nb : 0u, hi = min(d, na);
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (less(LK[mid], LP[mid], LK[na + d - 1 - mid], LP[na + d - 1 - mid])) lo = mid + 1;
+      else
+        hi = mid;
+    }
+    x = lo;
+  }
+  uint32_t y = d - x;
+  for (uint32_t i = d; i < de; ++i) {
+    bool from_a = y >= nb;
+    if (!from_a && x < na) from_a = less(LK[x], LP[x], LK[na + y], LP[na + y]);
+    const uint32_t j = from_a ? x++ : na + y++;
+    ok[t0 + i] = LK[j];
+    op[t0 + i] = LP[j];
   }
 }
 
@@ -3632,9 +3767,8 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
 // (key, position) of d_keys[0..n) in key order, positions ascending inside a key — what a stable
 // sort of the keys with their indices gives (kernels: "(key, position) in key order" above).
 // [lo, lo + span]: where the keys lie (a shard's key range; 0 and UINT64_MAX for any key) — keys
-// outside it are sorted as well, only slower.  *done = false: not sorted (a range of more than
-// kSpCap records, more nonzeros than the partition takes): the caller sorts some other way.
-// Waits for the stream once (the flag).
+// outside it are sorted as well, only slower.  *done = false: not sorted (more nonzeros than the
+// partition takes, xf_tune key_build = 1): the caller sorts some other way.  Waits for the stream.
 int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
                  uint32_t *spos, hipStream_t s, bool *done) {
   *done = false;
@@ -3644,7 +3778,6 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
     return XF_OK;
   // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap)
   const uint32_t nR = std::min<uint32_t>(kArMaxRanges, (n + 2999) / 3000);
-  if ((uint64_t)n > (uint64_t)nR * 6000) return XF_OK;
   Scratch sc;
   KbArgs a{};
   uint32_t *iota = nullptr;
@@ -3665,24 +3798,26 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
   a.npc = 0;  // (the scan's per-range part alone)
   const unsigned max_items = nR + n / kPart + 1;
   uint32_t *part1 = nullptr;
-  XF_TRY(sc.get(&part1, (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 2));
+  XF_TRY(sc.get(&part1, (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 4));
   a.scount = part1;
   a.sstart = a.scount + nR;
   a.items = a.sstart + nR + 1;
   a.nitems = a.items + max_items;
   a.wgcnt = a.nitems + 1;
   a.tile_r0 = a.wgcnt + (size_t)a.nW * nR;
-  unsigned int *d_flag = (unsigned int *)(a.tile_r0 + a.ntile + 1);
+  unsigned int *d_heavy = (unsigned int *)(a.tile_r0 + a.ntile + 1);
   uint64_t *bnd = nullptr;
   uint16_t *dir = nullptr;
+  SpArgs p{};
   XF_TRY(sc.get(&bnd, nR));
   XF_TRY(sc.get(&dir, nR + 1));
+  XF_TRY(sc.get(&p.hv, nR));
   XF_TRY(sc.get(&a.rec, n));
   a.sc.bnd = bnd;
   a.sc.dir = dir;
   a.sc.n = nR;
   a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((span >> 32) + 1), 0xFFFFFFFFull);
-  XF_HIP(hipMemsetAsync(d_flag, 0, 4, s));
+  XF_HIP(hipMemsetAsync(d_heavy, 0, 12, s));
   hipLaunchKernelGGL(k_sp_iota, dim3(std::min<uint32_t>(2048, (n + 255) / 256)), dim3(256), 0, s, iota, n);
   hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
   a.scan_part = 1;
@@ -3692,7 +3827,6 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
   if (a.tile == kTile) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
   else
     XF_KB_LAUNCH_N((k_kb_scatter<true, kTile / 2>), a.nW, kKb, sl, a);
-  SpArgs p{};
   p.rec = a.rec;
   p.sstart = a.sstart;
   p.bnd = bnd;
@@ -3700,13 +3834,42 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
   p.last = lo + span < lo ? ~0ull : lo + span;
   p.sk = sk;
   p.spos = spos;
-  p.flag = d_flag;
+  p.heavy = d_heavy;
   XF_KB_LAUNCH_N(k_sp_sort, nR, kSp, kSpLds, p);
-  unsigned int *h_flag = (unsigned int *)&sum->miss;  // (pinned)
-  XF_HIP(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+  unsigned int *h_heavy = (unsigned int *)sum;  // (pinned; three words)
+  static_assert(sizeof(KbSummary) >= 12, "the heavy ranges' three counts");
+  XF_HIP(hipMemcpyAsync(h_heavy, d_heavy, 12, hipMemcpyDeviceToHost, s));
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
-  *done = *h_flag == 0;
+  if (h_heavy[0]) {  // the merge sort of the ranges beyond a range's LDS
+    const uint32_t nparts = h_heavy[1], longest = (h_heavy[2] + kSpCap - 1) / kSpCap;
+    uint64_t *tk = nullptr;
+    uint32_t *tp = nullptr;
+    XF_TRY(sc.get(&tk, n));
+    XF_TRY(sc.get(&tp, n));
+    XF_KB_LAUNCH_N(k_sp_parts, nparts, kSp, kSpLds, p);
+    bool in_tmp = false;
+    const uint32_t nmerge = nparts * (kSpCap / kSpTile);
+    for (uint32_t pass = 0; (1u << pass) < longest; ++pass) {
+      p.pass = pass;
+      p.mk = in_tmp ? tk : sk;
+      p.mp = in_tmp ? tp : spos;
+      p.ok = in_tmp ? sk : tk;
+      p.op = in_tmp ? spos : tp;
+      hipLaunchKernelGGL(k_sp_merge, dim3(nmerge), dim3(kSpM), 0, s, p);
+      in_tmp = !in_tmp;
+    }
+    // (a range of 2^odd parts, or fewer, ended in the other buffer)
+    p.pass = 0xFFFFFFFFu;
+    p.mk = tk;
+    p.mp = tp;
+    p.ok = sk;
+    p.op = spos;
+    hipLaunchKernelGGL(k_sp_merge, dim3(nmerge), dim3(kSpM), 0, s, p);
+    XF_HIP(hipGetLastError());
+    XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+  }
+  *done = true;
   return XF_OK;
 }
 
