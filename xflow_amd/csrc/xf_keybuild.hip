@@ -2629,10 +2629,11 @@ k_fm_regroup(FmRegroup g) {
 //   k_sp_sort   the range's records (a few thousand) counted into 8192 equal pieces of the
 //               range's width, staged piece by piece (a counting sort in LDS); a piece holds one
 //               record, sometimes two or three — ranked by comparison, a lane per record — and
-//               now and then the thousand records of one hot key: those are sorted where they lie
-//               by a bitonic network over (key, position) (a wavefront for up to 512 records,
-//               the workgroup beyond); every record leaves for its place in the range's window
-//               of the output.
+//               now and then the thousand records of one hot key: a piece of up to 128 records
+//               is sorted where it lies by a wavefront (a bitonic network over (key, position)),
+//               a longer one by the workgroup (sp_long_piece: one key's positions, a second
+//               counting sort); every record leaves for its place in the range's window of the
+//               output.
 // The partition does not keep the positions' order (a tile's records of a range are ranked by an
 // LDS atomic), the comparisons are on (key, position): the result is THE sorted order, as a
 // stable sort's.  A range of more than kSpCap records (a power-law head — real click logs have
@@ -2644,7 +2645,7 @@ constexpr int kSp = 1024;
 constexpr uint32_t kSpCap = 8192;      // records of a range
 constexpr uint32_t kSpPieces = 8192;   // equal pieces of a range's width
 constexpr uint32_t kSpBrute = 32;      // records of a piece ranked by comparison
-constexpr uint32_t kSpWave = 512;      // ... sorted by one wavefront
+constexpr uint32_t kSpWave = 128;      // ... sorted by one wavefront (the bitonic network)
 constexpr uint32_t kSpList = 256;      // longer pieces per range and kind (8192 / 33 < 256)
 constexpr size_t kSpLds = (size_t)kSpCap * 12 + ((size_t)kSpPieces + 1 + 2 * kSpList) * 4;
 static_assert(kSpLds <= kDynMax && kSp == kKb, "k_sp_sort: LDS, block_excl_scan's workgroup");
@@ -2707,6 +2708,129 @@ __device__ __forceinline__ void sp_bitonic(unsigned long long *K, uint32_t *P, u
       sync();
     }
   }
+}
+
+// A piece of more than kSpWave records, the workgroup's: nearly always ONE key's (a hot key's
+// records, and now and then a cold neighbour's) — then the order is the positions' order, and
+// positions are spread evenly enough for a second counting sort: the other keys' few records
+// aside, the hot key's positions counted into as many equal pieces of their span as there are
+// records, staged (counters and stage lie where the piece's keys were: they are all the same),
+// ranked by comparison inside a piece.  A piece of several keys with many records each: the
+// bitonic network (91 steps over 8192 records: ~120 us, which made a power-law stream's sort
+// 1.5 ms).  c <= kSpCap; all kSp threads.
+constexpr uint32_t kSpOdd = 32;  // records of other keys a one-key piece may hold
+__device__ __forceinline__ void sp_long_piece(unsigned long long *K, uint32_t *P, uint32_t c,
+                                              uint32_t *wsum) {
+  __shared__ unsigned long long exK[kSpOdd];
+  __shared__ uint32_t exP[kSpOdd], s_nex, s_pmin, s_pmax;
+  const uint32_t tid = threadIdx.x;
+  constexpr int E = (int)(kSpCap / kSp);
+  const unsigned long long kh = K[c / 2];
+  if (tid == 0) {
+    s_nex = 0;
+    s_pmin = 0xFFFFFFFFu;
+    s_pmax = 0;
+  }
+  __syncthreads();
+  uint32_t pp[E], pc[E], at[E], lo = 0xFFFFFFFFu, hi = 0;
+  bool eq[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t i = q * kSp + tid;
+    eq[q] = false;
+    pp[q] = 0;
+    if (i < c) {
+      const unsigned long long kk = K[i];
+      pp[q] = P[i];
+      eq[q] = kk == kh;
+      if (eq[q]) {
+        lo = min(lo, pp[q]);
+        hi = max(hi, pp[q]);
+      } else if (s_nex <= kSpOdd) {  // (a piece of several keys: not thousands of atomics on one word)
+        const uint32_t e = atomicAdd(&s_nex, 1u);
+        if (e < kSpOdd) {
+          exK[e] = kk;
+          exP[e] = pp[q];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+  }
+  if ((tid & 63u) == 0 && lo <= hi) {
+    atomicMin(&s_pmin, lo);
+    atomicMax(&s_pmax, hi);
+  }
+  __syncthreads();
+  const uint32_t nex = s_nex;
+  if (nex > kSpOdd) {  // (workgroup-uniform; nothing was moved)
+    sp_bitonic(K, P, c, tid, (uint32_t)kSp, [] { lds_barrier(); });
+    __syncthreads();
+    return;
+  }
+  const uint32_t ceq = c - nex, pmin = s_pmin;
+  uint32_t np = 1;  // pieces of the positions' span: the largest power of two <= ceq
+  while (np * 2 <= ceq) np *= 2;
+  const int bw = 32 - __clz((int)((s_pmax - pmin) | 1u)), lg = 31 - __clz((int)np);
+  const int sh = bw > lg ? bw - lg : 0;
+  uint32_t *cnt = (uint32_t *)K, *tmp = cnt + np;  // np + ceq <= 2 c words
+  for (uint32_t i = tid; i < np; i += kSp) cnt[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (eq[q]) {
+      pc[q] = (pp[q] - pmin) >> sh;
+      at[q] = atomicAdd(&cnt[pc[q]], 1u);
+    }
+  __syncthreads();
+  {
+    const uint32_t per = (np + kSp - 1) / kSp;  // <= E
+    uint32_t v[E], sum = 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const uint32_t i = tid * per + k;
+      v[k] = (uint32_t)k < per && i < np ? cnt[i] : 0u;
+      sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, wsum, &total);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const uint32_t i = tid * per + k;
+      if ((uint32_t)k < per && i < np) cnt[i] = run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (eq[q]) tmp[cnt[pc[q]] + at[q]] = pp[q];
+  uint32_t nlt = 0;
+  for (uint32_t e = 0; e < nex; ++e) nlt += exK[e] < kh ? 1u : 0u;
+  __syncthreads();
+  for (uint32_t j = tid; j < ceq; j += kSp) {
+    const uint32_t pos = tmp[j], x = (pos - pmin) >> sh;
+    const uint32_t b = cnt[x], e = x + 1 < np ? cnt[x + 1] : ceq;
+    uint32_t rank = 0;
+    for (uint32_t q = b; q < e; ++q) rank += tmp[q] < pos ? 1u : 0u;
+    P[nlt + b + rank] = pos;
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < ceq; j += kSp) K[nlt + j] = kh;
+  if (tid < nex) {
+    const unsigned long long kk = exK[tid];
+    const uint32_t pos = exP[tid];
+    uint32_t r = 0;
+    for (uint32_t e = 0; e < nex; ++e)
+      r += (exK[e] < kk || (exK[e] == kk && exP[e] < pos)) ? 1u : 0u;
+    const uint32_t at2 = kk < kh ? r : ceq + r;
+    K[at2] = kk;
+    P[at2] = pos;
+  }
+  __syncthreads();
 }
 
 // records rec[0..m) of range S (all of them, or a part of a heavy range's) to out_k / out_p[0..m)
@@ -2789,7 +2913,7 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
   __syncthreads();
   for (uint32_t idx = 0; idx < s_ng; ++idx) {  // workgroup-uniform
     const uint32_t b = st[lg[idx]], c = st[lg[idx] + 1] - b;
-    sp_bitonic(stK + b, stP + b, c, tid, (uint32_t)kSp, [] { lds_barrier(); });
+    sp_long_piece(stK + b, stP + b, c, wsum);
   }
   // every record to its place: where it is staged, or — a short piece — at its rank in the piece
   for (uint32_t p = tid; p < m; p += kSp) {
