@@ -81,6 +81,12 @@ void blob_pool_limit(int blobs);  // 0 = no pooling (every free goes back to the
 // beyond its limits — and the caller sorts some other way.  Waits for the stream.
 int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
                  uint32_t *spos, hipStream_t s, bool *done);
+// LR, the worker side of the weight / gradient exchange (xf_keybuild.hip): a minibatch with its
+// sorted unique keys, row offsets and labels on the device — nothing else — and its cells over
+// the unique-key index.  *done = false: beyond that build's limits, nothing was built.
+int batch_compile_lr_dev(xf_batch **out, xf_cells **cells, const uint64_t *d_keys,
+                         const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                         uint32_t NNZ, bool key_sorted_copy, hipStream_t s, bool *done);
 // ... by that sort, or beyond its limits by the library's radix sort (xf_batch_dev.hip)
 int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
                      uint32_t *spos, hipStream_t s, bool *by_hand);

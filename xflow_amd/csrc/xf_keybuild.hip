@@ -1875,7 +1875,8 @@ k_ar_absent(ArArgs a, unsigned long long *__restrict__ out) {
 }
 
 // blk_cell[b] = the largest cell with cellptr[cell] <= kBlk * b, by `spare` workgroups
-__device__ __forceinline__ void ar_blk_cell(const ArArgs &a, uint32_t wg, uint32_t spare) {
+template <typename A>
+__device__ __forceinline__ void ar_blk_cell(const A &a, uint32_t wg, uint32_t spare) {
   const uint32_t ncell = a.nwin * a.nchunk, nblk = (a.n + kBlk - 1) / kBlk;
   for (uint32_t b = wg * blockDim.x + threadIdx.x; b <= nblk; b += spare * blockDim.x) {
     uint32_t lo = 0, hi = ncell;  // cellptr[0] = 0
@@ -2815,7 +2816,7 @@ __device__ __forceinline__ void sp_long_piece(unsigned long long *K, uint32_t *P
     const uint32_t pos = tmp[j], x = (pos - pmin) >> sh;
     const uint32_t b = cnt[x], e = x + 1 < np ? cnt[x + 1] : ceq;
     uint32_t rank = 0;
-    for (uint32_t q = b; q < e; ++q) rank += tmp[q] < pos ? 1u : 0u;
+    for (uint32_t q = b; q < e; ++q) rank += (tmp[q] < pos || (tmp[q] == pos && q < j)) ? 1u : 0u;
     P[nlt + b + rank] = pos;
   }
   __syncthreads();
@@ -2825,7 +2826,7 @@ __device__ __forceinline__ void sp_long_piece(unsigned long long *K, uint32_t *P
     const uint32_t pos = exP[tid];
     uint32_t r = 0;
     for (uint32_t e = 0; e < nex; ++e)
-      r += (exK[e] < kk || (exK[e] == kk && exP[e] < pos)) ? 1u : 0u;
+      r += (exK[e] < kk || (exK[e] == kk && (exP[e] < pos || (exP[e] == pos && e < tid)))) ? 1u : 0u;
     const uint32_t at2 = kk < kh ? r : ceq + r;
     K[at2] = kk;
     P[at2] = pos;
@@ -2923,10 +2924,10 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
     uint32_t out = p;
     if (c > 1 && c <= kSpBrute) {
       uint32_t rank = 0;
-      for (uint32_t q = 0; q < c; ++q) {
-        const unsigned long long kq = stK[b + q];
+      for (uint32_t q = 0; q < c; ++q) {  // (equal records — a key twice in a row, the payload the
+        const unsigned long long kq = stK[b + q];  // row — in the order they are staged in)
         const uint32_t pq = stP[b + q];
-        rank += (kq < kk || (kq == kk && pq < pp)) ? 1u : 0u;
+        rank += (kq < kk || (kq == kk && (pq < pp || (pq == pp && b + q < p)))) ? 1u : 0u;
       }
       out = b + rank;
     }
@@ -3061,6 +3062,175 @@ k_sp_merge(SpArgs a) {
     const uint32_t j = from_a ? x++ : na + y++;
     ok[t0 + i] = LK[j];
     op[t0 + i] = LP[j];
+  }
+}
+
+
+// ------------------------------------------- the worker side of the exchange, LR (round 6)
+// LRWorker::update's key build (lr_worker.cc:146-166) where the table is NOT on this GPU — the
+// worker side of the weight / gradient exchange (schedules sequential / stale1): the minibatch's
+// sorted unique keys (what travels to the owners, once) and its cells over the unique-key index
+// (the weights come back as a dense array in that order).  Until round 6: the library's radix sort
+// of (key, position), a scatter of the unique index by position (k_uidx_coo: 1e7 4-byte stores),
+// the panel-major and key-grouped views nobody reads on this path, and a second library sort on
+// the cell number (cells_build).  Now:
+//   the sort above with the nonzero's ROW as the payload (the partition walks the CSR anyway)
+//   k_wl_count / _scan / _unique   the sorted list's heads: every record's unique index, the keys
+//   k_wc_cells<false>              a range's records counted by cell — its keys' indices are
+//                                  consecutive: (row windows) x (a chunk or two), LDS counters
+//   k_kb_psum / k_kb_scan          (cell part) cellptr, the gradient's work items
+//   k_wc_cells<true>               the entries: slots taken from LDS cursors, one atomic on a
+//                                  cell's cursor per (work item, round, cell)
+// Inside a cell the entries come in no particular order (as the keyed build's).
+constexpr uint32_t kWlBlock = 4 * kKb;  // records per workgroup of k_wl_count / k_wl_unique
+struct WlArgs {
+  const uint64_t *sk;   // [n] sorted keys
+  uint32_t n, nb;
+  uint32_t *bsum;       // [nb + 1] heads per block, then (k_wl_scan) before every block; [nb] = U
+  uint32_t *su;         // [n] out: unique index of every record
+  uint64_t *ukeys;      // [U] out
+};
+__device__ __forceinline__ uint32_t wl_heads(const WlArgs &a, uint32_t j0, bool *h) {
+  uint32_t cnt = 0;
+  uint64_t prev = j0 > 0 && j0 <= a.n ? a.sk[j0 - 1] : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t j = j0 + q;
+    const uint64_t k = j < a.n ? a.sk[j] : 0;
+    h[q] = j < a.n && (j == 0 || k != prev);
+    cnt += h[q] ? 1u : 0u;
+    prev = k;
+  }
+  return cnt;
+}
+__global__ void __launch_bounds__(kKb)
+k_wl_count(WlArgs a) {
+  __shared__ uint32_t wsum[kKb / 64];
+  bool h[4];
+  const uint32_t cnt = wl_heads(a, blockIdx.x * kWlBlock + threadIdx.x * 4, h);
+  uint32_t total;
+  (void)block_excl_scan(cnt, wsum, &total);
+  if (threadIdx.x == 0) a.bsum[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kKb)
+k_wl_scan(WlArgs a) {  // one workgroup
+  __shared__ uint32_t wsum[kKb / 64];
+  uint32_t carry = 0;
+  for (uint32_t i0 = 0; i0 < a.nb; i0 += kKb) {  // workgroup-uniform
+    const uint32_t i = i0 + threadIdx.x, x = i < a.nb ? a.bsum[i] : 0u;
+    uint32_t total;
+    const uint32_t e = block_excl_scan(x, wsum, &total);
+    if (i < a.nb) a.bsum[i] = carry + e;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.bsum[a.nb] = carry;
+}
+__global__ void __launch_bounds__(kKb)
+k_wl_unique(WlArgs a) {
+  __shared__ uint32_t wsum[kKb / 64];
+  bool h[4];
+  const uint32_t j0 = blockIdx.x * kWlBlock + threadIdx.x * 4;
+  const uint32_t cnt = wl_heads(a, j0, h);
+  uint32_t total;
+  uint32_t u = a.bsum[blockIdx.x] + block_excl_scan(cnt, wsum, &total);  // heads before j0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t j = j0 + q;
+    if (j >= a.n) break;
+    if (h[q]) a.ukeys[u++] = a.sk[j];
+    a.su[j] = u - 1;
+  }
+}
+
+struct WcArgs {
+  const uint32_t *su;      // [n] the sorted records' unique-key indices
+  const uint32_t *srp;     // [n] ... rows (window << kRinBits | row in window)
+  const uint32_t *sstart;  // [nR + 1] the key ranges' records
+  const uint32_t *items, *nitems;  // the partition's work items (a range | its part << 16)
+  uint32_t n, max_items, nwin, nchunk;
+  uint32_t *hist, *cellcur, *entries;
+  const uint32_t *cellptr;
+  uint32_t *blk_cell;
+};
+// PLACE = false: the cell counts; true: the entries (the workgroups beyond the items: blk_cell)
+template <bool PLACE>
+__global__ void __launch_bounds__(kEb)
+k_wc_cells(WcArgs a) {
+  __shared__ uint32_t lcnt[kEbCells], lcur[kEbCells];
+  const uint32_t tid = threadIdx.x;
+  if (PLACE && blockIdx.x >= a.max_items) {
+    ar_blk_cell(a, blockIdx.x - a.max_items, gridDim.x - a.max_items);
+    return;
+  }
+  if (blockIdx.x >= *a.nitems) return;
+  const uint32_t item = a.items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  const uint32_t s0 = a.sstart[S], s1 = a.sstart[S + 1];
+  const uint32_t sb = s0 + part * kPart, m = min(s1, sb + kPart) - sb;
+  // the range's keys have consecutive indices: a chunk or two (keys that are no hashes — a
+  // range of thousands of chunks — count and take their slots in memory)
+  const uint32_t c_lo = a.su[s0] >> kChunkBits, nloc = (a.su[s1 - 1] >> kChunkBits) - c_lo + 1;
+  const uint32_t nl = a.nwin * nloc;
+  const bool lds = nloc <= kEbCells && nl <= kEbCells;  // workgroup-uniform
+  if (lds)
+    for (uint32_t i = tid; i < nl; i += kEb) lcnt[i] = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < m; i0 += kEb * 4) {
+    uint32_t rp[4], u[4], lc[4], at[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t i = i0 + q * kEb + tid;
+      ok[q] = i < m;
+      rp[q] = ok[q] ? a.srp[sb + i] : 0u;
+      u[q] = ok[q] ? a.su[sb + i] : c_lo << kChunkBits;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t v = rp[q] >> kRinBits, ch = u[q] >> kChunkBits;
+      lc[q] = v * nloc + (ch - c_lo);
+      at[q] = 0;
+      if (!ok[q]) continue;
+      if (lds) at[q] = atomicAdd(&lcnt[lc[q]], 1u);
+      else if (!PLACE)
+        atomicAdd(&a.hist[v * a.nchunk + ch], 1u);
+      else
+        a.entries[atomicAdd(&a.cellcur[v * a.nchunk + ch], 1u)] =
+            ((ch & xf::kTagMask) << kTagShift) | ((rp[q] & ((1u << kRinBits) - 1u)) << kChunkBits) |
+            (u[q] & (kChunk - 1));
+    }
+    if (PLACE && lds) {  // this round's records take their slots: a cursor moves once per round and cell
+      __syncthreads();
+      for (uint32_t c = tid; c < nl; c += kEb) {
+        const uint32_t k = lcnt[c];
+        if (k) {
+          const uint32_t v = c / nloc, ch = c_lo + (c - v * nloc);
+          lcur[c] = atomicAdd(&a.cellcur[v * a.nchunk + ch], k);
+          lcnt[c] = 0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) {
+          const uint32_t ch = u[q] >> kChunkBits;
+          a.entries[lcur[lc[q]] + at[q]] = ((ch & xf::kTagMask) << kTagShift) |
+                                           ((rp[q] & ((1u << kRinBits) - 1u)) << kChunkBits) |
+                                           (u[q] & (kChunk - 1));
+        }
+      __syncthreads();
+    }
+  }
+  if (!PLACE && lds) {
+    __syncthreads();
+    for (uint32_t c = tid; c < nl; c += kEb) {
+      const uint32_t k = lcnt[c];
+      if (k) {
+        const uint32_t v = c / nloc;
+        atomicAdd(&a.hist[v * a.nchunk + c_lo + (c - v * nloc)], k);
+      }
+    }
   }
 }
 
@@ -3888,30 +4058,55 @@ int fm_build_keyed(xf_table *t, const uint64_t *d_keys, const uint32_t *d_rowptr
 }
 
 
-// (key, position) of d_keys[0..n) in key order, positions ascending inside a key — what a stable
-// sort of the keys with their indices gives (kernels: "(key, position) in key order" above).
-// [lo, lo + span]: where the keys lie (a shard's key range; 0 and UINT64_MAX for any key) — keys
-// outside it are sorted as well, only slower.  *done = false: not sorted (more nonzeros than the
-// partition takes, xf_tune key_build = 1): the caller sorts some other way.  Waits for the stream.
-int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
-                 uint32_t *spos, hipStream_t s, bool *done) {
+// what a caller that goes on with the sorted list takes along (valid while its Scratch lives)
+struct SortExtra {
+  // in: the nonzeros come in CSR order and a record's payload is its ROW (window << kRinBits |
+  // row in window, W rows per window) instead of its position
+  const uint32_t *rowptr = nullptr;
+  uint32_t R = 0, W = 0;
+  bool count_keys = false;  // in: the distinct keys counted as well (the same wait)
+  // out (device unless said otherwise)
+  uint32_t U = 0;           // (host) distinct keys
+  uint32_t *bsum = nullptr; // distinct keys before every block of kWlBlock sorted records
+  const uint32_t *sstart = nullptr, *items = nullptr, *nitems = nullptr;
+  uint32_t nR = 0, max_items = 0;
+};
+
+// (key, payload) of d_keys[0..n) in (key, payload) order — the payload the nonzero's position:
+// what a stable sort of the keys with their indices gives (kernels: "(key, position) in key
+// order" above).  [lo, lo + span]: where the keys lie (a shard's key range; 0 and UINT64_MAX for
+// any key) — keys outside it are sorted as well, only slower.  *done = false: not sorted (more
+// nonzeros than the partition takes, xf_tune key_build = 1): the caller sorts some other way.
+// Waits for the stream; the scratch is the caller's.
+static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint64_t lo,
+                           uint64_t span, uint64_t *sk, uint32_t *spos, hipStream_t s, bool *done,
+                           SortExtra *ex) {
   *done = false;
   KbSummary *sum = summary_buf();
   if (n == 0 || n >= (1u << 30) || !sum || key_build_mode() == 1 ||
       ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256)
     return XF_OK;
+  const bool csr = ex && ex->rowptr;
   // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap)
   const uint32_t nR = std::min<uint32_t>(kArMaxRanges, (n + 2999) / 3000);
-  Scratch sc;
   KbArgs a{};
-  uint32_t *iota = nullptr;
-  XF_TRY(sc.get(&iota, n));
   a.keys = d_keys;
-  a.rowid = iota;  // the record's payload: (window << kRinBits | row in window) of "row" i is i
-  a.W = 1u << kRinBits;
-  a.R = n;
+  if (csr) {
+    a.rowptr = ex->rowptr;
+    a.R = ex->R;
+    a.W = ex->W;
+    a.nwin = std::max<uint32_t>(1, (ex->R + ex->W - 1) / ex->W);
+  } else {
+    uint32_t *iota = nullptr;
+    XF_TRY(sc.get(&iota, n));
+    hipLaunchKernelGGL(k_sp_iota, dim3(std::min<uint32_t>(2048, (n + 255) / 256)), dim3(256), 0, s,
+                       iota, n);
+    a.rowid = iota;  // (window << kRinBits | row in window) of "row" i with 2^kRinBits rows per window is i
+    a.W = 1u << kRinBits;
+    a.R = n;
+    a.nwin = (n + a.W - 1) / a.W;
+  }
   a.NNZ = n;
-  a.nwin = (n + a.W - 1) / a.W;
   a.nS = nR;
   a.tile = scatter_lds_bytes(nR, kTile) <= kDynMax ? kTile : kTile / 2;
   a.ntile = (n + a.tile - 1) / a.tile;
@@ -3937,20 +4132,34 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
   XF_TRY(sc.get(&dir, nR + 1));
   XF_TRY(sc.get(&p.hv, nR));
   XF_TRY(sc.get(&a.rec, n));
+  WlArgs wl{};
+  if (ex && ex->count_keys) {
+    wl.sk = sk;
+    wl.n = n;
+    wl.nb = (n + kWlBlock - 1) / kWlBlock;
+    XF_TRY(sc.get(&wl.bsum, (size_t)wl.nb + 1));
+  }
   a.sc.bnd = bnd;
   a.sc.dir = dir;
   a.sc.n = nR;
   a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((span >> 32) + 1), 0xFFFFFFFFull);
   XF_HIP(hipMemsetAsync(d_heavy, 0, 12, s));
-  hipLaunchKernelGGL(k_sp_iota, dim3(std::min<uint32_t>(2048, (n + 255) / 256)), dim3(256), 0, s, iota, n);
   hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
   a.scan_part = 1;
-  XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
+  if (csr) XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
+  else
+    XF_KB_LAUNCH_N((k_kb_hist_groups<true>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
   hipLaunchKernelGGL(k_kb_scan, dim3(kPlanWgs + (nR + kKb / 64 - 1) / (kKb / 64)), dim3(kKb), 0, s, a);
   const size_t sl = scatter_lds_bytes(nR, a.tile);
-  if (a.tile == kTile) XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
-  else
-    XF_KB_LAUNCH_N((k_kb_scatter<true, kTile / 2>), a.nW, kKb, sl, a);
+  if (a.tile == kTile) {
+    if (csr) XF_KB_LAUNCH_N((k_kb_scatter<false, kTile>), a.nW, kKb, sl, a);
+    else
+      XF_KB_LAUNCH_N((k_kb_scatter<true, kTile>), a.nW, kKb, sl, a);
+  } else {
+    if (csr) XF_KB_LAUNCH_N((k_kb_scatter<false, kTile / 2>), a.nW, kKb, sl, a);
+    else
+      XF_KB_LAUNCH_N((k_kb_scatter<true, kTile / 2>), a.nW, kKb, sl, a);
+  }
   p.rec = a.rec;
   p.sstart = a.sstart;
   p.bnd = bnd;
@@ -3960,8 +4169,17 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
   p.spos = spos;
   p.heavy = d_heavy;
   XF_KB_LAUNCH_N(k_sp_sort, nR, kSp, kSpLds, p);
-  unsigned int *h_heavy = (unsigned int *)sum;  // (pinned; three words)
-  static_assert(sizeof(KbSummary) >= 12, "the heavy ranges' three counts");
+  // (the distinct keys of a list without heavy ranges — the usual one — counted before the wait)
+  auto count_keys = [&]() {
+    hipLaunchKernelGGL(k_wl_count, dim3(wl.nb), dim3(kKb), 0, s, wl);
+    hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(kKb), 0, s, wl);
+  };
+  unsigned int *h_heavy = (unsigned int *)sum;  // (pinned; three words, and the keys' count)
+  static_assert(sizeof(KbSummary) >= 16, "the heavy ranges' three counts, the distinct keys");
+  if (wl.bsum) {
+    count_keys();
+    XF_HIP(hipMemcpyAsync(h_heavy + 3, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
+  }
   XF_HIP(hipMemcpyAsync(h_heavy, d_heavy, 12, hipMemcpyDeviceToHost, s));
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
@@ -3990,9 +4208,151 @@ int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
     p.ok = sk;
     p.op = spos;
     hipLaunchKernelGGL(k_sp_merge, dim3(nmerge), dim3(kSpM), 0, s, p);
+    if (wl.bsum) {
+      count_keys();
+      XF_HIP(hipMemcpyAsync(h_heavy + 3, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
+    }
     XF_HIP(hipGetLastError());
-    XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+    XF_HIP(hipStreamSynchronize(s));
   }
+  if (ex) {
+    ex->U = wl.bsum ? h_heavy[3] : 0;
+    ex->bsum = wl.bsum;
+    ex->sstart = a.sstart;
+    ex->items = a.items;
+    ex->nitems = a.nitems;
+    ex->nR = nR;
+    ex->max_items = max_items;
+  }
+  *done = true;
+  return XF_OK;
+}
+
+int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
+                 uint32_t *spos, hipStream_t s, bool *done) {
+  Scratch sc;
+  return sort_key_pos_sc(sc, d_keys, n, lo, span, sk, spos, s, done, nullptr);
+}
+
+// The worker side of the weight / gradient exchange, LR (kernels: "the worker side of the
+// exchange" above): *out = a minibatch with its sorted unique keys, row offsets and labels on the
+// device (no CSR index of the unique keys, no key-grouped or panel-major view: the LR kernels of
+// that path stream the cells), *cells = its cells over the unique-key index.  *done = false:
+// beyond the sort's limits, nothing was built.  Waits for the stream.
+int batch_compile_lr_dev(xf_batch **out, xf_cells **cells, const uint64_t *d_keys,
+                         const uint32_t *d_rowptr, const int32_t *d_labels, uint32_t R,
+                         uint32_t NNZ, bool key_sorted_copy, hipStream_t s, bool *done) {
+  *done = false;
+  if (NNZ == 0 || R == 0) return XF_OK;
+  Scratch sc;
+  uint64_t *sk = nullptr;
+  uint32_t *srp = nullptr, *su = nullptr;
+  XF_TRY(sc.get(&sk, NNZ));
+  XF_TRY(sc.get(&srp, NNZ));
+  XF_TRY(sc.get(&su, NNZ));
+  SortExtra ex;
+  ex.rowptr = d_rowptr;
+  ex.R = R;
+  {  // (cells_alloc's windows)
+    const uint32_t nwin = std::max<uint32_t>(1, (R + kWinMax - 1) / kWinMax);
+    ex.W = std::max<uint32_t>(1, (R + nwin - 1) / nwin);
+  }
+  ex.count_keys = true;
+  XF_TRY(sort_key_pos_sc(sc, d_keys, NNZ, 0, ~0ull, sk, srp, s, done, &ex));
+  if (!*done) return XF_OK;
+  *done = false;
+  const uint32_t U = ex.U;
+  xf_cells *c = nullptr;
+  XF_TRY(cells_alloc(&c, R, NNZ, U, kCellsUidx, key_sorted_copy, 0, 0));
+  struct Guard {
+    xf_cells *c;
+    xf_batch *b;
+    ~Guard() {
+      if (c) cells_free(c);
+      if (b) xf_batch_free(b);
+    }
+  } guard{c, nullptr};
+  if (c->W != ex.W) return XF_OK;  // (never: cells_alloc's windows are the ones above)
+  xf_batch *b = new xf_batch;
+  guard.b = b;
+  b->R = R;
+  b->NNZ = NNZ;
+  b->U = U;
+  b->on_device_only = true;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_ukeys = 0, o_rowptr = o_ukeys + al((size_t)U * 8);
+  const size_t o_labels = o_rowptr + al(((size_t)R + 1) * 4);
+  char *d = nullptr;
+  XF_TRY(blob_alloc((void **)&d, o_labels + al((size_t)R * 4) + 256, &b->d_blob_bytes));
+  b->d_blob = d;
+  xf_dev_batch &v = b->view;
+  v.R = R;
+  v.NNZ = NNZ;
+  v.U = U;
+  v.ukeys = (const uint64_t *)(d + o_ukeys);
+  v.rowptr = (const uint32_t *)(d + o_rowptr);
+  v.labels = (const int32_t *)(d + o_labels);
+  XF_HIP(hipMemcpyAsync(d + o_rowptr, d_rowptr, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, s));
+  XF_HIP(hipMemcpyAsync(d + o_labels, d_labels, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+  WlArgs wl{};
+  wl.sk = sk;
+  wl.n = NNZ;
+  wl.nb = (NNZ + kWlBlock - 1) / kWlBlock;
+  wl.bsum = ex.bsum;
+  wl.su = su;
+  wl.ukeys = (uint64_t *)(d + o_ukeys);
+  hipLaunchKernelGGL(k_wl_unique, dim3(wl.nb), dim3(kKb), 0, s, wl);
+  // the cells (as the first-touch build's tail)
+  const size_t ncell = (size_t)c->nwin * c->nchunk;
+  KbArgs a{};
+  a.NNZ = NNZ;
+  a.nwin = c->nwin;
+  a.cA = c->nchunk;
+  a.npc = (uint32_t)((ncell + kScanPiece - 1) / kScanPiece);
+  uint32_t *small = nullptr;
+  const size_t n_zero = 4 + ncell;  // the summary and the cell histogram: cleared together
+  XF_TRY(sc.get(&small, n_zero + ncell + a.npc));
+  a.sum = (KbSummary *)small;
+  a.hist = small + 4;
+  a.cellcur = a.hist + ncell;
+  a.psum = a.cellcur + ncell;
+  a.cellptr = c->cellptr;
+  a.entries = c->entries;
+  a.plan = c->plan;
+  a.blk_cell = c->blk_cell;
+  XF_HIP(hipMemsetAsync(small, 0, n_zero * 4, s));
+  WcArgs w{};
+  w.su = su;
+  w.srp = srp;
+  w.sstart = ex.sstart;
+  w.items = ex.items;
+  w.nitems = ex.nitems;
+  w.n = NNZ;
+  w.max_items = ex.max_items;
+  w.nwin = c->nwin;
+  w.nchunk = c->nchunk;
+  w.hist = a.hist;
+  w.cellcur = a.cellcur;
+  w.entries = c->entries;
+  w.cellptr = c->cellptr;
+  w.blk_cell = c->blk_cell;
+  hipLaunchKernelGGL(k_wc_cells<false>, dim3(ex.max_items), dim3(kEb), 0, s, w);
+  a.scan_part = 2;
+  if (a.npc > 1) hipLaunchKernelGGL(k_kb_psum, dim3(a.npc + a.cA / kKb + 1), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_kb_scan, dim3(a.npc + kPlanWgs), dim3(kKb), 0, s, a);
+  hipLaunchKernelGGL(k_wc_cells<true>, dim3(ex.max_items + std::min<uint32_t>(64, ex.nR / 8 + 1)),
+                     dim3(kEb), 0, s, w);
+  KbSummary *sum = summary_buf();
+  XF_HIP(hipMemcpyAsync(sum, a.sum, sizeof(KbSummary), hipMemcpyDeviceToHost, s));
+  XF_HIP(hipGetLastError());
+  XF_HIP(hipStreamSynchronize(s));
+  XF_TRY(cells_fill_items(c, sum->nitems, sum->nsplit, s));
+  XF_TRY(cells_key_sorted_copy(c, s));
+  XF_HIP(hipStreamSynchronize(s));  // (the scratch goes back)
+  guard.c = nullptr;
+  guard.b = nullptr;
+  *out = b;
+  *cells = c;
   *done = true;
   return XF_OK;
 }

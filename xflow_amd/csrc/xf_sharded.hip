@@ -1383,7 +1383,7 @@ static int compile_exchange_tail(xf_sharded *st, xf_sbatch *b, int keep) {
   hipStream_t s = st->main;
   XF_TRY(xf_batch_dims(b->b, &b->R, &b->NNZ, &b->U, nullptr));
   const xf_dev_batch &v = b->b->view;
-  if (st->cfg.model == 0)  // the LR kernels stream cells over the batch's unique-key index
+  if (st->cfg.model == 0 && !b->cells)  // the LR kernels stream cells over the batch's unique-key index
     XF_TRY(xf::cells_build(&b->cells, v.uidx, nullptr, v.rowptr, b->R, b->NNZ, b->U,
                            xf::kCellsUidx, keep != 0, s));
   const int W = st->world;
@@ -1446,6 +1446,33 @@ static int fused_room(xf_sharded *st, xf_sbatch *b) {
   return XF_OK;
 }
 
+// host-array front end of xf::batch_compile_lr_dev (as xf_batch_compile_gpu's: the raw slice
+// uploaded, the build on the GPU)
+static int compile_lr_from_host(xf_sbatch *b, const uint64_t *rowptr, const uint64_t *keys,
+                                const int32_t *labels, size_t row_begin, size_t row_end, int keep,
+                                hipStream_t s, bool *lean) {
+  *lean = false;
+  const size_t R = row_end - row_begin;
+  const uint64_t base = rowptr[row_begin];
+  const size_t NNZ = (size_t)(rowptr[row_end] - base);
+  if (!R || !NNZ || !keys || R >= 0xFFFFFFFFull || NNZ >= 0xFFFFFFFFull) return XF_OK;
+  std::vector<uint32_t> rp(R + 1);
+  for (size_t r = 0; r <= R; ++r) rp[r] = (uint32_t)(rowptr[row_begin + r] - base);
+  xf::Scratch sc;
+  uint64_t *d_keys = nullptr;
+  uint32_t *d_rp = nullptr;
+  int32_t *d_lab = nullptr;
+  XF_TRY(sc.get(&d_keys, NNZ));
+  XF_TRY(sc.get(&d_rp, R + 1));
+  XF_TRY(sc.get(&d_lab, R));
+  XF_HIP(hipMemcpyAsync(d_keys, keys + base, NNZ * 8, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_rp, rp.data(), (R + 1) * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipMemcpyAsync(d_lab, labels + row_begin, R * 4, hipMemcpyHostToDevice, s));
+  XF_HIP(hipStreamSynchronize(s));
+  return xf::batch_compile_lr_dev(&b->b, &b->cells, d_keys, d_rp, d_lab, (uint32_t)R, (uint32_t)NNZ,
+                                  keep != 0, s, lean);
+}
+
 // Compile a minibatch: the key build (lr_worker.cc:146-166) and the static part of the
 // exchange.  COLLECTIVE: every rank of the group calls it, in the same order.  Host arrays
 // (the reader's block arrays and a row slice).  keep != 0: the batch will be replayed.
@@ -1493,7 +1520,9 @@ extern "C" int xf_sharded_compile(xf_sharded *st, xf_sbatch **out, const uint64_
     XF_TRY(xf_batch_compile(&b->b, rowptr, keys, labels, row_begin, row_end));
     XF_TRY(xf_batch_upload(b->b, s));
   } else {
-    XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
+    bool lean = false;
+    if (st->cfg.model == 0) XF_TRY(compile_lr_from_host(b, rowptr, keys, labels, row_begin, row_end, keep, s, &lean));
+    if (!lean) XF_TRY(xf_batch_compile_gpu(&b->b, rowptr, keys, labels, row_begin, row_end, s));
   }
   XF_TRY(compile_exchange_tail(st, b, keep));
   guard.b = nullptr;
@@ -1535,7 +1564,13 @@ extern "C" int xf_sharded_compile_dev(xf_sharded *st, xf_sbatch **out, const uin
     b->oc_keep = keep != 0;
     XF_TRY(compile_owner_dev(st, b, d_keys, d_rowptr, d_labels, R, NNZ));
   } else {
-    XF_TRY(xf_batch_compile_dev(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s));
+    // LR: the keys and the cells, nothing else (xf::batch_compile_lr_dev); FM, or beyond that
+    // build's limits: the minibatch with all its views
+    bool lean = false;
+    if (st->cfg.model == 0)
+      XF_TRY(xf::batch_compile_lr_dev(&b->b, &b->cells, d_keys, d_rowptr, d_labels, R, NNZ, keep != 0,
+                                      s, &lean));
+    if (!lean) XF_TRY(xf_batch_compile_dev(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s));
     XF_TRY(compile_exchange_tail(st, b, keep));
   }
   guard.b = nullptr;
