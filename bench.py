@@ -982,6 +982,37 @@ def n8_shape_leg(args, n1_ms, nsrc=8):
                 del comp, tr
             out[shape] = leg
             del batches
+        # the worker side of the weight / gradient exchange (schedule sequential — the worker's
+        # default, the dataflow north_star words): the minibatch of ONE worker (the N = 1 shape:
+        # its keys lie in every shard) compiled from device arrays + stepped, a group of one
+        if args.key_build_steps > 0:
+            try:
+                a = _ap.Namespace(**vars(args))
+                a.batches, a.zipf, a.model, a.optimizer = 4, 0.0, "lr", "ftrl"
+                kt = make_key_table(a.keys_per_gpu)
+                batches = make_batches(a, 0, a.keys_per_gpu, kt)
+                os.environ.pop("XF_OWNER_TIMING_SOURCES", None)
+                tr = NativeSharded(group, a, "sequential",
+                                   int(a.keys_per_gpu / args.load_factor) + 1024)
+                comp = [tr.compile(*b) for b in batches]
+                for c in comp:
+                    tr.predict(c)
+                tr.check()
+                tr.defrag()
+                del comp
+                wk = with_key_build_sharded(args, tr, batches, a.rows, 1, capi_sync, lambda x: x)
+                out["exchange_worker_side"] = {
+                    "rows": a.rows, "nnz_per_row": a.nnz_per_row, "keys": a.keys_per_gpu,
+                    "ms_per_step": wk["ms_per_step"],
+                    "from_host_arrays_ms_per_step": wk["from_host_arrays_ms_per_step"],
+                    "what": "schedule sequential, one rank: xf_sharded_compile_dev (the "
+                            "hand-written (key, row) sort, the unique keys, the cells over the "
+                            "unique-key index: xf::batch_compile_lr_dev; the owner's merged order: "
+                            "xf_sort_key_pos) + Pull / forward / gradient / Push per minibatch, "
+                            "nothing cached; round 5's build (library sorts): --tune key_build=1"}
+                del tr, batches
+            except Exception as ex:
+                out["exchange_worker_side"] = {"error": str(ex)}
     finally:
         for k, v in saved.items():
             if v is None:
@@ -1092,6 +1123,7 @@ def summary_of(out):
             s["%s_%s_ms" % (tag, rule)] = get(out, "n8_shape", shape, rule, "ms_per_step")
         s[tag + "_with_key_build_ms"] = get(out, "n8_shape", shape, "sum_then_step",
                                            "with_key_build", "ms_per_step")
+    s["exchange_worker_side_ms"] = get(out, "n8_shape", "exchange_worker_side", "ms_per_step")
     s["n8_projected_speedup_sum_then_step"] = get(out, "n8_shape", "weak_1e7_nnz_per_gpu",
                                                   "sum_then_step",
                                                   "projected_speedup_free_exchange")
@@ -2028,7 +2060,8 @@ def main():
     out["summary"] = summary_of(out)
     for k in ("sustained_ms_per_step", "sustained_ratio", "n8_weak_sum_then_step_ms",
               "n8_weak_rank_ordered_ms", "n8_strong_sum_then_step_ms",
-              "n8_strong_rank_ordered_ms", "n8_weak_with_key_build_ms", "fresh_1e+07_examples_per_s",
+              "n8_strong_rank_ordered_ms", "n8_weak_with_key_build_ms", "exchange_worker_side_ms",
+              "fresh_1e+07_examples_per_s",
               "fresh_1e+07_first_minibatch_ms", "fresh_1e+08_examples_per_s",
               "sweep_1e+08_ms_per_step", "sweep_1e+08_gradient_frac",
               "sweep_1e+08_with_key_build_ms", "zipf_ms_per_step", "zipf_gradient_frac",

@@ -41,6 +41,10 @@ stats key_build python $R/tools/kb_knobs.py --knobs 0 --iters 24 --step
 stats fresh_table_1e7 python $R/tools/r6/fresh_probe.py 10000000 40
 stats fresh_table_1e8 python $R/tools/r6/fresh_probe.py 100000000 40
 stats n8_key_build python $R/bench.py $N8O --signal-keys 0 --steps 4 --warmup 2 --repeats 0 --batches 2 --no-owner-leg --key-build-steps 16
+# the worker side of the weight / gradient exchange (schedule sequential, one rank): compile from
+# device arrays + step per minibatch; the hand-written sort alone on the three streams
+stats seq_worker_side python $R/bench.py --force-sharded --general-path --schedule sequential --no-cpu-baseline --steps 4 --warmup 2 --repeats 0 --batches 4 --no-owner-leg --key-build-steps 16
+stats sort_key_pos python $R/tools/r6/sort_probe.py
 stats sweep_1e8 python $R/bench.py $QUIET --no-fm-leg --no-zipf-leg --steps 4 --warmup 2 --repeats 0 --batches 2 --key-build-steps 0 --sweep-keys 100000000
 stats zipf11 python $R/bench.py $QUIET --zipf 1.1 --signal-keys 0 --batches 8 --key-build-steps 0 --repeats 0 --no-fm-leg
 stats fm python $R/tools/fm_leg.py --batches 4

@@ -10,7 +10,7 @@
 //   1. (key, position) pairs sorted by key           xf::sort_key_pos (round 6: uniform key ranges,
 //                                                    a range sorted in LDS); rocPRIM's radix sort
 //                                                    beyond its limits
-//   2. segment heads -> unique index (scan), ukeys / segptr / uidx / coo_row
+//   2. segment heads -> unique index (scan: k_scan_*, by hand), ukeys / segptr / uidx / coo_row
 //   3. heavy-key list and gradient tiles             flag + scan + scatter (xf_tiling.h rules)
 //   4. panel-major forward view: cell counts (atomics), scan, stable in-row placement with
 //      wave ballots; forward tiles by the same flag + scan + scatter
@@ -24,7 +24,6 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -319,22 +318,70 @@ __global__ void k_panel_first(const uint32_t *__restrict__ scan, uint32_t R, uin
 
 using xf::Scratch;
 
-int exclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
-  size_t tb = 0;
-  XF_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
-  void *tmp = nullptr;
-  XF_TRY(sc.get((char **)&tmp, tb));
-  XF_HIP(rocprim::exclusive_scan(tmp, tb, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+// u32 prefix sums (round 6: by hand, the library's scan until then): blocks of kScanBlk elements
+// — their sums, one workgroup over the sums, the blocks again from their bases.  in == out is
+// allowed (a thread reads its 16 neighbouring elements before it writes them).
+constexpr uint32_t kScanPer = 16, kScanBlk = kBlock * kScanPer;
+__global__ void __launch_bounds__(kBlock)
+k_scan_sums(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ bs) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const size_t i0 = (size_t)blockIdx.x * kScanBlk + (size_t)threadIdx.x * kScanPer;
+  uint32_t x = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanPer; ++k) x += i0 + k < n ? in[i0 + k] : 0u;
+  uint32_t total;
+  (void)block_prefix(x, wsum, &total);
+  if (threadIdx.x == 0) bs[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kBlock)
+k_scan_bases(uint32_t *__restrict__ bs, uint32_t nb) {  // one workgroup: exclusive, in place
+  __shared__ uint32_t wsum[kBlock / 64];
+  uint32_t carry = 0;
+  for (uint32_t i0 = 0; i0 < nb; i0 += kBlock) {  // workgroup-uniform trip count
+    const uint32_t i = i0 + threadIdx.x, x = i < nb ? bs[i] : 0u;
+    uint32_t total;
+    const uint32_t e = block_prefix(x, wsum, &total);
+    if (i < nb) bs[i] = carry + e;
+    carry += total;
+  }
+}
+template <bool INCLUSIVE>
+__global__ void __launch_bounds__(kBlock)
+k_scan_apply(const uint32_t *in, uint32_t *out, size_t n, const uint32_t *__restrict__ bs) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const size_t i0 = (size_t)blockIdx.x * kScanBlk + (size_t)threadIdx.x * kScanPer;
+  uint32_t v[kScanPer], x = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanPer; ++k) {
+    v[k] = i0 + k < n ? in[i0 + k] : 0u;
+    x += v[k];
+  }
+  uint32_t total;
+  uint32_t run = bs[blockIdx.x] + block_prefix(x, wsum, &total);
+#pragma unroll
+  for (uint32_t k = 0; k < kScanPer; ++k) {
+    if (INCLUSIVE) run += v[k];
+    if (i0 + k < n) out[i0 + k] = run;
+    if (!INCLUSIVE) run += v[k];
+  }
+}
+template <bool INCLUSIVE>
+int scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+  if (!n) return XF_OK;
+  const uint32_t nb = (uint32_t)((n + kScanBlk - 1) / kScanBlk);
+  uint32_t *bs = nullptr;
+  XF_TRY(sc.get(&bs, nb));
+  hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kBlock), 0, s, in, n, bs);
+  hipLaunchKernelGGL(k_scan_bases, dim3(1), dim3(kBlock), 0, s, bs, nb);
+  hipLaunchKernelGGL(k_scan_apply<INCLUSIVE>, dim3(nb), dim3(kBlock), 0, s, in, out, n, bs);
+  XF_HIP(hipGetLastError());
   return XF_OK;
 }
-
+int exclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+  return scan_u32<false>(sc, in, out, n, s);
+}
 int inclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
-  size_t tb = 0;
-  XF_HIP(rocprim::inclusive_scan(nullptr, tb, in, out, n, rocprim::plus<uint32_t>(), s));
-  void *tmp = nullptr;
-  XF_TRY(sc.get((char **)&tmp, tb));
-  XF_HIP(rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::plus<uint32_t>(), s));
-  return XF_OK;
+  return scan_u32<true>(sc, in, out, n, s);
 }
 
 }  // namespace
