@@ -708,3 +708,77 @@ def test_compile_from_device_arrays_is_the_compile_from_host_arrays(tmp_path):
     same(k[order], ks)
     for f, ref in (("w", ws), ("n", ns), ("z", zs)):
         same(np.concatenate([p[f] for p in parts])[order].reshape(ref.shape), ref)
+
+
+def _awkward_minibatch(step):
+    """rows of 0 ... 60 nonzeros (a third of them empty), a key twice in a row, a field of 8 hot
+    keys, a power-law head that makes its key range a merge sort, a 9000-nonzero row"""
+    rng = np.random.RandomState(900 + step)
+    R, K = 30000, 400000
+    keytab = capi.hash_decimal_range(0, K)
+    lens = np.where(rng.rand(R) < 0.33, 0, rng.randint(1, 61, size=R))
+    lens[17] = 9000
+    n = int(lens.sum())
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    fid = rng.randint(0, K, size=n)
+    hot = rng.rand(n) < 0.2
+    fid[hot] = np.minimum(rng.zipf(1.15, size=int(hot.sum())) - 1, K - 1)
+    sig = rng.rand(n) < 0.03
+    fid[sig] = K - 1 - rng.randint(0, 8, size=int(sig.sum()))
+    fid[1::97] = fid[0:-1:97][:len(fid[1::97])]      # the neighbour's key again: twice in a row
+    return rowptr, keytab[fid], rng.randint(0, 2, size=R).astype(np.int32)
+
+
+def _worker_side_rank(port, mode, outdir, q):
+    try:
+        os.environ["XF_SHARDED_GENERAL"] = "1"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        g = capi.Group(0, 1, "127.0.0.1", port, capi.TRANSPORT_HOST, device=0)
+        st = capi.Sharded(g, model="lr", optimizer="ftrl", capacity=1 << 20, schedule="sequential")
+        capi.tune("key_build", mode)
+        import torch
+        alive = []
+        for s in range(4):
+            rp, ks, lb = _awkward_minibatch(s)
+            if s == 2:      # from device arrays; a one-row minibatch behind it
+                d = (torch.from_numpy(ks.view(np.int64)).cuda(),
+                     torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
+                     torch.from_numpy(lb).cuda())
+                torch.cuda.synchronize()
+                alive.append(st.compile_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                            len(lb), len(ks), keep=False))
+                st.step(alive[-1])
+                alive.append(st.compile(np.array([0, 3], np.uint64), ks[:3].copy(), lb[:1].copy()))
+            else:
+                alive.append(st.compile(rp, ks, lb, keep=(s != 1)))
+            st.step(alive[-1])
+        st.step(alive[0])            # a kept minibatch again (its key-sorted copy)
+        st.check()
+        k, w, n, z = st.w.export()
+        rp, ks, lb = _awkward_minibatch(99)
+        np.savez(os.path.join(outdir, "ws_%d.npz" % mode), k=k, w=w, n=n, z=z,
+                 p=st.predict(st.compile(rp, ks, lb)))
+        st.close()
+        g.close()
+        q.put(None)
+    except Exception:
+        q.put(traceback.format_exc())
+
+
+def test_worker_side_lr_build_equals_the_full_minibatch_build(tmp_path):
+    """schedule sequential at world one (XF_SHARDED_GENERAL=1): the minibatch of the exchange's
+    worker side built by hand — sorted unique keys + cells, xf::batch_compile_lr_dev — trains the
+    table the full minibatch build with the library's sorts (xf_tune key_build = 1) trains, bit
+    for bit, on minibatches with empty rows, repeated keys, hot keys and a power-law head"""
+    ctx = mp.get_context("spawn")
+    for mode in (0, 1):
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_side_rank, args=(free_port(), mode, str(tmp_path), q))
+        p.start()
+        err = q.get(timeout=240)
+        p.join(timeout=60)
+        assert not err, err
+    a, b = np.load(str(tmp_path / "ws_0.npz")), np.load(str(tmp_path / "ws_1.npz"))
+    assert len(a["k"]) > 100000
+    for f in ("k", "w", "n", "z", "p"):
+        same(a[f], b[f])
