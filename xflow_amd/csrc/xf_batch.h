@@ -79,8 +79,11 @@ void blob_pool_limit(int blobs);  // 0 = no pooling (every free goes back to the
 // (key, position) of d_keys[0..n) in key order, positions ascending inside a key (xf_keybuild.hip:
 // uniform key ranges over [lo, lo + span], a range sorted in LDS).  *done = false: not sorted —
 // beyond its limits — and the caller sorts some other way.  Waits for the stream.
+// site: who sorts — the sort remembers per call site (and host thread) whether the stream it saw
+// last was skewed, and looks for hot keys ahead of the partition when it was
+enum { kSortSiteAny = 0, kSortSiteBatch = 1, kSortSiteMerged = 2, kSortSiteLr = 3, kSortSites = 4 };
 int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
-                 uint32_t *spos, hipStream_t s, bool *done);
+                 uint32_t *spos, hipStream_t s, bool *done, uint32_t site = kSortSiteAny);
 // LR, the worker side of the weight / gradient exchange (xf_keybuild.hip): a minibatch with its
 // sorted unique keys, row offsets and labels on the device — nothing else — and its cells over
 // the unique-key index.  *done = false: beyond that build's limits, nothing was built.
@@ -89,7 +92,7 @@ int batch_compile_lr_dev(xf_batch **out, xf_cells **cells, const uint64_t *d_key
                          uint32_t NNZ, bool key_sorted_copy, hipStream_t s, bool *done);
 // ... by that sort, or beyond its limits by the library's radix sort (xf_batch_dev.hip)
 int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
-                     uint32_t *spos, hipStream_t s, bool *by_hand);
+                     uint32_t *spos, hipStream_t s, bool *by_hand, uint32_t site = kSortSiteAny);
 }  // namespace xf
 
 #endif  // XF_BATCH_H_

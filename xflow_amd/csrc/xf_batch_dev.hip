@@ -392,9 +392,9 @@ int inclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
 // no hashes, xf_tune key_build = 1 (the tests' second implementation).
 namespace xf {
 int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
-                     uint32_t *spos, hipStream_t s, bool *by_hand) {
+                     uint32_t *spos, hipStream_t s, bool *by_hand, uint32_t site) {
   bool sorted = false;
-  if (n) XF_TRY(sort_key_pos(d_keys, n, lo, span, sk, spos, s, &sorted));
+  if (n) XF_TRY(sort_key_pos(d_keys, n, lo, span, sk, spos, s, &sorted, site));
   if (by_hand) *by_hand = sorted;
   if (sorted || !n) return XF_OK;
   Scratch sc;
@@ -448,7 +448,7 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   XF_TRY(sc.get(&uid1, NNZ));
   uint32_t U = 0;
   if (NNZ) {
-    XF_TRY(xf::sort_key_pos_any(d_keys, NNZ, 0, ~0ull, sk, spos, s, nullptr));
+    XF_TRY(xf::sort_key_pos_any(d_keys, NNZ, 0, ~0ull, sk, spos, s, nullptr, xf::kSortSiteBatch));
     // ---- 2. unique index
     hipLaunchKernelGGL(k_heads, dim3(grid_for(NNZ)), dim3(kBlock), 0, s, sk, (size_t)NNZ, head);
     XF_TRY(inclusive_scan_u32(sc, head, uid1, NNZ, s));

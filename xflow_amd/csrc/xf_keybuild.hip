@@ -2649,6 +2649,7 @@ constexpr uint32_t kSpBrute = 32;      // records of a piece ranked by compariso
 constexpr uint32_t kSpWave = 128;      // ... sorted by one wavefront (the bitonic network)
 constexpr uint32_t kSpList = 256;      // longer pieces per range and kind (8192 / 33 < 256)
 constexpr size_t kSpLds = (size_t)kSpCap * 12 + ((size_t)kSpPieces + 1 + 2 * kSpList) * 4;
+constexpr uint32_t kSpTileSpan = 4096; // k_sp_tiles: a workgroup's tile groups begin inside so many records
 static_assert(kSpLds <= kDynMax && kSp == kKb, "k_sp_sort: LDS, block_excl_scan's workgroup");
 struct SpArgs {
   const Rec3 *rec;         // [n] records grouped by key range, rp = the nonzero's position
@@ -2658,9 +2659,17 @@ struct SpArgs {
   uint64_t last;           // the largest key of the span
   uint64_t *sk;            // [n] out: keys, ascending
   uint32_t *spos;          // [n] out: their positions (ascending inside a key)
+  uint32_t tbits;          // payload = position: log2 of the partition's tile (a range's records
+                           // lie tile after tile); 0: no use is made of that
+  uint32_t rows;           // != 0: the payload is the nonzero's row and its order inside a key
+                           // is nobody's concern (a range that is ONE key's is copied)
   unsigned int *heavy;     // [0] ranges of more than kSpCap records, [1] their parts of kSpCap
                            // records in all, [2] the longest one's records
   uint2 *hv;               // [nR] those ranges: (range, its first part's number among all parts)
+  // heavy[4], [5] and hv2: the one-key ranges among them whose payload is the position — their
+  // records lie in tile order, a tile's among themselves in none: sorted tile group by tile
+  // group (k_sp_tiles), parts of kSpTileSpan records
+  uint2 *hv2;
   // the merge passes (k_sp_merge): runs of kSpCap << pass records, from (mk, mp) to (ok, op)
   const uint64_t *mk;
   const uint32_t *mp;
@@ -2936,11 +2945,122 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
   }
 }
 
+// Hot keys get ranges of their own.  A key with thousands of records (a power-law head: real
+// click logs have them) makes its uniform range a merge sort's, cold keys and all; found ahead
+// of the partition — a strided sample of the keys, sorted by k_sp_sort as one range, runs of
+// equal keys in it — it becomes the one-key range [key, key + 1) between the uniform boundaries:
+// its records then need their payloads ordered (positions) or nothing at all (rows), and its
+// neighbours are ordinary ranges again.
+//   k_hot_gather   the sample as records of one range
+//   k_sp_sort      (one workgroup) the sample in key order
+//   k_hot_ranges   (one workgroup) the keys with runs of >= T samples (T the smallest that leaves
+//                  at most kHotMax of them), the boundaries — nR0 uniform ones and two per hot key,
+//                  merged; the rest of the nS = nR0 + 2 kHotMax ranges empty behind them — and the
+//                  directory over them (kb_bucket's nS buckets)
+constexpr uint32_t kHotSample = 8192, kHotMax = 128;
+__global__ void k_hot_gather(const uint64_t *__restrict__ keys, uint32_t n, uint32_t ns,
+                             Rec3 *__restrict__ samp, uint32_t *__restrict__ sstart,
+                             uint64_t *__restrict__ bnd0) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    sstart[0] = 0;
+    sstart[1] = ns;
+    bnd0[0] = 0;
+  }
+  if (i >= ns) return;
+  const uint32_t j = (uint32_t)(((uint64_t)i * n) / ns);
+  const uint64_t k = keys[j];
+  samp[i] = Rec3{(uint32_t)k, (uint32_t)(k >> 32), j};
+}
+
+__global__ void __launch_bounds__(kKb)
+k_hot_ranges(const uint64_t *__restrict__ ssk, uint32_t ns, uint64_t lo, uint64_t span,
+             uint32_t nR0, uint32_t nS, uint32_t mult, uint64_t *__restrict__ bnd,
+             uint16_t *__restrict__ dir, unsigned int *__restrict__ nhot) {
+  extern __shared__ uint64_t hr_lds[];
+  uint64_t *lb = hr_lds;        // [nS] the boundaries
+  uint64_t *hot = lb + nS;      // [kHotMax]
+  __shared__ uint32_t wsum[kKb / 64];
+  const uint32_t tid = threadIdx.x;
+  constexpr uint32_t per = kHotSample / kKb;
+  // runs of equal keys in the sorted sample: a thread's `per` neighbouring elements
+  auto long_run = [&](uint32_t i, uint32_t T) {
+    return i < ns && (i == 0 || ssk[i] != ssk[i - 1]) && i + T - 1 < ns && ssk[i + T - 1] == ssk[i];
+  };
+  uint32_t T = 3, H = 0;
+  for (;; T += (T + 1) / 2) {  // 3, 5, 8, 12, 18, ... (workgroup-uniform)
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < per; ++k) c += long_run(tid * per + k, T) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t e = block_excl_scan(c, wsum, &total);
+    if (total <= kHotMax) {
+      H = total;
+      uint32_t at = e;
+      for (uint32_t k = 0; k < per; ++k)
+        if (long_run(tid * per + k, T)) hot[at++] = ssk[tid * per + k];
+      break;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) *nhot = H;
+  // the boundaries: uniform ones u_r = lo + r * step and, per hot key h, h and h + 1, in order
+  // (a uniform one before an equal hot one); the ranges behind them begin at the largest key
+  const uint64_t step = span / nR0;
+  auto uniform_le = [&](uint64_t x) -> uint32_t {  // uniform boundaries <= x
+    if (x < lo) return 0u;
+    const uint64_t q = (x - lo) / (step ? step : 1ull);
+    return (uint32_t)min(q + 1ull, (uint64_t)nR0);
+  };
+  for (uint32_t r = tid; r < nR0; r += kKb) {
+    const uint64_t u = lo + (uint64_t)r * step;
+    uint32_t before = 0;  // hot boundaries < u
+    for (uint32_t j = 0; j < H; ++j) before += (hot[j] < u ? 1u : 0u) + (hot[j] + 1ull < u && hot[j] != ~0ull ? 1u : 0u);
+    lb[r + before] = u;
+  }
+  for (uint32_t j = tid; j < 2 * H; j += kKb) {
+    const uint64_t h = hot[j >> 1];
+    // (the key 2^64 - 1 has no successor: its second boundary is the key itself, an empty range)
+    const uint64_t x = (j & 1u) && h != ~0ull ? h + 1ull : h;
+    uint32_t before = uniform_le(x);
+    for (uint32_t q = 0; q < 2 * H; ++q) {
+      const uint64_t hq = hot[q >> 1];
+      const uint64_t y = (q & 1u) && hq != ~0ull ? hq + 1ull : hq;
+      before += (y < x || (y == x && q < j)) ? 1u : 0u;
+    }
+    lb[before] = x;
+  }
+  for (uint32_t i = nR0 + 2 * H + tid; i < nS; i += kKb) lb[i] = ~0ull;
+  __syncthreads();
+  for (uint32_t i = tid; i < nS; i += kKb) bnd[i] = lb[i];
+  // dir[b] = ranges that begin in buckets < b
+  for (uint32_t b = tid; b <= nS; b += kKb) {
+    uint32_t l = 0, h = nS;  // the first i with bucket(lb[i]) >= b
+    while (l < h) {
+      const uint32_t mid = l + (h - l) / 2;
+      if (kb_bucket(lb[mid], lo, mult, nS) < b) l = mid + 1;
+      else
+        h = mid;
+    }
+    dir[b] = (uint16_t)l;
+  }
+}
+
 __global__ void __launch_bounds__(kSp)
 k_sp_sort(SpArgs a) {
   const uint32_t S = blockIdx.x;
   const uint32_t s0 = a.sstart[S], m = a.sstart[S + 1] - s0;
   if (m == 0) return;
+  // (a hot key's own range, rows as payload: k_sp_copy's — the partition's work items)
+  if (a.rows && S + 1 < a.nR && a.bnd[S + 1] == a.bnd[S] + 1ull) return;
+  if (m > kSpCap && a.tbits && (1u << a.tbits) <= kSpCap - kSpTileSpan && S + 1 < a.nR &&
+      a.bnd[S + 1] == a.bnd[S] + 1ull) {  // a hot key's own range, positions as payload
+    if (threadIdx.x == 0) {
+      const uint32_t parts = (m + kSpTileSpan - 1) / kSpTileSpan;
+      a.hv2[atomicAdd(&a.heavy[4], 1u)] = make_uint2(S, atomicAdd(&a.heavy[5], parts));
+    }
+    return;
+  }
   if (m > kSpCap) {  // (workgroup-uniform) a merge sort's: on the list
     if (threadIdx.x == 0) {
       const uint32_t parts = (m + kSpCap - 1) / kSpCap;
@@ -2952,20 +3072,76 @@ k_sp_sort(SpArgs a) {
   sp_sort_block(a, S, a.rec + s0, m, a.sk + s0, a.spos + s0);
 }
 
+// the records of the one-key ranges as they are (rows as payload: no order inside a key), a
+// workgroup per work item of the partition (kPart records: a head key's 10^6 records copied by
+// the range's ONE workgroup were 0.5 ms)
+__global__ void __launch_bounds__(kSp)
+k_sp_copy(SpArgs a, const uint32_t *__restrict__ items, const uint32_t *__restrict__ nitems) {
+  if (blockIdx.x >= *nitems) return;
+  const uint32_t item = items[blockIdx.x];
+  const uint32_t S = item & 0xFFFFu, part = item >> 16;
+  if (!(S + 1 < a.nR && a.bnd[S + 1] == a.bnd[S] + 1ull)) return;
+  const uint32_t s0 = a.sstart[S], s1 = a.sstart[S + 1];
+  const uint32_t sb = s0 + part * kPart, m = min(s1, sb + kPart) - sb;
+  for (uint32_t i = threadIdx.x; i < m; i += kSp) {
+    const Rec3 r = a.rec[sb + i];
+    a.sk[sb + i] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    a.spos[sb + i] = r.rp;
+  }
+}
+
 // part b of the heavy ranges' parts: its range, the range's first record and length, the part's
 // number in the range
 struct SpPart {
   uint32_t S, s0, m, t;
 };
-__device__ __forceinline__ SpPart sp_part_of(const SpArgs &a, uint32_t b) {
+__device__ __forceinline__ SpPart sp_part_of(const SpArgs &a, uint32_t b, const uint2 *list = nullptr,
+                                             uint32_t nlist = 0, uint32_t granule = kSpCap) {
   __shared__ SpPart sp;
-  for (uint32_t e = threadIdx.x; e < a.heavy[0]; e += blockDim.x) {
-    const uint2 h = a.hv[e];
+  if (!list) {
+    list = a.hv;
+    nlist = a.heavy[0];
+  }
+  for (uint32_t e = threadIdx.x; e < nlist; e += blockDim.x) {
+    const uint2 h = list[e];
     const uint32_t s0 = a.sstart[h.x], m = a.sstart[h.x + 1] - s0;
-    if (b >= h.y && b < h.y + (m + kSpCap - 1) / kSpCap) sp = SpPart{h.x, s0, m, b - h.y};
+    if (b >= h.y && b < h.y + (m + granule - 1) / granule) sp = SpPart{h.x, s0, m, b - h.y};
   }
   __syncthreads();
   return sp;
+}
+
+// A hot key's own range, positions as payload: the partition wrote its records tile after tile
+// (a tile = 1 << tbits consecutive nonzeros), a tile's records among themselves in no order — so
+// the range is in order once every tile group is.  Workgroup t of the range takes the groups
+// that begin in its records [t, t + 1) * kSpTileSpan (at most kSpTileSpan + a tile of them).
+__global__ void __launch_bounds__(kSp)
+k_sp_tiles(SpArgs a) {
+  __shared__ uint32_t s_cut[2];
+  const SpPart p = sp_part_of(a, blockIdx.x, a.hv2, a.heavy[4], kSpTileSpan);
+  const Rec3 *__restrict__ rec = a.rec + p.s0;
+  if (threadIdx.x == 0 || threadIdx.x == 64) {  // the first group that begins at or behind x
+    const uint32_t x = min((p.t + (threadIdx.x ? 1u : 0u)) * kSpTileSpan, p.m);
+    uint32_t cut = x;
+    if (x > 0 && x < p.m) {
+      const uint32_t tau = rec[x].rp >> a.tbits;
+      if ((rec[x - 1].rp >> a.tbits) == tau) {  // inside a group: where the next one begins
+        uint32_t l = x + 1, h = min(x + (1u << a.tbits), p.m);
+        while (l < h) {
+          const uint32_t mid = l + (h - l) / 2;
+          if ((rec[mid].rp >> a.tbits) > tau) h = mid;
+          else
+            l = mid + 1;
+        }
+        cut = l;
+      }
+    }
+    s_cut[threadIdx.x ? 1 : 0] = cut;
+  }
+  __syncthreads();
+  const uint32_t b = s_cut[0], e = s_cut[1];
+  if (e <= b) return;  // (workgroup-uniform)
+  sp_sort_block(a, p.S, rec + b, e - b, a.sk + p.s0 + b, a.spos + p.s0 + b);
 }
 
 // a heavy range's parts of kSpCap records, each in (key, position) order where it lies
@@ -3153,6 +3329,33 @@ struct WcArgs {
   const uint32_t *cellptr;
   uint32_t *blk_cell;
 };
+// counter l of every lane that is `on` up by one, the value before it returned: a range's records
+// fall into a handful of cells (row windows x a chunk or two; ONE chunk for a hot key's range),
+// so the lanes of a wavefront that hold the same counter share one LDS atomic — up to eight
+// distinct counters a wavefront, the lanes left over one by one
+__device__ __forceinline__ uint32_t wc_slot(uint32_t *cnt, uint32_t l, bool on) {
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long todo = __ballot(on);
+  uint32_t slot = 0;
+  bool mine = false;
+  for (int round = 0; todo && round < 8; ++round) {  // wave-uniform
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)l, leader);
+    const bool same = on && !mine && l == l0;
+    const unsigned long long ms = __ballot(same);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cnt[l0], (uint32_t)__popcll(ms));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (same) {
+      slot = base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+      mine = true;
+    }
+    todo &= ~ms;
+  }
+  if (on && !mine) slot = atomicAdd(&cnt[l], 1u);
+  return slot;
+}
+
 // PLACE = false: the cell counts; true: the entries (the workgroups beyond the items: blk_cell)
 template <bool PLACE>
 __global__ void __launch_bounds__(kEb)
@@ -3191,9 +3394,12 @@ k_wc_cells(WcArgs a) {
       const uint32_t v = rp[q] >> kRinBits, ch = u[q] >> kChunkBits;
       lc[q] = v * nloc + (ch - c_lo);
       at[q] = 0;
+      if (lds) {  // (wave-uniform: every lane takes part in the ballots)
+        at[q] = wc_slot(lcnt, lc[q], ok[q]);
+        continue;
+      }
       if (!ok[q]) continue;
-      if (lds) at[q] = atomicAdd(&lcnt[lc[q]], 1u);
-      else if (!PLACE)
+      if (!PLACE)
         atomicAdd(&a.hist[v * a.nchunk + ch], 1u);
       else
         a.entries[atomicAdd(&a.cellcur[v * a.nchunk + ch], 1u)] =
@@ -4080,15 +4286,25 @@ struct SortExtra {
 // Waits for the stream; the scratch is the caller's.
 static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint64_t lo,
                            uint64_t span, uint64_t *sk, uint32_t *spos, hipStream_t s, bool *done,
-                           SortExtra *ex) {
+                           SortExtra *ex, uint32_t site) {
   *done = false;
   KbSummary *sum = summary_buf();
   if (n == 0 || n >= (1u << 30) || !sum || key_build_mode() == 1 ||
       ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256)
     return XF_OK;
   const bool csr = ex && ex->rowptr;
-  // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap)
-  const uint32_t nR = std::min<uint32_t>(kArMaxRanges, (n + 2999) / 3000);
+  // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap), and room
+  // for the hot keys' own ranges (kernels: "hot keys get ranges of their own")
+  // ... looked for when the stream has shown itself skewed: the last sort on this thread met a
+  // range beyond a range's LDS, or found a hot key (the sample costs ~35 us a sort)
+  // (a state per call site: a worker's minibatches and an owner's merged key lists — unique keys
+  // — are different streams)
+  static thread_local bool skewed_at[kSortSites] = {};
+  bool &skewed = skewed_at[site < kSortSites ? site : 0];
+  const uint32_t hot2 =
+      skewed && n >= 65536 && (n + 2999) / 3000 + 2 * kHotMax <= kArMaxRanges ? 2 * kHotMax : 0;
+  const uint32_t nR0 = std::min<uint32_t>(kArMaxRanges - hot2, (n + 2999) / 3000);
+  const uint32_t nR = nR0 + hot2;
   KbArgs a{};
   a.keys = d_keys;
   if (csr) {
@@ -4117,7 +4333,7 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
   a.npc = 0;  // (the scan's per-range part alone)
   const unsigned max_items = nR + n / kPart + 1;
   uint32_t *part1 = nullptr;
-  XF_TRY(sc.get(&part1, (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 4));
+  XF_TRY(sc.get(&part1, (size_t)nR * 2 + 1 + max_items + 1 + (size_t)a.nW * nR + a.ntile + 1 + 8));
   a.scount = part1;
   a.sstart = a.scount + nR;
   a.items = a.sstart + nR + 1;
@@ -4131,6 +4347,7 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
   XF_TRY(sc.get(&bnd, nR));
   XF_TRY(sc.get(&dir, nR + 1));
   XF_TRY(sc.get(&p.hv, nR));
+  XF_TRY(sc.get(&p.hv2, nR));
   XF_TRY(sc.get(&a.rec, n));
   WlArgs wl{};
   if (ex && ex->count_keys) {
@@ -4143,8 +4360,34 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
   a.sc.dir = dir;
   a.sc.n = nR;
   a.sc.mult = (uint32_t)std::min<uint64_t>(((uint64_t)nR << 32) / ((span >> 32) + 1), 0xFFFFFFFFull);
-  XF_HIP(hipMemsetAsync(d_heavy, 0, 12, s));
-  hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
+  XF_HIP(hipMemsetAsync(d_heavy, 0, 24, s));
+  if (hot2) {
+    Rec3 *samp = nullptr;
+    uint64_t *ssk = nullptr, *bnd0 = nullptr;
+    uint32_t *ssp = nullptr, *sst = nullptr;
+    XF_TRY(sc.get(&samp, kHotSample));
+    XF_TRY(sc.get(&ssk, kHotSample));
+    XF_TRY(sc.get(&ssp, kHotSample));
+    XF_TRY(sc.get(&sst, 2));
+    XF_TRY(sc.get(&bnd0, 1));
+    hipLaunchKernelGGL(k_hot_gather, dim3(kHotSample / 256), dim3(256), 0, s, d_keys, n, kHotSample,
+                       samp, sst, bnd0);
+    SpArgs q{};
+    q.rec = samp;
+    q.sstart = sst;
+    q.bnd = bnd0;
+    q.nR = 1;
+    q.last = ~0ull;
+    q.sk = ssk;
+    q.spos = ssp;
+    q.heavy = d_heavy;
+    q.hv = p.hv;
+    XF_KB_LAUNCH_N(k_sp_sort, 1, kSp, kSpLds, q);
+    hipLaunchKernelGGL(k_hot_ranges, dim3(1), dim3(kKb), ((size_t)nR + kHotMax) * 8, s, ssk,
+                       kHotSample, lo, span, nR0, nR, a.sc.mult, bnd, dir, d_heavy + 3);
+  } else {
+    hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
+  }
   a.scan_part = 1;
   if (csr) XF_KB_LAUNCH_N((k_kb_hist_groups<false>), a.nW, kKb, hist_groups_lds_bytes(nR), a);
   else
@@ -4168,21 +4411,39 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
   p.sk = sk;
   p.spos = spos;
   p.heavy = d_heavy;
+  p.rows = csr ? 1u : 0u;
+  p.tbits = csr ? 0u : (a.tile == kTile ? 13u : 12u);
+  static_assert(kTile == 8192, "tbits above");
   XF_KB_LAUNCH_N(k_sp_sort, nR, kSp, kSpLds, p);
+  if (csr && hot2) hipLaunchKernelGGL(k_sp_copy, dim3(max_items), dim3(kSp), 0, s, p, a.items, a.nitems);
   // (the distinct keys of a list without heavy ranges — the usual one — counted before the wait)
   auto count_keys = [&]() {
     hipLaunchKernelGGL(k_wl_count, dim3(wl.nb), dim3(kKb), 0, s, wl);
     hipLaunchKernelGGL(k_wl_scan, dim3(1), dim3(kKb), 0, s, wl);
   };
-  unsigned int *h_heavy = (unsigned int *)sum;  // (pinned; three words, and the keys' count)
-  static_assert(sizeof(KbSummary) >= 16, "the heavy ranges' three counts, the distinct keys");
+  // (pinned: the heavy ranges' three counts, the hot keys found, the distinct keys)
+  static thread_local unsigned int *h_heavy = nullptr;
+  if (!h_heavy) XF_HIP(hipHostMalloc((void **)&h_heavy, 32));
+  constexpr int kU = 6;
   if (wl.bsum) {
     count_keys();
-    XF_HIP(hipMemcpyAsync(h_heavy + 3, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
+    XF_HIP(hipMemcpyAsync(h_heavy + kU, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
   }
-  XF_HIP(hipMemcpyAsync(h_heavy, d_heavy, 12, hipMemcpyDeviceToHost, s));
+  XF_HIP(hipMemcpyAsync(h_heavy, d_heavy, 24, hipMemcpyDeviceToHost, s));
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));
+  skewed = h_heavy[0] != 0 || (hot2 && h_heavy[3] != 0);
+  if (h_heavy[4]) {  // the hot keys' own ranges, tile group by tile group
+    XF_KB_LAUNCH_N(k_sp_tiles, h_heavy[5], kSp, kSpLds, p);
+    if (!h_heavy[0]) {
+      if (wl.bsum) {
+        count_keys();
+        XF_HIP(hipMemcpyAsync(h_heavy + kU, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
+      }
+      XF_HIP(hipGetLastError());
+      XF_HIP(hipStreamSynchronize(s));
+    }
+  }
   if (h_heavy[0]) {  // the merge sort of the ranges beyond a range's LDS
     const uint32_t nparts = h_heavy[1], longest = (h_heavy[2] + kSpCap - 1) / kSpCap;
     uint64_t *tk = nullptr;
@@ -4210,13 +4471,13 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
     hipLaunchKernelGGL(k_sp_merge, dim3(nmerge), dim3(kSpM), 0, s, p);
     if (wl.bsum) {
       count_keys();
-      XF_HIP(hipMemcpyAsync(h_heavy + 3, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
+      XF_HIP(hipMemcpyAsync(h_heavy + kU, wl.bsum + wl.nb, 4, hipMemcpyDeviceToHost, s));
     }
     XF_HIP(hipGetLastError());
     XF_HIP(hipStreamSynchronize(s));
   }
   if (ex) {
-    ex->U = wl.bsum ? h_heavy[3] : 0;
+    ex->U = wl.bsum ? h_heavy[kU] : 0;
     ex->bsum = wl.bsum;
     ex->sstart = a.sstart;
     ex->items = a.items;
@@ -4229,9 +4490,9 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
 }
 
 int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
-                 uint32_t *spos, hipStream_t s, bool *done) {
+                 uint32_t *spos, hipStream_t s, bool *done, uint32_t site) {
   Scratch sc;
-  return sort_key_pos_sc(sc, d_keys, n, lo, span, sk, spos, s, done, nullptr);
+  return sort_key_pos_sc(sc, d_keys, n, lo, span, sk, spos, s, done, nullptr, site);
 }
 
 // The worker side of the weight / gradient exchange, LR (kernels: "the worker side of the
@@ -4258,7 +4519,7 @@ int batch_compile_lr_dev(xf_batch **out, xf_cells **cells, const uint64_t *d_key
     ex.W = std::max<uint32_t>(1, (R + nwin - 1) / nwin);
   }
   ex.count_keys = true;
-  XF_TRY(sort_key_pos_sc(sc, d_keys, NNZ, 0, ~0ull, sk, srp, s, done, &ex));
+  XF_TRY(sort_key_pos_sc(sc, d_keys, NNZ, 0, ~0ull, sk, srp, s, done, &ex, kSortSiteLr));
   if (!*done) return XF_OK;
   *done = false;
   const uint32_t U = ex.U;

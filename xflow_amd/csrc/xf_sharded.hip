@@ -1421,7 +1421,7 @@ static int compile_exchange_tail(xf_sharded *st, xf_sbatch *b, int keep) {
     // xf::sort_key_pos; the library's radix sort beyond its limits)
     const xf::TableDev &T = xf::table_dev(st->tw);
     XF_TRY(xf::sort_key_pos_any(b->rkeys.p, (uint32_t)b->n_recv, T.lo, T.span, b->rkeys_sorted.p,
-                                b->rorder.p, s, nullptr));
+                                b->rorder.p, s, nullptr, xf::kSortSiteMerged));
     XF_TRY(wait_stream(st, s));
   }
   return XF_OK;
