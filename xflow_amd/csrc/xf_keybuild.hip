@@ -2974,15 +2974,19 @@ __global__ void k_hot_gather(const uint64_t *__restrict__ keys, uint32_t n, uint
 }
 
 __global__ void __launch_bounds__(kKb)
-k_hot_ranges(const uint64_t *__restrict__ ssk, uint32_t ns, uint64_t lo, uint64_t span,
+k_hot_ranges(const uint64_t *ssk, uint32_t ns, uint64_t lo, uint64_t span,
              uint32_t nR0, uint32_t nS, uint32_t mult, uint64_t *__restrict__ bnd,
              uint16_t *__restrict__ dir, unsigned int *__restrict__ nhot) {
   extern __shared__ uint64_t hr_lds[];
   uint64_t *lb = hr_lds;        // [nS] the boundaries
   uint64_t *hot = lb + nS;      // [kHotMax]
+  uint64_t *sm = hot + kHotMax; // [kHotSample] the sorted sample
   __shared__ uint32_t wsum[kKb / 64];
   const uint32_t tid = threadIdx.x;
   constexpr uint32_t per = kHotSample / kKb;
+  for (uint32_t i = tid; i < ns; i += kKb) sm[i] = ssk[i];
+  __syncthreads();
+  ssk = sm;
   // runs of equal keys in the sorted sample: a thread's `per` neighbouring elements
   auto long_run = [&](uint32_t i, uint32_t T) {
     return i < ns && (i == 0 || ssk[i] != ssk[i - 1]) && i + T - 1 < ns && ssk[i + T - 1] == ssk[i];
@@ -3120,28 +3124,53 @@ k_sp_tiles(SpArgs a) {
   __shared__ uint32_t s_cut[2];
   const SpPart p = sp_part_of(a, blockIdx.x, a.hv2, a.heavy[4], kSpTileSpan);
   const Rec3 *__restrict__ rec = a.rec + p.s0;
-  if (threadIdx.x == 0 || threadIdx.x == 64) {  // the first group that begins at or behind x
-    const uint32_t x = min((p.t + (threadIdx.x ? 1u : 0u)) * kSpTileSpan, p.m);
+  if (threadIdx.x < 128) {  // the first group that begins at or behind x: a wavefront per cut
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = min((p.t + wv) * kSpTileSpan, p.m);
     uint32_t cut = x;
-    if (x > 0 && x < p.m) {
+    if (x > 0 && x < p.m) {  // wave-uniform
       const uint32_t tau = rec[x].rp >> a.tbits;
       if ((rec[x - 1].rp >> a.tbits) == tau) {  // inside a group: where the next one begins
+        // the first j in [l, h) whose tile is behind tau, or h: 64 probes a round
         uint32_t l = x + 1, h = min(x + (1u << a.tbits), p.m);
         while (l < h) {
-          const uint32_t mid = l + (h - l) / 2;
-          if ((rec[mid].rp >> a.tbits) > tau) h = mid;
-          else
-            l = mid + 1;
+          const uint32_t step = (h - l + 63u) / 64u, probe = l + lane * step;
+          const bool valid = probe < h;
+          const bool pr = valid && (rec[probe].rp >> a.tbits) > tau;
+          const unsigned long long bal = __ballot(pr);
+          if (!bal) l += (uint32_t)__popcll(__ballot(valid)) * step - step + 1;
+          else {
+            const uint32_t f = (uint32_t)__ffsll((long long)bal) - 1;
+            h = l + f * step;
+            l = f ? h - step + 1 : h;
+          }
         }
         cut = l;
       }
     }
-    s_cut[threadIdx.x ? 1 : 0] = cut;
+    if (lane == 0) s_cut[wv] = cut;
   }
   __syncthreads();
   const uint32_t b = s_cut[0], e = s_cut[1];
   if (e <= b) return;  // (workgroup-uniform)
-  sp_sort_block(a, p.S, rec + b, e - b, a.sk + p.s0 + b, a.spos + p.s0 + b);
+  // one key's records: nothing to count by key (8192 LDS atomics on one counter: 14 us) — staged
+  // as they come, ordered by position (sp_long_piece)
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+  unsigned long long *stK = (unsigned long long *)sp_lds;
+  uint32_t *stP = (uint32_t *)(stK + kSpCap);
+  __shared__ uint32_t wsum[kSp / 64];
+  const uint32_t m = e - b;
+  for (uint32_t i = threadIdx.x; i < m; i += kSp) {
+    const Rec3 r = rec[b + i];
+    stK[i] = (uint64_t)r.klo | ((uint64_t)r.khi << 32);
+    stP[i] = r.rp;
+  }
+  __syncthreads();
+  sp_long_piece(stK, stP, m, wsum);
+  for (uint32_t i = threadIdx.x; i < m; i += kSp) {
+    a.sk[p.s0 + b + i] = stK[i];
+    a.spos[p.s0 + b + i] = stP[i];
+  }
 }
 
 // a heavy range's parts of kSpCap records, each in (key, position) order where it lies
@@ -4383,8 +4412,16 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
     q.heavy = d_heavy;
     q.hv = p.hv;
     XF_KB_LAUNCH_N(k_sp_sort, 1, kSp, kSpLds, q);
-    hipLaunchKernelGGL(k_hot_ranges, dim3(1), dim3(kKb), ((size_t)nR + kHotMax) * 8, s, ssk,
-                       kHotSample, lo, span, nR0, nR, a.sc.mult, bnd, dir, d_heavy + 3);
+    {
+      static bool attr_done = false;
+      if (!attr_done) {
+        XF_HIP(hipFuncSetAttribute((const void *)k_hot_ranges,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynMax));
+        attr_done = true;
+      }
+    }
+    hipLaunchKernelGGL(k_hot_ranges, dim3(1), dim3(kKb), ((size_t)nR + kHotMax + kHotSample) * 8, s,
+                       ssk, kHotSample, lo, span, nR0, nR, a.sc.mult, bnd, dir, d_heavy + 3);
   } else {
     hipLaunchKernelGGL(k_ar_ranges, dim3((nR + 256) / 256), dim3(256), 0, s, lo, nR, a.sc.mult, bnd, dir);
   }
