@@ -504,9 +504,11 @@ const char *xf_source_hash(void);
 /* The sort at the top of the reference's key build (lr_worker.cc:146-166: all_keys[(fid, sid)],
  * std::sort by fid) as a device routine: d_sorted_keys = d_keys[0..n) ascending, d_sorted_pos =
  * their positions, ascending inside a key (what a stable sort gives).  [lo, lo + span] = where
- * the keys lie (0, UINT64_MAX: anywhere); n < 2^30.  Hashed keys: a partition by uniform key
- * range + a range sorted in LDS (*by_hand = 1); a power-law head's range, keys that are no
- * hashes: the library's radix sort (*by_hand = 0).  Waits for the stream. */
+ * the keys lie (0, UINT64_MAX: anywhere); n < 2^30.  Hand-written (*by_hand = 1): a partition by
+ * uniform key range + a range sorted in LDS; a range beyond the LDS (a power-law head, keys that
+ * are no hashes) is merged from sorted parts, a skewed stream's hot keys get ranges of their own.
+ * The library's radix sort (*by_hand = 0) beyond 3.3e7 keys and under xf_tune("key_build", 1).
+ * Waits for the stream. */
 int xf_sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span,
                     uint64_t *d_sorted_keys, uint32_t *d_sorted_pos, void *stream, int *by_hand);
 

@@ -9,7 +9,7 @@
 // Pipeline, all on one stream:
 //   1. (key, position) pairs sorted by key           xf::sort_key_pos (round 6: uniform key ranges,
 //                                                    a range sorted in LDS); rocPRIM's radix sort
-//                                                    beyond its limits
+//                                                    beyond 3.3e7 keys
 //   2. segment heads -> unique index (scan: k_scan_*, by hand), ukeys / segptr / uidx / coo_row
 //   3. heavy-key list and gradient tiles             flag + scan + scatter (xf_tiling.h rules)
 //   4. panel-major forward view: cell counts (atomics), scan, stable in-row placement with
@@ -388,8 +388,8 @@ int inclusive_scan_u32(Scratch &sc, const uint32_t *in, uint32_t *out, size_t n,
 
 // (key, position) of d_keys[0..n) in key order, positions ascending inside a key.  Round 6: the
 // partition by uniform key range + a range sorted in LDS (xf::sort_key_pos, xf_keybuild.hip);
-// the library's radix sort beyond that sort's limits — a power-law head's range, keys that are
-// no hashes, xf_tune key_build = 1 (the tests' second implementation).
+// the library's radix sort beyond that sort's limits — more than 3.3e7 keys — and under
+// xf_tune key_build = 1 (the tests' second implementation).
 namespace xf {
 int sort_key_pos_any(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
                      uint32_t *spos, hipStream_t s, bool *by_hand, uint32_t site) {

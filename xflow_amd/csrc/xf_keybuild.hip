@@ -2641,7 +2641,9 @@ k_fm_regroup(FmRegroup g) {
 // them —, keys that are no hashes) is a merge sort: it goes on a list the host reads with the
 // build's one wait; its parts of kSpCap records are sorted in LDS the same way (k_sp_parts) and
 // merged pair by pair, a pass per doubling (k_sp_merge: an output tile's two inputs found by a
-// search along its diagonal, merged in LDS, eight outputs per thread).
+// search along its diagonal, merged in LDS, eight outputs per thread).  A stream that has shown
+// itself skewed gets its hot keys ranges of their own first ("hot keys get ranges of their own"
+// below): no merge for them.
 constexpr int kSp = 1024;
 constexpr uint32_t kSpCap = 8192;      // records of a range
 constexpr uint32_t kSpPieces = 8192;   // equal pieces of a range's width
@@ -3185,8 +3187,9 @@ k_sp_parts(SpArgs a) {
 // pair by pair into (ok, op); a range whose runs are one by now takes no part (the host's last
 // launch, pass = ~0, copies the ranges that ended in the other buffer).  A workgroup per output
 // tile of kSpTile records: the tile's share of the two runs from a search along its first and
-// its last diagonal (a wavefront each, 64 probes a round; no two elements compare equal: the
-// positions differ), both shares into LDS, a thread's eight outputs from a search of its own there.
+// its last diagonal (a wavefront each, 64 probes a round; elements that compare equal — a key
+// twice in a row, rows as payload — are the same record twice: either order), both shares into
+// LDS, a thread's eight outputs from a search of its own there.
 constexpr int kSpM = 512;
 constexpr uint32_t kSpTile = 4096;
 static_assert(kSpCap % kSpTile == 0 && kSpTile % kSpM == 0, "k_sp_merge: tiles of a part");
