@@ -84,6 +84,10 @@ void blob_pool_limit(int blobs);  // 0 = no pooling (every free goes back to the
 enum { kSortSiteAny = 0, kSortSiteBatch = 1, kSortSiteMerged = 2, kSortSiteLr = 3, kSortSites = 4 };
 int sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, uint64_t span, uint64_t *sk,
                  uint32_t *spos, hipStream_t s, bool *done, uint32_t site = kSortSiteAny);
+// xf_batch_compile_dev, with or without the panel-major forward view (xf_batch_dev.hip)
+int batch_compile_dev_ex(xf_batch **out, const uint64_t *d_keys, const uint32_t *d_rowptr,
+                         const int32_t *d_labels, uint32_t R, uint32_t NNZ, hipStream_t stream,
+                         bool panels);
 // LR, the worker side of the weight / gradient exchange (xf_keybuild.hip): a minibatch with its
 // sorted unique keys, row offsets and labels on the device — nothing else — and its cells over
 // the unique-key index.  *done = false: beyond that build's limits, nothing was built.

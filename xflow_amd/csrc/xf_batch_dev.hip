@@ -428,6 +428,15 @@ extern "C" int xf_sort_key_pos(const uint64_t *d_keys, uint32_t n, uint64_t lo, 
 extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
                                     const uint32_t *d_rowptr, const int32_t *d_labels,
                                     uint32_t R, uint32_t NNZ, void *stream) {
+  return xf::batch_compile_dev_ex(out, d_keys, d_rowptr, d_labels, R, NNZ, (hipStream_t)stream, true);
+}
+
+// panels = false: without the panel-major forward view (pptr / pidx and its tiles: what
+// xf_lr_forward_dev streams — FM's kernels and the sharded trainer's never do; 0.35 ms of a 1e7-
+// nonzero build)
+int xf::batch_compile_dev_ex(xf_batch **out, const uint64_t *d_keys, const uint32_t *d_rowptr,
+                             const int32_t *d_labels, uint32_t R, uint32_t NNZ, hipStream_t stream,
+                             bool panels) {
   XF_REQUIRE(out && d_rowptr && (R == 0 || d_labels) && (NNZ == 0 || d_keys),
              "xf_batch_compile_dev: null argument");
   hipStream_t s = (hipStream_t)stream;
@@ -481,7 +490,8 @@ extern "C" int xf_batch_compile_dev(xf_batch **out, const uint64_t *d_keys,
   XF_TRY(key_lists(sc, segptr, U, nullptr, heavy, tile_ptr, &d_tot, s));
   XF_HIP(hipMemcpyAsync(tot, d_tot, 8, hipMemcpyDeviceToHost, s));
   // ---- 4. panel-major forward view
-  const uint32_t P = xf::panel_count(U, NNZ, xf::panel_slice_bytes(), xf::min_panel_nnz());
+  const uint32_t P =
+      panels ? xf::panel_count(U, NNZ, xf::panel_slice_bytes(), xf::min_panel_nnz()) : 0u;
   const size_t ncell = (size_t)P * ((size_t)R + 1);
   uint32_t *pptr = nullptr, *pidx = nullptr, *cflag = nullptr, *cscan = nullptr;
   uint32_t *ftile = nullptr, *fpf = nullptr;
@@ -720,7 +730,7 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
   const char *rec_off = getenv("XF_FM_TABLE_RECORDS");  // ("0": the records are switched off)
   if (NNZ && R && xf::fm_records_fit(xf::table_dim(v)) && !(rec_off && *rec_off == '0'))
     XF_TRY(same_numbering(w, v, s, &same));
-  if (!same) return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+  if (!same) return xf::batch_compile_dev_ex(out, d_keys, d_rowptr, d_labels, R, NNZ, (hipStream_t)stream, false);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   uint32_t *ridx = nullptr;
   size_t ridx_bytes = 0;
@@ -777,7 +787,7 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
                             &Place::at, &place));
   if (!ok) {
     XF_HIP(hipStreamSynchronize(s));
-    return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+    return xf::batch_compile_dev_ex(out, d_keys, d_rowptr, d_labels, R, NNZ, (hipStream_t)stream, false);
   }
   char *d = (char *)b->d_blob;
   const uint32_t *segptr = (const uint32_t *)(d + place.o_segptr);
@@ -802,7 +812,7 @@ extern "C" int xf_batch_compile_fm_dev(xf_batch **out, xf_table *w, xf_table *v,
   XF_HIP(hipGetLastError());
   XF_HIP(hipStreamSynchronize(s));  // the only wait of the build
   if (misses)  // a key the tiers do not hold: the sort-based build (what was built is dropped)
-    return xf_batch_compile_dev(out, d_keys, d_rowptr, d_labels, R, NNZ, stream);
+    return xf::batch_compile_dev_ex(out, d_keys, d_rowptr, d_labels, R, NNZ, (hipStream_t)stream, false);
   const uint32_t H = tot[0], ntiles = tot[1];
   uint32_t *hch = nullptr;
   uint32_t n_hch = 0;

@@ -895,7 +895,7 @@ static int compile_owner_dev(xf_sharded *st, xf_sbatch *b, const uint64_t *d_key
                          s, b->o_rowid.p + segoff[q], nq, Rq, d_rp.p);
       XF_HIP(hipGetLastError());
       XF_HIP(hipMemsetAsync(d_lab.p, 0, (size_t)Rq * 4, s));  // (labels stay with the workers)
-      XF_TRY(xf_batch_compile_dev(&b->bq[q], b->o_keys.p + segoff[q], d_rp.p, d_lab.p, Rq, nq, s));
+      XF_TRY(xf::batch_compile_dev_ex(&b->bq[q], b->o_keys.p + segoff[q], d_rp.p, d_lab.p, Rq, nq, s, false));
       XF_TRY(wait_stream(st, s));
       uint32_t Uq = 0;
       XF_TRY(xf_batch_dims(b->bq[q], nullptr, nullptr, &Uq, nullptr));
@@ -922,8 +922,8 @@ static int compile_owner_dev(xf_sharded *st, xf_sbatch *b, const uint64_t *d_key
       XF_HIP(hipGetLastError());
       XF_HIP(hipMemsetAsync(d_lab.p, 0, (size_t)b->o_total * 4, s));  // (labels stay with the
                                                                       // rows' workers)
-      XF_TRY(xf_batch_compile_dev(&b->b, b->o_keys.p, d_rp.p, d_lab.p, b->o_total,
-                                  (uint32_t)b->o_n, s));
+      XF_TRY(xf::batch_compile_dev_ex(&b->b, b->o_keys.p, d_rp.p, d_lab.p, b->o_total,
+                                      (uint32_t)b->o_n, s, false));
       XF_TRY(wait_stream(st, s));
       XF_TRY(xf_batch_dims(b->b, nullptr, nullptr, &b->U, nullptr));
       // first-touch keys are inserted by the step's Pull: room for all of them now
@@ -1570,7 +1570,7 @@ extern "C" int xf_sharded_compile_dev(xf_sharded *st, xf_sbatch **out, const uin
     if (st->cfg.model == 0)
       XF_TRY(xf::batch_compile_lr_dev(&b->b, &b->cells, d_keys, d_rowptr, d_labels, R, NNZ, keep != 0,
                                       s, &lean));
-    if (!lean) XF_TRY(xf_batch_compile_dev(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s));
+    if (!lean) XF_TRY(xf::batch_compile_dev_ex(&b->b, d_keys, d_rowptr, d_labels, R, NNZ, s, false));
     XF_TRY(compile_exchange_tail(st, b, keep));
   }
   guard.b = nullptr;
