@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--sorted", action="store_true", help="xf_batch_compile_dev (the sort-based "
                     "build) instead of xf_batch_compile_fm_dev")
+    ap.add_argument("--key-build", type=int, default=0, help="xf_tune key_build (1: the "
+                    "library's sorts, the tests' second implementation)")
     a = ap.parse_args()
     import torch
     args = argparse.Namespace(seed=20260926, rows=50000, nnz_per_row=200, batches=4, zipf=0.0)
@@ -37,6 +39,7 @@ def main():
     tr.defrag()
     del comp
     capi.tune("min_panel_nnz", 1e18)
+    capi.tune("key_build", a.key_build)
     L = capi.lib()
     raw = [(torch.from_numpy(k.view(np.int64)).cuda(),
             torch.from_numpy(rp.astype(np.uint32).view(np.int32)).cuda(),
