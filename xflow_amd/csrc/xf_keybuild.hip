@@ -2846,31 +2846,33 @@ __device__ __forceinline__ void sp_long_piece(unsigned long long *K, uint32_t *P
 }
 
 // records rec[0..m) of range S (all of them, or a part of a heavy range's) to out_k / out_p[0..m)
+template <uint32_t CAP = kSpCap, uint32_t PIECES = kSpPieces>
 __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const Rec3 *__restrict__ rec,
                                               uint32_t m, uint64_t *__restrict__ out_k,
                                               uint32_t *__restrict__ out_p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
-  unsigned long long *stK = (unsigned long long *)sp_lds;  // [kSpCap] the staged records' keys
-  uint32_t *stP = (uint32_t *)(stK + kSpCap);              // [kSpCap] ... positions
-  uint32_t *st = stP + kSpCap;                             // [kSpPieces + 1] counts, then starts
-  uint32_t *lw = st + kSpPieces + 1;                       // pieces a wavefront sorts
+  unsigned long long *stK = (unsigned long long *)sp_lds;  // [CAP] the staged records' keys
+  uint32_t *stP = (uint32_t *)(stK + CAP);                 // [CAP] ... positions
+  uint32_t *st = stP + CAP;                                // [PIECES + 1] counts, then starts
+  uint32_t *lw = st + PIECES + 1;                       // pieces a wavefront sorts
   uint32_t *lg = lw + kSpList;                             // pieces the workgroup sorts
   __shared__ uint32_t wsum[kSp / 64], s_nw, s_ng;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t k0 = a.bnd[S];
   const uint64_t width1 = (S + 1 < a.nR ? a.bnd[S + 1] - 1ull : a.last) - k0;  // width - 1
   const int bits = 64 - __clzll((long long)(width1 | 1ull));
-  const int sh = bits > 13 ? bits - 13 : 0;
-  static_assert(kSpPieces == 1u << 13, "the shift above");
+  constexpr int lgp = PIECES == 8192 ? 13 : 12;
+  static_assert(PIECES == 1u << lgp, "the pieces: 4096 or 8192");
+  const int sh = bits > lgp ? bits - lgp : 0;
   // (a key below the range's first — one that lies below the span, in range 0 — goes with the
   // first piece, one beyond the span with the last: the comparisons below are on whole keys)
   auto piece = [&](uint64_t key) -> uint32_t {
-    return key < k0 ? 0u : (uint32_t)min((key - k0) >> sh, (uint64_t)(kSpPieces - 1));
+    return key < k0 ? 0u : (uint32_t)min((key - k0) >> sh, (uint64_t)(PIECES - 1));
   };
-  for (uint32_t i = tid; i <= kSpPieces; i += kSp) st[i] = 0;
+  for (uint32_t i = tid; i <= PIECES; i += kSp) st[i] = 0;
   if (tid == 0) s_nw = s_ng = 0;
   __syncthreads();
-  constexpr int E = (int)(kSpCap / kSp);
+  constexpr int E = (int)(CAP / kSp);
   uint64_t key[E];
   uint32_t pos[E], pc[E], at[E];
 #pragma unroll
@@ -2887,7 +2889,7 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
   }
   __syncthreads();
   {  // st = exclusive scan of the counts; the long pieces on their lists
-    constexpr uint32_t per = kSpPieces / kSp;
+    constexpr uint32_t per = PIECES / kSp;
     uint32_t c[per], sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < per; ++k) {
@@ -2906,7 +2908,7 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
           lg[atomicAdd(&s_ng, 1u)] = tid * per + k;
       }
     }
-    if (tid == 0) st[kSpPieces] = m;
+    if (tid == 0) st[PIECES] = m;
   }
   __syncthreads();
 #pragma unroll
@@ -3052,11 +3054,22 @@ k_hot_ranges(const uint64_t *ssk, uint32_t ns, uint64_t lo, uint64_t span,
   }
 }
 
-__global__ void __launch_bounds__(kSp)
+// SMALL: the ranges of up to kSpSmall records — nearly all of them — with half the LDS (two
+// workgroups per CU: a range's load, its few barriers and its store are latency); the launch
+// without it takes the others (and lists the heavy ones)
+constexpr uint32_t kSpSmall = 4096, kSpSmallPieces = 4096;
+constexpr size_t kSpLdsSmall = (size_t)kSpSmall * 12 + ((size_t)kSpSmallPieces + 1 + 2 * kSpList) * 4;
+template <bool SMALL>
+__global__ void __launch_bounds__(kSp, SMALL ? 8 : 4)  // (waves per SIMD: two workgroups a CU)
 k_sp_sort(SpArgs a) {
   const uint32_t S = blockIdx.x;
   const uint32_t s0 = a.sstart[S], m = a.sstart[S + 1] - s0;
-  if (m == 0) return;
+  if (m == 0 || (m <= kSpSmall) != SMALL) return;
+  if (SMALL) {
+    if (a.rows && S + 1 < a.nR && a.bnd[S + 1] == a.bnd[S] + 1ull) return;  // (k_sp_copy's)
+    sp_sort_block<kSpSmall, kSpSmallPieces>(a, S, a.rec + s0, m, a.sk + s0, a.spos + s0);
+    return;
+  }
   // (a hot key's own range, rows as payload: k_sp_copy's — the partition's work items)
   if (a.rows && S + 1 < a.nR && a.bnd[S + 1] == a.bnd[S] + 1ull) return;
   if (m > kSpCap && a.tbits && (1u << a.tbits) <= kSpCap - kSpTileSpan && S + 1 < a.nR &&
@@ -4414,7 +4427,7 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
     q.spos = ssp;
     q.heavy = d_heavy;
     q.hv = p.hv;
-    XF_KB_LAUNCH_N(k_sp_sort, 1, kSp, kSpLds, q);
+    XF_KB_LAUNCH_N(k_sp_sort<false>, 1, kSp, kSpLds, q);
     {
       static bool attr_done = false;
       if (!attr_done) {
@@ -4454,7 +4467,8 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
   p.rows = csr ? 1u : 0u;
   p.tbits = csr ? 0u : (a.tile == kTile ? 13u : 12u);
   static_assert(kTile == 8192, "tbits above");
-  XF_KB_LAUNCH_N(k_sp_sort, nR, kSp, kSpLds, p);
+  XF_KB_LAUNCH_N(k_sp_sort<true>, nR, kSp, kSpLdsSmall, p);
+  XF_KB_LAUNCH_N(k_sp_sort<false>, nR, kSp, kSpLds, p);
   if (csr && hot2) hipLaunchKernelGGL(k_sp_copy, dim3(max_items), dim3(kSp), 0, s, p, a.items, a.nitems);
   // (the distinct keys of a list without heavy ranges — the usual one — counted before the wait)
   auto count_keys = [&]() {
