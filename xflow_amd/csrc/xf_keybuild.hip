@@ -1057,10 +1057,12 @@ k_kb_scatter(KbArgs a) {
       if (ROWID) {
         // one division per thread and tile: its first nonzero's window; the others are in that
         // window or (where a window ends inside the thread's run) divide for themselves
-        const uint32_t r0w = a.rowid[e0 + i0] / a.W;
+        // (rowid == null: a nonzero's "row" is its position — the (key, position) sort's payload)
+        const uint32_t *__restrict__ rid = a.rowid;
+        const uint32_t r0w = (rid ? rid[e0 + i0] : e0 + i0) / a.W;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-          const uint32_t r = i0 + q < n ? a.rowid[e0 + i0 + q] : r0w * a.W;
+          const uint32_t r = i0 + q < n ? (rid ? rid[e0 + i0 + q] : e0 + i0 + q) : r0w * a.W;
           uint32_t v = r0w, rin = r - r0w * a.W;
           if (rin >= a.W) {
             v = r / a.W;
@@ -2679,11 +2681,6 @@ struct SpArgs {
   uint32_t *op;
   uint32_t pass;
 };
-
-__global__ void k_sp_iota(uint32_t *__restrict__ p, uint32_t n) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    p[i] = i;
-}
 
 // K[0..c), P[0..c) in (key, position) order: the bitonic network whose every comparator puts the
 // smaller element at the lower index (a stage's first step mirrors the upper half), so c need
@@ -4358,11 +4355,9 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
     a.W = ex->W;
     a.nwin = std::max<uint32_t>(1, (ex->R + ex->W - 1) / ex->W);
   } else {
-    uint32_t *iota = nullptr;
-    XF_TRY(sc.get(&iota, n));
-    hipLaunchKernelGGL(k_sp_iota, dim3(std::min<uint32_t>(2048, (n + 255) / 256)), dim3(256), 0, s,
-                       iota, n);
-    a.rowid = iota;  // (window << kRinBits | row in window) of "row" i with 2^kRinBits rows per window is i
+    // (rowid = null with ROWID kernels: the record's "row" is its position; window << kRinBits | row
+    // in window with 2^kRinBits rows per window is the position itself)
+    a.rowid = nullptr;
     a.W = 1u << kRinBits;
     a.R = n;
     a.nwin = (n + a.W - 1) / a.W;
