@@ -1656,9 +1656,16 @@ def main():
             logloss_before = heldout_logloss()
         except Exception as e:
             print("bench.py: held-out logloss before training: %s" % e, file=sys.stderr)
+    # (the warm-up steps record their HIP events too: the first timed event of a process makes the
+    # runtime switch its queue to profiling — on a fresh box 30 ms and more, which belongs to no
+    # step; tools/r6/call53.sh: the first run on a box 1.65 ms per step in the official block,
+    # 0.109 in its repeats and in every later run)
+    trainer.profile(True)
     for i in range(args.warmup):
         trainer.step(compiled[i % len(compiled)])
     trainer.check()
+    trainer.profile_read()
+    trainer.profile(False)
     barrier()
     if sharded:
         # RCCL writes its version banner through C stdio; push it out now so that the JSON
