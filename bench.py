@@ -832,6 +832,9 @@ def fresh_table_leg(args, nkeys, nbatches=40, percent=30):
     del warm
     # the first minibatch's cells set aside (Worker::batch_training does both before its clock starts)
     capi.check(L.xf_batch_pool_reserve(R * nnz * 8 + (16 << 20)))
+    # ... and what the table's maintenance step would allocate (Worker::batch_training:
+    # xf_table_prepare_defrag before the clock starts)
+    capi.check(L.xf_table_prepare_defrag(tr.w.h))
     # the worker's init push (lr_worker.cc:180-182: key 0, a zero gradient) before the clock starts
     tr.w.push(np.zeros(1, np.uint64), np.zeros(1, np.float32))
     setup_s = time.perf_counter() - t_set

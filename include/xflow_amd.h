@@ -301,6 +301,10 @@ int xf_table_capacity(xf_table *t, uint64_t *slots);
 /* keys of the settled tier (sorted, key r owns state row r): what the last xf_table_defrag —
  * or the first-touch build of an empty table's first minibatch — left there; 0 before */
 int xf_table_settled(xf_table *t, uint64_t *nkeys);
+/* allocate now what xf_table_defrag would allocate (its second state buffer, both allocations of
+ * the settled tier at the size the table's rows allow): for a caller whose clock is about to
+ * start — a defrag then calls the driver's allocator no more.  Optional. */
+int xf_table_prepare_defrag(xf_table *t);
 /* grow to new_capacity slots (rehash on device); earlier slot arrays become invalid */
 int xf_table_reserve(xf_table *t, uint64_t new_capacity);
 /* renumber the state rows in key order (locality of the Pull gather and the Push pass once

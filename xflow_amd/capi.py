@@ -126,6 +126,7 @@ SIGNATURES = {
     "xf_table_destroy": (C.c_int, [vp]),
     "xf_table_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_settled": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "xf_table_prepare_defrag": (C.c_int, [vp]),
     "xf_table_capacity": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "xf_table_reserve": (C.c_int, [vp, C.c_uint64]),
     "xf_table_defrag": (C.c_int, [vp]),

@@ -1166,6 +1166,13 @@ struct xf_table {
   // the settled tier's keys and its two directories are ONE allocation (T.bkeys / bdir / cdir
   // point into it); tier_next: the one a build has asked for and not yet handed back
   void *tier = nullptr, *tier_next = nullptr;
+  // ... and a retired one kept for the next build (a table that settles again and again — a
+  // first epoch — would otherwise pay a hipMalloc and a hipFree of hundreds of MB per defrag:
+  // 3 ms as a rule, 30-170 ms now and then, tools/r6/call54.sh); their sizes; tier_full: every
+  // tier allocation is sized for max_rows keys (xf_table_prepare_defrag)
+  void *tier_spare = nullptr;
+  size_t tier_bytes = 0, tier_next_bytes = 0, tier_spare_bytes = 0;
+  bool tier_full = false;
 };
 // the tier of n keys: where its parts lie in one allocation
 struct TierLayout {
@@ -1182,12 +1189,59 @@ static TierLayout tier_layout(size_t n) {
   L.bytes = L.o_cdir + al((L.ncdir + 1) * sizeof(uint32_t));
   return L;
 }
+// the second state buffer a defrag moves the rows into (the two swap roles)
+static int alt_state(xf_table *t, size_t elems) {
+  if (t->w_alt && t->alt_elems == elems) return XF_OK;
+  if (t->w_alt) XF_HIP(hipFree(t->w_alt));
+  if (t->nz_alt) XF_HIP(hipFree(t->nz_alt));
+  t->w_alt = nullptr;
+  t->nz_alt = nullptr;
+  t->alt_elems = 0;
+  XF_HIP(hipMalloc((void **)&t->w_alt, elems * sizeof(float)));
+  XF_HIP(hipMemset(t->w_alt, 0, elems * sizeof(float)));
+  if (t->T.nz) {
+    XF_HIP(hipMalloc((void **)&t->nz_alt, elems * sizeof(float2)));
+    XF_HIP(hipMemset(t->nz_alt, 0, elems * sizeof(float2)));
+  }
+  t->alt_elems = elems;
+  return XF_OK;
+}
 static int tier_alloc(xf_table *t, size_t n, uint64_t **keys) {
-  if (t->tier_next) (void)hipFree(t->tier_next);
-  t->tier_next = nullptr;
-  XF_HIP(hipMalloc(&t->tier_next, tier_layout(n).bytes));
+  const size_t need = tier_layout(n).bytes;
+  if (t->tier_next && t->tier_next_bytes < need) {
+    (void)hipFree(t->tier_next);
+    t->tier_next = nullptr;
+  }
+  if (!t->tier_next && t->tier_spare && t->tier_spare_bytes >= need) {  // the retired one again
+    t->tier_next = t->tier_spare;
+    t->tier_next_bytes = t->tier_spare_bytes;
+    t->tier_spare = nullptr;
+    t->tier_spare_bytes = 0;
+  }
+  if (!t->tier_next) {
+    const size_t bytes = t->tier_full ? std::max(need, tier_layout(t->T.max_rows).bytes) : need;
+    XF_HIP(hipMalloc(&t->tier_next, bytes));
+    t->tier_next_bytes = bytes;
+  }
   *keys = (uint64_t *)t->tier_next;
   return XF_OK;
+}
+// the tier in use makes way for tier_next (the caller has waited for the device): kept as the
+// spare when it is the larger of the two
+static void tier_swap(xf_table *t) {
+  if (t->tier) {
+    if (t->tier_bytes > t->tier_spare_bytes) {
+      if (t->tier_spare) (void)hipFree(t->tier_spare);
+      t->tier_spare = t->tier;
+      t->tier_spare_bytes = t->tier_bytes;
+    } else {
+      (void)hipFree(t->tier);
+    }
+  }
+  t->tier = t->tier_next;
+  t->tier_bytes = t->tier_next_bytes;
+  t->tier_next = nullptr;
+  t->tier_next_bytes = 0;
 }
 // tier_next (n keys in place) becomes the table's tier: directories built on `s`, N's tier fields
 // set; the old tier is the caller's to free (after the device has finished with it)
@@ -1411,7 +1465,7 @@ extern "C" int xf_table_create(xf_table **out, const xf_table_config *cfg) {
 
 extern "C" int xf_table_destroy(xf_table *t) {
   if (!t) return XF_OK;
-  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, t->tier, t->tier_next, t->s_keys, t->s_rows, t->s_vals, t->miss,
+  void *ps[] = {t->T.keys, t->T.rows, t->T.w, t->T.nz, t->T.stat, t->tier, t->tier_next, t->tier_spare, t->s_keys, t->s_rows, t->s_vals, t->miss,
                 t->miss_n, t->aux, t->rec, t->w_alt, t->nz_alt};
   for (void *p : ps)
     if (p) hipFree(p);
@@ -1459,6 +1513,30 @@ extern "C" int xf_table_size(xf_table *t, uint64_t *nkeys) {
   xf::TableStat st;
   XF_TRY(read_stat(t, &st));
   *nkeys = std::min<uint64_t>(st.count, t->T.max_rows);
+  return XF_OK;
+}
+
+// What the table's maintenance step allocates, allocated now: the second state buffer and both
+// tier allocations at the size the table's rows allow.  For a caller whose clock is about to
+// start (the worker before its first block): a defrag then calls the driver's allocator no more
+// (hundreds of MB per call: 3 ms as a rule, 30-170 ms now and then — tools/r6/call54.sh).
+extern "C" int xf_table_prepare_defrag(xf_table *t) {
+  XF_REQUIRE(t, "xf_table_prepare_defrag: null table");
+  XF_TRY(alt_state(t, ((size_t)t->T.max_rows + 1) * (size_t)t->T.dim));
+  t->tier_full = true;
+  const size_t full = tier_layout(t->T.max_rows).bytes;
+  if (!t->tier_next || t->tier_next_bytes < full) {
+    if (t->tier_next) (void)hipFree(t->tier_next);
+    t->tier_next = nullptr;
+    XF_HIP(hipMalloc(&t->tier_next, full));
+    t->tier_next_bytes = full;
+  }
+  if (!t->tier_spare || t->tier_spare_bytes < full) {
+    if (t->tier_spare) (void)hipFree(t->tier_spare);
+    t->tier_spare = nullptr;
+    XF_HIP(hipMalloc(&t->tier_spare, full));
+    t->tier_spare_bytes = full;
+  }
   return XF_OK;
 }
 
@@ -1613,20 +1691,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
                                      (hipStream_t)0));
   }
   // state in rank order, into the second buffer; the spare key's row, if any, follows the tier
-  if (!t->w_alt || t->alt_elems != elems) {
-    if (t->w_alt) XF_HIP(hipFree(t->w_alt));
-    if (t->nz_alt) XF_HIP(hipFree(t->nz_alt));
-    t->w_alt = nullptr;
-    t->nz_alt = nullptr;
-    t->alt_elems = 0;
-    XF_HIP(hipMalloc((void **)&t->w_alt, elems * sizeof(float)));
-    XF_HIP(hipMemset(t->w_alt, 0, elems * sizeof(float)));
-    if (T.nz) {
-      XF_HIP(hipMalloc((void **)&t->nz_alt, elems * sizeof(float2)));
-      XF_HIP(hipMemset(t->nz_alt, 0, elems * sizeof(float2)));
-    }
-    t->alt_elems = elems;
-  }
+  XF_TRY(alt_state(t, elems));
   float *w2 = t->w_alt;
   float2 *nz2 = T.nz ? t->nz_alt : nullptr;
   hipLaunchKernelGGL(k_move_rows, dim3(grid_for(n * T.dim)), dim3(kBlock), 0, 0, T.w, T.nz, T.dim,
@@ -1650,9 +1715,7 @@ extern "C" int xf_table_defrag(xf_table *t) {
                        (uint32_t)n);
   XF_HIP(hipGetLastError());
   XF_HIP(hipDeviceSynchronize());
-  if (t->tier) (void)hipFree(t->tier);
-  t->tier = t->tier_next;
-  t->tier_next = nullptr;
+  tier_swap(t);
   t->w_alt = T.w;  // (the old state: rows below the old count hold data, all below n)
   t->nz_alt = T.nz;
   N.w = w2;
@@ -2108,9 +2171,7 @@ int table_settle_first(xf_table *t, size_t d, hipStream_t s) {
                        N.bkeys, d);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, T.stat, (unsigned long long)d);
   XF_HIP(hipGetLastError());
-  if (t->tier) (void)hipFree(t->tier);  // (a table without a settled tier has none)
-  t->tier = t->tier_next;
-  t->tier_next = nullptr;
+  tier_swap(t);  // (a table without a settled tier has none)
   T = N;
   ++t->writes;  // (rows that records derived from the state know nothing of)
   t->rec_all_ok = false;

@@ -216,6 +216,8 @@ int Worker::batch_training() {
   // ... and the first block's cells (4 bytes per nonzero, 8 when the minibatches are kept for
   // replay, + the cell offsets): set aside now, not mapped by the driver under the first build
   XF_TRY(xf_batch_pool_reserve(((size_t)block_size << 20) / 4 * 8 + ((size_t)16 << 20)));
+  // ... and what the table's maintenance step inside the epoch (defrag_if_grown) would allocate
+  if (world <= 1 && model_ == 0 && table_w_) XF_TRY(xf_table_prepare_defrag(table_w_));
   const double t0 = now_s();
   rows_trained_ = 0;
   blocks_gpu = blocks_host = 0;
