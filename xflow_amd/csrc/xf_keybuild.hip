@@ -3418,6 +3418,7 @@ k_wc_cells(WcArgs a) {
   const uint32_t c_lo = a.su[s0] >> kChunkBits, nloc = (a.su[s1 - 1] >> kChunkBits) - c_lo + 1;
   const uint32_t nl = a.nwin * nloc;
   const bool lds = nloc <= kEbCells && nl <= kEbCells;  // workgroup-uniform
+  const bool crowded = s1 - s0 > kSpCap;
   if (lds)
     for (uint32_t i = tid; i < nl; i += kEb) lcnt[i] = 0;
   __syncthreads();
@@ -3436,8 +3437,14 @@ k_wc_cells(WcArgs a) {
       const uint32_t v = rp[q] >> kRinBits, ch = u[q] >> kChunkBits;
       lc[q] = v * nloc + (ch - c_lo);
       at[q] = 0;
-      if (lds) {  // (wave-uniform: every lane takes part in the ballots)
-        at[q] = wc_slot(lcnt, lc[q], ok[q]);
+      if (lds) {  // (workgroup-uniform: every lane takes part in the ballots)
+        // a range of thousands of records is a hot key's: its records fall into its chunk's few
+        // cells (plain atomics: 91 + 112 us on a Zipf(1.1) minibatch, shared ones 66 + 65); an
+        // ordinary range's cells are few as well, but its lanes' atomics do not queue for long
+        // (shared ones there: 32 + 34 -> 47 + 48 us)
+        if (crowded) at[q] = wc_slot(lcnt, lc[q], ok[q]);
+        else if (ok[q])
+          at[q] = atomicAdd(&lcnt[lc[q]], 1u);
         continue;
       }
       if (!ok[q]) continue;
