@@ -2652,7 +2652,7 @@ constexpr uint32_t kSpPieces = 8192;   // equal pieces of a range's width
 constexpr uint32_t kSpBrute = 32;      // records of a piece ranked by comparison
 constexpr uint32_t kSpWave = 128;      // ... sorted by one wavefront (the bitonic network)
 constexpr uint32_t kSpList = 256;      // longer pieces per range and kind (8192 / 33 < 256)
-constexpr size_t kSpLds = (size_t)kSpCap * 12 + ((size_t)kSpPieces + 1 + 2 * kSpList) * 4;
+constexpr size_t kSpLds = (size_t)kSpCap * 14 + ((size_t)kSpPieces + 1 + 2 * kSpList) * 4;
 constexpr uint32_t kSpTileSpan = 4096; // k_sp_tiles: a workgroup's tile groups begin inside so many records
 static_assert(kSpLds <= kDynMax && kSp == kKb, "k_sp_sort: LDS, block_excl_scan's workgroup");
 struct SpArgs {
@@ -2728,12 +2728,12 @@ __device__ __forceinline__ void sp_bitonic(unsigned long long *K, uint32_t *P, u
 // bitonic network (91 steps over 8192 records: ~120 us, which made a power-law stream's sort
 // 1.5 ms).  c <= kSpCap; all kSp threads.
 constexpr uint32_t kSpOdd = 32;  // records of other keys a one-key piece may hold
+template <int E = (int)(kSpCap / kSp)>  // (records per thread: c <= E * kSp)
 __device__ __forceinline__ void sp_long_piece(unsigned long long *K, uint32_t *P, uint32_t c,
                                               uint32_t *wsum) {
   __shared__ unsigned long long exK[kSpOdd];
   __shared__ uint32_t exP[kSpOdd], s_nex, s_pmin, s_pmax;
   const uint32_t tid = threadIdx.x;
-  constexpr int E = (int)(kSpCap / kSp);
   const unsigned long long kh = K[c / 2];
   if (tid == 0) {
     s_nex = 0;
@@ -2924,9 +2924,14 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
   __syncthreads();
   for (uint32_t idx = 0; idx < s_ng; ++idx) {  // workgroup-uniform
     const uint32_t b = st[lg[idx]], c = st[lg[idx] + 1] - b;
-    sp_long_piece(stK + b, stP + b, c, wsum);
+    sp_long_piece<(int)(CAP / kSp)>(stK + b, stP + b, c, wsum);
   }
-  // every record to its place: where it is staged, or — a short piece — at its rank in the piece
+  // every record to its place — where it is staged, or, a short piece's, at its rank in the piece:
+  // the places first (who goes to place i: inv[i], 16 bits in LDS), then out in order — the
+  // records' 12 bytes stored straight to their places were 216 MB of write requests for 120 MB
+  // per 1e7 keys (profiles/r06/pmc_traffic_sort_key_pos.json; held in registers until all places
+  // are known they spill: 64 registers a thread)
+  uint16_t *inv = (uint16_t *)(lg + kSpList);  // [CAP]
   for (uint32_t p = tid; p < m; p += kSp) {
     const unsigned long long kk = stK[p];
     const uint32_t pp = stP[p], pcs = piece(kk);
@@ -2941,8 +2946,13 @@ __device__ __forceinline__ void sp_sort_block(const SpArgs &a, uint32_t S, const
       }
       out = b + rank;
     }
-    out_k[out] = kk;
-    out_p[out] = pp;
+    inv[out] = (uint16_t)p;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < m; i += kSp) {
+    const uint32_t p = inv[i];
+    out_k[i] = stK[p];
+    out_p[i] = stP[p];
   }
 }
 
@@ -3057,7 +3067,7 @@ k_hot_ranges(const uint64_t *ssk, uint32_t ns, uint64_t lo, uint64_t span,
 // workgroups per CU: a range's load, its few barriers and its store are latency); the launch
 // without it takes the others (and lists the heavy ones)
 constexpr uint32_t kSpSmall = 4096, kSpSmallPieces = 4096;
-constexpr size_t kSpLdsSmall = (size_t)kSpSmall * 12 + ((size_t)kSpSmallPieces + 1 + 2 * kSpList) * 4;
+constexpr size_t kSpLdsSmall = (size_t)kSpSmall * 14 + ((size_t)kSpSmallPieces + 1 + 2 * kSpList) * 4;
 template <bool SMALL>
 __global__ void __launch_bounds__(kSp, SMALL ? 8 : 4)  // (waves per SIMD: two workgroups a CU)
 k_sp_sort(SpArgs a) {
