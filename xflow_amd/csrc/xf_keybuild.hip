@@ -4354,17 +4354,21 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
       ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256)
     return XF_OK;
   const bool csr = ex && ex->rowptr;
-  // ranges of ~3000 records (a hot key's thousand or two on top stay below kSpCap), and room
+  // ranges of ~3600 records (a hot key's thousand or two on top stay below kSpCap), and room
   // for the hot keys' own ranges (kernels: "hot keys get ranges of their own")
   // ... looked for when the stream has shown itself skewed: the last sort on this thread met a
   // range beyond a range's LDS, or found a hot key (the sample costs ~35 us a sort)
+  // records per range: as many as leave a range's Poisson spread (8 sigma) below the 4096 of the
+  // 68 KB variant — fewer, longer runs out of the partition (1e7 keys: 0.255 ms at 3000 a range,
+  // 0.249 at 3400, 0.243 at 3700; 2400 leaves no room for the hot keys' ranges)
+  constexpr uint32_t per_range = 3600;
   // (a state per call site: a worker's minibatches and an owner's merged key lists — unique keys
   // — are different streams)
   static thread_local bool skewed_at[kSortSites] = {};
   bool &skewed = skewed_at[site < kSortSites ? site : 0];
   const uint32_t hot2 =
-      skewed && n >= 65536 && (n + 2999) / 3000 + 2 * kHotMax <= kArMaxRanges ? 2 * kHotMax : 0;
-  const uint32_t nR0 = std::min<uint32_t>(kArMaxRanges - hot2, (n + 2999) / 3000);
+      skewed && n >= 65536 && (n + per_range - 1) / per_range + 2 * kHotMax <= kArMaxRanges ? 2 * kHotMax : 0;
+  const uint32_t nR0 = std::min<uint32_t>(kArMaxRanges - hot2, (n + per_range - 1) / per_range);
   const uint32_t nR = nR0 + hot2;
   KbArgs a{};
   a.keys = d_keys;
