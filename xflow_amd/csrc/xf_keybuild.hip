@@ -4360,16 +4360,16 @@ static int sort_key_pos_sc(Scratch &sc, const uint64_t *d_keys, uint32_t n, uint
       ((uint64_t)n + kTile / 2 - 1) / (kTile / 2) > (uint64_t)kMaxSub * 256)
     return XF_OK;
   const bool csr = ex && ex->rowptr;
-  // ranges of ~3600 records (a hot key's thousand or two on top stay below kSpCap), and room
-  // for the hot keys' own ranges (kernels: "hot keys get ranges of their own")
-  // ... looked for when the stream has shown itself skewed: the last sort on this thread met a
-  // range beyond a range's LDS, or found a hot key (the sample costs ~35 us a sort)
-  // records per range: as many as leave a range's Poisson spread (8 sigma) below the 4096 of the
+  // Records per range: as many as leave a range's Poisson spread (8 sigma) below the 4096 of the
   // 68 KB variant — fewer, longer runs out of the partition (1e7 keys: 0.255 ms at 3000 a range,
-  // 0.249 at 3400, 0.243 at 3700; 2400 leaves no room for the hot keys' ranges)
+  // 0.249 at 3400, 0.243 at 3700; 2400 leaves no room for the hot keys' ranges); a hot key's
+  // thousand or two on top stay below kSpCap.
   constexpr uint32_t per_range = 3600;
-  // (a state per call site: a worker's minibatches and an owner's merged key lists — unique keys
-  // — are different streams)
+  // Room for the hot keys' own ranges (kernels: "hot keys get ranges of their own"), looked for
+  // when the stream has shown itself skewed: the call site's last sort on this thread met a range
+  // beyond a range's LDS, or found a hot key (the sample costs ~35 us a sort).  A state per call
+  // site: a worker's minibatches and an owner's merged key lists — unique keys — are different
+  // streams.
   static thread_local bool skewed_at[kSortSites] = {};
   bool &skewed = skewed_at[site < kSortSites ? site : 0];
   const uint32_t hot2 =
